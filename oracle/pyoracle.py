@@ -1,0 +1,347 @@
+"""CPU oracle (numpy) for the `panagram index` anchor hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``oracle/`` is product code: only
+``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg
+may import it, and only as the checker.  The product path (``panagram_amd``)
+never imports this module and fails loudly when the HIP library is missing.
+
+This is a restatement (not a copy) of the reference algorithm:
+
+* canonical k-mer walk + lookup      = KMC ``CKMCFile::GetCountersForRead``
+  (third-party, not vendored; call sites ``cpp/anchor.cpp:148``,
+  ``panagram/index.py:935``; semantics pinned by running the reference's own
+  ``cpp/run_anchor`` binary, see ``tests/golden/make_golden.py``)
+* byte scatter / popcount / 1-in-100 decimation / per-bin histogram
+                                      = ``KMCdb::write_bits`` ``cpp/anchor.cpp:112-195``
+* FASTA line parse, chrs.tsv rows    = ``KMCdb::anchor_fasta`` ``cpp/anchor.cpp:37-109``
+* k-mer set construction              = ``kmc -ci1 -fm`` + ``kmc_tools transform
+  set_counts`` + ``kmc_tools complex -ocsum`` (``panagram/workflow/Snakefile:54-110``,
+  ``panagram/index.py:407-426``): the counter of a k-mer in ``bitvec{i}`` is the OR
+  of ``1 << (g % 32)`` over the genomes g of group i that contain it.
+* KMC1 on-disk layout                 = SURVEY.md Appendix A (validated by having the
+  reference binary read files written by :func:`write_kmc1`).
+
+Parity status: PINNED against golden vectors produced by the reference binary
+(``tests/golden/*.npz``; ``tests/test_oracle_golden.py``).
+"""
+from __future__ import annotations
+
+import io
+import os
+import struct
+from typing import Dict, Iterable, List, Sequence, Tuple
+
+import numpy as np
+
+# ---------------------------------------------------------------------------
+# nucleotide codes: A=0 C=1 G=2 T=3, case-insensitive, anything else invalid
+# ---------------------------------------------------------------------------
+_CODE = np.full(256, 255, dtype=np.uint8)
+for _c, _v in zip(b"ACGT", range(4)):
+    _CODE[_c] = _v
+    _CODE[_c + 32] = _v  # lower case
+
+
+def encode(seq: bytes) -> np.ndarray:
+    """ASCII -> codes 0..3, 255 for any byte outside ``ACGTacgt``."""
+    return _CODE[np.frombuffer(seq, dtype=np.uint8)]
+
+
+def canonical_kmers(seq: bytes, k: int) -> Tuple[np.ndarray, np.ndarray]:
+    """All k-mer windows of ``seq``.
+
+    Returns ``(keys, valid)``: ``keys[i]`` = min(value(fwd), value(revcomp)) of
+    ``seq[i:i+k]`` as a 2k-bit integer, first symbol most significant
+    (SURVEY Appendix A); ``valid[i]`` False when the window holds a non-ACGT byte.
+    """
+    if not (1 <= k <= 32):
+        raise ValueError("k must be in 1..32")
+    codes = encode(seq)
+    n = len(codes) - k + 1
+    if n <= 0:
+        return np.zeros(0, np.uint64), np.zeros(0, bool)
+    bad = (codes == 255)
+    c = np.where(bad, 0, codes).astype(np.uint64)
+    fwd = np.zeros(n, np.uint64)
+    rc = np.zeros(n, np.uint64)
+    for j in range(k):
+        w = c[j:j + n]
+        fwd |= w << np.uint64(2 * (k - 1 - j))
+        rc |= (np.uint64(3) - w) << np.uint64(2 * j)
+    badc = np.concatenate([[0], np.cumsum(bad, dtype=np.int64)])
+    valid = (badc[k:k + n] - badc[:n]) == 0
+    return np.minimum(fwd, rc), valid
+
+
+# ---------------------------------------------------------------------------
+# FASTA parse exactly as cpp/anchor.cpp:77-100 does it (getline; '>' starts a
+# record; name = header up to first space; other lines concatenated verbatim)
+# ---------------------------------------------------------------------------
+def parse_fasta_cpp(data: bytes) -> List[Tuple[str, bytes]]:
+    recs: List[Tuple[str, bytes]] = []
+    name = None
+    parts: List[bytes] = []
+    lines = data.split(b"\n")
+    if lines and lines[-1] == b"":
+        lines.pop()  # getline does not yield a trailing empty line
+    for line in lines:
+        if line[:1] == b">":
+            if name:  # `if (!name.empty())`: an empty header never flushes
+                recs.append((name, b"".join(parts)))
+                parts = []
+            name = line[1:].decode("latin-1")
+        else:
+            parts.append(line)
+    if name is not None:
+        recs.append((name, b"".join(parts)))
+    return [(nm.split(" ")[0], s) for nm, s in recs]
+
+
+# ---------------------------------------------------------------------------
+# k-mer set construction (restates kmc -ci1 + set_counts + complex -ocsum)
+# ---------------------------------------------------------------------------
+def build_bitvec_dbs(genomes: Sequence[Sequence[bytes]], k: int) -> List[Tuple[np.ndarray, np.ndarray]]:
+    """``genomes[g]`` = list of contig sequences of sample g (sample order =
+    samples.tsv order).  Returns one ``(sorted_keys u64, masks u32)`` per group of
+    32 samples (``index.py:391-393``); mask bit ``g % 32`` set iff sample g holds
+    the canonical k-mer (``workflow/Snakefile:26-28,106-108``)."""
+    ndbs = (len(genomes) + 31) // 32
+    dbs = []
+    for d in range(ndbs):
+        all_keys = []
+        all_bits = []
+        for g in range(32 * d, min(32 * d + 32, len(genomes))):
+            ks = []
+            for contig in genomes[g]:
+                keys, valid = canonical_kmers(contig, k)
+                ks.append(keys[valid])
+            u = np.unique(np.concatenate(ks)) if ks else np.zeros(0, np.uint64)
+            all_keys.append(u)
+            all_bits.append(np.full(len(u), 1 << (g % 32), np.uint32))
+        keys = np.concatenate(all_keys) if all_keys else np.zeros(0, np.uint64)
+        bits = np.concatenate(all_bits) if all_bits else np.zeros(0, np.uint32)
+        order = np.argsort(keys, kind="stable")
+        keys, bits = keys[order], bits[order]
+        if len(keys):
+            starts = np.flatnonzero(np.concatenate([[True], keys[1:] != keys[:-1]]))
+            masks = np.bitwise_or.reduceat(bits, starts)
+            keys = keys[starts]
+        else:
+            masks = bits
+        dbs.append((keys, masks.astype(np.uint32)))
+    return dbs
+
+
+# ---------------------------------------------------------------------------
+# KMC1 database files
+# ---------------------------------------------------------------------------
+def pick_lut_prefix_len(k: int, nkeys: int) -> int:
+    """(k - lut_prefix_len) % 4 == 0, sized so buckets stay small."""
+    cands = [p for p in range(1, min(k, 13)) if (k - p) % 4 == 0]
+    best = cands[0]
+    for p in cands:
+        if 4 ** p <= max(nkeys, 1) * 4:
+            best = p
+    return best
+
+
+def write_kmc1(prefix: str, keys: np.ndarray, counters: np.ndarray, k: int,
+               lut_prefix_len: int | None = None, counter_size: int = 4,
+               min_count: int = 1, max_count: int = 0xFFFFFFFF) -> None:
+    """Write ``prefix.kmc_pre`` / ``prefix.kmc_suf`` in the KMC1 layout."""
+    keys = np.asarray(keys, np.uint64)
+    counters = np.asarray(counters, np.uint32)
+    assert np.all(keys[1:] > keys[:-1]), "keys must be sorted and unique"
+    p = pick_lut_prefix_len(k, len(keys)) if lut_prefix_len is None else lut_prefix_len
+    assert (k - p) % 4 == 0
+    suf_syms = k - p
+    suf_bytes = suf_syms // 4
+    pref = (keys >> np.uint64(2 * suf_syms)).astype(np.int64)
+    lut = np.searchsorted(pref, np.arange(4 ** p, dtype=np.int64), side="left").astype(np.uint64)
+    with open(prefix + ".kmc_pre", "wb") as f:
+        f.write(b"KMCP")
+        f.write(lut.tobytes())
+        hdr = struct.pack("<IIIIIIQB3x24xI", k, 0, counter_size, p, min_count,
+                          max_count & 0xFFFFFFFF, len(keys), 0, 0)
+        assert len(hdr) == 64
+        f.write(hdr)
+        f.write(struct.pack("<I", 64))
+        f.write(b"KMCP")
+    rec = np.zeros((len(keys), suf_bytes + counter_size), np.uint8)
+    for b in range(suf_bytes):  # most-significant suffix byte first
+        rec[:, b] = ((keys >> np.uint64(8 * (suf_bytes - 1 - b))) & np.uint64(0xFF)).astype(np.uint8)
+    for b in range(counter_size):
+        rec[:, suf_bytes + b] = ((counters >> np.uint32(8 * b)) & np.uint32(0xFF)).astype(np.uint8)
+    with open(prefix + ".kmc_suf", "wb") as f:
+        f.write(b"KMCS")
+        f.write(rec.tobytes())
+        f.write(b"KMCS")
+
+
+def read_kmc1(prefix: str):
+    """Read a KMC1 database -> dict(k, keys u64 sorted, counters u32, min_count, max_count)."""
+    with open(prefix + ".kmc_pre", "rb") as f:
+        pre = f.read()
+    with open(prefix + ".kmc_suf", "rb") as f:
+        suf = f.read()
+    return parse_kmc1(pre, suf)
+
+
+def parse_kmc1(pre: bytes, suf: bytes):
+    if pre[:4] != b"KMCP" or pre[-4:] != b"KMCP" or suf[:4] != b"KMCS" or suf[-4:] != b"KMCS":
+        raise ValueError("not a KMC database (bad markers)")
+    (hoff,) = struct.unpack("<I", pre[-8:-4])
+    hdr = pre[len(pre) - 8 - hoff:len(pre) - 8]
+    k, mode, csz, p, minc, maxc, total = struct.unpack("<IIIIIIQ", hdr[:32])
+    both = hdr[32]
+    (ver,) = struct.unpack("<I", hdr[60:64])
+    if ver != 0:
+        raise ValueError("only the KMC1 layout (kmc_version=0) is supported")
+    if mode != 0:
+        raise ValueError("quality-mode KMC databases are not supported")
+    lut = np.frombuffer(pre, np.uint64, 4 ** p, 4)
+    suf_bytes = (k - p) // 4
+    rec = np.frombuffer(suf, np.uint8, total * (suf_bytes + csz), 4).reshape(total, suf_bytes + csz)
+    keys = np.zeros(total, np.uint64)
+    for b in range(suf_bytes):
+        keys |= rec[:, b].astype(np.uint64) << np.uint64(8 * (suf_bytes - 1 - b))
+    # prefix of record i = the LUT bucket it falls in
+    bounds = np.concatenate([lut, [np.uint64(total)]]).astype(np.int64)
+    pref = np.repeat(np.arange(4 ** p, dtype=np.uint64), np.diff(bounds))
+    keys |= pref << np.uint64(2 * (k - p))
+    counters = np.zeros(total, np.uint32)
+    for b in range(csz):
+        counters |= rec[:, suf_bytes + b].astype(np.uint32) << np.uint32(8 * b)
+    return dict(k=k, keys=keys, counters=counters, min_count=minc, max_count=maxc,
+                lut_prefix_len=p, counter_size=csz, both_strands=both)
+
+
+# ---------------------------------------------------------------------------
+# lookup = GetCountersForRead
+# ---------------------------------------------------------------------------
+def counters_for_read(db: Tuple[np.ndarray, np.ndarray], seq: bytes, k: int,
+                      min_count: int = 1, max_count: int = 0xFFFFFFFF) -> np.ndarray:
+    keys, masks = db
+    q, valid = canonical_kmers(seq, k)
+    out = np.zeros(len(q), np.uint32)
+    if len(keys) == 0 or len(q) == 0:
+        return out
+    idx = np.searchsorted(keys, q)
+    idx[idx >= len(keys)] = len(keys) - 1
+    hit = valid & (keys[idx] == q)
+    c = masks[idx]
+    hit &= (c >= min_count) & (c <= max_count)
+    out[hit] = c[hit]
+    return out
+
+
+# ---------------------------------------------------------------------------
+# write_bits / anchor_fasta restatement
+# ---------------------------------------------------------------------------
+def row_byte_counts(ngenomes: int) -> List[int]:
+    """bytes taken from each DB's u32 (cpp/anchor.cpp:139-145; index.py:940-945)."""
+    nbytes = (ngenomes + 7) // 8
+    ndbs = (ngenomes + 31) // 32
+    ns = []
+    for d in range(ndbs):
+        if nbytes <= 4:
+            ns.append(nbytes)
+        elif d == ndbs - 1 and nbytes % 4 > 0:
+            ns.append(nbytes % 4)
+        else:
+            ns.append(4)
+    return ns
+
+
+def bin_length(nkmers: int) -> int:
+    """cpp/anchor.cpp:114-118 (== index.py:1170-1172 with the default params)."""
+    binlen = 200000
+    if nkmers // binlen < 100:
+        binlen = nkmers // 100
+    return binlen
+
+
+def anchor_contig(dbs, seq: bytes, k: int, ngenomes: int, min_count: int = 1,
+                  max_count: int = 0xFFFFFFFF):
+    """One contig -> (rows[nkmers, nbytes] u8, rows100, bins[nbins, N+1] i64,
+    bin_starts, colsums[N] i64).  Bit g of a row (byte g//8, bit g%8) = genome g."""
+    nbytes = (ngenomes + 7) // 8
+    nkmers = len(seq) - k + 1
+    ns = row_byte_counts(ngenomes)
+    rows = np.zeros((nkmers, nbytes), np.uint8)
+    popc = np.zeros(nkmers, np.int64)
+    off = 0
+    for d, n in enumerate(ns):
+        ints = counters_for_read(dbs[d], seq, k, min_count, max_count)
+        b4 = ints.view(np.uint8).reshape(nkmers, 4)
+        rows[:, off:off + n] = b4[:, :n]
+        popc += np.unpackbits(b4, axis=1).sum(axis=1, dtype=np.int64)
+        off += n
+    rows100 = rows[::100]
+    binlen = bin_length(nkmers)
+    starts = np.arange(0, nkmers, binlen, dtype=np.int64)
+    bins = np.zeros((len(starts), ngenomes + 1), np.int64)
+    for i, s in enumerate(starts):
+        bins[i] = np.bincount(popc[s:s + binlen], minlength=ngenomes + 1)[:ngenomes + 1]
+    bits = np.unpackbits(rows, axis=1, bitorder="little")[:, :ngenomes]
+    colsums = bits.sum(axis=0, dtype=np.int64)
+    return rows, rows100, bins, starts, colsums
+
+
+def anchor_fasta(dbs, fasta_bytes: bytes, k: int, ngenomes: int, min_count: int = 1,
+                 max_count: int = 0xFFFFFFFF):
+    """Whole anchor FASTA -> dict of payloads/texts as ``run_anchor`` writes them
+    (decompressed), plus ``colsums`` for total_paircounts (index.py:1051)."""
+    recs = parse_fasta_cpp(fasta_bytes)
+    b1, b100 = [], []
+    bins_txt = io.StringIO()
+    bins_txt.write("chr\tstart" + "".join(f"\t{i}" for i in range(ngenomes + 1)) + "\n")
+    chrs_txt = io.StringIO()
+    chrs_txt.write("name\tid\tsize\tgene_count\n")
+    colsums = np.zeros(ngenomes, np.int64)
+    for ci, (name, seq) in enumerate(recs):
+        rows, rows100, bins, starts, cs = anchor_contig(dbs, seq, k, ngenomes, min_count, max_count)
+        b1.append(rows.tobytes())
+        b100.append(rows100.tobytes())
+        for s, r in zip(starts, bins):
+            bins_txt.write(f"{ci}\t{s}" + "".join(f"\t{c}" for c in r) + "\n")
+        chrs_txt.write(f"{name}\t{ci}\t{len(rows)}\t0\n")
+        colsums += cs
+    return dict(bitmap1=b"".join(b1), bitmap100=b"".join(b100),
+                bins_tsv=bins_txt.getvalue(), chrs_tsv=chrs_txt.getvalue(), colsums=colsums)
+
+
+# ---------------------------------------------------------------------------
+# deterministic synthetic genomes
+# ---------------------------------------------------------------------------
+_ACGT = np.frombuffer(b"ACGT", np.uint8)
+
+
+def synth_genomes(ngenomes: int, contig_lens: Sequence[int], d: float, seed: int) -> List[List[np.ndarray]]:
+    """Base genome i.i.d. uniform; genome g>0 = base with per-base substitution at
+    rate d (new base != old), rng seed ``seed+g``.  Returns code arrays (0..3)."""
+    rng = np.random.default_rng(seed)
+    base = [rng.integers(0, 4, L, dtype=np.uint8) for L in contig_lens]
+    out = [base]
+    for g in range(1, ngenomes):
+        r = np.random.default_rng(seed + g)
+        contigs = []
+        for b in base:
+            mut = r.random(len(b)) < d
+            shift = r.integers(1, 4, len(b), dtype=np.uint8)
+            contigs.append(np.where(mut, (b + shift) & 3, b).astype(np.uint8))
+        out.append(contigs)
+    return out
+
+
+def codes_to_ascii(codes: np.ndarray) -> bytes:
+    return _ACGT[codes].tobytes()
+
+
+def fasta_text(names: Sequence[str], seqs: Sequence[bytes], width: int = 80) -> bytes:
+    out = []
+    for nm, s in zip(names, seqs):
+        out.append(b">" + nm.encode() + b"\n")
+        for i in range(0, len(s), width):
+            out.append(s[i:i + width] + b"\n")
+    return b"".join(out)
