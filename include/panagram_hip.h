@@ -1,0 +1,170 @@
+/*
+ * panagram_hip.h — C-ABI of libpanagram_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for the `panagram index` anchor hot path.  Each entry point
+ * names the reference interface it replaces (paths relative to the reference
+ * repo kjenike/panagram).  Plain pointers and sizes only; no C++ or torch types.
+ *
+ * Conventions
+ *   - every function returns 0 on success, <0 (PG_E_*) on failure;
+ *     pg_last_error() returns a thread-local, human-readable message.
+ *   - handles are opaque; the library owns all device memory behind them.
+ *   - host output buffers are allocated by the caller.
+ *   - all work of a context is enqueued on ONE HIP stream (pg_ctx_set_stream);
+ *     functions documented "async" do not synchronise it.
+ *   - a context is not re-entrant; different contexts are independent.
+ *
+ * Bit/byte conventions (identical to the reference):
+ *   nbytes = ceil(ngenomes/8) (cpp/anchor.cpp:34, index.py:484); genome g of a
+ *   position = byte g/8, bit g%8 of its row (index.py:824-825); a row is the
+ *   concatenation over 32-genome groups ("bitvec DBs", index.py:391-401) of the
+ *   low n bytes of that group's u32 mask (cpp/anchor.cpp:139-164).
+ */
+#ifndef PANAGRAM_HIP_H
+#define PANAGRAM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PG_OK 0
+#define PG_E_INVALID (-1)   /* bad argument */
+#define PG_E_HIP (-2)       /* HIP runtime error (no GPU, OOM, launch failure) */
+#define PG_E_FORMAT (-3)    /* ill-formed KMC database */
+#define PG_E_CAPACITY (-4)  /* table cannot grow further */
+#define PG_E_IO (-5)        /* file I/O (BGZF writer) */
+
+typedef struct pg_ctx pg_ctx;
+typedef struct pg_table pg_table;
+typedef struct pg_seqset pg_seqset;
+typedef struct pg_result pg_result;
+typedef struct pg_bgzf pg_bgzf;
+
+/* thread-local message of the last failing call on this thread */
+const char *pg_last_error(void);
+/* library version string, e.g. "panagram_hip 0.1 gfx950" */
+const char *pg_version(void);
+
+/* ---- context ---------------------------------------------------------- */
+/* One context per GPU / per process rank.  Fails with PG_E_HIP when no
+ * gfx950-class device is visible: there is NO CPU fallback in this library. */
+int pg_ctx_create(int device_id, pg_ctx **out);
+int pg_ctx_destroy(pg_ctx *ctx);
+/* adopt an external hipStream_t (e.g. torch.cuda.current_stream().cuda_stream);
+ * NULL restores the context's own stream. */
+int pg_ctx_set_stream(pg_ctx *ctx, void *hip_stream);
+int pg_ctx_synchronize(pg_ctx *ctx);
+
+/* ---- pan-kmer table: replaces the merged KMC "bitvec" databases --------
+ * Reference: KMCdb::KMCdb opens root/kmc/bitvec{i} with CKMCFile::OpenForRA
+ * (cpp/anchor.cpp:21-35); Genome._load_kmc (index.py:847-863).
+ * One GPU-resident open-addressed table per pair of 32-genome groups: 64-byte
+ * buckets, key = canonical k-mer (2k-bit integer, first base most significant),
+ * value = the group's u32 one-hot-OR mask(s).  k in 1..32. */
+int pg_table_create(pg_ctx *ctx, int k, int ngenomes, uint64_t expected_keys, pg_table **out);
+int pg_table_destroy(pg_table *tbl);
+
+/* k-mer set construction from sequence, replacing `kmc -ci1 -fm` +
+ * `kmc_tools transform set_counts` + `kmc_tools complex -ocsum`
+ * (workflow/Snakefile:54-110, index.py:407-426): every canonical k-mer of every
+ * contig of `seqs` gets bit genome_idx%32 set in group genome_idx/32.
+ * Grows the table as needed.  Synchronises. */
+int pg_table_insert_seqset(pg_table *tbl, int genome_idx, const pg_seqset *seqs);
+
+/* bulk insert of (canonical key, u32 counter) pairs into group db_idx; counters
+ * of equal keys are OR-ed.  Host pointers.  Synchronises. */
+int pg_table_insert_keys(pg_table *tbl, int db_idx, const uint64_t *keys,
+                         const uint32_t *counters, uint64_t n);
+
+/* load a real KMC1-layout database (kmc_tools output) as
+ * group db_idx: the in-memory images of X.kmc_pre / X.kmc_suf.  Counters outside
+ * the header's [min_count,max_count] read as 0 as in KMC.  Replaces
+ * CKMCFile::OpenForRA (cpp/anchor.cpp:29, index.py:859-860) — but returns
+ * PG_E_FORMAT instead of silently yielding zeros. */
+int pg_table_load_kmc1(pg_table *tbl, int db_idx, const void *pre, size_t pre_len,
+                       const void *suf, size_t suf_len);
+
+/* statistics: distinct keys, slot capacity, bucket count, bytes, summed over sub-tables */
+int pg_table_stats(pg_table *tbl, uint64_t *nkeys, uint64_t *nslots, uint64_t *nbuckets,
+                   uint64_t *bytes);
+/* re-hash into the smallest table whose mean bucket occupancy is <= keys_per_bucket */
+int pg_table_rehash(pg_table *tbl, double keys_per_bucket);
+/* export group db_idx as (key, counter) pairs, unsorted; *n receives the count
+ * (call with keys==NULL to query).  Lets the caller write a KMC1 database the
+ * reference can open. */
+int pg_table_export(pg_table *tbl, int db_idx, uint64_t *keys, uint32_t *counters,
+                    uint64_t cap, uint64_t *n);
+int pg_table_k(const pg_table *tbl);
+int pg_table_ngenomes(const pg_table *tbl);
+
+/* ---- sequences: 2-bit packed contigs resident in HBM -------------------
+ * Reference: the FASTA record strings handed to write_bits / _write_bitmap
+ * (cpp/anchor.cpp:77-100, index.py:1044-1046).  A seqset holds the contigs of
+ * one FASTA, each packed 2 bits/base (A=0 C=1 G=2 T=3, case-insensitive) plus a
+ * 1 bit/base "not ACGT" plane; packing runs on the GPU. */
+int pg_seqset_create(pg_ctx *ctx, uint32_t ncontigs, const uint64_t *lens, pg_seqset **out);
+int pg_seqset_destroy(pg_seqset *s);
+/* upload + pack contig `idx` from host ASCII (async w.r.t. the host only after
+ * the internal staging copy; synchronises the stream before returning) */
+int pg_seqset_load_host(pg_seqset *s, uint32_t idx, const char *ascii, uint64_t len);
+/* pack contig `idx` from ASCII already in device memory (16-byte aligned); async */
+int pg_seqset_load_dev(pg_seqset *s, uint32_t idx, const void *d_ascii, uint64_t len);
+uint64_t pg_seqset_total_kmers(const pg_seqset *s, int k);
+
+/* ---- anchoring ---------------------------------------------------------
+ * Reference: KMCdb::write_bits (cpp/anchor.cpp:112-195) per contig =
+ * Genome._write_bitmap + bin_bitsum + paircount sums (index.py:949-969,
+ * 1048-1051, 1169-1183).  For every k-mer position of every contig: the
+ * nbytes-byte presence row (bitmap.1), every row whose contig-relative index is
+ * a multiple of 100 (bitmap.100), the per-bin popcount histogram (N+1 counters
+ * per bin; bin length 200000 or nkmers/100) and per-genome column sums. */
+#define PG_ANCHOR_COLSUMS 1u  /* also accumulate per-genome column sums */
+int pg_result_create(pg_table *tbl, const pg_seqset *seqs, uint32_t flags, pg_result **out);
+int pg_result_destroy(pg_result *r);
+/* run the anchor kernels for all contigs of the result's seqset; async */
+int pg_anchor_run(pg_result *r);
+/* geometry of contig idx: k-mer count, bitmap.100 row count, bin count, bin length */
+int pg_result_contig_info(const pg_result *r, uint32_t idx, uint64_t *nkmers, uint64_t *nrows100,
+                          uint32_t *nbins, uint32_t *binlen);
+/* copy contig idx's outputs to host (any pointer may be NULL); synchronises.
+ *   bitmap1:   nkmers  * nbytes bytes        bitmap100: nrows100 * nbytes bytes
+ *   bins:      nbins * (ngenomes+1) u32      (row b covers [b*binlen, ...)) */
+int pg_result_download(pg_result *r, uint32_t idx, uint8_t *bitmap1, uint8_t *bitmap100,
+                       uint32_t *bins);
+/* per-genome column sums over ALL contigs of the seqset (ngenomes u64); synchronises */
+int pg_result_colsums(pg_result *r, uint64_t *colsums);
+/* device pointers (for benchmarking / checksums without PCIe traffic) */
+int pg_result_device_ptrs(pg_result *r, void **d_bitmap1, uint64_t *bitmap1_bytes,
+                          void **d_bitmap100, uint64_t *bitmap100_bytes);
+
+/* one-shot convenience for a single contig held in host memory: upload, pack,
+ * anchor, download.  nkmers = len-k+1 (0 and a warning-free no-op when len<k:
+ * the reference underflows here, cpp/anchor.cpp:115).  Any output may be NULL. */
+int pg_anchor_contig(pg_table *tbl, const char *ascii, uint64_t len, uint8_t *bitmap1,
+                     uint8_t *bitmap100, uint32_t *bins, uint64_t *colsums, uint64_t *nkmers);
+
+/* literal equivalent of CKMCFile::GetCountersForRead(seq, vector<uint32>&)
+ * (call sites cpp/anchor.cpp:148, index.py:934-935) for group db_idx:
+ * out[i] = counter of the canonical k-mer of ascii[i:i+k], 0 if absent or if the
+ * window holds a byte outside ACGTacgt.  out has len-k+1 entries. */
+int pg_counters_for_read(pg_table *tbl, int db_idx, const char *ascii, uint64_t len,
+                         uint32_t *out);
+
+/* ---- BGZF + .gzi writer (host, zlib, multi-threaded) -------------------
+ * Reference: htslib bgzf_open/bgzf_index_build_init/bgzf_write/
+ * bgzf_index_dump/bgzf_close (cpp/anchor.cpp:46-47,53-54,102-106,167,177) and
+ * bgzip.BGZipWriter + `bgzip -rI` (index.py:1035-1037,1091-1094).  Blocks hold
+ * <= 65280 uncompressed bytes; X.gzi = u64 n, n x (u64 compressed_off, u64
+ * uncompressed_off) for blocks 1..n (read by index.py:793-799). */
+int pg_bgzf_open(const char *path, int level, int nthreads, pg_bgzf **out);
+int pg_bgzf_write(pg_bgzf *w, const void *data, size_t len);
+/* writes the EOF block, closes the file and, if gzi_path != NULL, the index */
+int pg_bgzf_close(pg_bgzf *w, const char *gzi_path);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PANAGRAM_HIP_H */

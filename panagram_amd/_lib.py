@@ -1,0 +1,85 @@
+"""ctypes binding of libpanagram_hip.so (C-ABI: include/panagram_hip.h).
+
+The library is the product; this module only loads it and declares prototypes.
+There is deliberately no fallback: a missing library or a missing GPU raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpanagram_hip.so")
+
+PG_ANCHOR_COLSUMS = 1
+
+
+class PanagramHipError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"libpanagram_hip error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+# name -> (restype, argtypes); every symbol declared in include/panagram_hip.h
+_u8p, _u32p, _u64p = C.POINTER(C.c_uint8), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)
+_vp, _vpp = C.c_void_p, C.POINTER(C.c_void_p)
+PROTOTYPES = {
+    "pg_last_error": (C.c_char_p, []),
+    "pg_version": (C.c_char_p, []),
+    "pg_ctx_create": (C.c_int, [C.c_int, _vpp]),
+    "pg_ctx_destroy": (C.c_int, [_vp]),
+    "pg_ctx_set_stream": (C.c_int, [_vp, _vp]),
+    "pg_ctx_synchronize": (C.c_int, [_vp]),
+    "pg_table_create": (C.c_int, [_vp, C.c_int, C.c_int, C.c_uint64, _vpp]),
+    "pg_table_destroy": (C.c_int, [_vp]),
+    "pg_table_insert_seqset": (C.c_int, [_vp, C.c_int, _vp]),
+    "pg_table_insert_keys": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_uint64]),
+    "pg_table_load_kmc1": (C.c_int, [_vp, C.c_int, _vp, C.c_size_t, _vp, C.c_size_t]),
+    "pg_table_stats": (C.c_int, [_vp, _u64p, _u64p, _u64p, _u64p]),
+    "pg_table_rehash": (C.c_int, [_vp, C.c_double]),
+    "pg_table_export": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_uint64, _u64p]),
+    "pg_table_k": (C.c_int, [_vp]),
+    "pg_table_ngenomes": (C.c_int, [_vp]),
+    "pg_seqset_create": (C.c_int, [_vp, C.c_uint32, _vp, _vpp]),
+    "pg_seqset_destroy": (C.c_int, [_vp]),
+    "pg_seqset_load_host": (C.c_int, [_vp, C.c_uint32, _vp, C.c_uint64]),
+    "pg_seqset_load_dev": (C.c_int, [_vp, C.c_uint32, _vp, C.c_uint64]),
+    "pg_seqset_total_kmers": (C.c_uint64, [_vp, C.c_int]),
+    "pg_result_create": (C.c_int, [_vp, _vp, C.c_uint32, _vpp]),
+    "pg_result_destroy": (C.c_int, [_vp]),
+    "pg_anchor_run": (C.c_int, [_vp]),
+    "pg_result_contig_info": (C.c_int, [_vp, C.c_uint32, _u64p, _u64p, _u32p, _u32p]),
+    "pg_result_download": (C.c_int, [_vp, C.c_uint32, _vp, _vp, _vp]),
+    "pg_result_colsums": (C.c_int, [_vp, _vp]),
+    "pg_result_device_ptrs": (C.c_int, [_vp, _vpp, _u64p, _vpp, _u64p]),
+    "pg_anchor_contig": (C.c_int, [_vp, _vp, C.c_uint64, _vp, _vp, _vp, _vp, _u64p]),
+    "pg_counters_for_read": (C.c_int, [_vp, C.c_int, _vp, C.c_uint64, _vp]),
+    "pg_bgzf_open": (C.c_int, [C.c_char_p, C.c_int, C.c_int, _vpp]),
+    "pg_bgzf_write": (C.c_int, [_vp, _vp, C.c_size_t]),
+    "pg_bgzf_close": (C.c_int, [_vp, C.c_char_p]),
+}
+
+
+def load():
+    """Load the shared library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `python -m panagram_amd.build` "
+            "(hipcc --offload-arch=gfx950).  panagram_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise PanagramHipError(rc, load().pg_last_error().decode("utf-8", "replace"))

@@ -1,0 +1,782 @@
+// pg_api.hip — host side of the C-ABI declared in include/panagram_hip.h.
+// Owns device memory, sizes/grows the tables, builds launch geometry.  No CPU
+// compute fallback lives here: without a GPU pg_ctx_create fails.
+#include "../../include/panagram_hip.h"
+#include "pg_kernels.h"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace pg;
+
+// ---------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------
+static thread_local std::string g_err;
+
+static int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(PG_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+extern "C" const char *pg_last_error(void) { return g_err.c_str(); }
+// used by pg_bgzf.cpp so that both translation units share one error slot
+int pg_set_error(int code, const char *msg) {
+    g_err = msg ? msg : "";
+    return code;
+}
+extern "C" const char *pg_version(void) { return "panagram_hip 0.1 gfx950"; }
+
+// ---------------------------------------------------------------------------
+// handles
+// ---------------------------------------------------------------------------
+struct pg_ctx {
+    int device;
+    hipStream_t own_stream;
+    hipStream_t stream;
+};
+
+struct SubHost {
+    SubTable d;
+    uint64_t count;  // distinct keys
+};
+
+struct pg_table {
+    pg_ctx *ctx;
+    int k, ngenomes, ndbs;
+    std::vector<SubHost> subs;
+    unsigned long long *d_counters;  // [0] newly claimed, [1] overflow flag
+};
+
+struct pg_seqset {
+    pg_ctx *ctx;
+    uint32_t n;
+    std::vector<SeqDesc> desc;
+    uint64_t total_words;
+    uint64_t *d_seqw;
+    uint32_t *d_nmw;
+    uint32_t *d_has_n;
+    SeqDesc *d_desc;
+    void *d_stage;
+    size_t stage_cap;
+};
+
+struct pg_result {
+    pg_table *tbl;
+    const pg_seqset *seqs;
+    uint32_t flags;
+    std::vector<AnchorDesc> ad;
+    std::vector<uint64_t> nrows100;
+    AnchorDesc *d_ad;
+    uint32_t *d_tile_contig;
+    uint32_t ntiles;
+    uint8_t *d_out1;
+    uint64_t out1_bytes;
+    uint8_t *d_out100;
+    uint64_t out100_bytes;
+    uint32_t *d_bins;
+    uint64_t total_bins;
+    unsigned long long *d_colsums;
+};
+
+static constexpr uint32_t MAX_PROBE = 64;
+static constexpr double GROW_AT = 0.60;     // grow when keys > GROW_AT * slots
+static constexpr double TARGET_LOAD = 0.40; // load right after growing
+static constexpr double HARD_LOAD = 0.85;   // worst-case guard before a batch
+
+static int use_device(const pg_ctx *c) {
+    HIP_TRY(hipSetDevice(c->device));
+    return PG_OK;
+}
+
+// ---------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------
+extern "C" int pg_ctx_create(int device_id, pg_ctx **out) {
+    if (!out) return fail(PG_E_INVALID, "pg_ctx_create: out is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0)
+        return fail(PG_E_HIP, "no HIP device visible (%s); libpanagram_hip has no CPU fallback",
+                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    if (device_id < 0 || device_id >= n) return fail(PG_E_INVALID, "device %d out of range (0..%d)", device_id, n - 1);
+    HIP_TRY(hipSetDevice(device_id));
+    pg_ctx *c = new pg_ctx();
+    c->device = device_id;
+    hipError_t se = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+    if (se != hipSuccess) {
+        delete c;
+        return fail(PG_E_HIP, "hipStreamCreate failed: %s", hipGetErrorString(se));
+    }
+    c->stream = c->own_stream;
+    *out = c;
+    return PG_OK;
+}
+
+extern "C" int pg_ctx_destroy(pg_ctx *c) {
+    if (!c) return PG_OK;
+    hipSetDevice(c->device);
+    hipStreamDestroy(c->own_stream);
+    delete c;
+    return PG_OK;
+}
+
+extern "C" int pg_ctx_set_stream(pg_ctx *c, void *s) {
+    if (!c) return fail(PG_E_INVALID, "ctx is NULL");
+    c->stream = s ? reinterpret_cast<hipStream_t>(s) : c->own_stream;
+    return PG_OK;
+}
+
+extern "C" int pg_ctx_synchronize(pg_ctx *c) {
+    if (!c) return fail(PG_E_INVALID, "ctx is NULL");
+    if (int r = use_device(c)) return r;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return PG_OK;
+}
+
+// ---------------------------------------------------------------------------
+// table
+// ---------------------------------------------------------------------------
+static int alloc_sub(pg_ctx *ctx, uint32_t W, uint32_t word0, uint64_t nbuckets, SubTable *out) {
+    if (nbuckets < 64) nbuckets = 64;
+    if (nbuckets > 0xFFFFFFFFull) return fail(PG_E_CAPACITY, "sub-table would exceed 2^32 buckets (256 GB)");
+    SubTable t;
+    t.W = W;
+    t.word0 = word0;
+    t.nbuckets = nbuckets;
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, nbuckets * BUCKET_BYTES);
+    if (e != hipSuccess)
+        return fail(PG_E_HIP, "hipMalloc(%llu bytes) for k-mer table failed: %s",
+                    (unsigned long long)(nbuckets * BUCKET_BYTES), hipGetErrorString(e));
+    t.buckets = static_cast<uint8_t *>(p);
+    HIP_TRY(launch_table_init(ctx->stream, t));
+    *out = t;
+    return PG_OK;
+}
+
+extern "C" int pg_table_create(pg_ctx *ctx, int k, int ngenomes, uint64_t expected_keys, pg_table **out) {
+    if (!ctx || !out) return fail(PG_E_INVALID, "pg_table_create: NULL argument");
+    if (k < 1 || k > 32) return fail(PG_E_INVALID, "k=%d unsupported (1..32)", k);
+    if (ngenomes < 1) return fail(PG_E_INVALID, "ngenomes must be >= 1");
+    int ndbs = (ngenomes + 31) / 32;
+    int nsub = (ndbs + 1) / 2;
+    if (nsub > MAX_SUB) return fail(PG_E_INVALID, "ngenomes=%d exceeds the supported %d", ngenomes, MAX_SUB * 64);
+    if (int r = use_device(ctx)) return r;
+    pg_table *t = new pg_table();
+    t->ctx = ctx;
+    t->k = k;
+    t->ngenomes = ngenomes;
+    t->ndbs = ndbs;
+    t->d_counters = nullptr;
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&t->d_counters), 2 * sizeof(unsigned long long));
+    if (e != hipSuccess) {
+        delete t;
+        return fail(PG_E_HIP, "hipMalloc failed: %s", hipGetErrorString(e));
+    }
+    hipMemsetAsync(t->d_counters, 0, 2 * sizeof(unsigned long long), ctx->stream);
+    for (int s = 0; s < nsub; ++s) {
+        uint32_t W = (2 * s + 1 < ndbs) ? 2 : 1;
+        uint64_t want = expected_keys ? expected_keys : (1ull << 18);
+        uint64_t nb = (uint64_t)((double)want / (TARGET_LOAD * slots_per_bucket(W))) + 1;
+        SubHost sh;
+        sh.count = 0;
+        int r = alloc_sub(ctx, W, 2 * s, nb, &sh.d);
+        if (r) {
+            pg_table_destroy(t);
+            return r;
+        }
+        t->subs.push_back(sh);
+    }
+    *out = t;
+    return PG_OK;
+}
+
+extern "C" int pg_table_destroy(pg_table *t) {
+    if (!t) return PG_OK;
+    hipSetDevice(t->ctx->device);
+    hipStreamSynchronize(t->ctx->stream);
+    for (auto &s : t->subs) hipFree(s.d.buckets);
+    if (t->d_counters) hipFree(t->d_counters);
+    delete t;
+    return PG_OK;
+}
+
+extern "C" int pg_table_k(const pg_table *t) { return t ? t->k : 0; }
+extern "C" int pg_table_ngenomes(const pg_table *t) { return t ? t->ngenomes : 0; }
+
+static int read_counters(pg_table *t, unsigned long long out[2]) {
+    HIP_TRY(hipMemcpyAsync(out, t->d_counters, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost,
+                           t->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(t->ctx->stream));
+    return PG_OK;
+}
+
+// replace sub-table si by one with `nb` buckets holding the same content
+static int regrow(pg_table *t, int si, uint64_t nb) {
+    pg_ctx *ctx = t->ctx;
+    for (int attempt = 0; attempt < 8; ++attempt) {
+        SubTable nt;
+        if (int r = alloc_sub(ctx, t->subs[si].d.W, t->subs[si].d.word0, nb, &nt)) return r;
+        HIP_TRY(hipMemsetAsync(t->d_counters, 0, 2 * sizeof(unsigned long long), ctx->stream));
+        HIP_TRY(launch_rehash(ctx->stream, t->subs[si].d, nt, t->d_counters, MAX_PROBE));
+        unsigned long long c[2];
+        if (int r = read_counters(t, c)) {
+            hipFree(nt.buckets);
+            return r;
+        }
+        if (c[1] == 0) {
+            hipFree(t->subs[si].d.buckets);
+            t->subs[si].d = nt;
+            t->subs[si].count = c[0];
+            return PG_OK;
+        }
+        hipFree(nt.buckets);
+        nb *= 2;
+    }
+    return fail(PG_E_CAPACITY, "re-hash keeps overflowing");
+}
+
+static int ensure_room(pg_table *t, int si, uint64_t incoming) {
+    SubHost &s = t->subs[si];
+    const int ns = slots_per_bucket(s.d.W);
+    const double slots = (double)s.d.nbuckets * ns;
+    if ((double)(s.count + incoming) > HARD_LOAD * slots) {
+        uint64_t nb = (uint64_t)((double)(s.count + incoming) / (HARD_LOAD * 0.9 * ns)) + 1;
+        nb = std::max(nb, s.d.nbuckets * 2);
+        return regrow(t, si, nb);
+    }
+    return PG_OK;
+}
+
+static int after_insert(pg_table *t, int si) {
+    SubHost &s = t->subs[si];
+    const int ns = slots_per_bucket(s.d.W);
+    if ((double)s.count > GROW_AT * (double)s.d.nbuckets * ns) {
+        uint64_t nb = (uint64_t)((double)s.count / (TARGET_LOAD * ns)) + 1;
+        return regrow(t, si, nb);
+    }
+    return PG_OK;
+}
+
+extern "C" int pg_table_insert_seqset(pg_table *t, int g, const pg_seqset *sq) {
+    if (!t || !sq) return fail(PG_E_INVALID, "pg_table_insert_seqset: NULL argument");
+    if (g < 0 || g >= t->ngenomes) return fail(PG_E_INVALID, "genome index %d out of range (0..%d)", g, t->ngenomes - 1);
+    if (int r = use_device(t->ctx)) return r;
+    const int d = g / 32, si = d / 2, w = d % 2;
+    const uint32_t bits = 1u << (g % 32);
+    uint64_t total = 0;
+    for (auto &c : sq->desc)
+        if (c.len >= (uint64_t)t->k) total += c.len - t->k + 1;
+    if (int r = ensure_room(t, si, total)) return r;
+    for (int attempt = 0; attempt < 8; ++attempt) {
+        hipStream_t st = t->ctx->stream;
+        HIP_TRY(hipMemsetAsync(t->d_counters, 0, 2 * sizeof(unsigned long long), st));
+        for (uint32_t c = 0; c < sq->n; ++c) {
+            const SeqDesc &sd = sq->desc[c];
+            if (sd.len < (uint64_t)t->k) continue;
+            HIP_TRY(launch_insert_seq(st, t->subs[si].d, w, bits, t->k, sq->d_seqw + sd.seq_off,
+                                      sq->d_nmw + sd.seq_off, sq->d_has_n + c, sd.len - t->k + 1,
+                                      t->d_counters, MAX_PROBE));
+        }
+        unsigned long long cnt[2];
+        if (int r = read_counters(t, cnt)) return r;
+        t->subs[si].count += cnt[0];
+        if (cnt[1] == 0) return after_insert(t, si);
+        // a probe chain exceeded MAX_PROBE buckets: grow and redo (inserts are idempotent)
+        if (int r = regrow(t, si, t->subs[si].d.nbuckets * 2)) return r;
+    }
+    return fail(PG_E_CAPACITY, "k-mer table keeps overflowing");
+}
+
+static int insert_keys_dev(pg_table *t, int db_idx, const uint64_t *d_keys, const uint32_t *d_vals, uint64_t n) {
+    const int si = db_idx / 2, w = db_idx % 2;
+    if (int r = ensure_room(t, si, n)) return r;
+    for (int attempt = 0; attempt < 8; ++attempt) {
+        hipStream_t st = t->ctx->stream;
+        HIP_TRY(hipMemsetAsync(t->d_counters, 0, 2 * sizeof(unsigned long long), st));
+        HIP_TRY(launch_insert_keys(st, t->subs[si].d, w, d_keys, d_vals, n, t->d_counters, MAX_PROBE));
+        unsigned long long cnt[2];
+        if (int r = read_counters(t, cnt)) return r;
+        t->subs[si].count += cnt[0];
+        if (cnt[1] == 0) return after_insert(t, si);
+        if (int r = regrow(t, si, t->subs[si].d.nbuckets * 2)) return r;
+    }
+    return fail(PG_E_CAPACITY, "k-mer table keeps overflowing");
+}
+
+extern "C" int pg_table_insert_keys(pg_table *t, int db_idx, const uint64_t *keys, const uint32_t *counters,
+                                    uint64_t n) {
+    if (!t || (n && (!keys || !counters))) return fail(PG_E_INVALID, "pg_table_insert_keys: NULL argument");
+    if (db_idx < 0 || db_idx >= t->ndbs) return fail(PG_E_INVALID, "db index %d out of range (0..%d)", db_idx, t->ndbs - 1);
+    if (n == 0) return PG_OK;
+    if (int r = use_device(t->ctx)) return r;
+    uint64_t *dk = nullptr;
+    uint32_t *dv = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dk), n * 8));
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&dv), n * 4);
+    if (e != hipSuccess) {
+        hipFree(dk);
+        return fail(PG_E_HIP, "hipMalloc failed: %s", hipGetErrorString(e));
+    }
+    int r = PG_OK;
+    if (hipMemcpyAsync(dk, keys, n * 8, hipMemcpyHostToDevice, t->ctx->stream) != hipSuccess ||
+        hipMemcpyAsync(dv, counters, n * 4, hipMemcpyHostToDevice, t->ctx->stream) != hipSuccess)
+        r = fail(PG_E_HIP, "H2D copy of keys failed");
+    if (!r) r = insert_keys_dev(t, db_idx, dk, dv, n);
+    hipStreamSynchronize(t->ctx->stream);
+    hipFree(dk);
+    hipFree(dv);
+    return r;
+}
+
+// KMC1 layout, SURVEY.md Appendix A
+extern "C" int pg_table_load_kmc1(pg_table *t, int db_idx, const void *pre_, size_t pre_len, const void *suf_,
+                                  size_t suf_len) {
+    if (!t || !pre_ || !suf_) return fail(PG_E_INVALID, "pg_table_load_kmc1: NULL argument");
+    if (db_idx < 0 || db_idx >= t->ndbs) return fail(PG_E_INVALID, "db index %d out of range (0..%d)", db_idx, t->ndbs - 1);
+    const uint8_t *pre = static_cast<const uint8_t *>(pre_);
+    const uint8_t *suf = static_cast<const uint8_t *>(suf_);
+    if (pre_len < 4 + 8 + 64 + 8 || memcmp(pre, "KMCP", 4) || memcmp(pre + pre_len - 4, "KMCP", 4))
+        return fail(PG_E_FORMAT, "kmc_pre: missing KMCP markers");
+    if (suf_len < 8 || memcmp(suf, "KMCS", 4) || memcmp(suf + suf_len - 4, "KMCS", 4))
+        return fail(PG_E_FORMAT, "kmc_suf: missing KMCS markers");
+    uint32_t hoff;
+    memcpy(&hoff, pre + pre_len - 8, 4);
+    if (hoff < 64 || (size_t)hoff + 8 + 4 > pre_len) return fail(PG_E_FORMAT, "kmc_pre: bad header offset %u", hoff);
+    const uint8_t *h = pre + pre_len - 8 - hoff;
+    uint32_t kk, mode, csz, lut_p, minc, maxc, ver;
+    uint64_t total;
+    memcpy(&kk, h, 4);
+    memcpy(&mode, h + 4, 4);
+    memcpy(&csz, h + 8, 4);
+    memcpy(&lut_p, h + 12, 4);
+    memcpy(&minc, h + 16, 4);
+    memcpy(&maxc, h + 20, 4);
+    memcpy(&total, h + 24, 8);
+    memcpy(&ver, h + 60, 4);
+    if (ver != 0) return fail(PG_E_FORMAT, "kmc_pre: kmc_version=0x%x; only the KMC1 layout (kmc_tools output) is supported", ver);
+    if (mode != 0) return fail(PG_E_FORMAT, "kmc_pre: quality-mode databases are not supported");
+    if ((int)kk != t->k) return fail(PG_E_FORMAT, "database k=%u but table k=%d", kk, t->k);
+    if (csz < 1 || csz > 4) return fail(PG_E_FORMAT, "kmc_pre: counter_size=%u unsupported", csz);
+    if (lut_p < 1 || lut_p > 15 || lut_p > kk || (kk - lut_p) % 4) return fail(PG_E_FORMAT, "kmc_pre: lut_prefix_length=%u invalid for k=%u", lut_p, kk);
+    const uint64_t nlut = 1ull << (2 * lut_p);
+    if (4 + nlut * 8 + hoff + 8 > pre_len) return fail(PG_E_FORMAT, "kmc_pre: truncated prefix table");
+    const uint32_t sb = (kk - lut_p) / 4, rec = sb + csz;
+    if (8 + total * rec > suf_len) return fail(PG_E_FORMAT, "kmc_suf: truncated (%llu records of %u bytes expected)", (unsigned long long)total, rec);
+    std::vector<uint64_t> keys;
+    std::vector<uint32_t> vals;
+    keys.reserve(total);
+    vals.reserve(total);
+    const uint8_t *lutp = pre + 4;
+    const uint8_t *r = suf + 4;
+    uint64_t prev_end = 0;
+    for (uint64_t p = 0; p < nlut; ++p) {
+        uint64_t beg, end;
+        memcpy(&beg, lutp + p * 8, 8);
+        if (p + 1 < nlut) memcpy(&end, lutp + (p + 1) * 8, 8);
+        else end = total;
+        if (beg != prev_end || end < beg || end > total) return fail(PG_E_FORMAT, "kmc_pre: prefix table not monotone at %llu", (unsigned long long)p);
+        prev_end = end;
+        for (uint64_t i = beg; i < end; ++i) {
+            const uint8_t *q = r + i * rec;
+            uint64_t sfx = 0;
+            for (uint32_t b = 0; b < sb; ++b) sfx = (sfx << 8) | q[b];
+            uint32_t c = 0;
+            for (uint32_t b = 0; b < csz; ++b) c |= (uint32_t)q[sb + b] << (8 * b);
+            if (c < minc || c > maxc || c == 0) continue;  // KMC: outside [min,max] reads as 0
+            keys.push_back((p << (2 * (kk - lut_p))) | sfx);
+            vals.push_back(c);
+        }
+    }
+    return pg_table_insert_keys(t, db_idx, keys.data(), vals.data(), keys.size());
+}
+
+extern "C" int pg_table_stats(pg_table *t, uint64_t *nkeys, uint64_t *nslots, uint64_t *nbuckets, uint64_t *bytes) {
+    if (!t) return fail(PG_E_INVALID, "table is NULL");
+    uint64_t a = 0, b = 0, c = 0;
+    for (auto &s : t->subs) {
+        a += s.count;
+        b += s.d.nbuckets * slots_per_bucket(s.d.W);
+        c += s.d.nbuckets;
+    }
+    if (nkeys) *nkeys = a;
+    if (nslots) *nslots = b;
+    if (nbuckets) *nbuckets = c;
+    if (bytes) *bytes = c * BUCKET_BYTES;
+    return PG_OK;
+}
+
+extern "C" int pg_table_rehash(pg_table *t, double keys_per_bucket) {
+    if (!t) return fail(PG_E_INVALID, "table is NULL");
+    if (!(keys_per_bucket > 0.05 && keys_per_bucket <= 4.0)) return fail(PG_E_INVALID, "keys_per_bucket must be in (0.05, 4]");
+    if (int r = use_device(t->ctx)) return r;
+    for (size_t si = 0; si < t->subs.size(); ++si) {
+        double kpb = std::min(keys_per_bucket, 0.8 * slots_per_bucket(t->subs[si].d.W));
+        uint64_t nb = (uint64_t)((double)t->subs[si].count / kpb) + 1;
+        if (int r = regrow(t, (int)si, nb)) return r;
+    }
+    return PG_OK;
+}
+
+extern "C" int pg_table_export(pg_table *t, int db_idx, uint64_t *keys, uint32_t *counters, uint64_t cap, uint64_t *n) {
+    if (!t || !n) return fail(PG_E_INVALID, "pg_table_export: NULL argument");
+    if (db_idx < 0 || db_idx >= t->ndbs) return fail(PG_E_INVALID, "db index %d out of range", db_idx);
+    if (int r = use_device(t->ctx)) return r;
+    const int si = db_idx / 2, w = db_idx % 2;
+    hipStream_t st = t->ctx->stream;
+    uint64_t *dk = nullptr;
+    uint32_t *dv = nullptr;
+    if (keys && cap) {
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dk), cap * 8));
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&dv), cap * 4);
+        if (e != hipSuccess) {
+            hipFree(dk);
+            return fail(PG_E_HIP, "hipMalloc failed: %s", hipGetErrorString(e));
+        }
+    }
+    int rc = PG_OK;
+    unsigned long long cnt[2] = {0, 0};
+    do {
+        if (hipMemsetAsync(t->d_counters, 0, 16, st) != hipSuccess ||
+            launch_export(st, t->subs[si].d, w, dk, dv, dk ? cap : 0, t->d_counters) != hipSuccess) {
+            rc = fail(PG_E_HIP, "export kernel failed");
+            break;
+        }
+        if ((rc = read_counters(t, cnt))) break;
+        if (dk) {
+            uint64_t m = std::min<uint64_t>(cnt[0], cap);
+            if (hipMemcpy(keys, dk, m * 8, hipMemcpyDeviceToHost) != hipSuccess ||
+                hipMemcpy(counters, dv, m * 4, hipMemcpyDeviceToHost) != hipSuccess)
+                rc = fail(PG_E_HIP, "D2H copy failed");
+        }
+    } while (0);
+    if (dk) hipFree(dk);
+    if (dv) hipFree(dv);
+    *n = cnt[0];
+    return rc;
+}
+
+// ---------------------------------------------------------------------------
+// seqset
+// ---------------------------------------------------------------------------
+extern "C" int pg_seqset_create(pg_ctx *ctx, uint32_t ncontigs, const uint64_t *lens, pg_seqset **out) {
+    if (!ctx || !out || (ncontigs && !lens)) return fail(PG_E_INVALID, "pg_seqset_create: NULL argument");
+    if (int r = use_device(ctx)) return r;
+    pg_seqset *s = new pg_seqset();
+    s->ctx = ctx;
+    s->n = ncontigs;
+    s->d_seqw = nullptr;
+    s->d_nmw = nullptr;
+    s->d_has_n = nullptr;
+    s->d_desc = nullptr;
+    s->d_stage = nullptr;
+    s->stage_cap = 0;
+    uint64_t off = 0;
+    for (uint32_t i = 0; i < ncontigs; ++i) {
+        SeqDesc d;
+        d.len = lens[i];
+        d.nwords = (lens[i] + 31) / 32 + 2;  // +2 zero words: the kernels read one word past a window
+        d.seq_off = off;
+        off += d.nwords;
+        s->desc.push_back(d);
+    }
+    s->total_words = off;
+    hipStream_t st = ctx->stream;
+    hipError_t e = hipSuccess;
+    size_t nw = std::max<uint64_t>(off, 1), nc = std::max<uint32_t>(ncontigs, 1);
+    if ((e = hipMalloc(reinterpret_cast<void **>(&s->d_seqw), nw * 8)) == hipSuccess &&
+        (e = hipMalloc(reinterpret_cast<void **>(&s->d_nmw), nw * 4)) == hipSuccess &&
+        (e = hipMalloc(reinterpret_cast<void **>(&s->d_has_n), nc * 4)) == hipSuccess &&
+        (e = hipMalloc(reinterpret_cast<void **>(&s->d_desc), nc * sizeof(SeqDesc))) == hipSuccess &&
+        (e = hipMemsetAsync(s->d_seqw, 0, nw * 8, st)) == hipSuccess &&
+        (e = hipMemsetAsync(s->d_nmw, 0, nw * 4, st)) == hipSuccess &&
+        (e = hipMemsetAsync(s->d_has_n, 0, nc * 4, st)) == hipSuccess) {
+        if (ncontigs)
+            e = hipMemcpyAsync(s->d_desc, s->desc.data(), ncontigs * sizeof(SeqDesc), hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+    }
+    if (e != hipSuccess) {
+        pg_seqset_destroy(s);
+        return fail(PG_E_HIP, "seqset allocation failed: %s", hipGetErrorString(e));
+    }
+    *out = s;
+    return PG_OK;
+}
+
+extern "C" int pg_seqset_destroy(pg_seqset *s) {
+    if (!s) return PG_OK;
+    hipSetDevice(s->ctx->device);
+    hipStreamSynchronize(s->ctx->stream);
+    hipFree(s->d_seqw);
+    hipFree(s->d_nmw);
+    hipFree(s->d_has_n);
+    hipFree(s->d_desc);
+    if (s->d_stage) hipFree(s->d_stage);
+    delete s;
+    return PG_OK;
+}
+
+extern "C" int pg_seqset_load_dev(pg_seqset *s, uint32_t idx, const void *d_ascii, uint64_t len) {
+    if (!s || (len && !d_ascii)) return fail(PG_E_INVALID, "pg_seqset_load_dev: NULL argument");
+    if (idx >= s->n) return fail(PG_E_INVALID, "contig %u out of range (0..%u)", idx, s->n ? s->n - 1 : 0);
+    const SeqDesc &d = s->desc[idx];
+    if (len != d.len) return fail(PG_E_INVALID, "contig %u: length %llu != declared %llu", idx, (unsigned long long)len, (unsigned long long)d.len);
+    if (int r = use_device(s->ctx)) return r;
+    HIP_TRY(hipMemsetAsync(s->d_has_n + idx, 0, 4, s->ctx->stream));
+    HIP_TRY(launch_pack(s->ctx->stream, d_ascii, len, s->d_seqw + d.seq_off, s->d_nmw + d.seq_off,
+                        (len + 31) / 32, s->d_has_n + idx));
+    return PG_OK;
+}
+
+extern "C" int pg_seqset_load_host(pg_seqset *s, uint32_t idx, const char *ascii, uint64_t len) {
+    if (!s || (len && !ascii)) return fail(PG_E_INVALID, "pg_seqset_load_host: NULL argument");
+    if (idx >= s->n) return fail(PG_E_INVALID, "contig %u out of range", idx);
+    if (int r = use_device(s->ctx)) return r;
+    if (len > s->stage_cap) {
+        HIP_TRY(hipStreamSynchronize(s->ctx->stream));
+        if (s->d_stage) hipFree(s->d_stage);
+        s->d_stage = nullptr;
+        s->stage_cap = 0;
+        size_t cap = (len + 4095) & ~(size_t)4095;
+        HIP_TRY(hipMalloc(&s->d_stage, cap));
+        s->stage_cap = cap;
+    }
+    if (len) HIP_TRY(hipMemcpyAsync(s->d_stage, ascii, len, hipMemcpyHostToDevice, s->ctx->stream));
+    if (int r = pg_seqset_load_dev(s, idx, s->d_stage, len)) return r;
+    HIP_TRY(hipStreamSynchronize(s->ctx->stream));  // staging buffer is reused by the next call
+    return PG_OK;
+}
+
+extern "C" uint64_t pg_seqset_total_kmers(const pg_seqset *s, int k) {
+    uint64_t t = 0;
+    if (s)
+        for (auto &d : s->desc)
+            if (d.len >= (uint64_t)k) t += d.len - k + 1;
+    return t;
+}
+
+// ---------------------------------------------------------------------------
+// anchoring
+// ---------------------------------------------------------------------------
+static TableDesc make_desc(const pg_table *t) {
+    TableDesc T;
+    memset(&T, 0, sizeof T);
+    T.nsub = (uint32_t)t->subs.size();
+    for (uint32_t i = 0; i < T.nsub; ++i) T.sub[i] = t->subs[i].d;
+    T.ndbs = t->ndbs;
+    T.k = t->k;
+    T.ngenomes = t->ngenomes;
+    return T;
+}
+
+extern "C" int pg_result_create(pg_table *t, const pg_seqset *sq, uint32_t flags, pg_result **out) {
+    if (!t || !sq || !out) return fail(PG_E_INVALID, "pg_result_create: NULL argument");
+    if (t->ctx != sq->ctx) return fail(PG_E_INVALID, "table and seqset belong to different contexts");
+    if (int r = use_device(t->ctx)) return r;
+    const uint32_t N = t->ngenomes, nbytes = (N + 7) / 8;
+    pg_result *r = new pg_result();
+    r->tbl = t;
+    r->seqs = sq;
+    r->flags = flags;
+    r->d_ad = nullptr;
+    r->d_tile_contig = nullptr;
+    r->d_out1 = r->d_out100 = nullptr;
+    r->d_bins = nullptr;
+    r->d_colsums = nullptr;
+    uint64_t o1 = 0, o100 = 0, bins = 0, tiles = 0;
+    std::vector<uint32_t> tile_contig;
+    for (uint32_t c = 0; c < sq->n; ++c) {
+        const uint64_t len = sq->desc[c].len;
+        const uint64_t nk = len >= (uint64_t)t->k ? len - t->k + 1 : 0;
+        if (nk > 0xFFFFFFF0ull) {
+            delete r;
+            return fail(PG_E_INVALID, "contig %u has %llu k-mers; contigs must stay below 2^32 (as in KMC)", c, (unsigned long long)nk);
+        }
+        AnchorDesc a;
+        a.nkmers = (uint32_t)nk;
+        // cpp/anchor.cpp:114-118; contigs with < 100 k-mers make the reference divide by
+        // zero — here they get one bin per k-mer (documented deviation)
+        uint64_t binlen = 200000;
+        if (nk / binlen < 100) binlen = nk / 100;
+        if (binlen == 0) binlen = 1;
+        a.binlen = (uint32_t)binlen;
+        a.nbins = (uint32_t)((nk + binlen - 1) / binlen);
+        a.out_off = o1;
+        a.out100_off = o100;
+        a.bin_off = bins;
+        a.tile0 = (uint32_t)tiles;
+        const uint64_t n100 = (nk + 99) / 100;
+        r->nrows100.push_back(n100);
+        o1 += (nk * nbytes + 15) & ~15ull;
+        o100 += n100 * nbytes;
+        bins += a.nbins;
+        const uint64_t nt = (nk + ANCHOR_TILE - 1) / ANCHOR_TILE;
+        for (uint64_t i = 0; i < nt; ++i) tile_contig.push_back(c);
+        tiles += nt;
+        r->ad.push_back(a);
+    }
+    if (tiles > 0x7FFFFFFFull) {
+        delete r;
+        return fail(PG_E_INVALID, "too many tiles in one launch");
+    }
+    r->ntiles = (uint32_t)tiles;
+    r->out1_bytes = o1;
+    r->out100_bytes = o100;
+    r->total_bins = bins;
+    hipStream_t st = t->ctx->stream;
+    hipError_t e;
+    if ((e = hipMalloc(reinterpret_cast<void **>(&r->d_ad), std::max<size_t>(1, r->ad.size()) * sizeof(AnchorDesc))) == hipSuccess &&
+        (e = hipMalloc(reinterpret_cast<void **>(&r->d_tile_contig), std::max<size_t>(1, tile_contig.size()) * 4)) == hipSuccess &&
+        (e = hipMalloc(reinterpret_cast<void **>(&r->d_out1), std::max<uint64_t>(16, o1))) == hipSuccess &&
+        (e = hipMalloc(reinterpret_cast<void **>(&r->d_out100), std::max<uint64_t>(16, o100))) == hipSuccess &&
+        (e = hipMalloc(reinterpret_cast<void **>(&r->d_bins), std::max<uint64_t>(1, bins) * (N + 1) * 4)) == hipSuccess &&
+        (e = hipMalloc(reinterpret_cast<void **>(&r->d_colsums), (size_t)N * 8)) == hipSuccess) {
+        if (!r->ad.empty())
+            e = hipMemcpyAsync(r->d_ad, r->ad.data(), r->ad.size() * sizeof(AnchorDesc), hipMemcpyHostToDevice, st);
+        if (e == hipSuccess && !tile_contig.empty())
+            e = hipMemcpyAsync(r->d_tile_contig, tile_contig.data(), tile_contig.size() * 4, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+    }
+    if (e != hipSuccess) {
+        pg_result_destroy(r);
+        return fail(PG_E_HIP, "result allocation failed: %s", hipGetErrorString(e));
+    }
+    *out = r;
+    return PG_OK;
+}
+
+extern "C" int pg_result_destroy(pg_result *r) {
+    if (!r) return PG_OK;
+    hipSetDevice(r->tbl->ctx->device);
+    hipStreamSynchronize(r->tbl->ctx->stream);
+    hipFree(r->d_ad);
+    hipFree(r->d_tile_contig);
+    hipFree(r->d_out1);
+    hipFree(r->d_out100);
+    hipFree(r->d_bins);
+    hipFree(r->d_colsums);
+    delete r;
+    return PG_OK;
+}
+
+extern "C" int pg_anchor_run(pg_result *r) {
+    if (!r) return fail(PG_E_INVALID, "result is NULL");
+    pg_table *t = r->tbl;
+    if (int e = use_device(t->ctx)) return e;
+    hipStream_t st = t->ctx->stream;
+    const uint32_t N = t->ngenomes;
+    HIP_TRY(hipMemsetAsync(r->d_bins, 0, std::max<uint64_t>(1, r->total_bins) * (N + 1) * 4, st));
+    HIP_TRY(hipMemsetAsync(r->d_colsums, 0, (size_t)N * 8, st));
+    TableDesc T = make_desc(t);
+    HIP_TRY(launch_anchor(st, T, r->seqs->d_seqw, r->seqs->d_nmw, r->seqs->d_has_n, r->seqs->d_desc, r->d_ad,
+                          r->d_tile_contig, r->ntiles, r->d_out1, r->d_out100, r->d_bins, r->d_colsums,
+                          r->flags));
+    return PG_OK;
+}
+
+extern "C" int pg_result_contig_info(const pg_result *r, uint32_t idx, uint64_t *nkmers, uint64_t *nrows100,
+                                     uint32_t *nbins, uint32_t *binlen) {
+    if (!r) return fail(PG_E_INVALID, "result is NULL");
+    if (idx >= r->ad.size()) return fail(PG_E_INVALID, "contig %u out of range", idx);
+    if (nkmers) *nkmers = r->ad[idx].nkmers;
+    if (nrows100) *nrows100 = r->nrows100[idx];
+    if (nbins) *nbins = r->ad[idx].nbins;
+    if (binlen) *binlen = r->ad[idx].binlen;
+    return PG_OK;
+}
+
+extern "C" int pg_result_download(pg_result *r, uint32_t idx, uint8_t *bitmap1, uint8_t *bitmap100, uint32_t *bins) {
+    if (!r) return fail(PG_E_INVALID, "result is NULL");
+    if (idx >= r->ad.size()) return fail(PG_E_INVALID, "contig %u out of range", idx);
+    if (int e = use_device(r->tbl->ctx)) return e;
+    hipStream_t st = r->tbl->ctx->stream;
+    const AnchorDesc &a = r->ad[idx];
+    const uint32_t N = r->tbl->ngenomes, nbytes = (N + 7) / 8;
+    if (bitmap1 && a.nkmers)
+        HIP_TRY(hipMemcpyAsync(bitmap1, r->d_out1 + a.out_off, (uint64_t)a.nkmers * nbytes, hipMemcpyDeviceToHost, st));
+    if (bitmap100 && r->nrows100[idx])
+        HIP_TRY(hipMemcpyAsync(bitmap100, r->d_out100 + a.out100_off, r->nrows100[idx] * nbytes, hipMemcpyDeviceToHost, st));
+    if (bins && a.nbins)
+        HIP_TRY(hipMemcpyAsync(bins, r->d_bins + a.bin_off * (N + 1), (uint64_t)a.nbins * (N + 1) * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return PG_OK;
+}
+
+extern "C" int pg_result_colsums(pg_result *r, uint64_t *colsums) {
+    if (!r || !colsums) return fail(PG_E_INVALID, "pg_result_colsums: NULL argument");
+    if (!(r->flags & PG_ANCHOR_COLSUMS)) return fail(PG_E_INVALID, "result was created without PG_ANCHOR_COLSUMS");
+    if (int e = use_device(r->tbl->ctx)) return e;
+    hipStream_t st = r->tbl->ctx->stream;
+    HIP_TRY(hipMemcpyAsync(colsums, r->d_colsums, (size_t)r->tbl->ngenomes * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return PG_OK;
+}
+
+extern "C" int pg_result_device_ptrs(pg_result *r, void **d1, uint64_t *b1, void **d100, uint64_t *b100) {
+    if (!r) return fail(PG_E_INVALID, "result is NULL");
+    if (d1) *d1 = r->d_out1;
+    if (b1) *b1 = r->out1_bytes;
+    if (d100) *d100 = r->d_out100;
+    if (b100) *b100 = r->out100_bytes;
+    return PG_OK;
+}
+
+extern "C" int pg_anchor_contig(pg_table *t, const char *ascii, uint64_t len, uint8_t *bitmap1, uint8_t *bitmap100,
+                                uint32_t *bins, uint64_t *colsums, uint64_t *nkmers) {
+    if (!t || (len && !ascii)) return fail(PG_E_INVALID, "pg_anchor_contig: NULL argument");
+    if (nkmers) *nkmers = len >= (uint64_t)t->k ? len - t->k + 1 : 0;
+    if (colsums) memset(colsums, 0, (size_t)t->ngenomes * 8);
+    if (len < (uint64_t)t->k) return PG_OK;
+    pg_seqset *sq = nullptr;
+    pg_result *res = nullptr;
+    int rc = pg_seqset_create(t->ctx, 1, &len, &sq);
+    if (!rc) rc = pg_seqset_load_host(sq, 0, ascii, len);
+    if (!rc) rc = pg_result_create(t, sq, colsums ? PG_ANCHOR_COLSUMS : 0, &res);
+    if (!rc) rc = pg_anchor_run(res);
+    if (!rc) rc = pg_result_download(res, 0, bitmap1, bitmap100, bins);
+    if (!rc && colsums) rc = pg_result_colsums(res, colsums);
+    pg_result_destroy(res);
+    pg_seqset_destroy(sq);
+    return rc;
+}
+
+extern "C" int pg_counters_for_read(pg_table *t, int db_idx, const char *ascii, uint64_t len, uint32_t *out) {
+    if (!t || (len && !ascii)) return fail(PG_E_INVALID, "pg_counters_for_read: NULL argument");
+    if (db_idx < 0 || db_idx >= t->ndbs) return fail(PG_E_INVALID, "db index %d out of range (0..%d)", db_idx, t->ndbs - 1);
+    if (len < (uint64_t)t->k) return PG_OK;
+    if (!out) return fail(PG_E_INVALID, "pg_counters_for_read: out is NULL");
+    const uint64_t nk = len - t->k + 1;
+    pg_seqset *sq = nullptr;
+    int rc = pg_seqset_create(t->ctx, 1, &len, &sq);
+    if (!rc) rc = pg_seqset_load_host(sq, 0, ascii, len);
+    uint32_t *d_out = nullptr;
+    if (!rc && hipMalloc(reinterpret_cast<void **>(&d_out), nk * 4) != hipSuccess) rc = fail(PG_E_HIP, "hipMalloc failed");
+    if (!rc) {
+        hipStream_t st = t->ctx->stream;
+        const int si = db_idx / 2, w = db_idx % 2;
+        if (launch_counters(st, t->subs[si].d, w, t->k, sq->d_seqw, sq->d_nmw, sq->d_has_n, nk, d_out) != hipSuccess ||
+            hipMemcpyAsync(out, d_out, nk * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipStreamSynchronize(st) != hipSuccess)
+            rc = fail(PG_E_HIP, "counters kernel failed: %s", hipGetErrorString(hipGetLastError()));
+    }
+    if (d_out) hipFree(d_out);
+    pg_seqset_destroy(sq);
+    return rc;
+}

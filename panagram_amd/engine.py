@@ -1,0 +1,250 @@
+"""Thin object layer over the C-ABI: Context, PanTable, SeqSet, AnchorResult, BgzfWriter.
+
+All compute happens in libpanagram_hip.so on the GPU; this file moves pointers.
+numpy arrays are the host buffers the ABI asks the caller to own.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+from ._lib import PG_ANCHOR_COLSUMS, PanagramHipError, check  # noqa: F401
+
+
+def _ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _bytes_view(seq) -> np.ndarray:
+    """bytes / bytearray / str / uint8 ndarray -> contiguous uint8 ndarray (no copy when possible)."""
+    if isinstance(seq, str):
+        seq = seq.encode("latin-1")
+    if isinstance(seq, np.ndarray):
+        return np.ascontiguousarray(seq, dtype=np.uint8)
+    return np.frombuffer(seq, dtype=np.uint8)
+
+
+class Context:
+    """One per GPU / per rank."""
+
+    def __init__(self, device: int = 0):
+        self._lib = _lib.load()
+        h = C.c_void_p()
+        check(self._lib.pg_ctx_create(device, C.byref(h)))
+        self._h = h
+        self.device = device
+
+    def set_stream(self, hip_stream: Optional[int]) -> None:
+        check(self._lib.pg_ctx_set_stream(self._h, C.c_void_p(hip_stream or 0)))
+
+    def synchronize(self) -> None:
+        check(self._lib.pg_ctx_synchronize(self._h))
+
+    def close(self) -> None:
+        if self._h:
+            self._lib.pg_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class SeqSet:
+    """The contigs of one FASTA, 2-bit packed in HBM."""
+
+    def __init__(self, ctx: Context, lens: Sequence[int]):
+        self.ctx = ctx
+        self._lib = ctx._lib
+        self.lens = np.asarray(lens, dtype=np.uint64)
+        h = C.c_void_p()
+        check(self._lib.pg_seqset_create(ctx._h, len(self.lens), _ptr(self.lens), C.byref(h)))
+        self._h = h
+
+    @classmethod
+    def from_host(cls, ctx: Context, seqs: Sequence) -> "SeqSet":
+        views = [_bytes_view(s) for s in seqs]
+        ss = cls(ctx, [len(v) for v in views])
+        for i, v in enumerate(views):
+            ss.load_host(i, v)
+        return ss
+
+    def load_host(self, idx: int, seq) -> None:
+        v = _bytes_view(seq)
+        check(self._lib.pg_seqset_load_host(self._h, idx, _ptr(v), len(v)))
+
+    def load_dev(self, idx: int, dev_ptr: int, length: int) -> None:
+        check(self._lib.pg_seqset_load_dev(self._h, idx, C.c_void_p(dev_ptr), length))
+
+    def total_kmers(self, k: int) -> int:
+        return int(self._lib.pg_seqset_total_kmers(self._h, k))
+
+    def close(self) -> None:
+        if self._h:
+            self._lib.pg_seqset_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class PanTable:
+    """GPU-resident k-mer -> genome-mask table (replaces kmc/bitvec{i})."""
+
+    def __init__(self, ctx: Context, k: int, ngenomes: int, expected_keys: int = 0):
+        self.ctx = ctx
+        self._lib = ctx._lib
+        self.k, self.ngenomes = k, ngenomes
+        self.nbytes = (ngenomes + 7) // 8
+        self.ndbs = (ngenomes + 31) // 32
+        h = C.c_void_p()
+        check(self._lib.pg_table_create(ctx._h, k, ngenomes, expected_keys, C.byref(h)))
+        self._h = h
+
+    def insert_seqset(self, genome_idx: int, seqs: SeqSet) -> None:
+        check(self._lib.pg_table_insert_seqset(self._h, genome_idx, seqs._h))
+
+    def insert_keys(self, db_idx: int, keys: np.ndarray, counters: np.ndarray) -> None:
+        keys = np.ascontiguousarray(keys, np.uint64)
+        counters = np.ascontiguousarray(counters, np.uint32)
+        if len(keys) != len(counters):
+            raise ValueError("keys and counters differ in length")
+        check(self._lib.pg_table_insert_keys(self._h, db_idx, _ptr(keys), _ptr(counters), len(keys)))
+
+    def load_kmc1(self, db_idx: int, pre: bytes, suf: bytes) -> None:
+        check(self._lib.pg_table_load_kmc1(self._h, db_idx, pre, len(pre), suf, len(suf)))
+
+    def stats(self) -> dict:
+        v = [C.c_uint64() for _ in range(4)]
+        check(self._lib.pg_table_stats(self._h, *[C.byref(x) for x in v]))
+        return dict(nkeys=v[0].value, nslots=v[1].value, nbuckets=v[2].value, bytes=v[3].value)
+
+    def rehash(self, keys_per_bucket: float) -> None:
+        check(self._lib.pg_table_rehash(self._h, keys_per_bucket))
+
+    def export(self, db_idx: int) -> Tuple[np.ndarray, np.ndarray]:
+        n = C.c_uint64()
+        check(self._lib.pg_table_export(self._h, db_idx, None, None, 0, C.byref(n)))
+        keys = np.empty(n.value, np.uint64)
+        vals = np.empty(n.value, np.uint32)
+        if n.value:
+            check(self._lib.pg_table_export(self._h, db_idx, _ptr(keys), _ptr(vals), n.value, C.byref(n)))
+        return keys, vals
+
+    def counters_for_read(self, db_idx: int, seq) -> np.ndarray:
+        """GetCountersForRead equivalent (cpp/anchor.cpp:148, index.py:934-935)."""
+        v = _bytes_view(seq)
+        n = max(0, len(v) - self.k + 1)
+        out = np.zeros(n, np.uint32)
+        check(self._lib.pg_counters_for_read(self._h, db_idx, _ptr(v), len(v), _ptr(out)))
+        return out
+
+    def anchor_contig(self, seq, colsums: bool = True):
+        """One-shot: rows[nkmers,nbytes], rows100, bins[nbins,N+1], colsums[N] or None."""
+        v = _bytes_view(seq)
+        nk = max(0, len(v) - self.k + 1)
+        binlen = 200000
+        if nk // binlen < 100:
+            binlen = nk // 100
+        binlen = max(binlen, 1)
+        nbins = (nk + binlen - 1) // binlen
+        rows = np.zeros((nk, self.nbytes), np.uint8)
+        rows100 = np.zeros(((nk + 99) // 100, self.nbytes), np.uint8)
+        bins = np.zeros((nbins, self.ngenomes + 1), np.uint32)
+        cs = np.zeros(self.ngenomes, np.uint64) if colsums else None
+        nkm = C.c_uint64()
+        check(self._lib.pg_anchor_contig(self._h, _ptr(v), len(v), _ptr(rows), _ptr(rows100), _ptr(bins),
+                                         _ptr(cs), C.byref(nkm)))
+        assert nkm.value == nk
+        return rows, rows100, bins, cs
+
+    def close(self) -> None:
+        if self._h:
+            self._lib.pg_table_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class AnchorResult:
+    """Device-resident outputs of anchoring one SeqSet against one PanTable."""
+
+    def __init__(self, table: PanTable, seqs: SeqSet, colsums: bool = True):
+        self.table, self.seqs = table, seqs
+        self._lib = table._lib
+        h = C.c_void_p()
+        self.flags = PG_ANCHOR_COLSUMS if colsums else 0
+        check(self._lib.pg_result_create(table._h, seqs._h, self.flags, C.byref(h)))
+        self._h = h
+
+    def run(self) -> None:
+        """Enqueue the anchor kernels (asynchronous)."""
+        check(self._lib.pg_anchor_run(self._h))
+
+    def contig_info(self, idx: int) -> dict:
+        nk, n100 = C.c_uint64(), C.c_uint64()
+        nb, bl = C.c_uint32(), C.c_uint32()
+        check(self._lib.pg_result_contig_info(self._h, idx, C.byref(nk), C.byref(n100), C.byref(nb), C.byref(bl)))
+        return dict(nkmers=nk.value, nrows100=n100.value, nbins=nb.value, binlen=bl.value)
+
+    def download(self, idx: int, want_bitmap1: bool = True):
+        info = self.contig_info(idx)
+        nb = self.table.nbytes
+        rows = np.empty((info["nkmers"], nb), np.uint8) if want_bitmap1 else None
+        rows100 = np.empty((info["nrows100"], nb), np.uint8)
+        bins = np.empty((info["nbins"], self.table.ngenomes + 1), np.uint32)
+        check(self._lib.pg_result_download(self._h, idx, _ptr(rows), _ptr(rows100), _ptr(bins)))
+        return rows, rows100, bins, info
+
+    def colsums(self) -> np.ndarray:
+        cs = np.zeros(self.table.ngenomes, np.uint64)
+        check(self._lib.pg_result_colsums(self._h, _ptr(cs)))
+        return cs
+
+    def device_ptrs(self):
+        d1, d100 = C.c_void_p(), C.c_void_p()
+        b1, b100 = C.c_uint64(), C.c_uint64()
+        check(self._lib.pg_result_device_ptrs(self._h, C.byref(d1), C.byref(b1), C.byref(d100), C.byref(b100)))
+        return (d1.value, b1.value), (d100.value, b100.value)
+
+    def close(self) -> None:
+        if self._h:
+            self._lib.pg_result_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class BgzfWriter:
+    """BGZF + .gzi writer (replaces htslib bgzf_* / bgzip.BGZipWriter + `bgzip -rI`)."""
+
+    def __init__(self, path: str, level: int = 6, threads: int = 1):
+        self._lib = _lib.load()
+        h = C.c_void_p()
+        check(self._lib.pg_bgzf_open(path.encode(), level, threads, C.byref(h)))
+        self._h = h
+
+    def write(self, data) -> None:
+        v = _bytes_view(data)
+        check(self._lib.pg_bgzf_write(self._h, _ptr(v), v.size))
+
+    def close(self, gzi_path: Optional[str] = None) -> None:
+        if self._h:
+            h, self._h = self._h, None
+            check(self._lib.pg_bgzf_close(h, gzi_path.encode() if gzi_path else None))

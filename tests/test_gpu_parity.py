@@ -1,0 +1,216 @@
+"""GPU parity tests: the HIP path (through the C-ABI) vs the golden vectors the reference
+binary produced and vs the oracle on seeded inputs.  Bit-exact everywhere (integer work)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _table_from_dbs(ctx, fx, via_kmc1_files, tmp_path):
+    from panagram_amd import engine
+    n, k = int(fx["ngenomes"]), int(fx["k"])
+    tbl = engine.PanTable(ctx, k, n)
+    for i, (keys, masks) in enumerate(H.case_dbs(fx)):
+        if via_kmc1_files:
+            p = str(tmp_path / f"bitvec{i}")
+            po.write_kmc1(p, keys, masks, k, min_count=int(fx["min_count"]), max_count=int(fx["max_count"]))
+            tbl.load_kmc1(i, open(p + ".kmc_pre", "rb").read(), open(p + ".kmc_suf", "rb").read())
+        else:
+            sel = (masks >= int(fx["min_count"])) & (masks <= int(fx["max_count"]))
+            tbl.insert_keys(i, keys[sel], masks[sel])
+    return tbl
+
+
+def _anchor_fasta_gpu(ctx, tbl, fasta_bytes, colsums=True):
+    """Anchor all contigs of a FASTA in one launch; returns payloads + texts like run_anchor."""
+    from panagram_amd import engine
+    recs = po.parse_fasta_cpp(fasta_bytes)  # test-side parse; the product parser is tested elsewhere
+    ss = engine.SeqSet.from_host(ctx, [s for _, s in recs])
+    res = engine.AnchorResult(tbl, ss, colsums=colsums)
+    res.run()
+    b1, b100, bins, binlens, sizes = [], [], [], [], []
+    for i in range(len(recs)):
+        rows, rows100, bn, info = res.download(i)
+        b1.append(rows.tobytes())
+        b100.append(rows100.tobytes())
+        bins.append(bn)
+        binlens.append(info["binlen"])
+        sizes.append(info["nkmers"])
+    cs = res.colsums() if colsums else None
+    chrs = "name\tid\tsize\tgene_count\n" + "".join(
+        f"{nm}\t{i}\t{sz}\t0\n" for i, ((nm, _), sz) in enumerate(zip(recs, sizes)))
+    out = dict(bitmap1=b"".join(b1), bitmap100=b"".join(b100),
+               bins_tsv=H.bins_text(tbl.ngenomes, bins, binlens), chrs_tsv=chrs, colsums=cs)
+    res.close()
+    ss.close()
+    return out
+
+
+@pytest.mark.parametrize("via_files", [False, True])
+@pytest.mark.parametrize("name", H.payload_cases())
+def test_anchor_matches_reference_golden(ctx, name, via_files, tmp_path):
+    fx = H.load_case(name)
+    n, k = int(fx["ngenomes"]), int(fx["k"])
+    tbl = _table_from_dbs(ctx, fx, via_files, tmp_path)
+    dbs = H.case_dbs(fx)
+    for g in fx["anchors"]:
+        fa = fx[f"fasta_{g}"].tobytes()
+        got = _anchor_fasta_gpu(ctx, tbl, fa)
+        assert got["bitmap1"] == fx[f"a{g}_bitmap1"].tobytes(), "bitmap.1 payload differs from the reference"
+        assert got["bitmap100"] == fx[f"a{g}_bitmap100"].tobytes(), "bitmap.100 payload differs"
+        assert got["bins_tsv"].encode() == fx[f"a{g}_bitsum.bins.tsv"].tobytes()
+        assert got["chrs_tsv"].encode() == fx[f"a{g}_chrs.tsv"].tobytes()
+        ora = po.anchor_fasta(dbs, fa, k, n, int(fx["min_count"]), int(fx["max_count"]))
+        assert np.array_equal(got["colsums"].astype(np.int64), ora["colsums"])
+    tbl.close()
+
+
+@pytest.mark.parametrize("name", H.payload_cases())
+def test_gpu_set_construction_equals_kmc_semantics(ctx, name):
+    """insert_seqset (replaces kmc + kmc_tools) -> export == the fixture's DB contents."""
+    from panagram_amd import engine
+    fx = H.load_case(name)
+    if int(fx["min_count"]) != 1:
+        pytest.skip("header filter case")
+    n, k = int(fx["ngenomes"]), int(fx["k"])
+    tbl = engine.PanTable(ctx, k, n)
+    for g in range(n):
+        recs = po.parse_fasta_cpp(fx[f"fasta_{g}"].tobytes())
+        ss = engine.SeqSet.from_host(ctx, [s for _, s in recs])
+        tbl.insert_seqset(g, ss)
+        ss.close()
+    total = 0
+    for i, (fk, fm) in enumerate(H.case_dbs(fx)):
+        keys, vals = tbl.export(i)
+        o = np.argsort(keys)
+        assert np.array_equal(keys[o], fk) and np.array_equal(vals[o], fm)
+        total += len(fk)
+    st = tbl.stats()
+    assert st["nkeys"] <= total and st["nkeys"] >= max(len(k_) for k_, _ in H.case_dbs(fx))
+    # after a re-hash to a tighter table the contents are unchanged
+    tbl.rehash(3.0)
+    for i, (fk, fm) in enumerate(H.case_dbs(fx)):
+        keys, vals = tbl.export(i)
+        o = np.argsort(keys)
+        assert np.array_equal(keys[o], fk) and np.array_equal(vals[o], fm)
+    tbl.close()
+
+
+@pytest.mark.parametrize("name", ["n2_k21", "n40_k31", "n33_k16", "n3_k32", "n65_k21"])
+def test_counters_for_read_equals_oracle(ctx, name, tmp_path):
+    """the literal GetCountersForRead equivalent, per 32-genome group"""
+    fx = H.load_case(name)
+    k = int(fx["k"])
+    tbl = _table_from_dbs(ctx, fx, False, tmp_path)
+    dbs = H.case_dbs(fx)
+    g = int(fx["anchors"][0])
+    for _, seq in po.parse_fasta_cpp(fx[f"fasta_{g}"].tobytes()):
+        for d in range(len(dbs)):
+            want = po.counters_for_read(dbs[d], seq, k)
+            got = tbl.counters_for_read(d, seq)
+            assert np.array_equal(got, want)
+    # shorter than k: no k-mers, no error
+    assert len(tbl.counters_for_read(0, b"ACG")) == 0
+    tbl.close()
+
+
+@pytest.mark.parametrize("name", H.seed_cases())
+def test_seeded_large_cases_sha256(ctx, name):
+    """config-1 shape (2 x 1 Mb) and the 20 Mb / 102-bin case: tables built ON the GPU from the
+    sequences, payload sha256 + TSV texts must equal what the reference binary produced."""
+    from panagram_amd import engine
+    fx = H.load_case(name)
+    n, k = int(fx["ngenomes"]), int(fx["k"])
+    genomes, fastas = H.regen_seed_case(fx)
+    tbl = engine.PanTable(ctx, k, n)
+    for g in range(n):
+        ss = engine.SeqSet.from_host(ctx, genomes[g])
+        tbl.insert_seqset(g, ss)
+        ss.close()
+    for g in fx["anchors"]:
+        got = _anchor_fasta_gpu(ctx, tbl, fastas[g], colsums=False)
+        assert len(got["bitmap1"]) == int(fx[f"a{g}_len_1"])
+        assert H.sha(got["bitmap1"]) == str(fx[f"a{g}_sha_1"])
+        assert H.sha(got["bitmap100"]) == str(fx[f"a{g}_sha_100"])
+        assert got["bins_tsv"].encode() == fx[f"a{g}_bitsum.bins.tsv"].tobytes()
+        assert got["chrs_tsv"].encode() == fx[f"a{g}_chrs.tsv"].tobytes()
+    # same answers from a much denser table (70 % slot load: overflow chains + retry queue)
+    tbl.rehash(3.5)
+    g = int(fx["anchors"][0])
+    got = _anchor_fasta_gpu(ctx, tbl, fastas[g], colsums=False)
+    assert H.sha(got["bitmap1"]) == str(fx[f"a{g}_sha_1"])
+    assert got["bins_tsv"].encode() == fx[f"a{g}_bitsum.bins.tsv"].tobytes()
+    tbl.close()
+
+
+def test_one_shot_contig_and_edge_cases(ctx):
+    from panagram_amd import engine
+    rng = np.random.default_rng(3)
+    k, n = 21, 5
+    gen = po.synth_genomes(n, [5000], 0.05, 99)
+    genomes = [[po.codes_to_ascii(c) for c in g] for g in gen]
+    dbs = po.build_bitvec_dbs(genomes, k)
+    tbl = engine.PanTable(ctx, k, n)
+    tbl.insert_keys(0, *dbs[0])
+    seq = bytearray(genomes[2][0])
+    seq[100:140] = b"N" * 40
+    seq[3000:3200] = bytes(seq[3000:3200]).lower()
+    seq = bytes(seq)
+    rows, rows100, bins, cs = tbl.anchor_contig(seq)
+    o_rows, o_rows100, o_bins, _, o_cs = po.anchor_contig(dbs, seq, k, n)
+    assert np.array_equal(rows, o_rows) and np.array_equal(rows100, o_rows100)
+    assert np.array_equal(bins.astype(np.int64), o_bins) and np.array_equal(cs.astype(np.int64), o_cs)
+    # contig shorter than k: zero k-mers, no failure (reference underflows; documented)
+    r = tbl.anchor_contig(b"ACGT")
+    assert r[0].shape == (0, 1)
+    # exactly k bases: one k-mer
+    r = tbl.anchor_contig(genomes[0][0][:k])
+    assert r[0].shape == (1, 1) and r[0][0, 0] & 1
+    # all-N contig: all zero rows
+    r = tbl.anchor_contig(b"N" * 300)
+    assert not r[0].any() and r[2][:, 0].sum() == 300 - k + 1
+    # tile boundary sizes (TILE = 2048 positions)
+    for L in (2048 + k - 1, 2049 + k - 1, 4096 + k - 1 - 1):
+        s = genomes[1][0][:L]
+        got = tbl.anchor_contig(s)
+        want = po.anchor_contig(dbs, s, k, n)
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[2].astype(np.int64), want[2])
+    tbl.close()
+
+
+def test_errors_are_loud(ctx):
+    from panagram_amd import engine
+    with pytest.raises(engine.PanagramHipError):
+        engine.PanTable(ctx, 33, 2)  # k > 32
+    tbl = engine.PanTable(ctx, 21, 2)
+    with pytest.raises(engine.PanagramHipError):
+        tbl.load_kmc1(0, b"garbage-not-a-kmc-file" * 8, b"KMCSKMCS")
+    with pytest.raises(engine.PanagramHipError):
+        tbl.insert_keys(3, np.zeros(1, np.uint64), np.ones(1, np.uint32))  # db index out of range
+    tbl.close()
+
+
+def test_chain_overflow_and_growth(ctx):
+    """Many keys into a table created tiny: growth + bucket-overflow chains stay exact."""
+    from panagram_amd import engine
+    rng = np.random.default_rng(17)
+    k, n = 31, 64
+    keys = np.unique(rng.integers(0, 1 << 62, 400000, dtype=np.uint64))
+    seqs = []
+    m0 = rng.integers(1, 1 << 32, len(keys), dtype=np.uint64).astype(np.uint32)
+    m1 = rng.integers(0, 1 << 32, len(keys), dtype=np.uint64).astype(np.uint32)
+    tbl = engine.PanTable(ctx, k, n, expected_keys=1000)
+    tbl.insert_keys(0, keys, m0)
+    tbl.insert_keys(1, keys[::2], m1[::2])
+    tbl.rehash(3.1)  # dense: ~78 % of the 4-slot buckets' capacity -> long chains
+    for d, (kk, mm) in enumerate([(keys, m0), (keys[::2], m1[::2])]):
+        ek, ev = tbl.export(d)
+        o = np.argsort(ek)
+        nz = mm != 0
+        assert np.array_equal(ek[o], kk[nz]) and np.array_equal(ev[o], mm[nz])
+    tbl.close()
