@@ -53,9 +53,10 @@ const char *pg_version(void);
  * gfx950-class device is visible: there is NO CPU fallback in this library. */
 int pg_ctx_create(int device_id, pg_ctx **out);
 int pg_ctx_destroy(pg_ctx *ctx);
-/* adopt an external hipStream_t (e.g. torch.cuda.current_stream().cuda_stream);
- * NULL restores the context's own stream. */
-int pg_ctx_set_stream(pg_ctx *ctx, void *hip_stream);
+/* adopt an external hipStream_t (e.g. torch.cuda.current_stream().cuda_stream; NULL is
+ * HIP's legacy default stream, which is what torch's default stream is); use_own != 0
+ * restores the context's own non-blocking stream instead. */
+int pg_ctx_set_stream(pg_ctx *ctx, void *hip_stream, int use_own);
 int pg_ctx_synchronize(pg_ctx *ctx);
 
 /* ---- pan-kmer table: replaces the merged KMC "bitvec" databases --------

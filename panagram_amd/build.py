@@ -20,15 +20,16 @@ def _stale() -> bool:
     return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
-    """Compile the HIP extension; returns the path of the shared library."""
-    if not force and not _stale():
+def build(force: bool = False, verbose: bool = True, defines=()) -> str:
+    """Compile the HIP extension; returns the path of the shared library.
+    ``defines`` (e.g. ["PG_ANCHOR_TILE=1024"]) override kernel tuning constants."""
+    if not force and not defines and not _stale():
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build libpanagram_hip.so")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-Wall", "-Wno-unused-function", "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES] + ["-lz", "-lpthread"]
+           "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result", "-o", LIB] + [f"-D{d}" for d in defines] + [os.path.join(CSRC, s) for s in SOURCES] + ["-lz", "-lpthread"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)
@@ -36,4 +37,4 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    build(force="--force" in sys.argv, defines=[a[2:] for a in sys.argv[1:] if a.startswith("-D")])

@@ -96,8 +96,8 @@ struct pg_result {
 };
 
 static constexpr uint32_t MAX_PROBE = 64;
-static constexpr double GROW_AT = 0.60;     // grow when keys > GROW_AT * slots
-static constexpr double TARGET_LOAD = 0.40; // load right after growing
+static constexpr double GROW_AT = 0.65;     // grow when keys > GROW_AT * slots
+static constexpr double TARGET_LOAD = 0.45; // load right after growing
 static constexpr double HARD_LOAD = 0.85;   // worst-case guard before a batch
 
 static int use_device(const pg_ctx *c) {
@@ -137,9 +137,9 @@ extern "C" int pg_ctx_destroy(pg_ctx *c) {
     return PG_OK;
 }
 
-extern "C" int pg_ctx_set_stream(pg_ctx *c, void *s) {
+extern "C" int pg_ctx_set_stream(pg_ctx *c, void *s, int use_own) {
     if (!c) return fail(PG_E_INVALID, "ctx is NULL");
-    c->stream = s ? reinterpret_cast<hipStream_t>(s) : c->own_stream;
+    c->stream = use_own ? c->own_stream : reinterpret_cast<hipStream_t>(s);
     return PG_OK;
 }
 

@@ -1,9 +1,10 @@
 // pg_device.h — device-side building blocks shared by the gfx950 kernels.
 //
 // Table layout (one sub-table covers W = 1 or 2 consecutive 32-genome groups):
-//   bucket = 64 bytes, 64-byte aligned = one HBM fetch per probe.
-//   W == 1:  u64 key[5] | u32 mask[5] | u32 pad            (5 slots)
-//   W == 2:  4 x { u64 key ; u32 mask0 ; u32 mask1 }       (4 slots)
+//   bucket = 64 bytes, 64-byte aligned = one HBM fetch per probe
+//          = 4 slots x { u64 key ; u32 mask0 ; u32 mask1 }   (mask1 unused when W == 1)
+//   so that the four lanes of a quad each hold ONE complete slot of the bucket after a
+//   single 16-byte load: the match is lane-local, no cross-lane traffic for the masks.
 //   EMPTY key = ~0 (never a canonical k-mer for k <= 32: the all-T k-mer's
 //   reverse complement is 0).  Keys only ever go EMPTY -> key, masks only gain
 //   bits, so inserts need one 64-bit CAS + one 32-bit OR and no locks.
@@ -34,11 +35,10 @@ struct TableDesc {
     uint32_t ngenomes;
 };
 
-__host__ __device__ __forceinline__ int slots_per_bucket(uint32_t W) { return W == 1 ? 5 : 4; }
-__host__ __device__ __forceinline__ uint32_t key_off(uint32_t W, int s) { return W == 1 ? 8u * s : 16u * s; }
-__host__ __device__ __forceinline__ uint32_t mask_off(uint32_t W, int s, int w) {
-    return W == 1 ? 40u + 4u * s : 16u * s + 8u + 4u * w;
-}
+constexpr int SLOTS = 4;
+__host__ __device__ __forceinline__ int slots_per_bucket(uint32_t) { return SLOTS; }
+__host__ __device__ __forceinline__ uint32_t key_off(uint32_t, int s) { return 16u * s; }
+__host__ __device__ __forceinline__ uint32_t mask_off(uint32_t, int s, int w) { return 16u * s + 8u + 4u * w; }
 
 // murmur3 finaliser: a bijection on u64, so distinct keys never alias before the
 // range reduction.
@@ -112,51 +112,19 @@ __device__ __forceinline__ uint32_t quad_or(uint32_t v) {
     return v;
 }
 
-// Cooperative match of one 64-byte bucket held 16 bytes per lane of a quad.
-// j = lane index in the quad.  Returns true when `key` was found (masks in m0,m1);
-// `full` = no EMPTY slot in the bucket.  All four lanes return the same values.
-template <int W>
-__device__ __forceinline__ bool quad_match(const uint4 v, int j, uint64_t key, uint32_t &m0,
-                                           uint32_t &m1, bool &full) {
-    if (W == 1) {
-        uint64_t ka = (uint64_t)v.x | ((uint64_t)v.y << 32);
-        uint64_t kb = (uint64_t)v.z | ((uint64_t)v.w << 32);
-        // lane0: key0,key1   lane1: key2,key3   lane2: key4,mask0,mask1   lane3: mask2,mask3,mask4,pad
-        uint32_t hit = 0, emp = 0;  // hit = 1 + slot
-        if (j <= 2) {
-            if (ka == key) hit = (j == 2) ? 5u : 2u * j + 1u;
-            emp |= (ka == EMPTY_KEY);
-        }
-        if (j < 2) {
-            if (kb == key) hit = 2u * j + 2u;
-            emp |= (kb == EMPTY_KEY);
-        }
-        hit = quad_or(hit);  // at most one lane holds a hit
-        emp = quad_or(emp);
-        uint32_t a0 = quad_perm<QP_BC2>(v.z), a1 = quad_perm<QP_BC2>(v.w);
-        uint32_t a2 = quad_perm<QP_BC3>(v.x), a3 = quad_perm<QP_BC3>(v.y), a4 = quad_perm<QP_BC3>(v.z);
-        uint32_t r = 0;
-        r = (hit == 1) ? a0 : r;
-        r = (hit == 2) ? a1 : r;
-        r = (hit == 3) ? a2 : r;
-        r = (hit == 4) ? a3 : r;
-        r = (hit == 5) ? a4 : r;
-        m0 = r;
-        m1 = 0;
-        full = (emp == 0);
-        return hit != 0;
-    } else {
-        uint64_t kk = (uint64_t)v.x | ((uint64_t)v.y << 32);
-        uint32_t hit = (kk == key);
-        uint32_t emp = (kk == EMPTY_KEY);
-        uint32_t r0 = hit ? v.z : 0u, r1 = hit ? v.w : 0u;
-        hit = quad_or(hit);
-        emp = quad_or(emp);
-        m0 = quad_or(r0);
-        m1 = quad_or(r1);
-        full = (emp == 0);
-        return hit != 0;
-    }
+// Cooperative match of one 64-byte bucket held one 16-byte slot per lane of a quad:
+// v = {key.lo, key.hi, mask0, mask1}.  Returns found; masks are quad-uniform.
+__device__ __forceinline__ bool quad_match(const uint4 v, uint64_t key, uint32_t &m0, uint32_t &m1) {
+    const uint64_t kk = (uint64_t)v.x | ((uint64_t)v.y << 32);
+    const bool hit = (kk == key);
+    m0 = quad_or(hit ? v.z : 0u);
+    m1 = quad_or(hit ? v.w : 0u);
+    return quad_or(hit ? 1u : 0u) != 0;
+}
+// no EMPTY slot among the quad's four (only needed on the rare not-found path)
+__device__ __forceinline__ bool quad_full(const uint4 v) {
+    const uint64_t kk = (uint64_t)v.x | ((uint64_t)v.y << 32);
+    return quad_or(kk == EMPTY_KEY ? 1u : 0u) == 0;
 }
 
 // Single-lane lookup (used by the GetCountersForRead kernel, export and rehash).

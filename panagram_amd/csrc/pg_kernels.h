@@ -4,10 +4,16 @@
 
 namespace pg {
 
-constexpr int ANCHOR_TILE = 2048;  // k-mer positions per workgroup
-constexpr int ANCHOR_WG = 256;     // threads per workgroup (4 waves, 64 quads)
-constexpr int ANCHOR_SEQW = 68;    // packed words staged per tile: (2048+31)/32 + spill, 16-byte padded
-constexpr int ANCHOR_RQ = 256;     // LDS retry-queue entries
+#ifndef PG_ANCHOR_TILE
+#define PG_ANCHOR_TILE 1024
+#endif
+#ifndef PG_ANCHOR_UNROLL
+#define PG_ANCHOR_UNROLL 8
+#endif
+constexpr int ANCHOR_TILE = PG_ANCHOR_TILE;      // k-mer positions per workgroup
+constexpr int ANCHOR_UNROLL = PG_ANCHOR_UNROLL;  // independent bucket gathers in flight per lane
+constexpr int ANCHOR_WG = 256;                   // threads per workgroup (4 waves, 64 quads)
+constexpr int ANCHOR_RQ = 256;                   // LDS retry-queue entries
 
 // one packed contig of a seqset (offsets in 32-base words, shared by both planes)
 struct SeqDesc {

@@ -20,16 +20,7 @@ __global__ __launch_bounds__(256) void k_table_init(uint4 *chunks, uint64_t nchu
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (; i < nchunks; i += stride) {
-        uint32_t j = (uint32_t)(i & 3);
-        uint4 v;
-        if (W == 1) {
-            if (j < 2) v = make_uint4(~0u, ~0u, ~0u, ~0u);
-            else if (j == 2) v = make_uint4(~0u, ~0u, 0u, 0u);
-            else v = make_uint4(0u, 0u, 0u, 0u);
-        } else {
-            v = make_uint4(~0u, ~0u, 0u, 0u);
-        }
-        chunks[i] = v;
+        chunks[i] = make_uint4(~0u, ~0u, 0u, 0u);  // {EMPTY key, mask0 = 0, mask1 = 0}
     }
 }
 
@@ -183,103 +174,99 @@ __global__ __launch_bounds__(256) void k_counters(SubTable st, int w, int k, con
 // THE hot kernel.  One workgroup (256 threads = 4 waves = 64 quads) = one tile
 // of TILE consecutive k-mer positions of one contig.
 //   phase 0  packed bases of the tile (+k-1 halo) -> LDS (coalesced, 0.25 B/pos)
-//   phase 1  canonical k-mer of every position -> LDS key tile
+//   phase 1  canonical k-mer + home bucket of every position -> LDS (hashed ONCE)
 //   phase 2  LDS-staged probe batches: a quad fetches ONE 64-byte bucket with
-//            four 16-byte lanes (a wave instruction = 16 whole buckets), UNROLL
-//            independent gathers in flight per lane, DPP quad-permute match;
-//            the rare "bucket full, key absent" case goes to an LDS retry queue
+//            four 16-byte lanes (a wave instruction = 16 whole buckets, every
+//            fetched byte used), UNROLL independent gathers in flight per lane,
+//            lane-local slot match + DPP quad-OR; the rare "bucket full, key
+//            absent" case goes to an LDS retry queue resolved after the batch
 //   phase 3  popcount -> wave-ballot aggregated LDS histogram, column sums by
 //            ballot, rows packed into an LDS byte tile, 1-in-100 rows out,
 //            then coalesced 16-byte stores of the bitmap.1 tile
+// NDBS_C / NBYTES_C: compile-time row shape (0 = runtime, generic path).
 // ---------------------------------------------------------------------------
-constexpr int NQUAD = ANCHOR_WG / 4;
-constexpr int ROUNDS = ANCHOR_TILE / NQUAD;
-constexpr int UNROLL = 8;
-constexpr int PER_THREAD = ANCHOR_TILE / ANCHOR_WG;
+template <int TILE>
+struct Geo {
+    static constexpr int NQUAD = ANCHOR_WG / 4;
+    static constexpr int ROUNDS = TILE / NQUAD;
+    static constexpr int PER_THREAD = TILE / ANCHOR_WG;
+    static constexpr int SEQW = (TILE + 31) / 32 + 3 + ((4 - ((TILE + 31) / 32 + 3) % 4) % 4);  // 16-byte padded
+};
 
-template <int W>
 __device__ __forceinline__ void quad_chase(const SubTable &st, uint64_t key, uint64_t b, int j,
                                            uint32_t &m0, uint32_t &m1) {
     // follow the probe chain from bucket b until the key or a non-full bucket
     for (uint64_t n = 0; n < st.nbuckets; ++n) {
         uint4 v = *reinterpret_cast<const uint4 *>(st.buckets + b * BUCKET_BYTES + j * 16);
-        bool full;
-        if (quad_match<W>(v, j, key, m0, m1, full)) return;
-        if (!full) break;
+        if (quad_match(v, key, m0, m1)) return;
+        if (!quad_full(v)) break;
         b = (b + 1 == st.nbuckets) ? 0 : b + 1;
     }
     m0 = m1 = 0;
 }
 
-template <int W>
-__device__ __forceinline__ void probe_sub(const SubTable st, const uint64_t *keys, uint32_t *res,
-                                          uint32_t ndbs, uint32_t *rq_cnt, uint32_t *rq_pi,
+template <int TILE, int UNROLL>
+__device__ __forceinline__ void probe_sub(const SubTable st, const uint64_t *keys, const uint32_t *bkt,
+                                          uint32_t *res, uint32_t ndbs, uint32_t *rq_cnt, uint32_t *rq_pi,
                                           uint32_t *rq_b, int tid) {
+    using G = Geo<TILE>;
     const int q = tid >> 2, j = tid & 3;
-    if (tid == 0) *rq_cnt = 0;
-    __syncthreads();
-    for (int r0 = 0; r0 < ROUNDS; r0 += UNROLL) {
+    const uint8_t *lane_base = st.buckets + j * 16;
+    const bool two = (st.W == 2);
+    for (int r0 = 0; r0 < G::ROUNDS; r0 += UNROLL) {
         uint4 v[UNROLL];
-        uint64_t key[UNROLL];
-        uint32_t bk[UNROLL];
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
-            const int pi = (r0 + u) * NQUAD + q;
-            key[u] = keys[pi];
-            v[u] = make_uint4(0, 0, 0, 0);
-            bk[u] = 0;
-            if (key[u] != EMPTY_KEY) {
-                uint64_t b = home_bucket(key[u], st.nbuckets);
-                bk[u] = (uint32_t)b;
-                v[u] = *reinterpret_cast<const uint4 *>(st.buckets + b * BUCKET_BYTES + j * 16);
-            }
+            // UNCONDITIONAL load (invalid positions carry bucket 0): a branch here makes the
+            // compiler wait for each gather before issuing the next one
+            const int pi = (r0 + u) * G::NQUAD + q;
+            v[u] = *reinterpret_cast<const uint4 *>(lane_base + (uint64_t)bkt[pi] * BUCKET_BYTES);
         }
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
-            const int pi = (r0 + u) * NQUAD + q;
-            uint32_t m0 = 0, m1 = 0;
-            bool full = false;
-            const bool valid = key[u] != EMPTY_KEY;
-            bool found = quad_match<W>(v[u], j, key[u], m0, m1, full);
-            if (!valid) {
-                m0 = m1 = 0;
-            } else if (!found && full) {
-                uint64_t nb = (uint64_t)bk[u] + 1;
-                if (nb == st.nbuckets) nb = 0;
-                uint32_t idx = 0;
-                if (j == 0) idx = atomicAdd(rq_cnt, 1u);
-                idx = quad_perm<QP_BC0>(idx);
-                if (idx < (uint32_t)ANCHOR_RQ) {
-                    if (j == 0) {
-                        rq_pi[idx] = (uint32_t)pi;
-                        rq_b[idx] = (uint32_t)nb;
+            const int pi = (r0 + u) * G::NQUAD + q;
+            const uint64_t key = keys[pi];  // re-read from LDS: cheaper than holding 2*UNROLL VGPRs
+            uint32_t m0, m1;  // an invalid position (key == EMPTY) can only "match" an EMPTY slot: masks 0
+            const bool found = quad_match(v[u], key, m0, m1);
+            if (!found && key != EMPTY_KEY) {  // rare: absent key, or the key overflowed its bucket
+                if (quad_full(v[u])) {
+                    uint64_t nb = (uint64_t)bkt[pi] + 1;
+                    if (nb == st.nbuckets) nb = 0;
+                    uint32_t idx = 0;
+                    if (j == 0) idx = atomicAdd(rq_cnt, 1u);
+                    idx = quad_perm<QP_BC0>(idx);
+                    if (idx < (uint32_t)ANCHOR_RQ) {
+                        if (j == 0) {
+                            rq_pi[idx] = (uint32_t)pi;
+                            rq_b[idx] = (uint32_t)nb;
+                        }
+                    } else {
+                        quad_chase(st, key, nb, j, m0, m1);  // queue full: resolve inline
                     }
-                    m0 = m1 = 0;
-                } else {
-                    quad_chase<W>(st, key[u], nb, j, m0, m1);  // queue full: resolve inline
                 }
             }
             if (j == 0) {
                 res[pi * ndbs + st.word0] = m0;
-                if (W == 2) res[pi * ndbs + st.word0 + 1] = m1;
+                if (two) res[pi * ndbs + st.word0 + 1] = m1;
             }
         }
     }
     __syncthreads();
     uint32_t n = *rq_cnt;
     if (n > (uint32_t)ANCHOR_RQ) n = ANCHOR_RQ;
-    for (uint32_t i = q; i < n; i += NQUAD) {
+    for (uint32_t i = q; i < n; i += G::NQUAD) {
         const uint32_t pi = rq_pi[i];
         uint32_t m0, m1;
-        quad_chase<W>(st, keys[pi], rq_b[i], j, m0, m1);
+        quad_chase(st, keys[pi], rq_b[i], j, m0, m1);
         if (j == 0) {
             res[pi * ndbs + st.word0] = m0;
-            if (W == 2) res[pi * ndbs + st.word0 + 1] = m1;
+            if (two) res[pi * ndbs + st.word0 + 1] = m1;
         }
     }
     __syncthreads();
 }
 
+template <int TILE, int UNROLL, int NDBS_C, int NBYTES_C>
 __global__ __launch_bounds__(ANCHOR_WG) void k_anchor(const TableDesc T, const uint64_t *__restrict__ seqw,
                                                       const uint32_t *__restrict__ nmw,
                                                       const uint32_t *__restrict__ has_n,
@@ -289,22 +276,26 @@ __global__ __launch_bounds__(ANCHOR_WG) void k_anchor(const TableDesc T, const u
                                                       uint8_t *__restrict__ out1, uint8_t *__restrict__ out100,
                                                       uint32_t *__restrict__ bins,
                                                       unsigned long long *__restrict__ colsums, uint32_t flags) {
+    using G = Geo<TILE>;
     extern __shared__ uint4 smem[];
     const int tid = threadIdx.x;
-    const uint32_t N = T.ngenomes, ndbs = T.ndbs, k = T.k;
-    const uint32_t nbytes = (N + 7) / 8;
+    const uint32_t N = T.ngenomes, k = T.k;
+    const uint32_t ndbs = NDBS_C ? (uint32_t)NDBS_C : T.ndbs;
+    const uint32_t nbytes = NBYTES_C ? (uint32_t)NBYTES_C : (N + 7) / 8;
     // ---- LDS carve-up (all offsets multiples of 16 bytes) ----
     uint8_t *sp = reinterpret_cast<uint8_t *>(smem);
-    const uint32_t rows_bytes = ANCHOR_TILE * (nbytes > 8 ? nbytes : 8);
+    const uint32_t rows_bytes = TILE * (nbytes > 8 ? nbytes : 8);
     uint64_t *keys = reinterpret_cast<uint64_t *>(sp);          // phase 1-2
     uint8_t *rows = sp;                                         // phase 3 (aliases keys)
     sp += rows_bytes;
+    uint32_t *bkt = reinterpret_cast<uint32_t *>(sp);
+    sp += TILE * 4;
     uint32_t *res = reinterpret_cast<uint32_t *>(sp);
-    sp += ANCHOR_TILE * ndbs * 4;
+    sp += TILE * ndbs * 4;
     uint64_t *sw = reinterpret_cast<uint64_t *>(sp);
-    sp += ANCHOR_SEQW * 8;
+    sp += G::SEQW * 8;
     uint32_t *nw = reinterpret_cast<uint32_t *>(sp);
-    sp += ANCHOR_SEQW * 4;
+    sp += G::SEQW * 4;
     uint32_t *rq_pi = reinterpret_cast<uint32_t *>(sp);
     sp += ANCHOR_RQ * 4;
     uint32_t *rq_b = reinterpret_cast<uint32_t *>(sp);
@@ -318,37 +309,43 @@ __global__ __launch_bounds__(ANCHOR_WG) void k_anchor(const TableDesc T, const u
     const uint32_t c = tile_contig[blockIdx.x];
     const AnchorDesc a = ad[c];
     const SeqDesc s = sd[c];
-    const uint32_t tile_start = (blockIdx.x - a.tile0) * ANCHOR_TILE;
-    const uint32_t npos = min((uint32_t)ANCHOR_TILE, a.nkmers - tile_start);
+    const uint32_t tile_start = (blockIdx.x - a.tile0) * TILE;
+    const uint32_t npos = min((uint32_t)TILE, a.nkmers - tile_start);
     const bool hasn = has_n[c] != 0;
 
     // ---- phase 0 ----
-    if (tid < ANCHOR_SEQW) {
+    if (tid < G::SEQW) {
         uint64_t wi = (uint64_t)(tile_start >> 5) + tid;
         sw[tid] = wi < s.nwords ? seqw[s.seq_off + wi] : 0ull;
         nw[tid] = (hasn && wi < s.nwords) ? nmw[s.seq_off + wi] : 0u;
     }
     for (uint32_t i = tid; i < 2 * (N + 1); i += ANCHOR_WG) hist[i] = 0;
     for (uint32_t i = tid; i < N; i += ANCHOR_WG) cs[i] = 0;
+    if (tid == 0) *rq_cnt = 0;
     __syncthreads();
 
-    // ---- phase 1 ----
-#pragma unroll
-    for (int jj = 0; jj < PER_THREAD; ++jj) {
-        const uint32_t pl = jj * ANCHOR_WG + tid;
-        uint64_t key = EMPTY_KEY;
-        if (pl < npos) {
-            key = canonical_from_le(extract_bases(sw, pl), (int)k);
-            if (hasn && extract_nmask(nw, pl, (int)k)) key = EMPTY_KEY;
-        }
-        keys[pl] = key;
-    }
-    __syncthreads();
-
-    // ---- phase 2 ----
+    // ---- phase 1 + 2 (bucket indices depend on the sub-table's size) ----
     for (uint32_t si = 0; si < T.nsub; ++si) {
-        if (T.sub[si].W == 1) probe_sub<1>(T.sub[si], keys, res, ndbs, rq_cnt, rq_pi, rq_b, tid);
-        else probe_sub<2>(T.sub[si], keys, res, ndbs, rq_cnt, rq_pi, rq_b, tid);
+        const SubTable st = T.sub[si];
+#pragma unroll 2
+        for (int jj = 0; jj < G::PER_THREAD; ++jj) {
+            const uint32_t pl = jj * ANCHOR_WG + tid;
+            uint64_t key;
+            if (si == 0) {
+                key = EMPTY_KEY;
+                if (pl < npos) {
+                    key = canonical_from_le(extract_bases(sw, pl), (int)k);
+                    if (hasn && extract_nmask(nw, pl, (int)k)) key = EMPTY_KEY;
+                }
+                keys[pl] = key;
+            } else {
+                key = keys[pl];
+            }
+            bkt[pl] = key == EMPTY_KEY ? 0u : (uint32_t)home_bucket(key, st.nbuckets);
+        }
+        if (si && tid == 0) *rq_cnt = 0;
+        __syncthreads();
+        probe_sub<TILE, UNROLL>(st, keys, bkt, res, ndbs, rq_cnt, rq_pi, rq_b, tid);
     }
 
     // ---- phase 3 ----
@@ -358,22 +355,30 @@ __global__ __launch_bounds__(ANCHOR_WG) void k_anchor(const TableDesc T, const u
     const int lane = tid & 63;
     const bool want_cs = (flags & 1u) != 0;
 #pragma unroll 1
-    for (int jj = 0; jj < PER_THREAD; ++jj) {
+    for (int jj = 0; jj < G::PER_THREAD; ++jj) {
         const uint32_t pl = jj * ANCHOR_WG + tid;
         const bool active = pl < npos;
         const uint32_t pos = tile_start + pl;
         uint32_t popc = 0;
         const bool is100 = active && (pos % 100u == 0);
-        uint8_t *o100 = out100 + a.out100_off + (uint64_t)(pos / 100u) * nbytes;
-        for (uint32_t d = 0; d < ndbs; ++d) {
+#pragma unroll
+        for (uint32_t d = 0; d < (NDBS_C ? (uint32_t)NDBS_C : ndbs); ++d) {
             const uint32_t wv = active ? res[pl * ndbs + d] : 0u;
             popc += __popc(wv);
             // low n bytes of this group's u32 at columns 4d.. (cpp/anchor.cpp:139-164)
             const uint32_t nb = min(4u, nbytes - 4 * d);
-            for (uint32_t bb = 0; bb < nb; ++bb) {
-                const uint8_t byte = (uint8_t)(wv >> (8 * bb));
-                rows[pl * nbytes + 4 * d + bb] = byte;
-                if (is100) o100[4 * d + bb] = byte;
+            if (NBYTES_C == 1) {
+                rows[pl] = (uint8_t)wv;
+            } else if (NBYTES_C == 2) {
+                reinterpret_cast<uint16_t *>(rows)[pl] = (uint16_t)wv;
+            } else if (NBYTES_C == 4 || NBYTES_C == 8) {
+                reinterpret_cast<uint32_t *>(rows)[pl * (NBYTES_C / 4) + d] = wv;
+            } else {
+                for (uint32_t bb = 0; bb < nb; ++bb) rows[pl * nbytes + 4 * d + bb] = (uint8_t)(wv >> (8 * bb));
+            }
+            if (is100) {
+                uint8_t *o100 = out100 + a.out100_off + (uint64_t)(pos / 100u) * nbytes + 4 * d;
+                for (uint32_t bb = 0; bb < nb; ++bb) o100[bb] = (uint8_t)(wv >> (8 * bb));
             }
             if (want_cs) {
                 const uint32_t ng = min(32u, N - 32 * d);
@@ -386,7 +391,7 @@ __global__ __launch_bounds__(ANCHOR_WG) void k_anchor(const TableDesc T, const u
         if (popc > N) popc = N;  // junk bits beyond ngenomes: the reference indexes out of bounds here
         // wave-aggregated histogram of (bin, popcount)
         const uint32_t dpos = pos - bin0_start;
-        const uint32_t rel = (binlen >= (uint32_t)ANCHOR_TILE) ? (dpos >= binlen ? 1u : 0u) : dpos / binlen;
+        const uint32_t rel = (binlen >= (uint32_t)TILE) ? (dpos >= binlen ? 1u : 0u) : dpos / binlen;
         const uint32_t hk = rel * (N + 1) + popc;
         unsigned long long todo = __ballot(active);
         while (todo) {
@@ -498,10 +503,12 @@ hipError_t launch_counters(hipStream_t st, const SubTable &t, int w, int k, cons
 }
 
 size_t anchor_lds_bytes(uint32_t ngenomes) {
+    using G = Geo<ANCHOR_TILE>;
     const uint32_t nbytes = (ngenomes + 7) / 8, ndbs = (ngenomes + 31) / 32;
     size_t b = (size_t)ANCHOR_TILE * (nbytes > 8 ? nbytes : 8);
+    b += (size_t)ANCHOR_TILE * 4;
     b += (size_t)ANCHOR_TILE * ndbs * 4;
-    b += ANCHOR_SEQW * 8 + ANCHOR_SEQW * 4;
+    b += G::SEQW * 8 + G::SEQW * 4;
     b += 2 * ANCHOR_RQ * 4;
     b += ((2 * (ngenomes + 1) + 3) & ~3u) * 4;
     b += ((ngenomes + 3) & ~3u) * 4;
@@ -509,22 +516,39 @@ size_t anchor_lds_bytes(uint32_t ngenomes) {
     return b;
 }
 
+template <int NDBS_C, int NBYTES_C>
+static hipError_t launch_anchor_t(hipStream_t st, size_t lds, uint32_t ntiles, const TableDesc &T,
+                                  const uint64_t *seqw, const uint32_t *nmw, const uint32_t *has_n,
+                                  const SeqDesc *sd, const AnchorDesc *ad, const uint32_t *tile_contig,
+                                  uint8_t *out1, uint8_t *out100, uint32_t *bins, unsigned long long *colsums,
+                                  uint32_t flags) {
+    auto kern = k_anchor<ANCHOR_TILE, ANCHOR_UNROLL, NDBS_C, NBYTES_C>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(ntiles), dim3(ANCHOR_WG), lds, st, T, seqw, nmw, has_n, sd, ad, tile_contig,
+                       out1, out100, bins, colsums, flags);
+    return hipGetLastError();
+}
+
 hipError_t launch_anchor(hipStream_t st, const TableDesc &T, const uint64_t *seqw, const uint32_t *nmw,
                          const uint32_t *has_n, const SeqDesc *sd, const AnchorDesc *ad,
                          const uint32_t *tile_contig, uint32_t ntiles, uint8_t *out1, uint8_t *out100,
                          uint32_t *bins, unsigned long long *colsums, uint32_t flags) {
     if (ntiles == 0) return hipSuccess;
-    size_t lds = anchor_lds_bytes(T.ngenomes);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_anchor),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(k_anchor, dim3(ntiles), dim3(ANCHOR_WG), lds, st, T, seqw, nmw, has_n, sd, ad,
-                       tile_contig, out1, out100, bins, colsums, flags);
-    return hipGetLastError();
+    const size_t lds = anchor_lds_bytes(T.ngenomes);
+    const uint32_t nbytes = (T.ngenomes + 7) / 8;
+#define PG_ARGS st, lds, ntiles, T, seqw, nmw, has_n, sd, ad, tile_contig, out1, out100, bins, colsums, flags
+    if (T.ndbs == 1 && nbytes == 1) return launch_anchor_t<1, 1>(PG_ARGS);
+    if (T.ndbs == 1 && nbytes == 2) return launch_anchor_t<1, 2>(PG_ARGS);
+    if (T.ndbs == 1 && nbytes == 4) return launch_anchor_t<1, 4>(PG_ARGS);
+    if (T.ndbs == 2 && nbytes == 8) return launch_anchor_t<2, 8>(PG_ARGS);
+    return launch_anchor_t<0, 0>(PG_ARGS);
+#undef PG_ARGS
 }
 
 }  // namespace pg

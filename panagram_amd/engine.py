@@ -38,7 +38,12 @@ class Context:
         self.device = device
 
     def set_stream(self, hip_stream: Optional[int]) -> None:
-        check(self._lib.pg_ctx_set_stream(self._h, C.c_void_p(hip_stream or 0)))
+        """Adopt an external hipStream_t handle (0 = HIP's default stream, i.e. torch's
+        default stream); ``None`` goes back to the context's own stream."""
+        if hip_stream is None:
+            check(self._lib.pg_ctx_set_stream(self._h, None, 1))
+        else:
+            check(self._lib.pg_ctx_set_stream(self._h, C.c_void_p(hip_stream), 0))
 
     def synchronize(self) -> None:
         check(self._lib.pg_ctx_synchronize(self._h))
