@@ -1,0 +1,595 @@
+"""Host-side counterpart of the reference's write path (``panagram/index.py``), scoped to
+the anchor hot path and driving the HIP kernels through the C-ABI.
+
+Mirrors, with the same names / argument meaning / on-disk layout:
+
+* ``Index``  — config + orchestration (``panagram/index.py:85-466``): ``samples.tsv``
+  schema ``name fasta gff id anchor`` (``:269-295``), ``config.yaml`` keys (``:347-357``),
+  ``kmc_bitvec_count`` / ``bitvec_prefixes`` / ``steps`` (``:391-405``), ``run()``.
+  Where the reference launches Snakemake -> kmc -> kmc_tools -> one anchor job per genome,
+  ``Index.run()`` builds the pan-kmer table on the GPU (or loads existing
+  ``kmc/bitvec{i}.kmc_{pre,suf}``) and anchors every anchor genome in-process.
+* ``Genome`` — ``run_anchor`` (``:1012-1097``), ``iter_fasta`` (``:922-930``),
+  ``set_chrs`` offsets (``:596-604``) and the read side ``load_bgz_blocks`` /
+  ``_query_bytes`` / ``query`` (``:793-845``) so that what we write can be read back the way
+  ``panagram view`` reads it.
+
+Output tree (identical to the reference's):
+    <prefix>/config.yaml, samples.tsv
+    <prefix>/anchor/<name>/bitmap.1.gz(.gzi) bitmap.100.gz(.gzi) bitsum.bins.tsv chrs.tsv
+                           total_paircounts.csv
+
+Out of scope here: GFF annotation, UMAPs, mash distances, the viewer.
+"""
+from __future__ import annotations
+
+import dataclasses
+import gzip
+import logging
+import os
+import re
+import struct
+import zlib
+from typing import Dict, Iterator, List, Optional, Sequence, Tuple
+
+import numpy as np
+import pandas as pd
+import yaml
+
+from . import engine
+
+logger = logging.getLogger(__name__)
+
+NAME_REGEX = "[A-Za-z0-9_-]+"
+BGZ_SUFFIX = "gz"
+IDX_SUFFIX = "gzi"
+ANCHOR_DIR = "anchor"
+_WS = b" \t\r\n\x0b\x0c"
+
+
+# ---------------------------------------------------------------------------
+# FASTA
+# ---------------------------------------------------------------------------
+def read_fasta(path: str) -> Iterator[Tuple[str, bytes]]:
+    """Yield ``(record id, sequence bytes)``.  Semantics of the reference's Python path
+    (``Bio.SeqIO`` via ``iter_fasta``, index.py:922-930): id = header up to the first
+    whitespace, sequence lines joined with all whitespace removed, ``.gz``/``.bgz`` read
+    through gzip.  (The C++ variant keeps ``\\r`` bytes in the sequence, cpp/anchor.cpp:77-93;
+    the two agree on well-formed FASTA.)"""
+    opn = gzip.open if path.endswith((".gz", ".bgz")) else open
+    with opn(path, "rb") as f:
+        data = f.read()
+    pos = 0 if data[:1] == b">" else data.find(b"\n>") + 1
+    if pos == 0 and data[:1] != b">":
+        return
+    n = len(data)
+    while pos < n:
+        eol = data.find(b"\n", pos)
+        if eol < 0:
+            eol = n
+        header = data[pos + 1:eol].strip()
+        nxt = data.find(b"\n>", eol)
+        end = n if nxt < 0 else nxt + 1
+        seq = data[eol + 1:end].translate(None, _WS)
+        name = header.split(None, 1)[0].decode("latin-1") if header else ""
+        yield name, seq
+        pos = end
+
+
+# ---------------------------------------------------------------------------
+# KMC1 database files (format: SURVEY.md Appendix A) — writer, so that tables built on
+# the GPU can be handed to the reference (`kmc/bitvec{i}.kmc_pre|.kmc_suf`)
+# ---------------------------------------------------------------------------
+def write_kmc1(prefix: str, keys: np.ndarray, counters: np.ndarray, k: int,
+               lut_prefix_len: Optional[int] = None) -> None:
+    keys = np.ascontiguousarray(keys, np.uint64)
+    counters = np.ascontiguousarray(counters, np.uint32)
+    order = np.argsort(keys, kind="stable")
+    keys, counters = keys[order], counters[order]
+    if lut_prefix_len is None:
+        cands = [p for p in range(1, min(k, 13)) if (k - p) % 4 == 0]
+        lut_prefix_len = cands[0]
+        for p in cands:
+            if 4 ** p <= max(len(keys), 1) * 4:
+                lut_prefix_len = p
+    p = lut_prefix_len
+    if (k - p) % 4:
+        raise ValueError("(k - lut_prefix_len) must be a multiple of 4")
+    suf_bytes = (k - p) // 4
+    pref = (keys >> np.uint64(2 * (k - p))).astype(np.int64)
+    lut = np.searchsorted(pref, np.arange(4 ** p, dtype=np.int64), side="left").astype(np.uint64)
+    with open(prefix + ".kmc_pre", "wb") as f:
+        f.write(b"KMCP")
+        f.write(lut.tobytes())
+        f.write(struct.pack("<IIIIIIQB3x24xI", k, 0, 4, p, 1, 0xFFFFFFFF, len(keys), 0, 0))
+        f.write(struct.pack("<I", 64))
+        f.write(b"KMCP")
+    rec = np.zeros((len(keys), suf_bytes + 4), np.uint8)
+    for b in range(suf_bytes):
+        rec[:, b] = ((keys >> np.uint64(8 * (suf_bytes - 1 - b))) & np.uint64(0xFF)).astype(np.uint8)
+    rec[:, suf_bytes:] = counters.view(np.uint8).reshape(-1, 4)
+    with open(prefix + ".kmc_suf", "wb") as f:
+        f.write(b"KMCS")
+        f.write(rec.tobytes())
+        f.write(b"KMCS")
+
+
+# ---------------------------------------------------------------------------
+# BGZF read side (Bio.bgzf is not a dependency here)
+# ---------------------------------------------------------------------------
+def load_bgz_blocks(fname: str) -> np.ndarray:
+    """index.py:793-799: (rstart, dstart) per block, block 0 implicit."""
+    raw = np.fromfile(fname, "<u8")
+    n = int(raw[0])
+    blocks = np.zeros((n + 1, 2), np.int64)
+    blocks[1:] = raw[1:1 + 2 * n].reshape(n, 2)
+    return blocks
+
+
+def bgzf_read(path: str, blocks: np.ndarray, byte_start: int, length: int) -> bytes:
+    """Random access as in index.py:827-845: locate the block through the .gzi, then inflate."""
+    blk = int(np.searchsorted(blocks[:, 1], byte_start, side="right") - 1)
+    out = bytearray()
+    skip = byte_start - int(blocks[blk, 1])
+    with open(path, "rb") as f:
+        f.seek(int(blocks[blk, 0]))
+        while len(out) < length:
+            hdr = f.read(18)
+            if len(hdr) < 18:
+                break
+            bsize = struct.unpack("<H", hdr[16:18])[0] + 1
+            body = f.read(bsize - 18)
+            data = zlib.decompress(body[:-8], -15)
+            if not data:
+                break  # EOF block
+            out += data[skip:]
+            skip = 0
+    return bytes(out[:length])
+
+
+# ---------------------------------------------------------------------------
+# config dataclasses (same field names and defaults as index.py:63-138)
+# ---------------------------------------------------------------------------
+@dataclasses.dataclass
+class KMC:
+    memory: int = 8
+    threads: int = 1
+    use_existing: bool = False
+
+
+@dataclasses.dataclass
+class UMAP:
+    neighbors: int = 4
+    dist: float = 0
+    eps: float = 1
+    samples: int = 1
+    bin_size: int = 100000
+
+
+@dataclasses.dataclass
+class Index:
+    """Anchor k-mer bitvectors to reference FASTA files to create the pan-kmer bitmap."""
+
+    input: str
+    mode: Optional[str] = None
+    prefix: Optional[str] = None
+    k: int = 21
+    cores: int = 1
+    lowres_step: int = 100
+    max_bin_kbp: int = 200
+    min_bin_count: int = 100
+    max_view_chrs: int = 50
+    gff_gene_types: List[str] = dataclasses.field(default_factory=lambda: ["gene"])
+    gff_anno_types: Optional[List[str]] = None
+    gff_name: str = "Name"
+    anchor_genomes: Optional[List[str]] = None
+    prepare: bool = False
+    kmc: KMC = dataclasses.field(default_factory=KMC)
+    genome_umap: UMAP = dataclasses.field(default_factory=UMAP)
+    chrom_umap: UMAP = dataclasses.field(default_factory=UMAP)
+    use_existing: int = 1
+    threads: int = 1
+    memory: int = 1
+    # -- not part of the reference's schema: which GPU this process drives, and whether to
+    #    also export kmc/bitvec{i} in KMC1 layout for the reference to read
+    device: int = 0
+    export_kmc: bool = False
+
+    _EXTRA = ("device", "export_kmc")
+
+    def __post_init__(self):
+        if not (self.mode is None or self.mode in {"r", "w"}):
+            raise ValueError(f"Invalid mode '{self.mode}', must be 'r' or 'w'")
+        if self.lowres_step != 100 or self.max_bin_kbp != 200 or self.min_bin_count != 100:
+            # the kernels fuse the reference's defaults (cpp/anchor.cpp hard-codes them too)
+            raise ValueError("lowres_step / max_bin_kbp / min_bin_count other than 100 / 200 / 100 "
+                             "are not supported by the GPU path")
+        self.write_mode = os.path.isfile(self.input) if self.mode is None else self.mode == "w"
+        if self.write_mode:
+            if os.path.isdir(self.input):
+                self.prefix = self.input
+                if not (os.path.isfile(self.config_fname) and os.path.isfile(self.samples_fname)):
+                    raise ValueError("Index write directory not initialized")
+                self.input = self.samples_fname
+                self.load_config()
+            elif os.path.isfile(self.input):
+                if self.prefix is None:
+                    self.prefix = os.path.dirname(self.input)
+                if len(self.prefix) == 0:
+                    self.prefix = "."
+                os.makedirs(self.prefix, exist_ok=True)
+                self.init_config()
+            else:
+                raise ValueError("Index input must be sample TSV or initialized directory")
+        else:
+            if not os.path.isdir(self.input):
+                raise ValueError("Index input must be directory mode='r'")
+            self.prefix = self.input
+            self.load_config()
+
+        self.samples = pd.read_table(self.samples_fname)
+        missing = {"name", "id"}.difference(self.samples.columns)
+        if missing:
+            raise ValueError(f"{self.samples_fname} is missing required column(s): {', '.join(sorted(missing))}. "
+                             "This directory does not look like a prepared Panagram index.")
+        self.samples = self.samples.set_index("name")
+        self.ngenomes = len(self.samples)
+        self.genomes: Dict[str, Genome] = {}
+        for name, row in self.samples.iterrows():
+            self.genomes[name] = Genome(self, int(row["id"]), name, row["fasta"], row.get("gff"),
+                                        bool(row["anchor"]), write=self.write_mode)
+        if self.anchor_genomes is None:
+            self.anchor_genomes = [n for n, g in self.genomes.items() if g.anchored]
+        self._ctx = None
+        self._table = None
+
+    # ---- naming (index.py:155-165, 359-405) ----
+    @property
+    def params(self):
+        d = dataclasses.asdict(self)
+        for e in self._EXTRA:
+            d.pop(e, None)
+        return d
+
+    @property
+    def config_fname(self):
+        return os.path.join(self.prefix, "config.yaml")
+
+    @property
+    def samples_fname(self):
+        return os.path.join(self.prefix, "samples.tsv")
+
+    def get_subdir(self, name):
+        return os.path.join(self.prefix, name)
+
+    def kmc_prefix(self, *names):
+        return os.path.join(self.get_subdir("kmc"), ".".join(names))
+
+    @property
+    def genome_names(self):
+        return self.samples.index
+
+    @property
+    def kmc_bitvec_count(self):
+        return int(np.ceil(len(self.samples) / 32.0))
+
+    @property
+    def bitvec_prefixes(self):
+        return [self.kmc_prefix(f"bitvec{i}") for i in range(self.kmc_bitvec_count)]
+
+    @property
+    def steps(self):
+        return (1, self.lowres_step)
+
+    def __getitem__(self, genome):
+        return self.genomes[genome]
+
+    # ---- config files (index.py:269-295, 347-357) ----
+    def init_config(self):
+        samples = pd.read_table(self.input)
+        if "name" not in samples.columns or "fasta" not in samples.columns:
+            raise ValueError("Input samples must contain 'name' and 'fasta' column headers")
+        if "gff" not in samples:
+            samples["gff"] = pd.NA
+        invalid = ~samples["name"].astype(str).str.fullmatch(NAME_REGEX)
+        if np.any(invalid):
+            bad = "', '".join(samples["name"][invalid])
+            raise ValueError(f"Invalid genome names: '{bad}'\nMust match r'{NAME_REGEX}'.")
+        keep = ["name", "fasta", "gff"] + (["anchor"] if "anchor" in samples else [])
+        samples = samples[keep].set_index("name").dropna(how="all")
+        samples["id"] = np.arange(len(samples), dtype=int)
+        if self.anchor_genomes is None:
+            if "anchor" in samples:
+                self.anchor_genomes = list(samples.index[samples["anchor"].astype(bool)])
+            else:
+                self.anchor_genomes = list(samples["fasta"].dropna().index)
+        samples["anchor"] = samples.index.isin(self.anchor_genomes)
+        samples[["fasta", "gff", "id", "anchor"]].to_csv(self.samples_fname, sep="\t")
+        self.write_config()
+
+    def write_config(self, exclude=("prefix",)):
+        prms = self.params
+        for p in exclude:
+            del prms[p]
+        with open(self.config_fname, "w") as conf_out:
+            yaml.dump(prms, conf_out)
+
+    def load_config(self):
+        with open(self.config_fname) as f:
+            vals = yaml.load(f, yaml.SafeLoader) or {}
+        for key, val in vals.items():
+            cur = getattr(self, key, None)
+            if dataclasses.is_dataclass(cur) and isinstance(val, dict):
+                for k2, v2 in val.items():
+                    setattr(cur, k2, v2)
+            elif key not in ("input", "mode", "prefix"):
+                setattr(self, key, val)
+
+    # ---- the table: replaces rules kmc_count / opdefs / kmc_bitvec (workflow/Snakefile:54-110) ----
+    @property
+    def context(self) -> engine.Context:
+        if self._ctx is None:
+            self._ctx = engine.Context(self.device)
+        return self._ctx
+
+    def build_table(self) -> engine.PanTable:
+        if self._table is not None:
+            return self._table
+        tbl = engine.PanTable(self.context, self.k, self.ngenomes)
+        have = all(os.path.exists(p + ".kmc_pre") and os.path.exists(p + ".kmc_suf") for p in self.bitvec_prefixes)
+        if self.kmc.use_existing and have:
+            for i, p in enumerate(self.bitvec_prefixes):
+                with open(p + ".kmc_pre", "rb") as f:
+                    pre = f.read()
+                with open(p + ".kmc_suf", "rb") as f:
+                    suf = f.read()
+                tbl.load_kmc1(i, pre, suf)
+            logger.info("KMC Database Loaded")
+        else:
+            for name, g in self.genomes.items():
+                if pd.isna(g.fasta):
+                    continue
+                recs = [seq for _, seq in read_fasta(g.fasta)]
+                ss = engine.SeqSet.from_host(self.context, recs)
+                tbl.insert_seqset(g.id, ss)
+                ss.close()
+            logger.info("k-mer table built on GPU: %s", tbl.stats())
+            if self.export_kmc:
+                os.makedirs(self.get_subdir("kmc"), exist_ok=True)
+                for i, p in enumerate(self.bitvec_prefixes):
+                    keys, vals = tbl.export(i)
+                    write_kmc1(p, keys, vals, self.k)
+        self._table = tbl
+        return tbl
+
+    # ---- panagram index command (index.py:172-191) ----
+    def run(self):
+        print("Wrote config.yaml and samples.tsv")
+        if self.prepare:
+            print("Prepared. Run 'python -m panagram_amd index <dir>' to build the index")
+            return
+        os.makedirs(self.get_subdir("logs"), exist_ok=True)
+        tbl = self.build_table()
+        for name in self.anchor_genomes:
+            self.genomes[name].run_anchor(tbl, os.path.join(self.get_subdir("logs"), f"anchor.{name}.log.txt"))
+        self.close()
+
+    def query_bitmap(self, genome, chrom, start=None, end=None, step=1):
+        return self.genomes[genome].query(chrom, start, end, step)
+
+    def close(self):
+        if self._table is not None:
+            self._table.close()
+            self._table = None
+        if self._ctx is not None:
+            self._ctx.close()
+            self._ctx = None
+
+
+class Genome:
+    """One sample (index.py:468-1189), write side = ``run_anchor``, read side = ``query``."""
+
+    def __init__(self, idx: Index, id: int, name: str, fasta=None, gff=None, anchor=None, write=False):
+        self.index = idx
+        self.id = id
+        self.name = name
+        self.fasta = fasta
+        self.gff = gff
+        self.write_mode = write
+        self.prefix = os.path.join(idx.prefix, ANCHOR_DIR, name)
+        self.anchored = bool(anchor) if anchor is not None else (fasta is not None and not pd.isna(fasta))
+        self.ngenomes = idx.ngenomes
+        self.nbytes = int(np.ceil(self.ngenomes / 8))
+        self.steps = list(idx.steps)
+        self.chrs = None
+        self.blocks = None
+        if self.anchored and os.path.exists(self.chrs_fname):
+            self.load_chrs()
+
+    @property
+    def chrs_fname(self):
+        return os.path.join(self.prefix, "chrs.tsv")
+
+    @property
+    def bins_fname(self):
+        return os.path.join(self.prefix, "bitsum.bins.tsv")
+
+    def bitmap_gz_fname(self, step):
+        return os.path.join(self.prefix, f"bitmap.{step}.{BGZ_SUFFIX}")
+
+    def bitmap_gzi_fname(self, step):
+        return os.path.join(self.prefix, f"bitmap.{step}.{IDX_SUFFIX}")
+
+    @property
+    def anchor_filenames(self):
+        if not self.anchored:
+            return []
+        ret = [self.chrs_fname, self.bins_fname]
+        for s in self.steps:
+            ret += [self.bitmap_gz_fname(s), self.bitmap_gzi_fname(s)]
+        return ret
+
+    def iter_fasta(self):
+        return read_fasta(self.fasta)
+
+    # ---- chrs / offsets (index.py:576-604) ----
+    def set_chrs(self, chrs: pd.DataFrame):
+        self.chrs = chrs
+        if "gene_count" not in self.chrs.columns:
+            self.chrs["gene_count"] = 0
+        self.sizes = chrs["size"]
+        step_sizes = pd.DataFrame({step: np.ceil(self.sizes / step) for step in self.steps}, dtype=int)
+        self.offsets = step_sizes.cumsum().shift(fill_value=0)
+
+    def load_chrs(self):
+        self.set_chrs(pd.read_table(self.chrs_fname, index_col="name"))
+
+    # ---- WRITE: the hot path ----
+    def run_anchor(self, table: engine.PanTable, logfile: Optional[str] = None, bgzf_threads: Optional[int] = None):
+        """Counterpart of ``Genome.run_anchor(bitvecs, logfile)`` (index.py:1012-1097) and of
+        ``KMCdb::anchor_fasta`` (cpp/anchor.cpp:37-109): walks the anchor FASTA, anchors every
+        contig on the GPU and writes the anchor/<name>/ files.  ``table`` is the GPU-resident
+        pan-kmer table standing in for the list of ``kmc/bitvec{i}`` prefixes."""
+        if logfile:
+            logging.basicConfig(filename=logfile, level=logging.INFO,
+                                format="[ %(asctime)s %(levelname)7s ] %(message)s", datefmt="%Y-%m-%d %H:%M:%S")
+        if not self.anchored:
+            logger.info(f"Skipping non-anchor genome '{self.name}'")
+            return
+        ctx = table.ctx
+        N = self.ngenomes
+        os.makedirs(self.prefix, exist_ok=True)
+        recs = list(self.iter_fasta())
+        short = [nm for nm, s in recs if len(s) < table.k]
+        for nm in short:
+            logger.warning(f"Contig {nm} is shorter than k={table.k}: 0 k-mers (the reference underflows here)")
+        nthreads = bgzf_threads or max(1, min(32, self.index.cores if self.index.cores > 1 else (os.cpu_count() or 1)))
+        tmp = {s: self.bitmap_gz_fname(s) + ".tmp" for s in self.steps}
+        writers = {s: engine.BgzfWriter(tmp[s], level=6, threads=nthreads) for s in self.steps}
+        logger.info("Anchoring Started")
+
+        ss = engine.SeqSet.from_host(ctx, [s for _, s in recs])
+        res = engine.AnchorResult(table, ss, colsums=True)
+        res.run()
+        bins_rows: List[str] = ["chr\tstart" + "".join(f"\t{i}" for i in range(N + 1)) + "\n"]
+        chr_rows: List[Tuple[str, int, int, int]] = []
+        for ci, (chrom, _) in enumerate(recs):
+            rows, rows100, bins, info = res.download(ci)
+            writers[1].write(rows)
+            writers[self.steps[1]].write(rows100)
+            for b in range(info["nbins"]):
+                bins_rows.append(f"{ci}\t{b * info['binlen']}" + "".join(f"\t{int(c)}" for c in bins[b]) + "\n")
+            chr_rows.append((chrom, ci, info["nkmers"], 0))
+            logger.info(f"Anchored {chrom}")
+        paircount_sums = res.colsums().astype(np.int64)
+        res.close()
+        ss.close()
+
+        for s in self.steps:
+            writers[s].close(self.bitmap_gzi_fname(s) + ".tmp")
+            os.replace(tmp[s], self.bitmap_gz_fname(s))
+            os.replace(self.bitmap_gzi_fname(s) + ".tmp", self.bitmap_gzi_fname(s))
+        with open(self.bins_fname, "w") as f:
+            f.writelines(bins_rows)
+        # total_paircounts.csv (index.py:1068-1074): count[g] = positions holding genome g's bit
+        counts = pd.Series(paircount_sums, index=self.index.genome_names)
+        pd.DataFrame({"count": counts, "frac": counts / counts[self.name]}).to_csv(
+            os.path.join(self.prefix, "total_paircounts.csv"))
+        chrs = pd.DataFrame(chr_rows, columns=["name", "id", "size", "gene_count"]).set_index("name")
+        self.set_chrs(chrs)
+        self.chrs.to_csv(self.chrs_fname, sep="\t")  # written last: it is the rule's completion marker
+
+    # ---- READ: what `panagram view` does with our files (index.py:615-658, 793-845) ----
+    def init_read(self):
+        if self.chrs is None:
+            self.load_chrs()
+        self.blocks = {s: load_bgz_blocks(self.bitmap_gzi_fname(s)) for s in self.steps}
+        self.bitsum_bins = pd.read_table(self.bins_fname)
+        self.total_paircounts = pd.read_csv(os.path.join(self.prefix, "total_paircounts.csv"), index_col="name")
+
+    def seq_len(self, seq_name):
+        return int(self.sizes.loc[seq_name])
+
+    def _bytes_to_bits(self, pac):
+        return np.unpackbits(pac, bitorder="little", axis=1)[:, : self.ngenomes]
+
+    def _query_bytes(self, name, start, end, step, bstep):
+        byte_start = self.nbytes * (int(self.offsets.loc[name, bstep]) + (start // bstep))
+        length = int((end - start) // bstep) + 1
+        step = step // bstep
+        buf = bgzf_read(self.bitmap_gz_fname(bstep), self.blocks[bstep], byte_start, length * self.nbytes)
+        pac = np.frombuffer(buf, "uint8").reshape((len(buf) // self.nbytes, self.nbytes))
+        return pac[::step] if step > 1 else pac
+
+    def query(self, name, start=None, end=None, step=1) -> pd.DataFrame:
+        if self.blocks is None:
+            self.init_read()
+        bstep = 1
+        for s in self.steps:
+            if step % s == 0:
+                bstep = max(bstep, s)
+        start = 0 if start is None else start
+        end = self.seq_len(name) if end is None else end
+        pac = self._query_bytes(name, start, end - 1, step, bstep)
+        bits = self._bytes_to_bits(pac)
+        return pd.DataFrame(bits, index=pd.RangeIndex(start, end, step)[: len(bits)], columns=self.index.genome_names)
+
+
+# ---------------------------------------------------------------------------
+# process-level seam: `run_anchor <ngenomes> <root> [<name> <fasta>]...` (cpp/anchor.cpp:204-233)
+# ---------------------------------------------------------------------------
+def run_anchor_cli(argv: Sequence[str], device: int = 0) -> int:
+    """Same argv and file contract as the reference's ``cpp/run_anchor`` binary: reads
+    ``root/kmc/bitvec{i}`` (KMC1), writes ``root/anchor/<name>/{bitmap.1,bitmap.100}.gz(.gzi)``,
+    ``bitsum.bins.tsv``, ``chrs.tsv``.  Unlike the reference, a missing or ill-formed DB is an
+    error (cpp/anchor.cpp:29 ignores OpenForRA's result)."""
+    ngenomes = int(argv[0])
+    root = argv[1]
+    pairs = argv[2:]
+    if len(pairs) > 2 * ngenomes:
+        print(f"Error: expected {ngenomes * 2 + 1} or fewer arguments")
+        return 1
+    ndbs = (ngenomes + 31) // 32
+    ctx = engine.Context(device)
+    k = None
+    images = []
+    for i in range(ndbs):
+        p = os.path.join(root, "kmc", f"bitvec{i}")
+        with open(p + ".kmc_pre", "rb") as f:
+            pre = f.read()
+        with open(p + ".kmc_suf", "rb") as f:
+            suf = f.read()
+        hoff = struct.unpack("<I", pre[-8:-4])[0]
+        k = struct.unpack("<I", pre[len(pre) - 8 - hoff:len(pre) - 4 - hoff])[0]
+        images.append((pre, suf))
+    tbl = engine.PanTable(ctx, k, ngenomes)
+    for i, (pre, suf) in enumerate(images):
+        tbl.load_kmc1(i, pre, suf)
+    nbytes = (ngenomes + 7) // 8
+    for name, fasta in zip(pairs[0::2], pairs[1::2]):
+        print(f"Anchoring {name} {fasta}")
+        adir = os.path.join(root, "anchor", name)
+        os.makedirs(adir, exist_ok=True)
+        recs = list(read_fasta(fasta))
+        ss = engine.SeqSet.from_host(ctx, [s for _, s in recs])
+        res = engine.AnchorResult(tbl, ss, colsums=False)
+        res.run()
+        w1 = engine.BgzfWriter(os.path.join(adir, "bitmap.1.gz"), threads=os.cpu_count() or 1)
+        w100 = engine.BgzfWriter(os.path.join(adir, "bitmap.100.gz"), threads=2)
+        with open(os.path.join(adir, "bitsum.bins.tsv"), "w") as fb, open(os.path.join(adir, "chrs.tsv"), "w") as fc:
+            fb.write("chr\tstart" + "".join(f"\t{i}" for i in range(ngenomes + 1)) + "\n")
+            fc.write("name\tid\tsize\tgene_count\n")
+            for ci, (chrom, _) in enumerate(recs):
+                rows, rows100, bins, info = res.download(ci)
+                w1.write(rows)
+                w100.write(rows100)
+                for b in range(info["nbins"]):
+                    fb.write(f"{ci}\t{b * info['binlen']}" + "".join(f"\t{int(c)}" for c in bins[b]) + "\n")
+                fc.write(f"{chrom}\t{ci}\t{info['nkmers']}\t0\n")
+        w1.close(os.path.join(adir, "bitmap.1.gzi"))
+        w100.close(os.path.join(adir, "bitmap.100.gzi"))
+        res.close()
+        ss.close()
+    tbl.close()
+    ctx.close()
+    return 0

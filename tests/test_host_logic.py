@@ -1,0 +1,111 @@
+"""CPU: host-side logic of the product (FASTA parse, KMC1 writer, config/schema, BGZF read side)."""
+import gzip
+import os
+
+import numpy as np
+import pandas as pd
+import pytest
+import yaml
+
+from oracle import pyoracle as po
+from panagram_amd import index as pidx
+from tests import helpers as H
+
+
+def test_read_fasta_matches_reference_parse(tmp_path):
+    fx = H.load_case("n2_k21")
+    for g in (0, 1):
+        data = fx[f"fasta_{g}"].tobytes()
+        p = tmp_path / f"g{g}.fa"
+        p.write_bytes(data)
+        assert list(pidx.read_fasta(str(p))) == po.parse_fasta_cpp(data)
+        pz = tmp_path / f"g{g}.fa.gz"
+        with gzip.open(pz, "wb") as f:
+            f.write(data)
+        assert list(pidx.read_fasta(str(pz))) == po.parse_fasta_cpp(data)
+
+
+def test_read_fasta_edge_cases(tmp_path):
+    p = tmp_path / "x.fa"
+    p.write_bytes(b">a desc here\r\nACGT\r\nAC GT\n\n>b\tt\nNNNN\n>c\n")
+    assert list(pidx.read_fasta(str(p))) == [("a", b"ACGTACGT"), ("b", b"NNNN"), ("c", b"")]
+    p.write_bytes(b"")
+    assert list(pidx.read_fasta(str(p))) == []
+    p.write_bytes(b"junk before\n>z\nAC\nGT")
+    assert list(pidx.read_fasta(str(p))) == [("z", b"ACGT")]
+
+
+def test_write_kmc1_readable_by_oracle_reader(tmp_path):
+    fx = H.load_case("n40_k31")
+    rng = np.random.default_rng(0)
+    for i, (keys, masks) in enumerate(H.case_dbs(fx)):
+        perm = rng.permutation(len(keys))  # the GPU export is unsorted
+        pre = str(tmp_path / f"bitvec{i}")
+        pidx.write_kmc1(pre, keys[perm], masks[perm], 31)
+        db = po.read_kmc1(pre)
+        assert db["k"] == 31 and np.array_equal(db["keys"], keys) and np.array_equal(db["counters"], masks)
+
+
+def _samples(tmp_path, n=3):
+    rows = ["name\tfasta"]
+    for g in range(n):
+        fa = tmp_path / f"g{g}.fa"
+        fa.write_bytes(b">chr1\n" + b"ACGT" * 50 + b"\n")
+        rows.append(f"s{g}\t{fa}")
+    s = tmp_path / "samples.tsv"
+    s.write_text("\n".join(rows) + "\n")
+    return s
+
+
+def test_index_config_and_samples_schema(tmp_path):
+    s = _samples(tmp_path)
+    out = tmp_path / "idx"
+    idx = pidx.Index(str(s), prefix=str(out), k=21, prepare=True)
+    st = pd.read_table(out / "samples.tsv")
+    assert list(st.columns) == ["name", "fasta", "gff", "id", "anchor"]  # index.py:282-293
+    assert list(st["id"]) == [0, 1, 2] and st["anchor"].all()
+    cfg = yaml.safe_load(open(out / "config.yaml"))
+    for key in ("k", "lowres_step", "max_bin_kbp", "min_bin_count", "anchor_genomes", "kmc", "cores"):
+        assert key in cfg
+    assert "prefix" not in cfg and cfg["k"] == 21 and cfg["kmc"]["threads"] == 1
+    assert idx.kmc_bitvec_count == 1 and idx.steps == (1, 100)
+    assert idx.bitvec_prefixes == [os.path.join(str(out), "kmc", "bitvec0")]
+    # re-open the prepared directory in write mode, as the reference's Snakefile does
+    idx2 = pidx.Index(str(out), mode="w")
+    assert idx2.k == 21 and list(idx2.genome_names) == ["s0", "s1", "s2"]
+    with pytest.raises(ValueError):
+        bad = tmp_path / "bad.tsv"
+        bad.write_text("name\tfasta\nbad name!\t/x.fa\n")
+        pidx.Index(str(bad), prefix=str(tmp_path / "o2"))
+
+
+def test_bgzf_read_side_matches_reference_addressing(tmp_path):
+    """load_bgz_blocks + virtual-offset style random access (index.py:793-845) over our writer."""
+    from panagram_amd import engine
+    rng = np.random.default_rng(1)
+    data = rng.integers(0, 256, 400000, dtype=np.uint8).tobytes()
+    p = str(tmp_path / "bitmap.1.gz")
+    w = engine.BgzfWriter(p, threads=2)
+    w.write(data)
+    w.close(p + "i")
+    blocks = pidx.load_bgz_blocks(p + "i")
+    assert blocks.shape == ((len(data) + 65279) // 65280, 2) and tuple(blocks[0]) == (0, 0)
+    for start, ln in [(0, 10), (65279, 3), (65280, 65280), (130000, 200000), (399990, 10)]:
+        assert pidx.bgzf_read(p, blocks, start, ln) == data[start:start + ln]
+
+
+def test_golden_gzi_uncompressed_offsets_match_reference():
+    """our writer's .gzi layout == the reference's (htslib) on the same payload length"""
+    import tempfile
+    from panagram_amd import engine
+    fx = H.load_case("n65_k21")
+    payload = fx["a64_bitmap1"].tobytes()
+    ref = np.frombuffer(fx["a64_gzi1"].tobytes(), "<u8")
+    with tempfile.TemporaryDirectory() as d:
+        p = os.path.join(d, "b.gz")
+        w = engine.BgzfWriter(p)
+        w.write(payload)
+        w.close(p + "i")
+        ours = np.fromfile(p + "i", "<u8")
+    assert ours[0] == ref[0]
+    assert np.array_equal(ours[1:].reshape(-1, 2)[:, 1], ref[1:].reshape(-1, 2)[:, 1])
