@@ -122,11 +122,17 @@ uint64_t pg_seqset_total_kmers(const pg_seqset *s, int k);
  * nbytes-byte presence row (bitmap.1), every row whose contig-relative index is
  * a multiple of 100 (bitmap.100), the per-bin popcount histogram (N+1 counters
  * per bin; bin length 200000 or nkmers/100) and per-genome column sums. */
-#define PG_ANCHOR_COLSUMS 1u  /* also accumulate per-genome column sums */
+#define PG_ANCHOR_COLSUMS 1u   /* also accumulate per-genome column sums */
+#define PG_ANCHOR_ROWS_ONLY 2u /* genome-sharded mode: pg_anchor_run writes only the bitmap.1 rows (this
+                                * GPU's genomes' bits); after the rows of all GPUs have been combined in
+                                * place (RCCL) pg_rows_epilogue derives the rest */
 int pg_result_create(pg_table *tbl, const pg_seqset *seqs, uint32_t flags, pg_result **out);
 int pg_result_destroy(pg_result *r);
 /* run the anchor kernels for all contigs of the result's seqset; async */
 int pg_anchor_run(pg_result *r);
+/* bitmap.100 rows, bin histograms and column sums from the (combined) bitmap.1 rows in the
+ * result's device buffer; async.  Same outputs as the fused pg_anchor_run path. */
+int pg_rows_epilogue(pg_result *r);
 /* geometry of contig idx: k-mer count, bitmap.100 row count, bin count, bin length */
 int pg_result_contig_info(const pg_result *r, uint32_t idx, uint64_t *nkmers, uint64_t *nrows100,
                           uint32_t *nbins, uint32_t *binlen);

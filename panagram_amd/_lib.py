@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpanagram_hip.so")
 
 PG_ANCHOR_COLSUMS = 1
+PG_ANCHOR_ROWS_ONLY = 2
 
 
 class PanagramHipError(RuntimeError):
@@ -50,6 +51,7 @@ PROTOTYPES = {
     "pg_result_create": (C.c_int, [_vp, _vp, C.c_uint32, _vpp]),
     "pg_result_destroy": (C.c_int, [_vp]),
     "pg_anchor_run": (C.c_int, [_vp]),
+    "pg_rows_epilogue": (C.c_int, [_vp]),
     "pg_result_contig_info": (C.c_int, [_vp, C.c_uint32, _u64p, _u64p, _u32p, _u32p]),
     "pg_result_download": (C.c_int, [_vp, C.c_uint32, _vp, _vp, _vp]),
     "pg_result_colsums": (C.c_int, [_vp, _vp]),

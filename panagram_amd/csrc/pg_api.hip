@@ -691,6 +691,19 @@ extern "C" int pg_anchor_run(pg_result *r) {
     return PG_OK;
 }
 
+extern "C" int pg_rows_epilogue(pg_result *r) {
+    if (!r) return fail(PG_E_INVALID, "result is NULL");
+    pg_table *t = r->tbl;
+    if (int e = use_device(t->ctx)) return e;
+    hipStream_t st = t->ctx->stream;
+    const uint32_t N = t->ngenomes;
+    HIP_TRY(hipMemsetAsync(r->d_bins, 0, std::max<uint64_t>(1, r->total_bins) * (N + 1) * 4, st));
+    HIP_TRY(hipMemsetAsync(r->d_colsums, 0, (size_t)N * 8, st));
+    HIP_TRY(launch_rows_epilogue(st, N, r->d_ad, r->d_tile_contig, r->ntiles, r->d_out1, r->d_out100, r->d_bins,
+                                 r->d_colsums, r->flags));
+    return PG_OK;
+}
+
 extern "C" int pg_result_contig_info(const pg_result *r, uint32_t idx, uint64_t *nkmers, uint64_t *nrows100,
                                      uint32_t *nbins, uint32_t *binlen) {
     if (!r) return fail(PG_E_INVALID, "result is NULL");

@@ -54,4 +54,8 @@ hipError_t launch_anchor(hipStream_t st, const TableDesc &T, const uint64_t *seq
                          const uint32_t *tile_contig, uint32_t ntiles, uint8_t *out1, uint8_t *out100,
                          uint32_t *bins, unsigned long long *colsums, uint32_t flags);
 
+hipError_t launch_rows_epilogue(hipStream_t st, uint32_t ngenomes, const AnchorDesc *ad, const uint32_t *tile_contig,
+                                uint32_t ntiles, const uint8_t *out1, uint8_t *out100, uint32_t *bins,
+                                unsigned long long *colsums, uint32_t flags);
+
 }  // namespace pg

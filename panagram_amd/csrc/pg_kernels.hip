@@ -185,6 +185,55 @@ __global__ __launch_bounds__(256) void k_counters(SubTable st, int w, int k, con
 //            then coalesced 16-byte stores of the bitmap.1 tile
 // NDBS_C / NBYTES_C: compile-time row shape (0 = runtime, generic path).
 // ---------------------------------------------------------------------------
+// ---- per-position epilogue pieces shared by k_anchor (fused) and k_rows_epilogue ----
+// column sums: one ballot + popcount per genome bit, accumulated in LDS by lane 0
+__device__ __forceinline__ void colsum_word(uint32_t wv, uint32_t d, uint32_t N, uint32_t *cs, int lane) {
+    const uint32_t ng = min(32u, N - 32 * d);
+    for (uint32_t bit = 0; bit < ng; ++bit) {
+        const unsigned long long bal = __ballot((wv >> bit) & 1u);
+        if (lane == 0 && bal) atomicAdd(&cs[32 * d + bit], (uint32_t)__popcll(bal));
+    }
+}
+// wave-aggregated histogram of (bin, popcount): LDS for the tile's first two bins, global beyond
+template <int TILE>
+__device__ __forceinline__ void hist_position(bool active, uint32_t pos, uint32_t popc, uint32_t N,
+                                              uint32_t binlen, uint32_t bin0, uint32_t bin0_start,
+                                              uint32_t *hist, uint32_t *bins, uint64_t bin_off, int lane) {
+    if (popc > N) popc = N;  // junk bits beyond ngenomes: the reference indexes out of bounds here
+    const uint32_t dpos = pos - bin0_start;
+    const uint32_t rel = (binlen >= (uint32_t)TILE) ? (dpos >= binlen ? 1u : 0u) : dpos / binlen;
+    const uint32_t hk = rel * (N + 1) + popc;
+    unsigned long long todo = __ballot(active);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const uint32_t lk = __shfl(hk, leader);
+        const unsigned long long m = __ballot(active && hk == lk) & todo;
+        if (lane == leader) {
+            const uint32_t cnt = (uint32_t)__popcll(m);
+            if (rel < 2) atomicAdd(&hist[hk], cnt);
+            else atomicAdd(&bins[(bin_off + bin0 + rel) * (uint64_t)(N + 1) + popc], cnt);
+        }
+        todo &= ~m;
+    }
+}
+__device__ __forceinline__ void flush_stats(uint32_t N, const uint32_t *hist, const uint32_t *cs, uint32_t *bins,
+                                            unsigned long long *colsums, uint64_t bin_off, uint32_t bin0,
+                                            bool want_cs, int tid) {
+    for (uint32_t i = tid; i < 2 * (N + 1); i += ANCHOR_WG) {
+        const uint32_t hv = hist[i];
+        if (hv) {
+            const uint32_t rel = i / (N + 1), pc = i - rel * (N + 1);
+            atomicAdd(&bins[(bin_off + bin0 + rel) * (uint64_t)(N + 1) + pc], hv);
+        }
+    }
+    if (want_cs) {
+        for (uint32_t i = tid; i < N; i += ANCHOR_WG) {
+            const uint32_t v = cs[i];
+            if (v) atomicAdd(&colsums[i], (unsigned long long)v);
+        }
+    }
+}
+
 template <int TILE>
 struct Geo {
     static constexpr int NQUAD = ANCHOR_WG / 4;
@@ -354,13 +403,14 @@ __global__ __launch_bounds__(ANCHOR_WG) void k_anchor(const TableDesc T, const u
     const uint32_t bin0_start = bin0 * binlen;
     const int lane = tid & 63;
     const bool want_cs = (flags & 1u) != 0;
+    const bool stats = (flags & 2u) == 0;  // rows-only mode leaves the statistics to k_rows_epilogue
 #pragma unroll 1
     for (int jj = 0; jj < G::PER_THREAD; ++jj) {
         const uint32_t pl = jj * ANCHOR_WG + tid;
         const bool active = pl < npos;
         const uint32_t pos = tile_start + pl;
         uint32_t popc = 0;
-        const bool is100 = active && (pos % 100u == 0);
+        const bool is100 = stats && active && (pos % 100u == 0);
 #pragma unroll
         for (uint32_t d = 0; d < (NDBS_C ? (uint32_t)NDBS_C : ndbs); ++d) {
             const uint32_t wv = active ? res[pl * ndbs + d] : 0u;
@@ -380,48 +430,12 @@ __global__ __launch_bounds__(ANCHOR_WG) void k_anchor(const TableDesc T, const u
                 uint8_t *o100 = out100 + a.out100_off + (uint64_t)(pos / 100u) * nbytes + 4 * d;
                 for (uint32_t bb = 0; bb < nb; ++bb) o100[bb] = (uint8_t)(wv >> (8 * bb));
             }
-            if (want_cs) {
-                const uint32_t ng = min(32u, N - 32 * d);
-                for (uint32_t bit = 0; bit < ng; ++bit) {
-                    const unsigned long long bal = __ballot((wv >> bit) & 1u);
-                    if (lane == 0 && bal) atomicAdd(&cs[32 * d + bit], (uint32_t)__popcll(bal));
-                }
-            }
+            if (stats && want_cs) colsum_word(wv, d, N, cs, lane);
         }
-        if (popc > N) popc = N;  // junk bits beyond ngenomes: the reference indexes out of bounds here
-        // wave-aggregated histogram of (bin, popcount)
-        const uint32_t dpos = pos - bin0_start;
-        const uint32_t rel = (binlen >= (uint32_t)TILE) ? (dpos >= binlen ? 1u : 0u) : dpos / binlen;
-        const uint32_t hk = rel * (N + 1) + popc;
-        unsigned long long todo = __ballot(active);
-        while (todo) {
-            const int leader = __ffsll((long long)todo) - 1;
-            const uint32_t lk = __shfl(hk, leader);
-            const unsigned long long m = __ballot(active && hk == lk) & todo;
-            if (lane == leader) {
-                const uint32_t cnt = (uint32_t)__popcll(m);
-                if (rel < 2) atomicAdd(&hist[hk], cnt);
-                else atomicAdd(&bins[(a.bin_off + bin0 + rel) * (uint64_t)(N + 1) + popc], cnt);
-            }
-            todo &= ~m;
-        }
+        if (stats) hist_position<TILE>(active, pos, popc, N, binlen, bin0, bin0_start, hist, bins, a.bin_off, lane);
     }
     __syncthreads();
-
-    // flush histogram / column sums
-    for (uint32_t i = tid; i < 2 * (N + 1); i += ANCHOR_WG) {
-        const uint32_t hv = hist[i];
-        if (hv) {
-            const uint32_t rel = i / (N + 1), pc = i - rel * (N + 1);
-            atomicAdd(&bins[(a.bin_off + bin0 + rel) * (uint64_t)(N + 1) + pc], hv);
-        }
-    }
-    if (want_cs) {
-        for (uint32_t i = tid; i < N; i += ANCHOR_WG) {
-            const uint32_t v = cs[i];
-            if (v) atomicAdd(&colsums[i], (unsigned long long)v);
-        }
-    }
+    if (stats) flush_stats(N, hist, cs, bins, colsums, a.bin_off, bin0, want_cs, tid);
     // bitmap.1 tile: coalesced 16-byte stores (tile base is 16-byte aligned)
     {
         uint8_t *g = out1 + a.out_off + (uint64_t)tile_start * nbytes;
@@ -432,6 +446,58 @@ __global__ __launch_bounds__(ANCHOR_WG) void k_anchor(const TableDesc T, const u
         for (uint32_t i = tid; i < nvec; i += ANCHOR_WG) dst[i] = src[i];
         for (uint32_t i = (nvec << 4) + tid; i < total; i += ANCHOR_WG) g[i] = rows[i];
     }
+}
+
+// ---------------------------------------------------------------------------
+// Statistics pass over FINISHED rows (genome-sharded mode: every GPU anchors all positions
+// against its own genomes' table, the partial rows are combined over xGMI, then each row's
+// popcount histogram / column sums / 1-in-100 rows are taken from the combined bytes).
+// Streaming: nbytes read per position.
+// ---------------------------------------------------------------------------
+template <int TILE>
+__global__ __launch_bounds__(ANCHOR_WG) void k_rows_epilogue(uint32_t N, const AnchorDesc *__restrict__ ad,
+                                                             const uint32_t *__restrict__ tile_contig,
+                                                             const uint8_t *__restrict__ out1,
+                                                             uint8_t *__restrict__ out100,
+                                                             uint32_t *__restrict__ bins,
+                                                             unsigned long long *__restrict__ colsums,
+                                                             uint32_t flags) {
+    extern __shared__ uint4 smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const uint32_t nbytes = (N + 7) / 8, ndbs = (N + 31) / 32;
+    uint32_t *hist = reinterpret_cast<uint32_t *>(smem);
+    uint32_t *cs = hist + ((2 * (N + 1) + 3) & ~3u);
+    const uint32_t c = tile_contig[blockIdx.x];
+    const AnchorDesc a = ad[c];
+    const uint32_t tile_start = (blockIdx.x - a.tile0) * TILE;
+    const uint32_t npos = min((uint32_t)TILE, a.nkmers - tile_start);
+    for (uint32_t i = tid; i < 2 * (N + 1); i += ANCHOR_WG) hist[i] = 0;
+    for (uint32_t i = tid; i < N; i += ANCHOR_WG) cs[i] = 0;
+    __syncthreads();
+    const uint32_t binlen = a.binlen, bin0 = tile_start / binlen, bin0_start = bin0 * binlen;
+    const bool want_cs = (flags & 1u) != 0;
+    const uint8_t *g = out1 + a.out_off + (uint64_t)tile_start * nbytes;
+    for (uint32_t pl = tid; pl < (uint32_t)TILE; pl += ANCHOR_WG) {
+        const bool active = pl < npos;
+        const uint32_t pos = tile_start + pl;
+        uint32_t popc = 0;
+        const bool is100 = active && (pos % 100u == 0);
+        for (uint32_t d = 0; d < ndbs; ++d) {
+            const uint32_t nb = min(4u, nbytes - 4 * d);
+            uint32_t wv = 0;
+            if (active)
+                for (uint32_t bb = 0; bb < nb; ++bb) wv |= (uint32_t)g[(uint64_t)pl * nbytes + 4 * d + bb] << (8 * bb);
+            popc += __popc(wv);
+            if (is100) {
+                uint8_t *o100 = out100 + a.out100_off + (uint64_t)(pos / 100u) * nbytes + 4 * d;
+                for (uint32_t bb = 0; bb < nb; ++bb) o100[bb] = (uint8_t)(wv >> (8 * bb));
+            }
+            if (want_cs) colsum_word(wv, d, N, cs, lane);
+        }
+        hist_position<TILE>(active, pos, popc, N, binlen, bin0, bin0_start, hist, bins, a.bin_off, lane);
+    }
+    __syncthreads();
+    flush_stats(N, hist, cs, bins, colsums, a.bin_off, bin0, want_cs, tid);
 }
 
 // ---------------------------------------------------------------------------
@@ -549,6 +615,16 @@ hipError_t launch_anchor(hipStream_t st, const TableDesc &T, const uint64_t *seq
     if (T.ndbs == 2 && nbytes == 8) return launch_anchor_t<2, 8>(PG_ARGS);
     return launch_anchor_t<0, 0>(PG_ARGS);
 #undef PG_ARGS
+}
+
+hipError_t launch_rows_epilogue(hipStream_t st, uint32_t ngenomes, const AnchorDesc *ad, const uint32_t *tile_contig,
+                                uint32_t ntiles, const uint8_t *out1, uint8_t *out100, uint32_t *bins,
+                                unsigned long long *colsums, uint32_t flags) {
+    if (ntiles == 0) return hipSuccess;
+    size_t lds = (((2 * (ngenomes + 1) + 3) & ~3u) + ((ngenomes + 3) & ~3u)) * 4 + 16;
+    hipLaunchKernelGGL(k_rows_epilogue<ANCHOR_TILE>, dim3(ntiles), dim3(ANCHOR_WG), lds, st, ngenomes, ad,
+                       tile_contig, out1, out100, bins, colsums, flags);
+    return hipGetLastError();
 }
 
 }  // namespace pg

@@ -11,7 +11,7 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 
 from . import _lib
-from ._lib import PG_ANCHOR_COLSUMS, PanagramHipError, check  # noqa: F401
+from ._lib import PG_ANCHOR_COLSUMS, PG_ANCHOR_ROWS_ONLY, PanagramHipError, check  # noqa: F401
 
 
 def _ptr(a: Optional[np.ndarray]):
@@ -186,17 +186,31 @@ class PanTable:
 class AnchorResult:
     """Device-resident outputs of anchoring one SeqSet against one PanTable."""
 
-    def __init__(self, table: PanTable, seqs: SeqSet, colsums: bool = True):
+    def __init__(self, table: PanTable, seqs: SeqSet, colsums: bool = True, rows_only: bool = False):
         self.table, self.seqs = table, seqs
         self._lib = table._lib
         h = C.c_void_p()
-        self.flags = PG_ANCHOR_COLSUMS if colsums else 0
+        self.flags = (PG_ANCHOR_COLSUMS if colsums else 0) | (PG_ANCHOR_ROWS_ONLY if rows_only else 0)
         check(self._lib.pg_result_create(table._h, seqs._h, self.flags, C.byref(h)))
         self._h = h
 
     def run(self) -> None:
         """Enqueue the anchor kernels (asynchronous)."""
         check(self._lib.pg_anchor_run(self._h))
+
+    def rows_epilogue(self) -> None:
+        """bitmap.100 / bins / column sums from the (combined) rows in the device buffer (async)."""
+        check(self._lib.pg_rows_epilogue(self._h))
+
+    def rows_tensor(self):
+        """Zero-copy torch uint8 view of the device bitmap.1 buffer (for RCCL collectives)."""
+        import torch
+        (ptr, nbytes), _ = self.device_ptrs()
+
+        class _Wrap:
+            __cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 3}
+
+        return torch.as_tensor(_Wrap(), device=torch.device("cuda", self.table.ctx.device))
 
     def contig_info(self, idx: int) -> dict:
         nk, n100 = C.c_uint64(), C.c_uint64()

@@ -445,6 +445,51 @@ class Genome:
         self.set_chrs(pd.read_table(self.chrs_fname, index_col="name"))
 
     # ---- WRITE: the hot path ----
+    def anchor_contigs(self, table: engine.PanTable, seqs: Sequence[bytes]):
+        """GPU compute for a list of contigs: returns ([(rows, rows100, bins, info)], colsums)."""
+        ctx = table.ctx
+        ss = engine.SeqSet.from_host(ctx, seqs)
+        res = engine.AnchorResult(table, ss, colsums=True)
+        res.run()
+        out = [res.download(ci) for ci in range(len(seqs))]
+        cs = res.colsums().astype(np.int64)
+        res.close()
+        ss.close()
+        return out, cs
+
+    def write_outputs(self, names: Sequence[str], results, paircount_sums: np.ndarray,
+                      bgzf_threads: Optional[int] = None):
+        """Write anchor/<name>/ exactly as the reference lays it out (cpp/anchor.cpp:37-109,
+        index.py:1035-1094).  ``results[i] = (rows, rows100, bins, info)`` for contig i in
+        FASTA order; files are written to temporaries and renamed, chrs.tsv last."""
+        N = self.ngenomes
+        os.makedirs(self.prefix, exist_ok=True)
+        nthreads = bgzf_threads or max(1, min(32, self.index.cores if self.index.cores > 1 else (os.cpu_count() or 1)))
+        tmp = {s: self.bitmap_gz_fname(s) + ".tmp" for s in self.steps}
+        writers = {s: engine.BgzfWriter(tmp[s], level=6, threads=nthreads) for s in self.steps}
+        bins_rows: List[str] = ["chr\tstart" + "".join(f"\t{i}" for i in range(N + 1)) + "\n"]
+        chr_rows: List[Tuple[str, int, int, int]] = []
+        for ci, (chrom, (rows, rows100, bins, info)) in enumerate(zip(names, results)):
+            writers[1].write(rows)
+            writers[self.steps[1]].write(rows100)
+            for b in range(info["nbins"]):
+                bins_rows.append(f"{ci}\t{b * info['binlen']}" + "".join(f"\t{int(c)}" for c in bins[b]) + "\n")
+            chr_rows.append((chrom, ci, info["nkmers"], 0))
+            logger.info(f"Anchored {chrom}")
+        for s in self.steps:
+            writers[s].close(self.bitmap_gzi_fname(s) + ".tmp")
+            os.replace(tmp[s], self.bitmap_gz_fname(s))
+            os.replace(self.bitmap_gzi_fname(s) + ".tmp", self.bitmap_gzi_fname(s))
+        with open(self.bins_fname, "w") as f:
+            f.writelines(bins_rows)
+        # total_paircounts.csv (index.py:1068-1074): count[g] = positions holding genome g's bit
+        counts = pd.Series(np.asarray(paircount_sums, dtype=np.int64), index=self.index.genome_names)
+        pd.DataFrame({"count": counts, "frac": counts / counts[self.name]}).to_csv(
+            os.path.join(self.prefix, "total_paircounts.csv"))
+        chrs = pd.DataFrame(chr_rows, columns=["name", "id", "size", "gene_count"]).set_index("name")
+        self.set_chrs(chrs)
+        self.chrs.to_csv(self.chrs_fname, sep="\t")  # written last: it is the rule's completion marker
+
     def run_anchor(self, table: engine.PanTable, logfile: Optional[str] = None, bgzf_threads: Optional[int] = None):
         """Counterpart of ``Genome.run_anchor(bitvecs, logfile)`` (index.py:1012-1097) and of
         ``KMCdb::anchor_fasta`` (cpp/anchor.cpp:37-109): walks the anchor FASTA, anchors every
@@ -456,48 +501,13 @@ class Genome:
         if not self.anchored:
             logger.info(f"Skipping non-anchor genome '{self.name}'")
             return
-        ctx = table.ctx
-        N = self.ngenomes
-        os.makedirs(self.prefix, exist_ok=True)
         recs = list(self.iter_fasta())
-        short = [nm for nm, s in recs if len(s) < table.k]
-        for nm in short:
-            logger.warning(f"Contig {nm} is shorter than k={table.k}: 0 k-mers (the reference underflows here)")
-        nthreads = bgzf_threads or max(1, min(32, self.index.cores if self.index.cores > 1 else (os.cpu_count() or 1)))
-        tmp = {s: self.bitmap_gz_fname(s) + ".tmp" for s in self.steps}
-        writers = {s: engine.BgzfWriter(tmp[s], level=6, threads=nthreads) for s in self.steps}
+        for nm, s in recs:
+            if len(s) < table.k:
+                logger.warning(f"Contig {nm} is shorter than k={table.k}: 0 k-mers (the reference underflows here)")
         logger.info("Anchoring Started")
-
-        ss = engine.SeqSet.from_host(ctx, [s for _, s in recs])
-        res = engine.AnchorResult(table, ss, colsums=True)
-        res.run()
-        bins_rows: List[str] = ["chr\tstart" + "".join(f"\t{i}" for i in range(N + 1)) + "\n"]
-        chr_rows: List[Tuple[str, int, int, int]] = []
-        for ci, (chrom, _) in enumerate(recs):
-            rows, rows100, bins, info = res.download(ci)
-            writers[1].write(rows)
-            writers[self.steps[1]].write(rows100)
-            for b in range(info["nbins"]):
-                bins_rows.append(f"{ci}\t{b * info['binlen']}" + "".join(f"\t{int(c)}" for c in bins[b]) + "\n")
-            chr_rows.append((chrom, ci, info["nkmers"], 0))
-            logger.info(f"Anchored {chrom}")
-        paircount_sums = res.colsums().astype(np.int64)
-        res.close()
-        ss.close()
-
-        for s in self.steps:
-            writers[s].close(self.bitmap_gzi_fname(s) + ".tmp")
-            os.replace(tmp[s], self.bitmap_gz_fname(s))
-            os.replace(self.bitmap_gzi_fname(s) + ".tmp", self.bitmap_gzi_fname(s))
-        with open(self.bins_fname, "w") as f:
-            f.writelines(bins_rows)
-        # total_paircounts.csv (index.py:1068-1074): count[g] = positions holding genome g's bit
-        counts = pd.Series(paircount_sums, index=self.index.genome_names)
-        pd.DataFrame({"count": counts, "frac": counts / counts[self.name]}).to_csv(
-            os.path.join(self.prefix, "total_paircounts.csv"))
-        chrs = pd.DataFrame(chr_rows, columns=["name", "id", "size", "gene_count"]).set_index("name")
-        self.set_chrs(chrs)
-        self.chrs.to_csv(self.chrs_fname, sep="\t")  # written last: it is the rule's completion marker
+        results, cs = self.anchor_contigs(table, [s for _, s in recs])
+        self.write_outputs([nm for nm, _ in recs], results, cs, bgzf_threads)
 
     # ---- READ: what `panagram view` does with our files (index.py:615-658, 793-845) ----
     def init_read(self):

@@ -1,0 +1,90 @@
+"""CPU, world_size 2 over gloo: the multi-GPU host logic (sharding plan, part-file assembly,
+row combine).  The per-contig compute is injected (the oracle stands in for the GPU) so the
+N>1 control path runs here without a device."""
+import gzip
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import pyoracle as po
+from tests import helpers as H
+
+
+def test_plan_shards_is_balanced_and_deterministic():
+    from panagram_amd.distributed import plan_shards
+    units = [(f"g{g}", c, n) for g in range(5) for c, n in enumerate([3000, 2000, 2300, 1900, 2700, 10])]
+    for world in (1, 2, 3, 8):
+        sh = plan_shards(units, world)
+        assert sorted(u for s in sh for u in s) == sorted(units)
+        loads = [sum(u[2] for u in s) for s in sh]
+        assert max(loads) - min(loads) <= max(u[2] for u in units)
+        assert sh == plan_shards(list(reversed(units)), world)
+
+
+def _oracle_anchor_fn(dbs, k, n):
+    def fn(genome, seqs):
+        out, cs = [], np.zeros(n, np.int64)
+        for s in seqs:
+            rows, rows100, bins, starts, c = po.anchor_contig(dbs, s, k, n)
+            info = dict(nkmers=len(rows), nbins=len(bins), binlen=po.bin_length(len(rows)), nrows100=len(rows100))
+            out.append((rows, rows100, bins, info))
+            cs += c
+        return out, cs
+    return fn
+
+
+def _worker(rank, world, port, root, name):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from panagram_amd import index as pidx
+        from panagram_amd.distributed import combine_rows_, combine_rows_allgather, genome_owner, run_index_sharded
+        fx = H.load_case(name)
+        n, k = int(fx["ngenomes"]), int(fx["k"])
+        dbs = H.case_dbs(fx)
+        idx = pidx.Index(os.path.join(root, "idx"), mode="w")
+        run_index_sharded(idx, rank, world, dist.barrier, anchor_fn=_oracle_anchor_fn(dbs, k, n))
+        # genome-sharded combine: each rank holds rows with only its genomes' bits
+        g = int(fx["anchors"][0])
+        full = np.frombuffer(fx[f"a{g}_bitmap1"].tobytes(), np.uint8).copy()
+        nb = (n + 7) // 8
+        keep = np.zeros(nb * 8, np.uint8)
+        for gg in range(n):
+            keep[gg] = genome_owner(gg, n, world) == rank
+        mask = np.packbits(keep.reshape(nb, 8), axis=1, bitorder="little").reshape(-1)
+        part = (full.reshape(-1, nb) & mask).reshape(-1)
+        t = torch.from_numpy(part.copy())
+        ag = combine_rows_allgather(t)
+        combine_rows_(t)
+        assert np.array_equal(t.numpy(), full) and np.array_equal(ag.numpy(), full)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name", ["n9_k21", "n65_k21"])
+def test_world2_sharded_index_equals_reference(name, tmp_path):
+    from panagram_amd import index as pidx
+    fx = H.load_case(name)
+    n = int(fx["ngenomes"])
+    rows = ["name\tfasta"]
+    for g in range(n):
+        fa = tmp_path / f"g{g}.fa"
+        fa.write_bytes(fx[f"fasta_{g}"].tobytes())
+        rows.append(f"g{g}\t{fa}")
+    s = tmp_path / "samples.tsv"
+    s.write_text("\n".join(rows) + "\n")
+    pidx.Index(str(s), prefix=str(tmp_path / "idx"), k=int(fx["k"]), prepare=True,
+               anchor_genomes=[f"g{g}" for g in fx["anchors"]])
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(2, port, str(tmp_path), name), nprocs=2, join=True)
+    for g in fx["anchors"]:
+        adir = tmp_path / "idx" / "anchor" / f"g{g}"
+        assert gzip.open(adir / "bitmap.1.gz", "rb").read() == fx[f"a{g}_bitmap1"].tobytes()
+        assert gzip.open(adir / "bitmap.100.gz", "rb").read() == fx[f"a{g}_bitmap100"].tobytes()
+        assert (adir / "bitsum.bins.tsv").read_bytes() == fx[f"a{g}_bitsum.bins.tsv"].tobytes()
+        assert (adir / "chrs.tsv").read_bytes() == fx[f"a{g}_chrs.tsv"].tobytes()
+        assert not (adir / ".parts").exists()
