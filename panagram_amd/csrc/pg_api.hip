@@ -95,9 +95,9 @@ struct pg_result {
     unsigned long long *d_colsums;
 };
 
-static constexpr uint32_t MAX_PROBE = 64;
-static constexpr double GROW_AT = 0.65;     // grow when keys > GROW_AT * slots
-static constexpr double TARGET_LOAD = 0.45; // load right after growing
+static constexpr uint32_t MAX_PROBE = 512;  // lines an insert may walk before the table is grown
+static constexpr double GROW_AT = 0.55;     // grow when keys > GROW_AT * slots
+static constexpr double TARGET_LOAD = 0.375; // load right after growing (3 keys per 8-slot line)
 static constexpr double HARD_LOAD = 0.85;   // worst-case guard before a batch
 
 static int use_device(const pg_ctx *c) {
@@ -153,12 +153,32 @@ extern "C" int pg_ctx_synchronize(pg_ctx *c) {
 // ---------------------------------------------------------------------------
 // table
 // ---------------------------------------------------------------------------
-static int alloc_sub(pg_ctx *ctx, uint32_t W, uint32_t word0, uint64_t nbuckets, SubTable *out) {
+// smallest prime >= n: the probe sequence home + i*step (mod nlines) must visit every line
+// for every step, which needs gcd(step, nlines) == 1
+static uint64_t next_prime(uint64_t n) {
+    if (n < 3) return 3;
+    n |= 1;
+    for (;; n += 2) {
+        bool prime = true;
+        for (uint64_t d = 3; d * d <= n; d += 2)
+            if (n % d == 0) {
+                prime = false;
+                break;
+            }
+        if (prime) return n;
+    }
+}
+
+static int alloc_sub(pg_ctx *ctx, uint32_t W, uint32_t word0, uint32_t k, uint64_t nbuckets, SubTable *out) {
     if (nbuckets < 64) nbuckets = 64;
-    if (nbuckets > 0xFFFFFFFFull) return fail(PG_E_CAPACITY, "sub-table would exceed 2^32 buckets (256 GB)");
+    nbuckets = next_prime(nbuckets);
+    if (nbuckets > 0xFFFFFFFFull) return fail(PG_E_CAPACITY, "sub-table would exceed 2^32 lines (512 GB)");
     SubTable t;
     t.W = W;
     t.word0 = word0;
+    t.k = k;
+    const uint32_t w = minimizer_window(k);
+    t.m = w ? k - w + 1 : 0;
     t.nbuckets = nbuckets;
     void *p = nullptr;
     hipError_t e = hipMalloc(&p, nbuckets * BUCKET_BYTES);
@@ -197,7 +217,7 @@ extern "C" int pg_table_create(pg_ctx *ctx, int k, int ngenomes, uint64_t expect
         uint64_t nb = (uint64_t)((double)want / (TARGET_LOAD * slots_per_bucket(W))) + 1;
         SubHost sh;
         sh.count = 0;
-        int r = alloc_sub(ctx, W, 2 * s, nb, &sh.d);
+        int r = alloc_sub(ctx, W, 2 * s, (uint32_t)k, nb, &sh.d);
         if (r) {
             pg_table_destroy(t);
             return r;
@@ -233,7 +253,7 @@ static int regrow(pg_table *t, int si, uint64_t nb) {
     pg_ctx *ctx = t->ctx;
     for (int attempt = 0; attempt < 8; ++attempt) {
         SubTable nt;
-        if (int r = alloc_sub(ctx, t->subs[si].d.W, t->subs[si].d.word0, nb, &nt)) return r;
+        if (int r = alloc_sub(ctx, t->subs[si].d.W, t->subs[si].d.word0, (uint32_t)t->k, nb, &nt)) return r;
         HIP_TRY(hipMemsetAsync(t->d_counters, 0, 2 * sizeof(unsigned long long), ctx->stream));
         HIP_TRY(launch_rehash(ctx->stream, t->subs[si].d, nt, t->d_counters, MAX_PROBE));
         unsigned long long c[2];
@@ -425,7 +445,7 @@ extern "C" int pg_table_stats(pg_table *t, uint64_t *nkeys, uint64_t *nslots, ui
 
 extern "C" int pg_table_rehash(pg_table *t, double keys_per_bucket) {
     if (!t) return fail(PG_E_INVALID, "table is NULL");
-    if (!(keys_per_bucket > 0.05 && keys_per_bucket <= 4.0)) return fail(PG_E_INVALID, "keys_per_bucket must be in (0.05, 4]");
+    if (!(keys_per_bucket > 0.05 && keys_per_bucket <= 8.0)) return fail(PG_E_INVALID, "keys_per_bucket must be in (0.05, 8]");
     if (int r = use_device(t->ctx)) return r;
     for (size_t si = 0; si < t->subs.size(); ++si) {
         double kpb = std::min(keys_per_bucket, 0.8 * slots_per_bucket(t->subs[si].d.W));

@@ -1,15 +1,23 @@
 // pg_device.h — device-side building blocks shared by the gfx950 kernels.
 //
 // Table layout (one sub-table covers W = 1 or 2 consecutive 32-genome groups):
-//   bucket = 64 bytes, 64-byte aligned = one HBM fetch per probe
-//          = 4 slots x { u64 key ; u32 mask0 ; u32 mask1 }   (mask1 unused when W == 1)
-//   so that the four lanes of a quad each hold ONE complete slot of the bucket after a
-//   single 16-byte load: the match is lane-local, no cross-lane traffic for the masks.
-//   EMPTY key = ~0 (never a canonical k-mer for k <= 32: the all-T k-mer's
-//   reverse complement is 0).  Keys only ever go EMPTY -> key, masks only gain
-//   bits, so inserts need one 64-bit CAS + one 32-bit OR and no locks.
-//   Collision policy: bucketed linear probing — a lookup moves to the next
-//   bucket only when the key is absent AND the bucket has no EMPTY slot.
+//   line   = 128 bytes, 128-byte aligned: MI355X moves 128 B per random HBM access whatever
+//            the request size (tools/gather_bench.hip: 32/64/128-B random gathers all run at
+//            ~50 G requests/s), so a probe fetches — and uses — a whole line
+//          = 8 slots x { u64 key ; u32 mask0 ; u32 mask1 }   (mask1 unused when W == 1)
+//   a quad probes one line: lane j holds slots j and j+4 after two 16-byte loads, the match is
+//   lane-local and the masks are OR-reduced over the quad with two DPP quad-permutes.
+//   EMPTY key = ~0 (never a canonical k-mer for k <= 32: the all-T k-mer's reverse complement
+//   is 0).  Keys only ever go EMPTY -> key, masks only gain bits: inserts are one 64-bit CAS +
+//   one 32-bit OR, no locks.
+//
+// Home line = LOCALITY hash.  For 20 <= k <= 31 the home of a k-mer is a hash of its
+// MINIMIZER: the smallest (in a scrambled order) canonical m-mer among its w = k-m+1 m-mers,
+// w in {8,12,16}, m in 13..16.  Consecutive k-mers of a sequence share their minimizer for
+// ~(w+1)/2 positions, so consecutive anchor positions probe the SAME line: one HBM fetch
+// serves a run of positions (L1/L2 absorb the repeats).  Other k fall back to hashing the
+// k-mer itself (m = 0).  Collisions: linear probing by line; a lookup moves to the next line
+// only when the key is absent AND the line has no EMPTY slot.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -17,14 +25,17 @@
 namespace pg {
 
 constexpr uint64_t EMPTY_KEY = ~0ull;
-constexpr int BUCKET_BYTES = 64;
+constexpr int BUCKET_BYTES = 128;
+constexpr int SLOTS = 8;
 constexpr int MAX_SUB = 8;  // sub-tables per pan table => up to 512 genomes
 
 struct SubTable {
     uint8_t *buckets;
-    uint64_t nbuckets;
-    uint32_t W;      // mask words per slot
-    uint32_t word0;  // first 32-genome group covered
+    uint64_t nbuckets;  // lines
+    uint32_t W;         // mask words per slot in use
+    uint32_t word0;     // first 32-genome group covered
+    uint32_t k;
+    uint32_t m;         // minimizer length (0 = hash the whole k-mer)
 };
 
 struct TableDesc {
@@ -35,45 +46,94 @@ struct TableDesc {
     uint32_t ngenomes;
 };
 
-constexpr int SLOTS = 4;
 __host__ __device__ __forceinline__ int slots_per_bucket(uint32_t) { return SLOTS; }
 __host__ __device__ __forceinline__ uint32_t key_off(uint32_t, int s) { return 16u * s; }
 __host__ __device__ __forceinline__ uint32_t mask_off(uint32_t, int s, int w) { return 16u * s + 8u + 4u * w; }
 
-// murmur3 finaliser: a bijection on u64, so distinct keys never alias before the
-// range reduction.
-__host__ __device__ __forceinline__ uint64_t mix64(uint64_t x) {
-    x ^= x >> 33;
-    x *= 0xff51afd7ed558ccdull;
-    x ^= x >> 33;
-    x *= 0xc4ceb9fe1a85ec53ull;
-    x ^= x >> 33;
-    return x;
+// minimizer window for a given k: w in {8,12,16} with m = k-w+1 in 13..16, else 0 (direct)
+__host__ __device__ __forceinline__ uint32_t minimizer_window(uint32_t k) {
+    if (k >= 28 && k <= 31) return 16;
+    if (k >= 24 && k <= 27) return 12;
+    if (k >= 20 && k <= 23) return 8;
+    return 0;
 }
 
-__device__ __forceinline__ uint64_t home_bucket(uint64_t key, uint64_t nbuckets) {
-    return __umul64hi(mix64(key), nbuckets);
+// ---- hashing ------------------------------------------------------------------
+__host__ __device__ __forceinline__ uint32_t fmix32(uint32_t h) {
+    h ^= h >> 16;
+    h *= 0x85ebca6bu;
+    h ^= h >> 13;
+    h *= 0xc2b2ae35u;
+    h ^= h >> 16;
+    return h;
+}
+// scrambled order of canonical m-mers (a bijection on 32 bits: ties only between equal m-mers)
+__host__ __device__ __forceinline__ uint32_t mz_order(uint32_t c) { return c * 0x9E3779B1u; }
+
+__device__ __forceinline__ uint32_t range32(uint32_t h, uint64_t n) { return __umulhi(h, (uint32_t)n); }
+
+// Probe sequence of a group = home, home+step, home+2*step, ... (mod nlines): DOUBLE hashing on
+// the group id (minimizer, or the k-mer itself in direct mode).  Every k-mer of a group walks
+// the same sequence, so a group that spills stays together; and because spilled groups jump
+// to unrelated lines, full lines do not pile up into long chains the way +1 probing does.
+__device__ __forceinline__ uint32_t group_of_key(uint64_t key) {
+    return (uint32_t)key ^ fmix32((uint32_t)(key >> 32) + 0x9E3779B9u);
+}
+__device__ __forceinline__ uint32_t home_of_group(uint32_t g, uint64_t nlines) { return range32(fmix32(g), nlines); }
+__device__ __forceinline__ uint32_t step_of_group(uint32_t g, uint64_t nlines) {
+    return 1u + range32(fmix32(g ^ 0x5bd1e995u), nlines - 1);
+}
+__device__ __forceinline__ uint32_t next_line(uint32_t line, uint32_t step, uint64_t nlines) {
+    const uint64_t n = (uint64_t)line + step;
+    return (uint32_t)(n >= nlines ? n - nlines : n);
 }
 
 // ---- packed sequence ------------------------------------------------------
-// base i of a contig lives in bits [2*(i%32), 2*(i%32)+1] of u64 word i/32
-// (little-endian in the word); the "not ACGT" plane has bit i%32 of u32 word i/32.
+// base i of a contig lives in bits [2*(i%32), 2*(i%32)+1] of u64 word i/32 (little-endian in
+// the word); the "not ACGT" plane has bit i%32 of u32 word i/32.
 //
-// For a window x = bases [p, p+k) extracted little-endian (first base in the low
-// bits):   value(revcomp) = ~x & kmask          (complement, order already reversed)
-//          value(fwd)     = pairreverse(x) >> (64-2k)
-// with value() = first base most significant (KMC order).
+// Notation used everywhere:  X = LE window of a k-mer (first base in the low bits),
+//   B = LE window of its reverse complement = pairreverse(~X) >> (64-2k).
+//   value() = first base most significant (KMC order):
+//   value(fwd) = ~B & kmask,  value(revcomp) = ~X & kmask,
+//   canonical key = min of the two = ~max(X, B) & kmask.
 __device__ __forceinline__ uint64_t pair_reverse64(uint64_t x) {
     uint64_t r = __brevll(x);
     return ((r >> 1) & 0x5555555555555555ull) | ((r & 0x5555555555555555ull) << 1);
 }
+__device__ __forceinline__ uint64_t kmer_mask(int k) { return (k == 32) ? ~0ull : ((1ull << (2 * k)) - 1); }
 
+__device__ __forceinline__ uint64_t revcomp_le(uint64_t X, int k) {
+    return (pair_reverse64(~X) >> (64 - 2 * k)) & kmer_mask(k);
+}
+__device__ __forceinline__ uint64_t canonical_from_xb(uint64_t X, uint64_t B, int k) {
+    return ~(X > B ? X : B) & kmer_mask(k);
+}
 __device__ __forceinline__ uint64_t canonical_from_le(uint64_t x, int k) {
-    const uint64_t kmask = (k == 32) ? ~0ull : ((1ull << (2 * k)) - 1);
-    x &= kmask;
-    uint64_t rc = (~x) & kmask;
-    uint64_t fw = pair_reverse64(x) >> (64 - 2 * k);
-    return fw < rc ? fw : rc;
+    x &= kmer_mask(k);
+    return canonical_from_xb(x, revcomp_le(x, k), k);
+}
+
+// minimizer of a k-mer given X and B (generic, runtime w).  Symmetric in X <-> B.
+__device__ __forceinline__ uint32_t minimizer_from_xb(uint64_t X, uint64_t B, uint32_t m, uint32_t w) {
+    const uint32_t mm = (m == 16) ? ~0u : ((1u << (2 * m)) - 1);
+    uint32_t best = ~0u;
+    for (uint32_t i = 0; i < w; ++i) {
+        const uint32_t a = (uint32_t)(X >> (2 * i)) & mm;
+        const uint32_t b = (uint32_t)(B >> (2 * (w - 1 - i))) & mm;
+        const uint32_t h = mz_order(a < b ? a : b);
+        best = h < best ? h : best;
+    }
+    return best;
+}
+
+// group id of a canonical key (insert / single-lane lookup / rehash path)
+__device__ __forceinline__ uint32_t group_of(const SubTable &st, uint64_t key) {
+    if (st.m == 0) return group_of_key(key);
+    const int k = (int)st.k;
+    const uint64_t X = pair_reverse64(key) >> (64 - 2 * k);  // LE window of the canonical strand
+    const uint64_t B = ~key & kmer_mask(k);                  // LE window of the other strand
+    return minimizer_from_xb(X, B, st.m, st.k - st.m + 1);
 }
 
 // 64 bits (32 bases) starting at base p of a word array (works for LDS or global)
@@ -96,8 +156,17 @@ __device__ __forceinline__ uint32_t extract_nmask(P words, uint64_t p, int k) {
     uint32_t km = (k == 32) ? 0xFFFFFFFFu : ((1u << k) - 1);
     return (uint32_t)v & km;
 }
+// 64 "not ACGT" bits starting at base p (reads three u32 words)
+template <typename P>
+__device__ __forceinline__ uint64_t extract_nmask64(P words, uint64_t p) {
+    uint64_t w = p >> 5;
+    uint32_t sh = (uint32_t)(p & 31);
+    uint64_t lo = (uint64_t)words[w] | ((uint64_t)words[w + 1] << 32);
+    uint64_t hi = (uint64_t)words[w + 2];
+    return sh ? ((lo >> sh) | (hi << (64 - sh))) : lo;
+}
 
-// ---- DPP quad permutes: lanes 4q..4q+3 cooperate on one bucket ---------------
+// ---- DPP quad permutes: lanes 4q..4q+3 cooperate on one line ---------------
 template <int CTRL>
 __device__ __forceinline__ uint32_t quad_perm(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, false);
@@ -112,29 +181,33 @@ __device__ __forceinline__ uint32_t quad_or(uint32_t v) {
     return v;
 }
 
-// Cooperative match of one 64-byte bucket held one 16-byte slot per lane of a quad:
-// v = {key.lo, key.hi, mask0, mask1}.  Returns found; masks are quad-uniform.
-__device__ __forceinline__ bool quad_match(const uint4 v, uint64_t key, uint32_t &m0, uint32_t &m1) {
-    const uint64_t kk = (uint64_t)v.x | ((uint64_t)v.y << 32);
-    const bool hit = (kk == key);
-    m0 = quad_or(hit ? v.z : 0u);
-    m1 = quad_or(hit ? v.w : 0u);
-    return quad_or(hit ? 1u : 0u) != 0;
+// One line held by a quad: lane j has slot j in va and slot j+4 in vb, each
+// {key.lo, key.hi, mask0, mask1}.  A stored key always has a non-zero mask, so
+// "found" == (m0|m1) != 0; the masks come back quad-uniform.
+template <bool TWO>
+__device__ __forceinline__ void quad_match(const uint4 va, const uint4 vb, uint64_t key, uint32_t &m0, uint32_t &m1) {
+    const uint64_t ka = (uint64_t)va.x | ((uint64_t)va.y << 32);
+    const uint64_t kb = (uint64_t)vb.x | ((uint64_t)vb.y << 32);
+    const bool ha = (ka == key), hb = (kb == key);
+    m0 = quad_or((ha ? va.z : 0u) | (hb ? vb.z : 0u));
+    m1 = TWO ? quad_or((ha ? va.w : 0u) | (hb ? vb.w : 0u)) : 0u;
 }
-// no EMPTY slot among the quad's four (only needed on the rare not-found path)
-__device__ __forceinline__ bool quad_full(const uint4 v) {
-    const uint64_t kk = (uint64_t)v.x | ((uint64_t)v.y << 32);
-    return quad_or(kk == EMPTY_KEY ? 1u : 0u) == 0;
+// no EMPTY slot among the line's eight (only needed on the not-found path)
+__device__ __forceinline__ bool quad_full(const uint4 va, const uint4 vb) {
+    const uint64_t ka = (uint64_t)va.x | ((uint64_t)va.y << 32);
+    const uint64_t kb = (uint64_t)vb.x | ((uint64_t)vb.y << 32);
+    return quad_or((ka == EMPTY_KEY || kb == EMPTY_KEY) ? 1u : 0u) == 0;
 }
 
-// Single-lane lookup (used by the GetCountersForRead kernel, export and rehash).
+// Single-lane lookup (GetCountersForRead kernel).
 __device__ __forceinline__ bool lane_lookup(const SubTable &st, uint64_t key, uint32_t &m0, uint32_t &m1) {
-    uint64_t b = home_bucket(key, st.nbuckets);
-    const int ns = slots_per_bucket(st.W);
+    const uint32_t grp = group_of(st, key);
+    uint32_t b = home_of_group(grp, st.nbuckets);
+    const uint32_t step = step_of_group(grp, st.nbuckets);
     for (uint64_t probes = 0; probes < st.nbuckets; ++probes) {
-        const uint8_t *base = st.buckets + b * BUCKET_BYTES;
+        const uint8_t *base = st.buckets + (uint64_t)b * BUCKET_BYTES;
         bool empty_seen = false;
-        for (int s = 0; s < ns; ++s) {
+        for (int s = 0; s < SLOTS; ++s) {
             uint64_t cur = *reinterpret_cast<const uint64_t *>(base + key_off(st.W, s));
             if (cur == key) {
                 m0 = *reinterpret_cast<const uint32_t *>(base + mask_off(st.W, s, 0));
@@ -144,21 +217,22 @@ __device__ __forceinline__ bool lane_lookup(const SubTable &st, uint64_t key, ui
             empty_seen |= (cur == EMPTY_KEY);
         }
         if (empty_seen) break;
-        b = (b + 1 == st.nbuckets) ? 0 : b + 1;
+        b = next_line(b, step, st.nbuckets);
     }
     m0 = m1 = 0;
     return false;
 }
 
 // Insert-or-find `key`, OR `bits` into mask word w.  Returns 0 = existed,
-// 1 = newly claimed, -1 = gave up after max_probe buckets (table must grow).
+// 1 = newly claimed, -1 = gave up after max_probe lines (table must grow).
 __device__ __forceinline__ int lane_insert(const SubTable &st, uint64_t key, int w, uint32_t bits,
                                            uint32_t max_probe) {
-    uint64_t b = home_bucket(key, st.nbuckets);
-    const int ns = slots_per_bucket(st.W);
+    const uint32_t grp = group_of(st, key);
+    uint32_t b = home_of_group(grp, st.nbuckets);
+    const uint32_t step = step_of_group(grp, st.nbuckets);
     for (uint32_t probes = 0; probes < max_probe; ++probes) {
-        uint8_t *base = st.buckets + b * BUCKET_BYTES;
-        for (int s = 0; s < ns; ++s) {
+        uint8_t *base = st.buckets + (uint64_t)b * BUCKET_BYTES;
+        for (int s = 0; s < SLOTS; ++s) {
             unsigned long long *kp = reinterpret_cast<unsigned long long *>(base + key_off(st.W, s));
             unsigned long long cur = *kp;  // a stale EMPTY only costs a failed CAS
             int claimed = 0;
@@ -175,7 +249,7 @@ __device__ __forceinline__ int lane_insert(const SubTable &st, uint64_t key, int
                 return claimed;
             }
         }
-        b = (b + 1 == st.nbuckets) ? 0 : b + 1;
+        b = next_line(b, step, st.nbuckets);
     }
     return -1;
 }

@@ -8,12 +8,19 @@ namespace pg {
 #define PG_ANCHOR_TILE 1024
 #endif
 #ifndef PG_ANCHOR_UNROLL
-#define PG_ANCHOR_UNROLL 8
+#define PG_ANCHOR_UNROLL 4
 #endif
 constexpr int ANCHOR_TILE = PG_ANCHOR_TILE;      // k-mer positions per workgroup
 constexpr int ANCHOR_UNROLL = PG_ANCHOR_UNROLL;  // independent bucket gathers in flight per lane
-constexpr int ANCHOR_WG = 256;                   // threads per workgroup (4 waves, 64 quads)
-constexpr int ANCHOR_RQ = 256;                   // LDS retry-queue entries
+#ifndef PG_ANCHOR_WG
+#define PG_ANCHOR_WG 256
+#endif
+constexpr int ANCHOR_WG = PG_ANCHOR_WG;          // threads per workgroup (64 = one wave: barriers vanish)
+#ifndef PG_ANCHOR_LINES
+#define PG_ANCHOR_LINES (PG_ANCHOR_TILE * 5 / 16)
+#endif
+constexpr int ANCHOR_LINES = PG_ANCHOR_LINES;    // LDS line buffer (128-B table lines) per workgroup
+constexpr int ANCHOR_MAX_ROUNDS = 24;            // queued overflow rounds before chasing a chain inline
 
 // one packed contig of a seqset (offsets in 32-base words, shared by both planes)
 struct SeqDesc {

@@ -80,7 +80,7 @@ def test_config2_fullsize_properties(ctx):
     assert np.array_equal(a, b[::-1])
     # a denser table gives the same bytes
     before = tbl.anchor_contig(seq, colsums=False)[0]
-    tbl.rehash(3.5)
+    tbl.rehash(6.0)
     assert np.array_equal(tbl.anchor_contig(seq, colsums=False)[0], before)
     for s in seqsets:
         s.close()
