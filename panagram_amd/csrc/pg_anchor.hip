@@ -1,0 +1,567 @@
+// pg_anchor.hip — the anchor hot path on gfx950 (CDNA4, wave64): integer / HBM-bound, no MFMA.
+//
+// Replaces (reference, kjenike/panagram): KMC CKMCFile::GetCountersForRead as called from
+// KMCdb::write_bits (cpp/anchor.cpp:112-195) and Genome._write_bitmap / _query_kmc_bytes /
+// bin_bitsum (index.py:932-969,1169-1183).
+//
+// Three lean kernels per (anchor seqset, sub-table); instruction count per position is what
+// bounds them once the table fetches are shared between neighbouring positions:
+//
+//   k_probe      ONE WAVE = one tile of TILE consecutive k-mer positions, no barriers.
+//                Per batch of 64 lanes (lane = one position, neighbours = neighbouring positions):
+//                  * canonical k-mer from the LDS-staged 2-bit sequence (~0.25 B/pos from HBM)
+//                  * minimizer = sliding minimum over the W_C m-mer ranks of the neighbouring
+//                    lanes (wave shuffles) -> home line; runs of equal home line are found with
+//                    one ballot (leaders) and numbered with mbcnt
+//                  * LDS-STAGED PROBE BATCH: the batch's distinct table lines (~13-17 for 57
+//                    positions) are fetched cooperatively and coalesced — 8 lanes x 16 B = one
+//                    128-byte line — into a per-wave LDS buffer, then every lane scans the 8
+//                    slots of ITS line out of LDS
+//                  * the presence row goes straight to bitmap.1; a key absent from a FULL line is
+//                    appended to the tile's overflow worklist (next line of its probe sequence)
+//   k_fixup      dense passes over the overflow worklists (one lane = one entry, 8 slot loads in
+//                flight); found masks are patched into bitmap.1, still-unresolved entries move to
+//                the next pass; the last pass chases inline.
+//   k_epilogue   streaming statistics from the finished bitmap.1 rows: bitmap.100 (1-in-100
+//                rows), per-bin popcount histogram (wave ballots -> LDS -> global), per-genome
+//                column sums.
+//
+// Bytes from HBM per position: 0.25 (sequence) + 128 x (distinct lines per
+// position, ~0.25 with minimizer locality) + row bytes written + row bytes re-read.
+#include "pg_kernels.h"
+
+namespace pg {
+
+// A staged line occupies 144 bytes of LDS (128 + 16 pad): with a 128-byte stride every lane's
+// ds_read_b128 of "its" line would land on one of two bank groups; 144 = 4*36 bytes walks all
+// 16 four-bank groups over 16 consecutive lines.
+constexpr int LDS_LINE_U4 = SLOTS + 1;
+constexpr int PROBE_SEQW = ((PROBE_TILE + 31) / 32 + 6 + 3) & ~3;  // staged 32-base words per tile
+constexpr int STAGE_ITERS = (PROBE_MAXRUN * SLOTS + 63) / 64;       // 16-byte loads per lane per staging step
+
+// scan the 8 slots of a line staged in LDS.  Lines fill front to back without holes (an insert
+// claims the first EMPTY slot and slots never revert), so "full" == last slot used.
+// returns 1 = found, 0 = absent (line not full), -1 = absent from a full line
+template <bool TWO>
+__device__ __forceinline__ int scan_line_lds(const uint4 *line, uint64_t key, uint32_t &m0, uint32_t &m1) {
+    m0 = m1 = 0;
+    uint64_t last = 0;
+#pragma unroll
+    for (int sl = 0; sl < SLOTS; ++sl) {
+        const uint4 v = line[sl];
+        const uint64_t kk = (uint64_t)v.x | ((uint64_t)v.y << 32);
+        const bool hit = (kk == key);
+        m0 = hit ? v.z : m0;
+        if (TWO) m1 = hit ? v.w : m1;
+        if (sl == SLOTS - 1) last = kk;
+    }
+    return (m0 | m1) ? 1 : (last == EMPTY_KEY ? 0 : -1);
+}
+
+// one line straight from global memory: the 8 slot loads are issued together (one latency)
+template <bool TWO>
+__device__ __forceinline__ int scan_line_global(const SubTable &st, uint32_t b, uint64_t key, uint32_t &m0, uint32_t &m1) {
+    const uint4 *line = reinterpret_cast<const uint4 *>(st.buckets + (uint64_t)b * BUCKET_BYTES);
+    uint4 v[SLOTS];
+#pragma unroll
+    for (int sl = 0; sl < SLOTS; ++sl) v[sl] = line[sl];
+    m0 = m1 = 0;
+#pragma unroll
+    for (int sl = 0; sl < SLOTS; ++sl) {
+        const uint64_t kk = (uint64_t)v[sl].x | ((uint64_t)v[sl].y << 32);
+        const bool hit = (kk == key);
+        m0 = hit ? v[sl].z : m0;
+        if (TWO) m1 = hit ? v[sl].w : m1;
+    }
+    const uint64_t last = (uint64_t)v[SLOTS - 1].x | ((uint64_t)v[SLOTS - 1].y << 32);
+    return (m0 | m1) ? 1 : (last == EMPTY_KEY ? 0 : -1);
+}
+
+template <bool TWO>
+__device__ __forceinline__ void lane_chase(const SubTable &st, uint64_t key, uint32_t b, uint32_t step, uint32_t &m0,
+                                           uint32_t &m1) {
+    for (uint64_t n = 0; n < st.nbuckets; ++n) {
+        if (scan_line_global<TWO>(st, b, key, m0, m1) >= 0) return;
+        b = next_line(b, step, st.nbuckets);
+    }
+    m0 = m1 = 0;
+}
+
+// write the row bytes this sub-table owns: low nb0 bytes of m0 at column col0, low nb1 bytes of
+// m1 at col0+4 (cpp/anchor.cpp:139-164).  ROWMODE 1: one-byte rows; 2: 8-byte rows (N = 64);
+// 0: generic byte loop.
+template <int ROWMODE>
+__device__ __forceinline__ void store_row(uint8_t *row, uint32_t m0, uint32_t m1, const RowCols rc) {
+    if (ROWMODE == 1) {
+        row[0] = (uint8_t)m0;
+    } else if (ROWMODE == 2) {
+        *reinterpret_cast<uint2 *>(row) = make_uint2(m0, m1);
+    } else {
+        for (uint32_t bb = 0; bb < rc.nb0; ++bb) row[rc.col0 + bb] = (uint8_t)(m0 >> (8 * bb));
+        for (uint32_t bb = 0; bb < rc.nb1; ++bb) row[rc.col0 + 4 + bb] = (uint8_t)(m1 >> (8 * bb));
+    }
+}
+
+// inclusive count of set bits of `mask` at lanes <= this lane
+__device__ __forceinline__ uint32_t lanes_le_count(unsigned long long mask, bool own) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u)) + (own ? 1u : 0u);
+}
+
+template <int W_C, bool TWO, int ROWMODE>
+__global__ __launch_bounds__(64) void k_probe(const SubTable st, const uint64_t *__restrict__ seqw,
+                                              const uint32_t *__restrict__ nmw, const uint32_t *__restrict__ has_n,
+                                              const SeqDesc *__restrict__ sd, const AnchorDesc *__restrict__ ad,
+                                              const uint32_t *__restrict__ tile_contig, uint8_t *__restrict__ out1,
+                                              uint32_t nbytes, const RowCols rc) {
+    __shared__ uint64_t sw[PROBE_SEQW];
+    __shared__ uint32_t nw[PROBE_SEQW];
+    __shared__ uint32_t lines_w[PROBE_MAXRUN];
+    __shared__ uint4 buf[PROBE_MAXRUN * LDS_LINE_U4];
+    __shared__ uint64_t q_key[PROBE_QCAP];   // overflow queue of the tile (position order)
+    __shared__ uint32_t q_line[PROBE_QCAP];  // next line to try
+    __shared__ uint32_t q_step[PROBE_QCAP];
+    __shared__ uint16_t q_pl[PROBE_QCAP];    // position within the tile
+    const int lane = threadIdx.x;
+    const int k = (int)st.k;
+    const uint32_t c = tile_contig[blockIdx.x];
+    const AnchorDesc a = ad[c];
+    const SeqDesc s = sd[c];
+    const uint32_t tile_start = (blockIdx.x - a.tile0) * PROBE_TILE;
+    const uint32_t npos = min((uint32_t)PROBE_TILE, a.nkmers - tile_start);
+    const bool hasn = has_n[c] != 0;
+
+    // packed bases of the tile (+ halo), the only sequence traffic: 0.25 B per position
+    for (int i = lane; i < PROBE_SEQW; i += 64) {
+        const uint64_t wi = (uint64_t)(tile_start >> 5) + i;
+        sw[i] = wi < s.nwords ? seqw[s.seq_off + wi] : 0ull;
+        nw[i] = (hasn && wi < s.nwords) ? nmw[s.seq_off + wi] : 0u;
+    }
+    __syncthreads();  // single wave: compiles to a wave-level wait, not an s_barrier
+
+    const uint64_t kmask = kmer_mask(k);
+    constexpr int HALO = W_C ? W_C - 1 : 0;  // lanes of a batch that only supply m-mers to their successors
+    constexpr int STRIDE = 64 - HALO;        // new positions per batch
+    const uint32_t m = W_C ? (uint32_t)k - W_C + 1 : 0;
+    const uint32_t mm = (m >= 16) ? ~0u : ((1u << (2 * m)) - 1);
+    uint8_t *tile_rows = out1 + a.out_off + (uint64_t)tile_start * nbytes;
+    uint32_t qn = 0;  // wave-uniform: overflow entries of this tile so far
+
+    for (uint32_t b = 0; b < npos; b += STRIDE) {
+        // ---- keys: lane = position b + lane - HALO; it also owns m-mer number b + lane ----
+        const int32_t pl = (int32_t)(b + lane) - HALO;
+        const bool inrange = pl >= (int32_t)b && pl < (int32_t)npos;
+        const uint32_t pq = (uint32_t)max(pl, 0);
+        const uint64_t X = extract_bases(sw, pq) & kmask;
+        const uint64_t B = revcomp_le(X, k);
+        const uint64_t key = canonical_from_xb(X, B, k);
+        bool act = inrange;
+        if (hasn) act = act && (extract_nmask(nw, pq, k) == 0);
+        uint32_t grp;
+        if (W_C) {
+            const uint32_t fa = (uint32_t)extract_bases(sw, b + lane) & mm;  // m-mer b+lane, forward
+            uint32_t fr = __brev(~fa);                                       // ... and its reverse complement
+            fr = (((fr >> 1) & 0x55555555u) | ((fr & 0x55555555u) << 1)) >> (32 - 2 * m);
+            uint32_t best = mz_order(fa < fr ? fa : fr);
+            // sliding minimum over lanes [lane-W_C+1, lane] by doubling (lanes below the halo
+            // read their own value back: they are never active)
+#pragma unroll
+            for (int off = 1; off < W_C; off <<= 1) {
+                const int d = (2 * off <= W_C) ? off : (W_C - off);  // 8: 1,2,4  12: 1,2,4,4  16: 1,2,4,8
+                const uint32_t up = __shfl_up(best, d);
+                best = min(best, lane >= d ? up : best);
+            }
+            grp = best;
+        } else {
+            grp = group_of_key(key);
+        }
+        const uint32_t line = home_of_group(grp, st.nbuckets);
+
+        // ---- runs of equal home line among the active lanes ----
+        const uint32_t prev_line = __shfl_up(line, 1);
+        const unsigned long long amask = __ballot(act);
+        const bool prev_act = lane > 0 && ((amask >> (lane - 1)) & 1ull);
+        const bool leader = act && (!prev_act || line != prev_line);
+        const unsigned long long lmask = __ballot(leader);
+        const uint32_t rid = lanes_le_count(lmask, leader) - 1;  // run id of an active lane
+        const uint32_t nruns = (uint32_t)__popcll(lmask);
+
+        uint32_t m0 = 0, m1 = 0;
+        int rcode = 0;
+        for (uint32_t r0 = 0; r0 < nruns; r0 += PROBE_MAXRUN) {  // one trip unless the batch has > MAXRUN lines
+            const uint32_t nl = min((uint32_t)PROBE_MAXRUN, nruns - r0);
+            if (leader && rid - r0 < nl) lines_w[rid - r0] = line;
+            __syncthreads();
+            // stage: nl lines = nl*8 chunks of 16 bytes, coalesced, all loads of the step in flight
+            uint4 v[STAGE_ITERS];
+            const uint32_t total = nl * SLOTS;
+#pragma unroll
+            for (int u = 0; u < STAGE_ITERS; ++u) {
+                uint32_t idx = u * 64 + lane;
+                idx = idx < total ? idx : total - 1;  // clamp: unconditional loads issue back to back
+                v[u] = *reinterpret_cast<const uint4 *>(st.buckets + (uint64_t)lines_w[idx / SLOTS] * BUCKET_BYTES + (idx % SLOTS) * 16);
+            }
+#pragma unroll
+            for (int u = 0; u < STAGE_ITERS; ++u) {
+                const uint32_t idx = u * 64 + lane;
+                if (idx < total) buf[(idx / SLOTS) * LDS_LINE_U4 + (idx % SLOTS)] = v[u];
+            }
+            __syncthreads();
+            if (act && rid - r0 < nl) rcode = scan_line_lds<TWO>(buf + (rid - r0) * LDS_LINE_U4, key, m0, m1);
+            __syncthreads();
+        }
+
+        // ---- overflow: absent from a full line -> queue entry for the next line of its sequence ----
+        const bool ovf = act && rcode < 0;
+        const unsigned long long omask = __ballot(ovf);
+        if (omask) {
+            const uint32_t step = step_of_group(grp, st.nbuckets);
+            const uint32_t nx = next_line(line, step, st.nbuckets);
+            const uint32_t slot = qn + lanes_le_count(omask, ovf) - 1;
+            if (ovf) {
+                if (slot < (uint32_t)PROBE_QCAP) {
+                    q_key[slot] = key;
+                    q_line[slot] = nx;
+                    q_step[slot] = step;
+                    q_pl[slot] = (uint16_t)pl;
+                } else {
+                    lane_chase<TWO>(st, key, nx, step, m0, m1);  // queue full: resolve inline
+                }
+            }
+            qn = min(qn + (uint32_t)__popcll(omask), (uint32_t)PROBE_QCAP);
+        }
+        if (inrange) store_row<ROWMODE>(tile_rows + (uint64_t)pl * nbytes, m0, m1, rc);
+    }
+
+    // ---- overflow levels: dense 64-entry batches out of the LDS queue, staged exactly like the
+    // main batches (neighbouring entries belong to the same group and share their next line);
+    // entries that overflow again are compacted in place for the next level ----
+    for (int level = 1; qn > 0; ++level) {
+        __syncthreads();
+        uint32_t kept = 0;
+        for (uint32_t i0 = 0; i0 < qn; i0 += 64) {
+            const uint32_t e = i0 + lane;
+            const bool act = e < qn;
+            const uint32_t ec = act ? e : qn - 1;
+            const uint64_t key = q_key[ec];
+            const uint32_t line = q_line[ec], step = q_step[ec];
+            const uint32_t pl = q_pl[ec];
+            const uint32_t prev_line = __shfl_up(line, 1);
+            const bool leader = act && (lane == 0 || line != prev_line);
+            const unsigned long long lmask = __ballot(leader);
+            const uint32_t rid = lanes_le_count(lmask, leader) - 1;
+            const uint32_t nruns = (uint32_t)__popcll(lmask);
+            uint32_t m0 = 0, m1 = 0;
+            int rcode = 0;
+            for (uint32_t r0 = 0; r0 < nruns; r0 += PROBE_MAXRUN) {
+                const uint32_t nl = min((uint32_t)PROBE_MAXRUN, nruns - r0);
+                if (leader && rid - r0 < nl) lines_w[rid - r0] = line;
+                __syncthreads();
+                uint4 v[STAGE_ITERS];
+                const uint32_t total = nl * SLOTS;
+#pragma unroll
+                for (int u = 0; u < STAGE_ITERS; ++u) {
+                    uint32_t idx = u * 64 + lane;
+                    idx = idx < total ? idx : total - 1;
+                    v[u] = *reinterpret_cast<const uint4 *>(st.buckets + (uint64_t)lines_w[idx / SLOTS] * BUCKET_BYTES + (idx % SLOTS) * 16);
+                }
+#pragma unroll
+                for (int u = 0; u < STAGE_ITERS; ++u) {
+                    const uint32_t idx = u * 64 + lane;
+                    if (idx < total) buf[(idx / SLOTS) * LDS_LINE_U4 + (idx % SLOTS)] = v[u];
+                }
+                __syncthreads();
+                if (act && rid - r0 < nl) rcode = scan_line_lds<TWO>(buf + (rid - r0) * LDS_LINE_U4, key, m0, m1);
+                __syncthreads();
+            }
+            bool again = act && rcode < 0;
+            if (again && level >= ANCHOR_MAX_ROUNDS) {  // a very long chain: finish it inline
+                lane_chase<TWO>(st, key, next_line(line, step, st.nbuckets), step, m0, m1);
+                again = false;
+            }
+            if (act && (m0 | m1)) store_row<ROWMODE>(tile_rows + (uint64_t)pl * nbytes, m0, m1, rc);
+            const unsigned long long kmask2 = __ballot(again);
+            if (again) {  // in-place compaction: slot <= e, and this batch's reads are already done
+                const uint32_t slot = kept + lanes_le_count(kmask2, true) - 1;
+                q_key[slot] = key;
+                q_line[slot] = next_line(line, step, st.nbuckets);
+                q_step[slot] = step;
+                q_pl[slot] = (uint16_t)pl;
+            }
+            kept += (uint32_t)__popcll(kmask2);
+            __syncthreads();
+        }
+        qn = kept;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// statistics from finished rows: bitmap.100, per-bin popcount histogram, column sums.
+// A workgroup (256 threads) walks a CONTIGUOUS range of tiles (PT consecutive positions per
+// thread and tile); histogram counters stay in LDS until the bin changes and column sums until
+// the end, so that global atomics on the few shared counters stay rare.
+// (also the second half of the genome-sharded mode: rows combined over xGMI first)
+// ---------------------------------------------------------------------------
+// column sums: one ballot + popcount per genome bit, accumulated in LDS by lane 0
+__device__ __forceinline__ void colsum_word(uint32_t wv, uint32_t d, uint32_t N, uint32_t *cs, int lane) {
+    const uint32_t ng = min(32u, N - 32 * d);
+    for (uint32_t bit = 0; bit < ng; ++bit) {
+        const unsigned long long bal = __ballot((wv >> bit) & 1u);
+        if (lane == 0 && bal) atomicAdd(&cs[32 * d + bit], (uint32_t)__popcll(bal));
+    }
+}
+// wave-aggregated histogram of (bin, popcount): LDS for the tile's first two bins, global beyond
+__device__ __forceinline__ void hist_position(bool active, uint32_t pos, uint32_t popc, uint32_t N, uint32_t binlen,
+                                              uint32_t bin0, uint32_t bin0_start, uint32_t *hist, uint32_t *bins,
+                                              uint64_t bin_off, int lane) {
+    if (popc > N) popc = N;  // junk bits beyond ngenomes: the reference indexes out of bounds here
+    const uint32_t dpos = pos - bin0_start;
+    const uint32_t rel = (binlen >= (uint32_t)PROBE_TILE) ? (dpos >= binlen ? 1u : 0u) : dpos / binlen;
+    const uint32_t hk = rel * (N + 1) + popc;
+    unsigned long long todo = __ballot(active);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const uint32_t lk = __shfl(hk, leader);
+        const unsigned long long mk = __ballot(active && hk == lk) & todo;
+        if (lane == leader) {
+            const uint32_t cnt = (uint32_t)__popcll(mk);
+            if (rel < 2) atomicAdd(&hist[hk], cnt);
+            else atomicAdd(&bins[(bin_off + bin0 + rel) * (uint64_t)(N + 1) + popc], cnt);
+        }
+        todo &= ~mk;
+    }
+}
+
+constexpr int EPI_THREADS = PROBE_TILE / 4;
+static_assert(EPI_THREADS >= 64 && EPI_THREADS % 64 == 0, "PROBE_TILE must be a multiple of 256");
+
+__device__ __forceinline__ void flush_hist(uint32_t N, uint32_t *hist, uint32_t *bins, uint64_t bin_row0, int tid) {
+    for (uint32_t i = tid; i < 2 * (N + 1); i += EPI_THREADS) {
+        const uint32_t hv = hist[i];
+        if (hv) {
+            const uint32_t rel = i / (N + 1), pc2 = i - rel * (N + 1);
+            atomicAdd(&bins[(bin_row0 + rel) * (uint64_t)(N + 1) + pc2], hv);
+            hist[i] = 0;
+        }
+    }
+}
+
+__global__ __launch_bounds__(EPI_THREADS) void k_epilogue(uint32_t N, const AnchorDesc *__restrict__ ad,
+                                                          const uint32_t *__restrict__ tile_contig, uint32_t ntiles,
+                                                          const uint8_t *__restrict__ out1, uint8_t *__restrict__ out100,
+                                                          uint32_t *__restrict__ bins,
+                                                          unsigned long long *__restrict__ colsums, uint32_t flags) {
+    extern __shared__ uint4 smem[];
+    constexpr int PT = 4;  // rows per thread and tile: EPI_THREADS = PROBE_TILE / 4 threads per workgroup
+    const int tid = threadIdx.x, lane = tid & 63;
+    const uint32_t nbytes = (N + 7) / 8, ndbs = (N + 31) / 32;
+    uint32_t *hist = reinterpret_cast<uint32_t *>(smem);
+    uint32_t *cs = hist + ((2 * (N + 1) + 3) & ~3u);
+    for (uint32_t i = tid; i < 2 * (N + 1); i += EPI_THREADS) hist[i] = 0;
+    for (uint32_t i = tid; i < N; i += EPI_THREADS) cs[i] = 0;
+    __syncthreads();
+    const bool want_cs = (flags & 1u) != 0;
+    const uint32_t t_begin = (uint32_t)((uint64_t)ntiles * blockIdx.x / gridDim.x);
+    const uint32_t t_end = (uint32_t)((uint64_t)ntiles * (blockIdx.x + 1) / gridDim.x);
+    uint64_t cur_row0 = ~0ull;  // bins row the accumulators currently stand for
+    uint32_t cur_c = ~0u;
+    AnchorDesc a;
+    a.out_off = a.out100_off = a.bin_off = 0;
+    a.nkmers = a.binlen = a.tile0 = a.nbins = 0;
+    const uint32_t p0 = tid * PT;
+    // fast path (N <= 8) per-thread accumulators, reduced over the workgroup only when the bin
+    // changes / at the end: 9 popcount classes as 7-bit fields of one u64 (spilled to u32 counters
+    // every 31 tiles), 8 column counters
+    unsigned long long hacc = 0;
+    uint32_t hc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t cacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t since_spill = 0;
+    uint32_t next_packed = 0;  // software prefetch of the next tile's rows
+    bool next_valid = false;
+
+    auto spill = [&]() {
+#pragma unroll
+        for (int v = 0; v < 9; ++v) hc[v] += (uint32_t)(hacc >> (7 * v)) & 127u;
+        hacc = 0;
+        since_spill = 0;
+    };
+    auto reduce_hist = [&]() {  // per-thread classes -> LDS histogram (bin-relative row 0)
+        spill();
+#pragma unroll
+        for (int v = 0; v < 9; ++v) {
+            if ((uint32_t)v <= N && hc[v]) atomicAdd(&hist[v], hc[v]);
+            hc[v] = 0;
+        }
+    };
+
+    for (uint32_t tile = t_begin; tile < t_end; ++tile) {
+        const uint32_t c = tile_contig[tile];
+        if (c != cur_c) {  // block-uniform; consecutive tiles nearly always share their contig
+            a = ad[c];
+            cur_c = c;
+        }
+        const uint32_t tile_start = (tile - a.tile0) * PROBE_TILE;
+        const uint32_t npos = min((uint32_t)PROBE_TILE, a.nkmers - tile_start);
+        const uint32_t binlen = a.binlen, bin0 = tile_start / binlen, bin0_start = bin0 * binlen;
+        const uint64_t row0 = a.bin_off + bin0;
+        const bool fast = (nbytes == 1 && binlen >= (uint32_t)PROBE_TILE);
+        const bool onebin = (tile_start + npos) <= (bin0_start + binlen);  // block-uniform
+        if (row0 != cur_row0 || !(fast && onebin)) {  // block-uniform: the accumulators move on to another bin
+            if (cur_row0 != ~0ull) {
+                reduce_hist();
+                __syncthreads();
+                flush_hist(N, hist, bins, cur_row0, tid);
+                __syncthreads();
+            }
+            cur_row0 = row0;
+        }
+        const uint8_t *g = out1 + a.out_off + (uint64_t)tile_start * nbytes;
+        if (fast) {
+            // ---- fast path (N <= 8): 4 one-byte rows per thread in one 32-bit word ----
+            uint32_t packed = 0;
+            if (next_valid) packed = next_packed;
+            else if (p0 + 3 < npos) packed = *reinterpret_cast<const uint32_t *>(g + p0);
+            else
+                for (uint32_t j = 0; j < 4; ++j)
+                    if (p0 + j < npos) packed |= (uint32_t)g[p0 + j] << (8 * j);
+            // prefetch: the next tile of the same contig is a full tile right behind this one
+            next_valid = (tile + 1 < t_end) && (npos == (uint32_t)PROBE_TILE) &&
+                         (tile_start + 2u * PROBE_TILE <= a.nkmers) && (tile_contig[tile + 1] == c);
+            if (next_valid) next_packed = *reinterpret_cast<const uint32_t *>(g + PROBE_TILE + p0);
+            const uint32_t nact = p0 < npos ? min(4u, npos - p0) : 0u;
+            if (want_cs) {  // bit g of the 4 rows = bits g, g+8, g+16, g+24 of the word
+#pragma unroll
+                for (int gb = 0; gb < 8; ++gb) cacc[gb] += __popc(packed & (0x01010101u << gb));
+            }
+            if (onebin) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t pcj = min((uint32_t)__popc((packed >> (8 * j)) & 0xFFu), N);
+                    if ((uint32_t)j < nact) hacc += 1ull << (7 * pcj);
+                }
+                if (++since_spill == 31) spill();
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    hist_position((uint32_t)j < nact, tile_start + p0 + j,
+                                  min((uint32_t)__popc((packed >> (8 * j)) & 0xFFu), N), N, binlen, bin0, bin0_start,
+                                  hist, bins, a.bin_off, lane);
+            }
+            // 1-in-100 rows: at most one of 4 consecutive positions is a multiple of 100
+            if (nact) {
+                const uint32_t pos0 = tile_start + p0;
+                const uint32_t r100 = (pos0 + 99u) / 100u;
+                const uint32_t first = r100 * 100u;
+                if (first < pos0 + nact) out100[a.out100_off + r100] = (uint8_t)(packed >> (8 * (first - pos0)));
+            }
+        } else {
+            next_valid = false;
+#pragma unroll
+            for (int jj = 0; jj < PT; ++jj) {
+                const uint32_t pl = p0 + jj;
+                const bool active = pl < npos;
+                const uint32_t pos = tile_start + pl;
+                uint32_t popc = 0;
+                const bool is100 = active && (pos % 100u == 0);
+                for (uint32_t d = 0; d < ndbs; ++d) {
+                    const uint32_t nb = min(4u, nbytes - 4 * d);
+                    uint32_t wv = 0;
+                    if (active)
+                        for (uint32_t bb = 0; bb < nb; ++bb) wv |= (uint32_t)g[(uint64_t)pl * nbytes + 4 * d + bb] << (8 * bb);
+                    popc += __popc(wv);
+                    if (is100) {
+                        uint8_t *o100 = out100 + a.out100_off + (uint64_t)(pos / 100u) * nbytes + 4 * d;
+                        for (uint32_t bb = 0; bb < nb; ++bb) o100[bb] = (uint8_t)(wv >> (8 * bb));
+                    }
+                    if (want_cs) colsum_word(wv, d, N, cs, lane);
+                }
+                hist_position(active, pos, popc, N, binlen, bin0, bin0_start, hist, bins, a.bin_off, lane);
+            }
+        }
+    }
+    reduce_hist();
+    if (want_cs && nbytes == 1) {
+#pragma unroll
+        for (int gb = 0; gb < 8; ++gb)
+            if ((uint32_t)gb < N && cacc[gb]) atomicAdd(&cs[gb], cacc[gb]);
+    }
+    __syncthreads();
+    if (cur_row0 != ~0ull) flush_hist(N, hist, bins, cur_row0, tid);
+    if (want_cs)
+        for (uint32_t i = tid; i < N; i += EPI_THREADS) {
+            const uint32_t v = cs[i];
+            if (v) atomicAdd(&colsums[i], (unsigned long long)v);
+        }
+}
+
+// ---------------------------------------------------------------------------
+// launch
+// ---------------------------------------------------------------------------
+template <int W_C, bool TWO, int ROWMODE>
+static hipError_t probe_t(hipStream_t s, uint32_t ntiles, const SubTable &st, const uint64_t *seqw, const uint32_t *nmw,
+                          const uint32_t *has_n, const SeqDesc *sd, const AnchorDesc *ad, const uint32_t *tile_contig,
+                          uint8_t *out1, uint32_t nbytes, const RowCols &rc) {
+    hipLaunchKernelGGL((k_probe<W_C, TWO, ROWMODE>), dim3(ntiles), dim3(64), 0, s, st, seqw, nmw, has_n, sd, ad,
+                       tile_contig, out1, nbytes, rc);
+    return hipGetLastError();
+}
+
+template <int W_C>
+static hipError_t probe_w(hipStream_t s, uint32_t ntiles, const SubTable &st, const uint64_t *seqw, const uint32_t *nmw,
+                          const uint32_t *has_n, const SeqDesc *sd, const AnchorDesc *ad, const uint32_t *tile_contig,
+                          uint8_t *out1, uint32_t nbytes, const RowCols &rc, int rowmode) {
+#define PG_A s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, out1, nbytes, rc
+    if (st.W == 2) {
+        if (rowmode == 2) return probe_t<W_C, true, 2>(PG_A);
+        return probe_t<W_C, true, 0>(PG_A);
+    }
+    if (rowmode == 1) return probe_t<W_C, false, 1>(PG_A);
+    return probe_t<W_C, false, 0>(PG_A);
+#undef PG_A
+}
+
+static int row_mode(uint32_t nbytes, const RowCols &rc) {
+    if (nbytes == 1) return 1;
+    if (nbytes == 8 && rc.col0 == 0 && rc.nb0 == 4 && rc.nb1 == 4) return 2;
+    return 0;
+}
+
+hipError_t launch_anchor(hipStream_t s, const TableDesc &T, const uint64_t *seqw, const uint32_t *nmw,
+                         const uint32_t *has_n, const SeqDesc *sd, const AnchorDesc *ad, const uint32_t *tile_contig,
+                         uint32_t ntiles, uint8_t *out1, uint64_t out1_bytes) {
+    if (ntiles == 0) return hipSuccess;
+    const uint32_t nbytes = (T.ngenomes + 7) / 8;
+    hipError_t e = hipSuccess;
+    (void)out1_bytes;
+    for (uint32_t si = 0; si < T.nsub; ++si) {
+        const SubTable &st = T.sub[si];
+        RowCols rc;  // every sub-table writes all bytes of the columns it owns, so rows need no zero fill
+        rc.col0 = 4 * st.word0;
+        rc.nb0 = min(4u, nbytes - rc.col0);
+        rc.nb1 = (st.W == 2 && nbytes > rc.col0 + 4) ? min(4u, nbytes - rc.col0 - 4) : 0;
+        const int rm = (T.nsub == 1) ? row_mode(nbytes, rc) : 0;
+        const uint32_t w = st.m ? st.k - st.m + 1 : 0;
+        switch (w) {
+            case 0: e = probe_w<0>(s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, out1, nbytes, rc, rm); break;
+            case 8: e = probe_w<8>(s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, out1, nbytes, rc, rm); break;
+            case 12: e = probe_w<12>(s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, out1, nbytes, rc, rm); break;
+            case 16: e = probe_w<16>(s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, out1, nbytes, rc, rm); break;
+            default: return hipErrorInvalidValue;
+        }
+        if (e != hipSuccess) return e;
+    }
+    return e;
+}
+
+hipError_t launch_rows_epilogue(hipStream_t st, uint32_t ngenomes, const AnchorDesc *ad, const uint32_t *tile_contig,
+                                uint32_t ntiles, const uint8_t *out1, uint8_t *out100, uint32_t *bins,
+                                unsigned long long *colsums, uint32_t flags) {
+    if (ntiles == 0) return hipSuccess;
+    size_t lds = (((2 * (ngenomes + 1) + 3) & ~3u) + ((ngenomes + 3) & ~3u)) * 4 + 16;
+    const uint32_t maxg = 256u * (2048u / EPI_THREADS);  // fill every CU
+    const uint32_t grid = ntiles < maxg ? ntiles : maxg;  // contiguous tile ranges per workgroup
+    hipLaunchKernelGGL(k_epilogue, dim3(grid), dim3(EPI_THREADS), lds, st, ngenomes, ad, tile_contig, ntiles, out1, out100, bins,
+                       colsums, flags);
+    return hipGetLastError();
+}
+
+}  // namespace pg

@@ -132,6 +132,7 @@ extern "C" int pg_ctx_create(int device_id, pg_ctx **out) {
 extern "C" int pg_ctx_destroy(pg_ctx *c) {
     if (!c) return PG_OK;
     hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
     hipStreamDestroy(c->own_stream);
     delete c;
     return PG_OK;
@@ -647,7 +648,7 @@ extern "C" int pg_result_create(pg_table *t, const pg_seqset *sq, uint32_t flags
         o1 += (nk * nbytes + 15) & ~15ull;
         o100 += n100 * nbytes;
         bins += a.nbins;
-        const uint64_t nt = (nk + ANCHOR_TILE - 1) / ANCHOR_TILE;
+        const uint64_t nt = (nk + PROBE_TILE - 1) / PROBE_TILE;
         for (uint64_t i = 0; i < nt; ++i) tile_contig.push_back(c);
         tiles += nt;
         r->ad.push_back(a);
@@ -701,13 +702,10 @@ extern "C" int pg_anchor_run(pg_result *r) {
     pg_table *t = r->tbl;
     if (int e = use_device(t->ctx)) return e;
     hipStream_t st = t->ctx->stream;
-    const uint32_t N = t->ngenomes;
-    HIP_TRY(hipMemsetAsync(r->d_bins, 0, std::max<uint64_t>(1, r->total_bins) * (N + 1) * 4, st));
-    HIP_TRY(hipMemsetAsync(r->d_colsums, 0, (size_t)N * 8, st));
     TableDesc T = make_desc(t);
     HIP_TRY(launch_anchor(st, T, r->seqs->d_seqw, r->seqs->d_nmw, r->seqs->d_has_n, r->seqs->d_desc, r->d_ad,
-                          r->d_tile_contig, r->ntiles, r->d_out1, r->d_out100, r->d_bins, r->d_colsums,
-                          r->flags));
+                          r->d_tile_contig, r->ntiles, r->d_out1, r->out1_bytes));
+    if (!(r->flags & PG_ANCHOR_ROWS_ONLY)) return pg_rows_epilogue(r);
     return PG_OK;
 }
 

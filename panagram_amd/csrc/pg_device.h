@@ -25,8 +25,11 @@
 namespace pg {
 
 constexpr uint64_t EMPTY_KEY = ~0ull;
-constexpr int BUCKET_BYTES = 128;
-constexpr int SLOTS = 8;
+#ifndef PG_SLOTS
+#define PG_SLOTS 8
+#endif
+constexpr int SLOTS = PG_SLOTS;            // 16-byte slots per table line
+constexpr int BUCKET_BYTES = 16 * SLOTS;   // 128-byte lines (or 256 with PG_SLOTS=16)
 constexpr int MAX_SUB = 8;  // sub-tables per pan table => up to 512 genomes
 
 struct SubTable {
@@ -164,39 +167,6 @@ __device__ __forceinline__ uint64_t extract_nmask64(P words, uint64_t p) {
     uint64_t lo = (uint64_t)words[w] | ((uint64_t)words[w + 1] << 32);
     uint64_t hi = (uint64_t)words[w + 2];
     return sh ? ((lo >> sh) | (hi << (64 - sh))) : lo;
-}
-
-// ---- DPP quad permutes: lanes 4q..4q+3 cooperate on one line ---------------
-template <int CTRL>
-__device__ __forceinline__ uint32_t quad_perm(uint32_t v) {
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, false);
-}
-constexpr int QP_XOR1 = 0xB1;   // [1,0,3,2]
-constexpr int QP_XOR2 = 0x4E;   // [2,3,0,1]
-constexpr int QP_BC0 = 0x00, QP_BC1 = 0x55, QP_BC2 = 0xAA, QP_BC3 = 0xFF;
-
-__device__ __forceinline__ uint32_t quad_or(uint32_t v) {
-    v |= quad_perm<QP_XOR1>(v);
-    v |= quad_perm<QP_XOR2>(v);
-    return v;
-}
-
-// One line held by a quad: lane j has slot j in va and slot j+4 in vb, each
-// {key.lo, key.hi, mask0, mask1}.  A stored key always has a non-zero mask, so
-// "found" == (m0|m1) != 0; the masks come back quad-uniform.
-template <bool TWO>
-__device__ __forceinline__ void quad_match(const uint4 va, const uint4 vb, uint64_t key, uint32_t &m0, uint32_t &m1) {
-    const uint64_t ka = (uint64_t)va.x | ((uint64_t)va.y << 32);
-    const uint64_t kb = (uint64_t)vb.x | ((uint64_t)vb.y << 32);
-    const bool ha = (ka == key), hb = (kb == key);
-    m0 = quad_or((ha ? va.z : 0u) | (hb ? vb.z : 0u));
-    m1 = TWO ? quad_or((ha ? va.w : 0u) | (hb ? vb.w : 0u)) : 0u;
-}
-// no EMPTY slot among the line's eight (only needed on the not-found path)
-__device__ __forceinline__ bool quad_full(const uint4 va, const uint4 vb) {
-    const uint64_t ka = (uint64_t)va.x | ((uint64_t)va.y << 32);
-    const uint64_t kb = (uint64_t)vb.x | ((uint64_t)vb.y << 32);
-    return quad_or((ka == EMPTY_KEY || kb == EMPTY_KEY) ? 1u : 0u) == 0;
 }
 
 // Single-lane lookup (GetCountersForRead kernel).

@@ -4,23 +4,25 @@
 
 namespace pg {
 
-#ifndef PG_ANCHOR_TILE
-#define PG_ANCHOR_TILE 1024
+#ifndef PG_PROBE_TILE
+#define PG_PROBE_TILE 512
 #endif
-#ifndef PG_ANCHOR_UNROLL
-#define PG_ANCHOR_UNROLL 4
+#ifndef PG_PROBE_MAXRUN
+#define PG_PROBE_MAXRUN 16
 #endif
-constexpr int ANCHOR_TILE = PG_ANCHOR_TILE;      // k-mer positions per workgroup
-constexpr int ANCHOR_UNROLL = PG_ANCHOR_UNROLL;  // independent bucket gathers in flight per lane
-#ifndef PG_ANCHOR_WG
-#define PG_ANCHOR_WG 256
+constexpr int PROBE_TILE = PG_PROBE_TILE;      // k-mer positions per wave-tile (k_probe) / per block (k_epilogue)
+constexpr int PROBE_MAXRUN = PG_PROBE_MAXRUN;  // table lines staged in LDS per step of a 64-lane batch
+constexpr int ANCHOR_MAX_ROUNDS = 12;          // queued overflow levels; beyond: the lane chases its chain inline
+#ifndef PG_PROBE_QCAP
+#define PG_PROBE_QCAP (PG_PROBE_TILE * 3 / 8)
 #endif
-constexpr int ANCHOR_WG = PG_ANCHOR_WG;          // threads per workgroup (64 = one wave: barriers vanish)
-#ifndef PG_ANCHOR_LINES
-#define PG_ANCHOR_LINES (PG_ANCHOR_TILE * 5 / 16)
-#endif
-constexpr int ANCHOR_LINES = PG_ANCHOR_LINES;    // LDS line buffer (128-B table lines) per workgroup
-constexpr int ANCHOR_MAX_ROUNDS = 24;            // queued overflow rounds before chasing a chain inline
+constexpr int PROBE_QCAP = PG_PROBE_QCAP;      // per-tile LDS overflow queue (beyond: resolved inline)
+
+// which row bytes a sub-table writes: low nb0 bytes of mask word 0 at column col0, low nb1 bytes
+// of mask word 1 at col0+4
+struct RowCols {
+    uint32_t col0, nb0, nb1;
+};
 
 // one packed contig of a seqset (offsets in 32-base words, shared by both planes)
 struct SeqDesc {
@@ -55,12 +57,9 @@ hipError_t launch_export(hipStream_t st, const SubTable &t, int w, uint64_t *key
                          uint64_t cap, unsigned long long *count);
 hipError_t launch_counters(hipStream_t st, const SubTable &t, int w, int k, const uint64_t *seqw,
                            const uint32_t *nmw, const uint32_t *has_n, uint64_t nkmers, uint32_t *out);
-size_t anchor_lds_bytes(uint32_t ngenomes);
 hipError_t launch_anchor(hipStream_t st, const TableDesc &T, const uint64_t *seqw, const uint32_t *nmw,
                          const uint32_t *has_n, const SeqDesc *sd, const AnchorDesc *ad,
-                         const uint32_t *tile_contig, uint32_t ntiles, uint8_t *out1, uint8_t *out100,
-                         uint32_t *bins, unsigned long long *colsums, uint32_t flags);
-
+                         const uint32_t *tile_contig, uint32_t ntiles, uint8_t *out1, uint64_t out1_bytes);
 hipError_t launch_rows_epilogue(hipStream_t st, uint32_t ngenomes, const AnchorDesc *ad, const uint32_t *tile_contig,
                                 uint32_t ntiles, const uint8_t *out1, uint8_t *out100, uint32_t *bins,
                                 unsigned long long *colsums, uint32_t flags);

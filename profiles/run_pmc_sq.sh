@@ -15,7 +15,7 @@ for d in ("pmc_sq","pmc_sq2"):
         df = pd.read_csv("$OUT/%s/pmc_counter_collection.csv" % d)
     except Exception as e:
         print(d, "missing", e); continue
-    a = df[df.Kernel_Name.str.contains("k_anchor")]
+    a = df[df.Kernel_Name.str.contains("k_probe")]
     print(a.groupby("Counter_Name").Counter_Value.mean().to_string())
 PY
 cat $OUT/bench.json | python -c "import sys,json; d=json.loads(sys.stdin.read().splitlines()[-1]); print(d['value']/1e9, d['roofline']['avg_launch_ms'])"
