@@ -97,7 +97,7 @@ def main():
     ap.add_argument("--k", type=int, default=21)
     ap.add_argument("--d", type=float, default=0.01)
     ap.add_argument("--seed", type=int, default=1234)
-    ap.add_argument("--keys-per-bucket", type=float, default=3.0)
+    ap.add_argument("--keys-per-bucket", type=float, default=2.0)
     ap.add_argument("--no-colsums", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-mb", type=float, default=10.0)

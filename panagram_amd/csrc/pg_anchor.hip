@@ -237,6 +237,16 @@ __global__ __launch_bounds__(64) void k_probe(const SubTable st, const uint64_t 
     // entries that overflow again are compacted in place for the next level ----
     for (int level = 1; qn > 0; ++level) {
         __syncthreads();
+        if (level > PROBE_STAGED_LEVELS) {
+            // the few entries still unresolved (long chains) walk their sequences lane by lane:
+            // 8 slot loads in flight per line, no staging overhead
+            for (uint32_t e = lane; e < qn; e += 64) {
+                uint32_t m0, m1;
+                lane_chase<TWO>(st, q_key[e], q_line[e], q_step[e], m0, m1);
+                if (m0 | m1) store_row<ROWMODE>(tile_rows + (uint64_t)q_pl[e] * nbytes, m0, m1, rc);
+            }
+            break;
+        }
         uint32_t kept = 0;
         for (uint32_t i0 = 0; i0 < qn; i0 += 64) {
             const uint32_t e = i0 + lane;
@@ -273,11 +283,7 @@ __global__ __launch_bounds__(64) void k_probe(const SubTable st, const uint64_t 
                 if (act && rid - r0 < nl) rcode = scan_line_lds<TWO>(buf + (rid - r0) * LDS_LINE_U4, key, m0, m1);
                 __syncthreads();
             }
-            bool again = act && rcode < 0;
-            if (again && level >= ANCHOR_MAX_ROUNDS) {  // a very long chain: finish it inline
-                lane_chase<TWO>(st, key, next_line(line, step, st.nbuckets), step, m0, m1);
-                again = false;
-            }
+            const bool again = act && rcode < 0;
             if (act && (m0 | m1)) store_row<ROWMODE>(tile_rows + (uint64_t)pl * nbytes, m0, m1, rc);
             const unsigned long long kmask2 = __ballot(again);
             if (again) {  // in-place compaction: slot <= e, and this batch's reads are already done

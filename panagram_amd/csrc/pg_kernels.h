@@ -12,7 +12,10 @@ namespace pg {
 #endif
 constexpr int PROBE_TILE = PG_PROBE_TILE;      // k-mer positions per wave-tile (k_probe) / per block (k_epilogue)
 constexpr int PROBE_MAXRUN = PG_PROBE_MAXRUN;  // table lines staged in LDS per step of a 64-lane batch
-constexpr int ANCHOR_MAX_ROUNDS = 12;          // queued overflow levels; beyond: the lane chases its chain inline
+#ifndef PG_PROBE_STAGED_LEVELS
+#define PG_PROBE_STAGED_LEVELS 2
+#endif
+constexpr int PROBE_STAGED_LEVELS = PG_PROBE_STAGED_LEVELS;  // LDS-staged overflow levels; beyond: lanes chase inline
 #ifndef PG_PROBE_QCAP
 #define PG_PROBE_QCAP (PG_PROBE_TILE * 3 / 8)
 #endif

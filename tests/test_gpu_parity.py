@@ -183,6 +183,37 @@ def test_one_shot_contig_and_edge_cases(ctx):
     tbl.close()
 
 
+@pytest.mark.parametrize("k", [1, 7, 15, 19, 20, 22, 23, 24, 25, 27, 28, 29, 30, 32])
+def test_every_minimizer_window_and_direct_mode(ctx, k):
+    """k = 20..23 / 24..27 / 28..31 use minimizer windows of 8 / 12 / 16 m-mers, every other k hashes
+    the k-mer itself; tables built on the GPU, answers compared with the oracle (bit-exact)."""
+    from panagram_amd import engine
+    n = 3
+    gen = po.synth_genomes(n, [6000, 1500], 0.03, 500 + k)
+    genomes = [[po.codes_to_ascii(c) for c in g] for g in gen]
+    seq = bytearray(genomes[1][0])
+    seq[700:720] = b"N" * 20          # N run
+    seq[2000:2300] = bytes(seq[2000:2300]).lower()
+    genomes[1][0] = bytes(seq)
+    dbs = po.build_bitvec_dbs(genomes, k)
+    tbl = engine.PanTable(ctx, k, n)
+    for g in range(n):
+        ss = engine.SeqSet.from_host(ctx, genomes[g])
+        tbl.insert_seqset(g, ss)
+        ss.close()
+    keys, vals = tbl.export(0)
+    o = np.argsort(keys)
+    assert np.array_equal(keys[o], dbs[0][0]) and np.array_equal(vals[o], dbs[0][1])
+    tbl.rehash(5.0)  # dense: exercises the overflow queue and the inline chase
+    for g in (0, 1):
+        for seq_ in genomes[g]:
+            rows, rows100, bins, cs = tbl.anchor_contig(seq_)
+            o_rows, o_rows100, o_bins, _, o_cs = po.anchor_contig(dbs, seq_, k, n)
+            assert np.array_equal(rows, o_rows) and np.array_equal(rows100, o_rows100)
+            assert np.array_equal(bins.astype(np.int64), o_bins) and np.array_equal(cs.astype(np.int64), o_cs)
+    tbl.close()
+
+
 def test_errors_are_loud(ctx):
     from panagram_amd import engine
     with pytest.raises(engine.PanagramHipError):
