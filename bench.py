@@ -161,16 +161,13 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-          for _ in range(args.steps * G)]
+    # per-launch kernel durations come from HIP events recorded by the library on the stream
+    # the kernels run on (pg_result_timing); they are read back after the timed region
+    probe_ms, epi_ms = [], []
     t0 = time.perf_counter()
-    i = 0
     for _ in range(args.steps):
         for r in results:
-            ev[i][0].record()
             r.run()
-            ev[i][1].record()
-            i += 1
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -180,14 +177,30 @@ def main():
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    kern_ms = [a.elapsed_time(b) for a, b in ev]
-    avg_launch_s = float(np.mean(kern_ms)) / 1e3
+    for r in results:  # events of the last timed step (the library re-records them at every launch)
+        pm, em = r.timing()
+        probe_ms.append(pm)
+        epi_ms.append(em)
+    avg_launch_s = float(np.mean(probe_ms)) / 1e3       # dominant kernel: k_probe
+    avg_epi_s = float(np.mean(epi_ms)) / 1e3
 
     # ---- invariants at full size (cheap): anchor g contains all of its own k-mers ----
     if not args.no_colsums:
         cs = results[0].colsums()
         assert int(cs[0]) == pos_per_genome[0], "anchor genome 0 must contain every one of its k-mers"
 
+    # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process;
+    # the figure comes from the committed rocprofv3 --pmc passes of this same command
+    # (profiles/traffic.json, corrected as MI355X_MICROARCH.md prescribes) and is only quoted
+    # when the workload is the one that was profiled
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            tj = json.load(f)
+        if abs(tj["positions_per_launch"] - float(np.mean(pos_per_genome))) < 1 and k == 21 and G == 8:
+            traffic = tj["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
     nbytes = (G + 7) // 8
     P = (G + 63) // 64  # table probes per position in this design (one wide-mask sub-table per 64 genomes)
     B = 0.25 + 64.0 * P + 1.01 * nbytes
@@ -219,13 +232,16 @@ def main():
             "parallelism": f"contig-sharded x{world}, replicated table, no collective",
         },
         "roofline": {
-            "bound": "hbm", "kernel": "k_anchor",
+            "bound": "hbm", "kernel": "k_probe",
             "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
             "frac": achieved / HBM_PEAK,
             "algorithmic_bytes_per_position": B,
             "avg_launch_ms": avg_launch_s * 1e3,
+            "epilogue_kernel_ms": avg_epi_s * 1e3,
+            "whole_run_frac": (value / world) * B / HBM_PEAK,
             "hbm_read_frac": (float(np.mean(pos_per_genome)) * (0.25 + 64.0 * P) / avg_launch_s) / HBM_PEAK,
-            "traffic": None,
+            "traffic": traffic,
+            "algorithmic_bytes_per_launch": per_launch_bytes,
         },
     }
 

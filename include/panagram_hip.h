@@ -130,6 +130,10 @@ int pg_result_create(pg_table *tbl, const pg_seqset *seqs, uint32_t flags, pg_re
 int pg_result_destroy(pg_result *r);
 /* run the anchor kernels for all contigs of the result's seqset; async */
 int pg_anchor_run(pg_result *r);
+/* HIP-event durations of the last pg_anchor_run on this result, measured on the context's
+ * stream: the probe kernels (k_probe, one per sub-table) and the statistics kernel
+ * (k_epilogue; 0 in rows-only mode).  Synchronises on the run's last event. */
+int pg_result_timing(pg_result *r, float *probe_ms, float *epilogue_ms);
 /* bitmap.100 rows, bin histograms and column sums from the (combined) bitmap.1 rows in the
  * result's device buffer; async.  Same outputs as the fused pg_anchor_run path. */
 int pg_rows_epilogue(pg_result *r);

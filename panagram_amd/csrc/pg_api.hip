@@ -93,6 +93,8 @@ struct pg_result {
     uint32_t *d_bins;
     uint64_t total_bins;
     unsigned long long *d_colsums;
+    hipEvent_t ev[3];  // start / after k_probe / after k_epilogue of the last pg_anchor_run
+    bool ev_ok, ev_epi;
 };
 
 static constexpr uint32_t MAX_PROBE = 512;  // lines an insert may walk before the table is grown
@@ -621,6 +623,8 @@ extern "C" int pg_result_create(pg_table *t, const pg_seqset *sq, uint32_t flags
     r->d_out1 = r->d_out100 = nullptr;
     r->d_bins = nullptr;
     r->d_colsums = nullptr;
+    r->ev_ok = r->ev_epi = false;
+    for (auto &e : r->ev) e = nullptr;
     uint64_t o1 = 0, o100 = 0, bins = 0, tiles = 0;
     std::vector<uint32_t> tile_contig;
     for (uint32_t c = 0; c < sq->n; ++c) {
@@ -693,6 +697,8 @@ extern "C" int pg_result_destroy(pg_result *r) {
     hipFree(r->d_out100);
     hipFree(r->d_bins);
     hipFree(r->d_colsums);
+    for (auto &e : r->ev)
+        if (e) hipEventDestroy(e);
     delete r;
     return PG_OK;
 }
@@ -702,10 +708,33 @@ extern "C" int pg_anchor_run(pg_result *r) {
     pg_table *t = r->tbl;
     if (int e = use_device(t->ctx)) return e;
     hipStream_t st = t->ctx->stream;
+    if (!r->ev[0])
+        for (auto &e : r->ev) HIP_TRY(hipEventCreate(&e));
     TableDesc T = make_desc(t);
+    HIP_TRY(hipEventRecord(r->ev[0], st));
     HIP_TRY(launch_anchor(st, T, r->seqs->d_seqw, r->seqs->d_nmw, r->seqs->d_has_n, r->seqs->d_desc, r->d_ad,
                           r->d_tile_contig, r->ntiles, r->d_out1, r->out1_bytes));
-    if (!(r->flags & PG_ANCHOR_ROWS_ONLY)) return pg_rows_epilogue(r);
+    HIP_TRY(hipEventRecord(r->ev[1], st));
+    r->ev_ok = true;
+    r->ev_epi = false;
+    if (!(r->flags & PG_ANCHOR_ROWS_ONLY)) {
+        if (int e = pg_rows_epilogue(r)) return e;
+        HIP_TRY(hipEventRecord(r->ev[2], st));
+        r->ev_epi = true;
+    }
+    return PG_OK;
+}
+
+extern "C" int pg_result_timing(pg_result *r, float *probe_ms, float *epilogue_ms) {
+    if (!r) return fail(PG_E_INVALID, "result is NULL");
+    if (!r->ev_ok) return fail(PG_E_INVALID, "pg_anchor_run has not been called on this result");
+    if (int e = use_device(r->tbl->ctx)) return e;
+    HIP_TRY(hipEventSynchronize(r->ev[r->ev_epi ? 2 : 1]));
+    float a = 0, b = 0;
+    HIP_TRY(hipEventElapsedTime(&a, r->ev[0], r->ev[1]));
+    if (r->ev_epi) HIP_TRY(hipEventElapsedTime(&b, r->ev[1], r->ev[2]));
+    if (probe_ms) *probe_ms = a;
+    if (epilogue_ms) *epilogue_ms = b;
     return PG_OK;
 }
 

@@ -198,6 +198,12 @@ class AnchorResult:
         """Enqueue the anchor kernels (asynchronous)."""
         check(self._lib.pg_anchor_run(self._h))
 
+    def timing(self):
+        """(probe_ms, epilogue_ms) of the last run(), from HIP events on the context's stream."""
+        a, b = C.c_float(), C.c_float()
+        check(self._lib.pg_result_timing(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def rows_epilogue(self) -> None:
         """bitmap.100 / bins / column sums from the (combined) rows in the device buffer (async)."""
         check(self._lib.pg_rows_epilogue(self._h))

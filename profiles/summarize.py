@@ -29,7 +29,7 @@ for d in ("pmc_fetch", "pmc_write", "pmc_ea", "pmc_sq"):
     if not os.path.exists(f):
         continue
     df = pd.read_csv(f)
-    name = df.Kernel_Name[df.Kernel_Name.str.contains("k_anchor")]
+    name = df.Kernel_Name[df.Kernel_Name.str.contains("k_probe")]
     if name.empty:
         continue
     a = df[df.Kernel_Name == name.iloc[0]]
