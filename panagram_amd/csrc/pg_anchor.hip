@@ -383,6 +383,27 @@ __global__ __launch_bounds__(EPI_THREADS) void k_epilogue(uint32_t N, const Anch
     uint32_t since_spill = 0;
     uint32_t next_packed = 0;  // software prefetch of the next tile's rows
     bool next_valid = false;
+    // wide path (8 < N <= 64): column sums through per-thread VERTICAL counters — bit g of plane p
+    // is bit p of the number of rows seen with genome g set (4 planes: up to 15 rows) — emptied
+    // into LDS with one wave ballot per (bit, plane): ~7 ALU ops per row word instead of one
+    // ballot per genome per position
+    uint32_t vp[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    uint32_t vrows = 0;
+    auto vflush = [&]() {  // wave-uniform call sites only
+        for (uint32_t wsel = 0; wsel < ndbs && wsel < 2; ++wsel) {
+            const uint32_t ng = min(32u, N - 32 * wsel);
+            for (uint32_t gb = 0; gb < ng; ++gb) {
+                uint32_t cnt = 0;
+#pragma unroll
+                for (int pln = 0; pln < 4; ++pln)
+                    cnt += (uint32_t)__popcll(__ballot((vp[wsel][pln] >> gb) & 1u)) << pln;
+                if (lane == 0 && cnt) atomicAdd(&cs[32 * wsel + gb], cnt);
+            }
+#pragma unroll
+            for (int pln = 0; pln < 4; ++pln) vp[wsel][pln] = 0;
+        }
+        vrows = 0;
+    };
 
     auto spill = [&]() {
 #pragma unroll
@@ -411,7 +432,7 @@ __global__ __launch_bounds__(EPI_THREADS) void k_epilogue(uint32_t N, const Anch
         const uint64_t row0 = a.bin_off + bin0;
         const bool fast = (nbytes == 1 && binlen >= (uint32_t)PROBE_TILE);
         const bool onebin = (tile_start + npos) <= (bin0_start + binlen);  // block-uniform
-        if (row0 != cur_row0 || !(fast && onebin)) {  // block-uniform: the accumulators move on to another bin
+        if (row0 != cur_row0 || (fast && !onebin)) {  // block-uniform: the accumulators move on to another bin
             if (cur_row0 != ~0ull) {
                 reduce_hist();
                 __syncthreads();
@@ -459,6 +480,72 @@ __global__ __launch_bounds__(EPI_THREADS) void k_epilogue(uint32_t N, const Anch
                 const uint32_t first = r100 * 100u;
                 if (first < pos0 + nact) out100[a.out100_off + r100] = (uint8_t)(packed >> (8 * (first - pos0)));
             }
+        } else if (nbytes <= 8 && binlen >= (uint32_t)PROBE_TILE) {
+            // ---- wide path (N <= 64): rows as one or two 32-bit words ----
+            next_valid = false;
+            if (want_cs && vrows + PT > 15) vflush();
+            uint32_t w0[PT], w1[PT];
+            if (nbytes == 4) {
+                uint4 q = make_uint4(0, 0, 0, 0);
+                if (p0 + 3 < npos) q = *reinterpret_cast<const uint4 *>(g + (uint64_t)p0 * 4);
+                else {
+                    uint32_t t4[4] = {0, 0, 0, 0};
+                    for (uint32_t j = 0; j < 4; ++j)
+                        if (p0 + j < npos) t4[j] = *reinterpret_cast<const uint32_t *>(g + (uint64_t)(p0 + j) * 4);
+                    q = make_uint4(t4[0], t4[1], t4[2], t4[3]);
+                }
+                w0[0] = q.x; w0[1] = q.y; w0[2] = q.z; w0[3] = q.w;
+                w1[0] = w1[1] = w1[2] = w1[3] = 0;
+            } else if (nbytes == 8) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    uint2 q = make_uint2(0, 0);
+                    if (p0 + j < npos) q = *reinterpret_cast<const uint2 *>(g + (uint64_t)(p0 + j) * 8);
+                    w0[j] = q.x;
+                    w1[j] = q.y;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    uint64_t r = 0;
+                    if (p0 + j < npos)
+                        for (uint32_t bb = 0; bb < nbytes; ++bb) r |= (uint64_t)g[(uint64_t)(p0 + j) * nbytes + bb] << (8 * bb);
+                    w0[j] = (uint32_t)r;
+                    w1[j] = (uint32_t)(r >> 32);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t pl = p0 + j;
+                if (pl < npos) {
+                    const uint32_t pos = tile_start + pl;
+                    const uint32_t pcj = min((uint32_t)(__popc(w0[j]) + __popc(w1[j])), N);
+                    const uint32_t rel = (pos - bin0_start) >= binlen ? 1u : 0u;
+                    atomicAdd(&hist[rel * (N + 1) + pcj], 1u);
+                    if (pos % 100u == 0) {
+                        uint8_t *o100 = out100 + a.out100_off + (uint64_t)(pos / 100u) * nbytes;
+                        const uint64_t r = (uint64_t)w0[j] | ((uint64_t)w1[j] << 32);
+                        for (uint32_t bb = 0; bb < nbytes; ++bb) o100[bb] = (uint8_t)(r >> (8 * bb));
+                    }
+                }
+            }
+            if (want_cs) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {  // rows beyond npos are zero: adding them is harmless
+#pragma unroll
+                    for (int wsel = 0; wsel < 2; ++wsel) {
+                        const uint32_t r = wsel ? w1[j] : w0[j];
+                        const uint32_t c1 = vp[wsel][0] & r;
+                        vp[wsel][0] ^= r;
+                        const uint32_t c2 = vp[wsel][1] & c1;
+                        vp[wsel][1] ^= c1;
+                        const uint32_t c3 = vp[wsel][2] & c2;
+                        vp[wsel][2] ^= c2;
+                        vp[wsel][3] ^= c3;
+                    }
+                }
+                vrows += PT;
+            }
         } else {
             next_valid = false;
 #pragma unroll
@@ -484,6 +571,7 @@ __global__ __launch_bounds__(EPI_THREADS) void k_epilogue(uint32_t N, const Anch
             }
         }
     }
+    if (want_cs && vrows) vflush();
     reduce_hist();
     if (want_cs && nbytes == 1) {
 #pragma unroll
