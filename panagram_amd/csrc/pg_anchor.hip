@@ -32,17 +32,12 @@
 
 namespace pg {
 
-// A staged line occupies 144 bytes of LDS (128 + 16 pad): with a 128-byte stride every lane's
-// ds_read_b128 of "its" line would land on one of two bank groups; 144 = 4*36 bytes walks all
-// 16 four-bank groups over 16 consecutive lines.
-constexpr int LDS_LINE_U4 = SLOTS + 1;
 constexpr int PROBE_SEQW = ((PROBE_TILE + 31) / 32 + 6 + 3) & ~3;  // staged 32-base words per tile
-constexpr int STAGE_ITERS = (PROBE_MAXRUN * SLOTS + 63) / 64;       // 16-byte loads per lane per staging step
 
 // scan the 8 slots of a line staged in LDS.  Lines fill front to back without holes (an insert
 // claims the first EMPTY slot and slots never revert), so "full" == last slot used.
 // returns 1 = found, 0 = absent (line not full), -1 = absent from a full line
-template <bool TWO>
+template <bool TWO, int SLOTS>
 __device__ __forceinline__ int scan_line_lds(const uint4 *line, uint64_t key, uint32_t &m0, uint32_t &m1) {
     m0 = m1 = 0;
     uint64_t last = 0;
@@ -59,9 +54,9 @@ __device__ __forceinline__ int scan_line_lds(const uint4 *line, uint64_t key, ui
 }
 
 // one line straight from global memory: the 8 slot loads are issued together (one latency)
-template <bool TWO>
+template <bool TWO, int SLOTS>
 __device__ __forceinline__ int scan_line_global(const SubTable &st, uint32_t b, uint64_t key, uint32_t &m0, uint32_t &m1) {
-    const uint4 *line = reinterpret_cast<const uint4 *>(st.buckets + (uint64_t)b * BUCKET_BYTES);
+    const uint4 *line = reinterpret_cast<const uint4 *>(st.buckets + (uint64_t)b * (16 * SLOTS));
     uint4 v[SLOTS];
 #pragma unroll
     for (int sl = 0; sl < SLOTS; ++sl) v[sl] = line[sl];
@@ -77,11 +72,11 @@ __device__ __forceinline__ int scan_line_global(const SubTable &st, uint32_t b, 
     return (m0 | m1) ? 1 : (last == EMPTY_KEY ? 0 : -1);
 }
 
-template <bool TWO>
+template <bool TWO, int SLOTS>
 __device__ __forceinline__ void lane_chase(const SubTable &st, uint64_t key, uint32_t b, uint32_t step, uint32_t &m0,
                                            uint32_t &m1) {
     for (uint64_t n = 0; n < st.nbuckets; ++n) {
-        if (scan_line_global<TWO>(st, b, key, m0, m1) >= 0) return;
+        if (scan_line_global<TWO, SLOTS>(st, b, key, m0, m1) >= 0) return;
         b = next_line(b, step, st.nbuckets);
     }
     m0 = m1 = 0;
@@ -107,7 +102,7 @@ __device__ __forceinline__ uint32_t lanes_le_count(unsigned long long mask, bool
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u)) + (own ? 1u : 0u);
 }
 
-template <int W_C, bool TWO, int ROWMODE>
+template <int W_C, bool TWO, int ROWMODE, int SLOTS>
 __global__ __launch_bounds__(64) void k_probe(const SubTable st, const uint64_t *__restrict__ seqw,
                                               const uint32_t *__restrict__ nmw, const uint32_t *__restrict__ has_n,
                                               const SeqDesc *__restrict__ sd, const AnchorDesc *__restrict__ ad,
@@ -115,6 +110,11 @@ __global__ __launch_bounds__(64) void k_probe(const SubTable st, const uint64_t 
                                               uint32_t nbytes, const RowCols rc) {
     __shared__ uint64_t sw[PROBE_SEQW];
     __shared__ uint32_t nw[PROBE_SEQW];
+    // A staged line occupies 16*SLOTS + 16 bytes of LDS: the pad keeps the lanes' ds_read_b128 of
+    // "their" lines off a common bank group (a power-of-two stride would be a 32-way conflict)
+    constexpr int LDS_LINE_U4 = SLOTS + 1;
+    constexpr int BUCKET_BYTES = 16 * SLOTS;
+    constexpr int STAGE_ITERS = (PROBE_MAXRUN * SLOTS + 63) / 64;  // 16-byte loads per lane per staging step
     __shared__ uint32_t lines_w[PROBE_MAXRUN];
     __shared__ uint4 buf[PROBE_MAXRUN * LDS_LINE_U4];
     __shared__ uint64_t q_key[PROBE_QCAP];   // overflow queue of the tile (position order)
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(64) void k_probe(const SubTable st, const uint64_t 
                 if (idx < total) buf[(idx / SLOTS) * LDS_LINE_U4 + (idx % SLOTS)] = v[u];
             }
             __syncthreads();
-            if (act && rid - r0 < nl) rcode = scan_line_lds<TWO>(buf + (rid - r0) * LDS_LINE_U4, key, m0, m1);
+            if (act && rid - r0 < nl) rcode = scan_line_lds<TWO, SLOTS>(buf + (rid - r0) * LDS_LINE_U4, key, m0, m1);
             __syncthreads();
         }
 
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(64) void k_probe(const SubTable st, const uint64_t 
                     q_step[slot] = step;
                     q_pl[slot] = (uint16_t)pl;
                 } else {
-                    lane_chase<TWO>(st, key, nx, step, m0, m1);  // queue full: resolve inline
+                    lane_chase<TWO, SLOTS>(st, key, nx, step, m0, m1);  // queue full: resolve inline
                 }
             }
             qn = min(qn + (uint32_t)__popcll(omask), (uint32_t)PROBE_QCAP);
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(64) void k_probe(const SubTable st, const uint64_t 
             // 8 slot loads in flight per line, no staging overhead
             for (uint32_t e = lane; e < qn; e += 64) {
                 uint32_t m0, m1;
-                lane_chase<TWO>(st, q_key[e], q_line[e], q_step[e], m0, m1);
+                lane_chase<TWO, SLOTS>(st, q_key[e], q_line[e], q_step[e], m0, m1);
                 if (m0 | m1) store_row<ROWMODE>(tile_rows + (uint64_t)q_pl[e] * nbytes, m0, m1, rc);
             }
             break;
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(64) void k_probe(const SubTable st, const uint64_t 
                     if (idx < total) buf[(idx / SLOTS) * LDS_LINE_U4 + (idx % SLOTS)] = v[u];
                 }
                 __syncthreads();
-                if (act && rid - r0 < nl) rcode = scan_line_lds<TWO>(buf + (rid - r0) * LDS_LINE_U4, key, m0, m1);
+                if (act && rid - r0 < nl) rcode = scan_line_lds<TWO, SLOTS>(buf + (rid - r0) * LDS_LINE_U4, key, m0, m1);
                 __syncthreads();
             }
             const bool again = act && rcode < 0;
@@ -590,11 +590,11 @@ __global__ __launch_bounds__(EPI_THREADS) void k_epilogue(uint32_t N, const Anch
 // ---------------------------------------------------------------------------
 // launch
 // ---------------------------------------------------------------------------
-template <int W_C, bool TWO, int ROWMODE>
+template <int W_C, bool TWO, int ROWMODE, int SLOTS>
 static hipError_t probe_t(hipStream_t s, uint32_t ntiles, const SubTable &st, const uint64_t *seqw, const uint32_t *nmw,
                           const uint32_t *has_n, const SeqDesc *sd, const AnchorDesc *ad, const uint32_t *tile_contig,
                           uint8_t *out1, uint32_t nbytes, const RowCols &rc) {
-    hipLaunchKernelGGL((k_probe<W_C, TWO, ROWMODE>), dim3(ntiles), dim3(64), 0, s, st, seqw, nmw, has_n, sd, ad,
+    hipLaunchKernelGGL((k_probe<W_C, TWO, ROWMODE, SLOTS>), dim3(ntiles), dim3(64), 0, s, st, seqw, nmw, has_n, sd, ad,
                        tile_contig, out1, nbytes, rc);
     return hipGetLastError();
 }
@@ -604,12 +604,20 @@ static hipError_t probe_w(hipStream_t s, uint32_t ntiles, const SubTable &st, co
                           const uint32_t *has_n, const SeqDesc *sd, const AnchorDesc *ad, const uint32_t *tile_contig,
                           uint8_t *out1, uint32_t nbytes, const RowCols &rc, int rowmode) {
 #define PG_A s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, out1, nbytes, rc
-    if (st.W == 2) {
-        if (rowmode == 2) return probe_t<W_C, true, 2>(PG_A);
-        return probe_t<W_C, true, 0>(PG_A);
+    if (st.slots == 16) {
+        if (st.W == 2) {
+            if (rowmode == 2) return probe_t<W_C, true, 2, 16>(PG_A);
+            return probe_t<W_C, true, 0, 16>(PG_A);
+        }
+        if (rowmode == 1) return probe_t<W_C, false, 1, 16>(PG_A);
+        return probe_t<W_C, false, 0, 16>(PG_A);
     }
-    if (rowmode == 1) return probe_t<W_C, false, 1>(PG_A);
-    return probe_t<W_C, false, 0>(PG_A);
+    if (st.W == 2) {
+        if (rowmode == 2) return probe_t<W_C, true, 2, 8>(PG_A);
+        return probe_t<W_C, true, 0, 8>(PG_A);
+    }
+    if (rowmode == 1) return probe_t<W_C, false, 1, 8>(PG_A);
+    return probe_t<W_C, false, 0, 8>(PG_A);
 #undef PG_A
 }
 

@@ -172,7 +172,7 @@ static uint64_t next_prime(uint64_t n) {
     }
 }
 
-static int alloc_sub(pg_ctx *ctx, uint32_t W, uint32_t word0, uint32_t k, uint64_t nbuckets, SubTable *out) {
+static int alloc_sub(pg_ctx *ctx, uint32_t W, uint32_t word0, uint32_t k, uint32_t slots, uint64_t nbuckets, SubTable *out) {
     if (nbuckets < 64) nbuckets = 64;
     nbuckets = next_prime(nbuckets);
     if (nbuckets > 0xFFFFFFFFull) return fail(PG_E_CAPACITY, "sub-table would exceed 2^32 lines (512 GB)");
@@ -182,12 +182,14 @@ static int alloc_sub(pg_ctx *ctx, uint32_t W, uint32_t word0, uint32_t k, uint64
     t.k = k;
     const uint32_t w = minimizer_window(k);
     t.m = w ? k - w + 1 : 0;
+    t.slots = slots;
+    t.pad_ = 0;
     t.nbuckets = nbuckets;
     void *p = nullptr;
-    hipError_t e = hipMalloc(&p, nbuckets * BUCKET_BYTES);
+    hipError_t e = hipMalloc(&p, nbuckets * 16ull * slots);
     if (e != hipSuccess)
         return fail(PG_E_HIP, "hipMalloc(%llu bytes) for k-mer table failed: %s",
-                    (unsigned long long)(nbuckets * BUCKET_BYTES), hipGetErrorString(e));
+                    (unsigned long long)(nbuckets * 16ull * slots), hipGetErrorString(e));
     t.buckets = static_cast<uint8_t *>(p);
     HIP_TRY(launch_table_init(ctx->stream, t));
     *out = t;
@@ -217,10 +219,13 @@ extern "C" int pg_table_create(pg_ctx *ctx, int k, int ngenomes, uint64_t expect
     for (int s = 0; s < nsub; ++s) {
         uint32_t W = (2 * s + 1 < ndbs) ? 2 : 1;
         uint64_t want = expected_keys ? expected_keys : (1ull << 18);
-        uint64_t nb = (uint64_t)((double)want / (TARGET_LOAD * slots_per_bucket(W))) + 1;
+        // 256-byte lines where a minimizer group is expected to exceed 8 keys: long windows
+        // (k >= 28) or many genomes' variants per locus
+        const uint32_t slots = (minimizer_window((uint32_t)k) == 16 || ngenomes > 32) ? 16u : 8u;
+        uint64_t nb = (uint64_t)((double)want / (TARGET_LOAD * slots)) + 1;
         SubHost sh;
         sh.count = 0;
-        int r = alloc_sub(ctx, W, 2 * s, (uint32_t)k, nb, &sh.d);
+        int r = alloc_sub(ctx, W, 2 * s, (uint32_t)k, slots, nb, &sh.d);
         if (r) {
             pg_table_destroy(t);
             return r;
@@ -256,7 +261,7 @@ static int regrow(pg_table *t, int si, uint64_t nb) {
     pg_ctx *ctx = t->ctx;
     for (int attempt = 0; attempt < 8; ++attempt) {
         SubTable nt;
-        if (int r = alloc_sub(ctx, t->subs[si].d.W, t->subs[si].d.word0, (uint32_t)t->k, nb, &nt)) return r;
+        if (int r = alloc_sub(ctx, t->subs[si].d.W, t->subs[si].d.word0, (uint32_t)t->k, t->subs[si].d.slots, nb, &nt)) return r;
         HIP_TRY(hipMemsetAsync(t->d_counters, 0, 2 * sizeof(unsigned long long), ctx->stream));
         HIP_TRY(launch_rehash(ctx->stream, t->subs[si].d, nt, t->d_counters, MAX_PROBE));
         unsigned long long c[2];
@@ -278,7 +283,7 @@ static int regrow(pg_table *t, int si, uint64_t nb) {
 
 static int ensure_room(pg_table *t, int si, uint64_t incoming) {
     SubHost &s = t->subs[si];
-    const int ns = slots_per_bucket(s.d.W);
+    const int ns = (int)s.d.slots;
     const double slots = (double)s.d.nbuckets * ns;
     if ((double)(s.count + incoming) > HARD_LOAD * slots) {
         uint64_t nb = (uint64_t)((double)(s.count + incoming) / (HARD_LOAD * 0.9 * ns)) + 1;
@@ -290,7 +295,7 @@ static int ensure_room(pg_table *t, int si, uint64_t incoming) {
 
 static int after_insert(pg_table *t, int si) {
     SubHost &s = t->subs[si];
-    const int ns = slots_per_bucket(s.d.W);
+    const int ns = (int)s.d.slots;
     if ((double)s.count > GROW_AT * (double)s.d.nbuckets * ns) {
         uint64_t nb = (uint64_t)((double)s.count / (TARGET_LOAD * ns)) + 1;
         return regrow(t, si, nb);
@@ -436,13 +441,17 @@ extern "C" int pg_table_stats(pg_table *t, uint64_t *nkeys, uint64_t *nslots, ui
     uint64_t a = 0, b = 0, c = 0;
     for (auto &s : t->subs) {
         a += s.count;
-        b += s.d.nbuckets * slots_per_bucket(s.d.W);
+        b += s.d.nbuckets * s.d.slots;
         c += s.d.nbuckets;
     }
     if (nkeys) *nkeys = a;
     if (nslots) *nslots = b;
     if (nbuckets) *nbuckets = c;
-    if (bytes) *bytes = c * BUCKET_BYTES;
+    if (bytes) {
+        uint64_t by = 0;
+        for (auto &s2 : t->subs) by += s2.d.nbuckets * 16ull * s2.d.slots;
+        *bytes = by;
+    }
     return PG_OK;
 }
 
@@ -451,7 +460,7 @@ extern "C" int pg_table_rehash(pg_table *t, double keys_per_bucket) {
     if (!(keys_per_bucket > 0.05 && keys_per_bucket <= 8.0)) return fail(PG_E_INVALID, "keys_per_bucket must be in (0.05, 8]");
     if (int r = use_device(t->ctx)) return r;
     for (size_t si = 0; si < t->subs.size(); ++si) {
-        double kpb = std::min(keys_per_bucket, 0.8 * slots_per_bucket(t->subs[si].d.W));
+        double kpb = std::min(keys_per_bucket * (t->subs[si].d.slots / 8.0), 0.8 * t->subs[si].d.slots);  // keys per 128 bytes
         uint64_t nb = (uint64_t)((double)t->subs[si].count / kpb) + 1;
         if (int r = regrow(t, (int)si, nb)) return r;
     }

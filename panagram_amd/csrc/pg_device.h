@@ -4,9 +4,10 @@
 //   line   = 128 bytes, 128-byte aligned: MI355X moves 128 B per random HBM access whatever
 //            the request size (tools/gather_bench.hip: 32/64/128-B random gathers all run at
 //            ~50 G requests/s), so a probe fetches — and uses — a whole line
-//          = 8 slots x { u64 key ; u32 mask0 ; u32 mask1 }   (mask1 unused when W == 1)
-//   a quad probes one line: lane j holds slots j and j+4 after two 16-byte loads, the match is
-//   lane-local and the masks are OR-reduced over the quad with two DPP quad-permutes.
+//          = 8 slots x { u64 key ; u32 mask0 ; u32 mask1 }   (mask1 unused when W == 1);
+//            256-byte lines of 16 slots where minimizer groups are bigger (k >= 28, N > 32)
+//   k_probe fetches a line once per run of positions (8 or 16 lanes x 16 B, coalesced) into LDS
+//   and every lane scans its line's slots there.
 //   EMPTY key = ~0 (never a canonical k-mer for k <= 32: the all-T k-mer's reverse complement
 //   is 0).  Keys only ever go EMPTY -> key, masks only gain bits: inserts are one 64-bit CAS +
 //   one 32-bit OR, no locks.
@@ -25,11 +26,8 @@
 namespace pg {
 
 constexpr uint64_t EMPTY_KEY = ~0ull;
-#ifndef PG_SLOTS
-#define PG_SLOTS 8
-#endif
-constexpr int SLOTS = PG_SLOTS;            // 16-byte slots per table line
-constexpr int BUCKET_BYTES = 16 * SLOTS;   // 128-byte lines (or 256 with PG_SLOTS=16)
+// slots per table line: 8 (128-byte lines) or 16 (256-byte lines, for k >= 28 / many genomes,
+// where a minimizer group holds more keys); a property of the sub-table (SubTable::slots)
 constexpr int MAX_SUB = 8;  // sub-tables per pan table => up to 512 genomes
 
 struct SubTable {
@@ -39,6 +37,8 @@ struct SubTable {
     uint32_t word0;     // first 32-genome group covered
     uint32_t k;
     uint32_t m;         // minimizer length (0 = hash the whole k-mer)
+    uint32_t slots;     // 16-byte slots per line: 8 or 16
+    uint32_t pad_;
 };
 
 struct TableDesc {
@@ -49,7 +49,6 @@ struct TableDesc {
     uint32_t ngenomes;
 };
 
-__host__ __device__ __forceinline__ int slots_per_bucket(uint32_t) { return SLOTS; }
 __host__ __device__ __forceinline__ uint32_t key_off(uint32_t, int s) { return 16u * s; }
 __host__ __device__ __forceinline__ uint32_t mask_off(uint32_t, int s, int w) { return 16u * s + 8u + 4u * w; }
 
@@ -175,9 +174,9 @@ __device__ __forceinline__ bool lane_lookup(const SubTable &st, uint64_t key, ui
     uint32_t b = home_of_group(grp, st.nbuckets);
     const uint32_t step = step_of_group(grp, st.nbuckets);
     for (uint64_t probes = 0; probes < st.nbuckets; ++probes) {
-        const uint8_t *base = st.buckets + (uint64_t)b * BUCKET_BYTES;
+        const uint8_t *base = st.buckets + (uint64_t)b * (16u * st.slots);
         bool empty_seen = false;
-        for (int s = 0; s < SLOTS; ++s) {
+        for (int s = 0; s < (int)st.slots; ++s) {
             uint64_t cur = *reinterpret_cast<const uint64_t *>(base + key_off(st.W, s));
             if (cur == key) {
                 m0 = *reinterpret_cast<const uint32_t *>(base + mask_off(st.W, s, 0));
@@ -201,8 +200,8 @@ __device__ __forceinline__ int lane_insert(const SubTable &st, uint64_t key, int
     uint32_t b = home_of_group(grp, st.nbuckets);
     const uint32_t step = step_of_group(grp, st.nbuckets);
     for (uint32_t probes = 0; probes < max_probe; ++probes) {
-        uint8_t *base = st.buckets + (uint64_t)b * BUCKET_BYTES;
-        for (int s = 0; s < SLOTS; ++s) {
+        uint8_t *base = st.buckets + (uint64_t)b * (16u * st.slots);
+        for (int s = 0; s < (int)st.slots; ++s) {
             unsigned long long *kp = reinterpret_cast<unsigned long long *>(base + key_off(st.W, s));
             unsigned long long cur = *kp;  // a stale EMPTY only costs a failed CAS
             int claimed = 0;

@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void k_insert_keys(SubTable st, int w, const u
 // re-hash every occupied slot of `src` into `dst` (same W)
 __global__ __launch_bounds__(256) void k_rehash(SubTable src, SubTable dst, unsigned long long *counters,
                                                 uint32_t max_probe) {
-    const int ns = slots_per_bucket(src.W);
+    const int ns = (int)src.slots;
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     const uint64_t nslots = src.nbuckets * ns;
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void k_rehash(SubTable src, SubTable dst, unsi
     for (; i < nslots; i += stride) {
         uint64_t b = i / ns;
         int s = (int)(i - b * ns);
-        const uint8_t *base = src.buckets + b * BUCKET_BYTES;
+        const uint8_t *base = src.buckets + b * (16u * src.slots);
         uint64_t key = *reinterpret_cast<const uint64_t *>(base + key_off(src.W, s));
         if (key == EMPTY_KEY) continue;
         for (uint32_t w = 0; w < src.W; ++w) {
@@ -131,14 +131,14 @@ __global__ __launch_bounds__(256) void k_rehash(SubTable src, SubTable dst, unsi
 // export (key, mask word w) of every slot whose word w is non-zero
 __global__ __launch_bounds__(256) void k_export(SubTable st, int w, uint64_t *keys, uint32_t *vals,
                                                 uint64_t cap, unsigned long long *count) {
-    const int ns = slots_per_bucket(st.W);
+    const int ns = (int)st.slots;
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     const uint64_t nslots = st.nbuckets * ns;
     for (; i < nslots; i += stride) {
         uint64_t b = i / ns;
         int s = (int)(i - b * ns);
-        const uint8_t *base = st.buckets + b * BUCKET_BYTES;
+        const uint8_t *base = st.buckets + b * (16u * st.slots);
         uint64_t key = *reinterpret_cast<const uint64_t *>(base + key_off(st.W, s));
         if (key == EMPTY_KEY) continue;
         uint32_t m = *reinterpret_cast<const uint32_t *>(base + mask_off(st.W, s, w));
@@ -180,7 +180,7 @@ static inline unsigned grid_for(uint64_t n, unsigned block, unsigned cap) {
 }
 
 hipError_t launch_table_init(hipStream_t st, const SubTable &t) {
-    uint64_t nchunks = t.nbuckets * (BUCKET_BYTES / 16);
+    uint64_t nchunks = t.nbuckets * t.slots;
     hipLaunchKernelGGL(k_table_init, dim3(grid_for(nchunks, 256, 256 * 32)), dim3(256), 0, st,
                        reinterpret_cast<uint4 *>(t.buckets), nchunks, t.W);
     return hipGetLastError();
@@ -215,7 +215,7 @@ hipError_t launch_insert_keys(hipStream_t st, const SubTable &t, int w, const ui
 
 hipError_t launch_rehash(hipStream_t st, const SubTable &src, const SubTable &dst,
                          unsigned long long *counters, uint32_t max_probe) {
-    uint64_t nslots = src.nbuckets * slots_per_bucket(src.W);
+    uint64_t nslots = src.nbuckets * src.slots;
     hipLaunchKernelGGL(k_rehash, dim3(grid_for(nslots, 256, 256 * 64)), dim3(256), 0, st, src, dst, counters,
                        max_probe);
     return hipGetLastError();
@@ -223,7 +223,7 @@ hipError_t launch_rehash(hipStream_t st, const SubTable &src, const SubTable &ds
 
 hipError_t launch_export(hipStream_t st, const SubTable &t, int w, uint64_t *keys, uint32_t *vals,
                          uint64_t cap, unsigned long long *count) {
-    uint64_t nslots = t.nbuckets * slots_per_bucket(t.W);
+    uint64_t nslots = t.nbuckets * t.slots;
     hipLaunchKernelGGL(k_export, dim3(grid_for(nslots, 256, 256 * 64)), dim3(256), 0, st, t, w, keys, vals, cap,
                        count);
     return hipGetLastError();
