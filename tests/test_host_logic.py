@@ -109,3 +109,26 @@ def test_golden_gzi_uncompressed_offsets_match_reference():
         ours = np.fromfile(p + "i", "<u8")
     assert ours[0] == ref[0]
     assert np.array_equal(ours[1:].reshape(-1, 2)[:, 1], ref[1:].reshape(-1, 2)[:, 1])
+
+
+def test_bins_bits_make_bars_matches_reference_loop():
+    """scripts/make_bins_bits.py:34-59 restated as the plain loop it is, vs the vectorised counterpart"""
+    from panagram_amd.bins_bits import make_bars
+    rng = np.random.default_rng(9)
+    for n, num_samples, bin_size, step in [(12345, 8, 200000, 100), (50, 2, 1000, 100), (3000, 1, 20000, 100)]:
+        occ = rng.integers(0, num_samples + 1, n)
+        x, cntr = [], bin_size
+        while cntr < n * step:
+            x.append(cntr)
+            cntr += bin_size
+        z_unique, z_univ = [0] * (len(x) + 1), [0] * (len(x) + 1)
+        c = 0
+        for i in occ:
+            t = int(c / bin_size)
+            if i == 1:
+                z_unique[t] += 1
+            elif i == num_samples:
+                z_univ[t] += 1
+            c += step
+        gx, gu, gq = make_bars(occ, num_samples, bin_size, step)
+        assert gx == x and gu == z_univ[:len(x)] and gq == z_unique[:len(x)]
