@@ -214,6 +214,33 @@ def test_every_minimizer_window_and_direct_mode(ctx, k):
     tbl.close()
 
 
+def test_three_subtables_n130(ctx):
+    """N = 130 -> 5 bitvec groups -> 3 sub-tables (64 + 64 + 2 genomes), 17-byte rows"""
+    from panagram_amd import engine
+    n, k = 130, 21
+    gen = po.synth_genomes(n, [1500], 0.01, 4242)
+    genomes = [[po.codes_to_ascii(c) for c in g] for g in gen]
+    dbs = po.build_bitvec_dbs(genomes, k)
+    assert len(dbs) == 5
+    tbl = engine.PanTable(ctx, k, n)
+    for g in range(n):
+        ss = engine.SeqSet.from_host(ctx, genomes[g])
+        tbl.insert_seqset(g, ss)
+        ss.close()
+    for d, (fk, fm) in enumerate(dbs):
+        keys, vals = tbl.export(d)
+        o = np.argsort(keys)
+        assert np.array_equal(keys[o], fk) and np.array_equal(vals[o], fm)
+    for g in (0, 64, 129):
+        seq = genomes[g][0]
+        rows, rows100, bins, cs = tbl.anchor_contig(seq)
+        o_rows, o_rows100, o_bins, _, o_cs = po.anchor_contig(dbs, seq, k, n)
+        assert rows.shape[1] == 17
+        assert np.array_equal(rows, o_rows) and np.array_equal(rows100, o_rows100)
+        assert np.array_equal(bins.astype(np.int64), o_bins) and np.array_equal(cs.astype(np.int64), o_cs)
+    tbl.close()
+
+
 def test_errors_are_loud(ctx):
     from panagram_amd import engine
     with pytest.raises(engine.PanagramHipError):
