@@ -226,7 +226,7 @@ def main():
                         f"d={args.d}, all {G} genomes anchored per step, table resident in one GPU's HBM "
                         f"(BASELINE.json configs[1])",
             "positions_per_step_per_gpu": pos_per_step,
-            "table_keys": st["nkeys"], "table_bytes": st["bytes"], "keys_per_bucket": args.keys_per_bucket,
+            "table_keys": st["nkeys"], "table_bytes": st["bytes"], "keys_per_128B_line": args.keys_per_bucket,
             "table_build_s": build_s, "probes_per_position": P, "nbytes": nbytes,
             "colsums": not args.no_colsums,
             "parallelism": f"contig-sharded x{world}, replicated table, no collective",

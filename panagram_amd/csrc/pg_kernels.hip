@@ -1,13 +1,16 @@
-// pg_kernels.hip — hand-written gfx950 (CDNA4, wave64) kernels of the anchor path.
+// pg_kernels.hip — table construction / maintenance kernels and sequence packing for gfx950
+// (CDNA4, wave64).  Integer / HBM-bound work: no MFMA.  The anchor kernels live in pg_anchor.hip.
+//   k_pack         1 byte in, 0.375 byte out per base, streaming                -> HBM roofline
+//   k_insert_seq   one thread per k-mer: canonical key, minimizer, CAS + atomic OR on a random
+//                  table line                                                   -> HBM / atomics
+//   k_insert_keys  same for (key, counter) pairs (KMC1 import)
+//   k_rehash       every occupied slot of a table into a bigger / tighter one
+//   k_export       (key, counter) pairs of one 32-genome group (KMC1 export)
+//   k_counters     literal GetCountersForRead equivalent (single-lane lookup per position)
 //
-// Integer / HBM-bound work: no MFMA.  What bounds each kernel:
-//   (the anchor kernels live in pg_anchor.hip)
-//   k_insert_seq   random 64-byte read-modify-write per k-mer      -> HBM / atomics
-//   k_pack         1 byte in, 0.375 byte out per base, streaming   -> HBM roofline
-//
-// Replaces (reference, kjenike/panagram): KMC CKMCFile::GetCountersForRead as
-// called from KMCdb::write_bits (cpp/anchor.cpp:112-195) and
-// Genome._write_bitmap/_query_kmc_bytes/bin_bitsum (index.py:932-969,1169-1183).
+// Replaces (reference, kjenike/panagram): kmc -ci1 + kmc_tools transform set_counts + kmc_tools
+// complex -ocsum (workflow/Snakefile:54-110, index.py:407-426) and CKMCFile::OpenForRA /
+// GetCountersForRead (cpp/anchor.cpp:28-31,148; index.py:855-860,934-935).
 #include "pg_kernels.h"
 
 namespace pg {
