@@ -39,18 +39,21 @@ constexpr int PROBE_SEQW = ((PROBE_TILE + 31) / 32 + 6 + 3) & ~3;  // staged 32-
 // returns 1 = found, 0 = absent (line not full), -1 = absent from a full line
 template <bool TWO, int SLOTS>
 __device__ __forceinline__ int scan_line_lds(const uint4 *line, uint64_t key, uint32_t &m0, uint32_t &m1) {
-    m0 = m1 = 0;
-    uint64_t last = 0;
+    // all SLOTS key reads are issued together (one LDS wait), the hit slot is selected in
+    // registers, and only the masks of that one slot are read afterwards
+    uint64_t kk[SLOTS];
 #pragma unroll
-    for (int sl = 0; sl < SLOTS; ++sl) {
-        const uint4 v = line[sl];
-        const uint64_t kk = (uint64_t)v.x | ((uint64_t)v.y << 32);
-        const bool hit = (kk == key);
-        m0 = hit ? v.z : m0;
-        if (TWO) m1 = hit ? v.w : m1;
-        if (sl == SLOTS - 1) last = kk;
+    for (int sl = 0; sl < SLOTS; ++sl) kk[sl] = *reinterpret_cast<const uint64_t *>(line + sl);
+    int hit = -1;
+#pragma unroll
+    for (int sl = 0; sl < SLOTS; ++sl) hit = (kk[sl] == key) ? sl : hit;
+    m0 = m1 = 0;
+    if (hit >= 0) {
+        const uint2 mk = *reinterpret_cast<const uint2 *>(reinterpret_cast<const uint8_t *>(line + hit) + 8);
+        m0 = mk.x;
+        if (TWO) m1 = mk.y;
     }
-    return (m0 | m1) ? 1 : (last == EMPTY_KEY ? 0 : -1);
+    return hit >= 0 ? 1 : (kk[SLOTS - 1] == EMPTY_KEY ? 0 : -1);
 }
 
 // one line straight from global memory: the 8 slot loads are issued together (one latency)
@@ -116,7 +119,7 @@ __global__ __launch_bounds__(64) void k_probe(const SubTable st, const uint64_t 
     constexpr int BUCKET_BYTES = 16 * SLOTS;
     constexpr int STAGE_ITERS = (PROBE_MAXRUN * SLOTS + 63) / 64;  // 16-byte loads per lane per staging step
     __shared__ uint32_t lines_w[PROBE_MAXRUN];
-    __shared__ uint4 buf[PROBE_MAXRUN * LDS_LINE_U4];
+    __shared__ uint4 buf[((STAGE_ITERS * 64 + SLOTS - 1) / SLOTS) * LDS_LINE_U4];  // room for every staged chunk slot
     __shared__ uint64_t q_key[PROBE_QCAP];   // overflow queue of the tile (position order)
     __shared__ uint32_t q_line[PROBE_QCAP];  // next line to try
     __shared__ uint32_t q_step[PROBE_QCAP];
@@ -192,18 +195,20 @@ __global__ __launch_bounds__(64) void k_probe(const SubTable st, const uint64_t 
             if (leader && rid - r0 < nl) lines_w[rid - r0] = line;
             __syncthreads();
             // stage: nl lines = nl*8 chunks of 16 bytes, coalesced, all loads of the step in flight
+            // loads AND LDS writes are unconditional (chunks past the last line re-copy its last
+            // chunk into unused buffer lines): any predicate here makes the compiler sink each load
+            // into its own branch and wait for it there
             uint4 v[STAGE_ITERS];
             const uint32_t total = nl * SLOTS;
 #pragma unroll
             for (int u = 0; u < STAGE_ITERS; ++u) {
-                uint32_t idx = u * 64 + lane;
-                idx = idx < total ? idx : total - 1;  // clamp: unconditional loads issue back to back
+                const uint32_t idx = min((uint32_t)(u * 64 + lane), total - 1);
                 v[u] = *reinterpret_cast<const uint4 *>(st.buckets + (uint64_t)lines_w[idx / SLOTS] * BUCKET_BYTES + (idx % SLOTS) * 16);
             }
 #pragma unroll
             for (int u = 0; u < STAGE_ITERS; ++u) {
                 const uint32_t idx = u * 64 + lane;
-                if (idx < total) buf[(idx / SLOTS) * LDS_LINE_U4 + (idx % SLOTS)] = v[u];
+                buf[(idx / SLOTS) * LDS_LINE_U4 + (idx % SLOTS)] = v[u];
             }
             __syncthreads();
             if (act && rid - r0 < nl) rcode = scan_line_lds<TWO, SLOTS>(buf + (rid - r0) * LDS_LINE_U4, key, m0, m1);
@@ -270,14 +275,13 @@ __global__ __launch_bounds__(64) void k_probe(const SubTable st, const uint64_t 
                 const uint32_t total = nl * SLOTS;
 #pragma unroll
                 for (int u = 0; u < STAGE_ITERS; ++u) {
-                    uint32_t idx = u * 64 + lane;
-                    idx = idx < total ? idx : total - 1;
+                    const uint32_t idx = min((uint32_t)(u * 64 + lane), total - 1);
                     v[u] = *reinterpret_cast<const uint4 *>(st.buckets + (uint64_t)lines_w[idx / SLOTS] * BUCKET_BYTES + (idx % SLOTS) * 16);
                 }
 #pragma unroll
                 for (int u = 0; u < STAGE_ITERS; ++u) {
                     const uint32_t idx = u * 64 + lane;
-                    if (idx < total) buf[(idx / SLOTS) * LDS_LINE_U4 + (idx % SLOTS)] = v[u];
+                    buf[(idx / SLOTS) * LDS_LINE_U4 + (idx % SLOTS)] = v[u];
                 }
                 __syncthreads();
                 if (act && rid - r0 < nl) rcode = scan_line_lds<TWO, SLOTS>(buf + (rid - r0) * LDS_LINE_U4, key, m0, m1);
