@@ -145,7 +145,7 @@ __device__ __forceinline__ uint64_t extract_bases(P words, uint64_t p) {
     uint32_t sh = (uint32_t)(p & 31) * 2;
     uint64_t lo = words[w];
     uint64_t hi = words[w + 1];
-    return sh ? ((lo >> sh) | (hi << (64 - sh))) : lo;
+    return (lo >> sh) | ((hi << 1) << (63 - sh));  // branch-free also for sh == 0 (both reads always issue)
 }
 
 // k "not ACGT" bits starting at base p
@@ -165,7 +165,7 @@ __device__ __forceinline__ uint64_t extract_nmask64(P words, uint64_t p) {
     uint32_t sh = (uint32_t)(p & 31);
     uint64_t lo = (uint64_t)words[w] | ((uint64_t)words[w + 1] << 32);
     uint64_t hi = (uint64_t)words[w + 2];
-    return sh ? ((lo >> sh) | (hi << (64 - sh))) : lo;
+    return (lo >> sh) | ((hi << 1) << (63 - sh));
 }
 
 // Single-lane lookup (GetCountersForRead kernel).
