@@ -370,8 +370,10 @@ __global__ __launch_bounds__(EPI_THREADS) void k_epilogue(uint32_t N, const Anch
     for (uint32_t i = tid; i < N; i += EPI_THREADS) cs[i] = 0;
     __syncthreads();
     const bool want_cs = (flags & 1u) != 0;
-    const uint32_t t_begin = (uint32_t)((uint64_t)ntiles * blockIdx.x / gridDim.x);
-    const uint32_t t_end = (uint32_t)((uint64_t)ntiles * (blockIdx.x + 1) / gridDim.x);
+    // contiguous tile ranges, cut in units of 4 tiles (the 16-rows-per-thread group path)
+    const uint32_t ngroups = (ntiles + 3) / 4;
+    const uint32_t t_begin = 4u * (uint32_t)((uint64_t)ngroups * blockIdx.x / gridDim.x);
+    const uint32_t t_end = min(ntiles, 4u * (uint32_t)((uint64_t)ngroups * (blockIdx.x + 1) / gridDim.x));
     uint64_t cur_row0 = ~0ull;  // bins row the accumulators currently stand for
     uint32_t cur_c = ~0u;
     AnchorDesc a;
@@ -424,11 +426,60 @@ __global__ __launch_bounds__(EPI_THREADS) void k_epilogue(uint32_t N, const Anch
         }
     };
 
+    uint4 gq_next = make_uint4(0, 0, 0, 0);  // group path: prefetched rows of the next group
+    bool gq_valid = false;
     for (uint32_t tile = t_begin; tile < t_end; ++tile) {
         const uint32_t c = tile_contig[tile];
         if (c != cur_c) {  // block-uniform; consecutive tiles nearly always share their contig
             a = ad[c];
             cur_c = c;
+        }
+        // ---- group path (N <= 8): 4 full tiles of one contig inside one bin = 16 one-byte rows
+        // per thread in one 16-byte load; same accumulators as the per-tile fast path ----
+        {
+            const uint32_t ts = (tile - a.tile0) * PROBE_TILE;
+            const uint32_t span = 4u * PROBE_TILE;
+            const bool grp_ok = nbytes == 1 && tile + 3 < t_end && tile_contig[tile + 3] == c &&
+                                ts + span <= a.nkmers && a.binlen >= span &&
+                                (ts / a.binlen) == ((ts + span - 1) / a.binlen);
+            if (grp_ok) {
+                const uint64_t row0g = a.bin_off + ts / a.binlen;
+                if (row0g != cur_row0) {
+                    if (cur_row0 != ~0ull) {
+                        reduce_hist();
+                        __syncthreads();
+                        flush_hist(N, hist, bins, cur_row0, tid);
+                        __syncthreads();
+                    }
+                    cur_row0 = row0g;
+                }
+                const uint8_t *gg = out1 + a.out_off + (uint64_t)ts;
+                const uint4 q = gq_valid ? gq_next : *reinterpret_cast<const uint4 *>(gg + 16u * tid);
+                // prefetch the next group when it is an equally regular one right behind
+                gq_valid = tile + 7 < t_end && tile_contig[tile + 7] == c && ts + 2u * span <= a.nkmers &&
+                           ((ts + span) / a.binlen) == ((ts + 2u * span - 1) / a.binlen);
+                if (gq_valid) gq_next = *reinterpret_cast<const uint4 *>(gg + span + 16u * tid);
+                const uint32_t wq[4] = {q.x, q.y, q.z, q.w};
+                if (since_spill + 4 > 31) spill();
+#pragma unroll
+                for (int wi = 0; wi < 4; ++wi) {
+                    if (want_cs) {
+#pragma unroll
+                        for (int gb = 0; gb < 8; ++gb) cacc[gb] += __popc(wq[wi] & (0x01010101u << gb));
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) hacc += 1ull << (7 * min((uint32_t)__popc((wq[wi] >> (8 * j)) & 0xFFu), N));
+                }
+                since_spill += 4;
+                const uint32_t pos0 = ts + 16u * tid;  // at most one multiple of 100 among 16 positions
+                const uint32_t r100 = (pos0 + 99u) / 100u;
+                const uint32_t first = r100 * 100u - pos0;
+                if (first < 16u) out100[a.out100_off + r100] = (uint8_t)(wq[first >> 2] >> (8 * (first & 3)));
+                next_valid = false;
+                tile += 3;
+                continue;
+            }
+            gq_valid = false;
         }
         const uint32_t tile_start = (tile - a.tile0) * PROBE_TILE;
         const uint32_t npos = min((uint32_t)PROBE_TILE, a.nkmers - tile_start);
