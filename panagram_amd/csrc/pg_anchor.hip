@@ -118,8 +118,8 @@ __global__ __launch_bounds__(64) void k_probe(const SubTable st, const uint64_t 
     constexpr int LDS_LINE_U4 = SLOTS + 1;
     constexpr int BUCKET_BYTES = 16 * SLOTS;
     constexpr int STAGE_ITERS = (PROBE_MAXRUN * SLOTS + 63) / 64;  // 16-byte loads per lane per staging step
-    __shared__ uint32_t lines_w[PROBE_MAXRUN];
-    __shared__ uint4 buf[((STAGE_ITERS * 64 + SLOTS - 1) / SLOTS) * LDS_LINE_U4];  // room for every staged chunk slot
+    __shared__ uint32_t lines_w[PROBE_NB][PROBE_MAXRUN];
+    __shared__ uint4 buf[PROBE_NB][((STAGE_ITERS * 64 + SLOTS - 1) / SLOTS) * LDS_LINE_U4];  // room for every staged chunk slot
     __shared__ uint64_t q_key[PROBE_QCAP];   // overflow queue of the tile (position order)
     __shared__ uint32_t q_line[PROBE_QCAP];  // next line to try
     __shared__ uint32_t q_step[PROBE_QCAP];
@@ -149,92 +149,130 @@ __global__ __launch_bounds__(64) void k_probe(const SubTable st, const uint64_t 
     uint8_t *tile_rows = out1 + a.out_off + (uint64_t)tile_start * nbytes;
     uint32_t qn = 0;  // wave-uniform: overflow entries of this tile so far
 
-    for (uint32_t b = 0; b < npos; b += STRIDE) {
+    // NB independent 64-lane batches are carried through every stage together, so that the
+    // LDS shuffles and the staged table fetches of one batch overlap those of the other(s)
+    constexpr int NB = PROBE_NB;
+    for (uint32_t b0 = 0; b0 < npos; b0 += NB * STRIDE) {
+        int32_t pl[NB];
+        bool inrange[NB], act[NB], leader[NB];
+        uint64_t key[NB];
+        uint32_t grp[NB], line[NB], rid[NB], nruns[NB], m0[NB], m1[NB];
+        int rcode[NB];
         // ---- keys: lane = position b + lane - HALO; it also owns m-mer number b + lane ----
-        const int32_t pl = (int32_t)(b + lane) - HALO;
-        const bool inrange = pl >= (int32_t)b && pl < (int32_t)npos;
-        const uint32_t pq = (uint32_t)max(pl, 0);
-        const uint64_t X = extract_bases(sw, pq) & kmask;
-        const uint64_t B = revcomp_le(X, k);
-        const uint64_t key = canonical_from_xb(X, B, k);
-        bool act = inrange;
-        if (hasn) act = act && (extract_nmask(nw, pq, k) == 0);
-        uint32_t grp;
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const uint32_t b = b0 + u * STRIDE;
+            pl[u] = (int32_t)(b + lane) - HALO;
+            inrange[u] = pl[u] >= (int32_t)b && pl[u] < (int32_t)npos;
+            const uint32_t pq = (uint32_t)max(pl[u], 0);
+            const uint64_t X = extract_bases(sw, pq) & kmask;
+            const uint64_t B = revcomp_le(X, k);
+            key[u] = canonical_from_xb(X, B, k);
+            act[u] = inrange[u];
+            if (hasn) act[u] = act[u] && (extract_nmask(nw, pq, k) == 0);
+            if (W_C) {
+                const uint32_t fa = (uint32_t)extract_bases(sw, b + lane) & mm;  // m-mer b+lane, forward
+                uint32_t fr = __brev(~fa);                                       // ... and its reverse complement
+                fr = (((fr >> 1) & 0x55555555u) | ((fr & 0x55555555u) << 1)) >> (32 - 2 * m);
+                grp[u] = mz_order(fa < fr ? fa : fr);
+            } else {
+                grp[u] = group_of_key(key[u]);
+            }
+        }
         if (W_C) {
-            const uint32_t fa = (uint32_t)extract_bases(sw, b + lane) & mm;  // m-mer b+lane, forward
-            uint32_t fr = __brev(~fa);                                       // ... and its reverse complement
-            fr = (((fr >> 1) & 0x55555555u) | ((fr & 0x55555555u) << 1)) >> (32 - 2 * m);
-            uint32_t best = mz_order(fa < fr ? fa : fr);
             // sliding minimum over lanes [lane-W_C+1, lane] by doubling (lanes below the halo
             // read their own value back: they are never active)
 #pragma unroll
             for (int off = 1; off < W_C; off <<= 1) {
                 const int d = (2 * off <= W_C) ? off : (W_C - off);  // 8: 1,2,4  12: 1,2,4,4  16: 1,2,4,8
-                const uint32_t up = __shfl_up(best, d);
-                best = min(best, lane >= d ? up : best);
+                uint32_t up[NB];
+#pragma unroll
+                for (int u = 0; u < NB; ++u) up[u] = __shfl_up(grp[u], d);
+#pragma unroll
+                for (int u = 0; u < NB; ++u) grp[u] = min(grp[u], lane >= d ? up[u] : grp[u]);
             }
-            grp = best;
-        } else {
-            grp = group_of_key(key);
         }
-        const uint32_t line = home_of_group(grp, st.nbuckets);
-
         // ---- runs of equal home line among the active lanes ----
-        const uint32_t prev_line = __shfl_up(line, 1);
-        const unsigned long long amask = __ballot(act);
-        const bool prev_act = lane > 0 && ((amask >> (lane - 1)) & 1ull);
-        const bool leader = act && (!prev_act || line != prev_line);
-        const unsigned long long lmask = __ballot(leader);
-        const uint32_t rid = lanes_le_count(lmask, leader) - 1;  // run id of an active lane
-        const uint32_t nruns = (uint32_t)__popcll(lmask);
-
-        uint32_t m0 = 0, m1 = 0;
-        int rcode = 0;
-        for (uint32_t r0 = 0; r0 < nruns; r0 += PROBE_MAXRUN) {  // one trip unless the batch has > MAXRUN lines
-            const uint32_t nl = min((uint32_t)PROBE_MAXRUN, nruns - r0);
-            if (leader && rid - r0 < nl) lines_w[rid - r0] = line;
+        uint32_t prev_line[NB];
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            line[u] = home_of_group(grp[u], st.nbuckets);
+            prev_line[u] = __shfl_up(line[u], 1);
+        }
+        uint32_t maxruns = 0;
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const unsigned long long amask = __ballot(act[u]);
+            const bool prev_act = lane > 0 && ((amask >> (lane - 1)) & 1ull);
+            leader[u] = act[u] && (!prev_act || line[u] != prev_line[u]);
+            const unsigned long long lmask = __ballot(leader[u]);
+            rid[u] = lanes_le_count(lmask, leader[u]) - 1;  // run id of an active lane
+            nruns[u] = (uint32_t)__popcll(lmask);
+            maxruns = max(maxruns, nruns[u]);
+            m0[u] = m1[u] = 0;
+            rcode[u] = 0;
+        }
+        for (uint32_t r0 = 0; r0 < maxruns; r0 += PROBE_MAXRUN) {  // one trip unless a batch has > MAXRUN lines
+            uint32_t nl[NB];
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+                nl[u] = nruns[u] > r0 ? min((uint32_t)PROBE_MAXRUN, nruns[u] - r0) : 0u;
+                if (leader[u] && rid[u] - r0 < nl[u]) lines_w[u][rid[u] - r0] = line[u];
+            }
             __syncthreads();
-            // stage: nl lines = nl*8 chunks of 16 bytes, coalesced, all loads of the step in flight
-            // loads AND LDS writes are unconditional (chunks past the last line re-copy its last
+            // stage: nl lines = nl*SLOTS chunks of 16 bytes, coalesced, all loads of the step in flight.
+            // Loads AND LDS writes are unconditional (chunks past the last line re-copy its last
             // chunk into unused buffer lines): any predicate here makes the compiler sink each load
             // into its own branch and wait for it there
-            uint4 v[STAGE_ITERS];
-            const uint32_t total = nl * SLOTS;
+            uint4 v[NB][STAGE_ITERS];
 #pragma unroll
-            for (int u = 0; u < STAGE_ITERS; ++u) {
-                const uint32_t idx = min((uint32_t)(u * 64 + lane), total - 1);
-                v[u] = *reinterpret_cast<const uint4 *>(st.buckets + (uint64_t)lines_w[idx / SLOTS] * BUCKET_BYTES + (idx % SLOTS) * 16);
+            for (int u = 0; u < NB; ++u) {
+                const uint32_t total = max(nl[u], 1u) * SLOTS;
+#pragma unroll
+                for (int it = 0; it < STAGE_ITERS; ++it) {
+                    const uint32_t idx = min((uint32_t)(it * 64 + lane), total - 1);
+                    const uint32_t ln = nl[u] ? lines_w[u][idx / SLOTS] : 0u;
+                    v[u][it] = *reinterpret_cast<const uint4 *>(st.buckets + (uint64_t)ln * BUCKET_BYTES + (idx % SLOTS) * 16);
+                }
             }
 #pragma unroll
-            for (int u = 0; u < STAGE_ITERS; ++u) {
-                const uint32_t idx = u * 64 + lane;
-                buf[(idx / SLOTS) * LDS_LINE_U4 + (idx % SLOTS)] = v[u];
-            }
+            for (int u = 0; u < NB; ++u)
+#pragma unroll
+                for (int it = 0; it < STAGE_ITERS; ++it) {
+                    const uint32_t idx = it * 64 + lane;
+                    buf[u][(idx / SLOTS) * LDS_LINE_U4 + (idx % SLOTS)] = v[u][it];
+                }
             __syncthreads();
-            if (act && rid - r0 < nl) rcode = scan_line_lds<TWO, SLOTS>(buf + (rid - r0) * LDS_LINE_U4, key, m0, m1);
+#pragma unroll
+            for (int u = 0; u < NB; ++u)
+                if (act[u] && rid[u] - r0 < nl[u])
+                    rcode[u] = scan_line_lds<TWO, SLOTS>(buf[u] + (rid[u] - r0) * LDS_LINE_U4, key[u], m0[u], m1[u]);
             __syncthreads();
         }
 
         // ---- overflow: absent from a full line -> queue entry for the next line of its sequence ----
-        const bool ovf = act && rcode < 0;
-        const unsigned long long omask = __ballot(ovf);
-        if (omask) {
-            const uint32_t step = step_of_group(grp, st.nbuckets);
-            const uint32_t nx = next_line(line, step, st.nbuckets);
-            const uint32_t slot = qn + lanes_le_count(omask, ovf) - 1;
-            if (ovf) {
-                if (slot < (uint32_t)PROBE_QCAP) {
-                    q_key[slot] = key;
-                    q_line[slot] = nx;
-                    q_step[slot] = step;
-                    q_pl[slot] = (uint16_t)pl;
-                } else {
-                    lane_chase<TWO, SLOTS>(st, key, nx, step, m0, m1);  // queue full: resolve inline
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const bool ovf = act[u] && rcode[u] < 0;
+            const unsigned long long omask = __ballot(ovf);
+            if (omask) {
+                const uint32_t step = step_of_group(grp[u], st.nbuckets);
+                const uint32_t nx = next_line(line[u], step, st.nbuckets);
+                const uint32_t slot = qn + lanes_le_count(omask, ovf) - 1;
+                if (ovf) {
+                    if (slot < (uint32_t)PROBE_QCAP) {
+                        q_key[slot] = key[u];
+                        q_line[slot] = nx;
+                        q_step[slot] = step;
+                        q_pl[slot] = (uint16_t)pl[u];
+                    } else {
+                        lane_chase<TWO, SLOTS>(st, key[u], nx, step, m0[u], m1[u]);  // queue full: resolve inline
+                    }
                 }
+                qn = min(qn + (uint32_t)__popcll(omask), (uint32_t)PROBE_QCAP);
             }
-            qn = min(qn + (uint32_t)__popcll(omask), (uint32_t)PROBE_QCAP);
+            if (inrange[u]) store_row<ROWMODE>(tile_rows + (uint64_t)pl[u] * nbytes, m0[u], m1[u], rc);
         }
-        if (inrange) store_row<ROWMODE>(tile_rows + (uint64_t)pl * nbytes, m0, m1, rc);
     }
 
     // ---- overflow levels: dense 64-entry batches out of the LDS queue, staged exactly like the
@@ -269,22 +307,22 @@ __global__ __launch_bounds__(64) void k_probe(const SubTable st, const uint64_t 
             int rcode = 0;
             for (uint32_t r0 = 0; r0 < nruns; r0 += PROBE_MAXRUN) {
                 const uint32_t nl = min((uint32_t)PROBE_MAXRUN, nruns - r0);
-                if (leader && rid - r0 < nl) lines_w[rid - r0] = line;
+                if (leader && rid - r0 < nl) lines_w[0][rid - r0] = line;
                 __syncthreads();
                 uint4 v[STAGE_ITERS];
                 const uint32_t total = nl * SLOTS;
 #pragma unroll
                 for (int u = 0; u < STAGE_ITERS; ++u) {
                     const uint32_t idx = min((uint32_t)(u * 64 + lane), total - 1);
-                    v[u] = *reinterpret_cast<const uint4 *>(st.buckets + (uint64_t)lines_w[idx / SLOTS] * BUCKET_BYTES + (idx % SLOTS) * 16);
+                    v[u] = *reinterpret_cast<const uint4 *>(st.buckets + (uint64_t)lines_w[0][idx / SLOTS] * BUCKET_BYTES + (idx % SLOTS) * 16);
                 }
 #pragma unroll
                 for (int u = 0; u < STAGE_ITERS; ++u) {
                     const uint32_t idx = u * 64 + lane;
-                    buf[(idx / SLOTS) * LDS_LINE_U4 + (idx % SLOTS)] = v[u];
+                    buf[0][(idx / SLOTS) * LDS_LINE_U4 + (idx % SLOTS)] = v[u];
                 }
                 __syncthreads();
-                if (act && rid - r0 < nl) rcode = scan_line_lds<TWO, SLOTS>(buf + (rid - r0) * LDS_LINE_U4, key, m0, m1);
+                if (act && rid - r0 < nl) rcode = scan_line_lds<TWO, SLOTS>(buf[0] + (rid - r0) * LDS_LINE_U4, key, m0, m1);
                 __syncthreads();
             }
             const bool again = act && rcode < 0;

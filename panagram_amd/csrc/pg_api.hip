@@ -306,6 +306,7 @@ static int after_insert(pg_table *t, int si) {
 extern "C" int pg_table_insert_seqset(pg_table *t, int g, const pg_seqset *sq) {
     if (!t || !sq) return fail(PG_E_INVALID, "pg_table_insert_seqset: NULL argument");
     if (g < 0 || g >= t->ngenomes) return fail(PG_E_INVALID, "genome index %d out of range (0..%d)", g, t->ngenomes - 1);
+    if (t->ctx != sq->ctx) return fail(PG_E_INVALID, "table and seqset belong to different contexts");
     if (int r = use_device(t->ctx)) return r;
     const int d = g / 32, si = d / 2, w = d % 2;
     const uint32_t bits = 1u << (g % 32);

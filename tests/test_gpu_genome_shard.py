@@ -53,3 +53,31 @@ def test_partial_tables_combine_equals_reference(ctx, name, world):
     assert np.array_equal(res[0].colsums().astype(np.int64), ora["colsums"])
     for x in res + ss + tables:
         x.close()
+
+
+def test_rccl_code_path_world1(ctx):
+    """The real torch.distributed path (backend "nccl" = RCCL) with world_size 1 on the one GPU
+    of the test box: zero-copy view of the library's row buffer -> all_reduce -> pg_rows_epilogue."""
+    import os
+    import torch.distributed as dist
+    from panagram_amd import engine
+    from panagram_amd.distributed import anchor_genome_sharded, build_partial_table
+    fx = H.load_case("n9_k21")
+    n, k = int(fx["ngenomes"]), int(fx["k"])
+    genomes = [[s for _, s in po.parse_fasta_cpp(fx[f"fasta_{g}"].tobytes())] for g in range(n)]
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29600 + os.getpid() % 300))
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        tbl = build_partial_table(ctx, k, n, 0, 1, lambda g: genomes[g])
+        g = int(fx["anchors"][0])
+        out, cs = anchor_genome_sharded(tbl, genomes[g])
+        payload = b"".join(r[0].tobytes() for r in out)
+        assert payload == fx[f"a{g}_bitmap1"].tobytes()
+        assert b"".join(r[1].tobytes() for r in out) == fx[f"a{g}_bitmap100"].tobytes()
+        ora = po.anchor_fasta(H.case_dbs(fx), fx[f"fasta_{g}"].tobytes(), k, n)
+        assert np.array_equal(cs, ora["colsums"])
+        tbl.close()
+    finally:
+        dist.destroy_process_group()
