@@ -10,8 +10,11 @@
  *     pg_last_error() returns a thread-local, human-readable message.
  *   - handles are opaque; the library owns all device memory behind them.
  *   - host output buffers are allocated by the caller.
- *   - all work of a context is enqueued on ONE HIP stream (pg_ctx_set_stream);
- *     functions documented "async" do not synchronise it.
+ *   - all work of a context is enqueued on ONE HIP stream (pg_ctx_set_stream), except that
+ *     pg_anchor_run puts its statistics pass on a library-owned side stream, event-ordered
+ *     behind the probe kernels so that it overlaps the next result's probes; every function
+ *     that reads a result makes the main stream wait for that pass first.
+ *     Functions documented "async" do not synchronise.
  *   - a context is not re-entrant; different contexts are independent.
  *
  * Bit/byte conventions (identical to the reference):

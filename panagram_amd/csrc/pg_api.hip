@@ -50,6 +50,7 @@ struct pg_ctx {
     int device;
     hipStream_t own_stream;
     hipStream_t stream;
+    hipStream_t aux_stream;  // statistics kernels run here, event-ordered behind the probe kernels
 };
 
 struct SubHost {
@@ -93,7 +94,7 @@ struct pg_result {
     uint32_t *d_bins;
     uint64_t total_bins;
     unsigned long long *d_colsums;
-    hipEvent_t ev[3];  // start / after k_probe / after k_epilogue of the last pg_anchor_run
+    hipEvent_t ev[4];  // last pg_anchor_run: start / after k_probe (main stream), epilogue start / end (side stream)
     bool ev_ok, ev_epi;
 };
 
@@ -127,6 +128,12 @@ extern "C" int pg_ctx_create(int device_id, pg_ctx **out) {
         return fail(PG_E_HIP, "hipStreamCreate failed: %s", hipGetErrorString(se));
     }
     c->stream = c->own_stream;
+    se = hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking);
+    if (se != hipSuccess) {
+        hipStreamDestroy(c->own_stream);
+        delete c;
+        return fail(PG_E_HIP, "hipStreamCreate failed: %s", hipGetErrorString(se));
+    }
     *out = c;
     return PG_OK;
 }
@@ -135,6 +142,8 @@ extern "C" int pg_ctx_destroy(pg_ctx *c) {
     if (!c) return PG_OK;
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
+    hipStreamSynchronize(c->aux_stream);
+    hipStreamDestroy(c->aux_stream);
     hipStreamDestroy(c->own_stream);
     delete c;
     return PG_OK;
@@ -150,6 +159,7 @@ extern "C" int pg_ctx_synchronize(pg_ctx *c) {
     if (!c) return fail(PG_E_INVALID, "ctx is NULL");
     if (int r = use_device(c)) return r;
     HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipStreamSynchronize(c->aux_stream));
     return PG_OK;
 }
 
@@ -701,6 +711,7 @@ extern "C" int pg_result_destroy(pg_result *r) {
     if (!r) return PG_OK;
     hipSetDevice(r->tbl->ctx->device);
     hipStreamSynchronize(r->tbl->ctx->stream);
+    hipStreamSynchronize(r->tbl->ctx->aux_stream);
     hipFree(r->d_ad);
     hipFree(r->d_tile_contig);
     hipFree(r->d_out1);
@@ -713,13 +724,31 @@ extern "C" int pg_result_destroy(pg_result *r) {
     return PG_OK;
 }
 
+// statistics kernels of a result, on stream `st`
+static int enqueue_epilogue(pg_result *r, hipStream_t st) {
+    pg_table *t = r->tbl;
+    const uint32_t N = t->ngenomes;
+    HIP_TRY(hipMemsetAsync(r->d_bins, 0, std::max<uint64_t>(1, r->total_bins) * (N + 1) * 4, st));
+    HIP_TRY(hipMemsetAsync(r->d_colsums, 0, (size_t)N * 8, st));
+    HIP_TRY(launch_rows_epilogue(st, N, r->d_ad, r->d_tile_contig, r->ntiles, r->d_out1, r->d_out100, r->d_bins,
+                                 r->d_colsums, r->flags));
+    return PG_OK;
+}
+
+// make the context's main stream wait for the result's statistics (side stream)
+static int join_result(pg_result *r) {
+    if (r->ev_epi) HIP_TRY(hipStreamWaitEvent(r->tbl->ctx->stream, r->ev[3], 0));
+    return PG_OK;
+}
+
 extern "C" int pg_anchor_run(pg_result *r) {
     if (!r) return fail(PG_E_INVALID, "result is NULL");
     pg_table *t = r->tbl;
     if (int e = use_device(t->ctx)) return e;
-    hipStream_t st = t->ctx->stream;
+    hipStream_t st = t->ctx->stream, aux = t->ctx->aux_stream;
     if (!r->ev[0])
         for (auto &e : r->ev) HIP_TRY(hipEventCreate(&e));
+    if (int e = join_result(r)) return e;  // a previous run's statistics still read the rows we overwrite
     TableDesc T = make_desc(t);
     HIP_TRY(hipEventRecord(r->ev[0], st));
     HIP_TRY(launch_anchor(st, T, r->seqs->d_seqw, r->seqs->d_nmw, r->seqs->d_has_n, r->seqs->d_desc, r->d_ad,
@@ -728,8 +757,12 @@ extern "C" int pg_anchor_run(pg_result *r) {
     r->ev_ok = true;
     r->ev_epi = false;
     if (!(r->flags & PG_ANCHOR_ROWS_ONLY)) {
-        if (int e = pg_rows_epilogue(r)) return e;
-        HIP_TRY(hipEventRecord(r->ev[2], st));
+        // the streaming statistics pass runs on the side stream, ordered behind the probe kernels by
+        // an event, so that it overlaps the next result's probe kernels
+        HIP_TRY(hipStreamWaitEvent(aux, r->ev[1], 0));
+        HIP_TRY(hipEventRecord(r->ev[2], aux));
+        if (int e = enqueue_epilogue(r, aux)) return e;
+        HIP_TRY(hipEventRecord(r->ev[3], aux));
         r->ev_epi = true;
     }
     return PG_OK;
@@ -739,10 +772,10 @@ extern "C" int pg_result_timing(pg_result *r, float *probe_ms, float *epilogue_m
     if (!r) return fail(PG_E_INVALID, "result is NULL");
     if (!r->ev_ok) return fail(PG_E_INVALID, "pg_anchor_run has not been called on this result");
     if (int e = use_device(r->tbl->ctx)) return e;
-    HIP_TRY(hipEventSynchronize(r->ev[r->ev_epi ? 2 : 1]));
+    HIP_TRY(hipEventSynchronize(r->ev[r->ev_epi ? 3 : 1]));
     float a = 0, b = 0;
     HIP_TRY(hipEventElapsedTime(&a, r->ev[0], r->ev[1]));
-    if (r->ev_epi) HIP_TRY(hipEventElapsedTime(&b, r->ev[1], r->ev[2]));
+    if (r->ev_epi) HIP_TRY(hipEventElapsedTime(&b, r->ev[2], r->ev[3]));
     if (probe_ms) *probe_ms = a;
     if (epilogue_ms) *epilogue_ms = b;
     return PG_OK;
@@ -750,15 +783,10 @@ extern "C" int pg_result_timing(pg_result *r, float *probe_ms, float *epilogue_m
 
 extern "C" int pg_rows_epilogue(pg_result *r) {
     if (!r) return fail(PG_E_INVALID, "result is NULL");
-    pg_table *t = r->tbl;
-    if (int e = use_device(t->ctx)) return e;
-    hipStream_t st = t->ctx->stream;
-    const uint32_t N = t->ngenomes;
-    HIP_TRY(hipMemsetAsync(r->d_bins, 0, std::max<uint64_t>(1, r->total_bins) * (N + 1) * 4, st));
-    HIP_TRY(hipMemsetAsync(r->d_colsums, 0, (size_t)N * 8, st));
-    HIP_TRY(launch_rows_epilogue(st, N, r->d_ad, r->d_tile_contig, r->ntiles, r->d_out1, r->d_out100, r->d_bins,
-                                 r->d_colsums, r->flags));
-    return PG_OK;
+    if (int e = use_device(r->tbl->ctx)) return e;
+    if (int e = join_result(r)) return e;
+    r->ev_epi = false;
+    return enqueue_epilogue(r, r->tbl->ctx->stream);  // explicit call (genome-sharded mode): main stream
 }
 
 extern "C" int pg_result_contig_info(const pg_result *r, uint32_t idx, uint64_t *nkmers, uint64_t *nrows100,
@@ -776,6 +804,7 @@ extern "C" int pg_result_download(pg_result *r, uint32_t idx, uint8_t *bitmap1, 
     if (!r) return fail(PG_E_INVALID, "result is NULL");
     if (idx >= r->ad.size()) return fail(PG_E_INVALID, "contig %u out of range", idx);
     if (int e = use_device(r->tbl->ctx)) return e;
+    if (int e = join_result(r)) return e;
     hipStream_t st = r->tbl->ctx->stream;
     const AnchorDesc &a = r->ad[idx];
     const uint32_t N = r->tbl->ngenomes, nbytes = (N + 7) / 8;
@@ -793,6 +822,7 @@ extern "C" int pg_result_colsums(pg_result *r, uint64_t *colsums) {
     if (!r || !colsums) return fail(PG_E_INVALID, "pg_result_colsums: NULL argument");
     if (!(r->flags & PG_ANCHOR_COLSUMS)) return fail(PG_E_INVALID, "result was created without PG_ANCHOR_COLSUMS");
     if (int e = use_device(r->tbl->ctx)) return e;
+    if (int e = join_result(r)) return e;
     hipStream_t st = r->tbl->ctx->stream;
     HIP_TRY(hipMemcpyAsync(colsums, r->d_colsums, (size_t)r->tbl->ngenomes * 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
