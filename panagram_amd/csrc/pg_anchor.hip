@@ -105,6 +105,80 @@ __device__ __forceinline__ uint32_t lanes_le_count(unsigned long long mask, bool
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u)) + (own ? 1u : 0u);
 }
 
+// Overflow levels of a tile: dense 64-entry batches out of the wave's LDS queue, staged exactly
+// like the main batches (neighbouring entries belong to the same group and share their next
+// line); entries that overflow again are compacted in place for the next level.
+template <bool TWO, int ROWMODE, int SLOTS, int MAXRUN>
+__device__ __forceinline__ void drain_queue(const SubTable &st, uint32_t qn, uint64_t *q_key, uint32_t *q_line,
+                                            uint32_t *q_step, uint16_t *q_pl, uint32_t *lines_w, uint4 *buf,
+                                            uint8_t *tile_rows, uint32_t nbytes, const RowCols rc, int lane) {
+    constexpr int LDS_LINE_U4 = SLOTS + 1;
+    constexpr int BUCKET_BYTES = 16 * SLOTS;
+    constexpr int STAGE_ITERS = (MAXRUN * SLOTS + 63) / 64;
+    for (int level = 1; qn > 0; ++level) {
+        __syncthreads();
+        if (level > PROBE_STAGED_LEVELS) {
+            // the few entries still unresolved (long chains) walk their sequences lane by lane:
+            // 8 slot loads in flight per line, no staging overhead
+            for (uint32_t e = lane; e < qn; e += 64) {
+                uint32_t m0, m1;
+                lane_chase<TWO, SLOTS>(st, q_key[e], q_line[e], q_step[e], m0, m1);
+                if (m0 | m1) store_row<ROWMODE>(tile_rows + (uint64_t)q_pl[e] * nbytes, m0, m1, rc);
+            }
+            break;
+        }
+        uint32_t kept = 0;
+        for (uint32_t i0 = 0; i0 < qn; i0 += 64) {
+            const uint32_t e = i0 + lane;
+            const bool act = e < qn;
+            const uint32_t ec = act ? e : qn - 1;
+            const uint64_t key = q_key[ec];
+            const uint32_t line = q_line[ec], step = q_step[ec];
+            const uint32_t pl = q_pl[ec];
+            const uint32_t prev_line = __shfl_up(line, 1);
+            const bool leader = act && (lane == 0 || line != prev_line);
+            const unsigned long long lmask = __ballot(leader);
+            const uint32_t rid = lanes_le_count(lmask, leader) - 1;
+            const uint32_t nruns = (uint32_t)__popcll(lmask);
+            uint32_t m0 = 0, m1 = 0;
+            int rcode = 0;
+            for (uint32_t r0 = 0; r0 < nruns; r0 += MAXRUN) {
+                const uint32_t nl = min((uint32_t)MAXRUN, nruns - r0);
+                if (leader && rid - r0 < nl) lines_w[rid - r0] = line;
+                __syncthreads();
+                uint4 v[STAGE_ITERS];
+                const uint32_t total = nl * SLOTS;
+#pragma unroll
+                for (int u = 0; u < STAGE_ITERS; ++u) {
+                    const uint32_t idx = min((uint32_t)(u * 64 + lane), total - 1);
+                    v[u] = *reinterpret_cast<const uint4 *>(st.buckets + (uint64_t)lines_w[idx / SLOTS] * BUCKET_BYTES + (idx % SLOTS) * 16);
+                }
+#pragma unroll
+                for (int u = 0; u < STAGE_ITERS; ++u) {
+                    const uint32_t idx = u * 64 + lane;
+                    buf[(idx / SLOTS) * LDS_LINE_U4 + (idx % SLOTS)] = v[u];
+                }
+                __syncthreads();
+                if (act && rid - r0 < nl) rcode = scan_line_lds<TWO, SLOTS>(buf + (rid - r0) * LDS_LINE_U4, key, m0, m1);
+                __syncthreads();
+            }
+            const bool again = act && rcode < 0;
+            if (act && (m0 | m1)) store_row<ROWMODE>(tile_rows + (uint64_t)pl * nbytes, m0, m1, rc);
+            const unsigned long long kmask2 = __ballot(again);
+            if (again) {  // in-place compaction: slot <= e, and this batch's reads are already done
+                const uint32_t slot = kept + lanes_le_count(kmask2, true) - 1;
+                q_key[slot] = key;
+                q_line[slot] = next_line(line, step, st.nbuckets);
+                q_step[slot] = step;
+                q_pl[slot] = (uint16_t)pl;
+            }
+            kept += (uint32_t)__popcll(kmask2);
+            __syncthreads();
+        }
+        qn = kept;
+    }
+}
+
 template <int W_C, bool TWO, int ROWMODE, int SLOTS>
 __global__ __launch_bounds__(64) void k_probe(const SubTable st, const uint64_t *__restrict__ seqw,
                                               const uint32_t *__restrict__ nmw, const uint32_t *__restrict__ has_n,
@@ -275,71 +349,7 @@ __global__ __launch_bounds__(64) void k_probe(const SubTable st, const uint64_t 
         }
     }
 
-    // ---- overflow levels: dense 64-entry batches out of the LDS queue, staged exactly like the
-    // main batches (neighbouring entries belong to the same group and share their next line);
-    // entries that overflow again are compacted in place for the next level ----
-    for (int level = 1; qn > 0; ++level) {
-        __syncthreads();
-        if (level > PROBE_STAGED_LEVELS) {
-            // the few entries still unresolved (long chains) walk their sequences lane by lane:
-            // 8 slot loads in flight per line, no staging overhead
-            for (uint32_t e = lane; e < qn; e += 64) {
-                uint32_t m0, m1;
-                lane_chase<TWO, SLOTS>(st, q_key[e], q_line[e], q_step[e], m0, m1);
-                if (m0 | m1) store_row<ROWMODE>(tile_rows + (uint64_t)q_pl[e] * nbytes, m0, m1, rc);
-            }
-            break;
-        }
-        uint32_t kept = 0;
-        for (uint32_t i0 = 0; i0 < qn; i0 += 64) {
-            const uint32_t e = i0 + lane;
-            const bool act = e < qn;
-            const uint32_t ec = act ? e : qn - 1;
-            const uint64_t key = q_key[ec];
-            const uint32_t line = q_line[ec], step = q_step[ec];
-            const uint32_t pl = q_pl[ec];
-            const uint32_t prev_line = __shfl_up(line, 1);
-            const bool leader = act && (lane == 0 || line != prev_line);
-            const unsigned long long lmask = __ballot(leader);
-            const uint32_t rid = lanes_le_count(lmask, leader) - 1;
-            const uint32_t nruns = (uint32_t)__popcll(lmask);
-            uint32_t m0 = 0, m1 = 0;
-            int rcode = 0;
-            for (uint32_t r0 = 0; r0 < nruns; r0 += PROBE_MAXRUN) {
-                const uint32_t nl = min((uint32_t)PROBE_MAXRUN, nruns - r0);
-                if (leader && rid - r0 < nl) lines_w[0][rid - r0] = line;
-                __syncthreads();
-                uint4 v[STAGE_ITERS];
-                const uint32_t total = nl * SLOTS;
-#pragma unroll
-                for (int u = 0; u < STAGE_ITERS; ++u) {
-                    const uint32_t idx = min((uint32_t)(u * 64 + lane), total - 1);
-                    v[u] = *reinterpret_cast<const uint4 *>(st.buckets + (uint64_t)lines_w[0][idx / SLOTS] * BUCKET_BYTES + (idx % SLOTS) * 16);
-                }
-#pragma unroll
-                for (int u = 0; u < STAGE_ITERS; ++u) {
-                    const uint32_t idx = u * 64 + lane;
-                    buf[0][(idx / SLOTS) * LDS_LINE_U4 + (idx % SLOTS)] = v[u];
-                }
-                __syncthreads();
-                if (act && rid - r0 < nl) rcode = scan_line_lds<TWO, SLOTS>(buf[0] + (rid - r0) * LDS_LINE_U4, key, m0, m1);
-                __syncthreads();
-            }
-            const bool again = act && rcode < 0;
-            if (act && (m0 | m1)) store_row<ROWMODE>(tile_rows + (uint64_t)pl * nbytes, m0, m1, rc);
-            const unsigned long long kmask2 = __ballot(again);
-            if (again) {  // in-place compaction: slot <= e, and this batch's reads are already done
-                const uint32_t slot = kept + lanes_le_count(kmask2, true) - 1;
-                q_key[slot] = key;
-                q_line[slot] = next_line(line, step, st.nbuckets);
-                q_step[slot] = step;
-                q_pl[slot] = (uint16_t)pl;
-            }
-            kept += (uint32_t)__popcll(kmask2);
-            __syncthreads();
-        }
-        qn = kept;
-    }
+    drain_queue<TWO, ROWMODE, SLOTS, PROBE_MAXRUN>(st, qn, q_key, q_line, q_step, q_pl, lines_w[0], buf[0], tile_rows, nbytes, rc, lane);
 }
 
 // ---------------------------------------------------------------------------
