@@ -258,7 +258,7 @@ __global__ __launch_bounds__(64) void k_probe(const SubTable st, const uint64_t 
             // read their own value back: they are never active)
 #pragma unroll
             for (int off = 1; off < W_C; off <<= 1) {
-                const int d = (2 * off <= W_C) ? off : (W_C - off);  // 8: 1,2,4  12: 1,2,4,4  16: 1,2,4,8
+                const int d = (2 * off <= W_C) ? off : (W_C - off);  // 6: 1,2,2  8: 1,2,4  12: 1,2,4,4  16: 1,2,4,8
                 uint32_t up[NB];
 #pragma unroll
                 for (int u = 0; u < NB; ++u) up[u] = __shfl_up(grp[u], d);
@@ -747,8 +747,11 @@ hipError_t launch_anchor(hipStream_t s, const TableDesc &T, const uint64_t *seqw
         const uint32_t w = st.m ? st.k - st.m + 1 : 0;
         switch (w) {
             case 0: e = probe_w<0>(s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, out1, nbytes, rc, rm); break;
+            case 6: e = probe_w<6>(s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, out1, nbytes, rc, rm); break;
             case 8: e = probe_w<8>(s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, out1, nbytes, rc, rm); break;
+            case 10: e = probe_w<10>(s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, out1, nbytes, rc, rm); break;
             case 12: e = probe_w<12>(s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, out1, nbytes, rc, rm); break;
+            case 14: e = probe_w<14>(s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, out1, nbytes, rc, rm); break;
             case 16: e = probe_w<16>(s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, out1, nbytes, rc, rm); break;
             default: return hipErrorInvalidValue;
         }
