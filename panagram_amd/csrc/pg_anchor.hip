@@ -220,6 +220,7 @@ __global__ __launch_bounds__(64) void k_probe(const SubTable st, const uint64_t 
     constexpr int STRIDE = 64 - HALO;        // new positions per batch
     const uint32_t m = W_C ? (uint32_t)k - W_C + 1 : 0;
     const uint32_t mm = (m >= 16) ? ~0u : ((1u << (2 * m)) - 1);
+    const uint64_t mm64 = (m >= 32) ? ~0ull : ((1ull << (2 * (m ? m : 1))) - 1);
     uint8_t *tile_rows = out1 + a.out_off + (uint64_t)tile_start * nbytes;
     uint32_t qn = 0;  // wave-uniform: overflow entries of this tile so far
 
@@ -245,10 +246,16 @@ __global__ __launch_bounds__(64) void k_probe(const SubTable st, const uint64_t 
             act[u] = inrange[u];
             if (hasn) act[u] = act[u] && (extract_nmask(nw, pq, k) == 0);
             if (W_C) {
-                const uint32_t fa = (uint32_t)extract_bases(sw, b + lane) & mm;  // m-mer b+lane, forward
-                uint32_t fr = __brev(~fa);                                       // ... and its reverse complement
-                fr = (((fr >> 1) & 0x55555555u) | ((fr & 0x55555555u) << 1)) >> (32 - 2 * m);
-                grp[u] = mz_order(fa < fr ? fa : fr);
+                if (m <= 16) {
+                    const uint32_t fa = (uint32_t)extract_bases(sw, b + lane) & mm;  // m-mer b+lane, forward
+                    uint32_t fr = __brev(~fa);                                       // ... and its reverse complement
+                    fr = (((fr >> 1) & 0x55555555u) | ((fr & 0x55555555u) << 1)) >> (32 - 2 * m);
+                    grp[u] = mz_order(fa < fr ? fa : fr);
+                } else {  // long m-mers (k > 21): same thing in 64 bits
+                    const uint64_t fa = extract_bases(sw, b + lane) & mm64;
+                    const uint64_t fr = pair_reverse64(~fa) >> (64 - 2 * m);
+                    grp[u] = mmer_rank(fa < fr ? fa : fr);
+                }
             } else {
                 grp[u] = group_of_key(key[u]);
             }
@@ -258,7 +265,7 @@ __global__ __launch_bounds__(64) void k_probe(const SubTable st, const uint64_t 
             // read their own value back: they are never active)
 #pragma unroll
             for (int off = 1; off < W_C; off <<= 1) {
-                const int d = (2 * off <= W_C) ? off : (W_C - off);  // 6: 1,2,2  8: 1,2,4  12: 1,2,4,4  16: 1,2,4,8
+                const int d = (2 * off <= W_C) ? off : (W_C - off);  // 3: 1,1  5: 1,2,1  6: 1,2,2  7: 1,2,3  8: 1,2,4
                 uint32_t up[NB];
 #pragma unroll
                 for (int u = 0; u < NB; ++u) up[u] = __shfl_up(grp[u], d);
@@ -745,14 +752,14 @@ hipError_t launch_anchor(hipStream_t s, const TableDesc &T, const uint64_t *seqw
         rc.nb1 = (st.W == 2 && nbytes > rc.col0 + 4) ? min(4u, nbytes - rc.col0 - 4) : 0;
         const int rm = (T.nsub == 1) ? row_mode(nbytes, rc) : 0;
         const uint32_t w = st.m ? st.k - st.m + 1 : 0;
-        switch (w) {
+        switch (w) {  // the kernel's compile-time window must be the one the table was built with
             case 0: e = probe_w<0>(s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, out1, nbytes, rc, rm); break;
+            case 3: e = probe_w<3>(s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, out1, nbytes, rc, rm); break;
+            case 4: e = probe_w<4>(s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, out1, nbytes, rc, rm); break;
+            case 5: e = probe_w<5>(s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, out1, nbytes, rc, rm); break;
             case 6: e = probe_w<6>(s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, out1, nbytes, rc, rm); break;
+            case 7: e = probe_w<7>(s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, out1, nbytes, rc, rm); break;
             case 8: e = probe_w<8>(s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, out1, nbytes, rc, rm); break;
-            case 10: e = probe_w<10>(s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, out1, nbytes, rc, rm); break;
-            case 12: e = probe_w<12>(s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, out1, nbytes, rc, rm); break;
-            case 14: e = probe_w<14>(s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, out1, nbytes, rc, rm); break;
-            case 16: e = probe_w<16>(s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, out1, nbytes, rc, rm); break;
             default: return hipErrorInvalidValue;
         }
         if (e != hipSuccess) return e;

@@ -61,6 +61,8 @@ struct SubHost {
 struct pg_table {
     pg_ctx *ctx;
     int k, ngenomes, ndbs;
+    uint32_t m;  // minimizer length of every sub-table (0 = direct hashing)
+    bool m_pinned = false;  // set by pg_table_set_minimizer: re-hashing keeps m
     std::vector<SubHost> subs;
     unsigned long long *d_counters;  // [0] newly claimed, [1] overflow flag
 };
@@ -182,7 +184,7 @@ static uint64_t next_prime(uint64_t n) {
     }
 }
 
-static int alloc_sub(pg_ctx *ctx, uint32_t W, uint32_t word0, uint32_t k, uint32_t slots, uint64_t nbuckets, SubTable *out) {
+static int alloc_sub(pg_ctx *ctx, uint32_t W, uint32_t word0, uint32_t k, uint32_t m, uint32_t slots, uint64_t nbuckets, SubTable *out) {
     if (nbuckets < 64) nbuckets = 64;
     nbuckets = next_prime(nbuckets);
     if (nbuckets > 0xFFFFFFFFull) return fail(PG_E_CAPACITY, "sub-table would exceed 2^32 lines (512 GB)");
@@ -190,8 +192,7 @@ static int alloc_sub(pg_ctx *ctx, uint32_t W, uint32_t word0, uint32_t k, uint32
     t.W = W;
     t.word0 = word0;
     t.k = k;
-    const uint32_t w = minimizer_window(k);
-    t.m = w ? k - w + 1 : 0;
+    t.m = m;
     t.slots = slots;
     t.pad_ = 0;
     t.nbuckets = nbuckets;
@@ -219,6 +220,7 @@ extern "C" int pg_table_create(pg_ctx *ctx, int k, int ngenomes, uint64_t expect
     t->k = k;
     t->ngenomes = ngenomes;
     t->ndbs = ndbs;
+    t->m = minimizer_length((uint32_t)k, expected_keys);
     t->d_counters = nullptr;
     hipError_t e = hipMalloc(reinterpret_cast<void **>(&t->d_counters), 2 * sizeof(unsigned long long));
     if (e != hipSuccess) {
@@ -229,13 +231,13 @@ extern "C" int pg_table_create(pg_ctx *ctx, int k, int ngenomes, uint64_t expect
     for (int s = 0; s < nsub; ++s) {
         uint32_t W = (2 * s + 1 < ndbs) ? 2 : 1;
         uint64_t want = expected_keys ? expected_keys : (1ull << 18);
-        // 256-byte lines where a minimizer group is expected to exceed 8 keys: long windows
-        // (k >= 28) or many genomes' variants per locus
-        const uint32_t slots = (minimizer_window((uint32_t)k) == 16 || ngenomes > 32) ? 16u : 8u;
+        // 256-byte lines where a minimizer group is expected to exceed 8 keys: many genomes'
+        // variants per locus
+        const uint32_t slots = (ngenomes > 32) ? 16u : 8u;
         uint64_t nb = (uint64_t)((double)want / (TARGET_LOAD * slots)) + 1;
         SubHost sh;
         sh.count = 0;
-        int r = alloc_sub(ctx, W, 2 * s, (uint32_t)k, slots, nb, &sh.d);
+        int r = alloc_sub(ctx, W, 2 * s, (uint32_t)k, t->m, slots, nb, &sh.d);
         if (r) {
             pg_table_destroy(t);
             return r;
@@ -258,6 +260,21 @@ extern "C" int pg_table_destroy(pg_table *t) {
 
 extern "C" int pg_table_k(const pg_table *t) { return t ? t->k : 0; }
 extern "C" int pg_table_ngenomes(const pg_table *t) { return t ? t->ngenomes : 0; }
+extern "C" int pg_table_minimizer(const pg_table *t) { return t ? (int)t->m : 0; }
+
+extern "C" int pg_table_set_minimizer(pg_table *t, int m) {
+    if (!t) return fail(PG_E_INVALID, "table is NULL");
+    const int w = m ? t->k - m + 1 : 0;
+    if (m && (t->k < 20 || w < (int)MZ_WMIN || w > (int)MZ_WMAX))
+        return fail(PG_E_INVALID, "minimizer length %d: k=%d needs m=0 or a window k-m+1 in %u..%u (k >= 20)", m, t->k,
+                    MZ_WMIN, MZ_WMAX);
+    for (auto &s : t->subs)
+        if (s.count) return fail(PG_E_INVALID, "pg_table_set_minimizer: the table already holds keys");
+    t->m = (uint32_t)m;
+    t->m_pinned = true;
+    for (auto &s : t->subs) s.d.m = (uint32_t)m;
+    return PG_OK;
+}
 
 static int read_counters(pg_table *t, unsigned long long out[2]) {
     HIP_TRY(hipMemcpyAsync(out, t->d_counters, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost,
@@ -271,7 +288,7 @@ static int regrow(pg_table *t, int si, uint64_t nb) {
     pg_ctx *ctx = t->ctx;
     for (int attempt = 0; attempt < 8; ++attempt) {
         SubTable nt;
-        if (int r = alloc_sub(ctx, t->subs[si].d.W, t->subs[si].d.word0, (uint32_t)t->k, t->subs[si].d.slots, nb, &nt)) return r;
+        if (int r = alloc_sub(ctx, t->subs[si].d.W, t->subs[si].d.word0, (uint32_t)t->k, t->m, t->subs[si].d.slots, nb, &nt)) return r;
         HIP_TRY(hipMemsetAsync(t->d_counters, 0, 2 * sizeof(unsigned long long), ctx->stream));
         HIP_TRY(launch_rehash(ctx->stream, t->subs[si].d, nt, t->d_counters, MAX_PROBE));
         unsigned long long c[2];
@@ -470,6 +487,11 @@ extern "C" int pg_table_rehash(pg_table *t, double keys_per_bucket) {
     if (!t) return fail(PG_E_INVALID, "table is NULL");
     if (!(keys_per_bucket > 0.05 && keys_per_bucket <= 8.0)) return fail(PG_E_INVALID, "keys_per_bucket must be in (0.05, 8]");
     if (int r = use_device(t->ctx)) return r;
+    if (!t->m_pinned) {  // the key count is known now: settle the minimizer length for it
+        uint64_t most = 0;
+        for (auto &s : t->subs) most = std::max<uint64_t>(most, s.count);
+        t->m = minimizer_length((uint32_t)t->k, most);
+    }
     for (size_t si = 0; si < t->subs.size(); ++si) {
         double kpb = std::min(keys_per_bucket * (t->subs[si].d.slots / 8.0), 0.8 * t->subs[si].d.slots);  // keys per 128 bytes
         uint64_t nb = (uint64_t)((double)t->subs[si].count / kpb) + 1;

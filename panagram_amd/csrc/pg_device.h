@@ -12,9 +12,9 @@
 //   is 0).  Keys only ever go EMPTY -> key, masks only gain bits: inserts are one 64-bit CAS +
 //   one 32-bit OR, no locks.
 //
-// Home line = LOCALITY hash.  For 20 <= k <= 31 the home of a k-mer is a hash of its
-// MINIMIZER: the smallest (in a scrambled order) canonical m-mer among its w = k-m+1 m-mers,
-// w even in 6..16, m = 15 or 16.  Consecutive k-mers of a sequence share their minimizer for
+// Home line = LOCALITY hash.  For 20 <= k <= 32 the home of a k-mer is a hash of its
+// MINIMIZER: the smallest (in a scrambled order) canonical m-mer among its w = k-m+1 m-mers
+// (w = 3..8, see minimizer_length).  Consecutive k-mers of a sequence share their minimizer for
 // ~(w+1)/2 positions, so consecutive anchor positions probe the SAME line: one HBM fetch
 // serves a run of positions (L1/L2 absorb the repeats).  Other k fall back to hashing the
 // k-mer itself (m = 0).  Collisions: linear probing by line; a lookup moves to the next line
@@ -52,13 +52,25 @@ struct TableDesc {
 __host__ __device__ __forceinline__ uint32_t key_off(uint32_t, int s) { return 16u * s; }
 __host__ __device__ __forceinline__ uint32_t mask_off(uint32_t, int s, int w) { return 16u * s + 8u + 4u * w; }
 
-// minimizer window for a given k (20..31): the m-mers are as long as 32 bits allow (m = 15 or 16),
-// the window w = k-m+1 is even (6..16).  Short windows keep a minimizer group small (fewer keys
-// spill out of their home line) at the price of shorter runs of positions per fetched line;
-// measured on config 2 (k=21): w=6/m=16 94 G k-mers/s vs w=8/m=14 83 G.  Other k: 0 (direct).
-__host__ __device__ __forceinline__ uint32_t minimizer_window(uint32_t k) {
-    if (k < 20 || k > 31) return 0;
-    return 2 * ((k - 15 + 1) / 2);
+// Minimizer geometry of a table: w m-mers of m = k-w+1 bases per k-mer (m = 0: hash the k-mer
+// itself, k < 20).  Measured on MI355X: w = 7-8 is the sweet spot between small
+// minimizer groups (few keys spill out of their home line) and long runs of positions per fetched
+// line — PROVIDED the m-mers stay long enough that distinct loci rarely share one: with 4^m below
+// ~4x the number of keys the groups merge and throughput collapses (k=21 on 100 Mb genomes: m=15
+// 100 G k-mers/s, m=14 84 G, m=13 23 G).  So m is the larger of k-7 and ceil(log4(4*expected keys)),
+// and w = k-m+1 is kept in 3..8.  m-mers longer than 16 bases use 64-bit arithmetic.
+constexpr uint32_t MZ_WMIN = 3, MZ_WMAX = 8;
+__host__ __device__ __forceinline__ uint32_t minimizer_length(uint32_t k, uint64_t expected_keys) {
+    if (k < 20 || k > 32) return 0;
+    uint32_t m_need = 16;  // unknown cardinality: good up to ~1e9 keys
+    if (expected_keys) {
+        m_need = 15;
+        while (m_need < 27 && (1ull << (2 * m_need)) < 4 * expected_keys) ++m_need;
+    }
+    uint32_t m = k - (MZ_WMAX - 1);
+    if (m < m_need) m = m_need;
+    if (m > k - (MZ_WMIN - 1)) m = k - (MZ_WMIN - 1);
+    return m;
 }
 
 // ---- hashing ------------------------------------------------------------------
@@ -117,14 +129,21 @@ __device__ __forceinline__ uint64_t canonical_from_le(uint64_t x, int k) {
     return canonical_from_xb(x, revcomp_le(x, k), k);
 }
 
+// rank of a canonical m-mer (up to 27 bases = 54 bits) in the scrambled order: fold to 32 bits,
+// then a multiplicative scramble.  For m <= 16 the fold is the identity and the rank a bijection;
+// longer m-mers may tie, which only merges two groups.
+__host__ __device__ __forceinline__ uint32_t mmer_rank(uint64_t c) {
+    return mz_order((uint32_t)c ^ ((uint32_t)(c >> 32) * 0x85ebca6bu));
+}
+
 // minimizer of a k-mer given X and B (generic, runtime w).  Symmetric in X <-> B.
 __device__ __forceinline__ uint32_t minimizer_from_xb(uint64_t X, uint64_t B, uint32_t m, uint32_t w) {
-    const uint32_t mm = (m == 16) ? ~0u : ((1u << (2 * m)) - 1);
+    const uint64_t mm = (m >= 32) ? ~0ull : ((1ull << (2 * m)) - 1);
     uint32_t best = ~0u;
     for (uint32_t i = 0; i < w; ++i) {
-        const uint32_t a = (uint32_t)(X >> (2 * i)) & mm;
-        const uint32_t b = (uint32_t)(B >> (2 * (w - 1 - i))) & mm;
-        const uint32_t h = mz_order(a < b ? a : b);
+        const uint64_t a = (X >> (2 * i)) & mm;
+        const uint64_t b = (B >> (2 * (w - 1 - i))) & mm;
+        const uint32_t h = mmer_rank(a < b ? a : b);
         best = h < best ? h : best;
     }
     return best;

@@ -135,6 +135,15 @@ class PanTable:
     def rehash(self, keys_per_bucket: float) -> None:
         check(self._lib.pg_table_rehash(self._h, keys_per_bucket))
 
+    @property
+    def minimizer(self) -> int:
+        """minimizer length m the table places k-mers by (0 = the k-mer itself)"""
+        return int(self._lib.pg_table_minimizer(self._h))
+
+    def set_minimizer(self, m: int) -> None:
+        """pin m on an empty table (tuning knob; see include/panagram_hip.h)"""
+        check(self._lib.pg_table_set_minimizer(self._h, int(m)))
+
     def export(self, db_idx: int) -> Tuple[np.ndarray, np.ndarray]:
         n = C.c_uint64()
         check(self._lib.pg_table_export(self._h, db_idx, None, None, 0, C.byref(n)))

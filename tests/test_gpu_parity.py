@@ -183,10 +183,16 @@ def test_one_shot_contig_and_edge_cases(ctx):
     tbl.close()
 
 
-@pytest.mark.parametrize("k", [1, 7, 15, 19, 20, 22, 23, 24, 25, 27, 28, 29, 30, 32])
-def test_every_minimizer_window_and_direct_mode(ctx, k):
-    """k = 20..23 / 24..27 / 28..31 use minimizer windows of 8 / 12 / 16 m-mers, every other k hashes
-    the k-mer itself; tables built on the GPU, answers compared with the oracle (bit-exact)."""
+_KW = [(k, None) for k in (1, 7, 15, 19, 20, 22, 25, 27, 30, 32)] + \
+      [(k, w) for k in (20, 21, 26, 31, 32) for w in (0, 3, 4, 5, 6, 7, 8)]
+
+
+@pytest.mark.parametrize("k,w", _KW)
+def test_every_minimizer_window_and_direct_mode(ctx, k, w):
+    """The table places a k-mer (k >= 20) by the smallest of its w = 3..8 canonical m-mers, any other
+    k (or m = 0) by the k-mer itself; m-mers over 16 bases take the 64-bit path.  Every window is
+    pinned in turn (w None: the library's own choice); tables built on the GPU, answers compared
+    with the oracle (bit-exact)."""
     from panagram_amd import engine
     n = 3
     gen = po.synth_genomes(n, [6000, 1500], 0.03, 500 + k)
@@ -197,6 +203,12 @@ def test_every_minimizer_window_and_direct_mode(ctx, k):
     genomes[1][0] = bytes(seq)
     dbs = po.build_bitvec_dbs(genomes, k)
     tbl = engine.PanTable(ctx, k, n)
+    if w is not None:
+        tbl.set_minimizer(k - w + 1 if w else 0)
+    elif k >= 20:
+        assert 3 <= k - tbl.minimizer + 1 <= 8
+    else:
+        assert tbl.minimizer == 0
     for g in range(n):
         ss = engine.SeqSet.from_host(ctx, genomes[g])
         tbl.insert_seqset(g, ss)
@@ -204,7 +216,10 @@ def test_every_minimizer_window_and_direct_mode(ctx, k):
     keys, vals = tbl.export(0)
     o = np.argsort(keys)
     assert np.array_equal(keys[o], dbs[0][0]) and np.array_equal(vals[o], dbs[0][1])
+    m_before = tbl.minimizer
     tbl.rehash(5.0)  # dense: exercises the overflow queue and the inline chase
+    if w is not None:
+        assert tbl.minimizer == m_before  # pinned
     for g in (0, 1):
         for seq_ in genomes[g]:
             rows, rows100, bins, cs = tbl.anchor_contig(seq_)
@@ -246,6 +261,8 @@ def test_errors_are_loud(ctx):
     with pytest.raises(engine.PanagramHipError):
         engine.PanTable(ctx, 33, 2)  # k > 32
     tbl = engine.PanTable(ctx, 21, 2)
+    with pytest.raises(engine.PanagramHipError):
+        tbl.set_minimizer(5)  # window of 17 m-mers
     with pytest.raises(engine.PanagramHipError):
         tbl.load_kmc1(0, b"garbage-not-a-kmc-file" * 8, b"KMCSKMCS")
     with pytest.raises(engine.PanagramHipError):
