@@ -396,6 +396,9 @@ __device__ __forceinline__ void hist_position(bool active, uint32_t pos, uint32_
     }
 }
 
+#ifndef PG_EPI_MIN_TILES
+#define PG_EPI_MIN_TILES 32
+#endif
 constexpr int EPI_THREADS = PROBE_TILE / 4;
 static_assert(EPI_THREADS >= 64 && EPI_THREADS % 64 == 0, "PROBE_TILE must be a multiple of 256");
 
@@ -410,6 +413,9 @@ __device__ __forceinline__ void flush_hist(uint32_t N, uint32_t *hist, uint32_t 
     }
 }
 
+// MODE 0: one-byte rows (N <= 8), 1: rows of 2..8 bytes (N <= 64), 2: wider rows.  One instantiation
+// per mode so that each carries only its own accumulators in registers.
+template <int MODE>
 __global__ __launch_bounds__(EPI_THREADS) void k_epilogue(uint32_t N, const AnchorDesc *__restrict__ ad,
                                                           const uint32_t *__restrict__ tile_contig, uint32_t ntiles,
                                                           const uint8_t *__restrict__ out1, uint8_t *__restrict__ out100,
@@ -444,26 +450,73 @@ __global__ __launch_bounds__(EPI_THREADS) void k_epilogue(uint32_t N, const Anch
     uint32_t since_spill = 0;
     uint32_t next_packed = 0;  // software prefetch of the next tile's rows
     bool next_valid = false;
-    // wide path (8 < N <= 64): column sums through per-thread VERTICAL counters — bit g of plane p
-    // is bit p of the number of rows seen with genome g set (4 planes: up to 15 rows) — emptied
-    // into LDS with one wave ballot per (bit, plane): ~7 ALU ops per row word instead of one
-    // ballot per genome per position
+    // wide path (8 < N <= 64): column sums in three levels, all in registers until the very end —
+    //  L1  per-thread VERTICAL counters: bit g of plane p is bit p of the number of rows seen with
+    //      genome g set; the 4 rows of a tile enter through carry-save adders (12 ALU ops per 4 rows);
+    //  L2  every 12 rows the planes are transposed into nibbles and added to byte-sliced
+    //      accumulators: byte b of bacc[w][q] counts genome 32w + 8b + q (up to 252 rows);
+    //  L3  a halving exchange over the wave (17 shuffles per word) leaves each total in one lane,
+    //      which adds it to the workgroup's LDS counters.
     uint32_t vp[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
-    uint32_t vrows = 0;
-    auto vflush = [&]() {  // wave-uniform call sites only
-        for (uint32_t wsel = 0; wsel < ndbs && wsel < 2; ++wsel) {
-            const uint32_t ng = min(32u, N - 32 * wsel);
-            for (uint32_t gb = 0; gb < ng; ++gb) {
-                uint32_t cnt = 0;
+    uint32_t bacc[2][8] = {{0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0}};
+    uint32_t vrows = 0, brounds = 0;
+    auto vadd4 = [&](int ws, uint32_t r0, uint32_t r1, uint32_t r2, uint32_t r3) {
+        const uint32_t x = vp[ws][0];
+        const uint32_t t1 = x ^ r0, s1 = t1 ^ r1, ca = (t1 & r1) | (~t1 & x);      // x + r0 + r1
+        const uint32_t t2 = s1 ^ r2, s2 = t2 ^ r3, cb = (t2 & r3) | (~t2 & s1);    // .. + r2 + r3
+        vp[ws][0] = s2;
+        const uint32_t y = vp[ws][1];
+        const uint32_t t3 = y ^ ca, cc = (t3 & cb) | (~t3 & y);                     // twos + ca + cb
+        vp[ws][1] = t3 ^ cb;
+        const uint32_t c4 = vp[ws][2] & cc;
+        vp[ws][2] ^= cc;
+        vp[ws][3] ^= c4;
+    };
+    auto wave_colsums = [&]() {  // L3, wave-uniform call sites only
+        for (uint32_t ws = 0; ws < ndbs && ws < 2; ++ws) {
+            uint32_t R[16];
 #pragma unroll
-                for (int pln = 0; pln < 4; ++pln)
-                    cnt += (uint32_t)__popcll(__ballot((vp[wsel][pln] >> gb) & 1u)) << pln;
-                if (lane == 0 && cnt) atomicAdd(&cs[32 * wsel + gb], cnt);
+            for (int q = 0; q < 8; ++q) {
+                R[2 * q] = bacc[ws][q] & 0x00FF00FFu;
+                R[2 * q + 1] = (bacc[ws][q] >> 8) & 0x00FF00FFu;
+                bacc[ws][q] = 0;
             }
 #pragma unroll
-            for (int pln = 0; pln < 4; ++pln) vp[wsel][pln] = 0;
+            for (int half = 8, bit = 32; half >= 1; half >>= 1, bit >>= 1) {
+                const bool up = (lane & bit) != 0;
+#pragma unroll
+                for (int i = 0; i < half; ++i) {
+                    const uint32_t send = up ? R[i] : R[i + half];
+                    const uint32_t keep = up ? R[i + half] : R[i];
+                    R[i] = keep + (uint32_t)__shfl_xor((int)send, bit);
+                }
+            }
+            R[0] += (uint32_t)__shfl_xor((int)R[0], 2);
+            R[0] += (uint32_t)__shfl_xor((int)R[0], 1);
+            if ((lane & 3) == 0) {  // this lane holds register (lane >> 2): q = idx / 2, odd idx = bytes 1 and 3
+                const uint32_t idx = (uint32_t)lane >> 2;
+                const uint32_t g0 = 32 * ws + (idx >> 1) + ((idx & 1) ? 8u : 0u);
+                if (g0 < N && (R[0] & 0xFFFFu)) atomicAdd(&cs[g0], R[0] & 0xFFFFu);
+                if (g0 + 16 < N && (R[0] >> 16)) atomicAdd(&cs[g0 + 16], R[0] >> 16);
+            }
+        }
+        brounds = 0;
+    };
+    auto vflush = [&]() {  // L1 -> L2, wave-uniform call sites only
+        for (uint32_t ws = 0; ws < ndbs && ws < 2; ++ws) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t M = 0x11111111u;
+                const uint32_t nib = ((vp[ws][0] >> j) & M) | (((vp[ws][1] >> j) & M) << 1) |
+                                     (((vp[ws][2] >> j) & M) << 2) | (((vp[ws][3] >> j) & M) << 3);
+                bacc[ws][j] += nib & 0x0F0F0F0Fu;
+                bacc[ws][4 + j] += (nib >> 4) & 0x0F0F0F0Fu;
+            }
+#pragma unroll
+            for (int pln = 0; pln < 4; ++pln) vp[ws][pln] = 0;
         }
         vrows = 0;
+        if (++brounds == 21) wave_colsums();  // 21 x 12 rows: the byte counters are about to fill
     };
 
     auto spill = [&]() {
@@ -473,6 +526,7 @@ __global__ __launch_bounds__(EPI_THREADS) void k_epilogue(uint32_t N, const Anch
         since_spill = 0;
     };
     auto reduce_hist = [&]() {  // per-thread classes -> LDS histogram (bin-relative row 0)
+        if constexpr (MODE != 0) return;
         spill();
 #pragma unroll
         for (int v = 0; v < 9; ++v) {
@@ -491,10 +545,10 @@ __global__ __launch_bounds__(EPI_THREADS) void k_epilogue(uint32_t N, const Anch
         }
         // ---- group path (N <= 8): 4 full tiles of one contig inside one bin = 16 one-byte rows
         // per thread in one 16-byte load; same accumulators as the per-tile fast path ----
-        {
+        if constexpr (MODE == 0) {
             const uint32_t ts = (tile - a.tile0) * PROBE_TILE;
             const uint32_t span = 4u * PROBE_TILE;
-            const bool grp_ok = nbytes == 1 && tile + 3 < t_end && tile_contig[tile + 3] == c &&
+            const bool grp_ok = tile + 3 < t_end && tile_contig[tile + 3] == c &&
                                 ts + span <= a.nkmers && a.binlen >= span &&
                                 (ts / a.binlen) == ((ts + span - 1) / a.binlen);
             if (grp_ok) {
@@ -540,7 +594,7 @@ __global__ __launch_bounds__(EPI_THREADS) void k_epilogue(uint32_t N, const Anch
         const uint32_t npos = min((uint32_t)PROBE_TILE, a.nkmers - tile_start);
         const uint32_t binlen = a.binlen, bin0 = tile_start / binlen, bin0_start = bin0 * binlen;
         const uint64_t row0 = a.bin_off + bin0;
-        const bool fast = (nbytes == 1 && binlen >= (uint32_t)PROBE_TILE);
+        const bool fast = (MODE == 0 && binlen >= (uint32_t)PROBE_TILE);
         const bool onebin = (tile_start + npos) <= (bin0_start + binlen);  // block-uniform
         if (row0 != cur_row0 || (fast && !onebin)) {  // block-uniform: the accumulators move on to another bin
             if (cur_row0 != ~0ull) {
@@ -590,10 +644,9 @@ __global__ __launch_bounds__(EPI_THREADS) void k_epilogue(uint32_t N, const Anch
                 const uint32_t first = r100 * 100u;
                 if (first < pos0 + nact) out100[a.out100_off + r100] = (uint8_t)(packed >> (8 * (first - pos0)));
             }
-        } else if (nbytes <= 8 && binlen >= (uint32_t)PROBE_TILE) {
+        } else if (MODE == 1 && binlen >= (uint32_t)PROBE_TILE) {
             // ---- wide path (N <= 64): rows as one or two 32-bit words ----
             next_valid = false;
-            if (want_cs && vrows + PT > 15) vflush();
             uint32_t w0[PT], w1[PT];
             if (nbytes == 4) {
                 uint4 q = make_uint4(0, 0, 0, 0);
@@ -624,37 +677,36 @@ __global__ __launch_bounds__(EPI_THREADS) void k_epilogue(uint32_t N, const Anch
                     w1[j] = (uint32_t)(r >> 32);
                 }
             }
+            const uint32_t nact = p0 < npos ? min(4u, npos - p0) : 0u;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const uint32_t pl = p0 + j;
-                if (pl < npos) {
-                    const uint32_t pos = tile_start + pl;
+                if ((uint32_t)j < nact) {
                     const uint32_t pcj = min((uint32_t)(__popc(w0[j]) + __popc(w1[j])), N);
-                    const uint32_t rel = (pos - bin0_start) >= binlen ? 1u : 0u;
+                    const uint32_t rel = (tile_start + p0 + j - bin0_start) >= binlen ? 1u : 0u;
                     atomicAdd(&hist[rel * (N + 1) + pcj], 1u);
-                    if (pos % 100u == 0) {
-                        uint8_t *o100 = out100 + a.out100_off + (uint64_t)(pos / 100u) * nbytes;
-                        const uint64_t r = (uint64_t)w0[j] | ((uint64_t)w1[j] << 32);
+                }
+            }
+            if (nact) {  // 1-in-100 rows: at most one of 4 consecutive positions is a multiple of 100
+                const uint32_t pos0 = tile_start + p0;
+                const uint32_t r100 = (pos0 + 99u) / 100u;
+                const uint32_t jsel = r100 * 100u - pos0;
+                if (jsel < nact) {
+                    const uint32_t a0 = jsel == 0 ? w0[0] : jsel == 1 ? w0[1] : jsel == 2 ? w0[2] : w0[3];
+                    const uint32_t a1 = jsel == 0 ? w1[0] : jsel == 1 ? w1[1] : jsel == 2 ? w1[2] : w1[3];
+                    uint8_t *o100 = out100 + a.out100_off + (uint64_t)r100 * nbytes;
+                    if (nbytes == 4) *reinterpret_cast<uint32_t *>(o100) = a0;
+                    else if (nbytes == 8) *reinterpret_cast<uint2 *>(o100) = make_uint2(a0, a1);
+                    else {
+                        const uint64_t r = (uint64_t)a0 | ((uint64_t)a1 << 32);
                         for (uint32_t bb = 0; bb < nbytes; ++bb) o100[bb] = (uint8_t)(r >> (8 * bb));
                     }
                 }
             }
-            if (want_cs) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {  // rows beyond npos are zero: adding them is harmless
-#pragma unroll
-                    for (int wsel = 0; wsel < 2; ++wsel) {
-                        const uint32_t r = wsel ? w1[j] : w0[j];
-                        const uint32_t c1 = vp[wsel][0] & r;
-                        vp[wsel][0] ^= r;
-                        const uint32_t c2 = vp[wsel][1] & c1;
-                        vp[wsel][1] ^= c1;
-                        const uint32_t c3 = vp[wsel][2] & c2;
-                        vp[wsel][2] ^= c2;
-                        vp[wsel][3] ^= c3;
-                    }
-                }
+            if (want_cs) {  // rows beyond npos are zero: adding them is harmless
+                vadd4(0, w0[0], w0[1], w0[2], w0[3]);
+                if (ndbs > 1) vadd4(1, w1[0], w1[1], w1[2], w1[3]);
                 vrows += PT;
+                if (vrows == 12) vflush();
             }
         } else {
             next_valid = false;
@@ -681,9 +733,12 @@ __global__ __launch_bounds__(EPI_THREADS) void k_epilogue(uint32_t N, const Anch
             }
         }
     }
-    if (want_cs && vrows) vflush();
+    if (MODE == 1 && want_cs) {
+        if (vrows) vflush();
+        if (brounds) wave_colsums();
+    }
     reduce_hist();
-    if (want_cs && nbytes == 1) {
+    if (MODE == 0 && want_cs) {
 #pragma unroll
         for (int gb = 0; gb < 8; ++gb)
             if ((uint32_t)gb < N && cacc[gb]) atomicAdd(&cs[gb], cacc[gb]);
@@ -772,10 +827,21 @@ hipError_t launch_rows_epilogue(hipStream_t st, uint32_t ngenomes, const AnchorD
                                 unsigned long long *colsums, uint32_t flags) {
     if (ntiles == 0) return hipSuccess;
     size_t lds = (((2 * (ngenomes + 1) + 3) & ~3u) + ((ngenomes + 3) & ~3u)) * 4 + 16;
-    const uint32_t maxg = 256u * (2048u / EPI_THREADS);  // fill every CU
-    const uint32_t grid = ntiles < maxg ? ntiles : maxg;  // contiguous tile ranges per workgroup
-    hipLaunchKernelGGL(k_epilogue, dim3(grid), dim3(EPI_THREADS), lds, st, ngenomes, ad, tile_contig, ntiles, out1, out100, bins,
-                       colsums, flags);
+    // contiguous tile ranges per workgroup: enough workgroups to fill every CU, but no fewer than
+    // PG_EPI_MIN_TILES tiles each so that the end-of-range reductions stay amortised
+    const uint32_t maxg = 256u * (2048u / EPI_THREADS);
+    uint32_t grid = (ntiles + PG_EPI_MIN_TILES - 1) / PG_EPI_MIN_TILES;
+    grid = grid < 1 ? 1 : (grid > maxg ? maxg : grid);
+    const uint32_t nbytes = (ngenomes + 7) / 8;
+    if (nbytes == 1)
+        hipLaunchKernelGGL(k_epilogue<0>, dim3(grid), dim3(EPI_THREADS), lds, st, ngenomes, ad, tile_contig, ntiles, out1,
+                           out100, bins, colsums, flags);
+    else if (nbytes <= 8)
+        hipLaunchKernelGGL(k_epilogue<1>, dim3(grid), dim3(EPI_THREADS), lds, st, ngenomes, ad, tile_contig, ntiles, out1,
+                           out100, bins, colsums, flags);
+    else
+        hipLaunchKernelGGL(k_epilogue<2>, dim3(grid), dim3(EPI_THREADS), lds, st, ngenomes, ad, tile_contig, ntiles, out1,
+                           out100, bins, colsums, flags);
     return hipGetLastError();
 }
 
