@@ -98,6 +98,7 @@ def main():
     ap.add_argument("--d", type=float, default=0.01)
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--keys-per-bucket", type=float, default=2.0)
+    ap.add_argument("--minimizer", type=int, default=-1, help="pin the table's minimizer length (tuning; default: library's choice)")
     ap.add_argument("--no-colsums", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-mb", type=float, default=10.0)
@@ -139,6 +140,8 @@ def main():
     est_keys = int(L * (1 + (G - 1) * novel) * 1.05)
     t0 = time.perf_counter()
     tbl = engine.PanTable(ctx, k, G, expected_keys=est_keys)
+    if args.minimizer >= 0:
+        tbl.set_minimizer(args.minimizer)
     for g in range(G):
         tbl.insert_seqset(g, seqsets[g])
     torch.cuda.synchronize()

@@ -26,9 +26,10 @@ constexpr int PROBE_NB = PG_PROBE_NB;          // independent 64-lane batches in
 constexpr int PROBE_QCAP = PG_PROBE_QCAP;      // per-tile LDS overflow queue (beyond: resolved inline)
 
 // which row bytes a sub-table writes: low nb0 bytes of mask word 0 at column col0, low nb1 bytes
-// of mask word 1 at col0+4
+// of mask word 1 at col0+4; words != 0: rows are a whole number of 32-bit words, so a full mask word
+// goes out as one aligned store
 struct RowCols {
-    uint32_t col0, nb0, nb1;
+    uint32_t col0, nb0, nb1, words;
 };
 
 // one packed contig of a seqset (offsets in 32-base words, shared by both planes)

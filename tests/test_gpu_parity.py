@@ -256,6 +256,30 @@ def test_three_subtables_n130(ctx):
     tbl.close()
 
 
+@pytest.mark.parametrize("n", [27, 32, 96])
+def test_rows_of_whole_words(ctx, n):
+    """4- and 12-byte rows (N = 25..32, 89..96) leave the probe kernel as aligned 32-bit stores and go
+    through the carry-save column sums: compare everything with the oracle"""
+    from panagram_amd import engine
+    k = 21
+    gen = po.synth_genomes(n, [5000, 700], 0.02, 900 + n)
+    genomes = [[po.codes_to_ascii(c) for c in g] for g in gen]
+    dbs = po.build_bitvec_dbs(genomes, k)
+    tbl = engine.PanTable(ctx, k, n)
+    for g in range(n):
+        ss = engine.SeqSet.from_host(ctx, genomes[g])
+        tbl.insert_seqset(g, ss)
+        ss.close()
+    for g in (0, n // 2, n - 1):
+        for seq in genomes[g]:
+            rows, rows100, bins, cs = tbl.anchor_contig(seq)
+            o_rows, o_rows100, o_bins, _, o_cs = po.anchor_contig(dbs, seq, k, n)
+            assert rows.shape[1] == (n + 7) // 8
+            assert np.array_equal(rows, o_rows) and np.array_equal(rows100, o_rows100)
+            assert np.array_equal(bins.astype(np.int64), o_bins) and np.array_equal(cs.astype(np.int64), o_cs)
+    tbl.close()
+
+
 def test_errors_are_loud(ctx):
     from panagram_amd import engine
     with pytest.raises(engine.PanagramHipError):

@@ -1,0 +1,20 @@
+import cProfile, pstats, os, sys, tempfile, time
+sys.path.insert(0, os.getcwd())
+from oracle import pyoracle as po
+from panagram_amd import engine, index as pidx
+L, G, k = 100_000_000, 8, 21
+gen = po.synth_genomes(G, [L // 5] * 5, 0.01, 1234)
+genomes = [[po.codes_to_ascii(c) for c in g] for g in gen]
+with tempfile.TemporaryDirectory() as d:
+    rows = ["name\tfasta"]
+    for g in range(G):
+        fa = os.path.join(d, f"g{g}.fa")
+        open(fa, "wb").write(po.fasta_text([f"chr{c+1}" for c in range(5)], genomes[g]))
+        rows.append(f"g{g}\t{fa}")
+    open(os.path.join(d, "samples.tsv"), "w").write("\n".join(rows) + "\n")
+    idx = pidx.Index(os.path.join(d, "samples.tsv"), prefix=os.path.join(d, "idx"), k=k, cores=32)
+    pr = cProfile.Profile(); pr.enable()
+    t0 = time.perf_counter(); idx.run(); dt = time.perf_counter() - t0
+    pr.disable()
+    print("Index.run", dt)
+    pstats.Stats(pr).sort_stats("cumulative").print_stats(28)

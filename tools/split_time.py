@@ -15,6 +15,7 @@ ap.add_argument("--k", type=int, default=21)
 ap.add_argument("--d", type=float, default=0.01)
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--no-colsums", action="store_true")
+ap.add_argument("--minimizer", type=int, default=-1)
 ap.add_argument("--keys-per-bucket", type=float, default=2.0)
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
@@ -30,6 +31,8 @@ for g in range(a.genomes):
         ss.load_dev(c, t.data_ptr(), t.numel())
     seqsets.append(ss)
 tbl = engine.PanTable(ctx, a.k, a.genomes, expected_keys=int(L * (1 + (a.genomes - 1) * (1 - (1 - a.d) ** a.k)) * 1.05))
+if a.minimizer >= 0:
+    tbl.set_minimizer(a.minimizer)
 for g in range(a.genomes):
     tbl.insert_seqset(g, seqsets[g])
 tbl.rehash(a.keys_per_bucket)
