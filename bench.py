@@ -249,7 +249,7 @@ def main():
     }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        nthreads = min(G, os.cpu_count() or 1)
+        nthreads = min(G, engine.usable_cpus())
         sample = int(args.cpu_sample_mb * 1e6)
         cache = {}
 
@@ -264,7 +264,8 @@ def main():
             "value": v, "unit": "k-mers/s", "cores": nthreads, "kind": "port",
             "sample": f"{nthreads} threads x first {args.cpu_sample_mb:g} Mb of a genome each = {npos} positions "
                       f"in {dt:.1f} s against the full {st['nkeys']}-key DB (prefix LUT + binary search, "
-                      f"oracle/anchor_oracle.c); host has {os.cpu_count()} cores",
+                      f"oracle/anchor_oracle.c); host shows {os.cpu_count()} hardware threads, "
+                      f"{engine.usable_cpus()} usable under its CPU quota",
             "rows_equal_gpu": ok,
         }
     if rank == 0:

@@ -123,6 +123,19 @@ int pg_seqset_load_host(pg_seqset *s, uint32_t idx, const char *ascii, uint64_t 
 /* pack contig `idx` from ASCII already in device memory (16-byte aligned); async */
 int pg_seqset_load_dev(pg_seqset *s, uint32_t idx, const void *d_ascii, uint64_t len);
 uint64_t pg_seqset_total_kmers(const pg_seqset *s, int k);
+/* FASTA text (a whole file image in host memory) -> seqset: replaces the line-based parse of
+ * KMCdb::anchor_fasta (cpp/anchor.cpp:77-100) and Genome.iter_fasta (index.py:922-930).  A line
+ * starting with '>' opens a record whose id is the header up to the first white space; the other
+ * lines are joined with all white space removed (the Python path's Bio.SeqIO behaviour; the C++
+ * path differs only in keeping '\r').  The host only locates the header lines; the GPU strips the
+ * line breaks and packs.  Text before the first header is ignored.  Synchronises. */
+int pg_seqset_from_fasta(pg_ctx *ctx, const void *text, uint64_t nbytes, pg_seqset **out);
+uint32_t pg_seqset_ncontigs(const pg_seqset *s);
+/* record id ("" unless parsed from FASTA; owned by the seqset) and length in bases of contig idx */
+int pg_seqset_contig(const pg_seqset *s, uint32_t idx, const char **name, uint64_t *len);
+/* diagnostic: contig idx back as len ASCII bytes — ACGT upper case, 'N' for every byte the
+ * packing treats as "not ACGT" (what GetCountersForRead's window test sees); synchronises */
+int pg_seqset_unpack(const pg_seqset *s, uint32_t idx, char *out);
 
 /* ---- anchoring ---------------------------------------------------------
  * Reference: KMCdb::write_bits (cpp/anchor.cpp:112-195) per contig =
@@ -152,6 +165,13 @@ int pg_result_contig_info(const pg_result *r, uint32_t idx, uint64_t *nkmers, ui
 /* copy contig idx's outputs to host (any pointer may be NULL); synchronises.
  *   bitmap1:   nkmers  * nbytes bytes        bitmap100: nrows100 * nbytes bytes
  *   bins:      nbins * (ngenomes+1) u32      (row b covers [b*binlen, ...)) */
+/* stream the whole bitmap.1 (step 1) or bitmap.100 (step 100) payload of the result — every
+ * contig, in order — from HBM into a BGZF file + .gzi index (gzi_path may be NULL): D2H through
+ * pinned double buffers on a private stream overlapped with multi-threaded deflate.  Replaces
+ * bgzf_open/bgzf_write/bgzf_index_dump/bgzf_close of cpp/anchor.cpp:46-55,102-106,167,177.  Waits
+ * for the run's kernels; may be called from another host thread than the one enqueueing work. */
+int pg_result_write_bgzf(pg_result *r, int step, const char *gz_path, const char *gzi_path, int level,
+                         int nthreads);
 int pg_result_download(pg_result *r, uint32_t idx, uint8_t *bitmap1, uint8_t *bitmap100,
                        uint32_t *bins);
 /* per-genome column sums over ALL contigs of the seqset (ngenomes u64); synchronises */

@@ -78,6 +78,7 @@ struct pg_seqset {
     SeqDesc *d_desc;
     void *d_stage;
     size_t stage_cap;
+    std::vector<std::string> names;  // record ids when the seqset was parsed from FASTA text
 };
 
 struct pg_result {
@@ -629,6 +630,151 @@ extern "C" int pg_seqset_load_host(pg_seqset *s, uint32_t idx, const char *ascii
     return PG_OK;
 }
 
+// ---------------------------------------------------------------------------
+// FASTA text -> seqset.  Host: locate the header lines (memchr over the text, '>' is rare).
+// GPU: drop the white space of the sequence lines and pack (k_text_count/scan/pack).
+// ---------------------------------------------------------------------------
+static inline bool host_is_ws(unsigned char c) { return c == ' ' || (c >= 9 && c <= 13); }
+
+extern "C" int pg_seqset_from_fasta(pg_ctx *ctx, const void *text_, uint64_t nbytes, pg_seqset **out) {
+    if (!ctx || !out || (nbytes && !text_)) return fail(PG_E_INVALID, "pg_seqset_from_fasta: NULL argument");
+    if (int r = use_device(ctx)) return r;
+    const unsigned char *text = static_cast<const unsigned char *>(text_);
+    struct Rec {
+        std::string name;
+        uint64_t s, e;
+    };
+    std::vector<Rec> recs;
+    // first header: at offset 0 or right after a newline; anything before it is ignored
+    auto next_header = [&](uint64_t from) -> uint64_t {
+        uint64_t p = from;
+        while (p < nbytes) {
+            const void *q = memchr(text + p, '>', nbytes - p);
+            if (!q) return nbytes;
+            p = (uint64_t)(static_cast<const unsigned char *>(q) - text);
+            if (p == 0 || text[p - 1] == '\n') return p;
+            ++p;
+        }
+        return nbytes;
+    };
+    uint64_t h = next_header(0);
+    while (h < nbytes) {
+        const void *q = memchr(text + h, '\n', nbytes - h);
+        const uint64_t eol = q ? (uint64_t)(static_cast<const unsigned char *>(q) - text) : nbytes;
+        uint64_t a = h + 1;
+        while (a < eol && host_is_ws(text[a])) ++a;
+        uint64_t b = a;
+        while (b < eol && !host_is_ws(text[b])) ++b;
+        Rec r;
+        r.name.assign(reinterpret_cast<const char *>(text + a), b - a);
+        r.s = std::min<uint64_t>(eol + 1, nbytes);
+        const uint64_t hn = next_header(r.s);
+        r.e = hn;
+        recs.push_back(r);
+        h = hn;
+    }
+    const uint32_t nrec = (uint32_t)recs.size();
+    // upper-bound layout (text bytes >= bases): the packed planes can be laid out before counting
+    std::vector<uint64_t> ub(nrec);
+    std::vector<TextChunk> chunks;
+    std::vector<uint64_t> chunk0(nrec + 1, 0);
+    for (uint32_t i = 0; i < nrec; ++i) {
+        ub[i] = recs[i].e - recs[i].s;
+        chunk0[i] = chunks.size();
+        for (uint64_t p = recs[i].s; p < recs[i].e;) {
+            const uint64_t lim = std::min<uint64_t>(recs[i].e, (p / 4096 + 1) * 4096);
+            TextChunk c;
+            c.off = p;
+            c.len = (uint32_t)(lim - p);
+            c.rec = i;
+            chunks.push_back(c);
+            p = lim;
+        }
+    }
+    chunk0[nrec] = chunks.size();
+    pg_seqset *s = nullptr;
+    if (int r = pg_seqset_create(ctx, nrec, ub.data(), &s)) return r;
+    for (auto &r : recs) s->names.push_back(r.name);
+    if (nrec == 0) {
+        *out = s;
+        return PG_OK;
+    }
+    hipStream_t st = ctx->stream;
+    const uint64_t nch = chunks.size();
+    const uint64_t tcap = (nbytes + 4095) / 4096 * 4096 + 4096;
+    uint8_t *d_text = nullptr;
+    TextChunk *d_chunks = nullptr;
+    uint64_t *d_chunk0 = nullptr, *d_base = nullptr, *d_len = nullptr;
+    uint32_t *d_counts = nullptr;
+    std::vector<uint64_t> lens(nrec, 0);
+    hipError_t e = hipSuccess;
+    auto ok = [&](hipError_t x) {
+        if (e == hipSuccess) e = x;
+        return e == hipSuccess;
+    };
+    if (ok(hipMalloc(reinterpret_cast<void **>(&d_text), tcap)) &&
+        ok(hipMalloc(reinterpret_cast<void **>(&d_chunks), std::max<uint64_t>(nch, 1) * sizeof(TextChunk))) &&
+        ok(hipMalloc(reinterpret_cast<void **>(&d_chunk0), (nrec + 1) * 8)) &&
+        ok(hipMalloc(reinterpret_cast<void **>(&d_base), std::max<uint64_t>(nch, 1) * 8)) &&
+        ok(hipMalloc(reinterpret_cast<void **>(&d_len), nrec * 8)) &&
+        ok(hipMalloc(reinterpret_cast<void **>(&d_counts), std::max<uint64_t>(nch, 1) * 4))) {
+        ok(hipMemsetAsync(d_text + nbytes, 0, tcap - nbytes, st));
+        ok(hipMemcpyAsync(d_text, text, nbytes, hipMemcpyHostToDevice, st));
+        if (nch) ok(hipMemcpyAsync(d_chunks, chunks.data(), nch * sizeof(TextChunk), hipMemcpyHostToDevice, st));
+        ok(hipMemcpyAsync(d_chunk0, chunk0.data(), (nrec + 1) * 8, hipMemcpyHostToDevice, st));
+        if (e == hipSuccess)
+            ok(launch_text_pack(st, d_text, d_chunks, nch, d_chunk0, nrec, d_counts, d_base, d_len, s->d_desc, s->d_seqw,
+                                s->d_nmw, s->d_has_n));
+        ok(hipMemcpyAsync(lens.data(), d_len, nrec * 8, hipMemcpyDeviceToHost, st));
+        ok(hipStreamSynchronize(st));
+        if (e == hipSuccess) {
+            for (uint32_t i = 0; i < nrec; ++i) s->desc[i].len = lens[i];
+            ok(hipMemcpyAsync(s->d_desc, s->desc.data(), nrec * sizeof(SeqDesc), hipMemcpyHostToDevice, st));
+            ok(hipStreamSynchronize(st));
+        }
+    }
+    hipFree(d_text);
+    hipFree(d_chunks);
+    hipFree(d_chunk0);
+    hipFree(d_base);
+    hipFree(d_len);
+    hipFree(d_counts);
+    if (e != hipSuccess) {
+        pg_seqset_destroy(s);
+        return fail(PG_E_HIP, "FASTA packing failed: %s", hipGetErrorString(e));
+    }
+    *out = s;
+    return PG_OK;
+}
+
+extern "C" uint32_t pg_seqset_ncontigs(const pg_seqset *s) { return s ? s->n : 0; }
+
+extern "C" int pg_seqset_contig(const pg_seqset *s, uint32_t idx, const char **name, uint64_t *len) {
+    if (!s) return fail(PG_E_INVALID, "seqset is NULL");
+    if (idx >= s->n) return fail(PG_E_INVALID, "contig %u out of range", idx);
+    if (name) *name = idx < s->names.size() ? s->names[idx].c_str() : "";
+    if (len) *len = s->desc[idx].len;
+    return PG_OK;
+}
+
+extern "C" int pg_seqset_unpack(const pg_seqset *s, uint32_t idx, char *out) {
+    if (!s || !out) return fail(PG_E_INVALID, "pg_seqset_unpack: NULL argument");
+    if (idx >= s->n) return fail(PG_E_INVALID, "contig %u out of range", idx);
+    if (int r = use_device(s->ctx)) return r;
+    const SeqDesc &d = s->desc[idx];
+    const uint64_t nw = (d.len + 31) / 32;
+    std::vector<uint64_t> w(nw);
+    std::vector<uint32_t> nm(nw);
+    if (nw) {
+        HIP_TRY(hipMemcpyAsync(w.data(), s->d_seqw + d.seq_off, nw * 8, hipMemcpyDeviceToHost, s->ctx->stream));
+        HIP_TRY(hipMemcpyAsync(nm.data(), s->d_nmw + d.seq_off, nw * 4, hipMemcpyDeviceToHost, s->ctx->stream));
+        HIP_TRY(hipStreamSynchronize(s->ctx->stream));
+    }
+    for (uint64_t i = 0; i < d.len; ++i)
+        out[i] = ((nm[i >> 5] >> (i & 31)) & 1u) ? 'N' : "ACGT"[(w[i >> 5] >> (2 * (i & 31))) & 3u];
+    return PG_OK;
+}
+
 extern "C" uint64_t pg_seqset_total_kmers(const pg_seqset *s, int k) {
     uint64_t t = 0;
     if (s)
@@ -809,6 +955,92 @@ extern "C" int pg_rows_epilogue(pg_result *r) {
     if (int e = join_result(r)) return e;
     r->ev_epi = false;
     return enqueue_epilogue(r, r->tbl->ctx->stream);  // explicit call (genome-sharded mode): main stream
+}
+
+// ---------------------------------------------------------------------------
+// device rows -> BGZF file: D2H through two pinned buffers on a private stream while the previous
+// buffer is being deflated by the writer's threads.  Safe to call from a worker thread while the
+// context's streams keep running other results.
+// ---------------------------------------------------------------------------
+extern "C" int pg_result_write_bgzf(pg_result *r, int step, const char *gz_path, const char *gzi_path, int level,
+                                    int nthreads) {
+    if (!r || !gz_path) return fail(PG_E_INVALID, "pg_result_write_bgzf: NULL argument");
+    if (step != 1 && step != 100) return fail(PG_E_INVALID, "step must be 1 or 100");
+    if (!r->ev_ok) return fail(PG_E_INVALID, "pg_anchor_run has not been called on this result");
+    if (step == 100 && (r->flags & PG_ANCHOR_ROWS_ONLY) && !r->ev_epi)
+        return fail(PG_E_INVALID, "rows-only result: bitmap.100 needs pg_rows_epilogue first");
+    if (int e = use_device(r->tbl->ctx)) return e;
+    // the payload is the contigs' segments back to back (their device buffers are padded apart)
+    const uint8_t *src = step == 1 ? r->d_out1 : r->d_out100;
+    const uint32_t nbytes_row = (r->tbl->ngenomes + 7) / 8;
+    std::vector<std::pair<uint64_t, uint64_t>> segs;  // (device offset, length)
+    uint64_t total = 0;
+    for (size_t i = 0; i < r->ad.size(); ++i) {
+        const uint64_t len = (step == 1 ? (uint64_t)r->ad[i].nkmers : r->nrows100[i]) * nbytes_row;
+        if (len) segs.emplace_back(step == 1 ? r->ad[i].out_off : r->ad[i].out100_off, len);
+        total += len;
+    }
+    if (nthreads < 1) nthreads = 1;
+    pg_bgzf *w = nullptr;
+    if (int e = pg_bgzf_open(gz_path, level, nthreads, &w)) return e;
+    const size_t chunk = (size_t)512 * 65280;  // 32 MiB: 512 BGZF blocks, shared out one by one among the threads
+    hipStream_t cs = nullptr;
+    uint8_t *pin[2] = {nullptr, nullptr};
+    hipEvent_t done[2] = {nullptr, nullptr};
+    int rc = PG_OK;
+    hipError_t e = hipStreamCreateWithFlags(&cs, hipStreamNonBlocking);
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) {
+        e = hipHostMalloc(reinterpret_cast<void **>(&pin[i]), std::min<uint64_t>(chunk, std::max<uint64_t>(total, 1)), 0);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&done[i], hipEventDisableTiming);
+    }
+    if (e == hipSuccess) e = hipStreamWaitEvent(cs, r->ev[r->ev_epi ? 3 : 1], 0);
+    if (e == hipSuccess) {
+        size_t seg = 0;
+        uint64_t seg_pos = 0;  // cursor of the next byte to fetch
+        auto issue = [&](uint64_t off, int b) {  // payload bytes [off, off+n) -> pin[b]
+            const uint64_t n = std::min<uint64_t>(chunk, total - off);
+            hipError_t x = hipSuccess;
+            uint64_t got = 0;
+            while (got < n && x == hipSuccess) {
+                const uint64_t take = std::min<uint64_t>(n - got, segs[seg].second - seg_pos);
+                x = hipMemcpyAsync(pin[b] + got, src + segs[seg].first + seg_pos, take, hipMemcpyDeviceToHost, cs);
+                got += take;
+                seg_pos += take;
+                if (seg_pos == segs[seg].second) {
+                    ++seg;
+                    seg_pos = 0;
+                }
+            }
+            if (x == hipSuccess) x = hipEventRecord(done[b], cs);
+            return x;
+        };
+        uint64_t off = 0;
+        int b = 0;
+        if (total) e = issue(0, 0);
+        while (e == hipSuccess && off < total) {
+            const uint64_t n = std::min<uint64_t>(chunk, total - off);
+            e = hipEventSynchronize(done[b]);
+            if (e != hipSuccess) break;
+            if (off + n < total) {
+                e = issue(off + n, b ^ 1);
+                if (e != hipSuccess) break;
+            }
+            if ((rc = pg_bgzf_write(w, pin[b], n))) break;
+            off += n;
+            b ^= 1;
+        }
+    }
+    if (e != hipSuccess) rc = fail(PG_E_HIP, "pg_result_write_bgzf: %s", hipGetErrorString(e));
+    if (cs) hipStreamSynchronize(cs);
+    const std::string keep = rc ? g_err : std::string();
+    const int rc2 = pg_bgzf_close(w, rc ? nullptr : gzi_path);
+    if (rc) g_err = keep;
+    for (int i = 0; i < 2; ++i) {
+        if (pin[i]) hipHostFree(pin[i]);
+        if (done[i]) hipEventDestroy(done[i]);
+    }
+    if (cs) hipStreamDestroy(cs);
+    return rc ? rc : rc2;
 }
 
 extern "C" int pg_result_contig_info(const pg_result *r, uint32_t idx, uint64_t *nkmers, uint64_t *nrows100,

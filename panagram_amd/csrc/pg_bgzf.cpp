@@ -15,8 +15,10 @@
 #include <zlib.h>
 
 #include <atomic>
+#include <condition_variable>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -30,23 +32,35 @@ constexpr size_t MAX_CBLOCK = 65536;    // a BGZF block never exceeds 64 KiB
 const unsigned char EOF_BLOCK[28] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0x00, 0x42, 0x43,
                                      0x02, 0x00, 0x1b, 0x00, 0x03, 0x00, 0, 0, 0, 0, 0, 0, 0, 0};
 
-// compress one block; returns total BGZF block length or 0 on error
-size_t deflate_block(const unsigned char *src, size_t n, unsigned char *dst, int level) {
+// one deflate state per worker, reset (not re-allocated) between blocks
+struct Deflater {
     z_stream zs;
-    memset(&zs, 0, sizeof zs);
-    if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return 0;
-    zs.next_in = const_cast<unsigned char *>(src);
-    zs.avail_in = (uInt)n;
-    zs.next_out = dst + 18;
-    zs.avail_out = (uInt)(MAX_CBLOCK - 18 - 8);
-    int rc = deflate(&zs, Z_FINISH);
-    size_t clen = zs.total_out;
-    deflateEnd(&zs);
-    if (rc != Z_STREAM_END) {
-        // incompressible at this level: store (level 0 always fits 65280 bytes)
-        if (level == 0) return 0;
-        return deflate_block(src, n, dst, 0);
+    int level;
+    bool ok;
+    explicit Deflater(int lvl) : level(lvl) {
+        memset(&zs, 0, sizeof zs);
+        ok = deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) == Z_OK;
     }
+    ~Deflater() {
+        if (ok) deflateEnd(&zs);
+    }
+    // raw deflate of src[0..n) into dst; 0 when it does not fit
+    size_t run(const unsigned char *src, size_t n, unsigned char *dst, size_t cap) {
+        if (!ok || deflateReset(&zs) != Z_OK) return 0;
+        zs.next_in = const_cast<unsigned char *>(src);
+        zs.avail_in = (uInt)n;
+        zs.next_out = dst;
+        zs.avail_out = (uInt)cap;
+        return deflate(&zs, Z_FINISH) == Z_STREAM_END ? (size_t)zs.total_out : 0;
+    }
+};
+
+// compress one block; returns total BGZF block length or 0 on error
+size_t deflate_block(Deflater &d, Deflater &stored, const unsigned char *src, size_t n, unsigned char *dst) {
+    const size_t cap = MAX_CBLOCK - 18 - 8;
+    size_t clen = d.run(src, n, dst + 18, cap);
+    if (!clen) clen = stored.run(src, n, dst + 18, cap);  // incompressible: level 0 always fits 65280 bytes
+    if (!clen) return 0;
     const size_t total = clen + 18 + 8;
     static const unsigned char hdr[16] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0x00, 0x42, 0x43, 0x02, 0x00};
     memcpy(dst, hdr, 16);
@@ -58,43 +72,100 @@ size_t deflate_block(const unsigned char *src, size_t n, unsigned char *dst, int
     memcpy(dst + 18 + clen + 4, &isz, 4);
     return total;
 }
+
+// persistent workers: a "parallel for" over the 65280-byte blocks of one pg_bgzf_write call,
+// one block at a time from a shared counter (a block takes ~2 ms at level 6)
+struct Pool {
+    std::vector<std::thread> th;
+    std::mutex mu;
+    std::condition_variable cv_job, cv_done;
+    uint64_t gen = 0;
+    bool quit = false;
+    int level;
+    // current job
+    const unsigned char *data = nullptr;
+    size_t nbytes = 0, nblk = 0;
+    unsigned char *cbuf = nullptr;
+    size_t *clen = nullptr;
+    std::atomic<size_t> next{0};
+    size_t running = 0;
+
+    void work(Deflater &d, Deflater &stored) {
+        for (;;) {
+            const size_t i = next.fetch_add(1);
+            if (i >= nblk) break;
+            const size_t off = i * BLOCK, n = std::min(BLOCK, nbytes - off);
+            clen[i] = deflate_block(d, stored, data + off, n, cbuf + i * MAX_CBLOCK);
+        }
+    }
+    void loop() {
+        Deflater d(level), stored(0);
+        uint64_t seen = 0;
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            cv_job.wait(lk, [&] { return quit || gen != seen; });
+            if (quit) return;
+            seen = gen;
+            lk.unlock();
+            work(d, stored);
+            lk.lock();
+            if (--running == 0) cv_done.notify_all();
+        }
+    }
+    Pool(int nthreads, int lvl) : level(lvl) {
+        for (int t = 0; t < nthreads; ++t) th.emplace_back([this] { loop(); });
+    }
+    ~Pool() {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            quit = true;
+        }
+        cv_job.notify_all();
+        for (auto &t : th) t.join();
+    }
+    void run(const unsigned char *d, size_t n, size_t blocks, unsigned char *out, size_t *lens) {
+        std::unique_lock<std::mutex> lk(mu);
+        data = d;
+        nbytes = n;
+        nblk = blocks;
+        cbuf = out;
+        clen = lens;
+        next.store(0);
+        running = th.size();
+        ++gen;
+        cv_job.notify_all();
+        cv_done.wait(lk, [&] { return running == 0; });
+    }
+};
 }  // namespace
 
 struct pg_bgzf {
     FILE *f;
     int level, nthreads;
-    std::vector<unsigned char> pending;            // not yet compressed input
+    std::vector<unsigned char> pending;            // not yet compressed input (< one batch)
     std::vector<uint64_t> coffs, uoffs;            // start offsets of every data block
     uint64_t cpos, upos;
     size_t batch_blocks;
     std::vector<unsigned char> cbuf;
     std::vector<size_t> clen;
     bool failed;
+    Pool *pool;
 };
 
 static int bfail(int code, const std::string &m) { return pg_set_error(code, m.c_str()); }
 
-// compress + write `nblk` blocks starting at data (last one may be short when `tail`)
+// compress + write the blocks of data[0..nbytes) (only the very last block of a file may be short)
 static int flush_blocks(pg_bgzf *w, const unsigned char *data, size_t nbytes) {
     const size_t nblk = (nbytes + BLOCK - 1) / BLOCK;
     if (nblk == 0) return PG_OK;
     if (w->cbuf.size() < nblk * MAX_CBLOCK) w->cbuf.resize(nblk * MAX_CBLOCK);
     w->clen.assign(nblk, 0);
-    std::atomic<size_t> next(0);
-    auto work = [&]() {
-        for (;;) {
-            size_t i = next.fetch_add(1);
-            if (i >= nblk) break;
-            size_t off = i * BLOCK, n = std::min(BLOCK, nbytes - off);
-            w->clen[i] = deflate_block(data + off, n, w->cbuf.data() + i * MAX_CBLOCK, w->level);
-        }
-    };
-    int nt = (int)std::min<size_t>(w->nthreads, nblk);
-    if (nt <= 1) work();
+    if (w->pool && nblk > 1) w->pool->run(data, nbytes, nblk, w->cbuf.data(), w->clen.data());
     else {
-        std::vector<std::thread> th;
-        for (int t = 0; t < nt; ++t) th.emplace_back(work);
-        for (auto &t : th) t.join();
+        Deflater d(w->level), stored(0);
+        for (size_t i = 0; i < nblk; ++i)
+            w->clen[i] = deflate_block(d, stored, data + i * BLOCK, std::min(BLOCK, nbytes - i * BLOCK),
+                                       w->cbuf.data() + i * MAX_CBLOCK);
     }
     for (size_t i = 0; i < nblk; ++i) {
         if (w->clen[i] == 0) return bfail(PG_E_IO, "deflate failed");
@@ -117,8 +188,9 @@ extern "C" int pg_bgzf_open(const char *path, int level, int nthreads, pg_bgzf *
     w->level = (level < 0 || level > 9) ? 6 : level;
     w->nthreads = nthreads < 1 ? 1 : nthreads;
     w->cpos = w->upos = 0;
-    w->batch_blocks = (size_t)w->nthreads * 8;
+    w->batch_blocks = 256;  // 16 MiB of input per parallel batch whatever the thread count
     w->failed = false;
+    w->pool = w->nthreads > 1 ? new Pool(w->nthreads, w->level) : nullptr;
     *out = w;
     return PG_OK;
 }
@@ -143,13 +215,14 @@ extern "C" int pg_bgzf_write(pg_bgzf *w, const void *data_, size_t len) {
             w->pending.clear();
         }
     }
-    while (len >= batch) {  // compress straight from the caller's buffer
-        if (int r = flush_blocks(w, data, batch)) {
+    while (len >= batch) {  // compress whole blocks straight from the caller's buffer, <= 64 MiB at a time
+        const size_t whole = std::min<size_t>(len / BLOCK, 1024) * BLOCK;
+        if (int r = flush_blocks(w, data, whole)) {
             w->failed = true;
             return r;
         }
-        data += batch;
-        len -= batch;
+        data += whole;
+        len -= whole;
     }
     if (len) w->pending.insert(w->pending.end(), data, data + len);
     return PG_OK;
@@ -175,6 +248,7 @@ extern "C" int pg_bgzf_close(pg_bgzf *w, const char *gzi_path) {
         }
     }
     if (w->failed && !rc) rc = PG_E_IO;
+    delete w->pool;
     delete w;
     return rc;
 }

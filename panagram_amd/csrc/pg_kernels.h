@@ -51,6 +51,15 @@ struct AnchorDesc {
 };
 
 hipError_t launch_table_init(hipStream_t st, const SubTable &t);
+// bytes [off, off+len) of a FASTA text are sequence lines of record rec (len <= 4096, never
+// crossing an absolute multiple of 4096)
+struct TextChunk {
+    uint64_t off;
+    uint32_t len, rec;
+};
+hipError_t launch_text_pack(hipStream_t st, const uint8_t *d_text, const TextChunk *d_chunks, uint64_t nchunks,
+                            const uint64_t *d_rec_chunk0, uint32_t nrec, uint32_t *d_counts, uint64_t *d_base,
+                            uint64_t *d_rec_len, const SeqDesc *sd, uint64_t *seqw, uint32_t *nmw, uint32_t *has_n);
 hipError_t launch_pack(hipStream_t st, const void *d_ascii, uint64_t len, uint64_t *seqw, uint32_t *nmw,
                        uint64_t nwords, uint32_t *has_n);
 hipError_t launch_insert_seq(hipStream_t st, const SubTable &t, int w, uint32_t bits, int k,

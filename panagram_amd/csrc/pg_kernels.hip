@@ -69,6 +69,153 @@ __global__ __launch_bounds__(256) void k_pack(const uint8_t *ascii, uint64_t len
 }
 
 // ---------------------------------------------------------------------------
+// FASTA text -> packed planes.  The host only locates the header lines; the bytes between two
+// headers (sequence lines, any wrapping, any line ending) are compacted here: white space is
+// dropped, every other byte becomes one base, in text order.  The text is cut at absolute
+// multiples of 4096 bytes (clipped to the record), one workgroup per chunk:
+//   k_text_count  bases per chunk            k_text_scan  one wave per record: first base index of
+//   k_text_pack   each chunk's bases into LDS words, whole words stored, the two edge words of a
+//                 chunk (shared with its neighbours) OR-ed into the pre-zeroed planes
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ bool text_is_ws(uint32_t c) { return c == 0x20u || (c - 9u) <= 4u; }
+
+// the 16 text bytes of this thread (aligned load) and the mask of those that are bases of the chunk
+__device__ __forceinline__ uint32_t text_load16(const uint8_t *text, const TextChunk &ch, int tid, uint32_t d[4]) {
+    const uint64_t a0 = (ch.off & ~15ull) + 16ull * tid;
+    const uint4 q = *reinterpret_cast<const uint4 *>(text + a0);
+    d[0] = q.x; d[1] = q.y; d[2] = q.z; d[3] = q.w;
+    uint32_t m = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const uint64_t pos = a0 + j;
+        const uint32_t c = (d[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+        if (pos >= ch.off && pos < ch.off + ch.len && !text_is_ws(c)) m |= 1u << j;
+    }
+    return m;
+}
+
+// a chunk lies inside one aligned 4096-byte window of the text: 256 threads x 16 bytes cover it
+constexpr int TEXT_THREADS = 256;
+
+__global__ __launch_bounds__(TEXT_THREADS) void k_text_count(const uint8_t *__restrict__ text,
+                                                             const TextChunk *__restrict__ chunks,
+                                                             uint32_t *__restrict__ counts) {
+    __shared__ uint32_t tot;
+    if (threadIdx.x == 0) tot = 0;
+    __syncthreads();
+    const TextChunk ch = chunks[blockIdx.x];
+    uint32_t d[4];
+    const uint32_t n = __popc(text_load16(text, ch, threadIdx.x, d));
+    uint32_t v = n;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor((int)v, o);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(&tot, v);
+    __syncthreads();
+    if (threadIdx.x == 0) counts[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(64) void k_text_scan(const uint32_t *__restrict__ counts,
+                                                  const uint64_t *__restrict__ rec_chunk0, uint64_t *__restrict__ base,
+                                                  uint64_t *__restrict__ rec_len) {
+    const uint32_t r = blockIdx.x;
+    const int lane = threadIdx.x;
+    const uint64_t c0 = rec_chunk0[r], c1 = rec_chunk0[r + 1];
+    uint64_t running = 0;
+    for (uint64_t i0 = c0; i0 < c1; i0 += 64) {
+        const uint64_t i = i0 + lane;
+        const uint32_t v = i < c1 ? counts[i] : 0u;
+        uint32_t incl = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t up = (uint32_t)__shfl_up((int)incl, o);
+            if (lane >= o) incl += up;
+        }
+        if (i < c1) base[i] = running + incl - v;
+        running += (uint32_t)__shfl((int)incl, 63);
+    }
+    if (lane == 0) rec_len[r] = running;
+}
+
+__global__ __launch_bounds__(TEXT_THREADS) void k_text_pack(const uint8_t *__restrict__ text,
+                                                            const TextChunk *__restrict__ chunks,
+                                                            const uint64_t *__restrict__ base,
+                                                            const SeqDesc *__restrict__ sd, uint64_t *__restrict__ seqw,
+                                                            uint32_t *__restrict__ nmw, uint32_t *__restrict__ has_n) {
+    constexpr int NW = 4096 / 32 + 2;
+    __shared__ unsigned long long lw[NW];
+    __shared__ uint32_t ln[NW];
+    __shared__ uint32_t wave_tot[TEXT_THREADS / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int i = tid; i < NW; i += TEXT_THREADS) {
+        lw[i] = 0;
+        ln[i] = 0;
+    }
+    const TextChunk ch = chunks[blockIdx.x];
+    uint32_t d[4];
+    const uint32_t m = text_load16(text, ch, tid, d);
+    const uint32_t n = __popc(m);
+    uint32_t incl = n;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)incl, o);
+        if (lane >= o) incl += up;
+    }
+    if (lane == 63) wave_tot[wv] = incl;
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < TEXT_THREADS / 64; ++w) {
+        if (w < wv) before += wave_tot[w];
+        total += wave_tot[w];
+    }
+    if (total == 0) return;  // block-uniform
+    const uint64_t b_first = base[blockIdx.x];
+    const uint64_t w_first = b_first >> 5;
+    uint64_t b = b_first + before + incl - n;  // this thread's first base
+    uint32_t cur = (uint32_t)((b >> 5) - w_first);
+    unsigned long long wacc = 0;
+    uint32_t nacc = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        if (m & (1u << j)) {
+            const uint32_t wi = (uint32_t)((b >> 5) - w_first);
+            if (wi != cur) {
+                if (wacc) atomicOr(&lw[cur], wacc);
+                if (nacc) atomicOr(&ln[cur], nacc);
+                wacc = 0;
+                nacc = 0;
+                cur = wi;
+            }
+            uint64_t w1 = 0;
+            uint32_t n1 = 0;
+            pack_byte((d[j >> 2] >> (8 * (j & 3))) & 0xFFu, (uint32_t)(b & 31), w1, n1);
+            wacc |= w1;
+            nacc |= n1;
+            ++b;
+        }
+    }
+    if (wacc) atomicOr(&lw[cur], wacc);
+    if (nacc) atomicOr(&ln[cur], nacc);
+    __syncthreads();
+    const uint32_t nw = (uint32_t)(((b_first + total - 1) >> 5) - w_first) + 1;
+    const uint64_t g0 = sd[ch.rec].seq_off + w_first;
+    bool any_n = false;
+    for (uint32_t i = tid; i < nw; i += TEXT_THREADS) {
+        const unsigned long long v = lw[i];
+        const uint32_t nn = ln[i];
+        any_n |= nn != 0;
+        if (i == 0 || i == nw - 1) {
+            if (v) atomicOr(reinterpret_cast<unsigned long long *>(&seqw[g0 + i]), v);
+            if (nn) atomicOr(&nmw[g0 + i], nn);
+        } else {
+            seqw[g0 + i] = v;
+            nmw[g0 + i] = nn;
+        }
+    }
+    if (any_n) atomicOr(&has_n[ch.rec], 1u);
+}
+
+// ---------------------------------------------------------------------------
 // k-mer set construction: one thread per k-mer position, insert-or-OR.
 // counters[0] += newly claimed keys; counters[1] = overflow flag.
 // ---------------------------------------------------------------------------
@@ -195,6 +342,19 @@ hipError_t launch_pack(hipStream_t st, const void *d_ascii, uint64_t len, uint64
     uint64_t g = (nwords + 255) / 256;
     hipLaunchKernelGGL(k_pack, dim3((unsigned)g), dim3(256), 0, st, (const uint8_t *)d_ascii, len, seqw, nmw,
                        nwords, has_n);
+    return hipGetLastError();
+}
+
+hipError_t launch_text_pack(hipStream_t st, const uint8_t *d_text, const TextChunk *d_chunks, uint64_t nchunks,
+                            const uint64_t *d_rec_chunk0, uint32_t nrec, uint32_t *d_counts, uint64_t *d_base,
+                            uint64_t *d_rec_len, const SeqDesc *sd, uint64_t *seqw, uint32_t *nmw, uint32_t *has_n) {
+    if (nrec == 0) return hipSuccess;
+    if (nchunks)
+        hipLaunchKernelGGL(k_text_count, dim3((unsigned)nchunks), dim3(TEXT_THREADS), 0, st, d_text, d_chunks, d_counts);
+    hipLaunchKernelGGL(k_text_scan, dim3(nrec), dim3(64), 0, st, d_counts, d_rec_chunk0, d_base, d_rec_len);
+    if (nchunks)
+        hipLaunchKernelGGL(k_text_pack, dim3((unsigned)nchunks), dim3(TEXT_THREADS), 0, st, d_text, d_chunks, d_base, sd,
+                           seqw, nmw, has_n);
     return hipGetLastError();
 }
 

@@ -6,12 +6,27 @@ numpy arrays are the host buffers the ABI asks the caller to own.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
 
 from . import _lib
 from ._lib import PG_ANCHOR_COLSUMS, PG_ANCHOR_ROWS_ONLY, PanagramHipError, check  # noqa: F401
+
+
+def usable_cpus() -> int:
+    """Host cores this process may actually use: the scheduler affinity, capped by the cgroup CPU
+    quota (a container can see 256 hardware threads and be allowed 16 cores' worth of time)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
 
 
 def _ptr(a: Optional[np.ndarray]):
@@ -67,6 +82,7 @@ class SeqSet:
         self.ctx = ctx
         self._lib = ctx._lib
         self.lens = np.asarray(lens, dtype=np.uint64)
+        self.names = [""] * len(self.lens)
         h = C.c_void_p()
         check(self._lib.pg_seqset_create(ctx._h, len(self.lens), _ptr(self.lens), C.byref(h)))
         self._h = h
@@ -79,9 +95,44 @@ class SeqSet:
             ss.load_host(i, v)
         return ss
 
+    @classmethod
+    def from_fasta(cls, ctx: Context, source) -> "SeqSet":
+        """FASTA file (path; ``.gz``/``.bgz`` through gzip) or FASTA text (bytes / uint8 array):
+        the GPU strips the line breaks and packs; ``names`` / ``lens`` describe the records."""
+        if isinstance(source, (str, os.PathLike)):
+            path = os.fspath(source)
+            if path.endswith((".gz", ".bgz")):
+                import gzip
+                with gzip.open(path, "rb") as f:
+                    text = np.frombuffer(f.read(), dtype=np.uint8)
+            else:
+                text = np.fromfile(path, dtype=np.uint8)
+        else:
+            text = _bytes_view(source)
+        ss = cls.__new__(cls)
+        ss.ctx, ss._lib = ctx, ctx._lib
+        h = C.c_void_p()
+        check(ss._lib.pg_seqset_from_fasta(ctx._h, _ptr(text), len(text), C.byref(h)))
+        ss._h = h
+        n = int(ss._lib.pg_seqset_ncontigs(h))
+        names, lens = [], np.zeros(n, np.uint64)
+        for i in range(n):
+            nm, ln = C.c_char_p(), C.c_uint64()
+            check(ss._lib.pg_seqset_contig(h, i, C.byref(nm), C.byref(ln)))
+            names.append((nm.value or b"").decode("latin-1"))
+            lens[i] = ln.value
+        ss.names, ss.lens = names, lens
+        return ss
+
     def load_host(self, idx: int, seq) -> None:
         v = _bytes_view(seq)
         check(self._lib.pg_seqset_load_host(self._h, idx, _ptr(v), len(v)))
+
+    def unpack(self, idx: int) -> bytes:
+        """contig idx as the kernels see it: ACGT upper case, N for every non-ACGT byte"""
+        out = np.empty(int(self.lens[idx]), np.uint8)
+        check(self._lib.pg_seqset_unpack(self._h, idx, _ptr(out)))
+        return out.tobytes()
 
     def load_dev(self, idx: int, dev_ptr: int, length: int) -> None:
         check(self._lib.pg_seqset_load_dev(self._h, idx, C.c_void_p(dev_ptr), length))
@@ -233,11 +284,18 @@ class AnchorResult:
         check(self._lib.pg_result_contig_info(self._h, idx, C.byref(nk), C.byref(n100), C.byref(nb), C.byref(bl)))
         return dict(nkmers=nk.value, nrows100=n100.value, nbins=nb.value, binlen=bl.value)
 
-    def download(self, idx: int, want_bitmap1: bool = True):
+    def write_bgzf(self, step: int, gz_path: str, gzi_path: Optional[str] = None, level: int = 6,
+                   threads: int = 1) -> None:
+        """Stream the whole bitmap.<step> payload (all contigs) from HBM into a BGZF file + .gzi;
+        releases the GIL, so a worker thread can write while the main thread anchors on."""
+        check(self._lib.pg_result_write_bgzf(self._h, step, os.fsencode(gz_path),
+                                             os.fsencode(gzi_path) if gzi_path else None, level, threads))
+
+    def download(self, idx: int, want_bitmap1: bool = True, want_bitmap100: bool = True):
         info = self.contig_info(idx)
         nb = self.table.nbytes
         rows = np.empty((info["nkmers"], nb), np.uint8) if want_bitmap1 else None
-        rows100 = np.empty((info["nrows100"], nb), np.uint8)
+        rows100 = np.empty((info["nrows100"], nb), np.uint8) if want_bitmap100 else None
         bins = np.empty((info["nbins"], self.table.ngenomes + 1), np.uint32)
         check(self._lib.pg_result_download(self._h, idx, _ptr(rows), _ptr(rows100), _ptr(bins)))
         return rows, rows100, bins, info

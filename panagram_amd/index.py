@@ -242,6 +242,7 @@ class Index:
             self.anchor_genomes = [n for n, g in self.genomes.items() if g.anchored]
         self._ctx = None
         self._table = None
+        self._seqsets: Dict[str, engine.SeqSet] = {}
 
     # ---- naming (index.py:155-165, 359-405) ----
     @property
@@ -349,10 +350,11 @@ class Index:
             for name, g in self.genomes.items():
                 if pd.isna(g.fasta):
                     continue
-                recs = [seq for _, seq in read_fasta(g.fasta)]
-                ss = engine.SeqSet.from_host(self.context, recs)
+                # parsed and packed once on the GPU; anchors keep theirs resident for the anchor step
+                ss = self.seqset_for(name)
                 tbl.insert_seqset(g.id, ss)
-                ss.close()
+                if name not in self.anchor_genomes:
+                    self.drop_seqset(name)
             logger.info("k-mer table built on GPU: %s", tbl.stats())
             if self.export_kmc:
                 os.makedirs(self.get_subdir("kmc"), exist_ok=True)
@@ -362,22 +364,52 @@ class Index:
         self._table = tbl
         return tbl
 
+    def seqset_for(self, name: str) -> engine.SeqSet:
+        """The genome's FASTA, parsed and 2-bit packed in HBM (0.375 byte per base), cached."""
+        ss = self._seqsets.get(name)
+        if ss is None:
+            ss = self._seqsets[name] = engine.SeqSet.from_fasta(self.context, self.genomes[name].fasta)
+        return ss
+
+    def drop_seqset(self, name: str) -> None:
+        ss = self._seqsets.pop(name, None)
+        if ss is not None:
+            ss.close()
+
     # ---- panagram index command (index.py:172-191) ----
     def run(self):
+        """Table build, then every anchor: the GPU anchors genome g+1 while host threads stream
+        genome g's rows out of HBM into the BGZF files (the reference runs one thread per anchor
+        FASTA instead, cpp/anchor.cpp:217-223)."""
         print("Wrote config.yaml and samples.tsv")
         if self.prepare:
             print("Prepared. Run 'python -m panagram_amd index <dir>' to build the index")
             return
+        from concurrent.futures import ThreadPoolExecutor
         os.makedirs(self.get_subdir("logs"), exist_ok=True)
         tbl = self.build_table()
-        for name in self.anchor_genomes:
-            self.genomes[name].run_anchor(tbl, os.path.join(self.get_subdir("logs"), f"anchor.{name}.log.txt"))
+        with ThreadPoolExecutor(max_workers=2) as pool:
+            pending = []
+            for name in self.anchor_genomes:
+                g = self.genomes[name]
+                g.setup_log(os.path.join(self.get_subdir("logs"), f"anchor.{name}.log.txt"))
+                job = g.anchor_on_gpu(tbl, self.seqset_for(name))
+                pending.append((name, pool.submit(g.write_from_result, job)))
+                while len(pending) > 2:  # bound the results held in HBM
+                    nm, fut = pending.pop(0)
+                    fut.result()
+                    self.drop_seqset(nm)
+            for nm, fut in pending:
+                fut.result()
+                self.drop_seqset(nm)
         self.close()
 
     def query_bitmap(self, genome, chrom, start=None, end=None, step=1):
         return self.genomes[genome].query(chrom, start, end, step)
 
     def close(self):
+        for nm in list(self._seqsets):
+            self.drop_seqset(nm)
         if self._table is not None:
             self._table.close()
             self._table = None
@@ -464,22 +496,65 @@ class Genome:
         FASTA order; files are written to temporaries and renamed, chrs.tsv last."""
         N = self.ngenomes
         os.makedirs(self.prefix, exist_ok=True)
-        nthreads = bgzf_threads or max(1, min(32, self.index.cores if self.index.cores > 1 else (os.cpu_count() or 1)))
+        nthreads = bgzf_threads or self._bgzf_threads()
         tmp = {s: self.bitmap_gz_fname(s) + ".tmp" for s in self.steps}
         writers = {s: engine.BgzfWriter(tmp[s], level=6, threads=nthreads) for s in self.steps}
-        bins_rows: List[str] = ["chr\tstart" + "".join(f"\t{i}" for i in range(N + 1)) + "\n"]
-        chr_rows: List[Tuple[str, int, int, int]] = []
-        for ci, (chrom, (rows, rows100, bins, info)) in enumerate(zip(names, results)):
+        for rows, rows100, _, _ in results:
             writers[1].write(rows)
             writers[self.steps[1]].write(rows100)
-            for b in range(info["nbins"]):
-                bins_rows.append(f"{ci}\t{b * info['binlen']}" + "".join(f"\t{int(c)}" for c in bins[b]) + "\n")
-            chr_rows.append((chrom, ci, info["nkmers"], 0))
-            logger.info(f"Anchored {chrom}")
         for s in self.steps:
             writers[s].close(self.bitmap_gzi_fname(s) + ".tmp")
             os.replace(tmp[s], self.bitmap_gz_fname(s))
             os.replace(self.bitmap_gzi_fname(s) + ".tmp", self.bitmap_gzi_fname(s))
+        self._write_tables(names, [(b, info) for _, _, b, info in results], paircount_sums)
+
+    def setup_log(self, logfile: Optional[str]):
+        if logfile:
+            logging.basicConfig(filename=logfile, level=logging.INFO,
+                                format="[ %(asctime)s %(levelname)7s ] %(message)s", datefmt="%Y-%m-%d %H:%M:%S")
+
+    def anchor_on_gpu(self, table: engine.PanTable, ss: engine.SeqSet):
+        """Enqueue the anchor kernels for a packed FASTA and fetch the small outputs (bins, column
+        sums); the bitmap rows stay in HBM for ``write_from_result``."""
+        for nm, ln in zip(ss.names, ss.lens):
+            if int(ln) < table.k:
+                logger.warning(f"Contig {nm} is shorter than k={table.k}: 0 k-mers (the reference underflows here)")
+        logger.info("Anchoring Started")
+        res = engine.AnchorResult(table, ss, colsums=True)
+        res.run()
+        small = [res.download(ci, want_bitmap1=False, want_bitmap100=False) for ci in range(len(ss.names))]
+        cs = res.colsums().astype(np.int64)
+        return res, list(ss.names), small, cs
+
+    def write_from_result(self, job, bgzf_threads: Optional[int] = None):
+        """anchor/<name>/ exactly as the reference lays it out (cpp/anchor.cpp:37-109,
+        index.py:1035-1094), the two bitmaps streamed from HBM by the library."""
+        res, names, small, cs = job
+        try:
+            os.makedirs(self.prefix, exist_ok=True)
+            nthreads = bgzf_threads or self._bgzf_threads()
+            for s in self.steps:
+                gz, gzi = self.bitmap_gz_fname(s), self.bitmap_gzi_fname(s)
+                res.write_bgzf(s, gz + ".tmp", gzi + ".tmp", level=6, threads=nthreads)
+                os.replace(gz + ".tmp", gz)
+                os.replace(gzi + ".tmp", gzi)
+        finally:
+            res.close()
+        self._write_tables(names, [(b, info) for _, _, b, info in small], cs)
+
+    def _bgzf_threads(self) -> int:
+        return max(1, min(64, self.index.cores if self.index.cores > 1 else engine.usable_cpus()))
+
+    def _write_tables(self, names, bins_infos, paircount_sums):
+        N = self.ngenomes
+        bins_rows: List[str] = ["chr\tstart" + "".join(f"\t{i}" for i in range(N + 1)) + "\n"]
+        chr_rows: List[Tuple[str, int, int, int]] = []
+        for ci, (chrom, (bins, info)) in enumerate(zip(names, bins_infos)):
+            starts = np.arange(info["nbins"], dtype=np.int64) * info["binlen"]
+            body = np.column_stack([np.full(info["nbins"], ci, np.int64), starts, bins.astype(np.int64)])
+            bins_rows.extend("\t".join(map(str, row)) + "\n" for row in body.tolist())
+            chr_rows.append((chrom, ci, info["nkmers"], 0))
+            logger.info(f"Anchored {chrom}")
         with open(self.bins_fname, "w") as f:
             f.writelines(bins_rows)
         # total_paircounts.csv (index.py:1068-1074): count[g] = positions holding genome g's bit
@@ -495,19 +570,15 @@ class Genome:
         ``KMCdb::anchor_fasta`` (cpp/anchor.cpp:37-109): walks the anchor FASTA, anchors every
         contig on the GPU and writes the anchor/<name>/ files.  ``table`` is the GPU-resident
         pan-kmer table standing in for the list of ``kmc/bitvec{i}`` prefixes."""
-        if logfile:
-            logging.basicConfig(filename=logfile, level=logging.INFO,
-                                format="[ %(asctime)s %(levelname)7s ] %(message)s", datefmt="%Y-%m-%d %H:%M:%S")
+        self.setup_log(logfile)
         if not self.anchored:
             logger.info(f"Skipping non-anchor genome '{self.name}'")
             return
-        recs = list(self.iter_fasta())
-        for nm, s in recs:
-            if len(s) < table.k:
-                logger.warning(f"Contig {nm} is shorter than k={table.k}: 0 k-mers (the reference underflows here)")
-        logger.info("Anchoring Started")
-        results, cs = self.anchor_contigs(table, [s for _, s in recs])
-        self.write_outputs([nm for nm, _ in recs], results, cs, bgzf_threads)
+        ss = self.index.seqset_for(self.name)
+        try:
+            self.write_from_result(self.anchor_on_gpu(table, ss), bgzf_threads)
+        finally:
+            self.index.drop_seqset(self.name)
 
     # ---- READ: what `panagram view` does with our files (index.py:615-658, 793-845) ----
     def init_read(self):
@@ -584,7 +655,7 @@ def run_anchor_cli(argv: Sequence[str], device: int = 0) -> int:
         ss = engine.SeqSet.from_host(ctx, [s for _, s in recs])
         res = engine.AnchorResult(tbl, ss, colsums=False)
         res.run()
-        w1 = engine.BgzfWriter(os.path.join(adir, "bitmap.1.gz"), threads=os.cpu_count() or 1)
+        w1 = engine.BgzfWriter(os.path.join(adir, "bitmap.1.gz"), threads=engine.usable_cpus())
         w100 = engine.BgzfWriter(os.path.join(adir, "bitmap.100.gz"), threads=2)
         with open(os.path.join(adir, "bitsum.bins.tsv"), "w") as fb, open(os.path.join(adir, "chrs.tsv"), "w") as fc:
             fb.write("chr\tstart" + "".join(f"\t{i}" for i in range(ngenomes + 1)) + "\n")

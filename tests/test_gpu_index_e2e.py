@@ -124,3 +124,97 @@ def test_kmc_api_mirror(tmp_path):
         want = po.counters_for_read((keys, masks), seq, k, int(fx["min_count"]), int(fx["max_count"]))
         assert np.array_equal(pac32, want)
     db.Close()
+
+
+# ---------------------------------------------------------------------------
+# FASTA text parsed on the GPU, payloads streamed from HBM into BGZF files
+# ---------------------------------------------------------------------------
+_FASTA_CASES = {
+    "plain": b">chr1 some description\nACGTACGTAC\nGGGTTTAAAC\nAC\n>chr2\nTTTTGGGGCCCCAAAA\n",
+    "no_trailing_newline": b">a\nACGT\nAC",
+    "crlf_and_blank_lines": b">a desc\r\nACGTNNNN\r\n\r\nacgtacgt\r\n>b\r\n\r\nGG\r\n",
+    "junk_before_header": b"; comment\nACGT\n>x\nAAAA\nCC\n",
+    "empty_record": b">e1\n>e2\nACGTTT\n>e3\n",
+    "spaces_tabs_inside": b">s\nAC GT\tAC\x0bGT\x0cA\n",
+    "gt_inside_header": b">h a>b >c\nACGT\n",
+    "header_only_ws_name": b">   \nACGT\n>\t name2 x\nGG\n",
+    "no_header": b"ACGT\nACGT\n",
+    "empty": b"",
+}
+
+
+@pytest.mark.parametrize("case", sorted(_FASTA_CASES))
+def test_gpu_fasta_parser_matches_host_reader(ctx, case, tmp_path):
+    from panagram_amd import engine, index as pidx
+    text = _FASTA_CASES[case]
+    fa = tmp_path / "x.fa"
+    fa.write_bytes(text)
+    want = list(pidx.read_fasta(str(fa)))
+    ss = engine.SeqSet.from_fasta(ctx, text)
+    assert ss.names == [n for n, _ in want]
+    assert [int(x) for x in ss.lens] == [len(s) for _, s in want]
+    for i, (_, s) in enumerate(want):
+        exp = bytes(c if c in b"ACGT" else ord("N") for c in s.upper())
+        assert ss.unpack(i) == exp
+    ss.close()
+    ss2 = engine.SeqSet.from_fasta(ctx, str(fa))  # same through the file path
+    assert ss2.names == [n for n, _ in want]
+    ss2.close()
+
+
+def test_gpu_fasta_parser_large_random_wrapping(ctx, tmp_path):
+    """multi-chunk records, line widths from 1 to 200, N runs and lower case, .gz input"""
+    import gzip
+    from panagram_amd import engine, index as pidx
+    rng = np.random.default_rng(77)
+    recs = []
+    out = bytearray()
+    for r, n in enumerate([70001, 1, 4096, 4095, 123457, 31, 33]):
+        seq = rng.choice(np.frombuffer(b"ACGTacgtN", np.uint8), size=n, p=[.22, .22, .22, .22, .02, .02, .02, .02, .04]).tobytes()
+        recs.append((f"r{r}", seq))
+        out += f">r{r} len={n}\n".encode()
+        p = 0
+        while p < n:
+            w = int(rng.integers(1, 200))
+            out += seq[p:p + w] + (b"\r\n" if rng.random() < 0.1 else b"\n")
+            p += w
+    fa = tmp_path / "big.fa.gz"
+    with gzip.open(fa, "wb") as f:
+        f.write(bytes(out))
+    assert [(n, s) for n, s in pidx.read_fasta(str(fa))] == recs
+    ss = engine.SeqSet.from_fasta(ctx, str(fa))
+    assert ss.names == [n for n, _ in recs]
+    for i, (_, s) in enumerate(recs):
+        assert ss.unpack(i) == bytes(c if c in b"ACGT" else ord("N") for c in s.upper())
+    ss.close()
+
+
+def test_write_bgzf_from_hbm_equals_host_writer(ctx, tmp_path):
+    import gzip
+    from panagram_amd import engine
+    n, k = 9, 21
+    gen = po.synth_genomes(n, [300000, 70000, 25], 0.02, 31)
+    genomes = [[po.codes_to_ascii(c) for c in g] for g in gen]
+    tbl = engine.PanTable(ctx, k, n)
+    for g in range(n):
+        ss = engine.SeqSet.from_host(ctx, genomes[g])
+        tbl.insert_seqset(g, ss)
+        ss.close()
+    ss = engine.SeqSet.from_host(ctx, genomes[2])
+    res = engine.AnchorResult(tbl, ss)
+    res.run()
+    parts = [res.download(ci) for ci in range(3)]
+    for step, col in ((1, 0), (100, 1)):
+        gz, gzi = str(tmp_path / f"b{step}.gz"), str(tmp_path / f"b{step}.gzi")
+        res.write_bgzf(step, gz, gzi, level=6, threads=3)
+        w = engine.BgzfWriter(str(tmp_path / f"h{step}.gz"), level=6, threads=3)
+        for p in parts:
+            w.write(p[col])
+        w.close(str(tmp_path / f"h{step}.gzi"))
+        payload = b"".join(p[col].tobytes() for p in parts)
+        assert gzip.open(gz, "rb").read() == payload
+        assert open(gz, "rb").read() == open(tmp_path / f"h{step}.gz", "rb").read()
+        assert open(gzi, "rb").read() == open(tmp_path / f"h{step}.gzi", "rb").read()
+    res.close()
+    ss.close()
+    tbl.close()
