@@ -77,6 +77,10 @@ int pg_table_destroy(pg_table *tbl);
  * contig of `seqs` gets bit genome_idx%32 set in group genome_idx/32.
  * Grows the table as needed.  Synchronises. */
 int pg_table_insert_seqset(pg_table *tbl, int genome_idx, const pg_seqset *seqs);
+/* same with KMC's -ci<min_count> cut-off: only canonical k-mers occurring at least min_count times
+ * in the seqset enter the table (the reference counts FASTQ samples with -ci2,
+ * workflow/Snakefile:88-89; min_count <= 1 is pg_table_insert_seqset) */
+int pg_table_insert_seqset_min(pg_table *tbl, int genome_idx, const pg_seqset *seqs, uint32_t min_count);
 
 /* bulk insert of (canonical key, u32 counter) pairs into group db_idx; counters
  * of equal keys are OR-ed.  Host pointers.  Synchronises. */

@@ -100,11 +100,14 @@ def parse_fasta_cpp(data: bytes) -> List[Tuple[str, bytes]]:
 # ---------------------------------------------------------------------------
 # k-mer set construction (restates kmc -ci1 + set_counts + complex -ocsum)
 # ---------------------------------------------------------------------------
-def build_bitvec_dbs(genomes: Sequence[Sequence[bytes]], k: int) -> List[Tuple[np.ndarray, np.ndarray]]:
+def build_bitvec_dbs(genomes: Sequence[Sequence[bytes]], k: int,
+                     min_counts: Sequence[int] = ()) -> List[Tuple[np.ndarray, np.ndarray]]:
     """``genomes[g]`` = list of contig sequences of sample g (sample order =
     samples.tsv order).  Returns one ``(sorted_keys u64, masks u32)`` per group of
     32 samples (``index.py:391-393``); mask bit ``g % 32`` set iff sample g holds
-    the canonical k-mer (``workflow/Snakefile:26-28,106-108``)."""
+    the canonical k-mer (``workflow/Snakefile:26-28,106-108``).  ``min_counts[g]`` is
+    kmc's ``-ci`` for sample g (1 for assemblies, 2 for read sets: ``workflow/Snakefile:88-89``):
+    canonical k-mers occurring fewer times in the sample are dropped."""
     ndbs = (len(genomes) + 31) // 32
     dbs = []
     for d in range(ndbs):
@@ -115,7 +118,12 @@ def build_bitvec_dbs(genomes: Sequence[Sequence[bytes]], k: int) -> List[Tuple[n
             for contig in genomes[g]:
                 keys, valid = canonical_kmers(contig, k)
                 ks.append(keys[valid])
-            u = np.unique(np.concatenate(ks)) if ks else np.zeros(0, np.uint64)
+            if ks:
+                u, cnt = np.unique(np.concatenate(ks), return_counts=True)
+                ci = min_counts[g] if g < len(min_counts) else 1
+                u = u[cnt >= ci]
+            else:
+                u = np.zeros(0, np.uint64)
             all_keys.append(u)
             all_bits.append(np.full(len(u), 1 << (g % 32), np.uint32))
         keys = np.concatenate(all_keys) if all_keys else np.zeros(0, np.uint64)

@@ -362,6 +362,69 @@ extern "C" int pg_table_insert_seqset(pg_table *t, int g, const pg_seqset *sq) {
     return fail(PG_E_CAPACITY, "k-mer table keeps overflowing");
 }
 
+// kmc -ci<min_count> (workflow/Snakefile:88-89: -ci2 for FASTQ samples): occurrences are counted in
+// a private table first; the keys seen at least min_count times then enter the pan table.
+extern "C" int pg_table_insert_seqset_min(pg_table *t, int g, const pg_seqset *sq, uint32_t min_count) {
+    if (min_count <= 1) return pg_table_insert_seqset(t, g, sq);
+    if (!t || !sq) return fail(PG_E_INVALID, "pg_table_insert_seqset_min: NULL argument");
+    if (g < 0 || g >= t->ngenomes) return fail(PG_E_INVALID, "genome index %d out of range (0..%d)", g, t->ngenomes - 1);
+    if (t->ctx != sq->ctx) return fail(PG_E_INVALID, "table and seqset belong to different contexts");
+    if (int r = use_device(t->ctx)) return r;
+    const int d = g / 32, si = d / 2, w = d % 2;
+    const uint32_t bits = 1u << (g % 32);
+    uint64_t total = 0;
+    for (auto &c : sq->desc)
+        if (c.len >= (uint64_t)t->k) total += c.len - t->k + 1;
+    if (total == 0) return PG_OK;
+    hipStream_t st = t->ctx->stream;
+    uint64_t expect = total / 3 + 1024;
+    for (int attempt = 0; attempt < 8; ++attempt, expect *= 2) {
+        pg_table *cnt = nullptr;
+        if (int r = pg_table_create(t->ctx, t->k, 1, expect, &cnt)) return r;
+        int rc = PG_OK;
+        unsigned long long c2[2] = {0, 0};
+        do {
+            if (hipMemsetAsync(cnt->d_counters, 0, 2 * sizeof(unsigned long long), st) != hipSuccess) {
+                rc = fail(PG_E_HIP, "hipMemsetAsync failed");
+                break;
+            }
+            for (uint32_t c = 0; c < sq->n && !rc; ++c) {
+                const SeqDesc &sd = sq->desc[c];
+                if (sd.len < (uint64_t)t->k) continue;
+                if (launch_insert_seq(st, cnt->subs[0].d, 0, 1u, t->k, sq->d_seqw + sd.seq_off, sq->d_nmw + sd.seq_off,
+                                      sq->d_has_n + c, sd.len - t->k + 1, cnt->d_counters, MAX_PROBE, 1) != hipSuccess)
+                    rc = fail(PG_E_HIP, "counting kernel failed");
+            }
+            if (!rc) rc = read_counters(cnt, c2);
+        } while (0);
+        // counting is not idempotent: a table that overflowed (or ran too full) is thrown away and
+        // the pass repeated in a bigger one
+        const bool redo = !rc && (c2[1] != 0 || (double)c2[0] > HARD_LOAD * (double)cnt->subs[0].d.nbuckets * cnt->subs[0].d.slots);
+        if (!rc && !redo) {
+            rc = ensure_room(t, si, c2[0]);
+            for (int a2 = 0; a2 < 8 && !rc; ++a2) {
+                unsigned long long m2[2];
+                if (hipMemsetAsync(t->d_counters, 0, 2 * sizeof(unsigned long long), st) != hipSuccess ||
+                    launch_merge_min(st, cnt->subs[0].d, t->subs[si].d, w, bits, min_count, t->d_counters, MAX_PROBE) != hipSuccess) {
+                    rc = fail(PG_E_HIP, "merge kernel failed");
+                    break;
+                }
+                if ((rc = read_counters(t, m2))) break;
+                t->subs[si].count += m2[0];
+                if (m2[1] == 0) {
+                    rc = after_insert(t, si);
+                    break;
+                }
+                rc = regrow(t, si, t->subs[si].d.nbuckets * 2);  // the merge is idempotent: redo it
+                if (!rc && a2 == 7) rc = fail(PG_E_CAPACITY, "k-mer table keeps overflowing");
+            }
+        }
+        pg_table_destroy(cnt);
+        if (rc || !redo) return rc;
+    }
+    return fail(PG_E_CAPACITY, "k-mer counting table keeps overflowing");
+}
+
 static int insert_keys_dev(pg_table *t, int db_idx, const uint64_t *d_keys, const uint32_t *d_vals, uint64_t n) {
     const int si = db_idx / 2, w = db_idx % 2;
     if (int r = ensure_room(t, si, n)) return r;

@@ -214,6 +214,8 @@ __device__ __forceinline__ bool lane_lookup(const SubTable &st, uint64_t key, ui
 
 // Insert-or-find `key`, OR `bits` into mask word w.  Returns 0 = existed,
 // 1 = newly claimed, -1 = gave up after max_probe lines (table must grow).
+// COUNT: mask word w is an occurrence counter (bits is added) instead of a presence mask (OR-ed)
+template <bool COUNT = false>
 __device__ __forceinline__ int lane_insert(const SubTable &st, uint64_t key, int w, uint32_t bits,
                                            uint32_t max_probe) {
     const uint32_t grp = group_of(st, key);
@@ -234,7 +236,11 @@ __device__ __forceinline__ int lane_insert(const SubTable &st, uint64_t key, int
             }
             if (cur == key) {
                 uint32_t *mp = reinterpret_cast<uint32_t *>(base + mask_off(st.W, s, w));
-                if ((*mp & bits) != bits) atomicOr(mp, bits);
+                if (COUNT) {
+                    if (*mp < 0xFFFFFF00u) atomicAdd(mp, bits);  // saturates far above any -ci threshold
+                } else if ((*mp & bits) != bits) {
+                    atomicOr(mp, bits);
+                }
                 return claimed;
             }
         }

@@ -222,7 +222,7 @@ __global__ __launch_bounds__(TEXT_THREADS) void k_text_pack(const uint8_t *__res
 __global__ __launch_bounds__(256) void k_insert_seq(SubTable st, int w, uint32_t bits, int k,
                                                     const uint64_t *seqw, const uint32_t *nmw,
                                                     const uint32_t *has_n, uint64_t nkmers,
-                                                    unsigned long long *counters, uint32_t max_probe) {
+                                                    unsigned long long *counters, uint32_t max_probe, int count_mode) {
     uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     const bool hasn = (*has_n != 0);
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256) void k_insert_seq(SubTable st, int w, uint32_t
     for (; p < nkmers; p += stride) {
         if (hasn && extract_nmask(nmw, p, k)) continue;
         uint64_t key = canonical_from_le(extract_bases(seqw, p), k);
-        int r = lane_insert(st, key, w, bits, max_probe);
+        int r = count_mode ? lane_insert<true>(st, key, w, bits, max_probe) : lane_insert<false>(st, key, w, bits, max_probe);
         if (r < 0) atomicOr(reinterpret_cast<unsigned int *>(&counters[1]), 1u);
         else claimed += r;
     }
@@ -274,6 +274,29 @@ __global__ __launch_bounds__(256) void k_rehash(SubTable src, SubTable dst, unsi
             if (r < 0) atomicOr(reinterpret_cast<unsigned int *>(&counters[1]), 1u);
             else claimed += r;
         }
+    }
+    if (claimed) atomicAdd(&counters[0], (unsigned long long)claimed);
+}
+
+// kmc -ci<min_count>: every key of a private occurrence-count table (word 0 = count) that was seen
+// at least min_count times gets `bits` OR-ed into word w of the pan table
+__global__ __launch_bounds__(256) void k_merge_min(SubTable src, SubTable dst, int w, uint32_t bits, uint32_t min_count,
+                                                   unsigned long long *counters, uint32_t max_probe) {
+    const int ns = (int)src.slots;
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t nslots = src.nbuckets * ns;
+    uint32_t claimed = 0;
+    for (; i < nslots; i += stride) {
+        uint64_t b = i / ns;
+        int s = (int)(i - b * ns);
+        const uint8_t *base = src.buckets + b * (16u * src.slots);
+        uint64_t key = *reinterpret_cast<const uint64_t *>(base + key_off(src.W, s));
+        if (key == EMPTY_KEY) continue;
+        if (*reinterpret_cast<const uint32_t *>(base + mask_off(src.W, s, 0)) < min_count) continue;
+        int r = lane_insert(dst, key, w, bits, max_probe);
+        if (r < 0) atomicOr(reinterpret_cast<unsigned int *>(&counters[1]), 1u);
+        else claimed += r;
     }
     if (claimed) atomicAdd(&counters[0], (unsigned long long)claimed);
 }
@@ -360,10 +383,10 @@ hipError_t launch_text_pack(hipStream_t st, const uint8_t *d_text, const TextChu
 
 hipError_t launch_insert_seq(hipStream_t st, const SubTable &t, int w, uint32_t bits, int k,
                              const uint64_t *seqw, const uint32_t *nmw, const uint32_t *has_n,
-                             uint64_t nkmers, unsigned long long *counters, uint32_t max_probe) {
+                             uint64_t nkmers, unsigned long long *counters, uint32_t max_probe, int count_mode) {
     if (nkmers == 0) return hipSuccess;
     hipLaunchKernelGGL(k_insert_seq, dim3(grid_for(nkmers, 256, 256 * 64)), dim3(256), 0, st, t, w, bits, k,
-                       seqw, nmw, has_n, nkmers, counters, max_probe);
+                       seqw, nmw, has_n, nkmers, counters, max_probe, count_mode);
     return hipGetLastError();
 }
 
@@ -381,6 +404,14 @@ hipError_t launch_rehash(hipStream_t st, const SubTable &src, const SubTable &ds
     uint64_t nslots = src.nbuckets * src.slots;
     hipLaunchKernelGGL(k_rehash, dim3(grid_for(nslots, 256, 256 * 64)), dim3(256), 0, st, src, dst, counters,
                        max_probe);
+    return hipGetLastError();
+}
+
+hipError_t launch_merge_min(hipStream_t st, const SubTable &src, const SubTable &dst, int w, uint32_t bits,
+                            uint32_t min_count, unsigned long long *counters, uint32_t max_probe) {
+    uint64_t nslots = src.nbuckets * src.slots;
+    hipLaunchKernelGGL(k_merge_min, dim3(grid_for(nslots, 256, 256 * 64)), dim3(256), 0, st, src, dst, w, bits,
+                       min_count, counters, max_probe);
     return hipGetLastError();
 }
 

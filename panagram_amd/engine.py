@@ -165,7 +165,12 @@ class PanTable:
         check(self._lib.pg_table_create(ctx._h, k, ngenomes, expected_keys, C.byref(h)))
         self._h = h
 
-    def insert_seqset(self, genome_idx: int, seqs: SeqSet) -> None:
+    def insert_seqset(self, genome_idx: int, seqs: SeqSet, min_count: int = 1) -> None:
+        """OR genome ``genome_idx``'s bit into every canonical k-mer of ``seqs`` that occurs at least
+        ``min_count`` times in it (kmc -ci<min_count>; 2 for read sets)"""
+        if min_count > 1:
+            check(self._lib.pg_table_insert_seqset_min(self._h, genome_idx, seqs._h, min_count))
+            return
         check(self._lib.pg_table_insert_seqset(self._h, genome_idx, seqs._h))
 
     def insert_keys(self, db_idx: int, keys: np.ndarray, counters: np.ndarray) -> None:

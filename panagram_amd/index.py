@@ -76,6 +76,22 @@ def read_fasta(path: str) -> Iterator[Tuple[str, bytes]]:
         pos = end
 
 
+FASTQ_SUFFIXES = (".fastq", ".fastq.gz", ".fq", ".fq.gz")  # workflow/Snakefile:88-89
+
+
+def is_fastq(path) -> bool:
+    return isinstance(path, str) and path.endswith(FASTQ_SUFFIXES)
+
+
+def read_fastq_joined(path: str) -> bytes:
+    """The reads of a 4-line-record FASTQ joined by ``N``: no k-mer window spans two reads, which is
+    how kmc -fq counts them."""
+    opn = gzip.open if path.endswith(".gz") else open
+    with opn(path, "rb") as f:
+        lines = f.read().split(b"\n")
+    return b"N".join(ln.rstrip(b"\r") for ln in lines[1::4])
+
+
 # ---------------------------------------------------------------------------
 # KMC1 database files (format: SURVEY.md Appendix A) — writer, so that tables built on
 # the GPU can be handed to the reference (`kmc/bitvec{i}.kmc_pre|.kmc_suf`)
@@ -349,6 +365,14 @@ class Index:
         else:
             for name, g in self.genomes.items():
                 if pd.isna(g.fasta):
+                    continue
+                if is_fastq(g.fasta):
+                    # read sets: kmc -ci2 -fq (workflow/Snakefile:88-89) — k-mers seen once are dropped
+                    if name in self.anchor_genomes:
+                        raise ValueError(f"{name}: a FASTQ sample cannot be an anchor genome")
+                    ss = engine.SeqSet.from_host(self.context, [read_fastq_joined(g.fasta)])
+                    tbl.insert_seqset(g.id, ss, min_count=2)
+                    ss.close()
                     continue
                 # parsed and packed once on the GPU; anchors keep theirs resident for the anchor step
                 ss = self.seqset_for(name)

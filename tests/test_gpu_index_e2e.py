@@ -218,3 +218,30 @@ def test_write_bgzf_from_hbm_equals_host_writer(ctx, tmp_path):
     res.close()
     ss.close()
     tbl.close()
+
+
+def test_fastq_sample_is_counted_with_ci2(tmp_path):
+    """a FASTQ sample (non-anchor) enters the pan table with kmc -ci2 semantics
+    (workflow/Snakefile:88-89); the anchor's bitmap equals the oracle's"""
+    import gzip as gz
+    from panagram_amd import index as pidx
+    from tests.test_gpu_parity import _simulate_reads
+    k = 21
+    rng = np.random.default_rng(3)
+    gen = po.synth_genomes(2, [9000, 4000], 0.02, 99)
+    asm = [po.codes_to_ascii(c) for c in gen[0]]
+    reads = _simulate_reads(rng, po.codes_to_ascii(gen[1][0]), 300, 120, 0.01)
+    fa = tmp_path / "a.fa"
+    fa.write_bytes(po.fasta_text(["c1", "c2"], asm))
+    fq = tmp_path / "r.fq.gz"
+    with gz.open(fq, "wb") as f:
+        for i, r in enumerate(reads):
+            f.write(b"@r%d\n" % i + r + b"\n+\n" + b"I" * len(r) + b"\n")
+    (tmp_path / "samples.tsv").write_text(f"name\tfasta\tanchor\nasm\t{fa}\tTrue\nreads\t{fq}\tFalse\n")
+    idx = pidx.Index(str(tmp_path / "samples.tsv"), prefix=str(tmp_path / "idx"), k=k)
+    idx.run()
+    dbs = po.build_bitvec_dbs([asm, reads], k, min_counts=[1, 2])
+    want = b"".join(po.anchor_contig(dbs, s, k, 2)[0].tobytes() for s in asm)
+    got = gzip.open(tmp_path / "idx" / "anchor" / "asm" / "bitmap.1.gz").read()
+    assert got == want
+    assert not (tmp_path / "idx" / "anchor" / "reads").exists()

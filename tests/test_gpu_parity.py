@@ -313,3 +313,49 @@ def test_chain_overflow_and_growth(ctx):
         nz = mm != 0
         assert np.array_equal(ek[o], kk[nz]) and np.array_equal(ev[o], mm[nz])
     tbl.close()
+
+
+def _simulate_reads(rng, genome: bytes, nreads: int, rlen: int, err: float):
+    g = np.frombuffer(genome, np.uint8)
+    reads = []
+    for _ in range(nreads):
+        p = int(rng.integers(0, len(g) - rlen))
+        r = g[p:p + rlen].copy()
+        e = rng.random(rlen) < err
+        r[e] = rng.choice(np.frombuffer(b"ACGTN", np.uint8), size=int(e.sum()))
+        if rng.random() < 0.5:  # reverse strand
+            comp = np.zeros(256, np.uint8)
+            comp[list(b"ACGTN")] = list(b"TGCAN")
+            r = comp[r][::-1]
+        reads.append(r.tobytes())
+    return reads
+
+
+@pytest.mark.parametrize("k,min_count", [(21, 2), (31, 2), (15, 3)])
+def test_min_count_insertion_equals_kmc_ci(ctx, k, min_count):
+    """kmc -ci<c> (the reference counts FASTQ samples with -ci2): canonical k-mers seen fewer than c
+    times in the read set do not enter the table; sample 1 is an assembly (-ci1)."""
+    from panagram_amd import engine
+    rng = np.random.default_rng(5 + k)
+    gen = po.synth_genomes(2, [12000], 0.02, 77 + k)
+    asm = [po.codes_to_ascii(c) for c in gen[1]]
+    reads = _simulate_reads(rng, po.codes_to_ascii(gen[0][0]), 400, 150, 0.01)
+    dbs = po.build_bitvec_dbs([reads, asm], k, min_counts=[min_count, 1])
+    tbl = engine.PanTable(ctx, k, 2)
+    ss = engine.SeqSet.from_host(ctx, [b"N".join(reads)])
+    tbl.insert_seqset(0, ss, min_count=min_count)
+    ss.close()
+    ss = engine.SeqSet.from_host(ctx, asm)
+    tbl.insert_seqset(1, ss)
+    ss.close()
+    keys, vals = tbl.export(0)
+    o = np.argsort(keys)
+    assert np.array_equal(keys[o], dbs[0][0]) and np.array_equal(vals[o], dbs[0][1])
+    # and the same read set at -ci1 holds strictly more keys (the singletons)
+    tbl1 = engine.PanTable(ctx, k, 2)
+    ss = engine.SeqSet.from_host(ctx, [b"N".join(reads)])
+    tbl1.insert_seqset(0, ss)
+    ss.close()
+    assert tbl1.stats()["nkeys"] > int((dbs[0][1] & 1).sum())
+    tbl1.close()
+    tbl.close()

@@ -132,3 +132,27 @@ def test_bins_bits_make_bars_matches_reference_loop():
             c += step
         gx, gu, gq = make_bars(occ, num_samples, bin_size, step)
         assert gx == x and gu == z_univ[:len(x)] and gq == z_unique[:len(x)]
+
+
+def test_oracle_min_count_against_brute_force():
+    """kmc -ci<c> restated in the oracle: brute-force dictionary count of canonical k-mers"""
+    from collections import Counter
+    from oracle import pyoracle as po
+    rng = np.random.default_rng(11)
+    k = 5
+    reads = [bytes(rng.choice(np.frombuffer(b"ACGTN", np.uint8), size=40, p=[.24, .24, .24, .24, .04])) for _ in range(30)]
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    code = {c: i for i, c in enumerate(b"ACGT")}
+    cnt = Counter()
+    for r in reads:
+        for i in range(len(r) - k + 1):
+            w = r[i:i + k]
+            if b"N" in w:
+                continue
+            rc = w.translate(comp)[::-1]
+            val = lambda s: sum(code[c] << (2 * (k - 1 - j)) for j, c in enumerate(s))
+            cnt[min(val(w), val(rc))] += 1
+    for ci in (1, 2, 3):
+        keys, masks = po.build_bitvec_dbs([reads], k, min_counts=[ci])[0]
+        assert sorted(int(x) for x in keys) == sorted(v for v, c in cnt.items() if c >= ci)
+        assert np.all(masks == 1)
