@@ -169,6 +169,13 @@ int pg_result_contig_info(const pg_result *r, uint32_t idx, uint64_t *nkmers, ui
 /* copy contig idx's outputs to host (any pointer may be NULL); synchronises.
  *   bitmap1:   nkmers  * nbytes bytes        bitmap100: nrows100 * nbytes bytes
  *   bins:      nbins * (ngenomes+1) u32      (row b covers [b*binlen, ...)) */
+/* statistics of nwin row windows [starts[i], ends[i]) (clipped to the contig) of contig idx's
+ * bitmap.<step> rows in HBM: hist[i*(ngenomes+1) + c] = rows of the window with popcount c,
+ * colsums[i*ngenomes + g] = rows with genome g's bit (colsums may be NULL).  One kernel for the
+ * reference's per-gene occupancy tabulation (index.py:1055-1064), bin_bitsum with any bin length
+ * (index.py:1169-1183) and bitmap_to_bins / paircount bins (index.py:438-449).  Synchronises. */
+int pg_result_window_stats(pg_result *r, uint32_t idx, int step, uint32_t nwin, const uint64_t *starts,
+                           const uint64_t *ends, uint64_t *hist, uint64_t *colsums);
 /* stream the whole bitmap.1 (step 1) or bitmap.100 (step 100) payload of the result — every
  * contig, in order — from HBM into a BGZF file + .gzi index (gzi_path may be NULL): D2H through
  * pinned double buffers on a private stream overlapped with multi-threaded deflate.  Replaces

@@ -353,3 +353,23 @@ def fasta_text(names: Sequence[str], seqs: Sequence[bytes], width: int = 80) -> 
         for i in range(0, len(s), width):
             out.append(s[i:i + width] + b"\n")
     return b"".join(out)
+
+
+# ---------------------------------------------------------------------------
+# window statistics over bitmap rows: the per-gene occupancy tabulation of
+# Genome.run_anchor (index.py:1055-1064: np.unique(bitsum[start:end])) and the
+# per-bin pancount / paircount tables of Index.bitmap_to_bins (index.py:438-449)
+# ---------------------------------------------------------------------------
+def window_stats(rows: np.ndarray, ngenomes: int, starts, ends) -> Tuple[np.ndarray, np.ndarray]:
+    """``rows`` = (n, nbytes) u8 bitmap payload.  Returns ``hist[w, c]`` = positions of window
+    ``[starts[w], ends[w])`` whose row has c bits set, ``colsums[w, g]`` = positions with bit g."""
+    bits = np.unpackbits(rows, axis=1, bitorder="little")[:, :ngenomes]
+    popc = bits.sum(axis=1)
+    hist = np.zeros((len(starts), ngenomes + 1), np.int64)
+    cs = np.zeros((len(starts), ngenomes), np.int64)
+    for w, (s, e) in enumerate(zip(starts, ends)):
+        s, e = int(s), min(int(e), len(rows))
+        if s < e:
+            hist[w] = np.bincount(popc[s:e], minlength=ngenomes + 1)
+            cs[w] = bits[s:e].sum(axis=0)
+    return hist, cs

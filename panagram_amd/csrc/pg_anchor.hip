@@ -756,6 +756,47 @@ __global__ __launch_bounds__(EPI_THREADS) void k_epilogue(uint32_t N, const Anch
 }
 
 // ---------------------------------------------------------------------------
+// statistics of arbitrary row windows of a finished bitmap (genes, bins of any length): per window
+// the histogram of row popcounts and, optionally, the per-genome column sums.  Not on the hot
+// path: LDS atomics for the histogram, one ballot per genome bit and 64 rows for the columns.
+// grid = (windows, pieces): piece p of a window takes its 256-row groups p, p + pieces, ...
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_window_stats(uint32_t N, const uint8_t *__restrict__ rows, uint64_t nrows,
+                                                      const uint64_t *__restrict__ starts, const uint64_t *__restrict__ ends,
+                                                      unsigned long long *__restrict__ hist_out,
+                                                      unsigned long long *__restrict__ cs_out) {
+    extern __shared__ uint32_t wsm[];
+    uint32_t *hist = wsm, *cs = wsm + (N + 1);
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (uint32_t i = tid; i < 2 * N + 1; i += 256) wsm[i] = 0;
+    __syncthreads();
+    const uint32_t nbytes = (N + 7) / 8, ndbs = (N + 31) / 32;
+    const uint64_t s = starts[blockIdx.x], e = min(ends[blockIdx.x], nrows);
+    if (s < e) {
+        for (uint64_t g0 = s + 256ull * blockIdx.y; g0 < e; g0 += 256ull * gridDim.y) {
+            const uint64_t r = g0 + tid;
+            const bool active = r < e;
+            uint32_t popc = 0;
+            for (uint32_t d = 0; d < ndbs; ++d) {
+                const uint32_t nb = min(4u, nbytes - 4 * d);
+                uint32_t wv = 0;
+                if (active)
+                    for (uint32_t bb = 0; bb < nb; ++bb) wv |= (uint32_t)rows[r * nbytes + 4 * d + bb] << (8 * bb);
+                popc += __popc(wv);
+                if (cs_out) colsum_word(wv, d, N, cs, lane);
+            }
+            if (active) atomicAdd(&hist[min(popc, N)], 1u);
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i <= N; i += 256)
+        if (hist[i]) atomicAdd(&hist_out[(uint64_t)blockIdx.x * (N + 1) + i], (unsigned long long)hist[i]);
+    if (cs_out)
+        for (uint32_t i = tid; i < N; i += 256)
+            if (cs[i]) atomicAdd(&cs_out[(uint64_t)blockIdx.x * N + i], (unsigned long long)cs[i]);
+}
+
+// ---------------------------------------------------------------------------
 // launch
 // ---------------------------------------------------------------------------
 template <int W_C, bool TWO, int ROWMODE, int SLOTS>
@@ -846,6 +887,15 @@ hipError_t launch_rows_epilogue(hipStream_t st, uint32_t ngenomes, const AnchorD
     else
         hipLaunchKernelGGL(k_epilogue<2>, dim3(grid), dim3(EPI_THREADS), lds, st, ngenomes, ad, tile_contig, ntiles, out1,
                            out100, bins, colsums, flags);
+    return hipGetLastError();
+}
+
+hipError_t launch_window_stats(hipStream_t st, uint32_t ngenomes, const uint8_t *rows, uint64_t nrows, uint32_t nwin,
+                               uint32_t pieces, const uint64_t *starts, const uint64_t *ends, unsigned long long *hist,
+                               unsigned long long *cs) {
+    if (nwin == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_window_stats, dim3(nwin, pieces), dim3(256), (2 * ngenomes + 1) * 4, st, ngenomes, rows, nrows,
+                       starts, ends, hist, cs);
     return hipGetLastError();
 }
 

@@ -1106,6 +1106,47 @@ extern "C" int pg_result_write_bgzf(pg_result *r, int step, const char *gz_path,
     return rc ? rc : rc2;
 }
 
+// ---------------------------------------------------------------------------
+// window statistics over finished rows resident in HBM
+// ---------------------------------------------------------------------------
+extern "C" int pg_result_window_stats(pg_result *r, uint32_t idx, int step, uint32_t nwin, const uint64_t *starts,
+                                      const uint64_t *ends, uint64_t *hist, uint64_t *colsums) {
+    if (!r || (nwin && (!starts || !ends || !hist))) return fail(PG_E_INVALID, "pg_result_window_stats: NULL argument");
+    if (idx >= r->ad.size()) return fail(PG_E_INVALID, "contig %u out of range", idx);
+    if (step != 1 && step != 100) return fail(PG_E_INVALID, "step must be 1 or 100");
+    if (!r->ev_ok) return fail(PG_E_INVALID, "pg_anchor_run has not been called on this result");
+    if (nwin == 0) return PG_OK;
+    if (int e = use_device(r->tbl->ctx)) return e;
+    if (int e = join_result(r)) return e;
+    hipStream_t st = r->tbl->ctx->stream;
+    const uint32_t N = r->tbl->ngenomes;
+    const AnchorDesc &a = r->ad[idx];
+    const uint8_t *rows = step == 1 ? r->d_out1 + a.out_off : r->d_out100 + a.out100_off;
+    const uint64_t nrows = step == 1 ? (uint64_t)a.nkmers : r->nrows100[idx];
+    uint64_t longest = 0;
+    for (uint32_t i = 0; i < nwin; ++i)
+        if (ends[i] > starts[i]) longest = std::max(longest, std::min(ends[i], nrows) - std::min(starts[i], nrows));
+    const uint32_t pieces = (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(1, longest / 32768));
+    uint64_t *d_se = nullptr;
+    unsigned long long *d_out = nullptr;
+    const size_t nh = (size_t)nwin * (N + 1), nc = colsums ? (size_t)nwin * N : 0;
+    int rc = PG_OK;
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&d_se), (size_t)nwin * 16);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_out), (nh + nc) * 8);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_se, starts, (size_t)nwin * 8, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_se + nwin, ends, (size_t)nwin * 8, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemsetAsync(d_out, 0, (nh + nc) * 8, st);
+    if (e == hipSuccess)
+        e = launch_window_stats(st, N, rows, nrows, nwin, pieces, d_se, d_se + nwin, d_out, colsums ? d_out + nh : nullptr);
+    if (e == hipSuccess) e = hipMemcpyAsync(hist, d_out, nh * 8, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess && colsums) e = hipMemcpyAsync(colsums, d_out + nh, nc * 8, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) rc = fail(PG_E_HIP, "pg_result_window_stats: %s", hipGetErrorString(e));
+    if (d_se) hipFree(d_se);
+    if (d_out) hipFree(d_out);
+    return rc;
+}
+
 extern "C" int pg_result_contig_info(const pg_result *r, uint32_t idx, uint64_t *nkmers, uint64_t *nrows100,
                                      uint32_t *nbins, uint32_t *binlen) {
     if (!r) return fail(PG_E_INVALID, "result is NULL");

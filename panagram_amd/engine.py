@@ -289,6 +289,16 @@ class AnchorResult:
         check(self._lib.pg_result_contig_info(self._h, idx, C.byref(nk), C.byref(n100), C.byref(nb), C.byref(bl)))
         return dict(nkmers=nk.value, nrows100=n100.value, nbins=nb.value, binlen=bl.value)
 
+    def window_stats(self, idx: int, starts, ends, step: int = 1, colsums: bool = True):
+        """(hist [nwin, N+1], colsums [nwin, N] or None) of row windows [start, end) of contig idx"""
+        starts = np.ascontiguousarray(starts, np.uint64)
+        ends = np.ascontiguousarray(ends, np.uint64)
+        n, N = len(starts), self.table.ngenomes
+        hist = np.zeros((n, N + 1), np.uint64)
+        cs = np.zeros((n, N), np.uint64) if colsums else None
+        check(self._lib.pg_result_window_stats(self._h, idx, step, n, _ptr(starts), _ptr(ends), _ptr(hist), _ptr(cs)))
+        return hist, cs
+
     def write_bgzf(self, step: int, gz_path: str, gzi_path: Optional[str] = None, level: int = 6,
                    threads: int = 1) -> None:
         """Stream the whole bitmap.<step> payload (all contigs) from HBM into a BGZF file + .gzi;

@@ -428,6 +428,49 @@ class Index:
                 self.drop_seqset(nm)
         self.close()
 
+    # ---- bitmap -> bins (index.py:438-465): what the viewer does with a queried bitmap ----
+    @property
+    def bitsum_index(self):
+        return pd.RangeIndex(0, self.ngenomes + 1)
+
+    @staticmethod
+    def _bin_ids(bitmap: pd.DataFrame, binlen: int):
+        bins = np.asarray(bitmap.index) // binlen
+        ub, inv = np.unique(bins, return_inverse=True)
+        return ub, inv
+
+    def bitmap_to_bins(self, bitmap: pd.DataFrame, binlen: int):
+        """(pancount_bins, paircount_bins) of a positions x genomes 0/1 bitmap: rows = occupancy 0..N
+        and columns = bin number; rows = genomes and columns = bin start, every bin scaled by its
+        largest genome count (index.py:438-449)."""
+        ub, inv = self._bin_ids(bitmap, binlen)
+        vals = bitmap.to_numpy()
+        N = self.ngenomes
+        flat = np.bincount(inv * (N + 1) + vals.sum(axis=1).astype(np.int64), minlength=len(ub) * (N + 1))
+        pan = pd.DataFrame(flat.reshape(len(ub), N + 1).T, index=self.bitsum_index, columns=ub)
+        return pan, self._paircount_bins(vals, ub, inv, binlen, bitmap.columns)
+
+    @staticmethod
+    def _paircount_bins(vals, ub, inv, binlen, columns):
+        sums = np.zeros((len(ub), vals.shape[1]), np.int64)
+        np.add.at(sums, inv, vals.astype(np.int64))
+        pc = pd.DataFrame(sums.T, index=columns, columns=ub * binlen)
+        return pc.div(pc.max(axis=0), axis=1)
+
+    def bitmap_to_paircount_bins(self, bitmap: pd.DataFrame, binlen: int):
+        ub, inv = self._bin_ids(bitmap, binlen)
+        return self._paircount_bins(bitmap.to_numpy(), ub, inv, binlen, bitmap.columns)
+
+    def bitmap_to_pancount(self, bitmap: pd.DataFrame) -> pd.Series:
+        return pd.Series(bitmap.to_numpy().sum(axis=1), index=bitmap.index)
+
+    def pancount_to_bins(self, pancnts: pd.Series, binlen: int) -> pd.DataFrame:
+        bins = np.asarray(pancnts.index) // binlen
+        ub, inv = np.unique(bins, return_inverse=True)
+        N = self.ngenomes
+        flat = np.bincount(inv * (N + 1) + pancnts.to_numpy().astype(np.int64), minlength=len(ub) * (N + 1))
+        return pd.DataFrame(flat.reshape(len(ub), N + 1).T, index=self.bitsum_index, columns=ub)
+
     def query_bitmap(self, genome, chrom, start=None, end=None, step=1):
         return self.genomes[genome].query(chrom, start, end, step)
 
@@ -465,6 +508,24 @@ class Genome:
     @property
     def chrs_fname(self):
         return os.path.join(self.prefix, "chrs.tsv")
+
+    @property
+    def chr_genes_fname(self):
+        return os.path.join(self.prefix, "bitsum.genes.tsv")
+
+    @property
+    def annotated(self) -> bool:
+        return self.gff is not None and not pd.isna(self.gff)
+
+    def load_genes(self) -> pd.DataFrame:
+        """The GFF records whose type is a gene type (index.py:669-691,731-736), sorted by (chr,
+        start); ``start`` / ``end`` are used as they stand in the file, like the reference does
+        when it slices ``bitsum[start:end]`` (index.py:1056-1063)."""
+        df = pd.read_csv(self.gff, sep="\t", comment="#", header=None,
+                         names=["chr", "source", "type", "start", "end", "score", "strand", "phase", "attr"],
+                         usecols=["chr", "type", "start", "end"], dtype={"chr": str})
+        df = df[df["type"].isin(self.index.gff_gene_types)]
+        return df.sort_values(["chr", "start"], kind="stable").reset_index(drop=True)
 
     @property
     def bins_fname(self):
@@ -548,12 +609,36 @@ class Genome:
         res.run()
         small = [res.download(ci, want_bitmap1=False, want_bitmap100=False) for ci in range(len(ss.names))]
         cs = res.colsums().astype(np.int64)
-        return res, list(ss.names), small, cs
+        gene_hists = self._tabulate_genes(res, list(ss.names), small) if self.annotated else None
+        return res, list(ss.names), small, cs, gene_hists
+
+    def _tabulate_genes(self, res, names, small):
+        """occupancy histogram of every gene's positions, summed per chromosome (index.py:1055-1064,
+        1079-1082), from the rows in HBM: {chrom: (gene_count, hist[N+1])} in sorted-chr order"""
+        genes = self.load_genes()
+        out = {}
+        for chrom, grp in genes.groupby("chr", sort=True):
+            if chrom not in names:
+                out[chrom] = (len(grp), np.zeros(self.ngenomes + 1, np.int64))
+                continue
+            ci = names.index(chrom)
+            size = small[ci][3]["nkmers"]
+            st, en = grp["start"].to_numpy(np.int64), grp["end"].to_numpy(np.int64)
+            ok = (en > st) & (st >= 0) & (en <= size)
+            for s_, e_ in zip(st[~ok], en[~ok]):
+                logger.warning(f"Skipping gene at {chrom}:{s_}-{e_}, coordinates out-of-bounds")
+            hist = np.zeros(self.ngenomes + 1, np.int64)
+            if ok.any():
+                h, _ = res.window_stats(ci, st[ok], en[ok], step=1, colsums=False)
+                hist = h.sum(axis=0).astype(np.int64)
+            out[chrom] = (len(grp), hist)
+            logger.info(f"Annotated {chrom}")
+        return out
 
     def write_from_result(self, job, bgzf_threads: Optional[int] = None):
         """anchor/<name>/ exactly as the reference lays it out (cpp/anchor.cpp:37-109,
         index.py:1035-1094), the two bitmaps streamed from HBM by the library."""
-        res, names, small, cs = job
+        res, names, small, cs, gene_hists = job
         try:
             os.makedirs(self.prefix, exist_ok=True)
             nthreads = bgzf_threads or self._bgzf_threads()
@@ -564,12 +649,12 @@ class Genome:
                 os.replace(gzi + ".tmp", gzi)
         finally:
             res.close()
-        self._write_tables(names, [(b, info) for _, _, b, info in small], cs)
+        self._write_tables(names, [(b, info) for _, _, b, info in small], cs, gene_hists)
 
     def _bgzf_threads(self) -> int:
         return max(1, min(64, self.index.cores if self.index.cores > 1 else engine.usable_cpus()))
 
-    def _write_tables(self, names, bins_infos, paircount_sums):
+    def _write_tables(self, names, bins_infos, paircount_sums, gene_hists=None):
         N = self.ngenomes
         bins_rows: List[str] = ["chr\tstart" + "".join(f"\t{i}" for i in range(N + 1)) + "\n"]
         chr_rows: List[Tuple[str, int, int, int]] = []
@@ -577,10 +662,14 @@ class Genome:
             starts = np.arange(info["nbins"], dtype=np.int64) * info["binlen"]
             body = np.column_stack([np.full(info["nbins"], ci, np.int64), starts, bins.astype(np.int64)])
             bins_rows.extend("\t".join(map(str, row)) + "\n" for row in body.tolist())
-            chr_rows.append((chrom, ci, info["nkmers"], 0))
+            gene_count = gene_hists[chrom][0] if gene_hists and chrom in gene_hists else 0
+            chr_rows.append((chrom, ci, info["nkmers"], gene_count))
             logger.info(f"Anchored {chrom}")
         with open(self.bins_fname, "w") as f:
             f.writelines(bins_rows)
+        if gene_hists is not None:  # bitsum.genes.tsv: one row per annotated chromosome (index.py:1079-1082)
+            pd.DataFrame([h for _, h in gene_hists.values()], index=pd.Index(list(gene_hists), name="chr"),
+                         columns=range(N + 1)).to_csv(self.chr_genes_fname, sep="\t")
         # total_paircounts.csv (index.py:1068-1074): count[g] = positions holding genome g's bit
         counts = pd.Series(np.asarray(paircount_sums, dtype=np.int64), index=self.index.genome_names)
         pd.DataFrame({"count": counts, "frac": counts / counts[self.name]}).to_csv(

@@ -245,3 +245,42 @@ def test_fastq_sample_is_counted_with_ci2(tmp_path):
     got = gzip.open(tmp_path / "idx" / "anchor" / "asm" / "bitmap.1.gz").read()
     assert got == want
     assert not (tmp_path / "idx" / "anchor" / "reads").exists()
+
+
+def test_gene_tabulation_from_gff(tmp_path):
+    """bitsum.genes.tsv and chrs.tsv gene_count for an annotated anchor (index.py:1027-1033,
+    1055-1064, 1079-1082): per-gene occupancy counted on the GPU equals the oracle's rows"""
+    from panagram_amd import index as pidx
+    k, n = 21, 3
+    gen = po.synth_genomes(n, [20000, 8000, 1000], 0.02, 5)
+    genomes = [[po.codes_to_ascii(c) for c in g] for g in gen]
+    names = ["chrB", "chrA", "chrC"]  # the GFF is tabulated in sorted-chr order, the FASTA is not sorted
+    rows = ["name\tfasta\tgff"]
+    for g in range(n):
+        fa = tmp_path / f"g{g}.fa"
+        fa.write_bytes(po.fasta_text(names, genomes[g]))
+        rows.append(f"g{g}\t{fa}\t" + (str(tmp_path / "g0.gff") if g == 0 else ""))
+    genes = [("chrA", 100, 900), ("chrA", 850, 2000), ("chrB", 1, 19000), ("chrB", 500, 400),  # end <= start: skipped
+             ("chrB", 19000, 20001), ("chrZ", 10, 20), ("chrC", 0, 980)]                       # past the end / unknown chr
+    with open(tmp_path / "g0.gff", "w") as f:
+        f.write("##gff-version 3\n")
+        for c, s, e in genes:
+            f.write(f"{c}\tsrc\tgene\t{s}\t{e}\t.\t+\t.\tID=g{s};Name=n{s}\n")
+            f.write(f"{c}\tsrc\texon\t{s}\t{e}\t.\t+\t.\tParent=g{s}\n")
+    (tmp_path / "samples.tsv").write_text("\n".join(rows) + "\n")
+    idx = pidx.Index(str(tmp_path / "samples.tsv"), prefix=str(tmp_path / "idx"), k=k, anchor_genomes=["g0"])
+    idx.run()
+    dbs = po.build_bitvec_dbs(genomes, k)
+    want = {}
+    for c, s, e in genes:
+        want.setdefault(c, np.zeros(n + 1, np.int64))
+        if c in names:
+            o_rows = po.anchor_contig(dbs, genomes[0][names.index(c)], k, n)[0]
+            if e > s and s >= 0 and e <= len(o_rows):
+                want[c] += po.window_stats(o_rows, n, [s], [e])[0][0]
+    got = pd.read_table(tmp_path / "idx" / "anchor" / "g0" / "bitsum.genes.tsv").set_index("chr")
+    assert list(got.index) == sorted(want)
+    for c in want:
+        assert np.array_equal(got.loc[c].to_numpy(), want[c])
+    chrs = pd.read_table(tmp_path / "idx" / "anchor" / "g0" / "chrs.tsv").set_index("name")
+    assert chrs["gene_count"].to_dict() == {"chrB": 3, "chrA": 2, "chrC": 1}

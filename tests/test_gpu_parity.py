@@ -359,3 +359,40 @@ def test_min_count_insertion_equals_kmc_ci(ctx, k, min_count):
     assert tbl1.stats()["nkeys"] > int((dbs[0][1] & 1).sum())
     tbl1.close()
     tbl.close()
+
+
+@pytest.mark.parametrize("n,k", [(5, 21), (40, 31), (65, 21)])
+def test_window_stats_equal_oracle(ctx, n, k):
+    """per-window occupancy histograms and column sums (genes, bins of any length) from rows in HBM"""
+    from panagram_amd import engine
+    rng = np.random.default_rng(n)
+    gen = po.synth_genomes(n, [90000, 3000], 0.03, 400 + n)
+    genomes = [[po.codes_to_ascii(c) for c in g] for g in gen]
+    dbs = po.build_bitvec_dbs(genomes, k)
+    tbl = engine.PanTable(ctx, k, n)
+    for g in range(n):
+        ss = engine.SeqSet.from_host(ctx, genomes[g])
+        tbl.insert_seqset(g, ss)
+        ss.close()
+    ss = engine.SeqSet.from_host(ctx, genomes[1])
+    res = engine.AnchorResult(tbl, ss)
+    res.run()
+    for ci, seq in enumerate(genomes[1]):
+        o_rows, o_rows100 = po.anchor_contig(dbs, seq, k, n)[:2]
+        nk = len(o_rows)
+        starts = np.concatenate([rng.integers(0, nk, 40), [0, 0, nk - 1, nk, 5]])
+        lens = np.concatenate([rng.integers(0, 5000, 40), [nk, 1, 1, 10, 0]])
+        ends = starts + lens  # some run past the contig end (clipped), some are empty
+        h, cs = res.window_stats(ci, starts, ends)
+        oh, ocs = po.window_stats(o_rows, n, starts, ends)
+        assert np.array_equal(h.astype(np.int64), oh) and np.array_equal(cs.astype(np.int64), ocs)
+        # one window over everything, long enough to be split into pieces; and the 1-in-100 rows
+        h, cs = res.window_stats(ci, [0], [nk], colsums=False)
+        assert cs is None and np.array_equal(h.astype(np.int64), po.window_stats(o_rows, n, [0], [nk])[0])
+        s100 = np.arange(0, len(o_rows100), 37)
+        h, cs = res.window_stats(ci, s100, s100 + 50, step=100)
+        oh, ocs = po.window_stats(o_rows100, n, s100, s100 + 50)
+        assert np.array_equal(h.astype(np.int64), oh) and np.array_equal(cs.astype(np.int64), ocs)
+    res.close()
+    ss.close()
+    tbl.close()

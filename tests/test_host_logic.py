@@ -156,3 +156,30 @@ def test_oracle_min_count_against_brute_force():
         keys, masks = po.build_bitvec_dbs([reads], k, min_counts=[ci])[0]
         assert sorted(int(x) for x in keys) == sorted(v for v, c in cnt.items() if c >= ci)
         assert np.all(masks == 1)
+
+
+def test_bitmap_to_bins_against_brute_force(tmp_path):
+    """Index.bitmap_to_bins / bitmap_to_paircount_bins / pancount_to_bins (index.py:438-465)"""
+    from panagram_amd import index as pidx
+    rng = np.random.default_rng(2)
+    N, binlen = 5, 700
+    idx = pidx.Index.__new__(pidx.Index)
+    idx.ngenomes = N
+    names = [f"g{i}" for i in range(N)]
+    for start, end, step in ((0, 5000, 1), (1300, 9100, 100)):
+        pos = np.arange(start, end, step)
+        bits = (rng.random((len(pos), N)) < 0.6).astype(np.uint8)
+        bits[:, 0] = 1
+        bm = pd.DataFrame(bits, index=pd.RangeIndex(start, end, step), columns=names)
+        pan, pair = idx.bitmap_to_bins(bm, binlen)
+        bins = sorted(set(pos // binlen))
+        assert list(pan.columns) == bins and list(pan.index) == list(range(N + 1))
+        assert list(pair.columns) == [b * binlen for b in bins] and list(pair.index) == names
+        for b in bins:
+            sel = bits[pos // binlen == b]
+            assert list(pan[b]) == [int((sel.sum(axis=1) == c).sum()) for c in range(N + 1)]
+            assert np.allclose(pair[b * binlen].to_numpy(), sel.sum(axis=0) / sel.sum(axis=0).max())
+        assert pair.equals(idx.bitmap_to_paircount_bins(bm, binlen))
+        pc = idx.bitmap_to_pancount(bm)
+        assert list(pc.index) == list(pos) and list(pc) == list(bits.sum(axis=1))
+        assert idx.pancount_to_bins(pc, binlen).equals(pan)
