@@ -75,12 +75,14 @@ __device__ __forceinline__ int scan_line_global(const SubTable &st, uint32_t b, 
     return (m0 | m1) ? 1 : (last == EMPTY_KEY ? 0 : -1);
 }
 
+// follow a key's probe sequence from its line number `level` (b, step) to the end
 template <bool TWO, int SLOTS>
-__device__ __forceinline__ void lane_chase(const SubTable &st, uint64_t key, uint32_t b, uint32_t step, uint32_t &m0,
-                                           uint32_t &m1) {
-    for (uint64_t n = 0; n < st.nbuckets; ++n) {
+__device__ __forceinline__ void lane_chase(const SubTable &st, uint64_t key, uint32_t level, uint32_t b, uint32_t step,
+                                           uint32_t &m0, uint32_t &m1) {
+    for (uint64_t n = 0; n < st.nbuckets + GROUP_CHAIN; ++n) {
         if (scan_line_global<TWO, SLOTS>(st, b, key, m0, m1) >= 0) return;
-        b = next_line(b, step, st.nbuckets);
+        level = min(level + 1, GROUP_CHAIN + 1);
+        advance_line(key, level, st.nbuckets, b, step);
     }
     m0 = m1 = 0;
 }
@@ -125,7 +127,7 @@ __device__ __forceinline__ void drain_queue(const SubTable &st, uint32_t qn, uin
             // 8 slot loads in flight per line, no staging overhead
             for (uint32_t e = lane; e < qn; e += 64) {
                 uint32_t m0, m1;
-                lane_chase<TWO, SLOTS>(st, q_key[e], q_line[e], q_step[e], m0, m1);
+                lane_chase<TWO, SLOTS>(st, q_key[e], (uint32_t)level, q_line[e], q_step[e], m0, m1);
                 if (m0 | m1) store_row<ROWMODE>(tile_rows + (uint64_t)q_pl[e] * nbytes, m0, m1, rc);
             }
             break;
@@ -170,9 +172,11 @@ __device__ __forceinline__ void drain_queue(const SubTable &st, uint32_t qn, uin
             const unsigned long long kmask2 = __ballot(again);
             if (again) {  // in-place compaction: slot <= e, and this batch's reads are already done
                 const uint32_t slot = kept + lanes_le_count(kmask2, true) - 1;
+                uint32_t nl2 = line, ns2 = step;
+                advance_line(key, (uint32_t)level + 1, st.nbuckets, nl2, ns2);
                 q_key[slot] = key;
-                q_line[slot] = next_line(line, step, st.nbuckets);
-                q_step[slot] = step;
+                q_line[slot] = nl2;
+                q_step[slot] = ns2;
                 q_pl[slot] = (uint16_t)pl;
             }
             kept += (uint32_t)__popcll(kmask2);
@@ -350,7 +354,7 @@ __global__ __launch_bounds__(64) void k_probe(const SubTable st, const uint64_t 
                         q_step[slot] = step;
                         q_pl[slot] = (uint16_t)pl[u];
                     } else {
-                        lane_chase<TWO, SLOTS>(st, key[u], nx, step, m0[u], m1[u]);  // queue full: resolve inline
+                        lane_chase<TWO, SLOTS>(st, key[u], 1u, nx, step, m0[u], m1[u]);  // queue full: resolve inline
                     }
                 }
                 qn = min(qn + (uint32_t)__popcll(omask), (uint32_t)PROBE_QCAP);

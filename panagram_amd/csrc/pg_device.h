@@ -102,6 +102,22 @@ __device__ __forceinline__ uint32_t next_line(uint32_t line, uint32_t step, uint
     const uint64_t n = (uint64_t)line + step;
     return (uint32_t)(n >= nlines ? n - nlines : n);
 }
+// A minimizer group owns only the first GROUP_CHAIN lines of its sequence.  A key that finds them
+// all full continues on a sequence of ITS OWN (double hashing on the key): repeat families put
+// thousands of distinct k-mers behind one minimizer, and without this bound their chain — walked
+// by every insert and every lookup of the family — grows to hundreds of lines.
+// Line number `level` (0 = home) of a key's probe sequence, given the line before it:
+constexpr uint32_t GROUP_CHAIN = 4;
+__device__ __forceinline__ void advance_line(uint64_t key, uint32_t level, uint64_t nlines, uint32_t &line,
+                                             uint32_t &step) {
+    if (level == GROUP_CHAIN) {  // first line of the key's own sequence
+        const uint32_t g2 = fmix32(group_of_key(key) ^ 0x7feb352du);
+        line = home_of_group(g2, nlines);
+        step = step_of_group(g2, nlines);
+    } else {
+        line = next_line(line, step, nlines);
+    }
+}
 
 // ---- packed sequence ------------------------------------------------------
 // base i of a contig lives in bits [2*(i%32), 2*(i%32)+1] of u64 word i/32 (little-endian in
@@ -192,8 +208,8 @@ __device__ __forceinline__ uint64_t extract_nmask64(P words, uint64_t p) {
 __device__ __forceinline__ bool lane_lookup(const SubTable &st, uint64_t key, uint32_t &m0, uint32_t &m1) {
     const uint32_t grp = group_of(st, key);
     uint32_t b = home_of_group(grp, st.nbuckets);
-    const uint32_t step = step_of_group(grp, st.nbuckets);
-    for (uint64_t probes = 0; probes < st.nbuckets; ++probes) {
+    uint32_t step = step_of_group(grp, st.nbuckets);
+    for (uint64_t probes = 0; probes < st.nbuckets + GROUP_CHAIN; ++probes) {
         const uint8_t *base = st.buckets + (uint64_t)b * (16u * st.slots);
         bool empty_seen = false;
         for (int s = 0; s < (int)st.slots; ++s) {
@@ -206,7 +222,7 @@ __device__ __forceinline__ bool lane_lookup(const SubTable &st, uint64_t key, ui
             empty_seen |= (cur == EMPTY_KEY);
         }
         if (empty_seen) break;
-        b = next_line(b, step, st.nbuckets);
+        advance_line(key, (uint32_t)min(probes + 1, (uint64_t)GROUP_CHAIN + 1), st.nbuckets, b, step);
     }
     m0 = m1 = 0;
     return false;
@@ -220,7 +236,7 @@ __device__ __forceinline__ int lane_insert(const SubTable &st, uint64_t key, int
                                            uint32_t max_probe) {
     const uint32_t grp = group_of(st, key);
     uint32_t b = home_of_group(grp, st.nbuckets);
-    const uint32_t step = step_of_group(grp, st.nbuckets);
+    uint32_t step = step_of_group(grp, st.nbuckets);
     for (uint32_t probes = 0; probes < max_probe; ++probes) {
         uint8_t *base = st.buckets + (uint64_t)b * (16u * st.slots);
         for (int s = 0; s < (int)st.slots; ++s) {
@@ -244,7 +260,7 @@ __device__ __forceinline__ int lane_insert(const SubTable &st, uint64_t key, int
                 return claimed;
             }
         }
-        b = next_line(b, step, st.nbuckets);
+        advance_line(key, probes + 1, st.nbuckets, b, step);
     }
     return -1;
 }

@@ -396,3 +396,43 @@ def test_window_stats_equal_oracle(ctx, n, k):
     res.close()
     ss.close()
     tbl.close()
+
+
+@pytest.mark.parametrize("k", [21, 31, 12])
+def test_repeat_family_heavy_minimizer_groups(ctx, k):
+    """Hundreds of diverged copies of one element put hundreds of distinct k-mers behind one
+    minimizer: beyond GROUP_CHAIN lines the keys continue on their own probe sequence.  Table
+    contents, GetCountersForRead and anchored rows stay bit-exact."""
+    from panagram_amd import engine
+    rng = np.random.default_rng(k)
+    n = 3
+    elem = rng.integers(0, 4, 400, dtype=np.uint8)
+    genomes = []
+    for g in range(n):
+        parts = []
+        for c in range(500):
+            e = elem.copy()
+            mut = rng.random(len(e)) < 0.04
+            e[mut] = (e[mut] + rng.integers(1, 4, int(mut.sum()), dtype=np.uint8)) % 4
+            parts += [e, rng.integers(0, 4, 30, dtype=np.uint8)]
+        genomes.append([po.codes_to_ascii(np.concatenate(parts))])
+    dbs = po.build_bitvec_dbs(genomes, k)
+    tbl = engine.PanTable(ctx, k, n)
+    for g in range(n):
+        ss = engine.SeqSet.from_host(ctx, genomes[g])
+        tbl.insert_seqset(g, ss)
+        ss.close()
+    keys, vals = tbl.export(0)
+    o = np.argsort(keys)
+    assert np.array_equal(keys[o], dbs[0][0]) and np.array_equal(vals[o], dbs[0][1])
+    for dense in (False, True):
+        if dense:
+            tbl.rehash(4.0)
+        seq = genomes[1][0]
+        rows, rows100, bins, cs = tbl.anchor_contig(seq)
+        o_rows, o_rows100, o_bins, _, o_cs = po.anchor_contig(dbs, seq, k, n)
+        assert np.array_equal(rows, o_rows) and np.array_equal(rows100, o_rows100)
+        assert np.array_equal(bins.astype(np.int64), o_bins) and np.array_equal(cs.astype(np.int64), o_cs)
+        got = tbl.counters_for_read(0, seq[:5000])
+        assert np.array_equal(got, po.counters_for_read(dbs[0], seq[:5000], k))
+    tbl.close()
