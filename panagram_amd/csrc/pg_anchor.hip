@@ -373,6 +373,10 @@ __global__ __launch_bounds__(64) void k_probe(const SubTable st, const uint64_t 
 // the end, so that global atomics on the few shared counters stay rare.
 // (also the second half of the genome-sharded mode: rows combined over xGMI first)
 // ---------------------------------------------------------------------------
+// A workgroup keeps the histograms of EPI_MAXB consecutive bins in LDS at a time (rows relative to
+// cur_row0): contigs of a few kb .. Mb have bins of nkmers/100 positions, far shorter than a tile.
+constexpr uint32_t EPI_MAXB = 16;
+constexpr uint32_t EPI_MINBIN = (PROBE_TILE + EPI_MAXB - 3) / (EPI_MAXB - 2);  // a tile then spans <= EPI_MAXB bins
 // column sums: one ballot + popcount per genome bit, accumulated in LDS by lane 0
 __device__ __forceinline__ void colsum_word(uint32_t wv, uint32_t d, uint32_t N, uint32_t *cs, int lane) {
     const uint32_t ng = min(32u, N - 32 * d);
@@ -381,10 +385,10 @@ __device__ __forceinline__ void colsum_word(uint32_t wv, uint32_t d, uint32_t N,
         if (lane == 0 && bal) atomicAdd(&cs[32 * d + bit], (uint32_t)__popcll(bal));
     }
 }
-// wave-aggregated histogram of (bin, popcount): LDS for the tile's first two bins, global beyond
+// wave-aggregated histogram of (bin, popcount): LDS for the first EPI_MAXB bins from bin0, global beyond
 __device__ __forceinline__ void hist_position(bool active, uint32_t pos, uint32_t popc, uint32_t N, uint32_t binlen,
-                                              uint32_t bin0, uint32_t bin0_start, uint32_t *hist, uint32_t *bins,
-                                              uint64_t bin_off, int lane) {
+                                              uint32_t bin0, uint32_t bin0_start, uint32_t rel_base, uint32_t *hist,
+                                              uint32_t *bins, uint64_t bin_off, int lane) {
     if (popc > N) popc = N;  // junk bits beyond ngenomes: the reference indexes out of bounds here
     const uint32_t dpos = pos - bin0_start;
     const uint32_t rel = (binlen >= (uint32_t)PROBE_TILE) ? (dpos >= binlen ? 1u : 0u) : dpos / binlen;
@@ -396,7 +400,7 @@ __device__ __forceinline__ void hist_position(bool active, uint32_t pos, uint32_
         const unsigned long long mk = __ballot(active && hk == lk) & todo;
         if (lane == leader) {
             const uint32_t cnt = (uint32_t)__popcll(mk);
-            if (rel < 2) atomicAdd(&hist[hk], cnt);
+            if (rel_base + rel < EPI_MAXB) atomicAdd(&hist[rel_base * (N + 1) + hk], cnt);
             else atomicAdd(&bins[(bin_off + bin0 + rel) * (uint64_t)(N + 1) + popc], cnt);
         }
         todo &= ~mk;
@@ -407,10 +411,11 @@ __device__ __forceinline__ void hist_position(bool active, uint32_t pos, uint32_
 #define PG_EPI_MIN_TILES 32
 #endif
 constexpr int EPI_THREADS = PROBE_TILE / 4;
+
 static_assert(EPI_THREADS >= 64 && EPI_THREADS % 64 == 0, "PROBE_TILE must be a multiple of 256");
 
 __device__ __forceinline__ void flush_hist(uint32_t N, uint32_t *hist, uint32_t *bins, uint64_t bin_row0, int tid) {
-    for (uint32_t i = tid; i < 2 * (N + 1); i += EPI_THREADS) {
+    for (uint32_t i = tid; i < EPI_MAXB * (N + 1); i += EPI_THREADS) {
         const uint32_t hv = hist[i];
         if (hv) {
             const uint32_t rel = i / (N + 1), pc2 = i - rel * (N + 1);
@@ -433,8 +438,8 @@ __global__ __launch_bounds__(EPI_THREADS) void k_epilogue(uint32_t N, const Anch
     const int tid = threadIdx.x, lane = tid & 63;
     const uint32_t nbytes = (N + 7) / 8, ndbs = (N + 31) / 32;
     uint32_t *hist = reinterpret_cast<uint32_t *>(smem);
-    uint32_t *cs = hist + ((2 * (N + 1) + 3) & ~3u);
-    for (uint32_t i = tid; i < 2 * (N + 1); i += EPI_THREADS) hist[i] = 0;
+    uint32_t *cs = hist + ((EPI_MAXB * (N + 1) + 3) & ~3u);
+    for (uint32_t i = tid; i < EPI_MAXB * (N + 1); i += EPI_THREADS) hist[i] = 0;
     for (uint32_t i = tid; i < N; i += EPI_THREADS) cs[i] = 0;
     __syncthreads();
     const bool want_cs = (flags & 1u) != 0;
@@ -601,9 +606,18 @@ __global__ __launch_bounds__(EPI_THREADS) void k_epilogue(uint32_t N, const Anch
         const uint32_t npos = min((uint32_t)PROBE_TILE, a.nkmers - tile_start);
         const uint32_t binlen = a.binlen, bin0 = tile_start / binlen, bin0_start = bin0 * binlen;
         const uint64_t row0 = a.bin_off + bin0;
-        const bool fast = (MODE == 0 && binlen >= (uint32_t)PROBE_TILE);
         const bool onebin = (tile_start + npos) <= (bin0_start + binlen);  // block-uniform
-        if (row0 != cur_row0 || (fast && !onebin)) {  // block-uniform: the accumulators move on to another bin
+        const bool big = binlen >= (uint32_t)PROBE_TILE;                    // a tile spans at most 2 bins
+        const bool windowed = binlen >= EPI_MINBIN;                         // ... at most EPI_MAXB bins
+        const uint32_t last_rel = (tile_start + npos - 1 - bin0_start) / binlen;
+        // (bin - bin0) of a position for short bins: exact for pos - bin0_start < 2^16 > tile + bin
+        const uint32_t binv = big ? 0u : 0xFFFFFFFFu / binlen + 1u;
+        // block-uniform: may this tile add to the LDS window as it stands?  The per-thread one-byte
+        // accumulators stand for the window's first bin, so a one-bin tile needs row0 == cur_row0.
+        const bool reg_tile = MODE == 0 && big && onebin;
+        const bool fits = cur_row0 != ~0ull && (reg_tile || !windowed ? row0 == cur_row0
+                                                : (row0 >= cur_row0 && row0 + last_rel < cur_row0 + EPI_MAXB));
+        if (!fits) {
             if (cur_row0 != ~0ull) {
                 reduce_hist();
                 __syncthreads();
@@ -612,8 +626,13 @@ __global__ __launch_bounds__(EPI_THREADS) void k_epilogue(uint32_t N, const Anch
             }
             cur_row0 = row0;
         }
+        const uint32_t rel_base = (uint32_t)(row0 - cur_row0);
+        auto rel_of = [&](uint32_t pos) -> uint32_t {  // bin of a position of this tile, relative to bin0
+            const uint32_t dpos = pos - bin0_start;
+            return big ? (dpos >= binlen ? 1u : 0u) : __umulhi(dpos, binv);
+        };
         const uint8_t *g = out1 + a.out_off + (uint64_t)tile_start * nbytes;
-        if (fast) {
+        if (MODE == 0 && windowed) {
             // ---- fast path (N <= 8): 4 one-byte rows per thread in one 32-bit word ----
             uint32_t packed = 0;
             if (next_valid) packed = next_packed;
@@ -630,19 +649,19 @@ __global__ __launch_bounds__(EPI_THREADS) void k_epilogue(uint32_t N, const Anch
 #pragma unroll
                 for (int gb = 0; gb < 8; ++gb) cacc[gb] += __popc(packed & (0x01010101u << gb));
             }
-            if (onebin) {
+            if (reg_tile) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const uint32_t pcj = min((uint32_t)__popc((packed >> (8 * j)) & 0xFFu), N);
                     if ((uint32_t)j < nact) hacc += 1ull << (7 * pcj);
                 }
                 if (++since_spill == 31) spill();
-            } else {
+            } else {  // the tile spans several bins: one LDS counter per (bin, popcount)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    hist_position((uint32_t)j < nact, tile_start + p0 + j,
-                                  min((uint32_t)__popc((packed >> (8 * j)) & 0xFFu), N), N, binlen, bin0, bin0_start,
-                                  hist, bins, a.bin_off, lane);
+                    if ((uint32_t)j < nact)
+                        atomicAdd(&hist[(rel_base + rel_of(tile_start + p0 + j)) * (N + 1) +
+                                        min((uint32_t)__popc((packed >> (8 * j)) & 0xFFu), N)], 1u);
             }
             // 1-in-100 rows: at most one of 4 consecutive positions is a multiple of 100
             if (nact) {
@@ -651,7 +670,7 @@ __global__ __launch_bounds__(EPI_THREADS) void k_epilogue(uint32_t N, const Anch
                 const uint32_t first = r100 * 100u;
                 if (first < pos0 + nact) out100[a.out100_off + r100] = (uint8_t)(packed >> (8 * (first - pos0)));
             }
-        } else if (MODE == 1 && binlen >= (uint32_t)PROBE_TILE) {
+        } else if (MODE == 1 && windowed) {
             // ---- wide path (N <= 64): rows as one or two 32-bit words ----
             next_valid = false;
             uint32_t w0[PT], w1[PT];
@@ -689,8 +708,7 @@ __global__ __launch_bounds__(EPI_THREADS) void k_epilogue(uint32_t N, const Anch
             for (int j = 0; j < 4; ++j) {
                 if ((uint32_t)j < nact) {
                     const uint32_t pcj = min((uint32_t)(__popc(w0[j]) + __popc(w1[j])), N);
-                    const uint32_t rel = (tile_start + p0 + j - bin0_start) >= binlen ? 1u : 0u;
-                    atomicAdd(&hist[rel * (N + 1) + pcj], 1u);
+                    atomicAdd(&hist[(rel_base + rel_of(tile_start + p0 + j)) * (N + 1) + pcj], 1u);
                 }
             }
             if (nact) {  // 1-in-100 rows: at most one of 4 consecutive positions is a multiple of 100
@@ -736,7 +754,7 @@ __global__ __launch_bounds__(EPI_THREADS) void k_epilogue(uint32_t N, const Anch
                     }
                     if (want_cs) colsum_word(wv, d, N, cs, lane);
                 }
-                hist_position(active, pos, popc, N, binlen, bin0, bin0_start, hist, bins, a.bin_off, lane);
+                hist_position(active, pos, popc, N, binlen, bin0, bin0_start, rel_base, hist, bins, a.bin_off, lane);
             }
         }
     }
@@ -875,7 +893,7 @@ hipError_t launch_rows_epilogue(hipStream_t st, uint32_t ngenomes, const AnchorD
                                 uint32_t ntiles, const uint8_t *out1, uint8_t *out100, uint32_t *bins,
                                 unsigned long long *colsums, uint32_t flags) {
     if (ntiles == 0) return hipSuccess;
-    size_t lds = (((2 * (ngenomes + 1) + 3) & ~3u) + ((ngenomes + 3) & ~3u)) * 4 + 16;
+    size_t lds = (((EPI_MAXB * (ngenomes + 1) + 3) & ~3u) + ((ngenomes + 3) & ~3u)) * 4 + 16;
     // contiguous tile ranges per workgroup: enough workgroups to fill every CU, but no fewer than
     // PG_EPI_MIN_TILES tiles each so that the end-of-range reductions stay amortised
     const uint32_t maxg = 256u * (2048u / EPI_THREADS);
