@@ -100,6 +100,9 @@ def main():
     ap.add_argument("--keys-per-bucket", type=float, default=2.0)
     ap.add_argument("--minimizer", type=int, default=-1, help="pin the table's minimizer length (tuning; default: library's choice)")
     ap.add_argument("--no-colsums", action="store_true")
+    ap.add_argument("--per-genome-launches", action="store_true",
+                    help="one launch per anchor genome instead of one co-scheduled launch over all of them")
+    ap.add_argument("--piece-tiles", type=int, default=0, help="co-scheduling granularity in 512-position tiles (0: library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-mb", type=float, default=10.0)
     args = ap.parse_args()
@@ -150,46 +153,62 @@ def main():
     torch.cuda.synchronize()
     st = tbl.stats()
 
-    results = [engine.AnchorResult(tbl, seqsets[g], colsums=not args.no_colsums) for g in range(G)]
     pos_per_genome = [seqsets[g].total_kmers(k) for g in range(G)]
     pos_per_step = sum(pos_per_genome)
+    C = args.contigs
 
-    def step():
-        for r in results:
-            r.run()
+    def make_results(per_genome):
+        """per_genome: one result (= one k_probe launch) per anchor genome, the statistics pass of
+        genome g overlapping the probes of genome g+1.  Default: ONE result over all G genomes,
+        tiles co-scheduled so that homologous regions share their table lines in L2
+        (pg_result_coschedule) — the reference anchors its FASTAs in parallel threads too
+        (cpp/anchor.cpp:217-223)."""
+        if per_genome:
+            return [engine.AnchorResult(tbl, seqsets[g], colsums=not args.no_colsums) for g in range(G)], None
+        merged = engine.SeqSet.concat(ctx, seqsets)
+        r = engine.AnchorResult(tbl, merged, colsums=not args.no_colsums)
+        r.coschedule(np.repeat(np.arange(G), C), args.piece_tiles)
+        return [r], merged
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    # per-launch kernel durations come from HIP events recorded by the library on the stream
-    # the kernels run on (pg_result_timing); they are read back after the timed region
-    probe_ms, epi_ms = [], []
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        for r in results:
-            r.run()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    for r in results:  # events of the last timed step (the library re-records them at every launch)
-        pm, em = r.timing()
-        probe_ms.append(pm)
-        epi_ms.append(em)
+    def timed(results, steps, warmup):
+        for _ in range(warmup):
+            for r in results:
+                r.run()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            for r in results:
+                r.run()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt
+
+    results, merged = make_results(args.per_genome_launches)
+    elapsed = timed(results, args.steps, args.warmup)
+    # per-launch kernel durations come from HIP events recorded by the library on the stream the
+    # kernels run on (pg_result_timing): events of the last timed step, read after the timed region
+    probe_ms, epi_ms = zip(*[r.timing() for r in results])
     avg_launch_s = float(np.mean(probe_ms)) / 1e3       # dominant kernel: k_probe
     avg_epi_s = float(np.mean(epi_ms)) / 1e3
+    pos_per_launch = pos_per_step / len(results)
+
+    def genome_rows(g, n):  # first n rows of genome g's first contig
+        r, ci = (results[g], 0) if args.per_genome_launches else (results[0], g * C)
+        return r.download(ci)[0][:n]
 
     # ---- invariants at full size (cheap): anchor g contains all of its own k-mers ----
     if not args.no_colsums:
-        cs = results[0].colsums()
+        cs = results[0].colsums() if args.per_genome_launches else results[0].contig_colsums(0, C).sum(axis=0)
         assert int(cs[0]) == pos_per_genome[0], "anchor genome 0 must contain every one of its k-mers"
 
     # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process;
@@ -200,14 +219,14 @@ def main():
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
             tj = json.load(f)
-        if abs(tj["positions_per_launch"] - float(np.mean(pos_per_genome))) < 1 and k == 21 and G == 8:
+        if abs(tj["positions_per_launch"] - pos_per_launch) < 1 and k == 21 and G == 8:
             traffic = tj["hbm_bytes_per_launch"]
     except (OSError, KeyError, ValueError):
         pass
     nbytes = (G + 7) // 8
     P = (G + 63) // 64  # table probes per position in this design (one wide-mask sub-table per 64 genomes)
     B = 0.25 + 64.0 * P + 1.01 * nbytes
-    per_launch_bytes = float(np.mean(pos_per_genome)) * B
+    per_launch_bytes = pos_per_launch * B
     achieved = per_launch_bytes / avg_launch_s
     value = world * pos_per_step * args.steps / elapsed
 
@@ -232,6 +251,9 @@ def main():
             "table_keys": st["nkeys"], "table_bytes": st["bytes"], "keys_per_128B_line": args.keys_per_bucket,
             "table_build_s": build_s, "probes_per_position": P, "nbytes": nbytes,
             "colsums": not args.no_colsums,
+            "launches_per_step": len(results),
+            "schedule": "one launch per anchor genome" if args.per_genome_launches else
+                        "one launch over all anchor genomes, tiles co-scheduled (homologous regions side by side)",
             "parallelism": f"contig-sharded x{world}, replicated table, no collective",
         },
         "roofline": {
@@ -242,11 +264,19 @@ def main():
             "avg_launch_ms": avg_launch_s * 1e3,
             "epilogue_kernel_ms": avg_epi_s * 1e3,
             "whole_run_frac": (value / world) * B / HBM_PEAK,
-            "hbm_read_frac": (float(np.mean(pos_per_genome)) * (0.25 + 64.0 * P) / avg_launch_s) / HBM_PEAK,
+            "hbm_read_frac": (pos_per_launch * (0.25 + 64.0 * P) / avg_launch_s) / HBM_PEAK,
             "traffic": traffic,
             "algorithmic_bytes_per_launch": per_launch_bytes,
         },
     }
+
+    if world == 1 and not args.per_genome_launches:
+        # for comparison only (outside the timed region): the same work as one launch per genome
+        alt, _ = make_results(True)
+        dt = timed(alt, 3, 1)
+        out["config"]["per_genome_launches_value"] = pos_per_step * 3 / dt
+        for r in alt:
+            r.close()
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         nthreads = min(G, engine.usable_cpus())
@@ -256,7 +286,7 @@ def main():
         def gpu_rows(t, n):
             g = t % G
             if g not in cache:
-                cache[g] = results[g].download(0)[0]
+                cache[g] = genome_rows(g, n)
             return cache[g][:n]
 
         v, dt, npos, ok = cpu_baseline(tbl, genomes, k, G, sample, nthreads, gpu_rows)

@@ -134,6 +134,9 @@ uint64_t pg_seqset_total_kmers(const pg_seqset *s, int k);
  * path differs only in keeping '\r').  The host only locates the header lines; the GPU strips the
  * line breaks and packs.  Text before the first header is ignored.  Synchronises. */
 int pg_seqset_from_fasta(pg_ctx *ctx, const void *text, uint64_t nbytes, pg_seqset **out);
+/* one seqset holding the contigs of all `sets`, in order (packed planes copied device to device):
+ * lets ONE result anchor every anchor genome of a pangenome, see pg_result_coschedule */
+int pg_seqset_concat(pg_ctx *ctx, const pg_seqset *const *sets, uint32_t nsets, pg_seqset **out);
 uint32_t pg_seqset_ncontigs(const pg_seqset *s);
 /* record id ("" unless parsed from FASTA; owned by the seqset) and length in bases of contig idx */
 int pg_seqset_contig(const pg_seqset *s, uint32_t idx, const char **name, uint64_t *len);
@@ -183,6 +186,17 @@ int pg_result_window_stats(pg_result *r, uint32_t idx, int step, uint32_t nwin, 
  * for the run's kernels; may be called from another host thread than the one enqueueing work. */
 int pg_result_write_bgzf(pg_result *r, int step, const char *gz_path, const char *gzi_path, int level,
                          int nthreads);
+/* Launch-order hint for a result over SEVERAL anchor genomes (contig_group[c] = genome of contig
+ * c; NULL restores launch order): the reference anchors its FASTAs in parallel threads
+ * (cpp/anchor.cpp:217-223); here all of them share one kernel launch whose tiles interleave the
+ * genomes piece by piece (piece_tiles tiles, 0 = default), each genome traversed at the same
+ * relative pace, so that homologous regions — which need the same table lines — run side by side
+ * and the lines are fetched from HBM once instead of once per genome.  Results do not depend on
+ * the schedule. */
+int pg_result_coschedule(pg_result *r, const uint32_t *contig_group, uint32_t piece_tiles);
+/* column sums of contigs idx .. idx+ncontigs-1 (ncontigs x ngenomes u64); pg_result_colsums is
+ * their total */
+int pg_result_contig_colsums(pg_result *r, uint32_t idx, uint32_t ncontigs, uint64_t *colsums);
 int pg_result_download(pg_result *r, uint32_t idx, uint8_t *bitmap1, uint8_t *bitmap100,
                        uint32_t *bins);
 /* per-genome column sums over ALL contigs of the seqset (ngenomes u64); synchronises */

@@ -52,6 +52,7 @@ PROTOTYPES = {
     "pg_seqset_load_dev": (C.c_int, [_vp, C.c_uint32, _vp, C.c_uint64]),
     "pg_seqset_total_kmers": (C.c_uint64, [_vp, C.c_int]),
     "pg_seqset_from_fasta": (C.c_int, [_vp, _vp, C.c_uint64, _vpp]),
+    "pg_seqset_concat": (C.c_int, [_vp, _vp, C.c_uint32, _vpp]),
     "pg_seqset_ncontigs": (C.c_uint32, [_vp]),
     "pg_seqset_unpack": (C.c_int, [_vp, C.c_uint32, _vp]),
     "pg_seqset_contig": (C.c_int, [_vp, C.c_uint32, C.POINTER(C.c_char_p), _u64p]),
@@ -61,6 +62,8 @@ PROTOTYPES = {
     "pg_rows_epilogue": (C.c_int, [_vp]),
     "pg_result_timing": (C.c_int, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "pg_result_contig_info": (C.c_int, [_vp, C.c_uint32, _u64p, _u64p, _u32p, _u32p]),
+    "pg_result_coschedule": (C.c_int, [_vp, _vp, C.c_uint32]),
+    "pg_result_contig_colsums": (C.c_int, [_vp, C.c_uint32, C.c_uint32, _vp]),
     "pg_result_window_stats": (C.c_int, [_vp, C.c_uint32, C.c_int, C.c_uint32, _vp, _vp, _vp, _vp]),
     "pg_result_write_bgzf": (C.c_int, [_vp, C.c_int, C.c_char_p, C.c_char_p, C.c_int, C.c_int]),
     "pg_result_download": (C.c_int, [_vp, C.c_uint32, _vp, _vp, _vp]),

@@ -190,7 +190,8 @@ template <int W_C, bool TWO, int ROWMODE, int SLOTS>
 __global__ __launch_bounds__(64) void k_probe(const SubTable st, const uint64_t *__restrict__ seqw,
                                               const uint32_t *__restrict__ nmw, const uint32_t *__restrict__ has_n,
                                               const SeqDesc *__restrict__ sd, const AnchorDesc *__restrict__ ad,
-                                              const uint32_t *__restrict__ tile_contig, uint8_t *__restrict__ out1,
+                                              const uint32_t *__restrict__ tile_contig,
+                                              const uint32_t *__restrict__ sched, uint8_t *__restrict__ out1,
                                               uint32_t nbytes, const RowCols rc) {
     __shared__ uint64_t sw[PROBE_SEQW];
     __shared__ uint32_t nw[PROBE_SEQW];
@@ -207,10 +208,13 @@ __global__ __launch_bounds__(64) void k_probe(const SubTable st, const uint64_t 
     __shared__ uint16_t q_pl[PROBE_QCAP];    // position within the tile
     const int lane = threadIdx.x;
     const int k = (int)st.k;
-    const uint32_t c = tile_contig[blockIdx.x];
+    // tiles run in launch order unless the result carries a schedule (co-scheduled anchor genomes:
+    // homologous regions of all genomes next to each other, so that table lines are shared in L2)
+    const uint32_t tile = sched ? sched[blockIdx.x] : blockIdx.x;
+    const uint32_t c = tile_contig[tile];
     const AnchorDesc a = ad[c];
     const SeqDesc s = sd[c];
-    const uint32_t tile_start = (blockIdx.x - a.tile0) * PROBE_TILE;
+    const uint32_t tile_start = (tile - a.tile0) * PROBE_TILE;
     const uint32_t npos = min((uint32_t)PROBE_TILE, a.nkmers - tile_start);
     const bool hasn = has_n[c] != 0;
 
@@ -547,11 +551,37 @@ __global__ __launch_bounds__(EPI_THREADS) void k_epilogue(uint32_t N, const Anch
         }
     };
 
+    // column sums are kept per contig (colsums[contig][N]): register / LDS accumulators are emptied
+    // whenever the workgroup's tile range moves on to another contig (block-uniform, rare)
+    auto flush_colsums = [&](uint32_t contig) {
+        if constexpr (MODE == 0) {
+#pragma unroll
+            for (int gb = 0; gb < 8; ++gb) {
+                if ((uint32_t)gb < N && cacc[gb]) atomicAdd(&cs[gb], cacc[gb]);
+                cacc[gb] = 0;
+            }
+        }
+        if constexpr (MODE == 1) {
+            if (vrows) vflush();
+            if (brounds) wave_colsums();
+        }
+        __syncthreads();
+        for (uint32_t i = tid; i < N; i += EPI_THREADS) {
+            const uint32_t v = cs[i];
+            if (v) {
+                atomicAdd(&colsums[(uint64_t)contig * N + i], (unsigned long long)v);
+                cs[i] = 0;
+            }
+        }
+        __syncthreads();
+    };
+
     uint4 gq_next = make_uint4(0, 0, 0, 0);  // group path: prefetched rows of the next group
     bool gq_valid = false;
     for (uint32_t tile = t_begin; tile < t_end; ++tile) {
         const uint32_t c = tile_contig[tile];
         if (c != cur_c) {  // block-uniform; consecutive tiles nearly always share their contig
+            if (want_cs && cur_c != ~0u) flush_colsums(cur_c);
             a = ad[c];
             cur_c = c;
         }
@@ -758,23 +788,10 @@ __global__ __launch_bounds__(EPI_THREADS) void k_epilogue(uint32_t N, const Anch
             }
         }
     }
-    if (MODE == 1 && want_cs) {
-        if (vrows) vflush();
-        if (brounds) wave_colsums();
-    }
+    if (want_cs && cur_c != ~0u) flush_colsums(cur_c);
     reduce_hist();
-    if (MODE == 0 && want_cs) {
-#pragma unroll
-        for (int gb = 0; gb < 8; ++gb)
-            if ((uint32_t)gb < N && cacc[gb]) atomicAdd(&cs[gb], cacc[gb]);
-    }
     __syncthreads();
     if (cur_row0 != ~0ull) flush_hist(N, hist, bins, cur_row0, tid);
-    if (want_cs)
-        for (uint32_t i = tid; i < N; i += EPI_THREADS) {
-            const uint32_t v = cs[i];
-            if (v) atomicAdd(&colsums[i], (unsigned long long)v);
-        }
 }
 
 // ---------------------------------------------------------------------------
@@ -824,17 +841,17 @@ __global__ __launch_bounds__(256) void k_window_stats(uint32_t N, const uint8_t 
 template <int W_C, bool TWO, int ROWMODE, int SLOTS>
 static hipError_t probe_t(hipStream_t s, uint32_t ntiles, const SubTable &st, const uint64_t *seqw, const uint32_t *nmw,
                           const uint32_t *has_n, const SeqDesc *sd, const AnchorDesc *ad, const uint32_t *tile_contig,
-                          uint8_t *out1, uint32_t nbytes, const RowCols &rc) {
+                          const uint32_t *sched, uint8_t *out1, uint32_t nbytes, const RowCols &rc) {
     hipLaunchKernelGGL((k_probe<W_C, TWO, ROWMODE, SLOTS>), dim3(ntiles), dim3(64), 0, s, st, seqw, nmw, has_n, sd, ad,
-                       tile_contig, out1, nbytes, rc);
+                       tile_contig, sched, out1, nbytes, rc);
     return hipGetLastError();
 }
 
 template <int W_C>
 static hipError_t probe_w(hipStream_t s, uint32_t ntiles, const SubTable &st, const uint64_t *seqw, const uint32_t *nmw,
                           const uint32_t *has_n, const SeqDesc *sd, const AnchorDesc *ad, const uint32_t *tile_contig,
-                          uint8_t *out1, uint32_t nbytes, const RowCols &rc, int rowmode) {
-#define PG_A s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, out1, nbytes, rc
+                          const uint32_t *sched, uint8_t *out1, uint32_t nbytes, const RowCols &rc, int rowmode) {
+#define PG_A s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, sched, out1, nbytes, rc
     if (st.slots == 16) {
         if (st.W == 2) {
             if (rowmode == 2) return probe_t<W_C, true, 2, 16>(PG_A);
@@ -860,7 +877,7 @@ static int row_mode(uint32_t nbytes, const RowCols &rc) {
 
 hipError_t launch_anchor(hipStream_t s, const TableDesc &T, const uint64_t *seqw, const uint32_t *nmw,
                          const uint32_t *has_n, const SeqDesc *sd, const AnchorDesc *ad, const uint32_t *tile_contig,
-                         uint32_t ntiles, uint8_t *out1, uint64_t out1_bytes) {
+                         const uint32_t *sched, uint32_t ntiles, uint8_t *out1, uint64_t out1_bytes) {
     if (ntiles == 0) return hipSuccess;
     const uint32_t nbytes = (T.ngenomes + 7) / 8;
     hipError_t e = hipSuccess;
@@ -875,13 +892,13 @@ hipError_t launch_anchor(hipStream_t s, const TableDesc &T, const uint64_t *seqw
         const int rm = (T.nsub == 1) ? row_mode(nbytes, rc) : 0;
         const uint32_t w = st.m ? st.k - st.m + 1 : 0;
         switch (w) {  // the kernel's compile-time window must be the one the table was built with
-            case 0: e = probe_w<0>(s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, out1, nbytes, rc, rm); break;
-            case 3: e = probe_w<3>(s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, out1, nbytes, rc, rm); break;
-            case 4: e = probe_w<4>(s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, out1, nbytes, rc, rm); break;
-            case 5: e = probe_w<5>(s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, out1, nbytes, rc, rm); break;
-            case 6: e = probe_w<6>(s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, out1, nbytes, rc, rm); break;
-            case 7: e = probe_w<7>(s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, out1, nbytes, rc, rm); break;
-            case 8: e = probe_w<8>(s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, out1, nbytes, rc, rm); break;
+            case 0: e = probe_w<0>(s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, sched, out1, nbytes, rc, rm); break;
+            case 3: e = probe_w<3>(s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, sched, out1, nbytes, rc, rm); break;
+            case 4: e = probe_w<4>(s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, sched, out1, nbytes, rc, rm); break;
+            case 5: e = probe_w<5>(s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, sched, out1, nbytes, rc, rm); break;
+            case 6: e = probe_w<6>(s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, sched, out1, nbytes, rc, rm); break;
+            case 7: e = probe_w<7>(s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, sched, out1, nbytes, rc, rm); break;
+            case 8: e = probe_w<8>(s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, sched, out1, nbytes, rc, rm); break;
             default: return hipErrorInvalidValue;
         }
         if (e != hipSuccess) return e;

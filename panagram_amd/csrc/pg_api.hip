@@ -89,6 +89,7 @@ struct pg_result {
     std::vector<uint64_t> nrows100;
     AnchorDesc *d_ad;
     uint32_t *d_tile_contig;
+    uint32_t *d_sched = nullptr;  // optional launch order of the tiles (pg_result_coschedule)
     uint32_t ntiles;
     uint8_t *d_out1;
     uint64_t out1_bytes;
@@ -810,6 +811,42 @@ extern "C" int pg_seqset_from_fasta(pg_ctx *ctx, const void *text_, uint64_t nby
     return PG_OK;
 }
 
+// one seqset holding the contigs of all `sets` in order (device-to-device copy of the packed planes)
+extern "C" int pg_seqset_concat(pg_ctx *ctx, const pg_seqset *const *sets, uint32_t nsets, pg_seqset **out) {
+    if (!ctx || !out || (nsets && !sets)) return fail(PG_E_INVALID, "pg_seqset_concat: NULL argument");
+    std::vector<uint64_t> lens;
+    for (uint32_t i = 0; i < nsets; ++i) {
+        if (!sets[i] || sets[i]->ctx != ctx) return fail(PG_E_INVALID, "pg_seqset_concat: seqset %u is NULL or of another context", i);
+        for (auto &d : sets[i]->desc) lens.push_back(d.len);
+    }
+    pg_seqset *s = nullptr;
+    if (int r = pg_seqset_create(ctx, (uint32_t)lens.size(), lens.data(), &s)) return r;
+    hipStream_t st = ctx->stream;
+    hipError_t e = hipSuccess;
+    uint32_t c = 0;
+    for (uint32_t i = 0; i < nsets && e == hipSuccess; ++i) {
+        const pg_seqset *src = sets[i];
+        for (uint32_t j = 0; j < src->n && e == hipSuccess; ++j, ++c) {
+            const uint64_t nw = std::min(src->desc[j].nwords, s->desc[c].nwords);
+            e = hipMemcpyAsync(s->d_seqw + s->desc[c].seq_off, src->d_seqw + src->desc[j].seq_off, nw * 8,
+                               hipMemcpyDeviceToDevice, st);
+            if (e == hipSuccess)
+                e = hipMemcpyAsync(s->d_nmw + s->desc[c].seq_off, src->d_nmw + src->desc[j].seq_off, nw * 4,
+                                   hipMemcpyDeviceToDevice, st);
+            if (e == hipSuccess)
+                e = hipMemcpyAsync(s->d_has_n + c, src->d_has_n + j, 4, hipMemcpyDeviceToDevice, st);
+            s->names.push_back(j < src->names.size() ? src->names[j] : std::string());
+        }
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) {
+        pg_seqset_destroy(s);
+        return fail(PG_E_HIP, "pg_seqset_concat: %s", hipGetErrorString(e));
+    }
+    *out = s;
+    return PG_OK;
+}
+
 extern "C" uint32_t pg_seqset_ncontigs(const pg_seqset *s) { return s ? s->n : 0; }
 
 extern "C" int pg_seqset_contig(const pg_seqset *s, uint32_t idx, const char **name, uint64_t *len) {
@@ -923,7 +960,7 @@ extern "C" int pg_result_create(pg_table *t, const pg_seqset *sq, uint32_t flags
         (e = hipMalloc(reinterpret_cast<void **>(&r->d_out1), std::max<uint64_t>(16, o1))) == hipSuccess &&
         (e = hipMalloc(reinterpret_cast<void **>(&r->d_out100), std::max<uint64_t>(16, o100))) == hipSuccess &&
         (e = hipMalloc(reinterpret_cast<void **>(&r->d_bins), std::max<uint64_t>(1, bins) * (N + 1) * 4)) == hipSuccess &&
-        (e = hipMalloc(reinterpret_cast<void **>(&r->d_colsums), (size_t)N * 8)) == hipSuccess) {
+        (e = hipMalloc(reinterpret_cast<void **>(&r->d_colsums), std::max<size_t>(1, r->ad.size()) * N * 8)) == hipSuccess) {
         if (!r->ad.empty())
             e = hipMemcpyAsync(r->d_ad, r->ad.data(), r->ad.size() * sizeof(AnchorDesc), hipMemcpyHostToDevice, st);
         if (e == hipSuccess && !tile_contig.empty())
@@ -949,6 +986,7 @@ extern "C" int pg_result_destroy(pg_result *r) {
     hipFree(r->d_out100);
     hipFree(r->d_bins);
     hipFree(r->d_colsums);
+    if (r->d_sched) hipFree(r->d_sched);
     for (auto &e : r->ev)
         if (e) hipEventDestroy(e);
     delete r;
@@ -956,11 +994,60 @@ extern "C" int pg_result_destroy(pg_result *r) {
 }
 
 // statistics kernels of a result, on stream `st`
+// ---------------------------------------------------------------------------
+// co-scheduling: the anchor genomes of one pangenome are homologous, so the same table lines are
+// needed at corresponding places of every genome.  Launching the tiles genome by genome fetches each
+// line from HBM once per genome; interleaving the genomes piece by piece (pieces of `piece_tiles`
+// tiles, every genome traversed at the same relative pace) lets the later genomes find the lines in
+// L2 / Infinity Cache.  Only the launch order changes — results are identical for any schedule.
+// ---------------------------------------------------------------------------
+extern "C" int pg_result_coschedule(pg_result *r, const uint32_t *contig_group, uint32_t piece_tiles) {
+    if (!r) return fail(PG_E_INVALID, "result is NULL");
+    if (int e = use_device(r->tbl->ctx)) return e;
+    hipStream_t st = r->tbl->ctx->stream;
+    HIP_TRY(hipStreamSynchronize(st));
+    if (r->d_sched) {
+        hipFree(r->d_sched);
+        r->d_sched = nullptr;
+    }
+    if (!contig_group || r->ntiles == 0) return PG_OK;  // NULL: back to launch order
+    if (piece_tiles == 0) piece_tiles = 64;
+    const size_t nc = r->ad.size();
+    uint32_t ngroups = 0;
+    for (size_t c = 0; c < nc; ++c) ngroups = std::max(ngroups, contig_group[c] + 1);
+    std::vector<std::vector<uint32_t>> tiles(ngroups);  // every group's tiles, contig after contig
+    for (size_t c = 0; c < nc; ++c) {
+        const uint32_t nt = (uint32_t)(((uint64_t)r->ad[c].nkmers + PROBE_TILE - 1) / PROBE_TILE);
+        for (uint32_t i = 0; i < nt; ++i) tiles[contig_group[c]].push_back(r->ad[c].tile0 + i);
+    }
+    struct Piece {
+        double at;
+        uint32_t g, first;
+    };
+    std::vector<Piece> pieces;
+    for (uint32_t g = 0; g < ngroups; ++g) {
+        const size_t np = (tiles[g].size() + piece_tiles - 1) / piece_tiles;
+        for (size_t i = 0; i < np; ++i) pieces.push_back({(double)i / (double)np, g, (uint32_t)(i * piece_tiles)});
+    }
+    std::stable_sort(pieces.begin(), pieces.end(), [](const Piece &x, const Piece &y) { return x.at < y.at; });
+    std::vector<uint32_t> sched;
+    sched.reserve(r->ntiles);
+    for (const Piece &p : pieces) {
+        const size_t end = std::min<size_t>(tiles[p.g].size(), (size_t)p.first + piece_tiles);
+        for (size_t i = p.first; i < end; ++i) sched.push_back(tiles[p.g][i]);
+    }
+    if (sched.size() != r->ntiles) return fail(PG_E_INVALID, "internal: schedule does not cover the tiles");
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&r->d_sched), (size_t)r->ntiles * 4));
+    HIP_TRY(hipMemcpyAsync(r->d_sched, sched.data(), (size_t)r->ntiles * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return PG_OK;
+}
+
 static int enqueue_epilogue(pg_result *r, hipStream_t st) {
     pg_table *t = r->tbl;
     const uint32_t N = t->ngenomes;
     HIP_TRY(hipMemsetAsync(r->d_bins, 0, std::max<uint64_t>(1, r->total_bins) * (N + 1) * 4, st));
-    HIP_TRY(hipMemsetAsync(r->d_colsums, 0, (size_t)N * 8, st));
+    HIP_TRY(hipMemsetAsync(r->d_colsums, 0, std::max<size_t>(1, r->ad.size()) * N * 8, st));
     HIP_TRY(launch_rows_epilogue(st, N, r->d_ad, r->d_tile_contig, r->ntiles, r->d_out1, r->d_out100, r->d_bins,
                                  r->d_colsums, r->flags));
     return PG_OK;
@@ -983,7 +1070,7 @@ extern "C" int pg_anchor_run(pg_result *r) {
     TableDesc T = make_desc(t);
     HIP_TRY(hipEventRecord(r->ev[0], st));
     HIP_TRY(launch_anchor(st, T, r->seqs->d_seqw, r->seqs->d_nmw, r->seqs->d_has_n, r->seqs->d_desc, r->d_ad,
-                          r->d_tile_contig, r->ntiles, r->d_out1, r->out1_bytes));
+                          r->d_tile_contig, r->d_sched, r->ntiles, r->d_out1, r->out1_bytes));
     HIP_TRY(hipEventRecord(r->ev[1], st));
     r->ev_ok = true;
     r->ev_epi = false;
@@ -1182,7 +1269,28 @@ extern "C" int pg_result_colsums(pg_result *r, uint64_t *colsums) {
     if (int e = use_device(r->tbl->ctx)) return e;
     if (int e = join_result(r)) return e;
     hipStream_t st = r->tbl->ctx->stream;
-    HIP_TRY(hipMemcpyAsync(colsums, r->d_colsums, (size_t)r->tbl->ngenomes * 8, hipMemcpyDeviceToHost, st));
+    const size_t N = r->tbl->ngenomes, nc = r->ad.size();
+    std::vector<uint64_t> all(std::max<size_t>(1, nc) * N, 0);  // the device keeps them per contig
+    if (nc) {
+        HIP_TRY(hipMemcpyAsync(all.data(), r->d_colsums, nc * N * 8, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    for (size_t g = 0; g < N; ++g) colsums[g] = 0;
+    for (size_t c = 0; c < nc; ++c)
+        for (size_t g = 0; g < N; ++g) colsums[g] += all[c * N + g];
+    return PG_OK;
+}
+
+extern "C" int pg_result_contig_colsums(pg_result *r, uint32_t idx, uint32_t ncontigs, uint64_t *colsums) {
+    if (!r || !colsums) return fail(PG_E_INVALID, "pg_result_contig_colsums: NULL argument");
+    if (!(r->flags & PG_ANCHOR_COLSUMS)) return fail(PG_E_INVALID, "result was created without PG_ANCHOR_COLSUMS");
+    if ((uint64_t)idx + ncontigs > r->ad.size()) return fail(PG_E_INVALID, "contigs %u..%u out of range", idx, idx + ncontigs);
+    if (ncontigs == 0) return PG_OK;
+    if (int e = use_device(r->tbl->ctx)) return e;
+    if (int e = join_result(r)) return e;
+    hipStream_t st = r->tbl->ctx->stream;
+    const size_t N = r->tbl->ngenomes;
+    HIP_TRY(hipMemcpyAsync(colsums, r->d_colsums + (size_t)idx * N, (size_t)ncontigs * N * 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     return PG_OK;
 }

@@ -78,7 +78,7 @@ hipError_t launch_counters(hipStream_t st, const SubTable &t, int w, int k, cons
                            const uint32_t *nmw, const uint32_t *has_n, uint64_t nkmers, uint32_t *out);
 hipError_t launch_anchor(hipStream_t st, const TableDesc &T, const uint64_t *seqw, const uint32_t *nmw,
                          const uint32_t *has_n, const SeqDesc *sd, const AnchorDesc *ad,
-                         const uint32_t *tile_contig, uint32_t ntiles, uint8_t *out1, uint64_t out1_bytes);
+                         const uint32_t *tile_contig, const uint32_t *sched, uint32_t ntiles, uint8_t *out1, uint64_t out1_bytes);
 hipError_t launch_window_stats(hipStream_t st, uint32_t ngenomes, const uint8_t *rows, uint64_t nrows, uint32_t nwin,
                                uint32_t pieces, const uint64_t *starts, const uint64_t *ends, unsigned long long *hist,
                                unsigned long long *cs);

@@ -124,6 +124,20 @@ class SeqSet:
         ss.names, ss.lens = names, lens
         return ss
 
+    @classmethod
+    def concat(cls, ctx: Context, sets: Sequence["SeqSet"]) -> "SeqSet":
+        """One seqset with the contigs of all ``sets`` in order (device copy), for a co-scheduled
+        result over several anchor genomes."""
+        ss = cls.__new__(cls)
+        ss.ctx, ss._lib = ctx, ctx._lib
+        arr = (C.c_void_p * len(sets))(*[x._h for x in sets])
+        h = C.c_void_p()
+        check(ss._lib.pg_seqset_concat(ctx._h, arr, len(sets), C.byref(h)))
+        ss._h = h
+        ss.names = [n for x in sets for n in x.names]
+        ss.lens = np.concatenate([x.lens for x in sets]) if sets else np.zeros(0, np.uint64)
+        return ss
+
     def load_host(self, idx: int, seq) -> None:
         v = _bytes_view(seq)
         check(self._lib.pg_seqset_load_host(self._h, idx, _ptr(v), len(v)))
@@ -258,6 +272,23 @@ class AnchorResult:
         self.flags = (PG_ANCHOR_COLSUMS if colsums else 0) | (PG_ANCHOR_ROWS_ONLY if rows_only else 0)
         check(self._lib.pg_result_create(table._h, seqs._h, self.flags, C.byref(h)))
         self._h = h
+
+    def coschedule(self, contig_group, piece_tiles: int = 0) -> None:
+        """Interleave the tiles of several anchor genomes (``contig_group[c]`` = genome of contig c;
+        None: launch order) so that homologous regions share their table lines in L2."""
+        if contig_group is None:
+            check(self._lib.pg_result_coschedule(self._h, None, 0))
+            return
+        grp = np.ascontiguousarray(contig_group, np.uint32)
+        if len(grp) != len(self.seqs.lens):
+            raise ValueError("contig_group needs one entry per contig")
+        check(self._lib.pg_result_coschedule(self._h, _ptr(grp), piece_tiles))
+
+    def contig_colsums(self, idx: int = 0, ncontigs: Optional[int] = None) -> np.ndarray:
+        n = len(self.seqs.lens) - idx if ncontigs is None else ncontigs
+        out = np.zeros((n, self.table.ngenomes), np.uint64)
+        check(self._lib.pg_result_contig_colsums(self._h, idx, n, _ptr(out)))
+        return out
 
     def run(self) -> None:
         """Enqueue the anchor kernels (asynchronous)."""

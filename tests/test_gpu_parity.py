@@ -436,3 +436,52 @@ def test_repeat_family_heavy_minimizer_groups(ctx, k):
         got = tbl.counters_for_read(0, seq[:5000])
         assert np.array_equal(got, po.counters_for_read(dbs[0], seq[:5000], k))
     tbl.close()
+
+
+@pytest.mark.parametrize("n,k,piece", [(5, 21, 3), (40, 31, 0), (9, 21, 1)])
+def test_coscheduled_result_over_all_anchor_genomes(ctx, n, k, piece):
+    """one result over the concatenated contigs of every anchor genome, tiles interleaved genome by
+    genome (pg_result_coschedule): rows, bitmap.100, bins and per-genome column sums equal the
+    genome-by-genome results and the oracle, for any grouping"""
+    from panagram_amd import engine
+    lens = [40000, 2600, 700, 10]
+    gen = po.synth_genomes(n, lens, 0.02, 1000 + n)
+    genomes = [[po.codes_to_ascii(c) for c in g] for g in gen]
+    dbs = po.build_bitvec_dbs(genomes, k)
+    tbl = engine.PanTable(ctx, k, n)
+    sets = []
+    for g in range(n):
+        ss = engine.SeqSet.from_host(ctx, genomes[g])
+        tbl.insert_seqset(g, ss)
+        sets.append(ss)
+    anchors = [0, 2, n - 1]
+    per = {}
+    for g in anchors:
+        r = engine.AnchorResult(tbl, sets[g])
+        r.run()
+        per[g] = ([r.download(ci) for ci in range(len(lens))], r.colsums())
+        r.close()
+    merged = engine.SeqSet.concat(ctx, [sets[g] for g in anchors])
+    assert [int(x) for x in merged.lens] == lens * len(anchors)
+    res = engine.AnchorResult(tbl, merged)
+    groups = np.repeat(np.arange(len(anchors)), len(lens))
+    for grp in (groups, None, (groups + 1) % 2, np.zeros(len(groups), int)):
+        res.coschedule(grp, piece)
+        res.run()
+        for gi, g in enumerate(anchors):
+            for ci in range(len(lens)):
+                got = res.download(gi * len(lens) + ci)
+                want = per[g][0][ci]
+                for x, y in zip(got[:3], want[:3]):
+                    assert np.array_equal(x, y)
+            ccs = res.contig_colsums(gi * len(lens), len(lens))
+            assert np.array_equal(ccs.sum(axis=0), per[g][1])
+        assert np.array_equal(res.colsums(), sum(per[g][1] for g in anchors))
+    o = po.anchor_contig(dbs, genomes[2][0], k, n)
+    assert np.array_equal(res.download(len(lens))[0], o[0]) and np.array_equal(per[2][1].astype(np.int64), sum(
+        po.anchor_contig(dbs, s, k, n)[4] for s in genomes[2] if len(s) >= k))
+    res.close()
+    merged.close()
+    for ss in sets:
+        ss.close()
+    tbl.close()
