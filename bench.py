@@ -103,6 +103,7 @@ def main():
     ap.add_argument("--per-genome-launches", action="store_true",
                     help="one launch per anchor genome instead of one co-scheduled launch over all of them")
     ap.add_argument("--piece-tiles", type=int, default=0, help="co-scheduling granularity in 512-position tiles (0: library default)")
+    ap.add_argument("--no-compare", action="store_true", help="skip the untimed one-launch-per-genome comparison run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-mb", type=float, default=10.0)
     args = ap.parse_args()
@@ -270,7 +271,7 @@ def main():
         },
     }
 
-    if world == 1 and not args.per_genome_launches:
+    if world == 1 and not args.per_genome_launches and not args.no_compare:
         # for comparison only (outside the timed region): the same work as one launch per genome
         alt, _ = make_results(True)
         dt = timed(alt, 3, 1)
