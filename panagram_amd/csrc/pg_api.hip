@@ -102,6 +102,9 @@ struct pg_result {
     bool ev_ok, ev_epi;
 };
 
+#ifndef PG_WIDE_FROM
+#define PG_WIDE_FROM 32  // more genomes than this: 256-byte lines of 16 slots (measured: better at d=1 %, worse at d=0.5 %)
+#endif
 static constexpr uint32_t MAX_PROBE = 512;  // lines an insert may walk before the table is grown
 static constexpr double GROW_AT = 0.55;     // grow when keys > GROW_AT * slots
 static constexpr double TARGET_LOAD = 0.375; // load right after growing (3 keys per 8-slot line)
@@ -235,7 +238,7 @@ extern "C" int pg_table_create(pg_ctx *ctx, int k, int ngenomes, uint64_t expect
         uint64_t want = expected_keys ? expected_keys : (1ull << 18);
         // 256-byte lines where a minimizer group is expected to exceed 8 keys: many genomes'
         // variants per locus
-        const uint32_t slots = (ngenomes > 32) ? 16u : 8u;
+        const uint32_t slots = (ngenomes > PG_WIDE_FROM) ? 16u : 8u;
         uint64_t nb = (uint64_t)((double)want / (TARGET_LOAD * slots)) + 1;
         SubHost sh;
         sh.count = 0;
