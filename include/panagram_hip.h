@@ -55,6 +55,10 @@ const char *pg_version(void);
 /* One context per GPU / per process rank.  Fails with PG_E_HIP when no
  * gfx950-class device is visible: there is NO CPU fallback in this library. */
 int pg_ctx_create(int device_id, pg_ctx **out);
+/* *_destroy calls may come in any order (garbage-collected callers cannot promise one): a handle
+ * with live dependants — a context with tables / seqsets, a table or seqset with results — is
+ * retired at once for the caller but freed only when its last dependant is destroyed.  Destroy
+ * each handle exactly once and do not use it afterwards. */
 int pg_ctx_destroy(pg_ctx *ctx);
 /* adopt an external hipStream_t (e.g. torch.cuda.current_stream().cuda_stream; NULL is
  * HIP's legacy default stream, which is what torch's default stream is); use_own != 0

@@ -5,6 +5,7 @@
 #include "pg_kernels.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -51,6 +52,11 @@ struct pg_ctx {
     hipStream_t own_stream;
     hipStream_t stream;
     hipStream_t aux_stream;  // statistics kernels run here, event-ordered behind the probe kernels
+    // Handles may be destroyed in any order (a garbage collector frees a dropped object graph in no
+    // particular order): an object with live dependants is only marked dead and goes when the last
+    // dependant does.
+    std::atomic<int> refs{0};
+    bool dead = false;
 };
 
 struct SubHost {
@@ -65,6 +71,8 @@ struct pg_table {
     bool m_pinned = false;  // set by pg_table_set_minimizer: re-hashing keeps m
     std::vector<SubHost> subs;
     unsigned long long *d_counters;  // [0] newly claimed, [1] overflow flag
+    std::atomic<int> refs{0};        // results on this table
+    bool dead = false;
 };
 
 struct pg_seqset {
@@ -79,6 +87,8 @@ struct pg_seqset {
     void *d_stage;
     size_t stage_cap;
     std::vector<std::string> names;  // record ids when the seqset was parsed from FASTA text
+    std::atomic<int> refs{0};        // results on these sequences
+    bool dead = false;
 };
 
 struct pg_result {
@@ -145,14 +155,22 @@ extern "C" int pg_ctx_create(int device_id, pg_ctx **out) {
     return PG_OK;
 }
 
-extern "C" int pg_ctx_destroy(pg_ctx *c) {
-    if (!c) return PG_OK;
+static void ctx_free(pg_ctx *c) {
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     hipStreamSynchronize(c->aux_stream);
     hipStreamDestroy(c->aux_stream);
     hipStreamDestroy(c->own_stream);
     delete c;
+}
+static void ctx_release(pg_ctx *c) {
+    if (--c->refs == 0 && c->dead) ctx_free(c);
+}
+
+extern "C" int pg_ctx_destroy(pg_ctx *c) {
+    if (!c || c->dead) return PG_OK;
+    c->dead = true;
+    if (c->refs == 0) ctx_free(c);
     return PG_OK;
 }
 
@@ -222,6 +240,7 @@ extern "C" int pg_table_create(pg_ctx *ctx, int k, int ngenomes, uint64_t expect
     if (int r = use_device(ctx)) return r;
     pg_table *t = new pg_table();
     t->ctx = ctx;
+    ++ctx->refs;
     t->k = k;
     t->ngenomes = ngenomes;
     t->ndbs = ndbs;
@@ -230,6 +249,7 @@ extern "C" int pg_table_create(pg_ctx *ctx, int k, int ngenomes, uint64_t expect
     hipError_t e = hipMalloc(reinterpret_cast<void **>(&t->d_counters), 2 * sizeof(unsigned long long));
     if (e != hipSuccess) {
         delete t;
+        --ctx->refs;
         return fail(PG_E_HIP, "hipMalloc failed: %s", hipGetErrorString(e));
     }
     hipMemsetAsync(t->d_counters, 0, 2 * sizeof(unsigned long long), ctx->stream);
@@ -253,13 +273,23 @@ extern "C" int pg_table_create(pg_ctx *ctx, int k, int ngenomes, uint64_t expect
     return PG_OK;
 }
 
-extern "C" int pg_table_destroy(pg_table *t) {
-    if (!t) return PG_OK;
+static void table_free(pg_table *t) {
     hipSetDevice(t->ctx->device);
     hipStreamSynchronize(t->ctx->stream);
     for (auto &s : t->subs) hipFree(s.d.buckets);
     if (t->d_counters) hipFree(t->d_counters);
+    pg_ctx *c = t->ctx;
     delete t;
+    ctx_release(c);
+}
+static void table_release(pg_table *t) {
+    if (--t->refs == 0 && t->dead) table_free(t);
+}
+
+extern "C" int pg_table_destroy(pg_table *t) {
+    if (!t || t->dead) return PG_OK;
+    t->dead = true;
+    if (t->refs == 0) table_free(t);
     return PG_OK;
 }
 
@@ -614,6 +644,7 @@ extern "C" int pg_seqset_create(pg_ctx *ctx, uint32_t ncontigs, const uint64_t *
     if (int r = use_device(ctx)) return r;
     pg_seqset *s = new pg_seqset();
     s->ctx = ctx;
+    ++ctx->refs;
     s->n = ncontigs;
     s->d_seqw = nullptr;
     s->d_nmw = nullptr;
@@ -653,8 +684,7 @@ extern "C" int pg_seqset_create(pg_ctx *ctx, uint32_t ncontigs, const uint64_t *
     return PG_OK;
 }
 
-extern "C" int pg_seqset_destroy(pg_seqset *s) {
-    if (!s) return PG_OK;
+static void seqset_free(pg_seqset *s) {
     hipSetDevice(s->ctx->device);
     hipStreamSynchronize(s->ctx->stream);
     hipFree(s->d_seqw);
@@ -662,7 +692,18 @@ extern "C" int pg_seqset_destroy(pg_seqset *s) {
     hipFree(s->d_has_n);
     hipFree(s->d_desc);
     if (s->d_stage) hipFree(s->d_stage);
+    pg_ctx *c = s->ctx;
     delete s;
+    ctx_release(c);
+}
+static void seqset_release(pg_seqset *s) {
+    if (--s->refs == 0 && s->dead) seqset_free(s);
+}
+
+extern "C" int pg_seqset_destroy(pg_seqset *s) {
+    if (!s || s->dead) return PG_OK;
+    s->dead = true;
+    if (s->refs == 0) seqset_free(s);
     return PG_OK;
 }
 
@@ -908,6 +949,8 @@ extern "C" int pg_result_create(pg_table *t, const pg_seqset *sq, uint32_t flags
     pg_result *r = new pg_result();
     r->tbl = t;
     r->seqs = sq;
+    ++t->refs;
+    ++const_cast<pg_seqset *>(sq)->refs;
     r->flags = flags;
     r->d_ad = nullptr;
     r->d_tile_contig = nullptr;
@@ -922,7 +965,7 @@ extern "C" int pg_result_create(pg_table *t, const pg_seqset *sq, uint32_t flags
         const uint64_t len = sq->desc[c].len;
         const uint64_t nk = len >= (uint64_t)t->k ? len - t->k + 1 : 0;
         if (nk > 0xFFFFFFF0ull) {
-            delete r;
+            pg_result_destroy(r);
             return fail(PG_E_INVALID, "contig %u has %llu k-mers; contigs must stay below 2^32 (as in KMC)", c, (unsigned long long)nk);
         }
         AnchorDesc a;
@@ -949,7 +992,7 @@ extern "C" int pg_result_create(pg_table *t, const pg_seqset *sq, uint32_t flags
         r->ad.push_back(a);
     }
     if (tiles > 0x7FFFFFFFull) {
-        delete r;
+        pg_result_destroy(r);
         return fail(PG_E_INVALID, "too many tiles in one launch");
     }
     r->ntiles = (uint32_t)tiles;
@@ -992,7 +1035,11 @@ extern "C" int pg_result_destroy(pg_result *r) {
     if (r->d_sched) hipFree(r->d_sched);
     for (auto &e : r->ev)
         if (e) hipEventDestroy(e);
+    pg_table *t = r->tbl;
+    pg_seqset *sq = const_cast<pg_seqset *>(r->seqs);
     delete r;
+    table_release(t);
+    seqset_release(sq);
     return PG_OK;
 }
 

@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import weakref
 from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -29,6 +30,25 @@ def usable_cpus() -> int:
     return max(1, n)
 
 
+class _Owner:
+    """Handles are destroyed children first (the C-ABI's rule): a parent remembers its live
+    children weakly and closes them before itself, so that garbage collection — which finalises
+    a dropped object graph in no particular order — can never free a table under a result."""
+
+    def _adopt(self, child) -> None:
+        if not hasattr(self, "_children"):
+            self._children = []
+        self._children = [w for w in self._children if w() is not None]
+        self._children.append(weakref.ref(child))
+
+    def _close_children(self) -> None:
+        for w in getattr(self, "_children", []):
+            c = w()
+            if c is not None:
+                c.close()
+        self._children = []
+
+
 def _ptr(a: Optional[np.ndarray]):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
@@ -42,7 +62,7 @@ def _bytes_view(seq) -> np.ndarray:
     return np.frombuffer(seq, dtype=np.uint8)
 
 
-class Context:
+class Context(_Owner):
     """One per GPU / per rank."""
 
     def __init__(self, device: int = 0):
@@ -65,6 +85,7 @@ class Context:
 
     def close(self) -> None:
         if self._h:
+            self._close_children()
             self._lib.pg_ctx_destroy(self._h)
             self._h = None
 
@@ -75,7 +96,7 @@ class Context:
             pass
 
 
-class SeqSet:
+class SeqSet(_Owner):
     """The contigs of one FASTA, 2-bit packed in HBM."""
 
     def __init__(self, ctx: Context, lens: Sequence[int]):
@@ -86,6 +107,7 @@ class SeqSet:
         h = C.c_void_p()
         check(self._lib.pg_seqset_create(ctx._h, len(self.lens), _ptr(self.lens), C.byref(h)))
         self._h = h
+        ctx._adopt(self)
 
     @classmethod
     def from_host(cls, ctx: Context, seqs: Sequence) -> "SeqSet":
@@ -114,6 +136,7 @@ class SeqSet:
         h = C.c_void_p()
         check(ss._lib.pg_seqset_from_fasta(ctx._h, _ptr(text), len(text), C.byref(h)))
         ss._h = h
+        ctx._adopt(ss)
         n = int(ss._lib.pg_seqset_ncontigs(h))
         names, lens = [], np.zeros(n, np.uint64)
         for i in range(n):
@@ -134,6 +157,7 @@ class SeqSet:
         h = C.c_void_p()
         check(ss._lib.pg_seqset_concat(ctx._h, arr, len(sets), C.byref(h)))
         ss._h = h
+        ctx._adopt(ss)
         ss.names = [n for x in sets for n in x.names]
         ss.lens = np.concatenate([x.lens for x in sets]) if sets else np.zeros(0, np.uint64)
         return ss
@@ -156,6 +180,7 @@ class SeqSet:
 
     def close(self) -> None:
         if self._h:
+            self._close_children()
             self._lib.pg_seqset_destroy(self._h)
             self._h = None
 
@@ -166,7 +191,7 @@ class SeqSet:
             pass
 
 
-class PanTable:
+class PanTable(_Owner):
     """GPU-resident k-mer -> genome-mask table (replaces kmc/bitvec{i})."""
 
     def __init__(self, ctx: Context, k: int, ngenomes: int, expected_keys: int = 0):
@@ -178,6 +203,7 @@ class PanTable:
         h = C.c_void_p()
         check(self._lib.pg_table_create(ctx._h, k, ngenomes, expected_keys, C.byref(h)))
         self._h = h
+        ctx._adopt(self)
 
     def insert_seqset(self, genome_idx: int, seqs: SeqSet, min_count: int = 1) -> None:
         """OR genome ``genome_idx``'s bit into every canonical k-mer of ``seqs`` that occurs at least
@@ -252,6 +278,7 @@ class PanTable:
 
     def close(self) -> None:
         if self._h:
+            self._close_children()
             self._lib.pg_table_destroy(self._h)
             self._h = None
 
@@ -272,6 +299,8 @@ class AnchorResult:
         self.flags = (PG_ANCHOR_COLSUMS if colsums else 0) | (PG_ANCHOR_ROWS_ONLY if rows_only else 0)
         check(self._lib.pg_result_create(table._h, seqs._h, self.flags, C.byref(h)))
         self._h = h
+        table._adopt(self)   # a result dies before its table and before its sequences
+        seqs._adopt(self)
 
     def coschedule(self, contig_group, piece_tiles: int = 0) -> None:
         """Interleave the tiles of several anchor genomes (``contig_group[c]`` = genome of contig c;

@@ -485,3 +485,29 @@ def test_coscheduled_result_over_all_anchor_genomes(ctx, n, k, piece):
     for ss in sets:
         ss.close()
     tbl.close()
+
+
+def test_handles_close_children_first():
+    """dropping a whole object graph (or closing a parent early) must not free a table under a result"""
+    import gc
+    from panagram_amd import engine
+    c = engine.Context(0)
+    t = engine.PanTable(c, 21, 2)
+    s = engine.SeqSet.from_host(c, [b"ACGT" * 50])
+    t.insert_seqset(0, s)
+    r = engine.AnchorResult(t, s)
+    r.run()
+    t.close()              # parent first: the result goes with it
+    assert r._h is None
+    r2 = engine.AnchorResult(engine.PanTable(c, 21, 2), s)
+    c.close()              # closes tables, sequences and their results
+    assert r2._h is None and s._h is None
+    for _ in range(3):     # graphs dropped to the collector in one piece
+        c = engine.Context(0)
+        t = engine.PanTable(c, 21, 2)
+        s = engine.SeqSet.from_host(c, [b"ACGT" * 50])
+        r = engine.AnchorResult(t, s)
+        cyc = [c, t, s, r]
+        cyc.append(cyc)
+        del c, t, s, r, cyc
+        gc.collect()
