@@ -257,14 +257,17 @@ __global__ __launch_bounds__(64) void k_probe(const SubTable st, const uint64_t 
             act[u] = inrange[u];
             if (hasn) act[u] = act[u] && (extract_nmask(nw, pq, k) == 0);
             if (W_C) {
+                // m-mer number b+lane is the LAST m-mer of this lane's own k-mer (the first lanes of a
+                // tile, which have no k-mer, take theirs out of the tile's first k-mer): forward strand
+                // from X, reverse complement from B — no second pass over the sequence words
+                const uint32_t off = (uint32_t)(pl[u] + HALO) - pq;  // m-mer's offset inside the k-mer, 0..HALO
                 if (m <= 16) {
-                    const uint32_t fa = (uint32_t)extract_bases(sw, b + lane) & mm;  // m-mer b+lane, forward
-                    uint32_t fr = __brev(~fa);                                       // ... and its reverse complement
-                    fr = (((fr >> 1) & 0x55555555u) | ((fr & 0x55555555u) << 1)) >> (32 - 2 * m);
+                    const uint32_t fa = (uint32_t)(X >> (2 * off)) & mm;
+                    const uint32_t fr = (uint32_t)(B >> (2 * (HALO - off))) & mm;
                     grp[u] = mz_order(fa < fr ? fa : fr);
                 } else {  // long m-mers (k > 21): same thing in 64 bits
-                    const uint64_t fa = extract_bases(sw, b + lane) & mm64;
-                    const uint64_t fr = pair_reverse64(~fa) >> (64 - 2 * m);
+                    const uint64_t fa = (X >> (2 * off)) & mm64;
+                    const uint64_t fr = (B >> (2 * (HALO - off))) & mm64;
                     grp[u] = mmer_rank(fa < fr ? fa : fr);
                 }
             } else {
