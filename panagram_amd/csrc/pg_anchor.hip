@@ -105,6 +105,19 @@ __device__ __forceinline__ void store_row(uint8_t *row, uint32_t m0, uint32_t m1
     }
 }
 
+// value of lane-1 (lane 0 keeps its own): one DPP move (wave_shr:1) on the VALU instead of a
+// ds_bpermute round trip through the LDS crossbar
+__device__ __forceinline__ uint32_t lane_up1(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+}
+template <int D>
+__device__ __forceinline__ uint32_t lane_up(uint32_t v) {  // value of lane-D for lanes >= D (others: unspecified)
+    uint32_t r = v;
+#pragma unroll
+    for (int i = 0; i < D; ++i) r = lane_up1(r);
+    return r;
+}
+
 // inclusive count of set bits of `mask` at lanes <= this lane
 __device__ __forceinline__ uint32_t lanes_le_count(unsigned long long mask, bool own) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u)) + (own ? 1u : 0u);
@@ -114,9 +127,13 @@ __device__ __forceinline__ uint32_t lanes_le_count(unsigned long long mask, bool
 // like the main batches (neighbouring entries belong to the same group and share their next
 // line); entries that overflow again are compacted in place for the next level.
 template <bool TWO, int ROWMODE, int SLOTS, int MAXRUN>
-__device__ __forceinline__ void drain_queue(const SubTable &st, uint32_t qn, uint64_t *q_key, uint32_t *q_line,
+__device__ __forceinline__ void drain_queue(const SubTable &st, uint32_t qn, const uint64_t *sw, uint32_t *q_line,
                                             uint32_t *q_step, uint16_t *q_pl, uint32_t *lines_w, uint4 *buf,
                                             uint8_t *tile_rows, uint32_t nbytes, const RowCols rc, int lane) {
+    // a queue entry is (position in the tile, next line to try, step of its sequence): the key is
+    // taken from the tile's sequence words again — 10 bytes of LDS per entry instead of 18 let the
+    // kernel run 32 waves per CU instead of 26
+    const int k = (int)st.k;
     constexpr int LDS_LINE_U4 = SLOTS + 1;
     constexpr int BUCKET_BYTES = 16 * SLOTS;
     constexpr int STAGE_ITERS = (MAXRUN * SLOTS + 63) / 64;
@@ -127,7 +144,7 @@ __device__ __forceinline__ void drain_queue(const SubTable &st, uint32_t qn, uin
             // 8 slot loads in flight per line, no staging overhead
             for (uint32_t e = lane; e < qn; e += 64) {
                 uint32_t m0, m1;
-                lane_chase<TWO, SLOTS>(st, q_key[e], (uint32_t)level, q_line[e], q_step[e], m0, m1);
+                lane_chase<TWO, SLOTS>(st, canonical_from_le(extract_bases(sw, q_pl[e]), k), (uint32_t)level, q_line[e], q_step[e], m0, m1);
                 if (m0 | m1) store_row<ROWMODE>(tile_rows + (uint64_t)q_pl[e] * nbytes, m0, m1, rc);
             }
             break;
@@ -137,10 +154,10 @@ __device__ __forceinline__ void drain_queue(const SubTable &st, uint32_t qn, uin
             const uint32_t e = i0 + lane;
             const bool act = e < qn;
             const uint32_t ec = act ? e : qn - 1;
-            const uint64_t key = q_key[ec];
             const uint32_t line = q_line[ec], step = q_step[ec];
             const uint32_t pl = q_pl[ec];
-            const uint32_t prev_line = __shfl_up(line, 1);
+            const uint64_t key = canonical_from_le(extract_bases(sw, pl), k);
+            const uint32_t prev_line = lane_up1(line);
             const bool leader = act && (lane == 0 || line != prev_line);
             const unsigned long long lmask = __ballot(leader);
             const uint32_t rid = lanes_le_count(lmask, leader) - 1;
@@ -174,7 +191,6 @@ __device__ __forceinline__ void drain_queue(const SubTable &st, uint32_t qn, uin
                 const uint32_t slot = kept + lanes_le_count(kmask2, true) - 1;
                 uint32_t nl2 = line, ns2 = step;
                 advance_line(key, (uint32_t)level + 1, st.nbuckets, nl2, ns2);
-                q_key[slot] = key;
                 q_line[slot] = nl2;
                 q_step[slot] = ns2;
                 q_pl[slot] = (uint16_t)pl;
@@ -202,10 +218,9 @@ __global__ __launch_bounds__(64) void k_probe(const SubTable st, const uint64_t 
     constexpr int STAGE_ITERS = (PROBE_MAXRUN * SLOTS + 63) / 64;  // 16-byte loads per lane per staging step
     __shared__ uint32_t lines_w[PROBE_NB][PROBE_MAXRUN];
     __shared__ uint4 buf[PROBE_NB][((STAGE_ITERS * 64 + SLOTS - 1) / SLOTS) * LDS_LINE_U4];  // room for every staged chunk slot
-    __shared__ uint64_t q_key[PROBE_QCAP];   // overflow queue of the tile (position order)
-    __shared__ uint32_t q_line[PROBE_QCAP];  // next line to try
-    __shared__ uint32_t q_step[PROBE_QCAP];
-    __shared__ uint16_t q_pl[PROBE_QCAP];    // position within the tile
+    __shared__ uint32_t q_line[PROBE_QCAP];  // overflow queue of the tile (position order): next line to try,
+    __shared__ uint32_t q_step[PROBE_QCAP];  // step of the entry's sequence
+    __shared__ uint16_t q_pl[PROBE_QCAP];    // and position within the tile (the key is re-derived from sw)
     const int lane = threadIdx.x;
     const int k = (int)st.k;
     // tiles run in launch order unless the result carries a schedule (co-scheduled anchor genomes:
@@ -282,7 +297,10 @@ __global__ __launch_bounds__(64) void k_probe(const SubTable st, const uint64_t 
                 const int d = (2 * off <= W_C) ? off : (W_C - off);  // 3: 1,1  5: 1,2,1  6: 1,2,2  7: 1,2,3  8: 1,2,4
                 uint32_t up[NB];
 #pragma unroll
-                for (int u = 0; u < NB; ++u) up[u] = __shfl_up(grp[u], d);
+                for (int u = 0; u < NB; ++u) {
+                    up[u] = grp[u];
+                    for (int i = 0; i < d; ++i) up[u] = lane_up1(up[u]);
+                }
 #pragma unroll
                 for (int u = 0; u < NB; ++u) grp[u] = min(grp[u], lane >= d ? up[u] : grp[u]);
             }
@@ -292,7 +310,7 @@ __global__ __launch_bounds__(64) void k_probe(const SubTable st, const uint64_t 
 #pragma unroll
         for (int u = 0; u < NB; ++u) {
             line[u] = home_of_group(grp[u], st.nbuckets);
-            prev_line[u] = __shfl_up(line[u], 1);
+            prev_line[u] = lane_up1(line[u]);
         }
         uint32_t maxruns = 0;
 #pragma unroll
@@ -356,7 +374,6 @@ __global__ __launch_bounds__(64) void k_probe(const SubTable st, const uint64_t 
                 const uint32_t slot = qn + lanes_le_count(omask, ovf) - 1;
                 if (ovf) {
                     if (slot < (uint32_t)PROBE_QCAP) {
-                        q_key[slot] = key[u];
                         q_line[slot] = nx;
                         q_step[slot] = step;
                         q_pl[slot] = (uint16_t)pl[u];
@@ -370,7 +387,7 @@ __global__ __launch_bounds__(64) void k_probe(const SubTable st, const uint64_t 
         }
     }
 
-    drain_queue<TWO, ROWMODE, SLOTS, PROBE_MAXRUN>(st, qn, q_key, q_line, q_step, q_pl, lines_w[0], buf[0], tile_rows, nbytes, rc, lane);
+    drain_queue<TWO, ROWMODE, SLOTS, PROBE_MAXRUN>(st, qn, sw, q_line, q_step, q_pl, lines_w[0], buf[0], tile_rows, nbytes, rc, lane);
 }
 
 // ---------------------------------------------------------------------------

@@ -108,12 +108,15 @@ __device__ __forceinline__ uint32_t next_line(uint32_t line, uint32_t step, uint
 // by every insert and every lookup of the family — grows to hundreds of lines.
 // Line number `level` (0 = home) of a key's probe sequence, given the line before it:
 constexpr uint32_t GROUP_CHAIN = 4;
+__device__ __forceinline__ void key_sequence(uint64_t key, uint64_t nlines, uint32_t &home, uint32_t &step) {
+    const uint32_t g2 = fmix32(group_of_key(key) ^ 0x7feb352du);
+    home = home_of_group(g2, nlines);
+    step = step_of_group(g2, nlines);
+}
 __device__ __forceinline__ void advance_line(uint64_t key, uint32_t level, uint64_t nlines, uint32_t &line,
                                              uint32_t &step) {
     if (level == GROUP_CHAIN) {  // first line of the key's own sequence
-        const uint32_t g2 = fmix32(group_of_key(key) ^ 0x7feb352du);
-        line = home_of_group(g2, nlines);
-        step = step_of_group(g2, nlines);
+        key_sequence(key, nlines, line, step);
     } else {
         line = next_line(line, step, nlines);
     }
