@@ -16,6 +16,7 @@ ap.add_argument("--d", type=float, default=0.01)
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--no-colsums", action="store_true")
 ap.add_argument("--minimizer", type=int, default=-1)
+ap.add_argument("--n-blocks", type=int, default=0, help="1 kb blocks of N per contig")
 ap.add_argument("--keys-per-bucket", type=float, default=2.0)
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
@@ -24,6 +25,12 @@ ctx.set_stream(torch.cuda.current_stream().cuda_stream)
 L = int(a.genome_mb * 1e6)
 lens = [L // a.contigs] * a.contigs
 genomes = bench.synth_genomes_device(a.genomes, lens, a.d, 1234, dev)
+if a.n_blocks:
+    gen = torch.Generator(device=dev); gen.manual_seed(5)
+    for g in range(a.genomes):
+        for t in genomes[g]:
+            for p in torch.randint(0, t.numel() - 1000, (a.n_blocks,), device=dev, generator=gen).tolist():
+                t[p:p + 1000] = ord('N')
 seqsets = []
 for g in range(a.genomes):
     ss = engine.SeqSet(ctx, lens)
