@@ -250,7 +250,7 @@ def main():
                         f"(BASELINE.json configs[1])",
             "positions_per_step_per_gpu": pos_per_step,
             "table_keys": st["nkeys"], "table_bytes": st["bytes"], "keys_per_128B_line": args.keys_per_bucket,
-            "table_build_s": build_s, "probes_per_position": P, "nbytes": nbytes,
+            "table_build_s": build_s, "table_spill_fraction": tbl.spill()[0], "table_slots_per_line": tbl.spill()[1], "probes_per_position": P, "nbytes": nbytes,
             "colsums": not args.no_colsums,
             "launches_per_step": len(results),
             "schedule": "one launch per anchor genome" if args.per_genome_launches else

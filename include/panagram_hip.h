@@ -102,8 +102,11 @@ int pg_table_load_kmc1(pg_table *tbl, int db_idx, const void *pre, size_t pre_le
 /* statistics: distinct keys, slot capacity, bucket count, bytes, summed over sub-tables */
 int pg_table_stats(pg_table *tbl, uint64_t *nkeys, uint64_t *nslots, uint64_t *nbuckets,
                    uint64_t *bytes);
-/* re-hash into the smallest table whose mean bucket occupancy is <= keys_per_bucket */
+/* re-hash into the smallest table whose mean occupancy is <= keys_per_bucket keys per 128 bytes;
+ * also settles the minimizer length for the keys actually present */
 int pg_table_rehash(pg_table *tbl, double keys_per_bucket);
+/* as of the last pg_table_rehash: fraction of keys outside their home line, slots per line */
+int pg_table_spill(const pg_table *tbl, double *fraction, uint32_t *slots);
 /* export group db_idx as (key, counter) pairs, unsorted; *n receives the count
  * (call with keys==NULL to query).  Lets the caller write a KMC1 database the
  * reference can open. */

@@ -8,6 +8,7 @@
 #include <atomic>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -71,6 +72,7 @@ struct pg_table {
     bool m_pinned = false;  // set by pg_table_set_minimizer: re-hashing keeps m
     std::vector<SubHost> subs;
     unsigned long long *d_counters;  // [0] newly claimed, [1] overflow flag
+    double spill = 0;                // keys outside their home line / keys, as of the last pg_table_rehash
     std::atomic<int> refs{0};        // results on this table
     bool dead = false;
 };
@@ -112,9 +114,6 @@ struct pg_result {
     bool ev_ok, ev_epi;
 };
 
-#ifndef PG_WIDE_FROM
-#define PG_WIDE_FROM 32  // more genomes than this: 256-byte lines of 16 slots (measured: better at d=1 %, worse at d=0.5 %)
-#endif
 static constexpr uint32_t MAX_PROBE = 512;  // lines an insert may walk before the table is grown
 static constexpr double GROW_AT = 0.55;     // grow when keys > GROW_AT * slots
 static constexpr double TARGET_LOAD = 0.375; // load right after growing (3 keys per 8-slot line)
@@ -258,7 +257,7 @@ extern "C" int pg_table_create(pg_ctx *ctx, int k, int ngenomes, uint64_t expect
         uint64_t want = expected_keys ? expected_keys : (1ull << 18);
         // 256-byte lines where a minimizer group is expected to exceed 8 keys: many genomes'
         // variants per locus
-        const uint32_t slots = (ngenomes > PG_WIDE_FROM) ? 16u : 8u;
+        const uint32_t slots = 8u;  // pg_table_rehash widens the lines when the keys call for it
         uint64_t nb = (uint64_t)((double)want / (TARGET_LOAD * slots)) + 1;
         SubHost sh;
         sh.count = 0;
@@ -319,11 +318,12 @@ static int read_counters(pg_table *t, unsigned long long out[2]) {
 }
 
 // replace sub-table si by one with `nb` buckets holding the same content
-static int regrow(pg_table *t, int si, uint64_t nb) {
+static int regrow(pg_table *t, int si, uint64_t nb, uint32_t slots = 0) {
     pg_ctx *ctx = t->ctx;
+    if (slots == 0) slots = t->subs[si].d.slots;
     for (int attempt = 0; attempt < 8; ++attempt) {
         SubTable nt;
-        if (int r = alloc_sub(ctx, t->subs[si].d.W, t->subs[si].d.word0, (uint32_t)t->k, t->m, t->subs[si].d.slots, nb, &nt)) return r;
+        if (int r = alloc_sub(ctx, t->subs[si].d.W, t->subs[si].d.word0, (uint32_t)t->k, t->m, slots, nb, &nt)) return r;
         HIP_TRY(hipMemsetAsync(t->d_counters, 0, 2 * sizeof(unsigned long long), ctx->stream));
         HIP_TRY(launch_rehash(ctx->stream, t->subs[si].d, nt, t->d_counters, MAX_PROBE));
         unsigned long long c[2];
@@ -581,6 +581,17 @@ extern "C" int pg_table_stats(pg_table *t, uint64_t *nkeys, uint64_t *nslots, ui
     return PG_OK;
 }
 
+// keys of sub-table si that do not sit in their group's home line
+static int count_spill(pg_table *t, int si, uint64_t *out) {
+    hipStream_t st = t->ctx->stream;
+    HIP_TRY(hipMemsetAsync(t->d_counters, 0, 2 * sizeof(unsigned long long), st));
+    HIP_TRY(launch_count_spill(st, t->subs[si].d, t->d_counters));
+    unsigned long long c[2];
+    if (int r = read_counters(t, c)) return r;
+    *out = c[0];
+    return PG_OK;
+}
+
 extern "C" int pg_table_rehash(pg_table *t, double keys_per_bucket) {
     if (!t) return fail(PG_E_INVALID, "table is NULL");
     if (!(keys_per_bucket > 0.05 && keys_per_bucket <= 8.0)) return fail(PG_E_INVALID, "keys_per_bucket must be in (0.05, 8]");
@@ -590,11 +601,30 @@ extern "C" int pg_table_rehash(pg_table *t, double keys_per_bucket) {
         for (auto &s : t->subs) most = std::max<uint64_t>(most, s.count);
         t->m = minimizer_length((uint32_t)t->k, most);
     }
+    // Line width: 128-byte lines of 8 slots.  256-byte lines of 16 slots (PG_TABLE_SLOTS=16, a tuning
+    // knob) keep a many-variant locus in ONE place at the price of two requests per line; measured,
+    // they only pay for >= 40 genomes at 1 % divergence (+6 %) and cost 10-25 % everywhere else
+    // (tools/slots_calib.sh), so they are never chosen automatically.
+    uint32_t slots = 8;
+    if (const char *e = getenv("PG_TABLE_SLOTS"))
+        if (atoi(e) == 16) slots = 16;
+    uint64_t keys = 0, spilled = 0;
     for (size_t si = 0; si < t->subs.size(); ++si) {
-        double kpb = std::min(keys_per_bucket * (t->subs[si].d.slots / 8.0), 0.8 * t->subs[si].d.slots);  // keys per 128 bytes
-        uint64_t nb = (uint64_t)((double)t->subs[si].count / kpb) + 1;
-        if (int r = regrow(t, (int)si, nb)) return r;
+        const double kpb = std::min(keys_per_bucket * (slots / 8.0), 0.8 * slots);  // keys per line
+        if (int r = regrow(t, (int)si, (uint64_t)((double)t->subs[si].count / kpb) + 1, slots)) return r;
+        uint64_t sp = 0;
+        if (int r = count_spill(t, (int)si, &sp)) return r;
+        keys += t->subs[si].count;
+        spilled += sp;
     }
+    t->spill = keys ? (double)spilled / (double)keys : 0.0;
+    return PG_OK;
+}
+
+extern "C" int pg_table_spill(const pg_table *t, double *fraction, uint32_t *slots) {
+    if (!t) return fail(PG_E_INVALID, "table is NULL");
+    if (fraction) *fraction = t->spill;
+    if (slots) *slots = t->subs.empty() ? 0 : t->subs[0].d.slots;
     return PG_OK;
 }
 

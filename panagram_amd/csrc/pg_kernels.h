@@ -65,6 +65,7 @@ hipError_t launch_pack(hipStream_t st, const void *d_ascii, uint64_t len, uint64
 hipError_t launch_insert_seq(hipStream_t st, const SubTable &t, int w, uint32_t bits, int k,
                              const uint64_t *seqw, const uint32_t *nmw, const uint32_t *has_n,
                              uint64_t nkmers, unsigned long long *counters, uint32_t max_probe, int count_mode = 0);
+hipError_t launch_count_spill(hipStream_t st, const SubTable &t, unsigned long long *counters);
 hipError_t launch_merge_min(hipStream_t st, const SubTable &src, const SubTable &dst, int w, uint32_t bits,
                             uint32_t min_count, unsigned long long *counters, uint32_t max_probe);
 hipError_t launch_insert_keys(hipStream_t st, const SubTable &t, int w, const uint64_t *keys,

@@ -301,6 +301,23 @@ __global__ __launch_bounds__(256) void k_merge_min(SubTable src, SubTable dst, i
     if (claimed) atomicAdd(&counters[0], (unsigned long long)claimed);
 }
 
+// keys that do not sit in the home line of their group (they spilled down the probe sequence)
+__global__ __launch_bounds__(256) void k_count_spill(SubTable st, unsigned long long *counters) {
+    const int ns = (int)st.slots;
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t nslots = st.nbuckets * ns;
+    uint32_t spilled = 0;
+    for (; i < nslots; i += stride) {
+        const uint64_t b = i / ns;
+        const int s = (int)(i - b * ns);
+        const uint64_t key = *reinterpret_cast<const uint64_t *>(st.buckets + b * (16u * st.slots) + key_off(st.W, s));
+        if (key == EMPTY_KEY) continue;
+        if (home_of_group(group_of(st, key), st.nbuckets) != (uint32_t)b) ++spilled;
+    }
+    if (spilled) atomicAdd(&counters[0], (unsigned long long)spilled);
+}
+
 // export (key, mask word w) of every slot whose word w is non-zero
 __global__ __launch_bounds__(256) void k_export(SubTable st, int w, uint64_t *keys, uint32_t *vals,
                                                 uint64_t cap, unsigned long long *count) {
@@ -412,6 +429,12 @@ hipError_t launch_merge_min(hipStream_t st, const SubTable &src, const SubTable 
     uint64_t nslots = src.nbuckets * src.slots;
     hipLaunchKernelGGL(k_merge_min, dim3(grid_for(nslots, 256, 256 * 64)), dim3(256), 0, st, src, dst, w, bits,
                        min_count, counters, max_probe);
+    return hipGetLastError();
+}
+
+hipError_t launch_count_spill(hipStream_t st, const SubTable &t, unsigned long long *counters) {
+    uint64_t nslots = t.nbuckets * t.slots;
+    hipLaunchKernelGGL(k_count_spill, dim3(grid_for(nslots, 256, 256 * 64)), dim3(256), 0, st, t, counters);
     return hipGetLastError();
 }
 

@@ -231,6 +231,12 @@ class PanTable(_Owner):
     def rehash(self, keys_per_bucket: float) -> None:
         check(self._lib.pg_table_rehash(self._h, keys_per_bucket))
 
+    def spill(self):
+        """(fraction of keys outside their home line, slots per line) as of the last rehash()"""
+        f, n = C.c_double(), C.c_uint32()
+        check(self._lib.pg_table_spill(self._h, C.byref(f), C.byref(n)))
+        return f.value, n.value
+
     @property
     def minimizer(self) -> int:
         """minimizer length m the table places k-mers by (0 = the k-mer itself)"""

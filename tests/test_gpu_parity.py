@@ -511,3 +511,28 @@ def test_handles_close_children_first():
         cyc.append(cyc)
         del c, t, s, r, cyc
         gc.collect()
+
+
+def test_sixteen_slot_lines_knob(ctx, monkeypatch):
+    """PG_TABLE_SLOTS=16 re-hashes into 256-byte lines (tuning knob): same answers"""
+    from panagram_amd import engine
+    n, k = 40, 31
+    gen = po.synth_genomes(n, [20000, 900], 0.03, 4040)
+    genomes = [[po.codes_to_ascii(c) for c in g] for g in gen]
+    dbs = po.build_bitvec_dbs(genomes, k)
+    tbl = engine.PanTable(ctx, k, n)
+    for g in range(n):
+        ss = engine.SeqSet.from_host(ctx, genomes[g])
+        tbl.insert_seqset(g, ss)
+        ss.close()
+    for slots in ("16", "8"):
+        monkeypatch.setenv("PG_TABLE_SLOTS", slots)
+        tbl.rehash(3.0)
+        frac, got_slots = tbl.spill()
+        assert got_slots == int(slots) and 0.0 <= frac < 1.0
+        for seq in genomes[7]:
+            rows, rows100, bins, cs = tbl.anchor_contig(seq)
+            o_rows, o_rows100, o_bins, _, o_cs = po.anchor_contig(dbs, seq, k, n)
+            assert np.array_equal(rows, o_rows) and np.array_equal(rows100, o_rows100)
+            assert np.array_equal(bins.astype(np.int64), o_bins) and np.array_equal(cs.astype(np.int64), o_cs)
+    tbl.close()

@@ -3,7 +3,7 @@
 # G k-mers/s with one launch per genome, k_probe ms per launch, roofline frac, table GB)
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 : > gpurun_out/t.txt
-for A in "" "--k 31" "--genomes 27 --genome-mb 40" "--genomes 64 --genome-mb 20 --k 31" "--k 25" "--genomes 2 --genome-mb 400" "$@"; do
+for A in "" "--k 31" "--genomes 27 --genome-mb 40" "--genomes 64 --genome-mb 20 --k 31 --d 0.005" "--k 25" "--genomes 2 --genome-mb 400" "$@"; do
   echo "== $A" >> gpurun_out/t.txt
   timeout 600 python bench.py --steps 5 --warmup 1 --no-cpu-baseline $A 2>gpurun_out/shapes.err | python -c "
 import sys,json
