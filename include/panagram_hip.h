@@ -170,6 +170,15 @@ int pg_anchor_run(pg_result *r);
  * stream: the probe kernels (k_probe, one per sub-table) and the statistics kernel
  * (k_epilogue; 0 in rows-only mode).  Synchronises on the run's last event. */
 int pg_result_timing(pg_result *r, float *probe_ms, float *epilogue_ms);
+/* Genome-sharded exchange (union of tables > one GPU's HBM): rank i owns genomes
+ * [i*per, (i+1)*per) and its PG_ANCHOR_ROWS_ONLY rows hold only their bits.  extract writes the
+ * compact block of bit columns of genomes [g0, g0+width) — pg_result_columns_bytes(width) bytes,
+ * one u64 per genome per 64 positions — into device memory; the blocks of all ranks, all-gathered
+ * over RCCL/xGMI into one buffer (nparts blocks of equal size, block i = genomes from i*per), are
+ * merged back into full rows by merge.  Both are asynchronous on the context's stream. */
+uint64_t pg_result_columns_bytes(const pg_result *r, uint32_t width);
+int pg_result_extract_columns(pg_result *r, uint32_t g0, uint32_t width, void *d_dst);
+int pg_result_merge_columns(pg_result *r, const void *d_src, uint32_t nparts, uint32_t per);
 /* bitmap.100 rows, bin histograms and column sums from the (combined) bitmap.1 rows in the
  * result's device buffer; async.  Same outputs as the fused pg_anchor_run path. */
 int pg_rows_epilogue(pg_result *r);

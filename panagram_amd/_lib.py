@@ -65,6 +65,9 @@ PROTOTYPES = {
     "pg_result_contig_info": (C.c_int, [_vp, C.c_uint32, _u64p, _u64p, _u32p, _u32p]),
     "pg_result_coschedule": (C.c_int, [_vp, _vp, C.c_uint32]),
     "pg_result_contig_colsums": (C.c_int, [_vp, C.c_uint32, C.c_uint32, _vp]),
+    "pg_result_columns_bytes": (C.c_uint64, [_vp, C.c_uint32]),
+    "pg_result_extract_columns": (C.c_int, [_vp, C.c_uint32, C.c_uint32, _vp]),
+    "pg_result_merge_columns": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32]),
     "pg_result_window_stats": (C.c_int, [_vp, C.c_uint32, C.c_int, C.c_uint32, _vp, _vp, _vp, _vp]),
     "pg_result_write_bgzf": (C.c_int, [_vp, C.c_int, C.c_char_p, C.c_char_p, C.c_int, C.c_int]),
     "pg_result_download": (C.c_int, [_vp, C.c_uint32, _vp, _vp, _vp]),

@@ -856,6 +856,68 @@ __global__ __launch_bounds__(256) void k_window_stats(uint32_t N, const uint8_t 
 }
 
 // ---------------------------------------------------------------------------
+// genome-sharded exchange (tables too big for one GPU): a rank's partial rows hold only the bits of
+// the genomes it owns, so what crosses xGMI is a COMPACT block of bit columns — for every 64
+// positions, one u64 per owned genome (bit l = position l) — all-gathered over RCCL and merged back
+// into full rows: (n-1)/n row bytes received per position instead of the 2(n-1)/n of an all-reduce.
+// Layout: tile t (512 positions) owns 8 slots of `width` u64 words: word (8t + s) * width + j =
+// genome g0 + j at positions 64 s .. 64 s + 63 of the tile.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_cols_extract(uint32_t N, const AnchorDesc *__restrict__ ad,
+                                                      const uint32_t *__restrict__ tile_contig, uint32_t ntiles,
+                                                      const uint8_t *__restrict__ out1, uint32_t g0, uint32_t width,
+                                                      unsigned long long *__restrict__ dst) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t slot = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (slot >= (uint64_t)ntiles * 8) return;  // wave-uniform
+    const uint32_t tile = (uint32_t)(slot >> 3), sub = (uint32_t)(slot & 7);
+    const AnchorDesc a = ad[tile_contig[tile]];
+    const uint32_t nbytes = (N + 7) / 8;
+    const uint32_t p = (tile - a.tile0) * PROBE_TILE + sub * 64 + lane;
+    const bool active = p < a.nkmers;
+    const uint8_t *row = out1 + a.out_off + (uint64_t)p * nbytes;
+    for (uint32_t j0 = 0; j0 < width; j0 += 64) {
+        unsigned long long mine = 0;
+        const uint32_t jn = min(64u, width - j0);
+        for (uint32_t j = 0; j < jn; ++j) {
+            const uint32_t g = g0 + j0 + j;
+            const bool bit = active && g < N && ((row[g >> 3] >> (g & 7)) & 1u);
+            const unsigned long long m = __ballot(bit);
+            if ((uint32_t)lane == j) mine = m;
+        }
+        if ((uint32_t)lane < jn) dst[slot * width + j0 + lane] = mine;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_cols_merge(uint32_t N, const AnchorDesc *__restrict__ ad,
+                                                    const uint32_t *__restrict__ tile_contig, uint32_t ntiles,
+                                                    uint8_t *__restrict__ out1, const unsigned long long *__restrict__ src,
+                                                    uint32_t nparts, uint64_t part_words, uint32_t per) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t slot = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (slot >= (uint64_t)ntiles * 8) return;
+    const uint32_t tile = (uint32_t)(slot >> 3), sub = (uint32_t)(slot & 7);
+    const AnchorDesc a = ad[tile_contig[tile]];
+    const uint32_t nbytes = (N + 7) / 8, ndbs = (N + 31) / 32;
+    const uint32_t p = (tile - a.tile0) * PROBE_TILE + sub * 64 + lane;
+    uint8_t *row = out1 + a.out_off + (uint64_t)p * nbytes;
+    for (uint32_t d = 0; d < ndbs; ++d) {
+        uint32_t w = 0;
+        const uint32_t nb = min(32u, N - 32 * d);
+        for (uint32_t b = 0; b < nb; ++b) {
+            const uint32_t g = 32 * d + b, part = g / per, j = g - part * per;
+            if (part >= nparts) continue;
+            const unsigned long long word = src[(uint64_t)part * part_words + slot * per + j];  // wave-uniform
+            w |= (uint32_t)((word >> lane) & 1ull) << b;
+        }
+        if (p < a.nkmers) {
+            const uint32_t n = min(4u, nbytes - 4 * d);
+            for (uint32_t bb = 0; bb < n; ++bb) row[4 * d + bb] = (uint8_t)(w >> (8 * bb));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // launch
 // ---------------------------------------------------------------------------
 template <int W_C, bool TWO, int ROWMODE, int SLOTS>
@@ -955,6 +1017,23 @@ hipError_t launch_window_stats(hipStream_t st, uint32_t ngenomes, const uint8_t 
     if (nwin == 0) return hipSuccess;
     hipLaunchKernelGGL(k_window_stats, dim3(nwin, pieces), dim3(256), (2 * ngenomes + 1) * 4, st, ngenomes, rows, nrows,
                        starts, ends, hist, cs);
+    return hipGetLastError();
+}
+
+hipError_t launch_cols_extract(hipStream_t st, uint32_t ngenomes, const AnchorDesc *ad, const uint32_t *tile_contig,
+                               uint32_t ntiles, const uint8_t *out1, uint32_t g0, uint32_t width, void *dst) {
+    if (ntiles == 0 || width == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_cols_extract, dim3((unsigned)(((uint64_t)ntiles * 8 + 3) / 4)), dim3(256), 0, st, ngenomes, ad,
+                       tile_contig, ntiles, out1, g0, width, static_cast<unsigned long long *>(dst));
+    return hipGetLastError();
+}
+
+hipError_t launch_cols_merge(hipStream_t st, uint32_t ngenomes, const AnchorDesc *ad, const uint32_t *tile_contig,
+                             uint32_t ntiles, uint8_t *out1, const void *src, uint32_t nparts, uint64_t part_words,
+                             uint32_t per) {
+    if (ntiles == 0 || per == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_cols_merge, dim3((unsigned)(((uint64_t)ntiles * 8 + 3) / 4)), dim3(256), 0, st, ngenomes, ad,
+                       tile_contig, ntiles, out1, static_cast<const unsigned long long *>(src), nparts, part_words, per);
     return hipGetLastError();
 }
 

@@ -1179,6 +1179,31 @@ extern "C" int pg_result_timing(pg_result *r, float *probe_ms, float *epilogue_m
     return PG_OK;
 }
 
+// ---------------------------------------------------------------------------
+// genome-sharded exchange: compact bit columns out of / back into the rows
+// ---------------------------------------------------------------------------
+extern "C" uint64_t pg_result_columns_bytes(const pg_result *r, uint32_t width) {
+    return r ? (uint64_t)r->ntiles * 64ull * width : 0;
+}
+
+extern "C" int pg_result_extract_columns(pg_result *r, uint32_t g0, uint32_t width, void *d_dst) {
+    if (!r || !d_dst) return fail(PG_E_INVALID, "pg_result_extract_columns: NULL argument");
+    if (!r->ev_ok) return fail(PG_E_INVALID, "pg_anchor_run has not been called on this result");
+    if (int e = use_device(r->tbl->ctx)) return e;
+    HIP_TRY(launch_cols_extract(r->tbl->ctx->stream, r->tbl->ngenomes, r->d_ad, r->d_tile_contig, r->ntiles, r->d_out1, g0,
+                                width, d_dst));
+    return PG_OK;
+}
+
+extern "C" int pg_result_merge_columns(pg_result *r, const void *d_src, uint32_t nparts, uint32_t per) {
+    if (!r || !d_src) return fail(PG_E_INVALID, "pg_result_merge_columns: NULL argument");
+    if (per == 0 || nparts == 0) return fail(PG_E_INVALID, "pg_result_merge_columns: empty partition");
+    if (int e = use_device(r->tbl->ctx)) return e;
+    HIP_TRY(launch_cols_merge(r->tbl->ctx->stream, r->tbl->ngenomes, r->d_ad, r->d_tile_contig, r->ntiles, r->d_out1, d_src,
+                              nparts, (uint64_t)r->ntiles * 8ull * per, per));
+    return PG_OK;
+}
+
 extern "C" int pg_rows_epilogue(pg_result *r) {
     if (!r) return fail(PG_E_INVALID, "result is NULL");
     if (int e = use_device(r->tbl->ctx)) return e;

@@ -80,6 +80,11 @@ hipError_t launch_counters(hipStream_t st, const SubTable &t, int w, int k, cons
 hipError_t launch_anchor(hipStream_t st, const TableDesc &T, const uint64_t *seqw, const uint32_t *nmw,
                          const uint32_t *has_n, const SeqDesc *sd, const AnchorDesc *ad,
                          const uint32_t *tile_contig, const uint32_t *sched, uint32_t ntiles, uint8_t *out1, uint64_t out1_bytes);
+hipError_t launch_cols_extract(hipStream_t st, uint32_t ngenomes, const AnchorDesc *ad, const uint32_t *tile_contig,
+                               uint32_t ntiles, const uint8_t *out1, uint32_t g0, uint32_t width, void *dst);
+hipError_t launch_cols_merge(hipStream_t st, uint32_t ngenomes, const AnchorDesc *ad, const uint32_t *tile_contig,
+                             uint32_t ntiles, uint8_t *out1, const void *src, uint32_t nparts, uint64_t part_words,
+                             uint32_t per);
 hipError_t launch_window_stats(hipStream_t st, uint32_t ngenomes, const uint8_t *rows, uint64_t nrows, uint32_t nwin,
                                uint32_t pieces, const uint64_t *starts, const uint64_t *ends, unsigned long long *hist,
                                unsigned long long *cs);

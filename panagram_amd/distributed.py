@@ -125,6 +125,38 @@ def combine_rows_allgather(rows, group=None):
     return out
 
 
+def genomes_per_rank(ngenomes: int, world: int) -> int:
+    return (ngenomes + world - 1) // world
+
+
+def gather_columns(mine, group=None):
+    """All-gather of the ranks' compact bit-column blocks (equal-sized uint8 tensors, any device):
+    the one collective of the genome-sharded mode — RCCL over xGMI on GPUs, gloo on CPU.  Returns the
+    concatenation, block i from rank i."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    out = torch.empty(world * mine.numel(), dtype=mine.dtype, device=mine.device)
+    dist.all_gather_into_tensor(out, mine.contiguous(), group=group)
+    return out
+
+
+def exchange_columns_(res, ngenomes: int, rank: int, world: int, group=None) -> None:
+    """Complete this rank's partial rows (only its own genomes' bits are set) in place: extract the
+    compact columns of its genomes, all-gather every rank's block, merge them into the rows.
+    Moves (world-1)/world row bytes per position per rank — half of what the SUM all-reduce of
+    ``combine_rows_`` moves."""
+    import torch
+    per = genomes_per_rank(ngenomes, world)
+    dev = torch.device("cuda", res.table.ctx.device)
+    mine = torch.empty(res.columns_bytes(per), dtype=torch.uint8, device=dev)
+    res.extract_columns(rank * per, per, mine.data_ptr())
+    res.table.ctx.synchronize()
+    allb = gather_columns(mine, group)
+    res.merge_columns(allb.data_ptr(), world, per)
+    res.table.ctx.synchronize()  # allb may be freed by torch once we return
+
+
 def build_partial_table(ctx, k: int, ngenomes: int, rank: int, world: int, genome_seqs):
     """Table of the genomes this rank owns (full-width rows).  ``genome_seqs(g)`` -> list of
     contig byte strings of genome g, or None to skip."""
@@ -139,15 +171,24 @@ def build_partial_table(ctx, k: int, ngenomes: int, rank: int, world: int, genom
     return tbl
 
 
-def anchor_genome_sharded(table, seqs: Sequence[bytes], group=None):
-    """Anchor contigs against this rank's partial table, combine rows across ranks, derive
-    bitmap.100 / bins / column sums from the combined rows.  Returns like Genome.anchor_contigs."""
+def anchor_genome_sharded(table, seqs: Sequence[bytes], group=None, rank: Optional[int] = None,
+                          world: Optional[int] = None, exchange: str = "columns"):
+    """Anchor contigs against this rank's partial table, complete the rows across ranks, derive
+    bitmap.100 / bins / column sums from the completed rows.  Returns like Genome.anchor_contigs.
+    ``exchange``: "columns" = all-gather of compact bit columns (default; ranks must own the
+    contiguous genome blocks of ``genome_owner``), "allreduce" = SUM all-reduce of the rows."""
     from . import engine
     ss = engine.SeqSet.from_host(table.ctx, seqs)
     res = engine.AnchorResult(table, ss, colsums=True, rows_only=True)
     res.run()
     table.ctx.synchronize()
-    combine_rows_(res.rows_tensor(), group)
+    if exchange == "columns":
+        import torch.distributed as dist
+        rank = dist.get_rank(group) if rank is None else rank
+        world = dist.get_world_size(group) if world is None else world
+        exchange_columns_(res, table.ngenomes, rank, world, group)
+    else:
+        combine_rows_(res.rows_tensor(), group)
     res.rows_epilogue()
     out = [res.download(ci) for ci in range(len(seqs))]
     cs = res.colsums().astype(np.int64)

@@ -339,6 +339,17 @@ class AnchorResult:
         """bitmap.100 / bins / column sums from the (combined) rows in the device buffer (async)."""
         check(self._lib.pg_rows_epilogue(self._h))
 
+    def columns_bytes(self, width: int) -> int:
+        return int(self._lib.pg_result_columns_bytes(self._h, width))
+
+    def extract_columns(self, g0: int, width: int, dev_ptr: int) -> None:
+        """compact bit columns of genomes [g0, g0+width) of the rows -> device buffer (async)"""
+        check(self._lib.pg_result_extract_columns(self._h, g0, width, C.c_void_p(dev_ptr)))
+
+    def merge_columns(self, dev_ptr: int, nparts: int, per: int) -> None:
+        """all ranks' column blocks (block i = genomes from i*per) -> full rows (async)"""
+        check(self._lib.pg_result_merge_columns(self._h, C.c_void_p(dev_ptr), nparts, per))
+
     def rows_tensor(self):
         """Zero-copy torch uint8 view of the device bitmap.1 buffer (for RCCL collectives)."""
         import torch

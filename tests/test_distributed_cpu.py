@@ -61,6 +61,21 @@ def _worker(rank, world, port, root, name):
         ag = combine_rows_allgather(t)
         combine_rows_(t)
         assert np.array_equal(t.numpy(), full) and np.array_equal(ag.numpy(), full)
+        # the default exchange: compact bit columns of this rank's genomes, all-gathered, merged
+        from panagram_amd.distributed import gather_columns, genomes_per_rank
+        recs = po.parse_fasta_cpp(fx[f"fasta_{g}"].tobytes())
+        nks = [len(sq) - k + 1 for _, sq in recs]
+        per = genomes_per_rank(n, world)
+        rows_part, off = [], 0
+        for nk in nks:
+            rows_part.append(part.reshape(-1, nb)[off:off + nk])
+            off += nk
+        mine = po.extract_columns(rows_part, n, rank * per, per)
+        allb = gather_columns(torch.from_numpy(mine)).numpy()
+        blocks = np.split(allb, world)
+        assert np.array_equal(blocks[rank], mine)
+        merged = po.merge_columns(blocks, nks, n, per)
+        assert np.array_equal(np.concatenate(merged).reshape(-1), full)
     finally:
         dist.destroy_process_group()
 

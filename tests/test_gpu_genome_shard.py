@@ -11,10 +11,11 @@ from tests import helpers as H
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("mode", ["columns", "sum"])
 @pytest.mark.parametrize("name,world", [("n9_k21", 2), ("n65_k21", 4), ("n40_k31", 8)])
-def test_partial_tables_combine_equals_reference(ctx, name, world):
+def test_partial_tables_combine_equals_reference(ctx, name, world, mode):
     from panagram_amd import engine
-    from panagram_amd.distributed import genome_owner
+    from panagram_amd.distributed import genome_owner, genomes_per_rank
     fx = H.load_case(name)
     n, k = int(fx["ngenomes"]), int(fx["k"])
     dbs = H.case_dbs(fx)
@@ -37,9 +38,27 @@ def test_partial_tables_combine_equals_reference(ctx, name, world):
     for r_ in res:
         r_.run()
     ctx.synchronize()
-    total = res[0].rows_tensor()
-    for r_ in res[1:]:
-        total += r_.rows_tensor()  # what the SUM all-reduce does across GPUs
+    if mode == "sum":
+        total = res[0].rows_tensor()
+        for r_ in res[1:]:
+            total += r_.rows_tensor()  # what the SUM all-reduce does across GPUs
+    else:
+        # what exchange_columns_ does across GPUs: every rank extracts the compact bit columns of
+        # its own genomes into its slice of the gathered buffer; rank 0 merges all slices
+        per = genomes_per_rank(n, world)
+        nb_cols = res[0].columns_bytes(per)
+        allb = torch.zeros(world * nb_cols, dtype=torch.uint8, device="cuda")
+        for r, r_ in enumerate(res):
+            r_.extract_columns(r * per, per, allb.data_ptr() + r * nb_cols)
+        ctx.synchronize()
+        # the layout is the one the oracle restates (include/panagram_hip.h)
+        nks = [len(s_) - k + 1 for s_ in seqs]
+        part0, off = [], 0
+        for ci in range(len(seqs)):
+            part0.append(res[0].download(ci)[0])
+        assert np.array_equal(allb[:nb_cols].cpu().numpy(), po.extract_columns(part0, n, 0, per))
+        res[0].merge_columns(allb.data_ptr(), world, per)
+        ctx.synchronize()
     torch.cuda.synchronize()
     res[0].rows_epilogue()
     b1, b100, bins, binlens = [], [], [], []
