@@ -418,6 +418,8 @@ class AnchorResult:
 class BgzfWriter:
     """BGZF + .gzi writer (replaces htslib bgzf_* / bgzip.BGZipWriter + `bgzip -rI`)."""
 
+    RLE = 0x100  # PG_BGZF_RLE: zlib's run-length strategy, OR-ed into level (one-byte rows)
+
     def __init__(self, path: str, level: int = 6, threads: int = 1):
         self._lib = _lib.load()
         h = C.c_void_p()

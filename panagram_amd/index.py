@@ -583,7 +583,8 @@ class Genome:
         os.makedirs(self.prefix, exist_ok=True)
         nthreads = bgzf_threads or self._bgzf_threads()
         tmp = {s: self.bitmap_gz_fname(s) + ".tmp" for s in self.steps}
-        writers = {s: engine.BgzfWriter(tmp[s], level=6, threads=nthreads) for s in self.steps}
+        level = 6 | (engine.BgzfWriter.RLE if self.nbytes == 1 else 0)  # one-byte rows: equal rows are byte runs
+        writers = {s: engine.BgzfWriter(tmp[s], level=level, threads=nthreads) for s in self.steps}
         for rows, rows100, _, _ in results:
             writers[1].write(rows)
             writers[self.steps[1]].write(rows100)
@@ -768,8 +769,9 @@ def run_anchor_cli(argv: Sequence[str], device: int = 0) -> int:
         ss = engine.SeqSet.from_host(ctx, [s for _, s in recs])
         res = engine.AnchorResult(tbl, ss, colsums=False)
         res.run()
-        w1 = engine.BgzfWriter(os.path.join(adir, "bitmap.1.gz"), threads=engine.usable_cpus())
-        w100 = engine.BgzfWriter(os.path.join(adir, "bitmap.100.gz"), threads=2)
+        level = 6 | (engine.BgzfWriter.RLE if ngenomes <= 8 else 0)
+        w1 = engine.BgzfWriter(os.path.join(adir, "bitmap.1.gz"), level=level, threads=engine.usable_cpus())
+        w100 = engine.BgzfWriter(os.path.join(adir, "bitmap.100.gz"), level=level, threads=2)
         with open(os.path.join(adir, "bitsum.bins.tsv"), "w") as fb, open(os.path.join(adir, "chrs.tsv"), "w") as fc:
             fb.write("chr\tstart" + "".join(f"\t{i}" for i in range(ngenomes + 1)) + "\n")
             fc.write("name\tid\tsize\tgene_count\n")
