@@ -1237,7 +1237,7 @@ extern "C" int pg_result_write_bgzf(pg_result *r, int step, const char *gz_path,
     }
     if (nthreads < 1) nthreads = 1;
     pg_bgzf *w = nullptr;
-    if (nbytes_row == 1 && level >= 0) level |= PG_BGZF_RLE;  // one-byte rows: equal rows are byte runs
+    if (level >= 0) level |= nbytes_row == 1 ? PG_BGZF_RLE : (nbytes_row < 256 ? PG_BGZF_ROWS(nbytes_row) : 0);
     if (int e = pg_bgzf_open(gz_path, level, nthreads, &w)) return e;
     const size_t chunk = (size_t)512 * 65280;  // 32 MiB: 512 BGZF blocks, shared out one by one among the threads
     hipStream_t cs = nullptr;

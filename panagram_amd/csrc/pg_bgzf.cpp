@@ -14,6 +14,7 @@
 
 #include <zlib.h>
 
+#include <algorithm>
 #include <atomic>
 #include <condition_variable>
 #include <cstdio>
@@ -57,10 +58,250 @@ struct Deflater {
     }
 };
 
+// ---------------------------------------------------------------------------
+// Row-aware raw DEFLATE for bitmap payloads whose rows are wider than a byte.  zlib's matcher is
+// built for text: on 4- or 8-byte rows it runs at ~60 MB/s/core, and its run-length strategy only
+// sees distance 1.  Consecutive bitmap rows are mostly equal (a row changes where a genome's k-mer
+// presence flips), so the only match that matters is "same byte as one row earlier": the tokenizer
+// below emits literals and (length, distance = row width) matches in one pass, and a dynamic Huffman
+// code per BGZF block does the rest.  Output is ordinary DEFLATE (RFC 1951) — any inflater reads it.
+// ---------------------------------------------------------------------------
+struct BitWriter {
+    unsigned char *p, *end;
+    uint64_t acc = 0;
+    int n = 0;
+    bool overflow = false;
+    BitWriter(unsigned char *dst, size_t cap) : p(dst), end(dst + cap) {}
+    inline void put(uint32_t v, int bits) {  // LSB-first
+        acc |= (uint64_t)v << n;
+        n += bits;
+        while (n >= 8) {
+            if (p < end) *p++ = (unsigned char)acc;
+            else overflow = true;
+            acc >>= 8;
+            n -= 8;
+        }
+    }
+    inline void flush() {
+        if (n > 0) put(0, 8 - n);
+    }
+};
+
+static const uint16_t LEN_BASE[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+static const uint8_t LEN_EXTRA[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+static const uint16_t DIST_BASE[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+static const uint8_t DIST_EXTRA[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+static const uint8_t CL_ORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+
+// code lengths (<= maxlen) of a Huffman code for freq[0..n): heap-free two-queue construction on
+// the sorted symbols, then the usual Kraft-sum repair when the tree is deeper than maxlen
+static void huff_lengths(const uint32_t *freq, int n, int maxlen, uint8_t *len) {
+    struct Node {
+        uint64_t w;
+        int sym, a, b;
+    };
+    std::vector<int> used;
+    for (int i = 0; i < n; ++i) {
+        len[i] = 0;
+        if (freq[i]) used.push_back(i);
+    }
+    if (used.empty()) return;
+    if (used.size() == 1) {
+        len[used[0]] = 1;
+        return;
+    }
+    std::sort(used.begin(), used.end(), [&](int x, int y) { return freq[x] != freq[y] ? freq[x] < freq[y] : x < y; });
+    const int m = (int)used.size();
+    std::vector<Node> nodes;
+    nodes.reserve(2 * m);
+    for (int i = 0; i < m; ++i) nodes.push_back({freq[used[i]], used[i], -1, -1});
+    int leaf = 0, inner = m;
+    auto take = [&]() {
+        if (leaf < m && (inner >= (int)nodes.size() || nodes[leaf].w <= nodes[inner].w)) return leaf++;
+        return inner++;
+    };
+    while ((m - leaf) + ((int)nodes.size() - inner) > 1) {
+        const int a = take(), b = take();
+        nodes.push_back({nodes[a].w + nodes[b].w, -1, a, b});
+    }
+    std::vector<int> depth(nodes.size(), 0), cnt(64, 0);
+    for (int i = (int)nodes.size() - 1; i >= 0; --i) {
+        if (nodes[i].sym < 0) {
+            depth[nodes[i].a] = depth[i] + 1;
+            depth[nodes[i].b] = depth[i] + 1;
+        } else {
+            ++cnt[std::min(depth[i], 63)];
+        }
+    }
+    // repair: fold everything deeper than maxlen into maxlen, then restore the Kraft sum
+    for (int d = maxlen + 1; d < 64; ++d) {
+        cnt[maxlen] += cnt[d];
+        cnt[d] = 0;
+    }
+    uint64_t total = 0;
+    for (int d = maxlen; d >= 1; --d) total += (uint64_t)cnt[d] << (maxlen - d);
+    while (total > (1ull << maxlen)) {
+        --cnt[maxlen];
+        for (int d = maxlen - 1; d >= 1; --d)
+            if (cnt[d]) {
+                --cnt[d];
+                cnt[d + 1] += 2;
+                break;
+            }
+        --total;
+    }
+    // rarest symbols get the longest codes
+    int k = 0;
+    for (int d = maxlen; d >= 1; --d)
+        for (int c = 0; c < cnt[d]; ++c) len[used[k++]] = (uint8_t)d;
+}
+
+// canonical codes, bit-reversed for the LSB-first stream
+static void huff_codes(const uint8_t *len, int n, uint16_t *code) {
+    int bl[16] = {0};
+    for (int i = 0; i < n; ++i) ++bl[len[i]];
+    bl[0] = 0;
+    uint32_t next[16], c = 0;
+    for (int b = 1; b < 16; ++b) {
+        c = (c + bl[b - 1]) << 1;
+        next[b] = c;
+    }
+    for (int i = 0; i < n; ++i) {
+        if (!len[i]) {
+            code[i] = 0;
+            continue;
+        }
+        uint32_t v = next[len[i]]++, r = 0;
+        for (int b = 0; b < len[i]; ++b) r |= ((v >> b) & 1u) << (len[i] - 1 - b);
+        code[i] = (uint16_t)r;
+    }
+}
+
+struct RowDeflater {
+    std::vector<uint32_t> tok;  // literal: byte; match: 0x80000000 | length
+    // raw DEFLATE of src[0..n) with matches at distance `row` only; 0 when it does not fit
+    size_t run(const unsigned char *src, size_t n, unsigned row, unsigned char *dst, size_t cap) {
+        tok.clear();
+        uint32_t fl[286] = {0};
+        size_t i = 0;
+        bool any_match = false;
+        while (i < n) {
+            size_t L = 0;
+            if (i >= row) {
+                const size_t lim = std::min<size_t>(258, n - i);
+                while (L < lim && src[i + L] == src[i + L - row]) ++L;
+            }
+            if (L >= 3) {
+                int ls = 28;
+                while (LEN_BASE[ls] > L) --ls;
+                ++fl[257 + ls];
+                tok.push_back(0x80000000u | (uint32_t)L);
+                any_match = true;
+                i += L;
+            } else {
+                ++fl[src[i]];
+                tok.push_back(src[i]);
+                ++i;
+            }
+        }
+        fl[256] = 1;
+        uint8_t ll[286], dl[30] = {0};
+        uint16_t lc[286], dc[30] = {0};
+        huff_lengths(fl, 286, 15, ll);
+        huff_codes(ll, 286, lc);
+        int dsym = 0;
+        while (dsym < 29 && DIST_BASE[dsym + 1] <= row) ++dsym;
+        if (any_match) dl[dsym] = 1;  // a single distance code: one bit, code 0
+        int nlit = 286, ndist = any_match ? dsym + 1 : 1;
+        while (nlit > 257 && ll[nlit - 1] == 0) --nlit;
+        // code lengths of both alphabets, run-length coded with symbols 16 / 17 / 18
+        uint8_t all[286 + 30];
+        memcpy(all, ll, nlit);
+        memcpy(all + nlit, dl, ndist);
+        const int nall = nlit + ndist;
+        struct CL {
+            uint8_t sym, extra;
+        };
+        std::vector<CL> cl;
+        uint32_t cf[19] = {0};
+        for (int a = 0; a < nall;) {
+            int b = a;
+            while (b < nall && all[b] == all[a]) ++b;
+            int runlen = b - a;
+            if (all[a] == 0) {
+                while (runlen >= 11) {
+                    const int r = std::min(runlen, 138);
+                    cl.push_back({18, (uint8_t)(r - 11)});
+                    ++cf[18];
+                    runlen -= r;
+                }
+                if (runlen >= 3) {
+                    cl.push_back({17, (uint8_t)(runlen - 3)});
+                    ++cf[17];
+                    runlen = 0;
+                }
+            } else {
+                cl.push_back({all[a], 0});
+                ++cf[all[a]];
+                --runlen;
+                while (runlen >= 3) {
+                    const int r = std::min(runlen, 6);
+                    cl.push_back({16, (uint8_t)(r - 3)});
+                    ++cf[16];
+                    runlen -= r;
+                }
+            }
+            for (; runlen > 0; --runlen) {
+                cl.push_back({all[a], 0});
+                ++cf[all[a]];
+            }
+            a = b;
+        }
+        uint8_t cll[19];
+        uint16_t clc[19];
+        huff_lengths(cf, 19, 7, cll);
+        huff_codes(cll, 19, clc);
+        int ncl = 19;
+        while (ncl > 4 && cll[CL_ORDER[ncl - 1]] == 0) --ncl;
+        BitWriter bw(dst, cap);
+        bw.put(1, 1);  // BFINAL
+        bw.put(2, 2);  // dynamic Huffman
+        bw.put((uint32_t)(nlit - 257), 5);
+        bw.put((uint32_t)(ndist - 1), 5);
+        bw.put((uint32_t)(ncl - 4), 4);
+        for (int a = 0; a < ncl; ++a) bw.put(cll[CL_ORDER[a]], 3);
+        for (const CL &c : cl) {
+            bw.put(clc[c.sym], cll[c.sym]);
+            if (c.sym == 16) bw.put(c.extra, 2);
+            else if (c.sym == 17) bw.put(c.extra, 3);
+            else if (c.sym == 18) bw.put(c.extra, 7);
+        }
+        const uint32_t dextra = row - DIST_BASE[dsym];
+        for (uint32_t t : tok) {
+            if (t & 0x80000000u) {
+                const uint32_t L = t & 0xFFFFu;
+                int ls = 28;
+                while (LEN_BASE[ls] > L) --ls;
+                bw.put(lc[257 + ls], ll[257 + ls]);
+                if (LEN_EXTRA[ls]) bw.put(L - LEN_BASE[ls], LEN_EXTRA[ls]);
+                bw.put(dc[dsym], 1);
+                if (DIST_EXTRA[dsym]) bw.put(dextra, DIST_EXTRA[dsym]);
+            } else {
+                bw.put(lc[t], ll[t]);
+            }
+        }
+        bw.put(lc[256], ll[256]);
+        bw.flush();
+        return bw.overflow ? 0 : (size_t)(bw.p - dst);
+    }
+};
+
 // compress one block; returns total BGZF block length or 0 on error
-size_t deflate_block(Deflater &d, Deflater &stored, const unsigned char *src, size_t n, unsigned char *dst) {
+size_t deflate_block(Deflater &d, Deflater &stored, RowDeflater *rd, unsigned row, const unsigned char *src, size_t n,
+                     unsigned char *dst) {
     const size_t cap = MAX_CBLOCK - 18 - 8;
-    size_t clen = d.run(src, n, dst + 18, cap);
+    size_t clen = rd ? rd->run(src, n, row, dst + 18, cap) : 0;
+    if (!clen) clen = d.run(src, n, dst + 18, cap);
     if (!clen) clen = stored.run(src, n, dst + 18, cap);  // incompressible: level 0 always fits 65280 bytes
     if (!clen) return 0;
     const size_t total = clen + 18 + 8;
@@ -84,6 +325,7 @@ struct Pool {
     uint64_t gen = 0;
     bool quit = false;
     int level;
+    unsigned row = 0;  // > 0: rows of that many bytes, row-aware deflate
     // current job
     const unsigned char *data = nullptr;
     size_t nbytes = 0, nblk = 0;
@@ -92,16 +334,17 @@ struct Pool {
     std::atomic<size_t> next{0};
     size_t running = 0;
 
-    void work(Deflater &d, Deflater &stored) {
+    void work(Deflater &d, Deflater &stored, RowDeflater &rd) {
         for (;;) {
             const size_t i = next.fetch_add(1);
             if (i >= nblk) break;
             const size_t off = i * BLOCK, n = std::min(BLOCK, nbytes - off);
-            clen[i] = deflate_block(d, stored, data + off, n, cbuf + i * MAX_CBLOCK);
+            clen[i] = deflate_block(d, stored, row ? &rd : nullptr, row, data + off, n, cbuf + i * MAX_CBLOCK);
         }
     }
     void loop() {
         Deflater d(level), stored(0);
+        RowDeflater rd;
         uint64_t seen = 0;
         std::unique_lock<std::mutex> lk(mu);
         for (;;) {
@@ -109,12 +352,12 @@ struct Pool {
             if (quit) return;
             seen = gen;
             lk.unlock();
-            work(d, stored);
+            work(d, stored, rd);
             lk.lock();
             if (--running == 0) cv_done.notify_all();
         }
     }
-    Pool(int nthreads, int lvl) : level(lvl) {
+    Pool(int nthreads, int lvl, unsigned row_) : level(lvl), row(row_) {
         for (int t = 0; t < nthreads; ++t) th.emplace_back([this] { loop(); });
     }
     ~Pool() {
@@ -151,6 +394,7 @@ struct pg_bgzf {
     std::vector<unsigned char> cbuf;
     std::vector<size_t> clen;
     bool failed;
+    unsigned row;  // PG_BGZF_ROWS(width): row-aware deflate
     Pool *pool;
 };
 
@@ -165,9 +409,10 @@ static int flush_blocks(pg_bgzf *w, const unsigned char *data, size_t nbytes) {
     if (w->pool && nblk > 1) w->pool->run(data, nbytes, nblk, w->cbuf.data(), w->clen.data());
     else {
         Deflater d(w->level), stored(0);
+        RowDeflater rd;
         for (size_t i = 0; i < nblk; ++i)
-            w->clen[i] = deflate_block(d, stored, data + i * BLOCK, std::min(BLOCK, nbytes - i * BLOCK),
-                                       w->cbuf.data() + i * MAX_CBLOCK);
+            w->clen[i] = deflate_block(d, stored, w->row ? &rd : nullptr, w->row, data + i * BLOCK,
+                                       std::min(BLOCK, nbytes - i * BLOCK), w->cbuf.data() + i * MAX_CBLOCK);
     }
     for (size_t i = 0; i < nblk; ++i) {
         if (w->clen[i] == 0) return bfail(PG_E_IO, "deflate failed");
@@ -189,11 +434,12 @@ extern "C" int pg_bgzf_open(const char *path, int level, int nthreads, pg_bgzf *
     w->f = f;
     const int lv = level < 0 ? -1 : (level & 0xff);
     w->level = ((lv < 0 || lv > 9) ? 6 : lv) | (level > 0 ? (level & PG_BGZF_RLE) : 0);
+    w->row = level > 0 ? (unsigned)((level >> 16) & 0xff) : 0;
     w->nthreads = nthreads < 1 ? 1 : nthreads;
     w->cpos = w->upos = 0;
     w->batch_blocks = 256;  // 16 MiB of input per parallel batch whatever the thread count
     w->failed = false;
-    w->pool = w->nthreads > 1 ? new Pool(w->nthreads, w->level) : nullptr;
+    w->pool = w->nthreads > 1 ? new Pool(w->nthreads, w->level, w->row) : nullptr;
     *out = w;
     return PG_OK;
 }

@@ -420,6 +420,11 @@ class BgzfWriter:
 
     RLE = 0x100  # PG_BGZF_RLE: zlib's run-length strategy, OR-ed into level (one-byte rows)
 
+    @staticmethod
+    def ROWS(width: int) -> int:
+        """PG_BGZF_ROWS(width): row-aware deflate for rows of 2..255 bytes, OR-ed into level"""
+        return (width & 0xFF) << 16
+
     def __init__(self, path: str, level: int = 6, threads: int = 1):
         self._lib = _lib.load()
         h = C.c_void_p()

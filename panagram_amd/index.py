@@ -583,7 +583,8 @@ class Genome:
         os.makedirs(self.prefix, exist_ok=True)
         nthreads = bgzf_threads or self._bgzf_threads()
         tmp = {s: self.bitmap_gz_fname(s) + ".tmp" for s in self.steps}
-        level = 6 | (engine.BgzfWriter.RLE if self.nbytes == 1 else 0)  # one-byte rows: equal rows are byte runs
+        # one-byte rows: equal rows are byte runs (zlib RLE); wider rows: the row-aware encoder
+        level = 6 | (engine.BgzfWriter.RLE if self.nbytes == 1 else engine.BgzfWriter.ROWS(self.nbytes) if self.nbytes < 256 else 0)
         writers = {s: engine.BgzfWriter(tmp[s], level=level, threads=nthreads) for s in self.steps}
         for rows, rows100, _, _ in results:
             writers[1].write(rows)
@@ -769,7 +770,8 @@ def run_anchor_cli(argv: Sequence[str], device: int = 0) -> int:
         ss = engine.SeqSet.from_host(ctx, [s for _, s in recs])
         res = engine.AnchorResult(tbl, ss, colsums=False)
         res.run()
-        level = 6 | (engine.BgzfWriter.RLE if ngenomes <= 8 else 0)
+        nb_row = (ngenomes + 7) // 8
+        level = 6 | (engine.BgzfWriter.RLE if nb_row == 1 else engine.BgzfWriter.ROWS(nb_row) if nb_row < 256 else 0)
         w1 = engine.BgzfWriter(os.path.join(adir, "bitmap.1.gz"), level=level, threads=engine.usable_cpus())
         w100 = engine.BgzfWriter(os.path.join(adir, "bitmap.100.gz"), level=level, threads=2)
         with open(os.path.join(adir, "bitsum.bins.tsv"), "w") as fb, open(os.path.join(adir, "chrs.tsv"), "w") as fc:

@@ -207,7 +207,8 @@ def test_write_bgzf_from_hbm_equals_host_writer(ctx, tmp_path):
     for step, col in ((1, 0), (100, 1)):
         gz, gzi = str(tmp_path / f"b{step}.gz"), str(tmp_path / f"b{step}.gzi")
         res.write_bgzf(step, gz, gzi, level=6, threads=3)
-        w = engine.BgzfWriter(str(tmp_path / f"h{step}.gz"), level=6, threads=3)
+        # (write_bgzf picks the encoder by row width: 2-byte rows here -> the row-aware one)
+        w = engine.BgzfWriter(str(tmp_path / f"h{step}.gz"), level=6 | engine.BgzfWriter.ROWS(2), threads=3)
         for p in parts:
             w.write(p[col])
         w.close(str(tmp_path / f"h{step}.gzi"))

@@ -25,4 +25,15 @@ for G, L in ((8, 20_000_000), (27, 8_000_000), (64, 4_000_000)):
             out += len(c.compress(rows[i:i + 65280])) + len(c.flush())
         dt = time.perf_counter() - t0
         print(f"   {name:13s} {len(rows)/dt/1e6:7.1f} MB/s  ratio {len(rows)/out:.2f}")
+    import tempfile
+    nb = (G + 7) // 8
+    with tempfile.TemporaryDirectory() as d:
+        for name, level in (("writer zlib-6", 6), ("writer rle", 6 | engine.BgzfWriter.RLE), ("writer rows", 6 | engine.BgzfWriter.ROWS(nb))):
+            if nb == 1 and "rows" in name:
+                continue
+            p = os.path.join(d, "x.gz")
+            t0 = time.perf_counter()
+            w = engine.BgzfWriter(p, level=level, threads=1); w.write(rows); w.close()
+            dt = time.perf_counter() - t0
+            print(f"   {name:13s} {len(rows)/dt/1e6:7.1f} MB/s  ratio {len(rows)/os.path.getsize(p):.2f}")
     res.close(); ss.close(); tbl.close(); ctx.close()
