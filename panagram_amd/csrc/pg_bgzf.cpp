@@ -177,6 +177,18 @@ static void huff_codes(const uint8_t *len, int n, uint16_t *code) {
     }
 }
 
+struct LenSym {
+    uint8_t of[259];
+    LenSym() {
+        for (int L = 3; L <= 258; ++L) {
+            int ls = 28;
+            while (LEN_BASE[ls] > L) --ls;
+            of[L] = (uint8_t)ls;
+        }
+    }
+};
+static const LenSym LEN_SYM;
+
 struct RowDeflater {
     std::vector<uint32_t> tok;  // literal: byte; match: 0x80000000 | length
     // raw DEFLATE of src[0..n) with matches at distance `row` only; 0 when it does not fit
@@ -189,11 +201,21 @@ struct RowDeflater {
             size_t L = 0;
             if (i >= row) {
                 const size_t lim = std::min<size_t>(258, n - i);
+                while (L + 8 <= lim) {  // eight bytes at a time
+                    uint64_t x, y;
+                    memcpy(&x, src + i + L, 8);
+                    memcpy(&y, src + i + L - row, 8);
+                    if (x != y) {
+                        L += (size_t)(__builtin_ctzll(x ^ y) >> 3);
+                        goto matched;
+                    }
+                    L += 8;
+                }
                 while (L < lim && src[i + L] == src[i + L - row]) ++L;
+            matched:;
             }
             if (L >= 3) {
-                int ls = 28;
-                while (LEN_BASE[ls] > L) --ls;
+                const int ls = LEN_SYM.of[L];
                 ++fl[257 + ls];
                 tok.push_back(0x80000000u | (uint32_t)L);
                 any_match = true;
@@ -280,8 +302,7 @@ struct RowDeflater {
         for (uint32_t t : tok) {
             if (t & 0x80000000u) {
                 const uint32_t L = t & 0xFFFFu;
-                int ls = 28;
-                while (LEN_BASE[ls] > L) --ls;
+                const int ls = LEN_SYM.of[L];
                 bw.put(lc[257 + ls], ll[257 + ls]);
                 if (LEN_EXTRA[ls]) bw.put(L - LEN_BASE[ls], LEN_EXTRA[ls]);
                 bw.put(dc[dsym], 1);
