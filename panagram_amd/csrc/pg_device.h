@@ -242,19 +242,32 @@ __device__ __forceinline__ int lane_insert(const SubTable &st, uint64_t key, int
     uint32_t step = step_of_group(grp, st.nbuckets);
     for (uint32_t probes = 0; probes < max_probe; ++probes) {
         uint8_t *base = st.buckets + (uint64_t)b * (16u * st.slots);
-        for (int s = 0; s < (int)st.slots; ++s) {
-            unsigned long long *kp = reinterpret_cast<unsigned long long *>(base + key_off(st.W, s));
-            unsigned long long cur = *kp;  // a stale EMPTY only costs a failed CAS
+        for (uint32_t s0 = 0; s0 < st.slots; s0 += 8) {  // 8 slots at a time: all key loads in flight together
+            uint8_t *grp8 = base + 16u * s0;
+            uint64_t kk[8];
+#pragma unroll
+            for (int s = 0; s < 8; ++s) kk[s] = *reinterpret_cast<const volatile unsigned long long *>(grp8 + 16 * s);
+            int hit = -1, free_s = -1;
+#pragma unroll
+            for (int s = 7; s >= 0; --s) {
+                hit = (kk[s] == key) ? s : hit;
+                free_s = (kk[s] == EMPTY_KEY) ? s : free_s;  // first empty slot (lines fill front to back)
+            }
             int claimed = 0;
-            if (cur == EMPTY_KEY) {
-                cur = atomicCAS(kp, (unsigned long long)EMPTY_KEY, (unsigned long long)key);
+            // slots before the first empty one hold other keys for good; from there on a slot may be
+            // taken by a concurrent insert between our read and our CAS: walk on, one CAS per slot
+            for (int s = (hit >= 0 ? hit : free_s); hit < 0 && s >= 0 && s < 8; ++s) {
+                unsigned long long *kp = reinterpret_cast<unsigned long long *>(grp8 + 16 * s);
+                const unsigned long long cur = atomicCAS(kp, (unsigned long long)EMPTY_KEY, (unsigned long long)key);
                 if (cur == EMPTY_KEY) {
-                    cur = key;
+                    hit = s;
                     claimed = 1;
+                } else if (cur == key) {
+                    hit = s;
                 }
             }
-            if (cur == key) {
-                uint32_t *mp = reinterpret_cast<uint32_t *>(base + mask_off(st.W, s, w));
+            if (hit >= 0) {
+                uint32_t *mp = reinterpret_cast<uint32_t *>(grp8 + 16 * hit + 8 + 4 * w);
                 if (COUNT) {
                     if (*mp < 0xFFFFFF00u) atomicAdd(mp, bits);  // saturates far above any -ci threshold
                 } else if ((*mp & bits) != bits) {
