@@ -4,30 +4,32 @@
 // KMCdb::write_bits (cpp/anchor.cpp:112-195) and Genome._write_bitmap / _query_kmc_bytes /
 // bin_bitsum (index.py:932-969,1169-1183).
 //
-// Three lean kernels per (anchor seqset, sub-table); instruction count per position is what
-// bounds them once the table fetches are shared between neighbouring positions:
+// Two lean kernels per (result, sub-table); instruction count per position is what bounds them once
+// the table fetches are shared between neighbouring positions (minimizer homes) and between the
+// anchor genomes of a pangenome (co-scheduled tiles):
 //
-//   k_probe      ONE WAVE = one tile of TILE consecutive k-mer positions, no barriers.
-//                Per batch of 64 lanes (lane = one position, neighbours = neighbouring positions):
+//   k_probe      ONE WAVE = one tile of TILE consecutive k-mer positions, no barriers, 4.6 KB of LDS
+//                (32 waves per CU).  Per batch of 64 lanes (lane = one position, neighbours =
+//                neighbouring positions):
 //                  * canonical k-mer from the LDS-staged 2-bit sequence (~0.25 B/pos from HBM)
 //                  * minimizer = sliding minimum over the W_C m-mer ranks of the neighbouring
-//                    lanes (wave shuffles) -> home line; runs of equal home line are found with
+//                    lanes (DPP wave shifts) -> home line; runs of equal home line are found with
 //                    one ballot (leaders) and numbered with mbcnt
-//                  * LDS-STAGED PROBE BATCH: the batch's distinct table lines (~13-17 for 57
+//                  * LDS-STAGED PROBE BATCH: the batch's distinct table lines (~15 for 58
 //                    positions) are fetched cooperatively and coalesced — 8 lanes x 16 B = one
 //                    128-byte line — into a per-wave LDS buffer, then every lane scans the 8
 //                    slots of ITS line out of LDS
-//                  * the presence row goes straight to bitmap.1; a key absent from a FULL line is
-//                    appended to the tile's overflow worklist (next line of its probe sequence)
-//   k_fixup      dense passes over the overflow worklists (one lane = one entry, 8 slot loads in
-//                flight); found masks are patched into bitmap.1, still-unresolved entries move to
-//                the next pass; the last pass chases inline.
+//                  * the presence row goes straight to bitmap.1; a key absent from a FULL line
+//                    joins the tile's in-wave overflow queue (position, next line, step), which
+//                    drain_queue works off in dense 64-entry batches, level by level
 //   k_epilogue   streaming statistics from the finished bitmap.1 rows: bitmap.100 (1-in-100
-//                rows), per-bin popcount histogram (wave ballots -> LDS -> global), per-genome
-//                column sums.
+//                rows), per-bin popcount histogram, per-contig column sums — persistent
+//                workgroups, register accumulators, one instantiation per row width.
+//   k_window_stats, k_cols_extract / k_cols_merge: side paths (gene / bin windows; the
+//                genome-sharded exchange).
 //
-// Bytes from HBM per position: 0.25 (sequence) + 128 x (distinct lines per
-// position, ~0.25 with minimizer locality) + row bytes written + row bytes re-read.
+// Bytes from HBM per position: 0.25 (sequence) + 128 x (lines missed in L2 per
+// position: 0.34 with one launch per genome, 0.095 co-scheduled) + row bytes written + re-read.
 #include "pg_kernels.h"
 
 namespace pg {
@@ -110,14 +112,6 @@ __device__ __forceinline__ void store_row(uint8_t *row, uint32_t m0, uint32_t m1
 __device__ __forceinline__ uint32_t lane_up1(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
 }
-template <int D>
-__device__ __forceinline__ uint32_t lane_up(uint32_t v) {  // value of lane-D for lanes >= D (others: unspecified)
-    uint32_t r = v;
-#pragma unroll
-    for (int i = 0; i < D; ++i) r = lane_up1(r);
-    return r;
-}
-
 // inclusive count of set bits of `mask` at lanes <= this lane
 __device__ __forceinline__ uint32_t lanes_le_count(unsigned long long mask, bool own) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u)) + (own ? 1u : 0u);

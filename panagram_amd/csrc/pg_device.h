@@ -5,7 +5,7 @@
 //            the request size (tools/gather_bench.hip: 32/64/128-B random gathers all run at
 //            ~50 G requests/s), so a probe fetches — and uses — a whole line
 //          = 8 slots x { u64 key ; u32 mask0 ; u32 mask1 }   (mask1 unused when W == 1);
-//            256-byte lines of 16 slots where minimizer groups are bigger (k >= 28, N > 32)
+//            256-byte lines of 16 slots exist as a tuning knob (PG_TABLE_SLOTS=16)
 //   k_probe fetches a line once per run of positions (8 or 16 lanes x 16 B, coalesced) into LDS
 //   and every lane scans its line's slots there.
 //   EMPTY key = ~0 (never a canonical k-mer for k <= 32: the all-T k-mer's reverse complement
@@ -16,9 +16,10 @@
 // MINIMIZER: the smallest (in a scrambled order) canonical m-mer among its w = k-m+1 m-mers
 // (w = 3..8, see minimizer_length).  Consecutive k-mers of a sequence share their minimizer for
 // ~(w+1)/2 positions, so consecutive anchor positions probe the SAME line: one HBM fetch
-// serves a run of positions (L1/L2 absorb the repeats).  Other k fall back to hashing the
-// k-mer itself (m = 0).  Collisions: linear probing by line; a lookup moves to the next line
-// only when the key is absent AND the line has no EMPTY slot.
+// serves a run of positions.  Other k fall back to hashing the k-mer itself (m = 0).
+// Collisions: double hashing by line — the group's own sequence for its first GROUP_CHAIN lines, the
+// key's own sequence beyond (advance_line); a lookup moves to the next line only when the key is
+// absent AND the line has no EMPTY slot.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -26,8 +27,8 @@
 namespace pg {
 
 constexpr uint64_t EMPTY_KEY = ~0ull;
-// slots per table line: 8 (128-byte lines) or 16 (256-byte lines, for k >= 28 / many genomes,
-// where a minimizer group holds more keys); a property of the sub-table (SubTable::slots)
+// slots per table line: 8 (128-byte lines) or 16 (256-byte lines, tuning knob); a property of the
+// sub-table (SubTable::slots)
 constexpr int MAX_SUB = 8;  // sub-tables per pan table => up to 512 genomes
 
 struct SubTable {

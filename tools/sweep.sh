@@ -3,7 +3,7 @@
 # SWEEP_CFGS="defs,kpb ..."  (defs separated by ':'), SWEEP_ARGS = extra bench.py arguments
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
 OUT=gpurun_out/sweep.txt; : > $OUT
-for cfg in ${SWEEP_CFGS:-"-DPG_MZ_WINDOW=6,2.0" "-DPG_MZ_WINDOW=4,2.0" "-DPG_MZ_WINDOW=5,2.0" "-DPG_MZ_WINDOW=7,2.0" "-DPG_MZ_WINDOW=3,2.0"}; do
+for cfg in ${SWEEP_CFGS:-"-DPG_PROBE_QCAP=192,2.0" "-DPG_PROBE_QCAP=128,2.0" "-DPG_PROBE_TILE=256,2.0" "-DPG_PROBE_STAGED_LEVELS=1,2.0"}; do
   IFS=, read DEFS K <<< "$cfg"
   python panagram_amd/build.py --force ${DEFS//:/ } 2>/dev/null
   for A in "${SWEEP_ARGSETS[@]:-}"; do
