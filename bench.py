@@ -268,6 +268,10 @@ def main():
             "hbm_read_frac": (pos_per_launch * (0.25 + 64.0 * P) / avg_launch_s) / HBM_PEAK,
             "traffic": traffic,
             "algorithmic_bytes_per_launch": per_launch_bytes,
+            "note": "algorithmic bytes price one 64-byte table fetch per position (SURVEY 8d); minimizer-keyed "
+                    "lines serve runs of positions and, co-scheduled, all anchor genomes share them in L2, so "
+                    "the measured HBM bytes (traffic) are far fewer and frac can exceed 1; past that point "
+                    "k_probe is VALU-issue bound (DESIGN.md section 4)",
         },
     }
 
