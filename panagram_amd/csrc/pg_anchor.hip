@@ -32,6 +32,8 @@
 // position: 0.34 with one launch per genome, 0.095 co-scheduled) + row bytes written + re-read.
 #include "pg_kernels.h"
 
+#include <algorithm>
+
 namespace pg {
 
 constexpr int PROBE_SEQW = ((PROBE_TILE + 31) / 32 + 6 + 3) & ~3;  // staged 32-base words per tile
@@ -426,7 +428,7 @@ __device__ __forceinline__ void hist_position(bool active, uint32_t pos, uint32_
 }
 
 #ifndef PG_EPI_MIN_TILES
-#define PG_EPI_MIN_TILES 32
+#define PG_EPI_MIN_TILES 128
 #endif
 constexpr int EPI_THREADS = PROBE_TILE / 4;
 
@@ -988,9 +990,13 @@ hipError_t launch_rows_epilogue(hipStream_t st, uint32_t ngenomes, const AnchorD
     if (ntiles == 0) return hipSuccess;
     size_t lds = (((EPI_MAXB * (ngenomes + 1) + 3) & ~3u) + ((ngenomes + 3) & ~3u)) * 4 + 16;
     // contiguous tile ranges per workgroup: enough workgroups to fill every CU, but no fewer than
-    // PG_EPI_MIN_TILES tiles each so that the end-of-range reductions stay amortised
+    // a minimum number of tiles each so that the end-of-range reductions stay amortised
     const uint32_t maxg = 256u * (2048u / EPI_THREADS);
+    // long ranges (PG_EPI_MIN_TILES tiles) keep the pass light beside a concurrent k_probe; but never
+    // fewer than ~1024 workgroups (4 per CU) as long as each still gets 16 tiles, or small inputs
+    // turn latency-bound
     uint32_t grid = (ntiles + PG_EPI_MIN_TILES - 1) / PG_EPI_MIN_TILES;
+    grid = std::max(grid, std::min(1024u, ntiles / 16u));
     grid = grid < 1 ? 1 : (grid > maxg ? maxg : grid);
     const uint32_t nbytes = (ngenomes + 7) / 8;
     if (nbytes == 1)
