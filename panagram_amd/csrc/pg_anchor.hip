@@ -100,9 +100,11 @@ __device__ __forceinline__ void store_row(uint8_t *row, uint32_t m0, uint32_t m1
         row[0] = (uint8_t)m0;
     } else if (ROWMODE == 2) {
         *reinterpret_cast<uint2 *>(row) = make_uint2(m0, m1);
-    } else if (rc.words) {  // wave-uniform
+    } else if (rc.words == 1) {  // wave-uniform
         *reinterpret_cast<uint32_t *>(row + rc.col0) = m0;
         if (rc.nb1) *reinterpret_cast<uint32_t *>(row + rc.col0 + 4) = m1;
+    } else if (rc.words == 2) {  // two-byte rows (9..16 genomes): one aligned 16-bit store
+        *reinterpret_cast<uint16_t *>(row) = (uint16_t)m0;
     } else {
         for (uint32_t bb = 0; bb < rc.nb0; ++bb) row[rc.col0 + bb] = (uint8_t)(m0 >> (8 * bb));
         for (uint32_t bb = 0; bb < rc.nb1; ++bb) row[rc.col0 + 4 + bb] = (uint8_t)(m1 >> (8 * bb));
@@ -966,7 +968,7 @@ hipError_t launch_anchor(hipStream_t s, const TableDesc &T, const uint64_t *seqw
         rc.col0 = 4 * st.word0;
         rc.nb0 = min(4u, nbytes - rc.col0);
         rc.nb1 = (st.W == 2 && nbytes > rc.col0 + 4) ? min(4u, nbytes - rc.col0 - 4) : 0;
-        rc.words = (nbytes % 4 == 0 && rc.nb0 == 4 && (rc.nb1 == 0 || rc.nb1 == 4)) ? 1u : 0u;
+        rc.words = (nbytes % 4 == 0 && rc.nb0 == 4 && (rc.nb1 == 0 || rc.nb1 == 4)) ? 1u : (nbytes == 2 ? 2u : 0u);
         const int rm = (T.nsub == 1) ? row_mode(nbytes, rc) : 0;
         const uint32_t w = st.m ? st.k - st.m + 1 : 0;
         switch (w) {  // the kernel's compile-time window must be the one the table was built with

@@ -243,7 +243,7 @@ extern "C" int pg_table_create(pg_ctx *ctx, int k, int ngenomes, uint64_t expect
     t->k = k;
     t->ngenomes = ngenomes;
     t->ndbs = ndbs;
-    t->m = minimizer_length((uint32_t)k, expected_keys);
+    t->m = minimizer_length((uint32_t)k, expected_keys, (uint32_t)ngenomes);
     t->d_counters = nullptr;
     hipError_t e = hipMalloc(reinterpret_cast<void **>(&t->d_counters), 2 * sizeof(unsigned long long));
     if (e != hipSuccess) {
@@ -599,7 +599,7 @@ extern "C" int pg_table_rehash(pg_table *t, double keys_per_bucket) {
     if (!t->m_pinned) {  // the key count is known now: settle the minimizer length for it
         uint64_t most = 0;
         for (auto &s : t->subs) most = std::max<uint64_t>(most, s.count);
-        t->m = minimizer_length((uint32_t)t->k, most);
+        t->m = minimizer_length((uint32_t)t->k, most, (uint32_t)t->ngenomes);
     }
     // Line width: 128-byte lines of 8 slots.  256-byte lines of 16 slots (PG_TABLE_SLOTS=16, a tuning
     // knob) keep a many-variant locus in ONE place at the price of two requests per line; measured,

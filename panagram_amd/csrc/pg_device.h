@@ -54,21 +54,27 @@ __host__ __device__ __forceinline__ uint32_t key_off(uint32_t, int s) { return 1
 __host__ __device__ __forceinline__ uint32_t mask_off(uint32_t, int s, int w) { return 16u * s + 8u + 4u * w; }
 
 // Minimizer geometry of a table: w m-mers of m = k-w+1 bases per k-mer (m = 0: hash the k-mer
-// itself, k < 20).  Measured on MI355X: w = 7-8 is the sweet spot between small
-// minimizer groups (few keys spill out of their home line) and long runs of positions per fetched
-// line — PROVIDED the m-mers stay long enough that distinct loci rarely share one: with 4^m below
-// ~4x the number of keys the groups merge and throughput collapses (k=21 on 100 Mb genomes: m=15
-// 100 G k-mers/s, m=14 84 G, m=13 23 G).  So m is the larger of k-7 and ceil(log4(4*expected keys)),
-// and w = k-m+1 is kept in 3..8.  m-mers longer than 16 bases use 64-bit arithmetic.
+// itself, k < 20).  Two forces (measured on MI355X):
+//  * a wide window gives long runs of positions per fetched line, a narrow one gives small
+//    minimizer groups (a group = all variants of a locus, from every genome) that fit their home
+//    line.  With few genomes the fetches weigh more: w = 8 (k=31, 8 genomes: 138 G k-mers/s vs 127 at
+//    w = 4).  With many genomes the groups outgrow a line and, co-scheduled, the lines come from L2
+//    anyway: w = 4 (64 genomes k=21: 89 G vs 61 at w = 7; 40 genomes: 63 vs 48; 16: 89 vs 86).
+//  * the m-mers must stay long enough that distinct loci rarely share one: with 4^m below ~4x the
+//    number of keys the groups merge and throughput collapses (k=21, 100 Mb genomes: m=15 100 G
+//    k-mers/s, m=14 84 G, m=13 23 G).
+// So m = max(k - w_target + 1, ceil(log4(4 * keys))) with w_target = 8 up to 8 genomes and 4 beyond,
+// w = k-m+1 kept in 3..8.  m-mers longer than 16 bases use 64-bit arithmetic.
 constexpr uint32_t MZ_WMIN = 3, MZ_WMAX = 8;
-__host__ __device__ __forceinline__ uint32_t minimizer_length(uint32_t k, uint64_t expected_keys) {
+__host__ __device__ __forceinline__ uint32_t minimizer_length(uint32_t k, uint64_t expected_keys, uint32_t ngenomes) {
     if (k < 20 || k > 32) return 0;
     uint32_t m_need = 16;  // unknown cardinality: good up to ~1e9 keys
     if (expected_keys) {
         m_need = 15;
         while (m_need < 27 && (1ull << (2 * m_need)) < 4 * expected_keys) ++m_need;
     }
-    uint32_t m = k - (MZ_WMAX - 1);
+    const uint32_t w_target = ngenomes <= 8 ? MZ_WMAX : 4u;
+    uint32_t m = k - (w_target - 1);
     if (m < m_need) m = m_need;
     if (m > k - (MZ_WMIN - 1)) m = k - (MZ_WMIN - 1);
     return m;

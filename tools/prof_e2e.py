@@ -2,7 +2,10 @@ import cProfile, pstats, os, sys, tempfile, time
 sys.path.insert(0, os.getcwd())
 from oracle import pyoracle as po
 from panagram_amd import engine, index as pidx
-L, G, k = 100_000_000, 8, 21
+import argparse
+ap = argparse.ArgumentParser(); ap.add_argument('--genomes', type=int, default=8); ap.add_argument('--mb', type=float, default=100.0)
+a = ap.parse_args()
+L, G, k = int(a.mb * 1e6), a.genomes, 21
 gen = po.synth_genomes(G, [L // 5] * 5, 0.01, 1234)
 genomes = [[po.codes_to_ascii(c) for c in g] for g in gen]
 with tempfile.TemporaryDirectory() as d:
