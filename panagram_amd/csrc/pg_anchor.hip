@@ -105,6 +105,20 @@ __device__ __forceinline__ void store_row(uint8_t *row, uint32_t m0, uint32_t m1
         if (rc.nb1) *reinterpret_cast<uint32_t *>(row + rc.col0 + 4) = m1;
     } else if (rc.words == 2) {  // two-byte rows (9..16 genomes): one aligned 16-bit store
         *reinterpret_cast<uint16_t *>(row) = (uint16_t)m0;
+    } else if (rc.words == 3) {  // rows of 3, 5, 6 or 7 bytes: two stores at byte alignment (gfx950 global
+                                 // memory takes unaligned dword / short accesses), not one per byte
+        struct __attribute__((packed)) U32 { uint32_t v; };
+        struct __attribute__((packed)) U16 { uint16_t v; };
+        const uint32_t nb = rc.nb0 + rc.nb1;  // wave-uniform
+        if (nb == 3) {
+            reinterpret_cast<U16 *>(row)->v = (uint16_t)m0;
+            row[2] = (uint8_t)(m0 >> 16);
+        } else {
+            reinterpret_cast<U32 *>(row)->v = m0;
+            if (nb == 5) row[4] = (uint8_t)m1;
+            else if (nb == 6) reinterpret_cast<U16 *>(row + 4)->v = (uint16_t)m1;
+            else reinterpret_cast<U32 *>(row + 3)->v = (m0 >> 24) | (m1 << 8);  // bytes 3..6 (byte 3 again)
+        }
     } else {
         for (uint32_t bb = 0; bb < rc.nb0; ++bb) row[rc.col0 + bb] = (uint8_t)(m0 >> (8 * bb));
         for (uint32_t bb = 0; bb < rc.nb1; ++bb) row[rc.col0 + 4 + bb] = (uint8_t)(m1 >> (8 * bb));
@@ -429,6 +443,27 @@ __device__ __forceinline__ void hist_position(bool active, uint32_t pos, uint32_
     }
 }
 
+// four consecutive rows of NB bytes = NB aligned 32-bit words (a thread's first row starts at a
+// multiple of 4 rows): load the words, cut the rows out with static shifts
+template <int NB>
+__device__ __forceinline__ void load4_rows(const uint8_t *g4, uint32_t w0[4], uint32_t w1[4]) {
+    uint32_t w[NB + 1];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) w[i] = reinterpret_cast<const uint32_t *>(g4)[i];
+    w[NB] = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        constexpr uint64_t keep = NB >= 8 ? ~0ull : ((1ull << (8 * (NB & 7))) - 1);
+        const int off = j * NB, idx = off >> 2, sh = 8 * (off & 3);
+        uint64_t v = (uint64_t)w[idx] >> sh;
+        if (idx + 1 <= NB) v |= (uint64_t)w[idx + 1] << (32 - sh);
+        if (sh && idx + 2 <= NB) v |= (uint64_t)w[idx + 2] << (64 - sh);
+        v &= keep;
+        w0[j] = (uint32_t)v;
+        w1[j] = (uint32_t)(v >> 32);
+    }
+}
+
 #ifndef PG_EPI_MIN_TILES
 #define PG_EPI_MIN_TILES 128
 #endif
@@ -741,6 +776,15 @@ __global__ __launch_bounds__(EPI_THREADS) void k_epilogue(uint32_t N, const Anch
                     w0[j] = q.x;
                     w1[j] = q.y;
                 }
+            } else if (p0 + 3 < npos) {  // odd widths: whole words, rows cut out with static shifts
+                const uint8_t *g4 = g + (uint64_t)p0 * nbytes;
+                switch (nbytes) {  // block-uniform
+                    case 2: load4_rows<2>(g4, w0, w1); break;
+                    case 3: load4_rows<3>(g4, w0, w1); break;
+                    case 5: load4_rows<5>(g4, w0, w1); break;
+                    case 6: load4_rows<6>(g4, w0, w1); break;
+                    default: load4_rows<7>(g4, w0, w1); break;
+                }
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -969,6 +1013,7 @@ hipError_t launch_anchor(hipStream_t s, const TableDesc &T, const uint64_t *seqw
         rc.nb0 = min(4u, nbytes - rc.col0);
         rc.nb1 = (st.W == 2 && nbytes > rc.col0 + 4) ? min(4u, nbytes - rc.col0 - 4) : 0;
         rc.words = (nbytes % 4 == 0 && rc.nb0 == 4 && (rc.nb1 == 0 || rc.nb1 == 4)) ? 1u : (nbytes == 2 ? 2u : 0u);
+        if (T.nsub == 1 && (nbytes == 3 || (nbytes >= 5 && nbytes <= 7))) rc.words = 3u;
         const int rm = (T.nsub == 1) ? row_mode(nbytes, rc) : 0;
         const uint32_t w = st.m ? st.k - st.m + 1 : 0;
         switch (w) {  // the kernel's compile-time window must be the one the table was built with

@@ -27,7 +27,8 @@ constexpr int PROBE_QCAP = PG_PROBE_QCAP;      // per-tile LDS overflow queue (b
 
 // which row bytes a sub-table writes: low nb0 bytes of mask word 0 at column col0, low nb1 bytes
 // of mask word 1 at col0+4; words: 1 = rows are a whole number of 32-bit words, so a full mask word
-// goes out as one aligned store; 2 = two-byte rows, one aligned 16-bit store; 0 = byte stores
+// goes out as one aligned store; 2 = two-byte rows, one aligned 16-bit store; 3 = whole rows of 3/5/6/7 bytes in two byte-aligned stores;
+// 0 = byte stores
 struct RowCols {
     uint32_t col0, nb0, nb1, words;
 };
