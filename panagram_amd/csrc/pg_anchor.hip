@@ -482,18 +482,28 @@ __device__ __forceinline__ void flush_hist(uint32_t N, uint32_t *hist, uint32_t 
     }
 }
 
-// MODE 0: one-byte rows (N <= 8), 1: rows of 2..8 bytes (N <= 64), 2: wider rows.  One instantiation
+// MODE 0: one-byte rows (N <= 8), 1: rows of 2..8 bytes (N <= 64), 3: wider rows, one launch per 64
+// genomes (2: the all-generic fallback, no longer launched).  One instantiation
 // per mode so that each carries only its own accumulators in registers.
 template <int MODE>
 __global__ __launch_bounds__(EPI_THREADS) void k_epilogue(uint32_t N, const AnchorDesc *__restrict__ ad,
                                                           const uint32_t *__restrict__ tile_contig, uint32_t ntiles,
                                                           const uint8_t *__restrict__ out1, uint8_t *__restrict__ out100,
                                                           uint32_t *__restrict__ bins,
-                                                          unsigned long long *__restrict__ colsums, uint32_t flags) {
+                                                          unsigned long long *__restrict__ colsums, uint32_t flags,
+                                                          uint32_t pair) {
     extern __shared__ uint4 smem[];
     constexpr int PT = 4;  // rows per thread and tile: EPI_THREADS = PROBE_TILE / 4 threads per workgroup
+    constexpr bool WIDE = MODE == 1 || MODE == 3;
     const int tid = threadIdx.x, lane = tid & 63;
-    const uint32_t nbytes = (N + 7) / 8, ndbs = (N + 31) / 32;
+    const uint32_t nbytes = (N + 7) / 8;
+    // MODE 3 (rows wider than 8 bytes): one launch per pair of 32-genome words; this launch sums the
+    // columns of genomes [g_base, g_base + Nw) — bytes [8 pair, 8 pair + 8) of every row — and launch 0
+    // also does the popcount histogram and bitmap.100 of the whole rows
+    const uint32_t g_base = MODE == 3 ? 64u * pair : 0u;
+    const uint32_t Nw = MODE == 3 ? min(64u, N - g_base) : N;
+    const uint32_t ndbs = MODE == 3 ? (Nw + 31) / 32 : (N + 31) / 32;
+    const uint32_t nbw = MODE == 3 ? (Nw + 7) / 8 : nbytes;  // bytes of a row this launch sums
     uint32_t *hist = reinterpret_cast<uint32_t *>(smem);
     uint32_t *cs = hist + ((EPI_MAXB * (N + 1) + 3) & ~3u);
     for (uint32_t i = tid; i < EPI_MAXB * (N + 1); i += EPI_THREADS) hist[i] = 0;
@@ -565,8 +575,8 @@ __global__ __launch_bounds__(EPI_THREADS) void k_epilogue(uint32_t N, const Anch
             if ((lane & 3) == 0) {  // this lane holds register (lane >> 2): q = idx / 2, odd idx = bytes 1 and 3
                 const uint32_t idx = (uint32_t)lane >> 2;
                 const uint32_t g0 = 32 * ws + (idx >> 1) + ((idx & 1) ? 8u : 0u);
-                if (g0 < N && (R[0] & 0xFFFFu)) atomicAdd(&cs[g0], R[0] & 0xFFFFu);
-                if (g0 + 16 < N && (R[0] >> 16)) atomicAdd(&cs[g0 + 16], R[0] >> 16);
+                if (g0 < Nw && (R[0] & 0xFFFFu)) atomicAdd(&cs[g0], R[0] & 0xFFFFu);
+                if (g0 + 16 < Nw && (R[0] >> 16)) atomicAdd(&cs[g0 + 16], R[0] >> 16);
             }
         }
         brounds = 0;
@@ -614,15 +624,18 @@ __global__ __launch_bounds__(EPI_THREADS) void k_epilogue(uint32_t N, const Anch
                 cacc[gb] = 0;
             }
         }
-        if constexpr (MODE == 1) {
+        if constexpr (WIDE) {
             if (vrows) vflush();
             if (brounds) wave_colsums();
         }
         __syncthreads();
-        for (uint32_t i = tid; i < N; i += EPI_THREADS) {
+        // cs[] is indexed relative to g_base (0 unless MODE 3 with pair > 0, where only the wide path
+        // runs); launch 0 of MODE 3 also carries the generic path's sums of all N genomes
+        const uint32_t ncs = (MODE == 3 && pair > 0) ? Nw : N;
+        for (uint32_t i = tid; i < ncs; i += EPI_THREADS) {
             const uint32_t v = cs[i];
             if (v) {
-                atomicAdd(&colsums[(uint64_t)contig * N + i], (unsigned long long)v);
+                atomicAdd(&colsums[(uint64_t)contig * N + g_base + i], (unsigned long long)v);
                 cs[i] = 0;
             }
         }
@@ -753,11 +766,26 @@ __global__ __launch_bounds__(EPI_THREADS) void k_epilogue(uint32_t N, const Anch
                 const uint32_t first = r100 * 100u;
                 if (first < pos0 + nact) out100[a.out100_off + r100] = (uint8_t)(packed >> (8 * (first - pos0)));
             }
-        } else if (MODE == 1 && windowed) {
-            // ---- wide path (N <= 64): rows as one or two 32-bit words ----
+        } else if (WIDE && windowed) {
+            // ---- wide path: the row bytes this launch sums, as one or two 32-bit words ----
             next_valid = false;
             uint32_t w0[PT], w1[PT];
-            if (nbytes == 4) {
+            if (MODE == 3) {  // 8 (or fewer, last pair) bytes at column 8*pair of rows nbytes apart
+                struct __attribute__((packed)) U64 { uint64_t v; };
+                const uint8_t *gc = g + 8u * pair;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    uint64_t r = 0;
+                    if (p0 + j < npos) {
+                        const uint8_t *pr = gc + (uint64_t)(p0 + j) * nbytes;
+                        if (nbw == 8) r = reinterpret_cast<const U64 *>(pr)->v;
+                        else
+                            for (uint32_t bb = 0; bb < nbw; ++bb) r |= (uint64_t)pr[bb] << (8 * bb);
+                    }
+                    w0[j] = (uint32_t)r;
+                    w1[j] = (uint32_t)(r >> 32);
+                }
+            } else if (nbytes == 4) {
                 uint4 q = make_uint4(0, 0, 0, 0);
                 if (p0 + 3 < npos) q = *reinterpret_cast<const uint4 *>(g + (uint64_t)p0 * 4);
                 else {
@@ -796,14 +824,31 @@ __global__ __launch_bounds__(EPI_THREADS) void k_epilogue(uint32_t N, const Anch
                 }
             }
             const uint32_t nact = p0 < npos ? min(4u, npos - p0) : 0u;
+            if (MODE == 1 || pair == 0) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if ((uint32_t)j < nact) {
-                    const uint32_t pcj = min((uint32_t)(__popc(w0[j]) + __popc(w1[j])), N);
-                    atomicAdd(&hist[(rel_base + rel_of(tile_start + p0 + j)) * (N + 1) + pcj], 1u);
+                for (int j = 0; j < 4; ++j) {
+                    if ((uint32_t)j < nact) {
+                        uint32_t pc = __popc(w0[j]) + __popc(w1[j]);
+                        if (MODE == 3) {  // the rest of the row
+                            const uint8_t *pr = g + (uint64_t)(p0 + j) * nbytes;
+                            for (uint32_t bb = 8; bb < nbytes; ++bb) pc += __popc((uint32_t)pr[bb]);
+                        }
+                        atomicAdd(&hist[(rel_base + rel_of(tile_start + p0 + j)) * (N + 1) + min(pc, N)], 1u);
+                    }
                 }
             }
-            if (nact) {  // 1-in-100 rows: at most one of 4 consecutive positions is a multiple of 100
+            if (MODE == 3) {  // bitmap.100 of the whole row, by launch 0
+                if (pair == 0 && nact) {
+                    const uint32_t pos0 = tile_start + p0;
+                    const uint32_t r100 = (pos0 + 99u) / 100u;
+                    const uint32_t jsel = r100 * 100u - pos0;
+                    if (jsel < nact) {
+                        const uint8_t *pr = g + (uint64_t)(p0 + jsel) * nbytes;
+                        uint8_t *o100 = out100 + a.out100_off + (uint64_t)r100 * nbytes;
+                        for (uint32_t bb = 0; bb < nbytes; ++bb) o100[bb] = pr[bb];
+                    }
+                }
+            } else if (nact) {  // 1-in-100 rows: at most one of 4 consecutive positions is a multiple of 100
                 const uint32_t pos0 = tile_start + p0;
                 const uint32_t r100 = (pos0 + 99u) / 100u;
                 const uint32_t jsel = r100 * 100u - pos0;
@@ -825,8 +870,9 @@ __global__ __launch_bounds__(EPI_THREADS) void k_epilogue(uint32_t N, const Anch
                 vrows += PT;
                 if (vrows == 12) vflush();
             }
-        } else {
+        } else if (MODE != 3 || pair == 0) {  // (MODE 3: launch 0 does all of such a tile)
             next_valid = false;
+            const uint32_t ndbs_all = (N + 31) / 32;
 #pragma unroll
             for (int jj = 0; jj < PT; ++jj) {
                 const uint32_t pl = p0 + jj;
@@ -834,7 +880,7 @@ __global__ __launch_bounds__(EPI_THREADS) void k_epilogue(uint32_t N, const Anch
                 const uint32_t pos = tile_start + pl;
                 uint32_t popc = 0;
                 const bool is100 = active && (pos % 100u == 0);
-                for (uint32_t d = 0; d < ndbs; ++d) {
+                for (uint32_t d = 0; d < ndbs_all; ++d) {
                     const uint32_t nb = min(4u, nbytes - 4 * d);
                     uint32_t wv = 0;
                     if (active)
@@ -1048,13 +1094,14 @@ hipError_t launch_rows_epilogue(hipStream_t st, uint32_t ngenomes, const AnchorD
     const uint32_t nbytes = (ngenomes + 7) / 8;
     if (nbytes == 1)
         hipLaunchKernelGGL(k_epilogue<0>, dim3(grid), dim3(EPI_THREADS), lds, st, ngenomes, ad, tile_contig, ntiles, out1,
-                           out100, bins, colsums, flags);
+                           out100, bins, colsums, flags, 0u);
     else if (nbytes <= 8)
         hipLaunchKernelGGL(k_epilogue<1>, dim3(grid), dim3(EPI_THREADS), lds, st, ngenomes, ad, tile_contig, ntiles, out1,
-                           out100, bins, colsums, flags);
-    else
-        hipLaunchKernelGGL(k_epilogue<2>, dim3(grid), dim3(EPI_THREADS), lds, st, ngenomes, ad, tile_contig, ntiles, out1,
-                           out100, bins, colsums, flags);
+                           out100, bins, colsums, flags, 0u);
+    else  // one launch per pair of 32-genome words
+        for (uint32_t pair = 0; pair < (nbytes + 7) / 8; ++pair)
+            hipLaunchKernelGGL(k_epilogue<3>, dim3(grid), dim3(EPI_THREADS), lds, st, ngenomes, ad, tile_contig, ntiles, out1,
+                               out100, bins, colsums, flags, pair);
     return hipGetLastError();
 }
 
