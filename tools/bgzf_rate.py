@@ -3,7 +3,8 @@
 import os, sys, time, tempfile
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from oracle import pyoracle as po
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _synth as po
 from panagram_amd import engine
 L, G, k = 50_000_000, 8, 21
 gen = po.synth_genomes(G, [L], 0.01, 1234)

@@ -4,7 +4,8 @@ full Index.run() (FASTA on disk -> BGZF files on disk).   python tools/e2e_rate.
 import argparse, os, sys, tempfile, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from oracle import pyoracle as po
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _synth as po
 from panagram_amd import engine, index as pidx
 
 ap = argparse.ArgumentParser(); ap.add_argument("--mb", type=float, default=100.0); ap.add_argument("--genomes", type=int, default=8)
@@ -39,4 +40,4 @@ with tempfile.TemporaryDirectory() as d:
     idx = pidx.Index(os.path.join(d, "samples.tsv"), prefix=os.path.join(d, "idx"), k=k, cores=32)
     idx.run()
     dt = time.perf_counter() - t0
-    print(f"Index.run(): FASTA files -> table -> {G} anchors -> BGZF/.gzi/TSV files: {dt:.1f} s = {npos/dt/1e6:.0f} M k-mers/s end to end (32 BGZF threads, {os.cpu_count()} host cores)")
+    print(f"Index.run(): FASTA files -> table -> {G} anchors -> BGZF/.gzi/TSV files: {dt:.1f} s = {npos/dt/1e6:.0f} M k-mers/s end to end ({engine.usable_cpus()} usable host cores)")

@@ -1,6 +1,7 @@
 import cProfile, pstats, os, sys, tempfile, time
 sys.path.insert(0, os.getcwd())
-from oracle import pyoracle as po
+sys.path.insert(0, os.path.join(os.getcwd(), 'tools'))
+import _synth as po
 from panagram_amd import engine, index as pidx
 import argparse
 ap = argparse.ArgumentParser(); ap.add_argument('--genomes', type=int, default=8); ap.add_argument('--mb', type=float, default=100.0)

@@ -3,7 +3,8 @@
 import os, sys, time, zlib
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from oracle import pyoracle as po
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _synth as po
 from panagram_amd import engine
 for G, L in ((8, 20_000_000), (27, 8_000_000), (64, 4_000_000)):
     gen = po.synth_genomes(G, [L], 0.01, 1234)
