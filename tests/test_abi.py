@@ -43,6 +43,15 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".cpp", ".h")):
                 src = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "oracle" not in src.replace("no oracle", ""), f"{f} mentions the oracle"
+    # tools/ are measurement scripts around the product: they must not lean on the oracle either;
+    # bench.py may, in its cpu_baseline leg only
+    for f in os.listdir(os.path.join(ROOT, "tools")):
+        if f.endswith((".py", ".sh")):
+            src = open(os.path.join(ROOT, "tools", f), errors="replace").read()
+            assert "import oracle" not in src and "from oracle" not in src, f"tools/{f} imports the oracle"
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    assert bench.count("from oracle") == 1 and bench.index("from oracle") > bench.index("def cpu_baseline(")
+    assert bench.index("from oracle") < bench.index("def main(")
 
 
 def test_bgzf_writer_roundtrip(tmp_path):
