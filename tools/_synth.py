@@ -1,6 +1,6 @@
 """Synthetic pangenomes for the tools in this directory (SURVEY §8d generator: i.i.d. base genome,
-derived genomes by per-base substitution).  Kept apart from oracle/, which only tests, smoke() and
-bench.py's cpu_baseline leg may use."""
+derived genomes by per-base substitution).  The oracle package is off limits here: only tests, smoke() and
+bench.py's cpu_baseline leg may use it."""
 from typing import List, Sequence
 
 import numpy as np
