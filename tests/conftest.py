@@ -13,6 +13,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "slow: takes tens of seconds on CPU")
 
 
+def pytest_sessionstart(session):
+    """The shared libraries are build artefacts (git-ignored): make sure they exist and are current
+    before any test loads them — what __graft_entry__.build() does.  hipcc cross-compiles without a GPU."""
+    import subprocess
+    from panagram_amd import build
+    build.build(force=False, verbose=False)
+    mk = os.path.join(ROOT, "oracle", "Makefile")
+    if os.path.exists(mk):
+        subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle")], check=True)
+
+
 def _has_gpu():
     try:
         import torch
