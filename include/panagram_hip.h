@@ -202,6 +202,10 @@ int pg_result_window_stats(pg_result *r, uint32_t idx, int step, uint32_t nwin, 
  * for the run's kernels; may be called from another host thread than the one enqueueing work. */
 int pg_result_write_bgzf(pg_result *r, int step, const char *gz_path, const char *gzi_path, int level,
                          int nthreads);
+/* the same for contigs first_contig .. first_contig+ncontigs-1 only: one anchor genome of a result
+ * that spans several (pg_seqset_concat / pg_result_coschedule) */
+int pg_result_write_bgzf_range(pg_result *r, int step, uint32_t first_contig, uint32_t ncontigs,
+                               const char *gz_path, const char *gzi_path, int level, int nthreads);
 /* Launch-order hint for a result over SEVERAL anchor genomes (contig_group[c] = genome of contig
  * c; NULL restores launch order): the reference anchors its FASTAs in parallel threads
  * (cpp/anchor.cpp:217-223); here all of them share one kernel launch whose tiles interleave the

@@ -70,6 +70,7 @@ PROTOTYPES = {
     "pg_result_merge_columns": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32]),
     "pg_result_window_stats": (C.c_int, [_vp, C.c_uint32, C.c_int, C.c_uint32, _vp, _vp, _vp, _vp]),
     "pg_result_write_bgzf": (C.c_int, [_vp, C.c_int, C.c_char_p, C.c_char_p, C.c_int, C.c_int]),
+    "pg_result_write_bgzf_range": (C.c_int, [_vp, C.c_int, C.c_uint32, C.c_uint32, C.c_char_p, C.c_char_p, C.c_int, C.c_int]),
     "pg_result_download": (C.c_int, [_vp, C.c_uint32, _vp, _vp, _vp]),
     "pg_result_colsums": (C.c_int, [_vp, _vp]),
     "pg_result_device_ptrs": (C.c_int, [_vp, _vpp, _u64p, _vpp, _u64p]),

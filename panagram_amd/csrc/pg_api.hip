@@ -1219,7 +1219,15 @@ extern "C" int pg_rows_epilogue(pg_result *r) {
 // ---------------------------------------------------------------------------
 extern "C" int pg_result_write_bgzf(pg_result *r, int step, const char *gz_path, const char *gzi_path, int level,
                                     int nthreads) {
+    if (!r) return fail(PG_E_INVALID, "pg_result_write_bgzf: NULL argument");
+    return pg_result_write_bgzf_range(r, step, 0, (uint32_t)r->ad.size(), gz_path, gzi_path, level, nthreads);
+}
+
+extern "C" int pg_result_write_bgzf_range(pg_result *r, int step, uint32_t first_contig, uint32_t ncontigs,
+                                          const char *gz_path, const char *gzi_path, int level, int nthreads) {
     if (!r || !gz_path) return fail(PG_E_INVALID, "pg_result_write_bgzf: NULL argument");
+    if ((uint64_t)first_contig + ncontigs > r->ad.size())
+        return fail(PG_E_INVALID, "contigs %u..%u out of range", first_contig, first_contig + ncontigs);
     if (step != 1 && step != 100) return fail(PG_E_INVALID, "step must be 1 or 100");
     if (!r->ev_ok) return fail(PG_E_INVALID, "pg_anchor_run has not been called on this result");
     if (step == 100 && (r->flags & PG_ANCHOR_ROWS_ONLY) && !r->ev_epi)
@@ -1230,7 +1238,7 @@ extern "C" int pg_result_write_bgzf(pg_result *r, int step, const char *gz_path,
     const uint32_t nbytes_row = (r->tbl->ngenomes + 7) / 8;
     std::vector<std::pair<uint64_t, uint64_t>> segs;  // (device offset, length)
     uint64_t total = 0;
-    for (size_t i = 0; i < r->ad.size(); ++i) {
+    for (size_t i = first_contig; i < (size_t)first_contig + ncontigs; ++i) {
         const uint64_t len = (step == 1 ? (uint64_t)r->ad[i].nkmers : r->nrows100[i]) * nbytes_row;
         if (len) segs.emplace_back(step == 1 ? r->ad[i].out_off : r->ad[i].out100_off, len);
         total += len;

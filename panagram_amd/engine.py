@@ -377,11 +377,13 @@ class AnchorResult:
         return hist, cs
 
     def write_bgzf(self, step: int, gz_path: str, gzi_path: Optional[str] = None, level: int = 6,
-                   threads: int = 1) -> None:
-        """Stream the whole bitmap.<step> payload (all contigs) from HBM into a BGZF file + .gzi;
-        releases the GIL, so a worker thread can write while the main thread anchors on."""
-        check(self._lib.pg_result_write_bgzf(self._h, step, os.fsencode(gz_path),
-                                             os.fsencode(gzi_path) if gzi_path else None, level, threads))
+                   threads: int = 1, first_contig: int = 0, ncontigs: Optional[int] = None) -> None:
+        """Stream the bitmap.<step> payload of contigs [first_contig, first_contig + ncontigs) (default:
+        all) from HBM into a BGZF file + .gzi; releases the GIL, so a worker thread can write while
+        the main thread anchors on."""
+        n = len(self.seqs.lens) - first_contig if ncontigs is None else ncontigs
+        check(self._lib.pg_result_write_bgzf_range(self._h, step, first_contig, n, os.fsencode(gz_path),
+                                                   os.fsencode(gzi_path) if gzi_path else None, level, threads))
 
     def download(self, idx: int, want_bitmap1: bool = True, want_bitmap100: bool = True):
         info = self.contig_info(idx)

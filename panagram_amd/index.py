@@ -402,9 +402,10 @@ class Index:
 
     # ---- panagram index command (index.py:172-191) ----
     def run(self):
-        """Table build, then every anchor: the GPU anchors genome g+1 while host threads stream
-        genome g's rows out of HBM into the BGZF files (the reference runs one thread per anchor
-        FASTA instead, cpp/anchor.cpp:217-223)."""
+        """Table build, then the anchors in batches: the anchor genomes of a batch share ONE
+        co-scheduled launch (homologous regions side by side, table lines shared in L2 — the
+        reference runs one thread per anchor FASTA instead, cpp/anchor.cpp:217-223), and host threads
+        stream each genome's rows out of HBM into its BGZF files while the next batch is anchored."""
         print("Wrote config.yaml and samples.tsv")
         if self.prepare:
             print("Prepared. Run 'python -m panagram_amd index <dir>' to build the index")
@@ -412,21 +413,66 @@ class Index:
         from concurrent.futures import ThreadPoolExecutor
         os.makedirs(self.get_subdir("logs"), exist_ok=True)
         tbl = self.build_table()
+        nb = (self.ngenomes + 7) // 8
+        batches, cur, cur_bytes = [], [], 0
+        for name in self.anchor_genomes:  # a batch's rows stay in HBM until written: bound them
+            rows_bytes = int(self.seqset_for(name).lens.sum()) * nb
+            if cur and cur_bytes + rows_bytes > self.batch_bytes:
+                batches.append(cur)
+                cur, cur_bytes = [], 0
+            cur.append(name)
+            cur_bytes += rows_bytes
+        if cur:
+            batches.append(cur)
         with ThreadPoolExecutor(max_workers=2) as pool:
-            pending = []
-            for name in self.anchor_genomes:
-                g = self.genomes[name]
-                g.setup_log(os.path.join(self.get_subdir("logs"), f"anchor.{name}.log.txt"))
-                job = g.anchor_on_gpu(tbl, self.seqset_for(name))
-                pending.append((name, pool.submit(g.write_from_result, job)))
-                while len(pending) > 2:  # bound the results held in HBM
-                    nm, fut = pending.pop(0)
-                    fut.result()
-                    self.drop_seqset(nm)
-            for nm, fut in pending:
-                fut.result()
-                self.drop_seqset(nm)
+            previous = None
+            for batch in batches:
+                for name in batch:
+                    self.genomes[name].setup_log(os.path.join(self.get_subdir("logs"), f"anchor.{name}.log.txt"))
+                job = self._anchor_batch(tbl, batch)
+                futs = [pool.submit(self.genomes[name].write_from_result, job, gi) for gi, name in enumerate(batch)]
+                if previous is not None:  # at most two batches of rows resident
+                    self._finish_batch(*previous)
+                previous = (job, batch, futs)
+            if previous is not None:
+                self._finish_batch(*previous)
         self.close()
+
+    batch_bytes = 32 << 30  # rows of one batch of anchor genomes held in HBM (bitmap.1 payload bytes)
+
+    def _anchor_batch(self, tbl, batch):
+        sets = [self.seqset_for(name) for name in batch]
+        merged = engine.SeqSet.concat(self.context, sets) if len(sets) > 1 else sets[0]
+        for nm, ln in zip(merged.names, merged.lens):
+            if int(ln) < tbl.k:
+                logger.warning(f"Contig {nm} is shorter than k={tbl.k}: 0 k-mers (the reference underflows here)")
+        logger.info("Anchoring Started")
+        res = engine.AnchorResult(tbl, merged, colsums=True)
+        first = np.cumsum([0] + [len(s.names) for s in sets])
+        if len(sets) > 1:
+            res.coschedule(np.repeat(np.arange(len(sets)), [len(s.names) for s in sets]))
+        res.run()
+        small = [res.download(ci, want_bitmap1=False, want_bitmap100=False) for ci in range(len(merged.names))]
+        ccs = res.contig_colsums().astype(np.int64)
+        per_genome = []
+        for gi, name in enumerate(batch):
+            lo, hi = int(first[gi]), int(first[gi + 1])
+            g = self.genomes[name]
+            names = list(merged.names[lo:hi])
+            gene_hists = g._tabulate_genes(res, names, small[lo:hi], lo) if g.annotated else None
+            per_genome.append((lo, hi, names, small[lo:hi], ccs[lo:hi].sum(axis=0), gene_hists))
+        return dict(res=res, merged=merged if len(sets) > 1 else None, genomes=per_genome)
+
+    def _finish_batch(self, job, batch, futs):
+        try:
+            for f in futs:
+                f.result()
+        finally:
+            job["res"].close()
+            if job["merged"] is not None:
+                job["merged"].close()
+            for name in batch:
+                self.drop_seqset(name)
 
     # ---- bitmap -> bins (index.py:438-465): what the viewer does with a queried bitmap ----
     @property
@@ -612,9 +658,9 @@ class Genome:
         small = [res.download(ci, want_bitmap1=False, want_bitmap100=False) for ci in range(len(ss.names))]
         cs = res.colsums().astype(np.int64)
         gene_hists = self._tabulate_genes(res, list(ss.names), small) if self.annotated else None
-        return res, list(ss.names), small, cs, gene_hists
+        return dict(res=res, merged=None, genomes=[(0, len(ss.names), list(ss.names), small, cs, gene_hists)])
 
-    def _tabulate_genes(self, res, names, small):
+    def _tabulate_genes(self, res, names, small, first_contig: int = 0):
         """occupancy histogram of every gene's positions, summed per chromosome (index.py:1055-1064,
         1079-1082), from the rows in HBM: {chrom: (gene_count, hist[N+1])} in sorted-chr order"""
         genes = self.load_genes()
@@ -631,26 +677,25 @@ class Genome:
                 logger.warning(f"Skipping gene at {chrom}:{s_}-{e_}, coordinates out-of-bounds")
             hist = np.zeros(self.ngenomes + 1, np.int64)
             if ok.any():
-                h, _ = res.window_stats(ci, st[ok], en[ok], step=1, colsums=False)
+                h, _ = res.window_stats(first_contig + ci, st[ok], en[ok], step=1, colsums=False)
                 hist = h.sum(axis=0).astype(np.int64)
             out[chrom] = (len(grp), hist)
             logger.info(f"Annotated {chrom}")
         return out
 
-    def write_from_result(self, job, bgzf_threads: Optional[int] = None):
+    def write_from_result(self, job, gi: int = 0, bgzf_threads: Optional[int] = None):
         """anchor/<name>/ exactly as the reference lays it out (cpp/anchor.cpp:37-109,
-        index.py:1035-1094), the two bitmaps streamed from HBM by the library."""
-        res, names, small, cs, gene_hists = job
-        try:
-            os.makedirs(self.prefix, exist_ok=True)
-            nthreads = bgzf_threads or self._bgzf_threads()
-            for s in self.steps:
-                gz, gzi = self.bitmap_gz_fname(s), self.bitmap_gzi_fname(s)
-                res.write_bgzf(s, gz + ".tmp", gzi + ".tmp", level=6, threads=nthreads)
-                os.replace(gz + ".tmp", gz)
-                os.replace(gzi + ".tmp", gzi)
-        finally:
-            res.close()
+        index.py:1035-1094): this genome's contig range of the (possibly shared) result, the two
+        bitmaps streamed from HBM by the library.  The caller closes the result."""
+        res = job["res"]
+        lo, hi, names, small, cs, gene_hists = job["genomes"][gi]
+        os.makedirs(self.prefix, exist_ok=True)
+        nthreads = bgzf_threads or self._bgzf_threads()
+        for s in self.steps:
+            gz, gzi = self.bitmap_gz_fname(s), self.bitmap_gzi_fname(s)
+            res.write_bgzf(s, gz + ".tmp", gzi + ".tmp", level=6, threads=nthreads, first_contig=lo, ncontigs=hi - lo)
+            os.replace(gz + ".tmp", gz)
+            os.replace(gzi + ".tmp", gzi)
         self._write_tables(names, [(b, info) for _, _, b, info in small], cs, gene_hists)
 
     def _bgzf_threads(self) -> int:
@@ -690,9 +735,13 @@ class Genome:
             logger.info(f"Skipping non-anchor genome '{self.name}'")
             return
         ss = self.index.seqset_for(self.name)
+        job = None
         try:
-            self.write_from_result(self.anchor_on_gpu(table, ss), bgzf_threads)
+            job = self.anchor_on_gpu(table, ss)
+            self.write_from_result(job, 0, bgzf_threads)
         finally:
+            if job is not None:
+                job["res"].close()
             self.index.drop_seqset(self.name)
 
     # ---- READ: what `panagram view` does with our files (index.py:615-658, 793-845) ----

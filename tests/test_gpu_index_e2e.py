@@ -26,8 +26,11 @@ def _write_case(tmp_path, fx):
     return s
 
 
+@pytest.mark.parametrize("batch_bytes", [None, 1])
 @pytest.mark.parametrize("name", ["n2_k21", "n9_k21", "n40_k31", "n65_k21"])
-def test_index_run_writes_reference_identical_tree(name, tmp_path):
+def test_index_run_writes_reference_identical_tree(name, batch_bytes, tmp_path):
+    """batch_bytes None: all anchors of the case in one co-scheduled launch; 1: one batch per anchor
+    (the batches pipeline: anchoring of batch b+1 beside the file writers of batch b)"""
     from panagram_amd import index as pidx
     fx = H.load_case(name)
     n, k = int(fx["ngenomes"]), int(fx["k"])
@@ -35,6 +38,8 @@ def test_index_run_writes_reference_identical_tree(name, tmp_path):
     s = _write_case(tmp_path, fx)
     out = tmp_path / "idx"
     idx = pidx.Index(str(s), prefix=str(out), k=k, anchor_genomes=anchors, export_kmc=True)
+    if batch_bytes is not None:
+        idx.batch_bytes = batch_bytes
     idx.run()
     dbs = H.case_dbs(fx)
     for g in fx["anchors"]:
