@@ -290,3 +290,85 @@ def test_gene_tabulation_from_gff(tmp_path):
         assert np.array_equal(got.loc[c].to_numpy(), want[c])
     chrs = pd.read_table(tmp_path / "idx" / "anchor" / "g0" / "chrs.tsv").set_index("name")
     assert chrs["gene_count"].to_dict() == {"chrB": 3, "chrA": 2, "chrC": 1}
+
+
+def _messy_pangenome(rng, n):
+    """derived genomes with substitutions, indels, a repeat family, N runs, soft-masked stretches,
+    contigs of unequal length — and a different contig order in one genome"""
+    elem = rng.integers(0, 4, 600, dtype=np.uint8)
+    base = []
+    for L in (70000, 26000, 9000):
+        parts, left = [], L
+        while left > 0:
+            parts.append(rng.integers(0, 4, int(rng.integers(500, 3000)), dtype=np.uint8))
+            e = elem.copy()
+            mut = rng.random(len(e)) < 0.06
+            e[mut] = (e[mut] + rng.integers(1, 4, int(mut.sum()), dtype=np.uint8)) % 4
+            parts.append(e)
+            left -= len(parts[-1]) + len(parts[-2])
+        base.append(np.concatenate(parts))
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    genomes = []
+    for g in range(n):
+        contigs = []
+        for b in base:
+            x = b.copy()
+            if g:
+                mut = rng.random(len(x)) < 0.015
+                x[mut] = (x[mut] + rng.integers(1, 4, int(mut.sum()), dtype=np.uint8)) % 4
+                pieces, cur = [], 0
+                for p in np.sort(rng.integers(0, len(x), 12)):
+                    if p < cur:
+                        continue
+                    pieces.append(x[cur:p])
+                    ln = int(rng.integers(1, 400))
+                    if rng.random() < 0.5:
+                        cur = min(len(x), p + ln)
+                    else:
+                        pieces.append(rng.integers(0, 4, ln, dtype=np.uint8))
+                        cur = p
+                pieces.append(x[cur:])
+                x = np.concatenate(pieces)
+            s = bytearray(acgt[x].tobytes())
+            for _ in range(2):
+                p = int(rng.integers(0, len(s) - 300))
+                s[p:p + int(rng.integers(1, 200))] = b"N" * 1  # a single N and longer runs below
+                q = int(rng.integers(0, len(s) - 300))
+                s[q:q + 150] = b"N" * 150
+                u = int(rng.integers(0, len(s) - 2000))
+                s[u:u + 1500] = bytes(s[u:u + 1500]).lower()
+            contigs.append(bytes(s))
+        genomes.append(contigs)
+    return genomes
+
+
+def test_messy_pangenome_through_index_run(tmp_path):
+    """indels, repeats, N runs, soft masking, unequal contigs and a shuffled contig order in one
+    genome: every anchor's files from the co-scheduled Index.run() equal the oracle's"""
+    from panagram_amd import index as pidx
+    rng = np.random.default_rng(2024)
+    n, k = 6, 21
+    genomes = _messy_pangenome(rng, n)
+    names = ["chr1", "chr2", "chr3"]
+    order = {g: [0, 1, 2] for g in range(n)}
+    order[3] = [2, 0, 1]
+    rows = ["name\tfasta"]
+    fastas = {}
+    for g in range(n):
+        fa = tmp_path / f"g{g}.fa"
+        fastas[g] = po.fasta_text([names[i] for i in order[g]], [genomes[g][i] for i in order[g]], width=61 + g)
+        fa.write_bytes(fastas[g])
+        rows.append(f"g{g}\t{fa}")
+    (tmp_path / "samples.tsv").write_text("\n".join(rows) + "\n")
+    idx = pidx.Index(str(tmp_path / "samples.tsv"), prefix=str(tmp_path / "idx"), k=k)
+    idx.run()
+    dbs = po.build_bitvec_dbs([[genomes[g][i] for i in order[g]] for g in range(n)], k)
+    for g in range(n):
+        ora = po.anchor_fasta(dbs, fastas[g], k, n)
+        adir = tmp_path / "idx" / "anchor" / f"g{g}"
+        assert gzip.open(adir / "bitmap.1.gz", "rb").read() == ora["bitmap1"]
+        assert gzip.open(adir / "bitmap.100.gz", "rb").read() == ora["bitmap100"]
+        assert (adir / "bitsum.bins.tsv").read_text() == ora["bins_tsv"]
+        assert (adir / "chrs.tsv").read_text() == ora["chrs_tsv"]
+        tp = pd.read_csv(adir / "total_paircounts.csv", index_col="name")
+        assert np.array_equal(tp["count"].to_numpy(), ora["colsums"])
