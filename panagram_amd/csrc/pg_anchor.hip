@@ -91,6 +91,25 @@ __device__ __forceinline__ void lane_chase(const SubTable &st, uint64_t key, uin
     m0 = m1 = 0;
 }
 
+// the same out of line, everything by value (nothing of the caller is forced into scratch): for call
+// sites on a hot path where the chase itself is rare — inlined, its hash set-up gets hoisted into the
+// common path
+template <bool TWO, int SLOTS>
+__device__ __attribute__((noinline)) uint2 lane_chase_cold(uint8_t *buckets, uint64_t nbuckets, uint64_t key,
+                                                           uint32_t level, uint32_t b, uint32_t step) {
+    SubTable t;
+    t.buckets = buckets;
+    t.nbuckets = nbuckets;
+    t.W = TWO ? 2 : 1;
+    t.word0 = 0;
+    t.k = t.m = 0;
+    t.slots = SLOTS;
+    t.pad_ = 0;
+    uint32_t m0, m1;
+    lane_chase<TWO, SLOTS>(t, key, level, b, step, m0, m1);
+    return make_uint2(m0, m1);
+}
+
 // write the row bytes this sub-table owns: low nb0 bytes of m0 at column col0, low nb1 bytes of
 // m1 at col0+4 (cpp/anchor.cpp:139-164).  ROWMODE 1: one-byte rows; 2: 8-byte rows (N = 64);
 // 0: generic byte loop.
@@ -202,7 +221,10 @@ __device__ __forceinline__ void drain_queue(const SubTable &st, uint32_t qn, con
             if (again) {  // in-place compaction: slot <= e, and this batch's reads are already done
                 const uint32_t slot = kept + lanes_le_count(kmask2, true) - 1;
                 uint32_t nl2 = line, ns2 = step;
-                advance_line(key, (uint32_t)level + 1, st.nbuckets, nl2, ns2);
+                // (staged levels end before the group's chain does: no switch to the key's own sequence
+                // here, and none of its hashing on this path)
+                if constexpr (PROBE_STAGED_LEVELS + 1 < (int)GROUP_CHAIN) nl2 = next_line(line, step, st.nbuckets);
+                else advance_line(key, (uint32_t)level + 1, st.nbuckets, nl2, ns2);
                 q_line[slot] = nl2;
                 q_step[slot] = ns2;
                 q_pl[slot] = (uint16_t)pl;
@@ -390,7 +412,9 @@ __global__ __launch_bounds__(64) void k_probe(const SubTable st, const uint64_t 
                         q_step[slot] = step;
                         q_pl[slot] = (uint16_t)pl[u];
                     } else {
-                        lane_chase<TWO, SLOTS>(st, key[u], 1u, nx, step, m0[u], m1[u]);  // queue full: resolve inline
+                        const uint2 mm2 = lane_chase_cold<TWO, SLOTS>(st.buckets, st.nbuckets, key[u], 1u, nx, step);  // queue full
+                        m0[u] = mm2.x;
+                        m1[u] = mm2.y;
                     }
                 }
                 qn = min(qn + (uint32_t)__popcll(omask), (uint32_t)PROBE_QCAP);
