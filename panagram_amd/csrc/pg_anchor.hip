@@ -279,7 +279,6 @@ __global__ __launch_bounds__(64) void k_probe(const SubTable st, const uint64_t 
     constexpr int HALO = W_C ? W_C - 1 : 0;  // lanes of a batch that only supply m-mers to their successors
     constexpr int STRIDE = 64 - HALO;        // new positions per batch
     const uint32_t m = W_C ? (uint32_t)k - W_C + 1 : 0;
-    const uint32_t mm = (m >= 16) ? ~0u : ((1u << (2 * m)) - 1);
     const uint64_t mm64 = (m >= 32) ? ~0ull : ((1ull << (2 * (m ? m : 1))) - 1);
     uint8_t *tile_rows = out1 + a.out_off + (uint64_t)tile_start * nbytes;
     uint32_t qn = 0;  // wave-uniform: overflow entries of this tile so far
@@ -310,14 +309,10 @@ __global__ __launch_bounds__(64) void k_probe(const SubTable st, const uint64_t 
                 // tile, which have no k-mer, take theirs out of the tile's first k-mer): forward strand
                 // from X, reverse complement from B — no second pass over the sequence words
                 const uint32_t off = (uint32_t)(pl[u] + HALO) - pq;  // m-mer's offset inside the k-mer, 0..HALO
-                if (m <= 16) {
-                    const uint32_t fa = (uint32_t)(X >> (2 * off)) & mm;
-                    const uint32_t fr = (uint32_t)(B >> (2 * (HALO - off))) & mm;
-                    grp[u] = mz_order(fa < fr ? fa : fr);
-                } else {  // long m-mers (k > 21): same thing in 64 bits
-                    const uint64_t fa = (X >> (2 * off)) & mm64;
-                    const uint64_t fr = (B >> (2 * (HALO - off))) & mm64;
-                    grp[u] = mmer_rank(fa < fr ? fa : fr);
+                {
+                    const uint64_t fa = (X >> (2 * off)) & mm64;             // one path for every m: for m <= 16
+                    const uint64_t fr = (B >> (2 * (HALO - off))) & mm64;   // the high halves are zero and
+                    grp[u] = mmer_rank(fa < fr ? fa : fr);                   // mmer_rank is mz_order of the m-mer
                 }
             } else {
                 grp[u] = group_of_key(key[u]);
@@ -349,8 +344,7 @@ __global__ __launch_bounds__(64) void k_probe(const SubTable st, const uint64_t 
         uint32_t maxruns = 0;
 #pragma unroll
         for (int u = 0; u < NB; ++u) {
-            const unsigned long long amask = __ballot(act[u]);
-            const bool prev_act = lane > 0 && ((amask >> (lane - 1)) & 1ull);
+            const bool prev_act = lane > 0 && lane_up1(act[u] ? 1u : 0u) != 0;
             leader[u] = act[u] && (!prev_act || line[u] != prev_line[u]);
             const unsigned long long lmask = __ballot(leader[u]);
             rid[u] = lanes_le_count(lmask, leader[u]) - 1;  // run id of an active lane

@@ -139,8 +139,12 @@ __device__ __forceinline__ void advance_line(uint64_t key, uint32_t level, uint6
 //   value(fwd) = ~B & kmask,  value(revcomp) = ~X & kmask,
 //   canonical key = min of the two = ~max(X, B) & kmask.
 __device__ __forceinline__ uint64_t pair_reverse64(uint64_t x) {
-    uint64_t r = __brevll(x);
-    return ((r >> 1) & 0x5555555555555555ull) | ((r & 0x5555555555555555ull) << 1);
+    // bit reversal, then the two bits of every base swapped back — per 32-bit half (the masks drop
+    // the bits that would cross), one bit-field insert each
+    const uint32_t lo = __brev((uint32_t)(x >> 32)), hi = __brev((uint32_t)x);
+    const uint32_t lo2 = ((lo >> 1) & 0x55555555u) | ((lo << 1) & ~0x55555555u);
+    const uint32_t hi2 = ((hi >> 1) & 0x55555555u) | ((hi << 1) & ~0x55555555u);
+    return (uint64_t)lo2 | ((uint64_t)hi2 << 32);
 }
 __device__ __forceinline__ uint64_t kmer_mask(int k) { return (k == 32) ? ~0ull : ((1ull << (2 * k)) - 1); }
 
@@ -155,11 +159,12 @@ __device__ __forceinline__ uint64_t canonical_from_le(uint64_t x, int k) {
     return canonical_from_xb(x, revcomp_le(x, k), k);
 }
 
-// rank of a canonical m-mer (up to 27 bases = 54 bits) in the scrambled order: fold to 32 bits,
-// then a multiplicative scramble.  For m <= 16 the fold is the identity and the rank a bijection;
-// longer m-mers may tie, which only merges two groups.
+// rank of a canonical m-mer (up to 30 bases = 60 bits) in the scrambled order: the bits above 32
+// are folded in with rotates (no multiply), then a multiplicative scramble.  For m <= 16 the fold is
+// the identity and the rank a bijection; longer m-mers may tie, which only merges two groups.
 __host__ __device__ __forceinline__ uint32_t mmer_rank(uint64_t c) {
-    return mz_order((uint32_t)c ^ ((uint32_t)(c >> 32) * 0x85ebca6bu));
+    const uint32_t hi = (uint32_t)(c >> 32);
+    return mz_order((uint32_t)c ^ ((hi << 11) | (hi >> 21)) ^ ((hi << 23) | (hi >> 9)));
 }
 
 // minimizer of a k-mer given X and B (generic, runtime w).  Symmetric in X <-> B.
