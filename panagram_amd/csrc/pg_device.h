@@ -101,9 +101,15 @@ __device__ __forceinline__ uint32_t range32(uint32_t h, uint64_t n) { return __u
 __device__ __forceinline__ uint32_t group_of_key(uint64_t key) {
     return (uint32_t)key ^ fmix32((uint32_t)(key >> 32) + 0x9E3779B9u);
 }
-__device__ __forceinline__ uint32_t home_of_group(uint32_t g, uint64_t nlines) { return range32(fmix32(g), nlines); }
+// one multiply + xor-shift each (32-bit multiplies are quarter rate on CDNA): range32 takes the TOP
+// bits of the hash, and the top bits of g * odd depend on every bit of g
+__device__ __forceinline__ uint32_t mix1(uint32_t g, uint32_t mul) {
+    const uint32_t h = g * mul;
+    return h ^ (h >> 15);
+}
+__device__ __forceinline__ uint32_t home_of_group(uint32_t g, uint64_t nlines) { return range32(mix1(g, 0x85ebca6bu), nlines); }
 __device__ __forceinline__ uint32_t step_of_group(uint32_t g, uint64_t nlines) {
-    return 1u + range32(fmix32(g ^ 0x5bd1e995u), nlines - 1);
+    return 1u + range32(mix1(g ^ 0x5bd1e995u, 0xc2b2ae35u), nlines - 1);
 }
 __device__ __forceinline__ uint32_t next_line(uint32_t line, uint32_t step, uint64_t nlines) {
     const uint64_t n = (uint64_t)line + step;
