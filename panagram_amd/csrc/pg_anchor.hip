@@ -299,7 +299,7 @@ __global__ __launch_bounds__(64) void k_probe(const SubTable st, const uint64_t 
             pl[u] = (int32_t)(b + lane) - HALO;
             inrange[u] = pl[u] >= (int32_t)b && pl[u] < (int32_t)npos;
             const uint32_t pq = (uint32_t)max(pl[u], 0);
-            const uint64_t X = extract_bases(sw, pq) & kmask;
+            const uint64_t X = extract_bases32(reinterpret_cast<const uint32_t *>(sw), pq) & kmask;
             const uint64_t B = revcomp_le(X, k);
             key[u] = canonical_from_xb(X, B, k);
             act[u] = inrange[u];

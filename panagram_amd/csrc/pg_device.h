@@ -205,6 +205,16 @@ __device__ __forceinline__ uint64_t extract_bases(P words, uint64_t p) {
     return (lo >> sh) | ((hi << 1) << (63 - sh));  // branch-free also for sh == 0 (both reads always issue)
 }
 
+// the same out of a 32-bit view of the words: two funnel shifts (v_alignbit) instead of three 64-bit
+// shifts; reads three consecutive dwords
+__device__ __forceinline__ uint64_t extract_bases32(const uint32_t *words32, uint32_t p) {
+    const uint32_t d = p >> 4, sh = (p & 15u) * 2u;
+    const uint32_t d0 = words32[d], d1 = words32[d + 1], d2 = words32[d + 2];
+    const uint32_t lo = __builtin_amdgcn_alignbit(d1, d0, sh);
+    const uint32_t hi = __builtin_amdgcn_alignbit(d2, d1, sh);
+    return (uint64_t)lo | ((uint64_t)hi << 32);
+}
+
 // k "not ACGT" bits starting at base p
 template <typename P>
 __device__ __forceinline__ uint32_t extract_nmask(P words, uint64_t p, int k) {
