@@ -18,7 +18,7 @@
  *     rows with contig-relative index % 100 == 0 -> bitmap.100; per-chunk histogram.
  *
  * Parity status: PINNED — tests/test_oracle_c.py checks this file against the golden
- * vectors produced by the reference's own run_anchor binary (tests/golden/*.npz).
+ * vectors produced by the reference's own run_anchor binary (tests/golden, .npz files).
  */
 #include <stdint.h>
 #include <stdlib.h>
