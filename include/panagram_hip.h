@@ -199,7 +199,11 @@ int pg_result_window_stats(pg_result *r, uint32_t idx, int step, uint32_t nwin, 
  * contig, in order — from HBM into a BGZF file + .gzi index (gzi_path may be NULL): D2H through
  * pinned double buffers on a private stream overlapped with multi-threaded deflate.  Replaces
  * bgzf_open/bgzf_write/bgzf_index_dump/bgzf_close of cpp/anchor.cpp:46-55,102-106,167,177.  Waits
- * for the run's kernels; may be called from another host thread than the one enqueueing work. */
+ * for the run's kernels; may be called from another host thread than the one enqueueing work.
+ * level: a zlib level 0..9 for the host path (Z_RLE for one-byte rows, the library's row-aware
+ * encoder for wider ones) — or -2: the BGZF blocks are compressed ON THE GPU (k_row_deflate: one
+ * workgroup per 65280-byte block, matches one row back, dynamic Huffman, CRC32), the host only
+ * appends the finished blocks to the file (nthreads unused). */
 int pg_result_write_bgzf(pg_result *r, int step, const char *gz_path, const char *gzi_path, int level,
                          int nthreads);
 /* the same for contigs first_contig .. first_contig+ncontigs-1 only: one anchor genome of a result

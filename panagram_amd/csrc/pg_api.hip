@@ -10,7 +10,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace pg;
@@ -58,6 +60,15 @@ struct pg_ctx {
     // dependant does.
     std::atomic<int> refs{0};
     bool dead = false;
+    // staging of the GPU BGZF writer (write_bgzf_gpu): two sets, so that two writer threads can run;
+    // allocated at first use, kept — pinning 2 x 64 MiB per file would cost more than the compression
+    struct DfSet {
+        uint8_t *d_slots[2] = {nullptr, nullptr}, *h_slots[2] = {nullptr, nullptr};
+        uint32_t *d_sizes[2] = {nullptr, nullptr}, *h_sizes[2] = {nullptr, nullptr};
+        uint32_t *d_crc = nullptr;
+        bool ready = false, busy = false;
+    } df[2];
+    std::mutex df_mu;
 };
 
 struct SubHost {
@@ -158,6 +169,15 @@ static void ctx_free(pg_ctx *c) {
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     hipStreamSynchronize(c->aux_stream);
+    for (auto &d : c->df) {
+        for (int i = 0; i < 2; ++i) {
+            hipFree(d.d_slots[i]);
+            hipFree(d.d_sizes[i]);
+            if (d.h_slots[i]) hipHostFree(d.h_slots[i]);
+            if (d.h_sizes[i]) hipHostFree(d.h_sizes[i]);
+        }
+        hipFree(d.d_crc);
+    }
     hipStreamDestroy(c->aux_stream);
     hipStreamDestroy(c->own_stream);
     delete c;
@@ -1213,6 +1233,153 @@ extern "C" int pg_rows_epilogue(pg_result *r) {
 }
 
 // ---------------------------------------------------------------------------
+// GPU-compressed BGZF: k_row_deflate turns every 65280 payload bytes into a finished BGZF block in
+// a 64 KiB slot; the host copies the slots back in batches and appends the blocks to the file.
+// ---------------------------------------------------------------------------
+static const uint32_t *crc_tables_host() {
+    static uint32_t tab[1280];
+    static bool init = false;
+    if (!init) {
+        for (uint32_t i = 0; i < 256; ++i) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; ++k) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+            tab[i] = c;
+        }
+        for (uint32_t k = 0; k < 4; ++k)  // state byte k after 255 more (zero) bytes
+            for (uint32_t b = 0; b < 256; ++b) {
+                uint32_t s = b << (8 * k);
+                for (int z = 0; z < 255; ++z) s = tab[s & 255u] ^ (s >> 8);
+                tab[256 + 256 * k + b] = s;
+            }
+        init = true;
+    }
+    return tab;
+}
+
+static constexpr uint32_t DF_BATCH = 1024;  // BGZF blocks per k_row_deflate launch: 64 MiB of slots
+
+static pg_ctx::DfSet *df_acquire(pg_ctx *ctx) {
+    for (;;) {
+        {
+            std::lock_guard<std::mutex> lk(ctx->df_mu);
+            for (auto &d : ctx->df)
+                if (!d.busy) {
+                    d.busy = true;
+                    return &d;
+                }
+        }
+        std::this_thread::yield();
+    }
+}
+
+static int write_bgzf_gpu(pg_result *r, const uint8_t *src, const std::vector<std::pair<uint64_t, uint64_t>> &segs_in,
+                          uint64_t total, uint32_t row, const char *gz_path, const char *gzi_path) {
+    static const unsigned char EOF_BLOCK[28] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0x00, 0x42, 0x43,
+                                                0x02, 0x00, 0x1b, 0x00, 0x03, 0x00, 0, 0, 0, 0, 0, 0, 0, 0};
+    pg_ctx *ctx = r->tbl->ctx;
+    const uint64_t nblocks = (total + 65279) / 65280;
+    std::vector<PaySeg> segs;
+    uint64_t l = 0;
+    for (auto &sg : segs_in) {
+        segs.push_back({l, sg.first});
+        l += sg.second;
+    }
+    segs.push_back({total, 0});
+    FILE *f = fopen(gz_path, "wb");
+    if (!f) return fail(PG_E_IO, "cannot open %s for writing", gz_path);
+    pg_ctx::DfSet *D = df_acquire(ctx);
+    hipStream_t cs = nullptr;
+    PaySeg *d_segs = nullptr;
+    hipEvent_t done[2] = {nullptr, nullptr};
+    hipError_t e = hipStreamCreateWithFlags(&cs, hipStreamNonBlocking);
+    auto ok = [&](hipError_t x) {
+        if (e == hipSuccess) e = x;
+        return e == hipSuccess;
+    };
+    if (!D->ready) {
+        ok(hipMalloc(reinterpret_cast<void **>(&D->d_crc), 1280 * 4));
+        for (int i = 0; i < 2; ++i) {
+            ok(hipMalloc(reinterpret_cast<void **>(&D->d_slots[i]), (size_t)DF_BATCH * 65536));
+            ok(hipMalloc(reinterpret_cast<void **>(&D->d_sizes[i]), (size_t)DF_BATCH * 4));
+            ok(hipHostMalloc(reinterpret_cast<void **>(&D->h_slots[i]), (size_t)DF_BATCH * 65536, 0));
+            ok(hipHostMalloc(reinterpret_cast<void **>(&D->h_sizes[i]), (size_t)DF_BATCH * 4, 0));
+        }
+        if (e == hipSuccess) {
+            ok(hipMemcpyAsync(D->d_crc, crc_tables_host(), 1280 * 4, hipMemcpyHostToDevice, cs));
+            ok(hipStreamSynchronize(cs));
+        }
+        D->ready = e == hipSuccess;
+    }
+    ok(hipMalloc(reinterpret_cast<void **>(&d_segs), segs.size() * sizeof(PaySeg)));
+    for (int i = 0; i < 2; ++i) ok(hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
+    if (e == hipSuccess) {
+        ok(hipMemcpyAsync(d_segs, segs.data(), segs.size() * sizeof(PaySeg), hipMemcpyHostToDevice, cs));
+        ok(hipStreamWaitEvent(cs, r->ev[r->ev_epi ? 3 : 1], 0));
+    }
+    std::vector<uint64_t> coffs, uoffs;
+    uint64_t cpos = 0;
+    int rc = PG_OK;
+    auto issue = [&](uint64_t b0, int slot) {
+        const uint32_t nb = (uint32_t)std::min<uint64_t>(DF_BATCH, nblocks - b0);
+        hipError_t x = hipMemsetAsync(D->d_slots[slot], 0, (size_t)nb * 65536, cs);
+        if (x == hipSuccess)
+            x = launch_row_deflate(cs, src, d_segs, (uint32_t)segs.size() - 1, total, b0, nb, row, D->d_crc, D->d_slots[slot],
+                                   D->d_sizes[slot], getenv("PG_DEFLATE_FORCE_STORED") ? 1u : 0u);
+        if (x == hipSuccess) x = hipMemcpyAsync(D->h_sizes[slot], D->d_sizes[slot], (size_t)nb * 4, hipMemcpyDeviceToHost, cs);
+        if (x == hipSuccess) x = hipMemcpyAsync(D->h_slots[slot], D->d_slots[slot], (size_t)nb * 65536, hipMemcpyDeviceToHost, cs);
+        if (x == hipSuccess) x = hipEventRecord(done[slot], cs);
+        return x;
+    };
+    if (e == hipSuccess && nblocks) ok(issue(0, 0));
+    int slot = 0;
+    for (uint64_t b0 = 0; e == hipSuccess && rc == PG_OK && b0 < nblocks; b0 += DF_BATCH, slot ^= 1) {
+        const uint32_t nb = (uint32_t)std::min<uint64_t>(DF_BATCH, nblocks - b0);
+        if (!ok(hipEventSynchronize(done[slot]))) break;
+        if (b0 + DF_BATCH < nblocks && !ok(issue(b0 + DF_BATCH, slot ^ 1))) break;
+        for (uint32_t i = 0; i < nb; ++i) {
+            const uint32_t sz = D->h_sizes[slot][i];
+            if (sz < 26 || sz > 65536) {
+                rc = fail(PG_E_IO, "GPU deflate produced a block of %u bytes", sz);
+                break;
+            }
+            coffs.push_back(cpos);
+            uoffs.push_back((b0 + i) * 65280ull);
+            if (fwrite(D->h_slots[slot] + (size_t)i * 65536, 1, sz, f) != sz) {
+                rc = fail(PG_E_IO, "short write to BGZF file");
+                break;
+            }
+            cpos += sz;
+        }
+    }
+    if (e != hipSuccess) rc = fail(PG_E_HIP, "pg_result_write_bgzf (GPU deflate): %s", hipGetErrorString(e));
+    if (cs) hipStreamSynchronize(cs);
+    {
+        std::lock_guard<std::mutex> lk(ctx->df_mu);
+        D->busy = false;
+    }
+    const std::string keep = rc ? g_err : std::string();
+    if (!rc && fwrite(EOF_BLOCK, 1, sizeof EOF_BLOCK, f) != sizeof EOF_BLOCK) rc = fail(PG_E_IO, "short write of BGZF EOF block");
+    if (fclose(f) != 0 && !rc) rc = fail(PG_E_IO, "fclose failed on BGZF file");
+    if (!rc && gzi_path) {
+        FILE *g = fopen(gzi_path, "wb");
+        if (!g) rc = fail(PG_E_IO, "cannot open %s", gzi_path);
+        else {
+            const uint64_t ng = coffs.empty() ? 0 : coffs.size() - 1;
+            bool good = fwrite(&ng, 8, 1, g) == 1;
+            for (size_t i = 1; good && i < coffs.size(); ++i) good = fwrite(&coffs[i], 8, 1, g) == 1 && fwrite(&uoffs[i], 8, 1, g) == 1;
+            if (fclose(g) != 0) good = false;
+            if (!good) rc = fail(PG_E_IO, "short write to .gzi");
+        }
+    }
+    if (!keep.empty()) g_err = keep;
+    hipFree(d_segs);
+    for (int i = 0; i < 2; ++i)
+        if (done[i]) hipEventDestroy(done[i]);
+    if (cs) hipStreamDestroy(cs);
+    return rc;
+}
+
+// ---------------------------------------------------------------------------
 // device rows -> BGZF file: D2H through two pinned buffers on a private stream while the previous
 // buffer is being deflated by the writer's threads.  Safe to call from a worker thread while the
 // context's streams keep running other results.
@@ -1243,6 +1410,8 @@ extern "C" int pg_result_write_bgzf_range(pg_result *r, int step, uint32_t first
         if (len) segs.emplace_back(step == 1 ? r->ad[i].out_off : r->ad[i].out100_off, len);
         total += len;
     }
+    // level -2: compress on the GPU (k_row_deflate), the host only writes the blocks
+    if (level == -2 && nbytes_row < 256) return write_bgzf_gpu(r, src, segs, total, nbytes_row, gz_path, gzi_path);
     if (nthreads < 1) nthreads = 1;
     pg_bgzf *w = nullptr;
     if (level >= 0) level |= nbytes_row == 1 ? PG_BGZF_RLE : (nbytes_row < 256 ? PG_BGZF_ROWS(nbytes_row) : 0);

@@ -86,6 +86,14 @@ hipError_t launch_cols_extract(hipStream_t st, uint32_t ngenomes, const AnchorDe
 hipError_t launch_cols_merge(hipStream_t st, uint32_t ngenomes, const AnchorDesc *ad, const uint32_t *tile_contig,
                              uint32_t ntiles, uint8_t *out1, const void *src, uint32_t nparts, uint64_t part_words,
                              uint32_t per);
+// GPU-side BGZF compression of a payload (pg_deflate.hip): the payload is the concatenation of
+// segments of device memory; segs[nseg] is a sentinel with lstart = total
+struct PaySeg {
+    uint64_t lstart, doff;
+};
+hipError_t launch_row_deflate(hipStream_t st, const uint8_t *base, const PaySeg *segs, uint32_t nseg, uint64_t total,
+                              uint64_t first_block, uint32_t nblocks, uint32_t row, const uint32_t *crc_tabs, uint8_t *slots,
+                              uint32_t *sizes, uint32_t force_stored);
 hipError_t launch_window_stats(hipStream_t st, uint32_t ngenomes, const uint8_t *rows, uint64_t nrows, uint32_t nwin,
                                uint32_t pieces, const uint64_t *starts, const uint64_t *ends, unsigned long long *hist,
                                unsigned long long *cs);

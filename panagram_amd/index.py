@@ -439,6 +439,8 @@ class Index:
         self.close()
 
     batch_bytes = 32 << 30  # rows of one batch of anchor genomes held in HBM (bitmap.1 payload bytes)
+    # BGZF compression of the bitmaps: a zlib level (host threads), or -2 = on the GPU (k_row_deflate)
+    bgzf_level = int(os.environ.get("PG_BGZF_LEVEL", "-2"))
 
     def _anchor_batch(self, tbl, batch):
         sets = [self.seqset_for(name) for name in batch]
@@ -693,7 +695,8 @@ class Genome:
         nthreads = bgzf_threads or self._bgzf_threads()
         for s in self.steps:
             gz, gzi = self.bitmap_gz_fname(s), self.bitmap_gzi_fname(s)
-            res.write_bgzf(s, gz + ".tmp", gzi + ".tmp", level=6, threads=nthreads, first_contig=lo, ncontigs=hi - lo)
+            res.write_bgzf(s, gz + ".tmp", gzi + ".tmp", level=self.index.bgzf_level, threads=nthreads, first_contig=lo,
+                           ncontigs=hi - lo)
             os.replace(gz + ".tmp", gz)
             os.replace(gzi + ".tmp", gzi)
         self._write_tables(names, [(b, info) for _, _, b, info in small], cs, gene_hists)

@@ -221,6 +221,21 @@ def test_write_bgzf_from_hbm_equals_host_writer(ctx, tmp_path):
         assert gzip.open(gz, "rb").read() == payload
         assert open(gz, "rb").read() == open(tmp_path / f"h{step}.gz", "rb").read()
         assert open(gzi, "rb").read() == open(tmp_path / f"h{step}.gzi", "rb").read()
+        # level -2: the blocks are compressed on the GPU (k_row_deflate) — other bytes, same payload and
+        # the same uncompressed geometry; and its stored-block fallback
+        for stored in (False, True):
+            if stored:
+                os.environ["PG_DEFLATE_FORCE_STORED"] = "1"
+            try:
+                gz2, gzi2 = str(tmp_path / f"g{step}{stored}.gz"), str(tmp_path / f"g{step}{stored}.gzi")
+                res.write_bgzf(step, gz2, gzi2, level=-2)
+            finally:
+                os.environ.pop("PG_DEFLATE_FORCE_STORED", None)
+            assert gzip.open(gz2, "rb").read() == payload
+            a, b = np.fromfile(gzi2, "<u8"), np.fromfile(gzi, "<u8")
+            assert a[0] == b[0] and np.array_equal(a[2::2], b[2::2])
+            if not stored and step == 1:
+                assert os.path.getsize(gz2) < 0.5 * len(payload)
     res.close()
     ss.close()
     tbl.close()

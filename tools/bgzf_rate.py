@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import _synth as po
 from panagram_amd import engine
-L, G, k = 50_000_000, 8, 21
+L, G, k = int(os.environ.get("BR_L", 50_000_000)), int(os.environ.get("BR_G", 8)), 21
 gen = po.synth_genomes(G, [L], 0.01, 1234)
 genomes = [[po.codes_to_ascii(c) for c in g] for g in gen]
 ctx = engine.Context(0)
@@ -27,3 +27,6 @@ with tempfile.TemporaryDirectory() as d:
             print(f"level {level} threads {th:3d}: {rows.nbytes/dt/1e6:7.0f} MB/s  ratio {rows.nbytes/os.path.getsize(p):.2f}")
     t0 = time.perf_counter(); res.write_bgzf(1, p, p + "i", level=6, threads=64); dt = time.perf_counter() - t0
     print(f"write_bgzf from HBM level 6 threads 64: {rows.nbytes/dt/1e6:.0f} MB/s")
+    for lvl, nm in ((-2, "GPU deflate"), (6, "host, 16 threads")):
+        t0 = time.perf_counter(); res.write_bgzf(1, p, p + "i", level=lvl, threads=16); dt = time.perf_counter() - t0
+        print(f"write_bgzf from HBM, {nm}: {rows.nbytes/dt/1e6:.0f} MB/s  ratio {rows.nbytes/os.path.getsize(p):.2f}")
