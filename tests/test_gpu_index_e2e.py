@@ -387,3 +387,33 @@ def test_messy_pangenome_through_index_run(tmp_path):
         assert (adir / "chrs.tsv").read_text() == ora["chrs_tsv"]
         tp = pd.read_csv(adir / "total_paircounts.csv", index_col="name")
         assert np.array_equal(tp["count"].to_numpy(), ora["colsums"])
+
+
+def test_gpu_bgzf_multi_batch(ctx, tmp_path):
+    """a payload of more than 1024 BGZF blocks goes through several k_row_deflate launches and both
+    staging buffers; odd tail block"""
+    from panagram_amd import engine
+    rng = np.random.default_rng(8)
+    L = 70_000_123
+    a = rng.integers(0, 4, L, dtype=np.uint8)
+    b = a.copy()
+    mut = rng.random(L) < 0.02
+    b[mut] = (b[mut] + 1) & 3
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    ga, gb = acgt[a].tobytes(), acgt[b].tobytes()
+    tbl = engine.PanTable(ctx, 21, 2, expected_keys=int(L * 1.5))
+    sa, sb = engine.SeqSet.from_host(ctx, [ga]), engine.SeqSet.from_host(ctx, [gb])
+    tbl.insert_seqset(0, sa)
+    tbl.insert_seqset(1, sb)
+    res = engine.AnchorResult(tbl, sb)
+    res.run()
+    rows = res.download(0)[0]
+    gz, gzi = str(tmp_path / "m.gz"), str(tmp_path / "m.gzi")
+    res.write_bgzf(1, gz, gzi, level=-2)
+    assert gzip.open(gz, "rb").read() == rows.tobytes()
+    g = np.fromfile(gzi, "<u8")
+    nblocks = (len(rows) + 65279) // 65280
+    assert nblocks > 1024 and g[0] == nblocks - 1 and np.array_equal(g[2::2], np.arange(1, nblocks, dtype=np.uint64) * 65280)
+    assert np.array_equal(g[1::2][1:] > g[1::2][:-1], np.ones(nblocks - 2, bool))
+    for x in (res, sa, sb, tbl):
+        x.close()
