@@ -63,8 +63,8 @@ struct pg_ctx {
     // staging of the GPU BGZF writer (write_bgzf_gpu): two sets, so that two writer threads can run;
     // allocated at first use, kept — pinning 2 x 64 MiB per file would cost more than the compression
     struct DfSet {
-        uint8_t *d_slots[2] = {nullptr, nullptr}, *h_slots[2] = {nullptr, nullptr};
-        uint32_t *d_sizes[2] = {nullptr, nullptr}, *h_sizes[2] = {nullptr, nullptr};
+        uint8_t *d_slots[2] = {nullptr, nullptr}, *d_packed[2] = {nullptr, nullptr}, *h_slots[2] = {nullptr, nullptr};
+        uint32_t *d_sizes[2] = {nullptr, nullptr}, *d_offs[2] = {nullptr, nullptr}, *h_sizes[2] = {nullptr, nullptr};
         uint32_t *d_crc = nullptr;
         bool ready = false, busy = false;
     } df[2];
@@ -172,7 +172,9 @@ static void ctx_free(pg_ctx *c) {
     for (auto &d : c->df) {
         for (int i = 0; i < 2; ++i) {
             hipFree(d.d_slots[i]);
+            hipFree(d.d_packed[i]);
             hipFree(d.d_sizes[i]);
+            hipFree(d.d_offs[i]);
             if (d.h_slots[i]) hipHostFree(d.h_slots[i]);
             if (d.h_sizes[i]) hipHostFree(d.h_sizes[i]);
         }
@@ -1290,7 +1292,7 @@ static int write_bgzf_gpu(pg_result *r, const uint8_t *src, const std::vector<st
     pg_ctx::DfSet *D = df_acquire(ctx);
     hipStream_t cs = nullptr;
     PaySeg *d_segs = nullptr;
-    hipEvent_t done[2] = {nullptr, nullptr};
+    hipEvent_t done[2] = {nullptr, nullptr}, copied[2] = {nullptr, nullptr};
     hipError_t e = hipStreamCreateWithFlags(&cs, hipStreamNonBlocking);
     auto ok = [&](hipError_t x) {
         if (e == hipSuccess) e = x;
@@ -1300,9 +1302,11 @@ static int write_bgzf_gpu(pg_result *r, const uint8_t *src, const std::vector<st
         ok(hipMalloc(reinterpret_cast<void **>(&D->d_crc), 1280 * 4));
         for (int i = 0; i < 2; ++i) {
             ok(hipMalloc(reinterpret_cast<void **>(&D->d_slots[i]), (size_t)DF_BATCH * 65536));
+            ok(hipMalloc(reinterpret_cast<void **>(&D->d_packed[i]), (size_t)DF_BATCH * 65536));
             ok(hipMalloc(reinterpret_cast<void **>(&D->d_sizes[i]), (size_t)DF_BATCH * 4));
-            ok(hipHostMalloc(reinterpret_cast<void **>(&D->h_slots[i]), (size_t)DF_BATCH * 65536, 0));
-            ok(hipHostMalloc(reinterpret_cast<void **>(&D->h_sizes[i]), (size_t)DF_BATCH * 4, 0));
+            ok(hipMalloc(reinterpret_cast<void **>(&D->d_offs[i]), (size_t)(DF_BATCH + 1) * 4));
+            ok(hipHostMalloc(reinterpret_cast<void **>(&D->h_slots[i]), (size_t)DF_BATCH * 65536, 0));   // packed blocks
+            ok(hipHostMalloc(reinterpret_cast<void **>(&D->h_sizes[i]), (size_t)(DF_BATCH + 1) * 4, 0));  // their offsets
         }
         if (e == hipSuccess) {
             ok(hipMemcpyAsync(D->d_crc, crc_tables_host(), 1280 * 4, hipMemcpyHostToDevice, cs));
@@ -1311,7 +1315,10 @@ static int write_bgzf_gpu(pg_result *r, const uint8_t *src, const std::vector<st
         D->ready = e == hipSuccess;
     }
     ok(hipMalloc(reinterpret_cast<void **>(&d_segs), segs.size() * sizeof(PaySeg)));
-    for (int i = 0; i < 2; ++i) ok(hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
+    for (int i = 0; i < 2; ++i) {
+        ok(hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
+        ok(hipEventCreateWithFlags(&copied[i], hipEventDisableTiming));
+    }
     if (e == hipSuccess) {
         ok(hipMemcpyAsync(d_segs, segs.data(), segs.size() * sizeof(PaySeg), hipMemcpyHostToDevice, cs));
         ok(hipStreamWaitEvent(cs, r->ev[r->ev_epi ? 3 : 1], 0));
@@ -1319,14 +1326,16 @@ static int write_bgzf_gpu(pg_result *r, const uint8_t *src, const std::vector<st
     std::vector<uint64_t> coffs, uoffs;
     uint64_t cpos = 0;
     int rc = PG_OK;
+    // per batch: compress into slots, pack the finished blocks back to back, bring home the offsets first
+    // (they say how many packed bytes to fetch), then the bytes
     auto issue = [&](uint64_t b0, int slot) {
         const uint32_t nb = (uint32_t)std::min<uint64_t>(DF_BATCH, nblocks - b0);
         hipError_t x = hipMemsetAsync(D->d_slots[slot], 0, (size_t)nb * 65536, cs);
         if (x == hipSuccess)
             x = launch_row_deflate(cs, src, d_segs, (uint32_t)segs.size() - 1, total, b0, nb, row, D->d_crc, D->d_slots[slot],
-                                   D->d_sizes[slot], getenv("PG_DEFLATE_FORCE_STORED") ? 1u : 0u);
-        if (x == hipSuccess) x = hipMemcpyAsync(D->h_sizes[slot], D->d_sizes[slot], (size_t)nb * 4, hipMemcpyDeviceToHost, cs);
-        if (x == hipSuccess) x = hipMemcpyAsync(D->h_slots[slot], D->d_slots[slot], (size_t)nb * 65536, hipMemcpyDeviceToHost, cs);
+                                   D->d_sizes[slot], getenv("PG_DEFLATE_FORCE_STORED") ? 1u : 0u, D->d_offs[slot], D->d_packed[slot]);
+        if (x == hipSuccess)
+            x = hipMemcpyAsync(D->h_sizes[slot], D->d_offs[slot], (size_t)(nb + 1) * 4, hipMemcpyDeviceToHost, cs);
         if (x == hipSuccess) x = hipEventRecord(done[slot], cs);
         return x;
     };
@@ -1335,21 +1344,25 @@ static int write_bgzf_gpu(pg_result *r, const uint8_t *src, const std::vector<st
     for (uint64_t b0 = 0; e == hipSuccess && rc == PG_OK && b0 < nblocks; b0 += DF_BATCH, slot ^= 1) {
         const uint32_t nb = (uint32_t)std::min<uint64_t>(DF_BATCH, nblocks - b0);
         if (!ok(hipEventSynchronize(done[slot]))) break;
-        if (b0 + DF_BATCH < nblocks && !ok(issue(b0 + DF_BATCH, slot ^ 1))) break;
-        for (uint32_t i = 0; i < nb; ++i) {
-            const uint32_t sz = D->h_sizes[slot][i];
-            if (sz < 26 || sz > 65536) {
-                rc = fail(PG_E_IO, "GPU deflate produced a block of %u bytes", sz);
-                break;
-            }
-            coffs.push_back(cpos);
-            uoffs.push_back((b0 + i) * 65280ull);
-            if (fwrite(D->h_slots[slot] + (size_t)i * 65536, 1, sz, f) != sz) {
-                rc = fail(PG_E_IO, "short write to BGZF file");
-                break;
-            }
-            cpos += sz;
+        const uint32_t *offs = D->h_sizes[slot];
+        const uint32_t bytes = offs[nb];
+        if (bytes < 26u * nb || bytes > nb * 65536ull) {
+            rc = fail(PG_E_IO, "GPU deflate produced %u bytes for %u blocks", bytes, nb);
+            break;
         }
+        if (!ok(hipMemcpyAsync(D->h_slots[slot], D->d_packed[slot], bytes, hipMemcpyDeviceToHost, cs))) break;
+        if (!ok(hipEventRecord(copied[slot], cs))) break;
+        if (b0 + DF_BATCH < nblocks && !ok(issue(b0 + DF_BATCH, slot ^ 1))) break;  // the next batch runs behind the copy
+        if (!ok(hipEventSynchronize(copied[slot]))) break;
+        for (uint32_t i = 0; i < nb; ++i) {
+            coffs.push_back(cpos + offs[i]);
+            uoffs.push_back((b0 + i) * 65280ull);
+        }
+        if (fwrite(D->h_slots[slot], 1, bytes, f) != bytes) {
+            rc = fail(PG_E_IO, "short write to BGZF file");
+            break;
+        }
+        cpos += bytes;
     }
     if (e != hipSuccess) rc = fail(PG_E_HIP, "pg_result_write_bgzf (GPU deflate): %s", hipGetErrorString(e));
     if (cs) hipStreamSynchronize(cs);
@@ -1373,8 +1386,10 @@ static int write_bgzf_gpu(pg_result *r, const uint8_t *src, const std::vector<st
     }
     if (!keep.empty()) g_err = keep;
     hipFree(d_segs);
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i) {
         if (done[i]) hipEventDestroy(done[i]);
+        if (copied[i]) hipEventDestroy(copied[i]);
+    }
     if (cs) hipStreamDestroy(cs);
     return rc;
 }

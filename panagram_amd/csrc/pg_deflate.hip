@@ -464,12 +464,44 @@ __global__ __launch_bounds__(DF_THREADS) void k_row_deflate(const uint8_t *__res
     }
 }
 
+// finished blocks of a batch packed back to back (what goes to the file): offsets by one workgroup,
+// then one workgroup per block copies its bytes (destination at byte alignment)
+__global__ __launch_bounds__(1024) void k_bgzf_offsets(const uint32_t *__restrict__ sizes, uint32_t nb, uint32_t *__restrict__ offs) {
+    __shared__ uint32_t part[1024];
+    const int tid = threadIdx.x;
+    const uint32_t per = (nb + 1023) / 1024;
+    uint32_t sum = 0;
+    for (uint32_t i = tid * per; i < min(nb, (tid + 1) * per); ++i) sum += sizes[i];
+    part[tid] = sum;
+    __syncthreads();
+    uint32_t base = 0;
+    for (int t = 0; t < tid; ++t) base += part[t];
+    for (uint32_t i = tid * per; i < min(nb, (tid + 1) * per); ++i) {
+        offs[i] = base;
+        base += sizes[i];
+    }
+    if (tid == 1023) offs[nb] = base;
+}
+
+__global__ __launch_bounds__(256) void k_bgzf_pack(const uint8_t *__restrict__ slots, const uint32_t *__restrict__ sizes,
+                                                   const uint32_t *__restrict__ offs, uint8_t *__restrict__ packed) {
+    struct __attribute__((packed)) U32 { uint32_t v; };
+    const uint32_t sz = sizes[blockIdx.x];
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(slots + (uint64_t)blockIdx.x * 65536);
+    uint8_t *dst = packed + offs[blockIdx.x];
+    const uint32_t nw = sz >> 2;
+    for (uint32_t i = threadIdx.x; i < nw; i += 256) reinterpret_cast<U32 *>(dst + 4 * i)->v = src[i];
+    if (threadIdx.x < (sz & 3u)) dst[4 * nw + threadIdx.x] = reinterpret_cast<const uint8_t *>(src)[4 * nw + threadIdx.x];
+}
+
 hipError_t launch_row_deflate(hipStream_t st, const uint8_t *base, const PaySeg *segs, uint32_t nseg, uint64_t total,
                               uint64_t first_block, uint32_t nblocks, uint32_t row, const uint32_t *crc_tabs, uint8_t *slots,
-                              uint32_t *sizes, uint32_t force_stored) {
+                              uint32_t *sizes, uint32_t force_stored, uint32_t *offs, uint8_t *packed) {
     if (nblocks == 0) return hipSuccess;
     hipLaunchKernelGGL(k_row_deflate, dim3(nblocks), dim3(DF_THREADS), 0, st, base, segs, nseg, total, first_block, row,
                        crc_tabs, slots, sizes, force_stored);
+    hipLaunchKernelGGL(k_bgzf_offsets, dim3(1), dim3(1024), 0, st, sizes, nblocks, offs);
+    hipLaunchKernelGGL(k_bgzf_pack, dim3(nblocks), dim3(256), 0, st, slots, sizes, offs, packed);
     return hipGetLastError();
 }
 

@@ -93,7 +93,7 @@ struct PaySeg {
 };
 hipError_t launch_row_deflate(hipStream_t st, const uint8_t *base, const PaySeg *segs, uint32_t nseg, uint64_t total,
                               uint64_t first_block, uint32_t nblocks, uint32_t row, const uint32_t *crc_tabs, uint8_t *slots,
-                              uint32_t *sizes, uint32_t force_stored);
+                              uint32_t *sizes, uint32_t force_stored, uint32_t *offs, uint8_t *packed);
 hipError_t launch_window_stats(hipStream_t st, uint32_t ngenomes, const uint8_t *rows, uint64_t nrows, uint32_t nwin,
                                uint32_t pieces, const uint64_t *starts, const uint64_t *ends, unsigned long long *hist,
                                unsigned long long *cs);
