@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""Walks a GPU-compressed BGZF file block by block: header, raw-DEFLATE decode with zlib, payload and
+CRC32 of every block against the rows downloaded from the same result."""
 import os, sys, zlib, struct, tempfile
 import numpy as np
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tools"))
