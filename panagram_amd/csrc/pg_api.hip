@@ -1258,7 +1258,10 @@ static const uint32_t *crc_tables_host() {
     return tab;
 }
 
-static constexpr uint32_t DF_BATCH = 1024;  // BGZF blocks per k_row_deflate launch: 64 MiB of slots
+#ifndef PG_DF_BATCH
+#define PG_DF_BATCH 1024
+#endif
+static constexpr uint32_t DF_BATCH = PG_DF_BATCH;  // BGZF blocks per k_row_deflate launch (64 KiB slot each)
 
 static pg_ctx::DfSet *df_acquire(pg_ctx *ctx) {
     for (;;) {
