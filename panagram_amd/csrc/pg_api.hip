@@ -1238,8 +1238,11 @@ extern "C" int pg_rows_epilogue(pg_result *r) {
 // GPU-compressed BGZF: k_row_deflate turns every 65280 payload bytes into a finished BGZF block in
 // a 64 KiB slot; the host copies the slots back in batches and appends the blocks to the file.
 // ---------------------------------------------------------------------------
+static constexpr uint32_t CRC_TAB_WORDS = 256 + 8 * 1024;
+// [0..256): the CRC-32 byte table; then 8 sets of 4 x 256: set j = the register after 255 * 2^j more
+// (zero) bytes, as a function of each of its four bytes
 static const uint32_t *crc_tables_host() {
-    static uint32_t tab[1280];
+    static uint32_t tab[CRC_TAB_WORDS];
     static bool init = false;
     if (!init) {
         for (uint32_t i = 0; i < 256; ++i) {
@@ -1247,12 +1250,20 @@ static const uint32_t *crc_tables_host() {
             for (int k = 0; k < 8; ++k) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
             tab[i] = c;
         }
-        for (uint32_t k = 0; k < 4; ++k)  // state byte k after 255 more (zero) bytes
+        uint32_t *T0 = tab + 256;
+        for (uint32_t k = 0; k < 4; ++k)
             for (uint32_t b = 0; b < 256; ++b) {
                 uint32_t s = b << (8 * k);
                 for (int z = 0; z < 255; ++z) s = tab[s & 255u] ^ (s >> 8);
-                tab[256 + 256 * k + b] = s;
+                T0[256 * k + b] = s;
             }
+        for (uint32_t j = 1; j < 8; ++j) {  // set j = set j-1 applied twice
+            const uint32_t *P = tab + 256 + 1024 * (j - 1);
+            uint32_t *T = tab + 256 + 1024 * j;
+            auto apply = [&](uint32_t x) { return P[x & 255u] ^ P[256 + ((x >> 8) & 255u)] ^ P[512 + ((x >> 16) & 255u)] ^ P[768 + (x >> 24)]; };
+            for (uint32_t k = 0; k < 4; ++k)
+                for (uint32_t b = 0; b < 256; ++b) T[256 * k + b] = apply(apply(b << (8 * k)));
+        }
         init = true;
     }
     return tab;
@@ -1302,7 +1313,7 @@ static int write_bgzf_gpu(pg_result *r, const uint8_t *src, const std::vector<st
         return e == hipSuccess;
     };
     if (!D->ready) {
-        ok(hipMalloc(reinterpret_cast<void **>(&D->d_crc), 1280 * 4));
+        ok(hipMalloc(reinterpret_cast<void **>(&D->d_crc), CRC_TAB_WORDS * 4));
         for (int i = 0; i < 2; ++i) {
             ok(hipMalloc(reinterpret_cast<void **>(&D->d_slots[i]), (size_t)DF_BATCH * 65536));
             ok(hipMalloc(reinterpret_cast<void **>(&D->d_packed[i]), (size_t)DF_BATCH * 65536));
@@ -1312,7 +1323,7 @@ static int write_bgzf_gpu(pg_result *r, const uint8_t *src, const std::vector<st
             ok(hipHostMalloc(reinterpret_cast<void **>(&D->h_sizes[i]), (size_t)(DF_BATCH + 1) * 4, 0));  // their offsets
         }
         if (e == hipSuccess) {
-            ok(hipMemcpyAsync(D->d_crc, crc_tables_host(), 1280 * 4, hipMemcpyHostToDevice, cs));
+            ok(hipMemcpyAsync(D->d_crc, crc_tables_host(), CRC_TAB_WORDS * 4, hipMemcpyHostToDevice, cs));
             ok(hipStreamSynchronize(cs));
         }
         D->ready = e == hipSuccess;
@@ -1336,7 +1347,7 @@ static int write_bgzf_gpu(pg_result *r, const uint8_t *src, const std::vector<st
         hipError_t x = hipMemsetAsync(D->d_slots[slot], 0, (size_t)nb * 65536, cs);
         if (x == hipSuccess)
             x = launch_row_deflate(cs, src, d_segs, (uint32_t)segs.size() - 1, total, b0, nb, row, D->d_crc, D->d_slots[slot],
-                                   D->d_sizes[slot], getenv("PG_DEFLATE_FORCE_STORED") ? 1u : 0u, D->d_offs[slot], D->d_packed[slot]);
+                                   D->d_sizes[slot], getenv("PG_DEFLATE_FORCE_STORED") ? (uint32_t)atoi(getenv("PG_DEFLATE_FORCE_STORED")) : 0u, D->d_offs[slot], D->d_packed[slot]);
         if (x == hipSuccess)
             x = hipMemcpyAsync(D->h_sizes[slot], D->d_offs[slot], (size_t)(nb + 1) * 4, hipMemcpyDeviceToHost, cs);
         if (x == hipSuccess) x = hipEventRecord(done[slot], cs);

@@ -7,6 +7,7 @@
 // "same byte as one row earlier" — (length, distance = row width) — literals otherwise, one dynamic
 // Huffman code per block.  Output is ordinary RFC 1951 / BGZF: header, raw DEFLATE, CRC32, ISIZE.
 //
+//   stage   the block's 65280 bytes -> LDS (78 KB per workgroup, two per CU), every walk reads LDS
 //   pass A  bytes -> equality bits (vs one row earlier), CRC32 of the thread's chunk
 //   tokens  a maximal run of equal bytes [s, e) becomes matches of 258, then one of r = (e-s) % 258
 //           if r >= 3, else r literals: every position knows its role from (s, e) alone, so threads
@@ -21,8 +22,6 @@ namespace pg {
 constexpr int DF_THREADS = 256;
 constexpr uint32_t DF_BLOCK = 65280, DF_CHUNK = 255;
 
-__constant__ uint16_t DF_LEN_BASE[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
-__constant__ uint8_t DF_LEN_EXTRA[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
 __constant__ uint16_t DF_DIST_BASE[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
 __constant__ uint8_t DF_DIST_EXTRA[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
 __constant__ uint8_t DF_CL_ORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
@@ -54,34 +53,21 @@ __device__ __forceinline__ uint32_t cur_next(PayCur &c, const uint8_t *base, con
     return v;
 }
 
-// ---- Huffman code lengths (<= maxlen) for freq[0..n): thread-serial, LDS scratch ----------------
-// order[] (n), wgt[] (2n), kid0[]/kid1[] (2n), dep[] (2n) live in LDS; returns nothing, fills len[]
-__device__ void df_huff_lengths(const uint32_t *freq, int n, int maxlen, uint8_t *len, uint16_t *order, uint32_t *wgt,
-                                uint16_t *kid0, uint16_t *kid1, uint8_t *dep) {
-    int m = 0;
-    for (int i = 0; i < n; ++i) {
-        len[i] = 0;
-        if (freq[i]) order[m++] = (uint16_t)i;
-    }
+// ---- Huffman code lengths (<= maxlen): thread-serial part, LDS scratch ------------------------
+// order[0..m) = the used symbols sorted by (freq, symbol); wgt[] (2m), kid0[]/kid1[] (2m), dep[] (2m),
+// cnt[] (33) live in LDS; fills len[] of the used symbols (the caller zeroed the rest)
+__device__ void df_huff_from_sorted(const uint32_t *freq, int m, int maxlen, uint8_t *len, const uint16_t *order,
+                                    uint32_t *wgt, uint16_t *kid0, uint16_t *kid1, uint8_t *dep, uint32_t *cnt) {
     if (m == 0) return;
     if (m == 1) {
         len[order[0]] = 1;
         return;
     }
-    for (int i = 1; i < m; ++i) {  // insertion sort by (freq, symbol): rows use few distinct bytes
-        const uint16_t s = order[i];
-        const uint32_t f = freq[s];
-        int j = i - 1;
-        while (j >= 0 && (freq[order[j]] > f || (freq[order[j]] == f && order[j] > s))) {
-            order[j + 1] = order[j];
-            --j;
-        }
-        order[j + 1] = s;
-    }
     for (int i = 0; i < m; ++i) wgt[i] = freq[order[i]];
     int leaf = 0, inner = m, total = m;
-    while ((m - leaf) + (total - inner) > 1) {
+    while ((m - leaf) + (total - inner) > 1) {  // two-queue merge: leaves and inner nodes are both sorted
         int pick[2];
+#pragma unroll
         for (int t = 0; t < 2; ++t) {
             if (leaf < m && (inner >= total || wgt[leaf] <= wgt[inner])) pick[t] = leaf++;
             else pick[t] = inner++;
@@ -91,7 +77,6 @@ __device__ void df_huff_lengths(const uint32_t *freq, int n, int maxlen, uint8_t
         kid1[total] = (uint16_t)pick[1];
         ++total;
     }
-    int cnt[33];
     for (int d = 0; d < 33; ++d) cnt[d] = 0;
     dep[total - 1] = 0;
     for (int i = total - 1; i >= m; --i) {
@@ -101,7 +86,7 @@ __device__ void df_huff_lengths(const uint32_t *freq, int n, int maxlen, uint8_t
     }
     for (int i = 0; i < m; ++i) ++cnt[min((int)dep[i], maxlen)];
     uint32_t kraft = 0;
-    for (int d = maxlen; d >= 1; --d) kraft += (uint32_t)cnt[d] << (maxlen - d);
+    for (int d = maxlen; d >= 1; --d) kraft += cnt[d] << (maxlen - d);
     while (kraft > (1u << maxlen)) {
         --cnt[maxlen];
         for (int d = maxlen - 1; d >= 1; --d)
@@ -114,29 +99,47 @@ __device__ void df_huff_lengths(const uint32_t *freq, int n, int maxlen, uint8_t
     }
     int k = 0;
     for (int d = maxlen; d >= 1; --d)
-        for (int c = 0; c < cnt[d]; ++c) len[order[k++]] = (uint8_t)d;
+        for (uint32_t c = 0; c < cnt[d]; ++c) len[order[k++]] = (uint8_t)d;
+}
+
+// small alphabets (the 19 code-length symbols): sort serially, then as above
+__device__ void df_huff_lengths(const uint32_t *freq, int n, int maxlen, uint8_t *len, uint16_t *order, uint32_t *wgt,
+                                uint16_t *kid0, uint16_t *kid1, uint8_t *dep, uint32_t *cnt) {
+    int m = 0;
+    for (int i = 0; i < n; ++i) {
+        len[i] = 0;
+        if (freq[i]) order[m++] = (uint16_t)i;
+    }
+    for (int i = 1; i < m; ++i) {
+        const uint16_t s = order[i];
+        const uint32_t f = freq[s];
+        int j = i - 1;
+        while (j >= 0 && (freq[order[j]] > f || (freq[order[j]] == f && order[j] > s))) {
+            order[j + 1] = order[j];
+            --j;
+        }
+        order[j + 1] = s;
+    }
+    df_huff_from_sorted(freq, m, maxlen, len, order, wgt, kid0, kid1, dep, cnt);
+}
+
+// canonical code of symbol i, bit-reversed for the LSB-first stream, from the lengths alone:
+// code = sum over shorter used symbols j of 2^(len_i - len_j)  +  #{j < i : len_j == len_i}
+__device__ __forceinline__ uint32_t df_canon_code(const uint8_t *len, int n, int i) {
+    const uint32_t li = len[i];
+    if (!li) return 0;
+    uint32_t c = 0;
+    for (int j = 0; j < n; ++j) {
+        const uint32_t lj = len[j];
+        if (lj && lj < li) c += 1u << (li - lj);
+        else if (lj == li && j < i) ++c;
+    }
+    return __brev(c) >> (32 - li);
 }
 
 // canonical codes, bit-reversed for the LSB-first stream
 __device__ void df_huff_codes(const uint8_t *len, int n, uint16_t *code) {
-    uint32_t bl[16], next[16];
-    for (int b = 0; b < 16; ++b) bl[b] = 0;
-    for (int i = 0; i < n; ++i) ++bl[len[i]];
-    bl[0] = 0;
-    uint32_t c = 0;
-    next[0] = 0;
-    for (int b = 1; b < 16; ++b) {
-        c = (c + bl[b - 1]) << 1;
-        next[b] = c;
-    }
-    for (int i = 0; i < n; ++i) {
-        if (!len[i]) {
-            code[i] = 0;
-            continue;
-        }
-        const uint32_t v = next[len[i]]++;
-        code[i] = (uint16_t)(__brev(v) >> (32 - len[i]));
-    }
+    for (int i = 0; i < n; ++i) code[i] = (uint16_t)df_canon_code(len, n, i);
 }
 
 struct DfBits {  // LSB-first bit writer into a byte array in LDS (the block header)
@@ -154,18 +157,22 @@ struct DfBits {  // LSB-first bit writer into a byte array in LDS (the block hea
     }
 };
 
-__device__ __forceinline__ int df_len_sym(uint32_t L) {
-    int ls = 28;
-    while (DF_LEN_BASE[ls] > L) --ls;
-    return ls;
-}
-
-// role of position i of a run of equal bytes [s, e):  >0 = a match of that length starts here,
-// 0 = literal, -1 = covered by a match that started earlier
-__device__ __forceinline__ int df_role(uint32_t i, uint32_t s, uint32_t e) {
-    const uint32_t R = e - s, q258 = (R / 258u) * 258u, r = R - q258, o = i - s;
-    if (o >= q258) return r >= 3 ? (o == q258 ? (int)r : -1) : 0;
-    return (o % 258u == 0) ? 258 : -1;
+// DEFLATE length code of a match of L = 3..258 bytes, by arithmetic (a table walk in constant memory
+// per token is what the walks would otherwise spend their time on): symbol 257 + ls, nx extra bits of
+// value xv
+__device__ __forceinline__ int df_len_sym(uint32_t L, uint32_t &nx, uint32_t &xv) {
+    const uint32_t x = L - 3;
+    if (x < 8) {
+        nx = xv = 0;
+        return (int)x;
+    }
+    if (L == 258) {
+        nx = xv = 0;
+        return 28;
+    }
+    nx = (31u - (uint32_t)__clz((int)x)) - 2u;
+    xv = x & ((1u << nx) - 1u);
+    return (int)(4u * nx + 4u + ((x >> nx) & 3u));
 }
 
 __global__ __launch_bounds__(DF_THREADS) void k_row_deflate(const uint8_t *__restrict__ base, const PaySeg *__restrict__ segs,
@@ -180,10 +187,10 @@ __global__ __launch_bounds__(DF_THREADS) void k_row_deflate(const uint8_t *__res
     __shared__ int lastNE[DF_THREADS], firstNE[DF_THREADS];
     __shared__ uint32_t tbits[DF_THREADS], crcp[DF_THREADS];
     __shared__ uint8_t hdr[768];
-    __shared__ uint32_t hdr_bits, blk_crc;
+    __shared__ uint32_t hdr_bits, blk_crc, crc_acc;
     // thread-0 scratch of the Huffman builder
     __shared__ uint16_t h_order[288], h_kid0[576], h_kid1[576];
-    __shared__ uint32_t h_wgt[576];
+    __shared__ uint32_t h_wgt[576], h_cnt[33], h_m;
     __shared__ uint8_t h_dep[576], cl_sym[320], cl_extra[320];
 
     const int tid = threadIdx.x;
@@ -192,34 +199,42 @@ __global__ __launch_bounds__(DF_THREADS) void k_row_deflate(const uint8_t *__res
     const uint32_t n = (uint32_t)min((uint64_t)DF_BLOCK, total - L0);  // bytes of this block
     uint8_t *slot = slots + (uint64_t)blockIdx.x * 65536;
     for (int i = tid; i < 288; i += DF_THREADS) hist[i] = 0;
+    if (tid == 0) crc_acc = 0;
     crc_t[tid] = crc_tabs[tid];
+    // ---- the block's bytes into LDS once (gfx950: 160 KB per CU, two of these workgroups fit): a
+    // block inside one payload segment is copied coalesced, one that straddles segments chunk-wise ----
+    __shared__ uint8_t data[DF_BLOCK];
+    __shared__ PayCur blk_cur;
+    if (tid == 0) cur_seek(blk_cur, base, segs, nseg, L0);
+    __syncthreads();
+    const uint32_t c0 = min(n, (uint32_t)tid * DF_CHUNK), c1 = min(n, c0 + DF_CHUNK);
+    if (blk_cur.left >= n) {  // block-uniform
+        const uint8_t *sp = blk_cur.p;
+        const uint32_t head = min(n, (uint32_t)((4 - (reinterpret_cast<uintptr_t>(sp) & 3)) & 3));  // bytes up to 4-alignment
+        if ((uint32_t)tid < head) data[tid] = sp[tid];
+        const uint32_t nw = (n - head) >> 2;
+        // (data + head is generally not 4-aligned in LDS: packed stores)
+        struct __attribute__((packed)) U32 { uint32_t v; };
+        const uint32_t *sw = reinterpret_cast<const uint32_t *>(sp + head);
+        for (uint32_t i = tid; i < nw; i += DF_THREADS) reinterpret_cast<U32 *>(data + head + 4 * i)->v = sw[i];
+        for (uint32_t i = head + 4 * nw + tid; i < n; i += DF_THREADS) data[i] = sp[i];
+    } else if (c0 < c1) {
+        PayCur cur;
+        cur_seek(cur, base, segs, nseg, L0 + c0);
+        for (uint32_t i = c0; i < c1; ++i) data[i] = (uint8_t)cur_next(cur, base, segs, nseg);
+    }
     __syncthreads();
 
-    const uint32_t c0 = min(n, (uint32_t)tid * DF_CHUNK), c1 = min(n, c0 + DF_CHUNK);
-    // ---- pass A: equality bits and chunk CRC ----
-    uint32_t eq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // ---- pass A: chunk CRC and the chunk's first / last byte that differs from one row earlier ----
+    auto is_eq = [&](uint32_t i) { return i >= row && data[i] == data[i - row]; };
     int fne = 0x7fffffff, lne = -1;
     uint32_t crc = tid == 0 ? 0xFFFFFFFFu : 0u;
-    if (c0 < c1) {
-        PayCur cur, prv;
-        cur_seek(cur, base, segs, nseg, L0 + c0);
-        const bool prv_ok = c1 > row;
-        if (prv_ok) cur_seek(prv, base, segs, nseg, L0 + (c0 > row ? c0 - row : 0));
-#pragma unroll
-        for (int w = 0; w < 8; ++w) {
-            for (int b = 0; b < 32; ++b) {
-                const uint32_t i = c0 + 32 * w + b;
-                if (i >= c1) break;
-                const uint32_t v = cur_next(cur, base, segs, nseg);
-                crc = crc_t[(crc ^ v) & 255u] ^ (crc >> 8);
-                bool same = false;
-                if (i >= row) same = cur_next(prv, base, segs, nseg) == v;
-                if (same) eq[w] |= 1u << b;
-                else {
-                    if (fne == 0x7fffffff) fne = (int)i;
-                    lne = (int)i;
-                }
-            }
+    for (uint32_t i = c0; i < c1; ++i) {
+        const uint32_t v = data[i];
+        crc = crc_t[(crc ^ v) & 255u] ^ (crc >> 8);
+        if (!(i >= row && data[i - row] == v)) {
+            if (fne == 0x7fffffff) fne = (int)i;
+            lne = (int)i;
         }
     }
     firstNE[tid] = fne;
@@ -234,45 +249,71 @@ __global__ __launch_bounds__(DF_THREADS) void k_row_deflate(const uint8_t *__res
             nextNE = firstNE[t];
             break;
         }
-    auto is_eq = [&](uint32_t i) { return (eq[(i - c0) >> 5] >> ((i - c0) & 31)) & 1u; };
-    auto run_end = [&](uint32_t i) {  // first non-equal position >= i
-        for (uint32_t j = i; j < c1; ++j)
-            if (!is_eq(j)) return j;
-        return (uint32_t)nextNE;
-    };
-
-    // ---- pass B: symbol histogram ----
-    {
-        PayCur cur;
-        if (c0 < c1) cur_seek(cur, base, segs, nseg, L0 + c0);
-        uint32_t s = 0, e = 0;
-        bool in_run = false;
-        for (uint32_t i = c0; i < c1; ++i) {
-            const uint32_t v = cur_next(cur, base, segs, nseg);
+    // The tokens of this thread's chunk, run by run (not position by position: lanes of a wave are in
+    // different runs, and a per-position walk pays for the longest forward scan at every step).  A run of
+    // bytes equal to one row earlier, [s, e), is cut into matches of 258 from s, then one match of
+    // r = (e - s) % 258 if r >= 3, else r literals — the same for every thread that sees part of the run.
+    auto tokens = [&](auto &&on_lit, auto &&on_match) {
+        uint32_t i = c0;
+        while (i < c1) {
             if (!is_eq(i)) {
-                in_run = false;
-                atomicAdd(&hist[v], 1u);
+                on_lit((uint32_t)data[i]);
+                ++i;
                 continue;
             }
-            if (!in_run) {
-                s = (i == c0) ? (uint32_t)(prevNE + 1) : i;
-                e = run_end(i);
-                in_run = true;
+            const uint32_t s = (i == c0) ? (uint32_t)(prevNE + 1) : i;
+            uint32_t e = i + 1;
+            while (e < c1 && is_eq(e)) ++e;
+            const uint32_t hi = e;                     // end of the run inside this chunk
+            if (e == c1) e = (uint32_t)nextNE;         // ... and its true end
+            const uint32_t R = e - s, q258 = (R / 258u) * 258u, r = R - q258;
+            uint32_t p = s + ((i - s + 257u) / 258u) * 258u;  // first match start >= i
+            for (; p < min(s + q258, hi); p += 258u) on_match(258u);
+            const uint32_t tz = s + q258;              // tail zone [tz, e)
+            if (r >= 3) {
+                if (tz >= i && tz < hi) on_match(r);
+            } else {
+                for (uint32_t q = max(i, tz); q < hi; ++q) on_lit((uint32_t)data[q]);
             }
-            const int role = df_role(i, s, e);
-            if (role > 0) atomicAdd(&hist[257 + df_len_sym((uint32_t)role)], 1u);
-            else if (role == 0) atomicAdd(&hist[v], 1u);
+            i = hi;
+        }
+    };
+    // ---- pass B: symbol histogram ----
+    tokens([&](uint32_t v) { atomicAdd(&hist[v], 1u); },
+           [&](uint32_t L) {
+               uint32_t nx, xv;
+               atomicAdd(&hist[257 + df_len_sym(L, nx, xv)], 1u);
+           });
+    __syncthreads();
+
+    // ---- Huffman code of the literal/length alphabet: the used symbols are rank-sorted by the whole
+    // workgroup, thread 0 builds the tree over the sorted list, every thread derives its symbols' codes ----
+    if (tid == 0) {
+        hist[256] = 1;
+        h_m = 0;
+    }
+    __syncthreads();
+    for (int sy = tid; sy < 286; sy += DF_THREADS) {
+        llen[sy] = 0;
+        const uint32_t f = hist[sy];
+        if (f) {
+            uint32_t rank = 0;
+            for (int j = 0; j < 286; ++j) {
+                const uint32_t fj = hist[j];
+                rank += (fj && (fj < f || (fj == f && j < sy))) ? 1u : 0u;
+            }
+            h_order[rank] = (uint16_t)sy;
+            atomicAdd(&h_m, 1u);
         }
     }
     __syncthreads();
-
-    // ---- thread 0: Huffman code, block header, CRC of the block ----
+    if (tid == 0) df_huff_from_sorted(hist, (int)h_m, 15, llen, h_order, h_wgt, h_kid0, h_kid1, h_dep, h_cnt);
+    __syncthreads();
+    for (int sy = tid; sy < 286; sy += DF_THREADS) lcode[sy] = (uint16_t)df_canon_code(llen, 286, sy);
+    // ---- thread 0: block header ----
     if (tid == 0) {
-        hist[256] = 1;
         bool any_match = false;
         for (int i = 257; i < 286; ++i) any_match |= hist[i] != 0;
-        df_huff_lengths(hist, 286, 15, llen, h_order, h_wgt, h_kid0, h_kid1, h_dep);
-        df_huff_codes(llen, 286, lcode);
         int dsym = 0;
         while (dsym < 29 && DF_DIST_BASE[dsym + 1] <= row) ++dsym;
         int nlit = 286;
@@ -317,7 +358,7 @@ __global__ __launch_bounds__(DF_THREADS) void k_row_deflate(const uint8_t *__res
         for (int i = 0; i < 19; ++i) cf[i] = cfl[i];
         uint8_t cll[19];
         uint16_t clc[19];
-        df_huff_lengths(cf, 19, 7, cll, h_order, h_wgt, h_kid0, h_kid1, h_dep);
+        df_huff_lengths(cf, 19, 7, cll, h_order, h_wgt, h_kid0, h_kid1, h_dep, h_cnt);
         df_huff_codes(cll, 19, clc);
         int ncl = 19;
         while (ncl > 4 && cll[DF_CL_ORDER[ncl - 1]] == 0) --ncl;
@@ -340,18 +381,35 @@ __global__ __launch_bounds__(DF_THREADS) void k_row_deflate(const uint8_t *__res
         // distance code: the one used symbol gets the 1-bit code 0
         lcode[286] = 0;
         llen[286] = (uint8_t)dsym;  // (slot 286 carries the distance symbol for pass C)
-        // CRC32 of the block out of the chunk CRCs: state after |chunk| more bytes = shift(state) ^ crc(chunk)
-        uint32_t c = crcp[0];
-        for (int t = 1; t < DF_THREADS; ++t) {
-            const uint32_t a0 = min(n, (uint32_t)t * DF_CHUNK), a1 = min(n, a0 + DF_CHUNK);
-            if (a0 >= a1) break;
-            if (a1 - a0 == DF_CHUNK) {
-                c = crc_tabs[256 + (c & 255u)] ^ crc_tabs[512 + ((c >> 8) & 255u)] ^ crc_tabs[768 + ((c >> 16) & 255u)] ^
-                    crc_tabs[1024 + (c >> 24)];
-            } else {
-                for (uint32_t z = a0; z < a1; ++z) c = crc_t[c & 255u] ^ (c >> 8);
+    }
+    // CRC32 of the block out of the chunk CRCs.  The register is linear in its state: after a further
+    // chunk, state = shift(state) ^ crc(chunk), so the block's CRC is the XOR over the full chunks t of
+    // shift^(F-1-t)(crc_t), F = number of full chunks; shift^(2^j) is a table set (crc_tabs[256 +
+    // 1024 j ..]), so every thread applies at most 8 of them, in parallel; a short tail chunk (last
+    // block of a file) is appended bytewise by thread 0.
+    {
+        const uint32_t F = n / DF_CHUNK;
+        if ((uint32_t)tid < F) {
+            uint32_t x = crcp[tid];
+            const uint32_t e = F - 1 - (uint32_t)tid;
+            for (uint32_t j = 0; j < 8; ++j)
+                if ((e >> j) & 1u) {
+                    const uint32_t *T = crc_tabs + 256 + 1024 * j;
+                    x = T[x & 255u] ^ T[256 + ((x >> 8) & 255u)] ^ T[512 + ((x >> 16) & 255u)] ^ T[768 + (x >> 24)];
+                }
+            atomicXor(&crc_acc, x);
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t c = crc_acc;
+        const uint32_t F = n / DF_CHUNK, tail = n - F * DF_CHUNK;
+        if (tail) {
+            if (F == 0) c = crcp[0];
+            else {
+                for (uint32_t z = 0; z < tail; ++z) c = crc_t[c & 255u] ^ (c >> 8);
+                c ^= crcp[F];
             }
-            c ^= crcp[t];
         }
         blk_crc = c ^ 0xFFFFFFFFu;
     }
@@ -362,31 +420,14 @@ __global__ __launch_bounds__(DF_THREADS) void k_row_deflate(const uint8_t *__res
 
     // ---- pass C: bit counts, offsets, emission.  One walk = a lambda over the tokens ----
     auto walk = [&](auto &&emit) {
-        PayCur cur;
-        if (c0 < c1) cur_seek(cur, base, segs, nseg, L0 + c0);
-        uint32_t s = 0, e = 0;
-        bool in_run = false;
-        for (uint32_t i = c0; i < c1; ++i) {
-            const uint32_t v = cur_next(cur, base, segs, nseg);
-            int role = 0;
-            if (is_eq(i)) {
-                if (!in_run) {
-                    s = (i == c0) ? (uint32_t)(prevNE + 1) : i;
-                    e = run_end(i);
-                    in_run = true;
-                }
-                role = df_role(i, s, e);
-            } else {
-                in_run = false;
-            }
-            if (role == 0) emit(lcode[v], llen[v]);
-            else if (role > 0) {
-                const int ls = df_len_sym((uint32_t)role);
-                emit(lcode[257 + ls], llen[257 + ls]);
-                if (DF_LEN_EXTRA[ls]) emit((uint32_t)role - DF_LEN_BASE[ls], DF_LEN_EXTRA[ls]);
-                emit(dval, dbits);
-            }
-        }
+        tokens([&](uint32_t v) { emit(lcode[v], llen[v]); },
+               [&](uint32_t L) {
+                   uint32_t nx, xv;
+                   const int ls = df_len_sym(L, nx, xv);
+                   emit(lcode[257 + ls], llen[257 + ls]);
+                   if (nx) emit(xv, nx);
+                   emit(dval, dbits);
+               });
         if (c0 < c1 && c1 == n) emit(lcode[256], llen[256]);  // end of block, by the owner of the last byte
     };
     uint32_t mybits = 0;
@@ -446,9 +487,7 @@ __global__ __launch_bounds__(DF_THREADS) void k_row_deflate(const uint8_t *__res
             slot[21] = (uint8_t)~n;
             slot[22] = (uint8_t)(~n >> 8);
         }
-        PayCur cur;
-        if (c0 < c1) cur_seek(cur, base, segs, nseg, L0 + c0);
-        for (uint32_t i = c0; i < c1; ++i) slot[23 + i] = (uint8_t)cur_next(cur, base, segs, nseg);
+        for (uint32_t i = tid; i < n; i += DF_THREADS) slot[23 + i] = data[i];
     }
     if (tid == 0) {
         const uint32_t body = fits ? sbytes : 5 + n;
