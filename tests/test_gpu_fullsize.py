@@ -98,3 +98,38 @@ def test_multiword_shapes_properties(ctx, G, k):
     for s in seqsets:
         s.close()
     tbl.close()
+
+
+def test_more_than_2_32_positions_in_one_result(ctx):
+    """Human-pangenome scale: one result over > 2^32 positions (byte offsets, tile counts and the
+    co-scheduled order are 64-bit clean).  46 resident copies of a 2 x 100 Mb anchor are concatenated on
+    the device; every copy must reproduce the single-copy rows, bins and column sums."""
+    from panagram_amd import engine
+    G, k, copies = 2, 21, 46
+    contig_lens = [20_000_000] * 5
+    genomes, seqsets, tbl = _build(ctx, G, contig_lens, k, 0.01, 77)
+    tbl.rehash(2.0)
+    nc = len(contig_lens)
+    one = engine.AnchorResult(tbl, seqsets[1], colsums=True)
+    one.run()
+    ref_cs = one.contig_colsums()
+    ref = {c: one.download(c) for c in (0, nc - 1)}
+    big = engine.SeqSet.concat(ctx, [seqsets[1]] * copies)
+    total = copies * sum(L - k + 1 for L in contig_lens)
+    assert total > 2 ** 32
+    for grouped in (False, True):
+        res = engine.AnchorResult(tbl, big, colsums=True)
+        if grouped:
+            res.coschedule(np.repeat(np.arange(copies), nc), 64)
+        res.run()
+        cs = res.contig_colsums()
+        assert np.array_equal(cs, np.tile(ref_cs, (copies, 1)))
+        assert int(res.colsums()[1]) == total
+        for copy in (0, copies // 2, copies - 1):
+            for c in (0, nc - 1):
+                rows, rows100, bins, info = res.download(copy * nc + c)
+                assert np.array_equal(rows, ref[c][0]) and np.array_equal(rows100, ref[c][1])
+                assert np.array_equal(bins, ref[c][2])
+        res.close()
+    big.close()
+    one.close()
