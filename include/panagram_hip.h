@@ -102,6 +102,18 @@ int pg_table_load_kmc1(pg_table *tbl, int db_idx, const void *pre, size_t pre_le
 /* statistics: distinct keys, slot capacity, bucket count, bytes, summed over sub-tables */
 int pg_table_stats(pg_table *tbl, uint64_t *nkeys, uint64_t *nslots, uint64_t *nbuckets,
                    uint64_t *bytes);
+/* Distinct canonical k-mers of a set of inputs before a table exists (HyperLogLog, 2^16 registers,
+ * standard error 0.4 %): sizes pg_table_create's expected_keys, so the table is neither re-hashed
+ * while it grows nor held twice in HBM.  Replaces nothing in the reference (KMC is only given a memory cap:
+ * panagram/workflow/Snakefile:101 -m{config[kmc][memory]}); pg_sketch_registers exposes the
+ * 65536 register values for parity with the CPU restatement. */
+typedef struct pg_sketch pg_sketch;
+int pg_sketch_create(pg_ctx *ctx, int k, pg_sketch **out);
+int pg_sketch_add_seqset(pg_sketch *sk, const pg_seqset *seqs);
+int pg_sketch_estimate(pg_sketch *sk, uint64_t *distinct);
+int pg_sketch_registers(pg_sketch *sk, uint8_t *out65536);
+int pg_sketch_destroy(pg_sketch *sk);
+
 /* re-hash into the smallest table whose mean occupancy is <= keys_per_bucket keys per 128 bytes;
  * also settles the minimizer length for the keys actually present */
 int pg_table_rehash(pg_table *tbl, double keys_per_bucket);

@@ -143,6 +143,51 @@ def build_bitvec_dbs(genomes: Sequence[Sequence[bytes]], k: int,
 # ---------------------------------------------------------------------------
 # KMC1 database files
 # ---------------------------------------------------------------------------
+SKETCH_BITS = 16
+
+
+def sketch_registers(seqs: Sequence[bytes], k: int) -> np.ndarray:
+    """HyperLogLog registers (2^16, uint8) over the canonical k-mers of ``seqs`` — the CPU
+    restatement of the build's own table-sizing sketch (include/panagram_hip.h pg_sketch_*; the
+    reference has no counterpart: KMC is only given a memory cap, panagram/workflow/Snakefile:101).
+    hash = splitmix64 finalizer of the canonical k-mer value; register = top 16 bits; value = 1 +
+    leading zeros of the remaining 48 bits (49 when they are all zero)."""
+    regs = np.zeros(1 << SKETCH_BITS, np.uint8)
+    for seq in seqs:
+        vals, valid = canonical_kmers(seq, k)
+        x = vals[valid].astype(np.uint64)
+        with np.errstate(over="ignore"):
+            x ^= x >> np.uint64(30)
+            x *= np.uint64(0xbf58476d1ce4e5b9)
+            x ^= x >> np.uint64(27)
+            x *= np.uint64(0x94d049bb133111eb)
+            x ^= x >> np.uint64(31)
+        idx = (x >> np.uint64(64 - SKETCH_BITS)).astype(np.int64)
+        rest = x << np.uint64(SKETCH_BITS)
+        # leading zeros of a 64-bit word: 63 - floor(log2) through the bit length of the top set bit
+        rho = np.full(len(x), 65 - SKETCH_BITS, np.uint8)
+        nz = rest != 0
+        r = rest[nz]
+        lz = np.zeros(len(r), np.uint8)
+        for sh in (32, 16, 8, 4, 2, 1):
+            hi_clear = (r >> np.uint64(64 - sh)) == 0
+            lz[hi_clear] += sh
+            r[hi_clear] <<= np.uint64(sh)
+        rho[nz] = lz + 1
+        np.maximum.at(regs, idx, rho)
+    return regs
+
+
+def sketch_estimate(regs: np.ndarray) -> int:
+    """HyperLogLog estimate with the small-range (linear counting) correction."""
+    m = float(len(regs))
+    est = (0.7213 / (1.0 + 1.079 / m)) * m * m / float(np.sum(np.ldexp(1.0, -regs.astype(np.int64))))
+    zeros = int(np.count_nonzero(regs == 0))
+    if est <= 2.5 * m and zeros:
+        est = m * np.log(m / zeros)
+    return int(est + 0.5)
+
+
 def pick_lut_prefix_len(k: int, nkeys: int) -> int:
     """(k - lut_prefix_len) % 4 == 0, sized so buckets stay small."""
     cands = [p for p in range(1, min(k, 13)) if (k - p) % 4 == 0]

@@ -42,6 +42,11 @@ PROTOTYPES = {
     "pg_table_stats": (C.c_int, [_vp, _u64p, _u64p, _u64p, _u64p]),
     "pg_table_rehash": (C.c_int, [_vp, C.c_double]),
     "pg_table_spill": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]),
+    "pg_sketch_create": (C.c_int, [_vp, C.c_int, C.POINTER(_vp)]),
+    "pg_sketch_add_seqset": (C.c_int, [_vp, _vp]),
+    "pg_sketch_estimate": (C.c_int, [_vp, _u64p]),
+    "pg_sketch_registers": (C.c_int, [_vp, _vp]),
+    "pg_sketch_destroy": (C.c_int, [_vp]),
     "pg_table_export": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_uint64, _u64p]),
     "pg_table_k": (C.c_int, [_vp]),
     "pg_table_ngenomes": (C.c_int, [_vp]),

@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -81,6 +82,7 @@ struct pg_table {
     int k, ngenomes, ndbs;
     uint32_t m;  // minimizer length of every sub-table (0 = direct hashing)
     bool m_pinned = false;  // set by pg_table_set_minimizer: re-hashing keeps m
+    uint64_t expected = 0;  // pg_table_create's expected_keys (0: unknown)
     std::vector<SubHost> subs;
     unsigned long long *d_counters;  // [0] newly claimed, [1] overflow flag
     double spill = 0;                // keys outside their home line / keys, as of the last pg_table_rehash
@@ -266,6 +268,7 @@ extern "C" int pg_table_create(pg_ctx *ctx, int k, int ngenomes, uint64_t expect
     t->ngenomes = ngenomes;
     t->ndbs = ndbs;
     t->m = minimizer_length((uint32_t)k, expected_keys, (uint32_t)ngenomes);
+    t->expected = expected_keys;
     t->d_counters = nullptr;
     hipError_t e = hipMalloc(reinterpret_cast<void **>(&t->d_counters), 2 * sizeof(unsigned long long));
     if (e != hipSuccess) {
@@ -369,12 +372,27 @@ static int ensure_room(pg_table *t, int si, uint64_t incoming) {
     SubHost &s = t->subs[si];
     const int ns = (int)s.d.slots;
     const double slots = (double)s.d.nbuckets * ns;
+    // `incoming` counts positions, an upper bound on new keys.  A table created for a known number of
+    // distinct keys (pg_table_create's expected_keys, e.g. from a pg_sketch) is trusted while its
+    // count stays inside that number: should the estimate have been wrong, the insert's overflow flag
+    // and after_insert() still grow it.
+    if (t->expected && s.count <= t->expected && (double)t->expected <= HARD_LOAD * slots) return PG_OK;
     if ((double)(s.count + incoming) > HARD_LOAD * slots) {
         uint64_t nb = (uint64_t)((double)(s.count + incoming) / (HARD_LOAD * 0.9 * ns)) + 1;
         nb = std::max(nb, s.d.nbuckets * 2);
         return regrow(t, si, nb);
     }
     return PG_OK;
+}
+
+// an insert ran out of probe sequence: whatever sized the table was wrong — fall back to the
+// pessimistic bound (every incoming item a new key), or at least double
+static int grow_after_overflow(pg_table *t, int si, uint64_t incoming) {
+    t->expected = 0;
+    const uint64_t before = t->subs[si].d.nbuckets;
+    if (int r = ensure_room(t, si, incoming)) return r;
+    if (t->subs[si].d.nbuckets != before) return PG_OK;
+    return regrow(t, si, before * 2);
 }
 
 static int after_insert(pg_table *t, int si) {
@@ -413,7 +431,7 @@ extern "C" int pg_table_insert_seqset(pg_table *t, int g, const pg_seqset *sq) {
         t->subs[si].count += cnt[0];
         if (cnt[1] == 0) return after_insert(t, si);
         // a probe chain exceeded MAX_PROBE buckets: grow and redo (inserts are idempotent)
-        if (int r = regrow(t, si, t->subs[si].d.nbuckets * 2)) return r;
+        if (int r = grow_after_overflow(t, si, total)) return r;
     }
     return fail(PG_E_CAPACITY, "k-mer table keeps overflowing");
 }
@@ -471,7 +489,7 @@ extern "C" int pg_table_insert_seqset_min(pg_table *t, int g, const pg_seqset *s
                     rc = after_insert(t, si);
                     break;
                 }
-                rc = regrow(t, si, t->subs[si].d.nbuckets * 2);  // the merge is idempotent: redo it
+                rc = grow_after_overflow(t, si, c2[0]);  // the merge is idempotent: redo it
                 if (!rc && a2 == 7) rc = fail(PG_E_CAPACITY, "k-mer table keeps overflowing");
             }
         }
@@ -492,7 +510,7 @@ static int insert_keys_dev(pg_table *t, int db_idx, const uint64_t *d_keys, cons
         if (int r = read_counters(t, cnt)) return r;
         t->subs[si].count += cnt[0];
         if (cnt[1] == 0) return after_insert(t, si);
-        if (int r = regrow(t, si, t->subs[si].d.nbuckets * 2)) return r;
+        if (int r = grow_after_overflow(t, si, n)) return r;
     }
     return fail(PG_E_CAPACITY, "k-mer table keeps overflowing");
 }
@@ -686,6 +704,85 @@ extern "C" int pg_table_export(pg_table *t, int db_idx, uint64_t *keys, uint32_t
     if (dv) hipFree(dv);
     *n = cnt[0];
     return rc;
+}
+
+// ---------------------------------------------------------------------------
+// distinct-k-mer sketch (sizes a table before it is built)
+// ---------------------------------------------------------------------------
+struct pg_sketch {
+    pg_ctx *ctx;
+    int k;
+    uint32_t *d_regs;
+};
+
+extern "C" int pg_sketch_create(pg_ctx *ctx, int k, pg_sketch **out) {
+    if (!ctx || !out) return fail(PG_E_INVALID, "pg_sketch_create: NULL argument");
+    if (k < 1 || k > 32) return fail(PG_E_INVALID, "k=%d unsupported (1..32)", k);
+    if (int r = use_device(ctx)) return r;
+    uint32_t *regs = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&regs), sizeof(uint32_t) << SKETCH_BITS));
+    hipError_t e = hipMemsetAsync(regs, 0, sizeof(uint32_t) << SKETCH_BITS, ctx->stream);
+    if (e != hipSuccess) {
+        hipFree(regs);
+        return fail(PG_E_HIP, "hipMemsetAsync failed: %s", hipGetErrorString(e));
+    }
+    pg_sketch *sk = new pg_sketch{ctx, k, regs};
+    ++ctx->refs;
+    *out = sk;
+    return PG_OK;
+}
+
+extern "C" int pg_sketch_destroy(pg_sketch *sk) {
+    if (!sk) return PG_OK;
+    hipSetDevice(sk->ctx->device);
+    hipStreamSynchronize(sk->ctx->stream);
+    hipFree(sk->d_regs);
+    pg_ctx *c = sk->ctx;
+    delete sk;
+    ctx_release(c);
+    return PG_OK;
+}
+
+extern "C" int pg_sketch_add_seqset(pg_sketch *sk, const pg_seqset *sq) {
+    if (!sk || !sq) return fail(PG_E_INVALID, "pg_sketch_add_seqset: NULL argument");
+    if (sk->ctx != sq->ctx) return fail(PG_E_INVALID, "sketch and seqset belong to different contexts");
+    if (int r = use_device(sk->ctx)) return r;
+    for (uint32_t c = 0; c < sq->n; ++c) {
+        const SeqDesc &sd = sq->desc[c];
+        if (sd.len < (uint64_t)sk->k) continue;
+        HIP_TRY(launch_sketch(sk->ctx->stream, sk->k, sq->d_seqw + sd.seq_off, sq->d_nmw + sd.seq_off, sq->d_has_n + c,
+                              sd.len - sk->k + 1, sk->d_regs));
+    }
+    return PG_OK;
+}
+
+extern "C" int pg_sketch_registers(pg_sketch *sk, uint8_t *out) {
+    if (!sk || !out) return fail(PG_E_INVALID, "pg_sketch_registers: NULL argument");
+    if (int r = use_device(sk->ctx)) return r;
+    std::vector<uint32_t> regs((size_t)1 << SKETCH_BITS);
+    HIP_TRY(hipMemcpyAsync(regs.data(), sk->d_regs, regs.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, sk->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(sk->ctx->stream));
+    for (size_t i = 0; i < regs.size(); ++i) out[i] = (uint8_t)regs[i];
+    return PG_OK;
+}
+
+// HyperLogLog (Flajolet et al. 2007) with the small-range correction; 64-bit hashes need no
+// large-range one.  Standard error 1.04 / sqrt(2^16) = 0.4 %.
+extern "C" int pg_sketch_estimate(pg_sketch *sk, uint64_t *distinct) {
+    if (!sk || !distinct) return fail(PG_E_INVALID, "pg_sketch_estimate: NULL argument");
+    std::vector<uint8_t> regs((size_t)1 << SKETCH_BITS);
+    if (int r = pg_sketch_registers(sk, regs.data())) return r;
+    const double m = (double)regs.size();
+    double sum = 0.0;
+    size_t zeros = 0;
+    for (uint8_t v : regs) {
+        sum += std::ldexp(1.0, -(int)v);
+        zeros += v == 0;
+    }
+    double est = (0.7213 / (1.0 + 1.079 / m)) * m * m / sum;
+    if (est <= 2.5 * m && zeros) est = m * std::log(m / (double)zeros);
+    *distinct = (uint64_t)(est + 0.5);
+    return PG_OK;
 }
 
 // ---------------------------------------------------------------------------

@@ -165,6 +165,17 @@ __device__ __forceinline__ uint64_t canonical_from_le(uint64_t x, int k) {
     return canonical_from_xb(x, revcomp_le(x, k), k);
 }
 
+// hash of a key for the distinct-count sketch (splitmix64 finalizer: a bijection on 64 bits)
+constexpr uint32_t SKETCH_BITS = 16;
+__host__ __device__ __forceinline__ uint64_t sketch_hash(uint64_t x) {
+    x ^= x >> 30;
+    x *= 0xbf58476d1ce4e5b9ull;
+    x ^= x >> 27;
+    x *= 0x94d049bb133111ebull;
+    x ^= x >> 31;
+    return x;
+}
+
 // rank of a canonical m-mer (up to 30 bases = 60 bits) in the scrambled order: the bits above 32
 // are folded in with rotates (no multiply), then a multiplicative scramble.  For m <= 16 the fold is
 // the identity and the rank a bijection; longer m-mers may tie, which only merges two groups.

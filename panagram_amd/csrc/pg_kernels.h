@@ -63,6 +63,8 @@ hipError_t launch_text_pack(hipStream_t st, const uint8_t *d_text, const TextChu
                             uint64_t *d_rec_len, const SeqDesc *sd, uint64_t *seqw, uint32_t *nmw, uint32_t *has_n);
 hipError_t launch_pack(hipStream_t st, const void *d_ascii, uint64_t len, uint64_t *seqw, uint32_t *nmw,
                        uint64_t nwords, uint32_t *has_n);
+hipError_t launch_sketch(hipStream_t st, int k, const uint64_t *seqw, const uint32_t *nmw, const uint32_t *has_n,
+                         uint64_t nkmers, uint32_t *regs);
 hipError_t launch_insert_seq(hipStream_t st, const SubTable &t, int w, uint32_t bits, int k,
                              const uint64_t *seqw, const uint32_t *nmw, const uint32_t *has_n,
                              uint64_t nkmers, unsigned long long *counters, uint32_t max_probe, int count_mode = 0);

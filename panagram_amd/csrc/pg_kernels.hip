@@ -237,6 +237,27 @@ __global__ __launch_bounds__(256) void k_insert_seq(SubTable st, int w, uint32_t
     if (claimed) atomicAdd(&counters[0], (unsigned long long)claimed);
 }
 
+// ---------------------------------------------------------------------------
+// Distinct canonical k-mers of the inputs BEFORE any table exists: a HyperLogLog sketch (2^16
+// registers).  One streaming pass (no table access); sizes the table once, so that it is neither
+// re-hashed while it grows nor held twice in HBM.  register = hash >> 48, value = 1 + leading zeros
+// of the remaining 48 bits.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_sketch(int k, const uint64_t *seqw, const uint32_t *nmw, const uint32_t *has_n,
+                                                uint64_t nkmers, uint32_t *regs) {
+    uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const bool hasn = (*has_n != 0);
+    for (; p < nkmers; p += stride) {
+        if (hasn && extract_nmask(nmw, p, k)) continue;
+        const uint64_t h = sketch_hash(canonical_from_le(extract_bases(seqw, p), k));
+        const uint32_t idx = (uint32_t)(h >> (64 - SKETCH_BITS));
+        const uint64_t rest = h << SKETCH_BITS;
+        const uint32_t rho = rest ? (uint32_t)__clzll((long long)rest) + 1u : (65u - SKETCH_BITS);
+        if (regs[idx] < rho) atomicMax(&regs[idx], rho);  // (a stale read only costs a redundant atomic)
+    }
+}
+
 __global__ __launch_bounds__(256) void k_insert_keys(SubTable st, int w, const uint64_t *keys,
                                                      const uint32_t *vals, uint64_t n,
                                                      unsigned long long *counters, uint32_t max_probe) {
@@ -395,6 +416,13 @@ hipError_t launch_text_pack(hipStream_t st, const uint8_t *d_text, const TextChu
     if (nchunks)
         hipLaunchKernelGGL(k_text_pack, dim3((unsigned)nchunks), dim3(TEXT_THREADS), 0, st, d_text, d_chunks, d_base, sd,
                            seqw, nmw, has_n);
+    return hipGetLastError();
+}
+
+hipError_t launch_sketch(hipStream_t st, int k, const uint64_t *seqw, const uint32_t *nmw, const uint32_t *has_n,
+                         uint64_t nkmers, uint32_t *regs) {
+    if (nkmers == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_sketch, dim3(grid_for(nkmers, 256, 256 * 64)), dim3(256), 0, st, k, seqw, nmw, has_n, nkmers, regs);
     return hipGetLastError();
 }
 

@@ -191,6 +191,42 @@ class SeqSet(_Owner):
             pass
 
 
+class KmerSketch:
+    """Distinct canonical k-mers of a set of inputs before any table exists (HyperLogLog on the GPU,
+    standard error 0.4 %): ``PanTable(..., expected_keys=sketch.estimate())`` is then sized once."""
+
+    def __init__(self, ctx: Context, k: int):
+        self.ctx, self._lib, self.k = ctx, ctx._lib, k
+        h = C.c_void_p()
+        check(self._lib.pg_sketch_create(ctx._h, k, C.byref(h)))
+        self._h = h
+        ctx._adopt(self)
+
+    def add(self, seqs: SeqSet) -> None:
+        check(self._lib.pg_sketch_add_seqset(self._h, seqs._h))
+
+    def estimate(self) -> int:
+        n = C.c_uint64()
+        check(self._lib.pg_sketch_estimate(self._h, C.byref(n)))
+        return int(n.value)
+
+    def registers(self) -> np.ndarray:
+        out = np.empty(65536, np.uint8)
+        check(self._lib.pg_sketch_registers(self._h, _ptr(out)))
+        return out
+
+    def close(self) -> None:
+        if self._h:
+            self._lib.pg_sketch_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class PanTable(_Owner):
     """GPU-resident k-mer -> genome-mask table (replaces kmc/bitvec{i})."""
 

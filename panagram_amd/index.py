@@ -352,9 +352,9 @@ class Index:
     def build_table(self) -> engine.PanTable:
         if self._table is not None:
             return self._table
-        tbl = engine.PanTable(self.context, self.k, self.ngenomes)
         have = all(os.path.exists(p + ".kmc_pre") and os.path.exists(p + ".kmc_suf") for p in self.bitvec_prefixes)
         if self.kmc.use_existing and have:
+            tbl = engine.PanTable(self.context, self.k, self.ngenomes)
             for i, p in enumerate(self.bitvec_prefixes):
                 with open(p + ".kmc_pre", "rb") as f:
                     pre = f.read()
@@ -363,23 +363,35 @@ class Index:
                 tbl.load_kmc1(i, pre, suf)
             logger.info("KMC Database Loaded")
         else:
+            # every input is parsed and packed once on the GPU (0.375 byte per base) and stays
+            # resident through the build; a sketch of the distinct k-mers over all of them sizes the
+            # table (and settles its minimizer length) once: no re-hash while it grows, no second
+            # copy of the table in HBM.  Anchors keep their sequences for the anchor step.
+            inputs = []
+            sketch = engine.KmerSketch(self.context, self.k)
             for name, g in self.genomes.items():
                 if pd.isna(g.fasta):
                     continue
                 if is_fastq(g.fasta):
                     # read sets: kmc -ci2 -fq (workflow/Snakefile:88-89) — k-mers seen once are dropped
+                    # (the sketch counts them too: the table is sized from above)
                     if name in self.anchor_genomes:
                         raise ValueError(f"{name}: a FASTQ sample cannot be an anchor genome")
                     ss = engine.SeqSet.from_host(self.context, [read_fastq_joined(g.fasta)])
-                    tbl.insert_seqset(g.id, ss, min_count=2)
+                    inputs.append((name, g, ss, 2))
+                else:
+                    inputs.append((name, g, self.seqset_for(name), 1))
+                sketch.add(inputs[-1][2])
+            expected = sketch.estimate()
+            sketch.close()
+            tbl = engine.PanTable(self.context, self.k, self.ngenomes, expected_keys=expected + expected // 32 + 1024)
+            for name, g, ss, min_count in inputs:
+                tbl.insert_seqset(g.id, ss, min_count=min_count)
+                if min_count > 1:
                     ss.close()
-                    continue
-                # parsed and packed once on the GPU; anchors keep theirs resident for the anchor step
-                ss = self.seqset_for(name)
-                tbl.insert_seqset(g.id, ss)
-                if name not in self.anchor_genomes:
+                elif name not in self.anchor_genomes:
                     self.drop_seqset(name)
-            logger.info("k-mer table built on GPU: %s", tbl.stats())
+            logger.info("k-mer table built on GPU (sketch: %d distinct k-mers): %s", expected, tbl.stats())
             if self.export_kmc:
                 os.makedirs(self.get_subdir("kmc"), exist_ok=True)
                 for i, p in enumerate(self.bitvec_prefixes):

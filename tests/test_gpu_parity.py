@@ -536,3 +536,42 @@ def test_sixteen_slot_lines_knob(ctx, monkeypatch):
             assert np.array_equal(rows, o_rows) and np.array_equal(rows100, o_rows100)
             assert np.array_equal(bins.astype(np.int64), o_bins) and np.array_equal(cs.astype(np.int64), o_cs)
     tbl.close()
+
+
+@pytest.mark.parametrize("k", [21, 31, 9])
+def test_kmer_sketch_registers_equal_oracle(ctx, k):
+    """Table sizing: the GPU sketch's registers are bit-exact with the restatement, the estimate is
+    within 5 standard errors of the exact distinct count, and adding an input twice changes nothing."""
+    from panagram_amd import engine
+    rng = np.random.default_rng(100 + k)
+    base = rng.integers(0, 4, 400_000, dtype=np.uint8)
+    other = base.copy()
+    hit = rng.random(len(other)) < 0.02
+    other[hit] = (other[hit] + rng.integers(1, 4, int(hit.sum()), dtype=np.uint8)) & 3
+    a = bytearray(po.codes_to_ascii(base))
+    a[1000:1300] = b"N" * 300
+    a[50_000:50_010] = b"acgtnacgtn"
+    seqs = [[bytes(a[:250_000]), bytes(a[250_000:])], [po.codes_to_ascii(other), b"ACGT"]]
+    sk = engine.KmerSketch(ctx, k)
+    for contigs in seqs:
+        ss = engine.SeqSet.from_host(ctx, contigs)
+        sk.add(ss)
+        sk.add(ss)
+        ss.close()
+    want = po.sketch_registers([c for g in seqs for c in g], k)
+    assert np.array_equal(sk.registers(), want)
+    exact = len(np.unique(np.concatenate([v[ok] for v, ok in (po.canonical_kmers(c, k) for g in seqs for c in g)])))
+    est = sk.estimate()
+    assert est == po.sketch_estimate(want)
+    assert abs(est - exact) <= 0.02 * exact
+    # a table created from the estimate takes all keys without growing
+    tbl = engine.PanTable(ctx, k, 2, expected_keys=est + est // 32 + 1024)
+    before = tbl.stats()["nbuckets"]
+    for g, contigs in enumerate(seqs):
+        ss = engine.SeqSet.from_host(ctx, contigs)
+        tbl.insert_seqset(g, ss)
+        ss.close()
+    st = tbl.stats()
+    assert st["nkeys"] == exact and st["nbuckets"] == before
+    sk.close()
+    tbl.close()

@@ -218,3 +218,36 @@ def test_row_aware_deflate_round_trips(tmp_path, row):
             assert gi[0] == gr[0] and np.array_equal(gi[2::2], gr[2::2])   # same uncompressed block starts
     big = cases["runs"]
     assert os.path.getsize(tmp_path / "runs.gz") < 0.6 * len(big) or row >= 64
+
+
+def test_oracle_sketch_against_pure_python_and_exact_count():
+    """The distinct-k-mer sketch restated in the oracle: registers against a pure-Python loop over
+    Python ints, the estimate against the exact number of distinct canonical k-mers."""
+    from oracle import pyoracle as po
+    rng = np.random.default_rng(3)
+    k = 11
+    seqs = [bytes(rng.choice(np.frombuffer(b"ACGTN", np.uint8), size=3000, p=[.2495, .2495, .2495, .2495, .002])) for _ in range(3)]
+    regs = po.sketch_registers(seqs, k)
+    M = (1 << 64) - 1
+    want = [0] * 65536
+    distinct = set()
+    for s in seqs:
+        vals, valid = po.canonical_kmers(s, k)
+        for v in vals[valid].tolist():
+            distinct.add(v)
+            x = v
+            x ^= x >> 30; x = (x * 0xbf58476d1ce4e5b9) & M
+            x ^= x >> 27; x = (x * 0x94d049bb133111eb) & M
+            x ^= x >> 31
+            rest = (x << 16) & M
+            rho = 49 if rest == 0 else 64 - rest.bit_length() + 1
+            want[x >> 48] = max(want[x >> 48], rho)
+    assert regs.tolist() == want
+    # small range: linear counting is nearly exact
+    assert abs(po.sketch_estimate(regs) - len(distinct)) <= 0.02 * len(distinct)
+    # large range
+    big = [bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), size=1_500_000))]
+    vals, valid = po.canonical_kmers(big[0], 21)
+    exact = len(np.unique(vals[valid]))
+    est = po.sketch_estimate(po.sketch_registers(big, 21))
+    assert abs(est - exact) <= 0.02 * exact  # 5 standard errors
