@@ -2,6 +2,7 @@
 [--prepare]`, panagram/__main__.py:154-194, index.py:90-123) plus the process-level seam of
 cpp/run_anchor (`run_anchor <ngenomes> <root> [<name> <fasta>]...`)."""
 import argparse
+import os
 import sys
 
 
@@ -15,7 +16,8 @@ def main(argv=None):
     ix.add_argument("-c", "--cores", type=int, default=1)
     ix.add_argument("-p", "--prepare", action="store_true")
     ix.add_argument("--anchor_genomes", nargs="*", default=None)
-    ix.add_argument("--device", type=int, default=0)
+    # one process per GPU under torchrun: LOCAL_RANK picks the GPU, RANK / WORLD_SIZE the anchor genomes
+    ix.add_argument("--device", type=int, default=int(os.environ.get("LOCAL_RANK", "0")))
     ix.add_argument("--export_kmc", action="store_true", help="also write kmc/bitvec{i} (KMC1 layout)")
     ix.add_argument("--kmc.use_existing", dest="use_existing", action="store_true")
     ra = sub.add_parser("run_anchor", help="argv-compatible with the reference's cpp/run_anchor")

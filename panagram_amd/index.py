@@ -210,8 +210,10 @@ class Index:
     #    also export kmc/bitvec{i} in KMC1 layout for the reference to read
     device: int = 0
     export_kmc: bool = False
+    rank: int = dataclasses.field(default_factory=lambda: int(os.environ.get("RANK", "0")))
+    world: int = dataclasses.field(default_factory=lambda: int(os.environ.get("WORLD_SIZE", "1")))
 
-    _EXTRA = ("device", "export_kmc")
+    _EXTRA = ("device", "export_kmc", "rank", "world")
 
     def __post_init__(self):
         if not (self.mode is None or self.mode in {"r", "w"}):
@@ -321,15 +323,20 @@ class Index:
             else:
                 self.anchor_genomes = list(samples["fasta"].dropna().index)
         samples["anchor"] = samples.index.isin(self.anchor_genomes)
-        samples[["fasta", "gff", "id", "anchor"]].to_csv(self.samples_fname, sep="\t")
+        # (several ranks of one multi-GPU job write the same bytes: write-then-rename keeps readers whole)
+        tmp = f"{self.samples_fname}.{os.getpid()}.tmp"
+        samples[["fasta", "gff", "id", "anchor"]].to_csv(tmp, sep="\t")
+        os.replace(tmp, self.samples_fname)
         self.write_config()
 
     def write_config(self, exclude=("prefix",)):
         prms = self.params
         for p in exclude:
             del prms[p]
-        with open(self.config_fname, "w") as conf_out:
+        tmp = f"{self.config_fname}.{os.getpid()}.tmp"
+        with open(tmp, "w") as conf_out:
             yaml.dump(prms, conf_out)
+        os.replace(tmp, self.config_fname)
 
     def load_config(self):
         with open(self.config_fname) as f:
@@ -349,7 +356,9 @@ class Index:
             self._ctx = engine.Context(self.device)
         return self._ctx
 
-    def build_table(self) -> engine.PanTable:
+    def build_table(self, keep: Optional[Sequence[str]] = None) -> engine.PanTable:
+        """``keep``: the genomes whose packed sequences stay resident for the anchor step (default: all anchors)"""
+        keep = set(self.anchor_genomes if keep is None else keep)
         if self._table is not None:
             return self._table
         have = all(os.path.exists(p + ".kmc_pre") and os.path.exists(p + ".kmc_suf") for p in self.bitvec_prefixes)
@@ -389,7 +398,7 @@ class Index:
                 tbl.insert_seqset(g.id, ss, min_count=min_count)
                 if min_count > 1:
                     ss.close()
-                elif name not in self.anchor_genomes:
+                elif name not in keep:
                     self.drop_seqset(name)
             logger.info("k-mer table built on GPU (sketch: %d distinct k-mers): %s", expected, tbl.stats())
             if self.export_kmc:
@@ -424,10 +433,14 @@ class Index:
             return
         from concurrent.futures import ThreadPoolExecutor
         os.makedirs(self.get_subdir("logs"), exist_ok=True)
-        tbl = self.build_table()
+        mine = self.my_anchor_genomes()
+        if not mine:  # more ranks than anchor genomes
+            logger.info("rank %d of %d: no anchor genome to write", self.rank, self.world)
+            return
+        tbl = self.build_table(keep=mine)
         nb = (self.ngenomes + 7) // 8
         batches, cur, cur_bytes = [], [], 0
-        for name in self.anchor_genomes:  # a batch's rows stay in HBM until written: bound them
+        for name in mine:  # a batch's rows stay in HBM until written: bound them
             rows_bytes = int(self.seqset_for(name).lens.sum()) * nb
             if cur and cur_bytes + rows_bytes > self.batch_bytes:
                 batches.append(cur)
@@ -449,6 +462,19 @@ class Index:
             if previous is not None:
                 self._finish_batch(*previous)
         self.close()
+
+    def my_anchor_genomes(self) -> List[str]:
+        """Multi-GPU (one process per GPU, e.g. under torchrun: RANK / WORLD_SIZE): the table is
+        replicated — every rank builds it from all inputs — and the anchor GENOMES are dealt to the
+        ranks longest-first (FASTA size); each rank writes the directories of its genomes.  Anchors are
+        independent (cpp/anchor.cpp:217-223 runs them as OpenMP iterations), so there is no collective
+        and the files do not depend on the GPU count."""
+        if self.world <= 1:
+            return list(self.anchor_genomes)
+        from .distributed import plan_shards
+        units = [(n, 0, os.path.getsize(self.genomes[n].fasta)) for n in self.anchor_genomes]
+        mine = {u[0] for u in plan_shards(units, self.world)[self.rank]}
+        return [n for n in self.anchor_genomes if n in mine]
 
     batch_bytes = 32 << 30  # rows of one batch of anchor genomes held in HBM (bitmap.1 payload bytes)
     # BGZF compression of the bitmaps: a zlib level (host threads), or -2 = on the GPU (k_row_deflate)

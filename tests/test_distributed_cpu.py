@@ -103,3 +103,34 @@ def test_world2_sharded_index_equals_reference(name, tmp_path):
         assert (adir / "bitsum.bins.tsv").read_bytes() == fx[f"a{g}_bitsum.bins.tsv"].tobytes()
         assert (adir / "chrs.tsv").read_bytes() == fx[f"a{g}_chrs.tsv"].tobytes()
         assert not (adir / ".parts").exists()
+
+
+def test_index_deals_anchor_genomes_to_ranks(tmp_path, monkeypatch):
+    """Index.run under torchrun (RANK / WORLD_SIZE): every anchor genome goes to exactly one rank,
+    larger FASTAs first, the same answer in every process."""
+    from panagram_amd import index as pidx
+    rows = ["name\tfasta"]
+    sizes = [900, 100, 500, 400, 300, 50, 800]
+    for g, sz in enumerate(sizes):
+        fa = tmp_path / f"g{g}.fa"
+        fa.write_bytes(b">c\n" + b"A" * sz + b"\n")
+        rows.append(f"g{g}\t{fa}")
+    s = tmp_path / "samples.tsv"
+    s.write_text("\n".join(rows) + "\n")
+    for world in (1, 2, 3, 8):
+        monkeypatch.setenv("WORLD_SIZE", str(world))
+        dealt = []
+        for rank in range(world):
+            monkeypatch.setenv("RANK", str(rank))
+            idx = pidx.Index(str(s), prefix=str(tmp_path / f"idx{world}"), k=21)
+            assert (idx.rank, idx.world) == (rank, world)
+            mine = idx.my_anchor_genomes()
+            assert mine == [n for n in idx.anchor_genomes if n in mine]  # sample order is kept
+            dealt.append(mine)
+        flat = [n for m in dealt for n in m]
+        assert sorted(flat) == sorted(f"g{g}" for g in range(len(sizes)))
+        loads = [sum(sizes[int(n[1:])] for n in m) for m in dealt]
+        if world == 2:
+            assert abs(loads[0] - loads[1]) <= 150
+        if world == 8:
+            assert sum(1 for m in dealt if not m) == 1  # 7 genomes on 8 ranks

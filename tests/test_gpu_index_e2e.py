@@ -417,3 +417,37 @@ def test_gpu_bgzf_multi_batch(ctx, tmp_path):
     assert np.array_equal(g[1::2][1:] > g[1::2][:-1], np.ones(nblocks - 2, bool))
     for x in (res, sa, sb, tbl):
         x.close()
+
+
+@pytest.mark.parametrize("name,world", [("n9_k21", 2), ("n40_k31", 3)])
+def test_index_run_on_several_ranks_writes_the_same_tree(name, world, tmp_path):
+    """Multi-GPU Index.run (one process per GPU; here the ranks run one after the other on the one
+    GPU of the box): anchor genomes are dealt to the ranks, the table is replicated, and the tree of
+    files is byte-identical to the single-rank run — it does not depend on the GPU count."""
+    from panagram_amd import index as pidx
+    fx = H.load_case(name)
+    k = int(fx["k"])
+    anchors = [f"g{g}" for g in fx["anchors"]]
+    s = _write_case(tmp_path, fx)
+    one = tmp_path / "one"
+    pidx.Index(str(s), prefix=str(one), k=k, anchor_genomes=anchors).run()
+    many = tmp_path / "many"
+    seen = []
+    for rank in range(world):
+        idx = pidx.Index(str(s), prefix=str(many), k=k, anchor_genomes=anchors, rank=rank, world=world)
+        mine = idx.my_anchor_genomes()
+        seen += mine
+        idx.run()
+        for nm in mine:  # a rank leaves exactly its genomes' directories complete
+            assert (many / "anchor" / nm / "total_paircounts.csv").exists()
+    assert sorted(seen) == sorted(anchors) and len(seen) == len(anchors)
+    if len(anchors) >= world:
+        assert all(pidx.Index(str(s), prefix=str(many), k=k, anchor_genomes=anchors, rank=r, world=world).my_anchor_genomes()
+                   for r in range(world))
+    for dirpath, _, files in os.walk(one):
+        if os.path.basename(dirpath) == "logs":
+            continue
+        for f in files:
+            a = os.path.join(dirpath, f)
+            b = os.path.join(many, os.path.relpath(a, one))
+            assert open(a, "rb").read() == open(b, "rb").read(), f
