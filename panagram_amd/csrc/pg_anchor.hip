@@ -465,12 +465,17 @@ __device__ __forceinline__ void hist_position(bool active, uint32_t pos, uint32_
 }
 
 // four consecutive rows of NB bytes = NB aligned 32-bit words (a thread's first row starts at a
-// multiple of 4 rows): load the words, cut the rows out with static shifts
+// multiple of 4 rows): load the words (all in flight together), cut the rows out with static shifts
 template <int NB>
-__device__ __forceinline__ void load4_rows(const uint8_t *g4, uint32_t w0[4], uint32_t w1[4]) {
+__device__ __forceinline__ void load_row_words(const uint8_t *g4, uint32_t raw[8]) {
+#pragma unroll
+    for (int i = 0; i < NB; ++i) raw[i] = reinterpret_cast<const uint32_t *>(g4)[i];
+}
+template <int NB>
+__device__ __forceinline__ void cut4_rows(const uint32_t raw[8], uint32_t w0[4], uint32_t w1[4]) {
     uint32_t w[NB + 1];
 #pragma unroll
-    for (int i = 0; i < NB; ++i) w[i] = reinterpret_cast<const uint32_t *>(g4)[i];
+    for (int i = 0; i < NB; ++i) w[i] = raw[i];
     w[NB] = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -484,7 +489,6 @@ __device__ __forceinline__ void load4_rows(const uint8_t *g4, uint32_t w0[4], ui
         w1[j] = (uint32_t)(v >> 32);
     }
 }
-
 #ifndef PG_EPI_MIN_TILES
 #define PG_EPI_MIN_TILES 128
 #endif
@@ -503,28 +507,22 @@ __device__ __forceinline__ void flush_hist(uint32_t N, uint32_t *hist, uint32_t 
     }
 }
 
-// MODE 0: one-byte rows (N <= 8), 1: rows of 2..8 bytes (N <= 64), 3: wider rows, one launch per 64
-// genomes (2: the all-generic fallback, no longer launched).  One instantiation
-// per mode so that each carries only its own accumulators in registers.
+// MODE 0: one-byte rows (N <= 8), 1: rows of 2..8 bytes (N <= 64); wider rows go through
+// k_epilogue_words below.  One instantiation per mode so that each carries only its own accumulators
+// in registers.
 template <int MODE>
 __global__ __launch_bounds__(EPI_THREADS) void k_epilogue(uint32_t N, const AnchorDesc *__restrict__ ad,
                                                           const uint32_t *__restrict__ tile_contig, uint32_t ntiles,
                                                           const uint8_t *__restrict__ out1, uint8_t *__restrict__ out100,
                                                           uint32_t *__restrict__ bins,
-                                                          unsigned long long *__restrict__ colsums, uint32_t flags,
-                                                          uint32_t pair) {
+                                                          unsigned long long *__restrict__ colsums, uint32_t flags) {
     extern __shared__ uint4 smem[];
     constexpr int PT = 4;  // rows per thread and tile: EPI_THREADS = PROBE_TILE / 4 threads per workgroup
-    constexpr bool WIDE = MODE == 1 || MODE == 3;
+    constexpr bool WIDE = MODE == 1;
     const int tid = threadIdx.x, lane = tid & 63;
     const uint32_t nbytes = (N + 7) / 8;
-    // MODE 3 (rows wider than 8 bytes): one launch per pair of 32-genome words; this launch sums the
-    // columns of genomes [g_base, g_base + Nw) — bytes [8 pair, 8 pair + 8) of every row — and launch 0
-    // also does the popcount histogram and bitmap.100 of the whole rows
-    const uint32_t g_base = MODE == 3 ? 64u * pair : 0u;
-    const uint32_t Nw = MODE == 3 ? min(64u, N - g_base) : N;
-    const uint32_t ndbs = MODE == 3 ? (Nw + 31) / 32 : (N + 31) / 32;
-    const uint32_t nbw = MODE == 3 ? (Nw + 7) / 8 : nbytes;  // bytes of a row this launch sums
+    const uint32_t Nw = N;
+    const uint32_t ndbs = (N + 31) / 32;
     uint32_t *hist = reinterpret_cast<uint32_t *>(smem);
     uint32_t *cs = hist + ((EPI_MAXB * (N + 1) + 3) & ~3u);
     for (uint32_t i = tid; i < EPI_MAXB * (N + 1); i += EPI_THREADS) hist[i] = 0;
@@ -550,6 +548,8 @@ __global__ __launch_bounds__(EPI_THREADS) void k_epilogue(uint32_t N, const Anch
     uint32_t since_spill = 0;
     uint32_t next_packed = 0;  // software prefetch of the next tile's rows
     bool next_valid = false;
+    uint4 wp_a = make_uint4(0, 0, 0, 0), wp_b = make_uint4(0, 0, 0, 0);  // ... and of 4- / 8-byte rows on the wide path
+    bool wp_valid = false;
     // wide path (8 < N <= 64): column sums in three levels, all in registers until the very end —
     //  L1  per-thread VERTICAL counters: bit g of plane p is bit p of the number of rows seen with
     //      genome g set; the 4 rows of a tile enter through carry-save adders (12 ALU ops per 4 rows);
@@ -650,13 +650,10 @@ __global__ __launch_bounds__(EPI_THREADS) void k_epilogue(uint32_t N, const Anch
             if (brounds) wave_colsums();
         }
         __syncthreads();
-        // cs[] is indexed relative to g_base (0 unless MODE 3 with pair > 0, where only the wide path
-        // runs); launch 0 of MODE 3 also carries the generic path's sums of all N genomes
-        const uint32_t ncs = (MODE == 3 && pair > 0) ? Nw : N;
-        for (uint32_t i = tid; i < ncs; i += EPI_THREADS) {
+        for (uint32_t i = tid; i < N; i += EPI_THREADS) {
             const uint32_t v = cs[i];
             if (v) {
-                atomicAdd(&colsums[(uint64_t)contig * N + g_base + i], (unsigned long long)v);
+                atomicAdd(&colsums[(uint64_t)contig * N + i], (unsigned long long)v);
                 cs[i] = 0;
             }
         }
@@ -791,50 +788,47 @@ __global__ __launch_bounds__(EPI_THREADS) void k_epilogue(uint32_t N, const Anch
             // ---- wide path: the row bytes this launch sums, as one or two 32-bit words ----
             next_valid = false;
             uint32_t w0[PT], w1[PT];
-            if (MODE == 3) {  // 8 (or fewer, last pair) bytes at column 8*pair of rows nbytes apart
-                struct __attribute__((packed)) U64 { uint64_t v; };
-                const uint8_t *gc = g + 8u * pair;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    uint64_t r = 0;
-                    if (p0 + j < npos) {
-                        const uint8_t *pr = gc + (uint64_t)(p0 + j) * nbytes;
-                        if (nbw == 8) r = reinterpret_cast<const U64 *>(pr)->v;
-                        else
-                            for (uint32_t bb = 0; bb < nbw; ++bb) r |= (uint64_t)pr[bb] << (8 * bb);
-                    }
-                    w0[j] = (uint32_t)r;
-                    w1[j] = (uint32_t)(r >> 32);
-                }
-            } else if (nbytes == 4) {
-                uint4 q = make_uint4(0, 0, 0, 0);
-                if (p0 + 3 < npos) q = *reinterpret_cast<const uint4 *>(g + (uint64_t)p0 * 4);
-                else {
-                    uint32_t t4[4] = {0, 0, 0, 0};
-                    for (uint32_t j = 0; j < 4; ++j)
-                        if (p0 + j < npos) t4[j] = *reinterpret_cast<const uint32_t *>(g + (uint64_t)(p0 + j) * 4);
-                    q = make_uint4(t4[0], t4[1], t4[2], t4[3]);
-                }
-                w0[0] = q.x; w0[1] = q.y; w0[2] = q.z; w0[3] = q.w;
-                w1[0] = w1[1] = w1[2] = w1[3] = 0;
-            } else if (nbytes == 8) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    uint2 q = make_uint2(0, 0);
-                    if (p0 + j < npos) q = *reinterpret_cast<const uint2 *>(g + (uint64_t)(p0 + j) * 8);
-                    w0[j] = q.x;
-                    w1[j] = q.y;
-                }
-            } else if (p0 + 3 < npos) {  // odd widths: whole words, rows cut out with static shifts
+            if (npos == (uint32_t)PROBE_TILE && (nbytes == 4 || nbytes == 8)) {  // (block-uniform) a full tile of 4- or 8-byte rows
+                // the thread's 4 rows are 16 / 32 aligned bytes.  The next tile's are requested before this
+                // tile is worked on when it is an equally regular one right behind: loads issued only when
+                // their tile starts leave the memory latency exposed (2.2-3.4 TB/s of the 6.3 a plain
+                // streaming read reaches with this geometry)
+                const bool two = nbytes == 8;
+                uint4 qa, qb = make_uint4(0, 0, 0, 0);
                 const uint8_t *g4 = g + (uint64_t)p0 * nbytes;
+                if (wp_valid) {
+                    qa = wp_a;
+                    qb = wp_b;
+                } else {
+                    qa = *reinterpret_cast<const uint4 *>(g4);
+                    if (two) qb = *reinterpret_cast<const uint4 *>(g4 + 16);
+                }
+                wp_valid = (tile + 1 < t_end) && (tile_start + 2u * PROBE_TILE <= a.nkmers) && (tile_contig[tile + 1] == c);
+                if (wp_valid) {
+                    const uint8_t *gn = g4 + (uint64_t)PROBE_TILE * nbytes;
+                    wp_a = *reinterpret_cast<const uint4 *>(gn);
+                    if (two) wp_b = *reinterpret_cast<const uint4 *>(gn + 16);
+                }
+                if (two) {
+                    w0[0] = qa.x; w1[0] = qa.y; w0[1] = qa.z; w1[1] = qa.w;
+                    w0[2] = qb.x; w1[2] = qb.y; w0[3] = qb.z; w1[3] = qb.w;
+                } else {
+                    w0[0] = qa.x; w0[1] = qa.y; w0[2] = qa.z; w0[3] = qa.w;
+                    w1[0] = w1[1] = w1[2] = w1[3] = 0;
+                }
+            } else if (npos == (uint32_t)PROBE_TILE) {  // other widths: nbytes aligned words, rows cut out with static shifts
+                wp_valid = false;
+                const uint8_t *g4 = g + (uint64_t)p0 * nbytes;
+                uint32_t raw[8];
                 switch (nbytes) {  // block-uniform
-                    case 2: load4_rows<2>(g4, w0, w1); break;
-                    case 3: load4_rows<3>(g4, w0, w1); break;
-                    case 5: load4_rows<5>(g4, w0, w1); break;
-                    case 6: load4_rows<6>(g4, w0, w1); break;
-                    default: load4_rows<7>(g4, w0, w1); break;
+                    case 2: load_row_words<2>(g4, raw); cut4_rows<2>(raw, w0, w1); break;
+                    case 3: load_row_words<3>(g4, raw); cut4_rows<3>(raw, w0, w1); break;
+                    case 5: load_row_words<5>(g4, raw); cut4_rows<5>(raw, w0, w1); break;
+                    case 6: load_row_words<6>(g4, raw); cut4_rows<6>(raw, w0, w1); break;
+                    default: load_row_words<7>(g4, raw); cut4_rows<7>(raw, w0, w1); break;
                 }
             } else {
+                wp_valid = false;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     uint64_t r = 0;
@@ -845,31 +839,16 @@ __global__ __launch_bounds__(EPI_THREADS) void k_epilogue(uint32_t N, const Anch
                 }
             }
             const uint32_t nact = p0 < npos ? min(4u, npos - p0) : 0u;
-            if (MODE == 1 || pair == 0) {
+            {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     if ((uint32_t)j < nact) {
-                        uint32_t pc = __popc(w0[j]) + __popc(w1[j]);
-                        if (MODE == 3) {  // the rest of the row
-                            const uint8_t *pr = g + (uint64_t)(p0 + j) * nbytes;
-                            for (uint32_t bb = 8; bb < nbytes; ++bb) pc += __popc((uint32_t)pr[bb]);
-                        }
+                        const uint32_t pc = __popc(w0[j]) + __popc(w1[j]);
                         atomicAdd(&hist[(rel_base + rel_of(tile_start + p0 + j)) * (N + 1) + min(pc, N)], 1u);
                     }
                 }
             }
-            if (MODE == 3) {  // bitmap.100 of the whole row, by launch 0
-                if (pair == 0 && nact) {
-                    const uint32_t pos0 = tile_start + p0;
-                    const uint32_t r100 = (pos0 + 99u) / 100u;
-                    const uint32_t jsel = r100 * 100u - pos0;
-                    if (jsel < nact) {
-                        const uint8_t *pr = g + (uint64_t)(p0 + jsel) * nbytes;
-                        uint8_t *o100 = out100 + a.out100_off + (uint64_t)r100 * nbytes;
-                        for (uint32_t bb = 0; bb < nbytes; ++bb) o100[bb] = pr[bb];
-                    }
-                }
-            } else if (nact) {  // 1-in-100 rows: at most one of 4 consecutive positions is a multiple of 100
+            if (nact) {  // 1-in-100 rows: at most one of 4 consecutive positions is a multiple of 100
                 const uint32_t pos0 = tile_start + p0;
                 const uint32_t r100 = (pos0 + 99u) / 100u;
                 const uint32_t jsel = r100 * 100u - pos0;
@@ -891,7 +870,7 @@ __global__ __launch_bounds__(EPI_THREADS) void k_epilogue(uint32_t N, const Anch
                 vrows += PT;
                 if (vrows == 12) vflush();
             }
-        } else if (MODE != 3 || pair == 0) {  // (MODE 3: launch 0 does all of such a tile)
+        } else {
             next_valid = false;
             const uint32_t ndbs_all = (N + 31) / 32;
 #pragma unroll
@@ -919,6 +898,211 @@ __global__ __launch_bounds__(EPI_THREADS) void k_epilogue(uint32_t N, const Anch
     }
     if (want_cs && cur_c != ~0u) flush_colsums(cur_c);
     reduce_hist();
+    __syncthreads();
+    if (cur_row0 != ~0ull) flush_hist(N, hist, bins, cur_row0, tid);
+}
+
+// ---------------------------------------------------------------------------
+// Rows wider than 8 bytes (more than 64 genomes): the same statistics WORD-PARALLEL.  A lane owns one
+// 32-bit word d of the rows it visits (lanes d = 0..W-1 of consecutive lanes share a row, 64 / W rows
+// per wave and step, loads contiguous over the wave), so every lane carries the vertical counters of
+// ONE word whatever the row width, the whole row is read once, and one launch does all columns (the
+// earlier scheme ran one pass per 64 genomes, each re-reading every row).
+//   popcount of a row   W - 1 shuffles to its first lane, one LDS atomic into the bin window
+//   bitmap.100          each lane copies its word of the 1-in-100 rows
+//   column sums         carry-save vertical counters per lane (4 rows at a time), byte-sliced
+//                       accumulators, LDS atomics every 252 rows, per contig to global
+// ---------------------------------------------------------------------------
+template <int W_T>  // words per row known at compile time (1..4), or 0: any
+__global__ __launch_bounds__(EPI_THREADS) void k_epilogue_words(uint32_t N, const AnchorDesc *__restrict__ ad,
+                                                                const uint32_t *__restrict__ tile_contig, uint32_t ntiles,
+                                                                const uint8_t *__restrict__ out1, uint8_t *__restrict__ out100,
+                                                                uint32_t *__restrict__ bins,
+                                                                unsigned long long *__restrict__ colsums, uint32_t flags) {
+    extern __shared__ uint4 smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t nbytes = (N + 7) / 8, W = W_T ? (uint32_t)W_T : (nbytes + 3) / 4;
+    const uint32_t RPW = 64u / W, RPS = RPW * (EPI_THREADS / 64);  // rows per wave / per workgroup and step
+    const uint32_t d = (uint32_t)lane % W, rsub = (uint32_t)wave * RPW + (uint32_t)lane / W;
+    const bool lane_on = (uint32_t)lane < RPW * W;
+    const uint32_t wbytes = min(4u, nbytes - 4u * d);  // bytes of this lane's word (the last one may be short)
+    const uint32_t wmask = wbytes == 4 ? 0xFFFFFFFFu : (1u << (8 * wbytes)) - 1u;
+    uint32_t *hist = reinterpret_cast<uint32_t *>(smem);
+    uint32_t *cs = hist + ((EPI_MAXB * (N + 1) + 3) & ~3u);
+    for (uint32_t i = tid; i < EPI_MAXB * (N + 1); i += EPI_THREADS) hist[i] = 0;
+    for (uint32_t i = tid; i < 32u * W; i += EPI_THREADS) cs[i] = 0;
+    __syncthreads();
+    const bool want_cs = (flags & 1u) != 0;
+    const uint32_t ngroups = (ntiles + 3) / 4;
+    const uint32_t t_begin = 4u * (uint32_t)((uint64_t)ngroups * blockIdx.x / gridDim.x);
+    const uint32_t t_end = min(ntiles, 4u * (uint32_t)((uint64_t)ngroups * (blockIdx.x + 1) / gridDim.x));
+    uint64_t cur_row0 = ~0ull;
+    uint32_t cur_c = ~0u;
+    AnchorDesc a;
+    a.out_off = a.out100_off = a.bin_off = 0;
+    a.nkmers = a.binlen = a.tile0 = a.nbins = 0;
+    uint32_t vp[4] = {0, 0, 0, 0}, bacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t vrows = 0, brounds = 0;
+    auto vadd4 = [&](uint32_t r0, uint32_t r1, uint32_t r2, uint32_t r3) {
+        const uint32_t x = vp[0];
+        const uint32_t t1 = x ^ r0, s1 = t1 ^ r1, ca = (t1 & r1) | (~t1 & x);
+        const uint32_t t2 = s1 ^ r2, s2 = t2 ^ r3, cb = (t2 & r3) | (~t2 & s1);
+        vp[0] = s2;
+        const uint32_t y = vp[1];
+        const uint32_t t3 = y ^ ca, cc = (t3 & cb) | (~t3 & y);
+        vp[1] = t3 ^ cb;
+        const uint32_t c4 = vp[2] & cc;
+        vp[2] ^= cc;
+        vp[3] ^= c4;
+    };
+    auto bflush = [&]() {  // byte-sliced accumulators -> the workgroup's LDS counters of this lane's word
+        for (int q = 0; q < 8; ++q) {  // (not unrolled: rare)
+            const uint32_t v = bacc[q];
+            for (int b = 0; b < 4; ++b) {
+                const uint32_t cnt = (v >> (8 * b)) & 255u;
+                if (cnt) atomicAdd(&cs[32u * d + 8u * b + q], cnt);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) bacc[q] = 0;
+        brounds = 0;
+    };
+    auto vflush = [&]() {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t M = 0x11111111u;
+            const uint32_t nib = ((vp[0] >> j) & M) | (((vp[1] >> j) & M) << 1) | (((vp[2] >> j) & M) << 2) | (((vp[3] >> j) & M) << 3);
+            bacc[j] += nib & 0x0F0F0F0Fu;
+            bacc[4 + j] += (nib >> 4) & 0x0F0F0F0Fu;
+        }
+        vp[0] = vp[1] = vp[2] = vp[3] = 0;
+        vrows = 0;
+        if (++brounds == 31) bflush();  // 31 x 8 rows: the byte counters are about to fill
+    };
+    auto flush_colsums = [&](uint32_t contig) {
+        if (vrows) vflush();
+        if (brounds) bflush();
+        __syncthreads();
+        for (uint32_t i = tid; i < N; i += EPI_THREADS) {
+            const uint32_t v = cs[i];
+            if (v) {
+                atomicAdd(&colsums[(uint64_t)contig * N + i], (unsigned long long)v);
+                cs[i] = 0;
+            }
+        }
+        __syncthreads();
+    };
+    struct __attribute__((packed)) U32 { uint32_t v; };
+    // popcount of a whole row from its lanes' words, valid (at least) in the row's first lane
+    auto row_popc = [&](uint32_t pc) -> uint32_t {
+        if (W_T == 1) return pc;
+        if (W_T == 2) return pc + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pc, 0xB1, 0xF, 0xF, false);  // quad_perm [1,0,3,2]
+        if (W_T == 4) {
+            pc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pc, 0xB1, 0xF, 0xF, false);
+            return pc + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pc, 0x4E, 0xF, 0xF, false);  // quad_perm [2,3,0,1]
+        }
+        uint32_t tot = pc;
+        for (uint32_t q = 1; q < W; ++q) tot += (uint32_t)__shfl_down((int)pc, q);
+        return tot;
+    };
+    // The rows are streamed in iterations of 8 steps (8 x RPS rows), the loads of iteration i + 1 issued
+    // before iteration i is worked on — also across tiles: 16 loads per lane in flight keep enough
+    // bytes on their way to cover HBM latency (with 4 the kernel ran at 1.5 TB/s).
+    constexpr uint32_t NJ = 8;
+    const uint32_t iter_rows = NJ * RPS, IPT = ((uint32_t)PROBE_TILE + iter_rows - 1) / iter_rows;
+    const uint32_t nit = t_end > t_begin ? (t_end - t_begin) * IPT : 0u;
+    auto issue = [&](uint32_t it, uint32_t (&out)[NJ]) {
+        const uint32_t tile = t_begin + it / IPT, r0 = (it % IPT) * iter_rows;
+        const AnchorDesc A = ad[tile_contig[tile]];  // (uniform: scalar loads)
+        const uint32_t ts = (tile - A.tile0) * PROBE_TILE;
+        const uint32_t rows_left = A.nkmers - ts, npos = min((uint32_t)PROBE_TILE, rows_left);
+        const uint8_t *g = out1 + A.out_off + (uint64_t)ts * nbytes;
+        // branch-free: every lane always loads 4 bytes from a clamped, valid address (a predicated load per
+        // row makes the compiler wait for each load in turn); a short last word that would read past the
+        // contig's rows is fetched from 1..3 bytes earlier and shifted down
+        const uint32_t lim = max(min(rows_left, 2u * (uint32_t)PROBE_TILE) * nbytes, 4u) - 4u;  // (contig regions are 16-byte padded)
+#pragma unroll
+        for (uint32_t j = 0; j < NJ; ++j) {
+            const uint32_t pl = r0 + j * RPS + rsub;
+            const uint32_t want = min(pl, npos - 1u) * nbytes + 4u * d;
+            const uint32_t o = min(want, lim);
+            out[j] = reinterpret_cast<const U32 *>(g + o)->v;  // raw: shifted / masked when it is consumed
+        }
+    };
+    uint32_t v[NJ], vn[NJ];
+    if (nit) issue(0, v);
+    // per-tile state (block-uniform), set when an iteration starts a tile
+    uint32_t tile_start = 0, npos = 0, binlen = 1, bin0 = 0, bin0_start = 0, binv = 0, rel_base = 0;
+    bool big = false, windowed = false;
+    for (uint32_t it = 0; it < nit; ++it) {
+        if (it + 1 < nit) issue(it + 1, vn);
+        const uint32_t tile = t_begin + it / IPT, r0 = (it % IPT) * iter_rows;
+        if (r0 == 0) {
+            const uint32_t c = tile_contig[tile];
+            if (c != cur_c) {
+                if (want_cs && cur_c != ~0u) flush_colsums(cur_c);
+                a = ad[c];
+                cur_c = c;
+            }
+            tile_start = (tile - a.tile0) * PROBE_TILE;
+            npos = min((uint32_t)PROBE_TILE, a.nkmers - tile_start);
+            binlen = a.binlen;
+            bin0 = tile_start / binlen;
+            bin0_start = bin0 * binlen;
+            const uint64_t row0 = a.bin_off + bin0;
+            big = binlen >= (uint32_t)PROBE_TILE;
+            windowed = binlen >= EPI_MINBIN;
+            const uint32_t last_rel = (tile_start + npos - 1 - bin0_start) / binlen;
+            binv = big ? 0u : 0xFFFFFFFFu / binlen + 1u;
+            const bool fits = cur_row0 != ~0ull && (!windowed ? row0 == cur_row0 : (row0 >= cur_row0 && row0 + last_rel < cur_row0 + EPI_MAXB));
+            if (!fits) {
+                if (cur_row0 != ~0ull) {
+                    __syncthreads();
+                    flush_hist(N, hist, bins, cur_row0, tid);
+                    __syncthreads();
+                }
+                cur_row0 = row0;
+            }
+            rel_base = (uint32_t)(row0 - cur_row0);
+        }
+        if (r0 < npos) {  // (block-uniform)
+            uint32_t *hrow = hist + rel_base * (N + 1);
+            const uint32_t lim = max(min(a.nkmers - tile_start, 2u * (uint32_t)PROBE_TILE) * nbytes, 4u) - 4u;  // as in issue()
+#pragma unroll
+            for (uint32_t j = 0; j < NJ; ++j) {
+                const uint32_t pl = r0 + j * RPS + rsub;
+                const bool on = lane_on && pl < npos;
+                const uint32_t want = min(pl, npos - 1u) * nbytes + 4u * d;
+                v[j] = on ? (v[j] >> (8u * (want - min(want, lim)))) & wmask : 0u;
+                const uint32_t tot = row_popc(__popc(v[j]));
+                const uint32_t pos = tile_start + pl;
+                if (windowed) {
+                    if (on && d == 0) {
+                        const uint32_t dpos = pos - bin0_start;
+                        const uint32_t rel = big ? (dpos >= binlen ? 1u : 0u) : __umulhi(dpos, binv);
+                        atomicAdd(&hrow[rel * (N + 1) + min(tot, N)], 1u);
+                    }
+                } else {
+                    hist_position(on && d == 0, pos, tot, N, binlen, bin0, bin0_start, rel_base, hist, bins, a.bin_off, lane);
+                }
+                if (on && pos % 100u == 0) {  // 1-in-100 rows: every lane copies its word
+                    uint8_t *o = out100 + a.out100_off + (uint64_t)(pos / 100u) * nbytes + 4u * d;
+                    if (wbytes == 4) reinterpret_cast<U32 *>(o)->v = v[j];
+                    else
+                        for (uint32_t bb = 0; bb < wbytes; ++bb) o[bb] = (uint8_t)(v[j] >> (8 * bb));
+                }
+            }
+            if (want_cs) {  // rows beyond npos are zero: adding them is harmless
+                vadd4(v[0], v[1], v[2], v[3]);
+                vadd4(v[4], v[5], v[6], v[7]);
+                vrows += 8;
+                if (vrows >= 8) vflush();  // (the 4 planes count to 15)
+            }
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < NJ; ++j) v[j] = vn[j];
+    }
+    if (want_cs && cur_c != ~0u) flush_colsums(cur_c);
     __syncthreads();
     if (cur_row0 != ~0ull) flush_hist(N, hist, bins, cur_row0, tid);
 }
@@ -1115,14 +1299,18 @@ hipError_t launch_rows_epilogue(hipStream_t st, uint32_t ngenomes, const AnchorD
     const uint32_t nbytes = (ngenomes + 7) / 8;
     if (nbytes == 1)
         hipLaunchKernelGGL(k_epilogue<0>, dim3(grid), dim3(EPI_THREADS), lds, st, ngenomes, ad, tile_contig, ntiles, out1,
-                           out100, bins, colsums, flags, 0u);
+                           out100, bins, colsums, flags);
     else if (nbytes <= 8)
         hipLaunchKernelGGL(k_epilogue<1>, dim3(grid), dim3(EPI_THREADS), lds, st, ngenomes, ad, tile_contig, ntiles, out1,
-                           out100, bins, colsums, flags, 0u);
-    else  // one launch per pair of 32-genome words
-        for (uint32_t pair = 0; pair < (nbytes + 7) / 8; ++pair)
-            hipLaunchKernelGGL(k_epilogue<3>, dim3(grid), dim3(EPI_THREADS), lds, st, ngenomes, ad, tile_contig, ntiles, out1,
-                               out100, bins, colsums, flags, pair);
+                           out100, bins, colsums, flags);
+    else {  // word-parallel: one launch, every row read once
+        const uint32_t W = (nbytes + 3) / 4;
+        if (W > 64) return hipErrorInvalidValue;
+        const size_t lds_w = (((EPI_MAXB * (ngenomes + 1) + 3) & ~3u) + 32u * W) * 4 + 16;
+        auto kern = W == 3 ? k_epilogue_words<3> : W == 4 ? k_epilogue_words<4> : k_epilogue_words<0>;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(EPI_THREADS), lds_w, st, ngenomes, ad, tile_contig, ntiles, out1, out100, bins,
+                           colsums, flags);
+    }
     return hipGetLastError();
 }
 

@@ -15,6 +15,7 @@ ap.add_argument("--k", type=int, default=21)
 ap.add_argument("--d", type=float, default=0.01)
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--no-colsums", action="store_true")
+ap.add_argument("--cosched", action="store_true", help="one co-scheduled launch over all genomes (the bench default)")
 ap.add_argument("--minimizer", type=int, default=-1)
 ap.add_argument("--n-blocks", type=int, default=0, help="1 kb blocks of N per contig")
 ap.add_argument("--keys-per-bucket", type=float, default=2.0)
@@ -55,11 +56,25 @@ def timed(fn):
     return (time.perf_counter() - t0) / a.reps
 
 
-full = [engine.AnchorResult(tbl, s, colsums=not a.no_colsums) for s in seqsets]
+if a.cosched:
+    import numpy as np
+    merged = engine.SeqSet.concat(ctx, seqsets)
+    grp = np.repeat(np.arange(a.genomes), a.contigs)
+    seqsets = [merged]
+
+
+def mk(**kw):
+    rs = [engine.AnchorResult(tbl, s, colsums=not a.no_colsums, **kw) for s in seqsets]
+    if a.cosched:
+        rs[0].coschedule(grp, 64)
+    return rs
+
+
+full = mk()
 t_full = timed(lambda: [r.run() for r in full])
 for r in full:
     r.close()
-rows = [engine.AnchorResult(tbl, s, colsums=not a.no_colsums, rows_only=True) for s in seqsets]
+rows = mk(rows_only=True)
 t_probe = timed(lambda: [r.run() for r in rows])
 t_epi = timed(lambda: [r.rows_epilogue() for r in rows])
 print(f"m={tbl.minimizer} positions/step={npos}  full {t_full*1e3:.2f} ms ({npos/t_full/1e9:.1f} G/s)  "

@@ -1,0 +1,83 @@
+// Streaming-read rates of the access geometries the statistics kernels use (gfx950):
+//   hipcc --offload-arch=gfx950 -O3 -o tools/stream_bench tools/stream_bench.hip && tools/stream_bench
+// A: grid-stride, 16 B per lane, fully coalesced (what the memory system can do)
+// B: 128-thread workgroups walk contiguous ranges (RANGE bytes each), lane t reads 4 x 8 B at
+//    32 t + 8 j per 4 KB step (k_epilogue<1> on 8-byte rows)
+// C: same ranges, lane t reads 8 B at 8 t + 1024 j (rows t, t + 128, ...: coalesced per instruction)
+// D: same ranges, 16 B per lane coalesced, 2 KB per step
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+
+__global__ __launch_bounds__(256) void kA(const uint4 *p, uint64_t n, uint32_t *out) {
+    uint32_t acc = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+        const uint4 v = p[i];
+        acc += v.x ^ v.y ^ v.z ^ v.w;
+    }
+    if (acc == 0x12345) out[0] = acc;
+}
+template <int MODE>
+__global__ __launch_bounds__(128) void kR(const uint8_t *p, uint64_t range, uint32_t *out) {
+    const uint8_t *b = p + (uint64_t)blockIdx.x * range;
+    uint32_t acc = 0;
+    const int t = threadIdx.x;
+    for (uint64_t off = 0; off < range; off += 4096) {
+        if (MODE == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint2 v = *reinterpret_cast<const uint2 *>(b + off + 32 * t + 8 * j);
+                acc += __popc(v.x) + __popc(v.y);
+            }
+        } else if (MODE == 1) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint2 v = *reinterpret_cast<const uint2 *>(b + off + 8 * t + 1024 * j);
+                acc += __popc(v.x) + __popc(v.y);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(b + off + 16 * t + 2048 * j);
+                acc += __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
+            }
+        }
+    }
+    if (acc == 0x12345) out[0] = acc;
+}
+
+int main() {
+    const uint64_t bytes = 10ull << 30;
+    uint8_t *d;
+    uint32_t *o;
+    hipMalloc(&d, bytes);
+    hipMalloc(&o, 4);
+    hipMemset(d, 1, bytes);
+    hipEvent_t a, b;
+    hipEventCreate(&a);
+    hipEventCreate(&b);
+    auto report = [&](const char *name, float ms) { printf("%-40s %7.3f ms  %6.2f TB/s\n", name, ms, bytes / (ms * 1e-3) / 1e12); };
+    for (int rep = 0; rep < 2; ++rep) {
+        float ms;
+        hipEventRecord(a);
+        hipLaunchKernelGGL(kA, dim3(256 * 8), dim3(256), 0, 0, reinterpret_cast<const uint4 *>(d), bytes / 16, o);
+        hipEventRecord(b);
+        hipEventSynchronize(b);
+        hipEventElapsedTime(&ms, a, b);
+        report("A grid-stride 16 B/lane", ms);
+        for (uint64_t range : {524288ull, 1048576ull, 65536ull}) {
+            char nm[64];
+            const unsigned grid = (unsigned)(bytes / range);
+#define RUNR(M, LABEL)                                                                        \
+    hipEventRecord(a);                                                                        \
+    hipLaunchKernelGGL(kR<M>, dim3(grid), dim3(128), 0, 0, d, range, o);                      \
+    hipEventRecord(b);                                                                        \
+    hipEventSynchronize(b);                                                                   \
+    hipEventElapsedTime(&ms, a, b);                                                           \
+    snprintf(nm, sizeof nm, "%s range %llu KB", LABEL, (unsigned long long)(range >> 10));    \
+    report(nm, ms);
+            RUNR(0, "B 4x8B at stride 32") RUNR(1, "C 8B coalesced x4") RUNR(2, "D 16B coalesced x2")
+        }
+    }
+    return 0;
+}
