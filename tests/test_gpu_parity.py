@@ -575,3 +575,53 @@ def test_kmer_sketch_registers_equal_oracle(ctx, k):
     assert st["nkeys"] == exact and st["nbuckets"] == before
     sk.close()
     tbl.close()
+
+
+_FUZZ_N = [2, 8, 9, 16, 17, 24, 25, 32, 33, 40, 63, 64, 65, 72, 96, 97, 127, 128, 129, 160, 193, 256, 257, 300]
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("PG_FUZZ_SEEDS", "12"))))  # (more seeds: PG_FUZZ_SEEDS=200)
+def test_random_shapes_against_oracle(ctx, seed):
+    """Randomised sweep over genome counts around every row-width boundary (1..38-byte rows, 1..5
+    sub-tables), k, and contig lengths around the tile / bin / 1-in-100 boundaries, N runs included:
+    rows, bitmap.100, bins and column sums of a multi-contig launch against the oracle."""
+    from panagram_amd import engine
+    rng = np.random.default_rng(7000 + seed)
+    n = int(_FUZZ_N[(2 * seed + int(rng.integers(0, 2))) % len(_FUZZ_N)])
+    k = int(rng.choice([15, 21, 31, 32]))
+    # (contigs of fewer than 100 k-mers divide by zero in the reference, cpp/anchor.cpp:114-118: not pinned)
+    special = [k + 99, k + 100, k + 198, k + 199, k + 298, k + 510, k + 511, k + 512, k + 1023, k + 1500, k + 3700, k + 5199, k + 9999]
+    lens = [int(x) for x in rng.choice(special, size=int(rng.integers(3, 8)))] + [int(rng.integers(k + 99, 30000))]
+    gen = po.synth_genomes(n, lens, float(rng.choice([0.003, 0.02, 0.1])), 100 + seed)
+    genomes = [[bytearray(po.codes_to_ascii(c)) for c in g] for g in gen]
+    for g in range(0, n, max(1, n // 5)):  # N runs, lower case
+        for c in genomes[g]:
+            if len(c) > 200 and rng.random() < 0.5:
+                p = int(rng.integers(0, len(c) - 60))
+                c[p:p + int(rng.integers(1, 60))] = b"N" * 1
+                q = int(rng.integers(0, len(c) - 50))
+                c[q:q + 40] = bytes(c[q:q + 40]).lower()
+    genomes = [[bytes(c) for c in g] for g in genomes]
+    dbs = po.build_bitvec_dbs(genomes, k)
+    tbl = engine.PanTable(ctx, k, n)
+    for g in range(n):
+        ss = engine.SeqSet.from_host(ctx, genomes[g])
+        tbl.insert_seqset(g, ss)
+        ss.close()
+    if seed % 3 == 0:
+        tbl.rehash(3.0)
+    for g in {0, int(rng.integers(0, n)), n - 1}:
+        ss = engine.SeqSet.from_host(ctx, genomes[g])
+        res = engine.AnchorResult(tbl, ss, colsums=True)
+        res.run()
+        ccs = res.contig_colsums().astype(np.int64)
+        for ci, seq in enumerate(genomes[g]):
+            rows, rows100, bins, info = res.download(ci)
+            o_rows, o_rows100, o_bins, _, o_cs = po.anchor_contig(dbs, seq, k, n)
+            assert np.array_equal(rows, o_rows), (n, k, len(seq))
+            assert np.array_equal(rows100, o_rows100), (n, k, len(seq))
+            assert np.array_equal(bins.astype(np.int64), o_bins), (n, k, len(seq))
+            assert np.array_equal(ccs[ci], o_cs), (n, k, len(seq))
+        res.close()
+        ss.close()
+    tbl.close()
