@@ -100,6 +100,8 @@ def main():
     ap.add_argument("--keys-per-bucket", type=float, default=2.0)
     ap.add_argument("--minimizer", type=int, default=-1, help="pin the table's minimizer length (tuning; default: library's choice)")
     ap.add_argument("--no-colsums", action="store_true")
+    ap.add_argument("--no-rehash", action="store_true",
+                    help="keep the table as created from the expected key count (a re-hash holds the table twice in HBM)")
     ap.add_argument("--per-genome-launches", action="store_true",
                     help="one launch per anchor genome instead of one co-scheduled launch over all of them")
     ap.add_argument("--piece-tiles", type=int, default=0, help="co-scheduling granularity in 512-position tiles (0: library default)")
@@ -138,6 +140,9 @@ def main():
             ss.load_dev(c, t.data_ptr(), t.numel())
         seqsets.append(ss)
     torch.cuda.synchronize()
+    if args.no_cpu_baseline and L > 1_000_000_000:  # multi-Gb genomes: the ASCII copies are only needed by the CPU leg
+        genomes = None
+        torch.cuda.empty_cache()
 
     # ---- k-mer set construction on the GPU (replaces kmc + kmc_tools; timed separately) ----
     novel = 1.0 - (1.0 - args.d) ** k
@@ -150,7 +155,8 @@ def main():
         tbl.insert_seqset(g, seqsets[g])
     torch.cuda.synchronize()
     build_s = time.perf_counter() - t0
-    tbl.rehash(args.keys_per_bucket)
+    if not args.no_rehash:
+        tbl.rehash(args.keys_per_bucket)
     torch.cuda.synchronize()
     st = tbl.stats()
 
