@@ -911,7 +911,7 @@ __global__ __launch_bounds__(EPI_THREADS) void k_epilogue(uint32_t N, const Anch
 //   popcount of a row   W - 1 shuffles to its first lane, one LDS atomic into the bin window
 //   bitmap.100          each lane copies its word of the 1-in-100 rows
 //   column sums         carry-save vertical counters per lane (4 rows at a time), byte-sliced
-//                       accumulators, LDS atomics every 252 rows, per contig to global
+//                       accumulators, LDS atomics every 248 rows, per contig to global
 // ---------------------------------------------------------------------------
 template <int W_T>  // words per row known at compile time (1..4), or 0: any
 __global__ __launch_bounds__(EPI_THREADS) void k_epilogue_words(uint32_t N, const AnchorDesc *__restrict__ ad,
