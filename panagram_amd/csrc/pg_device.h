@@ -273,7 +273,7 @@ __device__ __forceinline__ bool lane_lookup(const SubTable &st, uint64_t key, ui
 // Insert-or-find `key`, OR `bits` into mask word w.  Returns 0 = existed,
 // 1 = newly claimed, -1 = gave up after max_probe lines (table must grow).
 // COUNT: mask word w is an occurrence counter (bits is added) instead of a presence mask (OR-ed)
-template <bool COUNT = false>
+template <bool COUNT = false, bool ATOMIC_OR = false>
 __device__ __forceinline__ int lane_insert(const SubTable &st, uint64_t key, int w, uint32_t bits,
                                            uint32_t max_probe) {
     const uint32_t grp = group_of(st, key);
@@ -309,8 +309,17 @@ __device__ __forceinline__ int lane_insert(const SubTable &st, uint64_t key, int
                 uint32_t *mp = reinterpret_cast<uint32_t *>(grp8 + 16 * hit + 8 + 4 * w);
                 if (COUNT) {
                     if (*mp < 0xFFFFFF00u) atomicAdd(mp, bits);  // saturates far above any -ci threshold
-                } else if ((*mp & bits) != bits) {
-                    atomicOr(mp, bits);
+                } else {
+                    // A plain store, not an atomic OR (7 % of the table build): every writer of this word during
+                    // one launch ORs in the SAME bits — one genome per insert launch, one writer per key in
+                    // re-hash / merge / import, launches of one table serialised on its stream — so two racing
+                    // read-modify-writes store the same value and no other bit can be lost.
+                    // (ATOMIC_OR: callers that cannot promise it — key arrays handed in through the ABI.)
+                    const uint32_t cur = *mp;
+                    if ((cur & bits) != bits) {
+                        if (ATOMIC_OR) atomicOr(mp, bits);
+                        else *reinterpret_cast<volatile uint32_t *>(mp) = cur | bits;
+                    }
                 }
                 return claimed;
             }

@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256) void k_insert_keys(SubTable st, int w, const u
     for (; i < n; i += stride) {
         uint32_t v = vals[i];
         if (v == 0) continue;  // a zero counter reads the same as an absent key
-        int r = lane_insert(st, keys[i], w, v, max_probe);
+        int r = lane_insert<false, true>(st, keys[i], w, v, max_probe);
         if (r < 0) atomicOr(reinterpret_cast<unsigned int *>(&counters[1]), 1u);
         else claimed += r;
     }
