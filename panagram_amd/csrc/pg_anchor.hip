@@ -31,6 +31,7 @@
 // Bytes from HBM per position: 0.25 (sequence) + 128 x (lines missed in L2 per
 // position: 0.34 with one launch per genome, 0.095 co-scheduled) + row bytes written + re-read.
 #include "pg_kernels.h"
+#include <type_traits>
 
 #include <algorithm>
 
@@ -510,7 +511,7 @@ __device__ __forceinline__ void flush_hist(uint32_t N, uint32_t *hist, uint32_t 
 // MODE 0: one-byte rows (N <= 8), 1: rows of 2..8 bytes (N <= 64); wider rows go through
 // k_epilogue_words below.  One instantiation per mode so that each carries only its own accumulators
 // in registers.
-template <int MODE>
+template <int MODE, int NBT>  // NBT = bytes per row (1..8): one instantiation, and one register allocation, per width
 __global__ __launch_bounds__(EPI_THREADS) void k_epilogue(uint32_t N, const AnchorDesc *__restrict__ ad,
                                                           const uint32_t *__restrict__ tile_contig, uint32_t ntiles,
                                                           const uint8_t *__restrict__ out1, uint8_t *__restrict__ out100,
@@ -520,7 +521,7 @@ __global__ __launch_bounds__(EPI_THREADS) void k_epilogue(uint32_t N, const Anch
     constexpr int PT = 4;  // rows per thread and tile: EPI_THREADS = PROBE_TILE / 4 threads per workgroup
     constexpr bool WIDE = MODE == 1;
     const int tid = threadIdx.x, lane = tid & 63;
-    const uint32_t nbytes = (N + 7) / 8;
+    constexpr uint32_t nbytes = NBT;
     const uint32_t Nw = N;
     const uint32_t ndbs = (N + 31) / 32;
     uint32_t *hist = reinterpret_cast<uint32_t *>(smem);
@@ -715,6 +716,74 @@ __global__ __launch_bounds__(EPI_THREADS) void k_epilogue(uint32_t N, const Anch
                 continue;
             }
             gq_valid = false;
+        }
+        // ---- group path (2..8-byte rows): 4 full tiles of one contig inside one bin = 16 consecutive
+        // rows per thread (4 x nbytes aligned words).  The per-tile bookkeeping (bin arithmetic, window
+        // check, 1-in-100 search) is paid once per 16 rows instead of once per 4 — it was two thirds of
+        // the instructions of this pass — and the histogram index needs no bin lookup ----
+        if constexpr (MODE == 1) {
+            const uint32_t ts = (tile - a.tile0) * PROBE_TILE;
+            const uint32_t span = 4u * PROBE_TILE;
+            const bool grp_ok = tile + 3 < t_end && tile_contig[tile + 3] == c &&
+                                ts + span <= a.nkmers && a.binlen >= span &&
+                                (ts / a.binlen) == ((ts + span - 1) / a.binlen);
+            if (grp_ok) {
+                const uint64_t row0g = a.bin_off + ts / a.binlen;
+                if (cur_row0 == ~0ull || row0g < cur_row0 || row0g >= cur_row0 + EPI_MAXB) {
+                    if (cur_row0 != ~0ull) {
+                        __syncthreads();
+                        flush_hist(N, hist, bins, cur_row0, tid);
+                        __syncthreads();
+                    }
+                    cur_row0 = row0g;
+                }
+                uint32_t *hrow = hist + (uint32_t)(row0g - cur_row0) * (N + 1);
+                const uint8_t *gt = out1 + a.out_off + ((uint64_t)ts + 16u * tid) * nbytes;
+                auto rows16 = [&](auto nbc) {
+                    constexpr int NB = decltype(nbc)::value;
+                    uint32_t raw[4][8];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) load_row_words<NB>(gt + q * 4 * NB, raw[q]);  // all 16 rows in flight
+                    // (fewer in flight saves registers but measured slower: 2.6 / 2.74 / 2.78 ms at N=64 for 4 / 2 / 1
+                    // groups ahead; requesting the NEXT group's rows as well costs a wave of occupancy: 2.2 vs 1.4 ms at N=27)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        uint32_t w0[4], w1[4];
+                        cut4_rows<NB>(raw[q], w0, w1);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            atomicAdd(&hrow[min((uint32_t)(__popc(w0[j]) + (NB > 4 ? __popc(w1[j]) : 0)), N)], 1u);
+                        if (want_cs) {
+                            vadd4(0, w0[0], w0[1], w0[2], w0[3]);
+                            if (NB > 4) vadd4(1, w1[0], w1[1], w1[2], w1[3]);
+                            vrows += PT;
+                            if (vrows == 12) vflush();
+                        }
+                    }
+                };
+                switch (nbytes) {  // block-uniform
+                    case 2: rows16(std::integral_constant<int, 2>{}); break;
+                    case 3: rows16(std::integral_constant<int, 3>{}); break;
+                    case 4: rows16(std::integral_constant<int, 4>{}); break;
+                    case 5: rows16(std::integral_constant<int, 5>{}); break;
+                    case 6: rows16(std::integral_constant<int, 6>{}); break;
+                    case 7: rows16(std::integral_constant<int, 7>{}); break;
+                    default: rows16(std::integral_constant<int, 8>{}); break;
+                }
+                // 1-in-100 rows: at most one multiple of 100 among 16 consecutive positions; its row is read
+                // again (a cache hit) rather than selected out of 16 register pairs
+                const uint32_t pos0 = ts + 16u * tid;
+                const uint32_t r100 = (pos0 + 99u) / 100u;
+                const uint32_t first = r100 * 100u - pos0;
+                if (first < 16u) {
+                    const uint8_t *pr = gt + first * nbytes;
+                    uint8_t *o100 = out100 + a.out100_off + (uint64_t)r100 * nbytes;
+                    for (uint32_t bb = 0; bb < nbytes; ++bb) o100[bb] = pr[bb];
+                }
+                wp_valid = false;
+                tile += 3;
+                continue;
+            }
         }
         const uint32_t tile_start = (tile - a.tile0) * PROBE_TILE;
         const uint32_t npos = min((uint32_t)PROBE_TILE, a.nkmers - tile_start);
@@ -1297,12 +1366,21 @@ hipError_t launch_rows_epilogue(hipStream_t st, uint32_t ngenomes, const AnchorD
     grid = std::max(grid, std::min(1024u, ntiles / 16u));
     grid = grid < 1 ? 1 : (grid > maxg ? maxg : grid);
     const uint32_t nbytes = (ngenomes + 7) / 8;
-    if (nbytes == 1)
-        hipLaunchKernelGGL(k_epilogue<0>, dim3(grid), dim3(EPI_THREADS), lds, st, ngenomes, ad, tile_contig, ntiles, out1,
-                           out100, bins, colsums, flags);
-    else if (nbytes <= 8)
-        hipLaunchKernelGGL(k_epilogue<1>, dim3(grid), dim3(EPI_THREADS), lds, st, ngenomes, ad, tile_contig, ntiles, out1,
-                           out100, bins, colsums, flags);
+    if (nbytes <= 8) {
+        auto kern = k_epilogue<0, 1>;
+        switch (nbytes) {
+            case 2: kern = k_epilogue<1, 2>; break;
+            case 3: kern = k_epilogue<1, 3>; break;
+            case 4: kern = k_epilogue<1, 4>; break;
+            case 5: kern = k_epilogue<1, 5>; break;
+            case 6: kern = k_epilogue<1, 6>; break;
+            case 7: kern = k_epilogue<1, 7>; break;
+            case 8: kern = k_epilogue<1, 8>; break;
+            default: break;
+        }
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(EPI_THREADS), lds, st, ngenomes, ad, tile_contig, ntiles, out1, out100, bins,
+                           colsums, flags);
+    }
     else {  // word-parallel: one launch, every row read once
         const uint32_t W = (nbytes + 3) / 4;
         if (W > 64) return hipErrorInvalidValue;
