@@ -140,7 +140,7 @@ def main():
             ss.load_dev(c, t.data_ptr(), t.numel())
         seqsets.append(ss)
     torch.cuda.synchronize()
-    if args.no_cpu_baseline and L > 1_000_000_000:  # multi-Gb genomes: the ASCII copies are only needed by the CPU leg
+    if args.no_cpu_baseline and G * L > 4_000_000_000:  # big inputs: the ASCII copies are only needed by the CPU leg
         genomes = None
         torch.cuda.empty_cache()
 
@@ -237,6 +237,11 @@ def main():
     achieved = per_launch_bytes / avg_launch_s
     value = world * pos_per_step * args.steps / elapsed
 
+    shape = (G, round(args.genome_mb), k)
+    baseline_config = {(8, 100, 21): "BASELINE.json configs[1]", (27, 135, 21): "BASELINE.json configs[2] at full size",
+                       (64, 200, 31): "BASELINE.json configs[3] at full size, all 64 genomes anchored",
+                       (8, 3000, 21): "the shape of BASELINE.json configs[4] on ONE GPU, at a divergence whose table fits"
+                       }.get(shape, "not a BASELINE.json config")
     out = {
         "metric": "anchored k-mers/sec building pan-kmer bitmap",
         "value": value,
@@ -253,7 +258,7 @@ def main():
         "config": {
             "workload": f"{G} synthetic {args.genome_mb:g} Mb genomes ({args.contigs} contigs each), k={k}, "
                         f"d={args.d}, all {G} genomes anchored per step, table resident in one GPU's HBM "
-                        f"(BASELINE.json configs[1])",
+                        f"({baseline_config})",
             "positions_per_step_per_gpu": pos_per_step,
             "table_keys": st["nkeys"], "table_bytes": st["bytes"], "keys_per_128B_line": args.keys_per_bucket,
             "table_build_s": build_s, "table_spill_fraction": tbl.spill()[0], "table_slots_per_line": tbl.spill()[1], "probes_per_position": P, "nbytes": nbytes,
