@@ -61,14 +61,14 @@ struct pg_ctx {
     // dependant does.
     std::atomic<int> refs{0};
     bool dead = false;
-    // staging of the GPU BGZF writer (write_bgzf_gpu): two sets, so that two writer threads can run;
+    // staging of the GPU BGZF writer (write_bgzf_gpu): four sets, so that four writer threads can run;
     // allocated at first use, kept — pinning 2 x 64 MiB per file would cost more than the compression
     struct DfSet {
         uint8_t *d_slots[2] = {nullptr, nullptr}, *d_packed[2] = {nullptr, nullptr}, *h_slots[2] = {nullptr, nullptr};
         uint32_t *d_sizes[2] = {nullptr, nullptr}, *d_offs[2] = {nullptr, nullptr}, *h_sizes[2] = {nullptr, nullptr};
         uint32_t *d_crc = nullptr;
         bool ready = false, busy = false;
-    } df[2];
+    } df[4];
     std::mutex df_mu;
 };
 
