@@ -60,6 +60,9 @@ int pg_ctx_create(int device_id, pg_ctx **out);
  * retired at once for the caller but freed only when its last dependant is destroyed.  Destroy
  * each handle exactly once and do not use it afterwards. */
 int pg_ctx_destroy(pg_ctx *ctx);
+/* give back device memory the context keeps for reuse (row buffers of destroyed results: freeing and
+ * re-allocating tens of GB per batch of anchors costs seconds) */
+int pg_ctx_trim(pg_ctx *ctx);
 /* adopt an external hipStream_t (e.g. torch.cuda.current_stream().cuda_stream; NULL is
  * HIP's legacy default stream, which is what torch's default stream is); use_own != 0
  * restores the context's own non-blocking stream instead. */

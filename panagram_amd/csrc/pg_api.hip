@@ -70,6 +70,16 @@ struct pg_ctx {
         bool ready = false, busy = false;
     } df[4];
     std::mutex df_mu;
+    // Row buffers of destroyed results, kept for the next result: hipFree of tens of GB costs about 40 ms per
+    // GB on this stack (paid inside the NEXT hipMalloc: tools/malloc_time.py), which a run that anchors its
+    // genomes in batches would pay for every batch.  At most two buffers; emptied by pg_ctx_trim, when an
+    // allocation fails, and with the context.
+    struct RowBuf {
+        uint8_t *p;
+        uint64_t cap;
+    };
+    std::vector<RowBuf> row_cache;
+    std::mutex row_mu;
 };
 
 struct SubHost {
@@ -118,6 +128,7 @@ struct pg_result {
     uint32_t ntiles;
     uint8_t *d_out1;
     uint64_t out1_bytes;
+    uint64_t out1_cap = 0;  // bytes actually allocated behind d_out1 (it may come out of the context's cache)
     uint8_t *d_out100;
     uint64_t out100_bytes;
     uint32_t *d_bins;
@@ -171,6 +182,8 @@ static void ctx_free(pg_ctx *c) {
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     hipStreamSynchronize(c->aux_stream);
+    for (auto &b : c->row_cache) hipFree(b.p);
+    c->row_cache.clear();
     for (auto &d : c->df) {
         for (int i = 0; i < 2; ++i) {
             hipFree(d.d_slots[i]);
@@ -188,6 +201,52 @@ static void ctx_free(pg_ctx *c) {
 }
 static void ctx_release(pg_ctx *c) {
     if (--c->refs == 0 && c->dead) ctx_free(c);
+}
+
+static constexpr uint64_t ROW_CACHE_MIN = 1ull << 30;  // smaller buffers are not worth keeping
+static void row_cache_trim(pg_ctx *c) {
+    std::lock_guard<std::mutex> lk(c->row_mu);
+    for (auto &b : c->row_cache) hipFree(b.p);
+    c->row_cache.clear();
+}
+// a buffer of at least `bytes` (never more than twice that) out of the cache, or a fresh one
+static hipError_t row_alloc(pg_ctx *c, uint64_t bytes, uint8_t **out, uint64_t *cap) {
+    {
+        std::lock_guard<std::mutex> lk(c->row_mu);
+        for (size_t i = 0; i < c->row_cache.size(); ++i)
+            if (c->row_cache[i].cap >= bytes && c->row_cache[i].cap <= 2 * bytes) {
+                *out = c->row_cache[i].p;
+                *cap = c->row_cache[i].cap;
+                c->row_cache.erase(c->row_cache.begin() + (long)i);
+                return hipSuccess;
+            }
+    }
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(out), bytes);
+    if (e != hipSuccess) {  // make room: give the cached buffers back and try once more
+        (void)hipGetLastError();
+        row_cache_trim(c);
+        e = hipMalloc(reinterpret_cast<void **>(out), bytes);
+    }
+    *cap = bytes;
+    return e;
+}
+static void row_free(pg_ctx *c, uint8_t *p, uint64_t cap) {
+    if (!p) return;
+    if (cap >= ROW_CACHE_MIN && !c->dead) {
+        std::lock_guard<std::mutex> lk(c->row_mu);
+        if (c->row_cache.size() < 2) {
+            c->row_cache.push_back({p, cap});
+            return;
+        }
+    }
+    hipFree(p);
+}
+
+extern "C" int pg_ctx_trim(pg_ctx *c) {
+    if (!c) return fail(PG_E_INVALID, "ctx is NULL");
+    if (int r = use_device(c)) return r;
+    row_cache_trim(c);
+    return PG_OK;
 }
 
 extern "C" int pg_ctx_destroy(pg_ctx *c) {
@@ -244,6 +303,11 @@ static int alloc_sub(pg_ctx *ctx, uint32_t W, uint32_t word0, uint32_t k, uint32
     t.nbuckets = nbuckets;
     void *p = nullptr;
     hipError_t e = hipMalloc(&p, nbuckets * 16ull * slots);
+    if (e != hipSuccess) {  // the context may be sitting on cached row buffers: give them back and try once more
+        (void)hipGetLastError();
+        row_cache_trim(ctx);
+        e = hipMalloc(&p, nbuckets * 16ull * slots);
+    }
     if (e != hipSuccess)
         return fail(PG_E_HIP, "hipMalloc(%llu bytes) for k-mer table failed: %s",
                     (unsigned long long)(nbuckets * 16ull * slots), hipGetErrorString(e));
@@ -1152,7 +1216,7 @@ extern "C" int pg_result_create(pg_table *t, const pg_seqset *sq, uint32_t flags
     hipError_t e;
     if ((e = hipMalloc(reinterpret_cast<void **>(&r->d_ad), std::max<size_t>(1, r->ad.size()) * sizeof(AnchorDesc))) == hipSuccess &&
         (e = hipMalloc(reinterpret_cast<void **>(&r->d_tile_contig), std::max<size_t>(1, tile_contig.size()) * 4)) == hipSuccess &&
-        (e = hipMalloc(reinterpret_cast<void **>(&r->d_out1), std::max<uint64_t>(16, o1))) == hipSuccess &&
+        (e = row_alloc(t->ctx, std::max<uint64_t>(16, o1), &r->d_out1, &r->out1_cap)) == hipSuccess &&
         (e = hipMalloc(reinterpret_cast<void **>(&r->d_out100), std::max<uint64_t>(16, o100))) == hipSuccess &&
         (e = hipMalloc(reinterpret_cast<void **>(&r->d_bins), std::max<uint64_t>(1, bins) * (N + 1) * 4)) == hipSuccess &&
         (e = hipMalloc(reinterpret_cast<void **>(&r->d_colsums), std::max<size_t>(1, r->ad.size()) * N * 8)) == hipSuccess) {
@@ -1177,7 +1241,7 @@ extern "C" int pg_result_destroy(pg_result *r) {
     hipStreamSynchronize(r->tbl->ctx->aux_stream);
     hipFree(r->d_ad);
     hipFree(r->d_tile_contig);
-    hipFree(r->d_out1);
+    row_free(r->tbl->ctx, r->d_out1, r->out1_cap);
     hipFree(r->d_out100);
     hipFree(r->d_bins);
     hipFree(r->d_colsums);

@@ -83,6 +83,10 @@ class Context(_Owner):
     def synchronize(self) -> None:
         check(self._lib.pg_ctx_synchronize(self._h))
 
+    def trim(self) -> None:
+        """give back device memory kept for reuse (row buffers of closed results)"""
+        check(self._lib.pg_ctx_trim(self._h))
+
     def close(self) -> None:
         if self._h:
             self._close_children()

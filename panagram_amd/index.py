@@ -79,6 +79,15 @@ def read_fasta(path: str) -> Iterator[Tuple[str, bytes]]:
 FASTQ_SUFFIXES = (".fastq", ".fastq.gz", ".fq", ".fq.gz")  # workflow/Snakefile:88-89
 
 
+def _read_fasta_image(path: str) -> np.ndarray:
+    """the bytes of a FASTA file (``.gz`` / ``.bgz`` inflated) for ``SeqSet.from_fasta``"""
+    if path.endswith((".gz", ".bgz")):
+        import gzip
+        with gzip.open(path, "rb") as f:
+            return np.frombuffer(f.read(), dtype=np.uint8)
+    return np.fromfile(path, dtype=np.uint8)
+
+
 def is_fastq(path) -> bool:
     return isinstance(path, str) and path.endswith(FASTQ_SUFFIXES)
 
@@ -378,9 +387,20 @@ class Index:
             # copy of the table in HBM.  Anchors keep their sequences for the anchor step.
             inputs = []
             sketch = engine.KmerSketch(self.context, self.k)
+            # the FASTA files are read a few ahead by host threads while the GPU parses and sketches
+            from concurrent.futures import ThreadPoolExecutor
+            todo = [n for n, g in self.genomes.items() if not pd.isna(g.fasta) and not is_fastq(g.fasta) and n not in self._seqsets]
+            reader = ThreadPoolExecutor(max_workers=3)
+            ahead = {n: reader.submit(_read_fasta_image, self.genomes[n].fasta) for n in todo[:4]}
+            nxt = 4
             for name, g in self.genomes.items():
                 if pd.isna(g.fasta):
                     continue
+                if name in ahead:
+                    self._seqsets[name] = engine.SeqSet.from_fasta(self.context, ahead.pop(name).result())
+                    if nxt < len(todo):
+                        ahead[todo[nxt]] = reader.submit(_read_fasta_image, self.genomes[todo[nxt]].fasta)
+                        nxt += 1
                 if is_fastq(g.fasta):
                     # read sets: kmc -ci2 -fq (workflow/Snakefile:88-89) — k-mers seen once are dropped
                     # (the sketch counts them too: the table is sized from above)
@@ -391,6 +411,7 @@ class Index:
                 else:
                     inputs.append((name, g, self.seqset_for(name), 1))
                 sketch.add(inputs[-1][2])
+            reader.shutdown()
             expected = sketch.estimate()
             sketch.close()
             tbl = engine.PanTable(self.context, self.k, self.ngenomes, expected_keys=expected + expected // 32 + 1024)
@@ -515,8 +536,8 @@ class Index:
             job["res"].close()
             if job["merged"] is not None:
                 job["merged"].close()
-            for name in batch:
-                self.drop_seqset(name)
+            # (the batch's packed sequences — 0.375 byte per base — stay until close(): every hipFree waits
+            # for the device, i.e. for the writers' kernels of the other batch, 10-20 ms apiece)
 
     # ---- bitmap -> bins (index.py:438-465): what the viewer does with a queried bitmap ----
     @property
