@@ -195,6 +195,8 @@ __global__ __launch_bounds__(DF_THREADS) void k_row_deflate(const uint8_t *__res
     __shared__ uint16_t s_clc[19];
     __shared__ uint8_t h_dep[576], cl_sym[320], cl_extra[320];
 
+    struct __attribute__((packed)) U32 { uint32_t v; };
+    struct __attribute__((packed)) U64 { uint64_t v; };
     const int tid = threadIdx.x;
     const uint64_t blk = first_block + blockIdx.x;
     const uint64_t L0 = blk * DF_BLOCK;
@@ -216,7 +218,6 @@ __global__ __launch_bounds__(DF_THREADS) void k_row_deflate(const uint8_t *__res
         if ((uint32_t)tid < head) data[tid] = sp[tid];
         const uint32_t nw = (n - head) >> 2;
         // (data + head is generally not 4-aligned in LDS: packed stores)
-        struct __attribute__((packed)) U32 { uint32_t v; };
         const uint32_t *sw = reinterpret_cast<const uint32_t *>(sp + head);
         for (uint32_t i = tid; i < nw; i += DF_THREADS) reinterpret_cast<U32 *>(data + head + 4 * i)->v = sw[i];
         for (uint32_t i = head + 4 * nw + tid; i < n; i += DF_THREADS) data[i] = sp[i];
@@ -265,7 +266,19 @@ __global__ __launch_bounds__(DF_THREADS) void k_row_deflate(const uint8_t *__res
             }
             const uint32_t s = (i == c0) ? (uint32_t)(prevNE + 1) : i;
             uint32_t e = i + 1;
-            while (e < c1 && is_eq(e)) ++e;
+            // the run's end, eight bytes at a time (unaligned LDS words; e > i >= row here)
+            bool open_end = true;
+            while (e + 8 <= c1) {
+                const uint64_t x = reinterpret_cast<const U64 *>(data + e)->v ^ reinterpret_cast<const U64 *>(data + e - row)->v;
+                if (x) {
+                    e += (uint32_t)(__ffsll((long long)x) - 1) >> 3;
+                    open_end = false;
+                    break;
+                }
+                e += 8;
+            }
+            if (open_end)
+                while (e < c1 && is_eq(e)) ++e;
             const uint32_t hi = e;                     // end of the run inside this chunk
             if (e == c1) e = (uint32_t)nextNE;         // ... and its true end
             const uint32_t R = e - s, q258 = (R / 258u) * 258u, r = R - q258;
