@@ -370,9 +370,14 @@ def test_messy_pangenome_through_index_run(tmp_path):
     rows = ["name\tfasta"]
     fastas = {}
     for g in range(n):
-        fa = tmp_path / f"g{g}.fa"
         fastas[g] = po.fasta_text([names[i] for i in order[g]], [genomes[g][i] for i in order[g]], width=61 + g)
-        fa.write_bytes(fastas[g])
+        if g % 2:  # every other input gzip-compressed (read ahead by the host threads like the plain ones)
+            fa = tmp_path / f"g{g}.fa.gz"
+            with gzip.open(fa, "wb") as f:
+                f.write(fastas[g])
+        else:
+            fa = tmp_path / f"g{g}.fa"
+            fa.write_bytes(fastas[g])
         rows.append(f"g{g}\t{fa}")
     (tmp_path / "samples.tsv").write_text("\n".join(rows) + "\n")
     idx = pidx.Index(str(tmp_path / "samples.tsv"), prefix=str(tmp_path / "idx"), k=k)
