@@ -456,3 +456,33 @@ def test_index_run_on_several_ranks_writes_the_same_tree(name, world, tmp_path):
             a = os.path.join(dirpath, f)
             b = os.path.join(many, os.path.relpath(a, one))
             assert open(a, "rb").read() == open(b, "rb").read(), f
+
+
+@pytest.mark.parametrize("n", [3, 12, 20, 27, 33, 50, 64, 96, 130, 300])
+def test_gpu_bgzf_every_row_width(ctx, n, tmp_path):
+    """k_row_deflate on rows of 1..38 bytes (matches at distance = row width, unaligned for odd widths):
+    the decompressed files equal the rows, for bitmap.1 and bitmap.100, and compress"""
+    import gzip
+    from panagram_amd import engine
+    k = 21
+    gen = po.synth_genomes(n, [40000, 9000], 0.01, 500 + n)
+    genomes = [[po.codes_to_ascii(c) for c in g] for g in gen]
+    tbl = engine.PanTable(ctx, k, n)
+    for g in range(n):
+        ss = engine.SeqSet.from_host(ctx, genomes[g])
+        tbl.insert_seqset(g, ss)
+        ss.close()
+    ss = engine.SeqSet.from_host(ctx, genomes[n // 2])
+    res = engine.AnchorResult(tbl, ss)
+    res.run()
+    parts = [res.download(ci) for ci in range(2)]
+    for step, col in ((1, 0), (100, 1)):
+        gz, gzi = str(tmp_path / f"b{step}.gz"), str(tmp_path / f"b{step}.gzi")
+        res.write_bgzf(step, gz, gzi, level=-2)
+        payload = b"".join(p[col].tobytes() for p in parts)
+        assert gzip.open(gz, "rb").read() == payload
+        if step == 1:
+            assert os.path.getsize(gz) < 0.6 * len(payload)
+    res.close()
+    ss.close()
+    tbl.close()
