@@ -24,7 +24,10 @@
 //                    drain_queue works off in dense 64-entry batches, level by level
 //   k_epilogue   streaming statistics from the finished bitmap.1 rows: bitmap.100 (1-in-100
 //                rows), per-bin popcount histogram, per-contig column sums — persistent
-//                workgroups, register accumulators, one instantiation per row width.
+//                workgroups, register accumulators, one instantiation per row width (1..8 bytes;
+//                16 consecutive rows per thread over 4 full tiles of one bin).
+//   k_epilogue_words   the same for rows wider than 8 bytes (more than 64 genomes): a lane owns one
+//                32-bit word of the rows it visits, one launch reads every row once.
 //   k_window_stats, k_cols_extract / k_cols_merge: side paths (gene / bin windows; the
 //                genome-sharded exchange).
 //
