@@ -107,7 +107,7 @@ def main():
     ap.add_argument("--piece-tiles", type=int, default=0, help="co-scheduling granularity in 512-position tiles (0: library default)")
     ap.add_argument("--no-compare", action="store_true", help="skip the untimed one-launch-per-genome comparison run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-mb", type=float, default=10.0)
+    ap.add_argument("--cpu-sample-mb", type=float, default=20.0, help="bases per thread of the CPU baseline leg (about 12 s of CPU work)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
