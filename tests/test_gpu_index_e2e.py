@@ -486,3 +486,32 @@ def test_gpu_bgzf_every_row_width(ctx, n, tmp_path):
     res.close()
     ss.close()
     tbl.close()
+
+
+def test_degenerate_inputs_produce_valid_empty_outputs(tmp_path):
+    """An empty FASTA, a header without sequence, sequence without a header, contigs shorter than k and an
+    all-N contig as anchors: no crash, valid (possibly empty) files."""
+    from panagram_amd import index as pidx
+    rng = np.random.default_rng(77)
+    good = b">c1\n" + po.codes_to_ascii(rng.integers(0, 4, 3000, dtype=np.uint8)) + b"\n"
+    files = {"a": good, "empty": b"", "hdr": b">x\n", "nohdr": b"ACGTACGTACGTACGTACGTACGTACGTACGT\n",
+             "short": b">x\nACGT\n>y\nACGTACGT\n", "alln": b">n\n" + b"N" * 500 + b"\n"}
+    rows = ["name\tfasta"]
+    for nm, txt in files.items():
+        (tmp_path / f"{nm}.fa").write_bytes(txt)
+        rows.append(f"{nm}\t{tmp_path / (nm + '.fa')}")
+    (tmp_path / "s.tsv").write_text("\n".join(rows) + "\n")
+    pidx.Index(str(tmp_path / "s.tsv"), prefix=str(tmp_path / "o"), k=21).run()
+    nb = 1
+    want = {"a": 3000 - 20, "empty": 0, "hdr": 0, "nohdr": 0, "short": 0, "alln": 480}
+    for nm, nk in want.items():
+        adir = tmp_path / "o" / "anchor" / nm
+        payload = gzip.open(adir / "bitmap.1.gz", "rb").read()
+        assert len(payload) == nk * nb, nm
+        assert len(gzip.open(adir / "bitmap.100.gz", "rb").read()) == ((nk + 99) // 100) * nb, nm
+        chrs = pd.read_table(adir / "chrs.tsv")
+        assert int(chrs["size"].clip(lower=0).sum()) == nk, nm
+        if nm == "alln":
+            assert not any(payload)
+    tp = pd.read_csv(tmp_path / "o" / "anchor" / "a" / "total_paircounts.csv", index_col="name")
+    assert int(tp.loc["a", "count"]) == 2980 and int(tp.loc["alln", "count"]) == 0
