@@ -63,6 +63,8 @@ int pg_ctx_destroy(pg_ctx *ctx);
 /* give back device memory the context keeps for reuse (row buffers of destroyed results: freeing and
  * re-allocating tens of GB per batch of anchors costs seconds) */
 int pg_ctx_trim(pg_ctx *ctx);
+/* device memory free for new tables / results (cached row buffers counted as free), and the device's total */
+int pg_ctx_mem_info(pg_ctx *ctx, uint64_t *free_bytes, uint64_t *total_bytes);
 /* adopt an external hipStream_t (e.g. torch.cuda.current_stream().cuda_stream; NULL is
  * HIP's legacy default stream, which is what torch's default stream is); use_own != 0
  * restores the context's own non-blocking stream instead. */

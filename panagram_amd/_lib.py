@@ -32,6 +32,7 @@ PROTOTYPES = {
     "pg_ctx_create": (C.c_int, [C.c_int, _vpp]),
     "pg_ctx_destroy": (C.c_int, [_vp]),
     "pg_ctx_trim": (C.c_int, [_vp]),
+    "pg_ctx_mem_info": (C.c_int, [_vp, _u64p, _u64p]),
     "pg_ctx_set_stream": (C.c_int, [_vp, _vp, C.c_int]),
     "pg_ctx_synchronize": (C.c_int, [_vp]),
     "pg_table_create": (C.c_int, [_vp, C.c_int, C.c_int, C.c_uint64, _vpp]),

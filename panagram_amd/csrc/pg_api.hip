@@ -242,6 +242,20 @@ static void row_free(pg_ctx *c, uint8_t *p, uint64_t cap) {
     hipFree(p);
 }
 
+extern "C" int pg_ctx_mem_info(pg_ctx *c, uint64_t *free_bytes, uint64_t *total_bytes) {
+    if (!c) return fail(PG_E_INVALID, "ctx is NULL");
+    if (int r = use_device(c)) return r;
+    size_t f = 0, t = 0;
+    HIP_TRY(hipMemGetInfo(&f, &t));
+    {
+        std::lock_guard<std::mutex> lk(c->row_mu);  // cached row buffers are as good as free
+        for (auto &b : c->row_cache) f += b.cap;
+    }
+    if (free_bytes) *free_bytes = f;
+    if (total_bytes) *total_bytes = t;
+    return PG_OK;
+}
+
 extern "C" int pg_ctx_trim(pg_ctx *c) {
     if (!c) return fail(PG_E_INVALID, "ctx is NULL");
     if (int r = use_device(c)) return r;

@@ -83,6 +83,12 @@ class Context(_Owner):
     def synchronize(self) -> None:
         check(self._lib.pg_ctx_synchronize(self._h))
 
+    def mem_info(self) -> Tuple[int, int]:
+        """(free, total) device memory in bytes"""
+        f, t = C.c_uint64(), C.c_uint64()
+        check(self._lib.pg_ctx_mem_info(self._h, C.byref(f), C.byref(t)))
+        return int(f.value), int(t.value)
+
     def trim(self) -> None:
         """give back device memory kept for reuse (row buffers of closed results)"""
         check(self._lib.pg_ctx_trim(self._h))

@@ -460,10 +460,14 @@ class Index:
             return
         tbl = self.build_table(keep=mine)
         nb = (self.ngenomes + 7) // 8
+        # two batches of rows are resident at a time (one being written, one being anchored), next to the
+        # table: with a table that fills most of the HBM the batches shrink to what is left
+        free = self.context.mem_info()[0]
+        batch_bytes = int(min(self.batch_bytes, max(1 << 30, (free - (6 << 30)) / 2.3)))
         batches, cur, cur_bytes = [], [], 0
         for name in mine:  # a batch's rows stay in HBM until written: bound them
             rows_bytes = int(self.seqset_for(name).lens.sum()) * nb
-            if cur and cur_bytes + rows_bytes > self.batch_bytes:
+            if cur and cur_bytes + rows_bytes > batch_bytes:
                 batches.append(cur)
                 cur, cur_bytes = [], 0
             cur.append(name)
