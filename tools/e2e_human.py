@@ -43,6 +43,16 @@ with tempfile.TemporaryDirectory() as d:
     idx = pidx.Index(os.path.join(d, "samples.tsv"), prefix=os.path.join(d, "idx"), k=a.k, cores=32)
     idx.run()
     dt = time.perf_counter() - t0
+    # sanity at full size: every anchor holds all of its own k-mers; the .gzi geometry matches the payload length
+    import numpy as np, pandas as pd
+    per = sum(x - a.k + 1 for x in lens)
+    for g in (0, G - 1):
+        adir = os.path.join(d, "idx", "anchor", f"g{g}")
+        tp = pd.read_csv(os.path.join(adir, "total_paircounts.csv"), index_col="name")
+        assert int(tp.loc[f"g{g}", "count"]) == per, (g, int(tp.loc[f"g{g}", "count"]), per)
+        assert (tp["count"] <= per).all() and (tp["count"] > 0).all()
+        gzi = np.fromfile(os.path.join(adir, "bitmap.1.gzi"), "<u8")
+        assert int(gzi[0]) == (per * ((G + 7) // 8) + 65279) // 65280 - 1
     out = sum(os.path.getsize(os.path.join(r, f)) for r, _, fs in os.walk(os.path.join(d, "idx")) for f in fs)
     print(f"Index.run(): {G} x {a.mb:g} Mb FASTA files -> table -> {G} anchors -> BGZF/.gzi/TSV files: {dt:.1f} s = "
           f"{npos / dt / 1e6:.0f} M k-mers/s end to end; {npos} positions, {out / 1e9:.1f} GB written")
