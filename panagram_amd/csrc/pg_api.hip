@@ -1047,7 +1047,9 @@ extern "C" int pg_seqset_from_fasta(pg_ctx *ctx, const void *text_, uint64_t nby
         if (e == hipSuccess) e = x;
         return e == hipSuccess;
     };
-    if (ok(hipMalloc(reinterpret_cast<void **>(&d_text), tcap)) &&
+    uint64_t text_cap = 0;  // (the text buffer comes out of the context's buffer cache: one per genome of a pangenome,
+                            // all about the same size, and freeing GBs is paid by the next big allocation)
+    if (ok(row_alloc(ctx, tcap, &d_text, &text_cap)) &&
         ok(hipMalloc(reinterpret_cast<void **>(&d_chunks), std::max<uint64_t>(nch, 1) * sizeof(TextChunk))) &&
         ok(hipMalloc(reinterpret_cast<void **>(&d_chunk0), (nrec + 1) * 8)) &&
         ok(hipMalloc(reinterpret_cast<void **>(&d_base), std::max<uint64_t>(nch, 1) * 8)) &&
@@ -1068,7 +1070,7 @@ extern "C" int pg_seqset_from_fasta(pg_ctx *ctx, const void *text_, uint64_t nby
             ok(hipStreamSynchronize(st));
         }
     }
-    hipFree(d_text);
+    row_free(ctx, d_text, text_cap);
     hipFree(d_chunks);
     hipFree(d_chunk0);
     hipFree(d_base);

@@ -390,9 +390,10 @@ class Index:
             # the FASTA files are read a few ahead by host threads while the GPU parses and sketches
             from concurrent.futures import ThreadPoolExecutor
             todo = [n for n, g in self.genomes.items() if not pd.isna(g.fasta) and not is_fastq(g.fasta) and n not in self._seqsets]
-            reader = ThreadPoolExecutor(max_workers=3)
-            ahead = {n: reader.submit(_read_fasta_image, self.genomes[n].fasta) for n in todo[:4]}
-            nxt = 4
+            nread = max(2, min(6, engine.usable_cpus() // 2))
+            reader = ThreadPoolExecutor(max_workers=nread)
+            ahead = {n: reader.submit(_read_fasta_image, self.genomes[n].fasta) for n in todo[:nread + 2]}
+            nxt = nread + 2
             for name, g in self.genomes.items():
                 if pd.isna(g.fasta):
                     continue
@@ -414,6 +415,7 @@ class Index:
             reader.shutdown()
             expected = sketch.estimate()
             sketch.close()
+            self.context.trim()  # (the FASTA text buffer the parser kept for the next file)
             tbl = engine.PanTable(self.context, self.k, self.ngenomes, expected_keys=expected + expected // 32 + 1024)
             for name, g, ss, min_count in inputs:
                 tbl.insert_seqset(g.id, ss, min_count=min_count)
