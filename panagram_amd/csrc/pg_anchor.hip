@@ -985,7 +985,7 @@ __global__ __launch_bounds__(EPI_THREADS) void k_epilogue(uint32_t N, const Anch
 //   column sums         carry-save vertical counters per lane (4 rows at a time), byte-sliced
 //                       accumulators, LDS atomics every 248 rows, per contig to global
 // ---------------------------------------------------------------------------
-template <int W_T>  // words per row known at compile time (1..4), or 0: any
+template <int W_T>  // words per row known at compile time (3..8), or 0: any
 __global__ __launch_bounds__(EPI_THREADS) void k_epilogue_words(uint32_t N, const AnchorDesc *__restrict__ ad,
                                                                 const uint32_t *__restrict__ tile_contig, uint32_t ntiles,
                                                                 const uint8_t *__restrict__ out1, uint8_t *__restrict__ out100,
@@ -1388,7 +1388,16 @@ hipError_t launch_rows_epilogue(hipStream_t st, uint32_t ngenomes, const AnchorD
         const uint32_t W = (nbytes + 3) / 4;
         if (W > 64) return hipErrorInvalidValue;
         const size_t lds_w = (((EPI_MAXB * (ngenomes + 1) + 3) & ~3u) + 32u * W) * 4 + 16;
-        auto kern = W == 3 ? k_epilogue_words<3> : W == 4 ? k_epilogue_words<4> : k_epilogue_words<0>;
+        auto kern = k_epilogue_words<0>;  // (compile-time W: the lanes-per-row shuffles and index arithmetic unroll; 2x at W=5)
+        switch (W) {
+            case 3: kern = k_epilogue_words<3>; break;
+            case 4: kern = k_epilogue_words<4>; break;
+            case 5: kern = k_epilogue_words<5>; break;
+            case 6: kern = k_epilogue_words<6>; break;
+            case 7: kern = k_epilogue_words<7>; break;
+            case 8: kern = k_epilogue_words<8>; break;
+            default: break;
+        }
         hipLaunchKernelGGL(kern, dim3(grid), dim3(EPI_THREADS), lds_w, st, ngenomes, ad, tile_contig, ntiles, out1, out100, bins,
                            colsums, flags);
     }
