@@ -123,6 +123,8 @@ __device__ __forceinline__ void store_row(uint8_t *row, uint32_t m0, uint32_t m1
         row[0] = (uint8_t)m0;
     } else if (ROWMODE == 2) {
         *reinterpret_cast<uint2 *>(row) = make_uint2(m0, m1);
+    } else if (rc.words == 4) {  // both words of the sub-table at an 8-byte aligned column: one store
+        *reinterpret_cast<uint2 *>(row + rc.col0) = make_uint2(m0, m1);
     } else if (rc.words == 1) {  // wave-uniform
         *reinterpret_cast<uint32_t *>(row + rc.col0) = m0;
         if (rc.nb1) *reinterpret_cast<uint32_t *>(row + rc.col0 + 4) = m1;
@@ -1337,6 +1339,7 @@ hipError_t launch_anchor(hipStream_t s, const TableDesc &T, const uint64_t *seqw
         rc.nb1 = (st.W == 2 && nbytes > rc.col0 + 4) ? min(4u, nbytes - rc.col0 - 4) : 0;
         rc.words = (nbytes % 4 == 0 && rc.nb0 == 4 && (rc.nb1 == 0 || rc.nb1 == 4)) ? 1u : (nbytes == 2 ? 2u : 0u);
         if (T.nsub == 1 && (nbytes == 3 || (nbytes >= 5 && nbytes <= 7))) rc.words = 3u;
+        if (rc.words == 1 && rc.nb1 == 4 && rc.col0 % 8 == 0 && nbytes % 8 == 0) rc.words = 4u;  // (one 8-byte store per row: -9 % probe time at N=128)
         const int rm = (T.nsub == 1) ? row_mode(nbytes, rc) : 0;
         const uint32_t w = st.m ? st.k - st.m + 1 : 0;
         switch (w) {  // the kernel's compile-time window must be the one the table was built with
