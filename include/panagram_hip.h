@@ -48,8 +48,11 @@ typedef struct pg_bgzf pg_bgzf;
 
 /* thread-local message of the last failing call on this thread */
 const char *pg_last_error(void);
-/* library version string, e.g. "panagram_hip 0.1 gfx950" */
+/* library version string, e.g. "panagram_hip 0.2 gfx950" */
 const char *pg_version(void);
+/* k-mer positions per tile: the unit of a launch, of pg_result_coschedule's pieces and of the bit-column blocks
+ * (64 bytes per tile and genome) */
+uint32_t pg_tile_positions(void);
 
 /* ---- context ---------------------------------------------------------- */
 /* One context per GPU / per process rank.  Fails with PG_E_HIP when no
@@ -74,10 +77,15 @@ int pg_ctx_synchronize(pg_ctx *ctx);
 /* ---- pan-kmer table: replaces the merged KMC "bitvec" databases --------
  * Reference: KMCdb::KMCdb opens root/kmc/bitvec{i} with CKMCFile::OpenForRA
  * (cpp/anchor.cpp:21-35); Genome._load_kmc (index.py:847-863).
- * One GPU-resident open-addressed table per pair of 32-genome groups: 64-byte
- * buckets, key = canonical k-mer (2k-bit integer, first base most significant),
- * value = the group's u32 one-hot-OR mask(s).  k in 1..32. */
+ * One GPU-resident open-addressed table per pair of 32-genome groups: 128-byte lines of
+ * 8 slots {u64 key, u32 mask, u32 mask}, home line = hash of the k-mer's minimizer;
+ * key = canonical k-mer (2k-bit integer, first base most significant), value = the group's u32
+ * one-hot-OR mask(s).  k in 1..32.  One writer at a time: the calls that add keys (insert_*, load_kmc1,
+ * rehash) serialise on a per-table lock; lookups (pg_anchor_run ...) must not overlap them. */
 int pg_table_create(pg_ctx *ctx, int k, int ngenomes, uint64_t expected_keys, pg_table **out);
+/* device bytes pg_table_create would allocate for that many keys (host only): lets the caller decide between one
+ * replicated table and the genome-sharded mode before allocating anything */
+int pg_table_bytes_for(int k, int ngenomes, uint64_t expected_keys, uint64_t *bytes);
 int pg_table_destroy(pg_table *tbl);
 
 /* k-mer set construction from sequence, replacing `kmc -ci1 -fm` +
@@ -117,6 +125,11 @@ int pg_sketch_create(pg_ctx *ctx, int k, pg_sketch **out);
 int pg_sketch_add_seqset(pg_sketch *sk, const pg_seqset *seqs);
 int pg_sketch_estimate(pg_sketch *sk, uint64_t *distinct);
 int pg_sketch_registers(pg_sketch *sk, uint8_t *out65536);
+/* sketches merge by register-wise maximum: the estimate for 65536 register values held by the caller (host only,
+ * no device needed) — the distinct k-mers of any union of inputs whose registers were kept; and a sketch emptied
+ * for the next input */
+int pg_sketch_estimate_registers(const uint8_t *regs65536, uint64_t *distinct);
+int pg_sketch_reset(pg_sketch *sk);
 int pg_sketch_destroy(pg_sketch *sk);
 
 /* re-hash into the smallest table whose mean occupancy is <= keys_per_bucket keys per 128 bytes;
@@ -180,13 +193,32 @@ int pg_seqset_unpack(const pg_seqset *s, uint32_t idx, char *out);
                                 * GPU's genomes' bits); after the rows of all GPUs have been combined in
                                 * place (RCCL) pg_rows_epilogue derives the rest */
 int pg_result_create(pg_table *tbl, const pg_seqset *seqs, uint32_t flags, pg_result **out);
+/* the same with the Python path's parameters (index.py:101-106, 1169-1172; cpp/anchor.cpp:114-118,169-176
+ * hard-codes 100 / 200000 / 100): the low-resolution bitmap keeps every lowres_step-th row (bitmap.<lowres_step>;
+ * "bitmap100" / step 100 in the calls below then mean that bitmap), bins are max_bin_len positions long unless the
+ * contig would get fewer than min_bin_count of them (then nkmers / min_bin_count) */
+int pg_result_create_ex(pg_table *tbl, const pg_seqset *seqs, uint32_t flags, uint32_t lowres_step,
+                        uint64_t max_bin_len, uint32_t min_bin_count, pg_result **out);
+/* a result WITHOUT a table: an ngenomes-wide row buffer over the contigs of `seqs` (zeroed) that is filled
+ * through pg_result_merge_columns_range and finished with pg_rows_epilogue — the writer's side of the
+ * genome-sharded mode, where no single GPU holds a table of all genomes */
+int pg_result_create_rows(pg_ctx *ctx, int k, int ngenomes, const pg_seqset *seqs, uint32_t flags, uint32_t lowres_step,
+                          uint64_t max_bin_len, uint32_t min_bin_count, pg_result **out);
 int pg_result_destroy(pg_result *r);
 /* run the anchor kernels for all contigs of the result's seqset; async */
 int pg_anchor_run(pg_result *r);
+/* PG_ANCHOR_ROWS_ONLY results: probe contigs first_contig .. first_contig+ncontigs-1 only (bitmap.1 rows, no
+ * statistics); async.  The unit of the genome-sharded pipeline: probe a chunk, extract its columns, exchange them
+ * while the next chunk is probed. */
+int pg_anchor_run_range(pg_result *r, uint32_t first_contig, uint32_t ncontigs);
 /* HIP-event durations of the last pg_anchor_run on this result, measured on the context's
  * stream: the probe kernels (k_probe, one per sub-table) and the statistics kernel
  * (k_epilogue; 0 in rows-only mode).  Synchronises on the run's last event. */
 int pg_result_timing(pg_result *r, float *probe_ms, float *epilogue_ms);
+/* mean durations over EVERY run since pg_result_timing_reset (each run records into events of its own, nothing
+ * is waited for between runs): what a benchmark quotes as its average launch.  nruns = probe launches counted. */
+int pg_result_timing_reset(pg_result *r);
+int pg_result_timing_mean(pg_result *r, double *probe_ms, double *epilogue_ms, uint32_t *nruns);
 /* Genome-sharded exchange (union of tables > one GPU's HBM): rank i owns genomes
  * [i*per, (i+1)*per) and its PG_ANCHOR_ROWS_ONLY rows hold only their bits.  extract writes the
  * compact block of bit columns of genomes [g0, g0+width) — pg_result_columns_bytes(width) bytes,
@@ -196,6 +228,14 @@ int pg_result_timing(pg_result *r, float *probe_ms, float *epilogue_ms);
 uint64_t pg_result_columns_bytes(const pg_result *r, uint32_t width);
 int pg_result_extract_columns(pg_result *r, uint32_t g0, uint32_t width, void *d_dst);
 int pg_result_merge_columns(pg_result *r, const void *d_src, uint32_t nparts, uint32_t per);
+/* the same over a contig range (the pipeline's chunk): the block then holds only that range's tiles.  merge:
+ * the nparts blocks are genome blocks part0 .. part0+nparts-1 of `per` genomes each; accumulate != 0 ORs their bits
+ * into the rows (blocks arriving pass by pass — more genome blocks than GPUs), 0 writes the rows whole. */
+uint64_t pg_result_columns_bytes_range(const pg_result *r, uint32_t width, uint32_t first_contig, uint32_t ncontigs);
+int pg_result_extract_columns_range(pg_result *r, uint32_t g0, uint32_t width, uint32_t first_contig, uint32_t ncontigs,
+                                    void *d_dst);
+int pg_result_merge_columns_range(pg_result *r, const void *d_src, uint32_t part0, uint32_t nparts, uint32_t per,
+                                  uint32_t first_contig, uint32_t ncontigs, int accumulate);
 /* bitmap.100 rows, bin histograms and column sums from the (combined) bitmap.1 rows in the
  * result's device buffer; async.  Same outputs as the fused pg_anchor_run path. */
 int pg_rows_epilogue(pg_result *r);

@@ -29,6 +29,7 @@ _vp, _vpp = C.c_void_p, C.POINTER(C.c_void_p)
 PROTOTYPES = {
     "pg_last_error": (C.c_char_p, []),
     "pg_version": (C.c_char_p, []),
+    "pg_tile_positions": (C.c_uint32, []),
     "pg_ctx_create": (C.c_int, [C.c_int, _vpp]),
     "pg_ctx_destroy": (C.c_int, [_vp]),
     "pg_ctx_trim": (C.c_int, [_vp]),
@@ -48,6 +49,9 @@ PROTOTYPES = {
     "pg_sketch_add_seqset": (C.c_int, [_vp, _vp]),
     "pg_sketch_estimate": (C.c_int, [_vp, _u64p]),
     "pg_sketch_registers": (C.c_int, [_vp, _vp]),
+    "pg_sketch_estimate_registers": (C.c_int, [_vp, _u64p]),
+    "pg_sketch_reset": (C.c_int, [_vp]),
+    "pg_table_bytes_for": (C.c_int, [C.c_int, C.c_int, C.c_uint64, _u64p]),
     "pg_sketch_destroy": (C.c_int, [_vp]),
     "pg_table_export": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_uint64, _u64p]),
     "pg_table_k": (C.c_int, [_vp]),
@@ -65,8 +69,16 @@ PROTOTYPES = {
     "pg_seqset_unpack": (C.c_int, [_vp, C.c_uint32, _vp]),
     "pg_seqset_contig": (C.c_int, [_vp, C.c_uint32, C.POINTER(C.c_char_p), _u64p]),
     "pg_result_create": (C.c_int, [_vp, _vp, C.c_uint32, _vpp]),
+    "pg_result_create_ex": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, _vpp]),
+    "pg_result_create_rows": (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, _vpp]),
     "pg_result_destroy": (C.c_int, [_vp]),
     "pg_anchor_run": (C.c_int, [_vp]),
+    "pg_anchor_run_range": (C.c_int, [_vp, C.c_uint32, C.c_uint32]),
+    "pg_result_timing_reset": (C.c_int, [_vp]),
+    "pg_result_timing_mean": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double), _u32p]),
+    "pg_result_columns_bytes_range": (C.c_uint64, [_vp, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "pg_result_extract_columns_range": (C.c_int, [_vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _vp]),
+    "pg_result_merge_columns_range": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]),
     "pg_rows_epilogue": (C.c_int, [_vp]),
     "pg_result_timing": (C.c_int, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "pg_result_contig_info": (C.c_int, [_vp, C.c_uint32, _u64p, _u64p, _u32p, _u32p]),

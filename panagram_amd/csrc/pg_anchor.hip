@@ -247,8 +247,8 @@ __global__ __launch_bounds__(64) void k_probe(const SubTable st, const uint64_t 
                                               const uint32_t *__restrict__ nmw, const uint32_t *__restrict__ has_n,
                                               const SeqDesc *__restrict__ sd, const AnchorDesc *__restrict__ ad,
                                               const uint32_t *__restrict__ tile_contig,
-                                              const uint32_t *__restrict__ sched, uint8_t *__restrict__ out1,
-                                              uint32_t nbytes, const RowCols rc) {
+                                              const uint32_t *__restrict__ sched, uint32_t tile_base,
+                                              uint8_t *__restrict__ out1, uint32_t nbytes, const RowCols rc) {
     __shared__ uint64_t sw[PROBE_SEQW];
     __shared__ uint32_t nw[PROBE_SEQW];
     // A staged line occupies 16*SLOTS + 16 bytes of LDS: the pad keeps the lanes' ds_read_b128 of
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(64) void k_probe(const SubTable st, const uint64_t 
     const int k = (int)st.k;
     // tiles run in launch order unless the result carries a schedule (co-scheduled anchor genomes:
     // homologous regions of all genomes next to each other, so that table lines are shared in L2)
-    const uint32_t tile = sched ? sched[blockIdx.x] : blockIdx.x;
+    const uint32_t tile = sched ? sched[blockIdx.x] : blockIdx.x + tile_base;  // (tile_base: a contig range of the result)
     const uint32_t c = tile_contig[tile];
     const AnchorDesc a = ad[c];
     const SeqDesc s = sd[c];
@@ -535,6 +535,7 @@ __global__ __launch_bounds__(EPI_THREADS) void k_epilogue(uint32_t N, const Anch
     for (uint32_t i = tid; i < N; i += EPI_THREADS) cs[i] = 0;
     __syncthreads();
     const bool want_cs = (flags & 1u) != 0;
+    const bool want100 = (flags & 2u) == 0;  // bit 1: the low-resolution rows are taken by k_lowres (step != 100)
     // contiguous tile ranges, cut in units of 4 tiles (the 16-rows-per-thread group path)
     const uint32_t ngroups = (ntiles + 3) / 4;
     const uint32_t t_begin = 4u * (uint32_t)((uint64_t)ngroups * blockIdx.x / gridDim.x);
@@ -715,7 +716,7 @@ __global__ __launch_bounds__(EPI_THREADS) void k_epilogue(uint32_t N, const Anch
                 const uint32_t pos0 = ts + 16u * tid;  // at most one multiple of 100 among 16 positions
                 const uint32_t r100 = (pos0 + 99u) / 100u;
                 const uint32_t first = r100 * 100u - pos0;
-                if (first < 16u) out100[a.out100_off + r100] = (uint8_t)(wq[first >> 2] >> (8 * (first & 3)));
+                if (want100 && first < 16u) out100[a.out100_off + r100] = (uint8_t)(wq[first >> 2] >> (8 * (first & 3)));
                 next_valid = false;
                 tile += 3;
                 continue;
@@ -780,7 +781,7 @@ __global__ __launch_bounds__(EPI_THREADS) void k_epilogue(uint32_t N, const Anch
                 const uint32_t pos0 = ts + 16u * tid;
                 const uint32_t r100 = (pos0 + 99u) / 100u;
                 const uint32_t first = r100 * 100u - pos0;
-                if (first < 16u) {
+                if (want100 && first < 16u) {
                     const uint8_t *pr = gt + first * nbytes;
                     uint8_t *o100 = out100 + a.out100_off + (uint64_t)r100 * nbytes;
                     for (uint32_t bb = 0; bb < nbytes; ++bb) o100[bb] = pr[bb];
@@ -856,7 +857,7 @@ __global__ __launch_bounds__(EPI_THREADS) void k_epilogue(uint32_t N, const Anch
                 const uint32_t pos0 = tile_start + p0;
                 const uint32_t r100 = (pos0 + 99u) / 100u;
                 const uint32_t first = r100 * 100u;
-                if (first < pos0 + nact) out100[a.out100_off + r100] = (uint8_t)(packed >> (8 * (first - pos0)));
+                if (want100 && first < pos0 + nact) out100[a.out100_off + r100] = (uint8_t)(packed >> (8 * (first - pos0)));
             }
         } else if (WIDE && windowed) {
             // ---- wide path: the row bytes this launch sums, as one or two 32-bit words ----
@@ -926,7 +927,7 @@ __global__ __launch_bounds__(EPI_THREADS) void k_epilogue(uint32_t N, const Anch
                 const uint32_t pos0 = tile_start + p0;
                 const uint32_t r100 = (pos0 + 99u) / 100u;
                 const uint32_t jsel = r100 * 100u - pos0;
-                if (jsel < nact) {
+                if (want100 && jsel < nact) {
                     const uint32_t a0 = jsel == 0 ? w0[0] : jsel == 1 ? w0[1] : jsel == 2 ? w0[2] : w0[3];
                     const uint32_t a1 = jsel == 0 ? w1[0] : jsel == 1 ? w1[1] : jsel == 2 ? w1[2] : w1[3];
                     uint8_t *o100 = out100 + a.out100_off + (uint64_t)r100 * nbytes;
@@ -953,7 +954,7 @@ __global__ __launch_bounds__(EPI_THREADS) void k_epilogue(uint32_t N, const Anch
                 const bool active = pl < npos;
                 const uint32_t pos = tile_start + pl;
                 uint32_t popc = 0;
-                const bool is100 = active && (pos % 100u == 0);
+                const bool is100 = want100 && active && (pos % 100u == 0);
                 for (uint32_t d = 0; d < ndbs_all; ++d) {
                     const uint32_t nb = min(4u, nbytes - 4 * d);
                     uint32_t wv = 0;
@@ -1007,6 +1008,7 @@ __global__ __launch_bounds__(EPI_THREADS) void k_epilogue_words(uint32_t N, cons
     for (uint32_t i = tid; i < 32u * W; i += EPI_THREADS) cs[i] = 0;
     __syncthreads();
     const bool want_cs = (flags & 1u) != 0;
+    const bool want100 = (flags & 2u) == 0;
     const uint32_t ngroups = (ntiles + 3) / 4;
     const uint32_t t_begin = 4u * (uint32_t)((uint64_t)ngroups * blockIdx.x / gridDim.x);
     const uint32_t t_end = min(ntiles, 4u * (uint32_t)((uint64_t)ngroups * (blockIdx.x + 1) / gridDim.x));
@@ -1159,7 +1161,7 @@ __global__ __launch_bounds__(EPI_THREADS) void k_epilogue_words(uint32_t N, cons
                 } else {
                     hist_position(on && d == 0, pos, tot, N, binlen, bin0, bin0_start, rel_base, hist, bins, a.bin_off, lane);
                 }
-                if (on && pos % 100u == 0) {  // 1-in-100 rows: every lane copies its word
+                if (want100 && on && pos % 100u == 0) {  // 1-in-100 rows: every lane copies its word
                     uint8_t *o = out100 + a.out100_off + (uint64_t)(pos / 100u) * nbytes + 4u * d;
                     if (wbytes == 4) reinterpret_cast<U32 *>(o)->v = v[j];
                     else
@@ -1231,18 +1233,29 @@ __global__ __launch_bounds__(256) void k_window_stats(uint32_t N, const uint8_t 
 // genome g0 + j at positions 64 s .. 64 s + 63 of the tile.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_cols_extract(uint32_t N, const AnchorDesc *__restrict__ ad,
-                                                      const uint32_t *__restrict__ tile_contig, uint32_t ntiles,
-                                                      const uint8_t *__restrict__ out1, uint32_t g0, uint32_t width,
-                                                      unsigned long long *__restrict__ dst) {
+                                                      const uint32_t *__restrict__ tile_contig, uint32_t tile_base,
+                                                      uint32_t ntiles, const uint8_t *__restrict__ out1, uint32_t g0,
+                                                      uint32_t width, unsigned long long *__restrict__ dst) {
     const int lane = threadIdx.x & 63;
-    const uint64_t slot = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint64_t slot = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);  // relative to the range's first tile
     if (slot >= (uint64_t)ntiles * 8) return;  // wave-uniform
-    const uint32_t tile = (uint32_t)(slot >> 3), sub = (uint32_t)(slot & 7);
+    const uint32_t tile = tile_base + (uint32_t)(slot >> 3), sub = (uint32_t)(slot & 7);
     const AnchorDesc a = ad[tile_contig[tile]];
     const uint32_t nbytes = (N + 7) / 8;
     const uint32_t p = (tile - a.tile0) * PROBE_TILE + sub * 64 + lane;
     const bool active = p < a.nkmers;
     const uint8_t *row = out1 + a.out_off + (uint64_t)p * nbytes;
+    if (nbytes == 1 && width <= 8) {  // one-byte rows (a block of up to 8 genomes): one load per position
+        const uint32_t v = active ? (uint32_t)row[0] : 0u;
+        unsigned long long mine = 0;
+        for (uint32_t j = 0; j < width; ++j) {
+            const uint32_t g = g0 + j;
+            const unsigned long long m = __ballot(g < N && ((v >> g) & 1u));
+            if ((uint32_t)lane == j) mine = m;
+        }
+        if ((uint32_t)lane < width) dst[slot * width + lane] = mine;
+        return;
+    }
     for (uint32_t j0 = 0; j0 < width; j0 += 64) {
         unsigned long long mine = 0;
         const uint32_t jn = min(64u, width - j0);
@@ -1256,31 +1269,62 @@ __global__ __launch_bounds__(256) void k_cols_extract(uint32_t N, const AnchorDe
     }
 }
 
+// src = nparts blocks of part_words u64 each (block i = genomes (part0 + i) * per ...); the bits of those genomes are
+// set in the rows from the blocks.  accumulate == 0: the rows are written whole (bits of genomes outside the
+// blocks become 0); != 0: the blocks' bits are OR-ed into what the rows hold (genome blocks arriving pass by pass).
 __global__ __launch_bounds__(256) void k_cols_merge(uint32_t N, const AnchorDesc *__restrict__ ad,
-                                                    const uint32_t *__restrict__ tile_contig, uint32_t ntiles,
-                                                    uint8_t *__restrict__ out1, const unsigned long long *__restrict__ src,
-                                                    uint32_t nparts, uint64_t part_words, uint32_t per) {
+                                                    const uint32_t *__restrict__ tile_contig, uint32_t tile_base,
+                                                    uint32_t ntiles, uint8_t *__restrict__ out1,
+                                                    const unsigned long long *__restrict__ src, uint32_t part0,
+                                                    uint32_t nparts, uint64_t part_words, uint32_t per, uint32_t accumulate) {
     const int lane = threadIdx.x & 63;
     const uint64_t slot = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (slot >= (uint64_t)ntiles * 8) return;
-    const uint32_t tile = (uint32_t)(slot >> 3), sub = (uint32_t)(slot & 7);
+    const uint32_t tile = tile_base + (uint32_t)(slot >> 3), sub = (uint32_t)(slot & 7);
     const AnchorDesc a = ad[tile_contig[tile]];
     const uint32_t nbytes = (N + 7) / 8, ndbs = (N + 31) / 32;
     const uint32_t p = (tile - a.tile0) * PROBE_TILE + sub * 64 + lane;
     uint8_t *row = out1 + a.out_off + (uint64_t)p * nbytes;
+    const uint32_t gfirst = part0 * per, gend = min(N, (part0 + nparts) * per);  // genomes the blocks cover
     for (uint32_t d = 0; d < ndbs; ++d) {
+        if (accumulate && (32 * d + 32 <= gfirst || 32 * d >= gend)) continue;  // (uniform) word untouched by these blocks
         uint32_t w = 0;
         const uint32_t nb = min(32u, N - 32 * d);
         for (uint32_t b = 0; b < nb; ++b) {
-            const uint32_t g = 32 * d + b, part = g / per, j = g - part * per;
-            if (part >= nparts) continue;
+            const uint32_t g = 32 * d + b;
+            if (g < gfirst || g >= gend) continue;
+            const uint32_t part = g / per - part0, j = g % per;
             const unsigned long long word = src[(uint64_t)part * part_words + slot * per + j];  // wave-uniform
             w |= (uint32_t)((word >> lane) & 1ull) << b;
         }
         if (p < a.nkmers) {
             const uint32_t n = min(4u, nbytes - 4 * d);
-            for (uint32_t bb = 0; bb < n; ++bb) row[4 * d + bb] = (uint8_t)(w >> (8 * bb));
+            if (accumulate) {
+                for (uint32_t bb = 0; bb < n; ++bb) {
+                    const uint8_t add = (uint8_t)(w >> (8 * bb));
+                    if (add) row[4 * d + bb] |= add;
+                }
+            } else {
+                for (uint32_t bb = 0; bb < n; ++bb) row[4 * d + bb] = (uint8_t)(w >> (8 * bb));
+            }
         }
+    }
+}
+
+// every step-th row of bitmap.1 -> the low-resolution bitmap, for steps other than the 100 the statistics
+// kernels fuse (index.py:101-106 lowres_step): one wave per tile, a handful of rows each
+__global__ __launch_bounds__(64) void k_lowres(uint32_t N, const AnchorDesc *__restrict__ ad,
+                                               const uint32_t *__restrict__ tile_contig, const uint8_t *__restrict__ out1,
+                                               uint8_t *__restrict__ outlow, uint32_t step) {
+    const uint32_t tile = blockIdx.x;
+    const AnchorDesc a = ad[tile_contig[tile]];
+    const uint32_t nbytes = (N + 7) / 8;
+    const uint32_t ts = (tile - a.tile0) * PROBE_TILE, te = min(a.nkmers, ts + (uint32_t)PROBE_TILE);
+    const uint64_t r0 = ((uint64_t)ts + step - 1) / step;
+    for (uint64_t r = r0 + threadIdx.x; r * step < te; r += 64) {
+        const uint8_t *src = out1 + a.out_off + r * step * nbytes;
+        uint8_t *dst = outlow + a.out100_off + r * nbytes;
+        for (uint32_t bb = 0; bb < nbytes; ++bb) dst[bb] = src[bb];
     }
 }
 
@@ -1290,17 +1334,17 @@ __global__ __launch_bounds__(256) void k_cols_merge(uint32_t N, const AnchorDesc
 template <int W_C, bool TWO, int ROWMODE, int SLOTS>
 static hipError_t probe_t(hipStream_t s, uint32_t ntiles, const SubTable &st, const uint64_t *seqw, const uint32_t *nmw,
                           const uint32_t *has_n, const SeqDesc *sd, const AnchorDesc *ad, const uint32_t *tile_contig,
-                          const uint32_t *sched, uint8_t *out1, uint32_t nbytes, const RowCols &rc) {
+                          const uint32_t *sched, uint32_t tile_base, uint8_t *out1, uint32_t nbytes, const RowCols &rc) {
     hipLaunchKernelGGL((k_probe<W_C, TWO, ROWMODE, SLOTS>), dim3(ntiles), dim3(64), 0, s, st, seqw, nmw, has_n, sd, ad,
-                       tile_contig, sched, out1, nbytes, rc);
+                       tile_contig, sched, tile_base, out1, nbytes, rc);
     return hipGetLastError();
 }
 
 template <int W_C>
 static hipError_t probe_w(hipStream_t s, uint32_t ntiles, const SubTable &st, const uint64_t *seqw, const uint32_t *nmw,
                           const uint32_t *has_n, const SeqDesc *sd, const AnchorDesc *ad, const uint32_t *tile_contig,
-                          const uint32_t *sched, uint8_t *out1, uint32_t nbytes, const RowCols &rc, int rowmode) {
-#define PG_A s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, sched, out1, nbytes, rc
+                          const uint32_t *sched, uint32_t tile_base, uint8_t *out1, uint32_t nbytes, const RowCols &rc, int rowmode) {
+#define PG_A s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, sched, tile_base, out1, nbytes, rc
     if (st.slots == 16) {
         if (st.W == 2) {
             if (rowmode == 2) return probe_t<W_C, true, 2, 16>(PG_A);
@@ -1326,7 +1370,7 @@ static int row_mode(uint32_t nbytes, const RowCols &rc) {
 
 hipError_t launch_anchor(hipStream_t s, const TableDesc &T, const uint64_t *seqw, const uint32_t *nmw,
                          const uint32_t *has_n, const SeqDesc *sd, const AnchorDesc *ad, const uint32_t *tile_contig,
-                         const uint32_t *sched, uint32_t ntiles, uint8_t *out1, uint64_t out1_bytes) {
+                         const uint32_t *sched, uint32_t tile_base, uint32_t ntiles, uint8_t *out1, uint64_t out1_bytes) {
     if (ntiles == 0) return hipSuccess;
     const uint32_t nbytes = (T.ngenomes + 7) / 8;
     hipError_t e = hipSuccess;
@@ -1343,13 +1387,13 @@ hipError_t launch_anchor(hipStream_t s, const TableDesc &T, const uint64_t *seqw
         const int rm = (T.nsub == 1) ? row_mode(nbytes, rc) : 0;
         const uint32_t w = st.m ? st.k - st.m + 1 : 0;
         switch (w) {  // the kernel's compile-time window must be the one the table was built with
-            case 0: e = probe_w<0>(s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, sched, out1, nbytes, rc, rm); break;
-            case 3: e = probe_w<3>(s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, sched, out1, nbytes, rc, rm); break;
-            case 4: e = probe_w<4>(s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, sched, out1, nbytes, rc, rm); break;
-            case 5: e = probe_w<5>(s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, sched, out1, nbytes, rc, rm); break;
-            case 6: e = probe_w<6>(s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, sched, out1, nbytes, rc, rm); break;
-            case 7: e = probe_w<7>(s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, sched, out1, nbytes, rc, rm); break;
-            case 8: e = probe_w<8>(s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, sched, out1, nbytes, rc, rm); break;
+            case 0: e = probe_w<0>(s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, sched, tile_base, out1, nbytes, rc, rm); break;
+            case 3: e = probe_w<3>(s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, sched, tile_base, out1, nbytes, rc, rm); break;
+            case 4: e = probe_w<4>(s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, sched, tile_base, out1, nbytes, rc, rm); break;
+            case 5: e = probe_w<5>(s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, sched, tile_base, out1, nbytes, rc, rm); break;
+            case 6: e = probe_w<6>(s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, sched, tile_base, out1, nbytes, rc, rm); break;
+            case 7: e = probe_w<7>(s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, sched, tile_base, out1, nbytes, rc, rm); break;
+            case 8: e = probe_w<8>(s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, sched, tile_base, out1, nbytes, rc, rm); break;
             default: return hipErrorInvalidValue;
         }
         if (e != hipSuccess) return e;
@@ -1417,19 +1461,27 @@ hipError_t launch_window_stats(hipStream_t st, uint32_t ngenomes, const uint8_t 
 }
 
 hipError_t launch_cols_extract(hipStream_t st, uint32_t ngenomes, const AnchorDesc *ad, const uint32_t *tile_contig,
-                               uint32_t ntiles, const uint8_t *out1, uint32_t g0, uint32_t width, void *dst) {
+                               uint32_t tile_base, uint32_t ntiles, const uint8_t *out1, uint32_t g0, uint32_t width, void *dst) {
     if (ntiles == 0 || width == 0) return hipSuccess;
     hipLaunchKernelGGL(k_cols_extract, dim3((unsigned)(((uint64_t)ntiles * 8 + 3) / 4)), dim3(256), 0, st, ngenomes, ad,
-                       tile_contig, ntiles, out1, g0, width, static_cast<unsigned long long *>(dst));
+                       tile_contig, tile_base, ntiles, out1, g0, width, static_cast<unsigned long long *>(dst));
     return hipGetLastError();
 }
 
 hipError_t launch_cols_merge(hipStream_t st, uint32_t ngenomes, const AnchorDesc *ad, const uint32_t *tile_contig,
-                             uint32_t ntiles, uint8_t *out1, const void *src, uint32_t nparts, uint64_t part_words,
-                             uint32_t per) {
-    if (ntiles == 0 || per == 0) return hipSuccess;
+                             uint32_t tile_base, uint32_t ntiles, uint8_t *out1, const void *src, uint32_t part0,
+                             uint32_t nparts, uint64_t part_words, uint32_t per, uint32_t accumulate) {
+    if (ntiles == 0 || per == 0 || nparts == 0) return hipSuccess;
     hipLaunchKernelGGL(k_cols_merge, dim3((unsigned)(((uint64_t)ntiles * 8 + 3) / 4)), dim3(256), 0, st, ngenomes, ad,
-                       tile_contig, ntiles, out1, static_cast<const unsigned long long *>(src), nparts, part_words, per);
+                       tile_contig, tile_base, ntiles, out1, static_cast<const unsigned long long *>(src), part0, nparts,
+                       part_words, per, accumulate);
+    return hipGetLastError();
+}
+
+hipError_t launch_lowres(hipStream_t st, uint32_t ngenomes, const AnchorDesc *ad, const uint32_t *tile_contig,
+                         uint32_t ntiles, const uint8_t *out1, uint8_t *outlow, uint32_t step) {
+    if (ntiles == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_lowres, dim3(ntiles), dim3(64), 0, st, ngenomes, ad, tile_contig, out1, outlow, step);
     return hipGetLastError();
 }
 

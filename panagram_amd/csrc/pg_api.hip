@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -46,7 +47,8 @@ int pg_set_error(int code, const char *msg) {
     g_err = msg ? msg : "";
     return code;
 }
-extern "C" const char *pg_version(void) { return "panagram_hip 0.1 gfx950"; }
+extern "C" const char *pg_version(void) { return "panagram_hip 0.2 gfx950"; }
+extern "C" uint32_t pg_tile_positions(void) { return (uint32_t)PROBE_TILE; }
 
 // ---------------------------------------------------------------------------
 // handles
@@ -70,6 +72,7 @@ struct pg_ctx {
         bool ready = false, busy = false;
     } df[4];
     std::mutex df_mu;
+    std::condition_variable df_cv;
     // Row buffers of destroyed results, kept for the next result: hipFree of tens of GB costs about 40 ms per
     // GB on this stack (paid inside the NEXT hipMalloc: tools/malloc_time.py), which a run that anchors its
     // genomes in batches would pay for every batch.  At most two buffers; emptied by pg_ctx_trim, when an
@@ -98,7 +101,14 @@ struct pg_table {
     double spill = 0;                // keys outside their home line / keys, as of the last pg_table_rehash
     std::atomic<int> refs{0};        // results on this table
     bool dead = false;
+    // ONE writer at a time: lane_insert's mask update is a plain read-modify-write that is only safe while every
+    // concurrent writer of a word ORs in the same bits (pg_device.h) — i.e. one insert call (one genome, its launches
+    // serialised on the context's stream and synchronised before the call returns) at a time.  Every entry point
+    // that writes the table holds this lock for its whole duration: a second host thread queues up behind the
+    // first instead of racing it, whatever stream the context has been pointed at in between.
+    std::mutex write_mu;
 };
+#define TABLE_WRITER(t) std::lock_guard<std::mutex> writer_guard_((t)->write_mu)
 
 struct pg_seqset {
     pg_ctx *ctx;
@@ -117,9 +127,13 @@ struct pg_seqset {
 };
 
 struct pg_result {
-    pg_table *tbl;
+    pg_ctx *ctx;
+    pg_table *tbl;  // NULL for a rows container (pg_result_create_rows): rows arrive through pg_result_merge_columns*
     const pg_seqset *seqs;
+    uint32_t N;     // genomes per row (the table's, or the container's own)
+    int k;
     uint32_t flags;
+    uint32_t lowres_step = 100;  // bitmap.<lowres_step> = every lowres_step-th row (index.py:101-106)
     std::vector<AnchorDesc> ad;
     std::vector<uint64_t> nrows100;
     AnchorDesc *d_ad;
@@ -136,7 +150,21 @@ struct pg_result {
     unsigned long long *d_colsums;
     hipEvent_t ev[4];  // last pg_anchor_run: start / after k_probe (main stream), epilogue start / end (side stream)
     bool ev_ok, ev_epi;
+    bool rows_valid = false;  // rows were merged in (pg_result_merge_columns*)
+    // HIP-event durations of every pg_anchor_run since the last pg_result_timing_reset: a benchmark
+    // averages the launches of all its timed steps, not only the last one
+    // (every run records into an event set of its own — ev[] is the latest — so that nothing has to be
+    // waited for between steps; sets beyond EV_RING are folded into the sums and recycled)
+    struct EvSet {
+        hipEvent_t e[4];
+        bool probe, epi;  // which of the two intervals (e[0]..e[1] probe, e[2]..e[3] statistics) were recorded
+    };
+    std::vector<EvSet> ev_hist, ev_free;
+    size_t hist_skip = 0;  // leading sets of ev_hist from before the last pg_result_timing_reset
+    double probe_ms_sum = 0, epi_ms_sum = 0;
+    uint32_t probe_runs = 0, epi_runs = 0;
 };
+static constexpr size_t EV_RING = 128;
 
 static constexpr uint32_t MAX_PROBE = 512;  // lines an insert may walk before the table is grown
 static constexpr double GROW_AT = 0.55;     // grow when keys > GROW_AT * slots
@@ -178,23 +206,14 @@ extern "C" int pg_ctx_create(int device_id, pg_ctx **out) {
     return PG_OK;
 }
 
+static void df_free_buffers(pg_ctx::DfSet &d);
 static void ctx_free(pg_ctx *c) {
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     hipStreamSynchronize(c->aux_stream);
     for (auto &b : c->row_cache) hipFree(b.p);
     c->row_cache.clear();
-    for (auto &d : c->df) {
-        for (int i = 0; i < 2; ++i) {
-            hipFree(d.d_slots[i]);
-            hipFree(d.d_packed[i]);
-            hipFree(d.d_sizes[i]);
-            hipFree(d.d_offs[i]);
-            if (d.h_slots[i]) hipHostFree(d.h_slots[i]);
-            if (d.h_sizes[i]) hipHostFree(d.h_sizes[i]);
-        }
-        hipFree(d.d_crc);
-    }
+    for (auto &d : c->df) df_free_buffers(d);
     hipStreamDestroy(c->aux_stream);
     hipStreamDestroy(c->own_stream);
     delete c;
@@ -328,6 +347,22 @@ static int alloc_sub(pg_ctx *ctx, uint32_t W, uint32_t word0, uint32_t k, uint32
     t.buckets = static_cast<uint8_t *>(p);
     HIP_TRY(launch_table_init(ctx->stream, t));
     *out = t;
+    return PG_OK;
+}
+
+// lines a sub-table is created with for `want` expected keys (pg_table_create) — also what pg_table_bytes_for prices
+static uint64_t lines_for(uint64_t want, uint32_t slots) {
+    uint64_t nb = (uint64_t)((double)want / (TARGET_LOAD * slots)) + 1;
+    return next_prime(std::max<uint64_t>(nb, 64));
+}
+
+extern "C" int pg_table_bytes_for(int k, int ngenomes, uint64_t expected_keys, uint64_t *bytes) {
+    if (!bytes) return fail(PG_E_INVALID, "pg_table_bytes_for: NULL argument");
+    if (k < 1 || k > 32 || ngenomes < 1) return fail(PG_E_INVALID, "pg_table_bytes_for: bad k / ngenomes");
+    const int ndbs = (ngenomes + 31) / 32, nsub = (ndbs + 1) / 2;
+    // (an estimate: one prime search less — the line count itself, not the next prime above it)
+    const uint64_t nb = (uint64_t)((double)std::max<uint64_t>(expected_keys, 1ull << 18) / (TARGET_LOAD * 8)) + 1;
+    *bytes = (uint64_t)nsub * std::max<uint64_t>(nb, 64) * 128ull;
     return PG_OK;
 }
 
@@ -488,6 +523,7 @@ extern "C" int pg_table_insert_seqset(pg_table *t, int g, const pg_seqset *sq) {
     if (g < 0 || g >= t->ngenomes) return fail(PG_E_INVALID, "genome index %d out of range (0..%d)", g, t->ngenomes - 1);
     if (t->ctx != sq->ctx) return fail(PG_E_INVALID, "table and seqset belong to different contexts");
     if (int r = use_device(t->ctx)) return r;
+    TABLE_WRITER(t);
     const int d = g / 32, si = d / 2, w = d % 2;
     const uint32_t bits = 1u << (g % 32);
     uint64_t total = 0;
@@ -528,6 +564,7 @@ extern "C" int pg_table_insert_seqset_min(pg_table *t, int g, const pg_seqset *s
     for (auto &c : sq->desc)
         if (c.len >= (uint64_t)t->k) total += c.len - t->k + 1;
     if (total == 0) return PG_OK;
+    TABLE_WRITER(t);
     hipStream_t st = t->ctx->stream;
     uint64_t expect = total / 3 + 1024;
     for (int attempt = 0; attempt < 8; ++attempt, expect *= 2) {
@@ -599,6 +636,7 @@ extern "C" int pg_table_insert_keys(pg_table *t, int db_idx, const uint64_t *key
     if (db_idx < 0 || db_idx >= t->ndbs) return fail(PG_E_INVALID, "db index %d out of range (0..%d)", db_idx, t->ndbs - 1);
     if (n == 0) return PG_OK;
     if (int r = use_device(t->ctx)) return r;
+    TABLE_WRITER(t);
     uint64_t *dk = nullptr;
     uint32_t *dv = nullptr;
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dk), n * 8));
@@ -714,6 +752,7 @@ extern "C" int pg_table_rehash(pg_table *t, double keys_per_bucket) {
     if (!t) return fail(PG_E_INVALID, "table is NULL");
     if (!(keys_per_bucket > 0.05 && keys_per_bucket <= 8.0)) return fail(PG_E_INVALID, "keys_per_bucket must be in (0.05, 8]");
     if (int r = use_device(t->ctx)) return r;
+    TABLE_WRITER(t);
     if (!t->m_pinned) {  // the key count is known now: settle the minimizer length for it
         uint64_t most = 0;
         for (auto &s : t->subs) most = std::max<uint64_t>(most, s.count);
@@ -846,20 +885,33 @@ extern "C" int pg_sketch_registers(pg_sketch *sk, uint8_t *out) {
 
 // HyperLogLog (Flajolet et al. 2007) with the small-range correction; 64-bit hashes need no
 // large-range one.  Standard error 1.04 / sqrt(2^16) = 0.4 %.
-extern "C" int pg_sketch_estimate(pg_sketch *sk, uint64_t *distinct) {
-    if (!sk || !distinct) return fail(PG_E_INVALID, "pg_sketch_estimate: NULL argument");
-    std::vector<uint8_t> regs((size_t)1 << SKETCH_BITS);
-    if (int r = pg_sketch_registers(sk, regs.data())) return r;
-    const double m = (double)regs.size();
+extern "C" int pg_sketch_estimate_registers(const uint8_t *regs, uint64_t *distinct) {
+    if (!regs || !distinct) return fail(PG_E_INVALID, "pg_sketch_estimate_registers: NULL argument");
+    const size_t n = (size_t)1 << SKETCH_BITS;
+    const double m = (double)n;
     double sum = 0.0;
     size_t zeros = 0;
-    for (uint8_t v : regs) {
-        sum += std::ldexp(1.0, -(int)v);
-        zeros += v == 0;
+    for (size_t i = 0; i < n; ++i) {
+        sum += std::ldexp(1.0, -(int)regs[i]);
+        zeros += regs[i] == 0;
     }
     double est = (0.7213 / (1.0 + 1.079 / m)) * m * m / sum;
     if (est <= 2.5 * m && zeros) est = m * std::log(m / (double)zeros);
     *distinct = (uint64_t)(est + 0.5);
+    return PG_OK;
+}
+
+extern "C" int pg_sketch_estimate(pg_sketch *sk, uint64_t *distinct) {
+    if (!sk || !distinct) return fail(PG_E_INVALID, "pg_sketch_estimate: NULL argument");
+    std::vector<uint8_t> regs((size_t)1 << SKETCH_BITS);
+    if (int r = pg_sketch_registers(sk, regs.data())) return r;
+    return pg_sketch_estimate_registers(regs.data(), distinct);
+}
+
+extern "C" int pg_sketch_reset(pg_sketch *sk) {
+    if (!sk) return fail(PG_E_INVALID, "pg_sketch_reset: NULL argument");
+    if (int r = use_device(sk->ctx)) return r;
+    HIP_TRY(hipMemsetAsync(sk->d_regs, 0, sizeof(uint32_t) << SKETCH_BITS, sk->ctx->stream));
     return PG_OK;
 }
 
@@ -1170,17 +1222,32 @@ static TableDesc make_desc(const pg_table *t) {
     return T;
 }
 
-extern "C" int pg_result_create(pg_table *t, const pg_seqset *sq, uint32_t flags, pg_result **out) {
-    if (!t || !sq || !out) return fail(PG_E_INVALID, "pg_result_create: NULL argument");
-    if (t->ctx != sq->ctx) return fail(PG_E_INVALID, "table and seqset belong to different contexts");
-    if (int r = use_device(t->ctx)) return r;
-    const uint32_t N = t->ngenomes, nbytes = (N + 7) / 8;
+// bitmap.<lowres_step> / bin geometry of a result (index.py:101-106, 1169-1172; cpp/anchor.cpp:114-118 hard-codes
+// 100 / 200000 / 100)
+struct ResultGeom {
+    uint32_t lowres_step = 100;
+    uint64_t max_bin_len = 200000;
+    uint32_t min_bin_count = 100;
+};
+
+static int result_create(pg_ctx *ctx, pg_table *t, int k, uint32_t N, const pg_seqset *sq, uint32_t flags,
+                         const ResultGeom &geo, pg_result **out) {
+    if (ctx != sq->ctx) return fail(PG_E_INVALID, "table / context and seqset belong to different contexts");
+    if (geo.lowres_step < 1 || geo.max_bin_len < 1 || geo.min_bin_count < 1)
+        return fail(PG_E_INVALID, "lowres_step, max_bin_len and min_bin_count must be >= 1");
+    if (int r = use_device(ctx)) return r;
+    const uint32_t nbytes = (N + 7) / 8;
     pg_result *r = new pg_result();
+    r->ctx = ctx;
     r->tbl = t;
     r->seqs = sq;
-    ++t->refs;
+    r->N = N;
+    r->k = k;
+    if (t) ++t->refs;
+    else ++ctx->refs;
     ++const_cast<pg_seqset *>(sq)->refs;
     r->flags = flags;
+    r->lowres_step = geo.lowres_step;
     r->d_ad = nullptr;
     r->d_tile_contig = nullptr;
     r->d_out1 = r->d_out100 = nullptr;
@@ -1192,17 +1259,17 @@ extern "C" int pg_result_create(pg_table *t, const pg_seqset *sq, uint32_t flags
     std::vector<uint32_t> tile_contig;
     for (uint32_t c = 0; c < sq->n; ++c) {
         const uint64_t len = sq->desc[c].len;
-        const uint64_t nk = len >= (uint64_t)t->k ? len - t->k + 1 : 0;
+        const uint64_t nk = len >= (uint64_t)k ? len - k + 1 : 0;
         if (nk > 0xFFFFFFF0ull) {
             pg_result_destroy(r);
             return fail(PG_E_INVALID, "contig %u has %llu k-mers; contigs must stay below 2^32 (as in KMC)", c, (unsigned long long)nk);
         }
         AnchorDesc a;
         a.nkmers = (uint32_t)nk;
-        // cpp/anchor.cpp:114-118; contigs with < 100 k-mers make the reference divide by
-        // zero — here they get one bin per k-mer (documented deviation)
-        uint64_t binlen = 200000;
-        if (nk / binlen < 100) binlen = nk / 100;
+        // cpp/anchor.cpp:114-118 / index.py:1169-1172; contigs with fewer k-mers than min_bin_count make the
+        // reference divide by zero — here they get one bin per k-mer (documented deviation)
+        uint64_t binlen = geo.max_bin_len;
+        if (nk / binlen < geo.min_bin_count) binlen = nk / geo.min_bin_count;
         if (binlen == 0) binlen = 1;
         a.binlen = (uint32_t)binlen;
         a.nbins = (uint32_t)((nk + binlen - 1) / binlen);
@@ -1210,7 +1277,7 @@ extern "C" int pg_result_create(pg_table *t, const pg_seqset *sq, uint32_t flags
         a.out100_off = o100;
         a.bin_off = bins;
         a.tile0 = (uint32_t)tiles;
-        const uint64_t n100 = (nk + 99) / 100;
+        const uint64_t n100 = (nk + geo.lowres_step - 1) / geo.lowres_step;
         r->nrows100.push_back(n100);
         o1 += (nk * nbytes + 15) & ~15ull;
         o100 += n100 * nbytes;
@@ -1228,11 +1295,11 @@ extern "C" int pg_result_create(pg_table *t, const pg_seqset *sq, uint32_t flags
     r->out1_bytes = o1;
     r->out100_bytes = o100;
     r->total_bins = bins;
-    hipStream_t st = t->ctx->stream;
+    hipStream_t st = ctx->stream;
     hipError_t e;
     if ((e = hipMalloc(reinterpret_cast<void **>(&r->d_ad), std::max<size_t>(1, r->ad.size()) * sizeof(AnchorDesc))) == hipSuccess &&
         (e = hipMalloc(reinterpret_cast<void **>(&r->d_tile_contig), std::max<size_t>(1, tile_contig.size()) * 4)) == hipSuccess &&
-        (e = row_alloc(t->ctx, std::max<uint64_t>(16, o1), &r->d_out1, &r->out1_cap)) == hipSuccess &&
+        (e = row_alloc(ctx, std::max<uint64_t>(16, o1), &r->d_out1, &r->out1_cap)) == hipSuccess &&
         (e = hipMalloc(reinterpret_cast<void **>(&r->d_out100), std::max<uint64_t>(16, o100))) == hipSuccess &&
         (e = hipMalloc(reinterpret_cast<void **>(&r->d_bins), std::max<uint64_t>(1, bins) * (N + 1) * 4)) == hipSuccess &&
         (e = hipMalloc(reinterpret_cast<void **>(&r->d_colsums), std::max<size_t>(1, r->ad.size()) * N * 8)) == hipSuccess) {
@@ -1240,6 +1307,8 @@ extern "C" int pg_result_create(pg_table *t, const pg_seqset *sq, uint32_t flags
             e = hipMemcpyAsync(r->d_ad, r->ad.data(), r->ad.size() * sizeof(AnchorDesc), hipMemcpyHostToDevice, st);
         if (e == hipSuccess && !tile_contig.empty())
             e = hipMemcpyAsync(r->d_tile_contig, tile_contig.data(), tile_contig.size() * 4, hipMemcpyHostToDevice, st);
+        // a rows container is filled block by block (pg_result_merge_columns_range with accumulate): start from zero
+        if (e == hipSuccess && !t) e = hipMemsetAsync(r->d_out1, 0, std::max<uint64_t>(16, o1), st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);
     }
     if (e != hipSuccess) {
@@ -1250,24 +1319,55 @@ extern "C" int pg_result_create(pg_table *t, const pg_seqset *sq, uint32_t flags
     return PG_OK;
 }
 
+extern "C" int pg_result_create(pg_table *t, const pg_seqset *sq, uint32_t flags, pg_result **out) {
+    if (!t || !sq || !out) return fail(PG_E_INVALID, "pg_result_create: NULL argument");
+    return result_create(t->ctx, t, t->k, (uint32_t)t->ngenomes, sq, flags, ResultGeom(), out);
+}
+
+extern "C" int pg_result_create_ex(pg_table *t, const pg_seqset *sq, uint32_t flags, uint32_t lowres_step,
+                                   uint64_t max_bin_len, uint32_t min_bin_count, pg_result **out) {
+    if (!t || !sq || !out) return fail(PG_E_INVALID, "pg_result_create_ex: NULL argument");
+    ResultGeom g;
+    g.lowres_step = lowres_step;
+    g.max_bin_len = max_bin_len;
+    g.min_bin_count = min_bin_count;
+    return result_create(t->ctx, t, t->k, (uint32_t)t->ngenomes, sq, flags, g, out);
+}
+
+extern "C" int pg_result_create_rows(pg_ctx *ctx, int k, int ngenomes, const pg_seqset *sq, uint32_t flags,
+                                     uint32_t lowres_step, uint64_t max_bin_len, uint32_t min_bin_count, pg_result **out) {
+    if (!ctx || !sq || !out) return fail(PG_E_INVALID, "pg_result_create_rows: NULL argument");
+    if (k < 1 || k > 32) return fail(PG_E_INVALID, "k=%d unsupported (1..32)", k);
+    if (ngenomes < 1) return fail(PG_E_INVALID, "ngenomes must be >= 1");
+    ResultGeom g;
+    g.lowres_step = lowres_step;
+    g.max_bin_len = max_bin_len;
+    g.min_bin_count = min_bin_count;
+    return result_create(ctx, nullptr, k, (uint32_t)ngenomes, sq, flags | PG_ANCHOR_ROWS_ONLY, g, out);
+}
+
 extern "C" int pg_result_destroy(pg_result *r) {
     if (!r) return PG_OK;
-    hipSetDevice(r->tbl->ctx->device);
-    hipStreamSynchronize(r->tbl->ctx->stream);
-    hipStreamSynchronize(r->tbl->ctx->aux_stream);
+    hipSetDevice(r->ctx->device);
+    hipStreamSynchronize(r->ctx->stream);
+    hipStreamSynchronize(r->ctx->aux_stream);
     hipFree(r->d_ad);
     hipFree(r->d_tile_contig);
-    row_free(r->tbl->ctx, r->d_out1, r->out1_cap);
+    row_free(r->ctx, r->d_out1, r->out1_cap);
     hipFree(r->d_out100);
     hipFree(r->d_bins);
     hipFree(r->d_colsums);
     if (r->d_sched) hipFree(r->d_sched);
-    for (auto &e : r->ev)
-        if (e) hipEventDestroy(e);
+    for (auto *v : {&r->ev_hist, &r->ev_free})
+        for (auto &s : *v)
+            for (auto &e : s.e)
+                if (e) hipEventDestroy(e);
     pg_table *t = r->tbl;
+    pg_ctx *c = r->ctx;
     pg_seqset *sq = const_cast<pg_seqset *>(r->seqs);
     delete r;
-    table_release(t);
+    if (t) table_release(t);
+    else ctx_release(c);
     seqset_release(sq);
     return PG_OK;
 }
@@ -1282,8 +1382,8 @@ extern "C" int pg_result_destroy(pg_result *r) {
 // ---------------------------------------------------------------------------
 extern "C" int pg_result_coschedule(pg_result *r, const uint32_t *contig_group, uint32_t piece_tiles) {
     if (!r) return fail(PG_E_INVALID, "result is NULL");
-    if (int e = use_device(r->tbl->ctx)) return e;
-    hipStream_t st = r->tbl->ctx->stream;
+    if (int e = use_device(r->ctx)) return e;
+    hipStream_t st = r->ctx->stream;
     HIP_TRY(hipStreamSynchronize(st));
     if (r->d_sched) {
         hipFree(r->d_sched);
@@ -1323,37 +1423,94 @@ extern "C" int pg_result_coschedule(pg_result *r, const uint32_t *contig_group, 
 }
 
 static int enqueue_epilogue(pg_result *r, hipStream_t st) {
-    pg_table *t = r->tbl;
-    const uint32_t N = t->ngenomes;
+    const uint32_t N = r->N;
     HIP_TRY(hipMemsetAsync(r->d_bins, 0, std::max<uint64_t>(1, r->total_bins) * (N + 1) * 4, st));
     HIP_TRY(hipMemsetAsync(r->d_colsums, 0, std::max<size_t>(1, r->ad.size()) * N * 8, st));
+    // the statistics kernels fuse the 1-in-100 rows; any other step is a small gather of its own
+    const uint32_t kflags = (r->flags & PG_ANCHOR_COLSUMS) | (r->lowres_step == 100 ? 0u : 2u);
     HIP_TRY(launch_rows_epilogue(st, N, r->d_ad, r->d_tile_contig, r->ntiles, r->d_out1, r->d_out100, r->d_bins,
-                                 r->d_colsums, r->flags));
+                                 r->d_colsums, kflags));
+    if (r->lowres_step != 100)
+        HIP_TRY(launch_lowres(st, N, r->d_ad, r->d_tile_contig, r->ntiles, r->d_out1, r->d_out100, r->lowres_step));
     return PG_OK;
 }
 
 // make the context's main stream wait for the result's statistics (side stream)
 static int join_result(pg_result *r) {
-    if (r->ev_epi) HIP_TRY(hipStreamWaitEvent(r->tbl->ctx->stream, r->ev[3], 0));
+    if (r->ev_epi) HIP_TRY(hipStreamWaitEvent(r->ctx->stream, r->ev[3], 0));
     return PG_OK;
 }
 
-extern "C" int pg_anchor_run(pg_result *r) {
-    if (!r) return fail(PG_E_INVALID, "result is NULL");
+// durations of a finished event set into the running sums
+static int fold_timing(pg_result *r, const pg_result::EvSet &s) {
+    HIP_TRY(hipEventSynchronize(s.e[s.epi ? 3 : 1]));
+    float a = 0, b = 0;
+    if (s.probe) {
+        HIP_TRY(hipEventElapsedTime(&a, s.e[0], s.e[1]));
+        r->probe_ms_sum += a;
+        ++r->probe_runs;
+    }
+    if (s.epi) {
+        HIP_TRY(hipEventElapsedTime(&b, s.e[2], s.e[3]));
+        r->epi_ms_sum += b;
+        ++r->epi_runs;
+    }
+    return PG_OK;
+}
+
+// a fresh event set for the work about to be enqueued; r->ev[] point at it
+static int next_events(pg_result *r, bool probe) {
+    if (r->ev_hist.size() >= EV_RING) {  // the oldest run finished long ago: fold it, reuse its events
+        if (r->hist_skip) --r->hist_skip;
+        else if (int e = fold_timing(r, r->ev_hist.front())) return e;
+        r->ev_free.push_back(r->ev_hist.front());
+        r->ev_hist.erase(r->ev_hist.begin());
+    }
+    pg_result::EvSet s;
+    if (!r->ev_free.empty()) {
+        s = r->ev_free.back();
+        r->ev_free.pop_back();
+    } else {
+        for (auto &e : s.e) {
+            e = nullptr;
+            HIP_TRY(hipEventCreate(&e));
+        }
+    }
+    s.probe = probe;
+    s.epi = false;
+    r->ev_hist.push_back(s);
+    for (int i = 0; i < 4; ++i) r->ev[i] = s.e[i];
+    return PG_OK;
+}
+
+// tiles of contigs [first, first + n)
+static int contig_tiles(const pg_result *r, uint32_t first, uint32_t n, uint32_t *t0, uint32_t *nt) {
+    if ((uint64_t)first + n > r->ad.size()) return fail(PG_E_INVALID, "contigs %u..%u out of range (the result has %zu)", first, first + n, r->ad.size());
+    if (n == 0) {
+        *t0 = *nt = 0;
+        return PG_OK;
+    }
+    const AnchorDesc &a = r->ad[first], &z = r->ad[first + n - 1];
+    *t0 = a.tile0;
+    *nt = z.tile0 + (uint32_t)(((uint64_t)z.nkmers + PROBE_TILE - 1) / PROBE_TILE) - a.tile0;
+    return PG_OK;
+}
+
+static int anchor_run(pg_result *r, uint32_t tile_base, uint32_t ntiles, bool whole) {
     pg_table *t = r->tbl;
-    if (int e = use_device(t->ctx)) return e;
-    hipStream_t st = t->ctx->stream, aux = t->ctx->aux_stream;
-    if (!r->ev[0])
-        for (auto &e : r->ev) HIP_TRY(hipEventCreate(&e));
+    if (!t) return fail(PG_E_INVALID, "this result is a rows container (pg_result_create_rows): it has no table to probe");
+    if (int e = use_device(r->ctx)) return e;
+    hipStream_t st = r->ctx->stream, aux = r->ctx->aux_stream;
     if (int e = join_result(r)) return e;  // a previous run's statistics still read the rows we overwrite
+    if (int e = next_events(r, true)) return e;
     TableDesc T = make_desc(t);
     HIP_TRY(hipEventRecord(r->ev[0], st));
     HIP_TRY(launch_anchor(st, T, r->seqs->d_seqw, r->seqs->d_nmw, r->seqs->d_has_n, r->seqs->d_desc, r->d_ad,
-                          r->d_tile_contig, r->d_sched, r->ntiles, r->d_out1, r->out1_bytes));
+                          r->d_tile_contig, whole ? r->d_sched : nullptr, tile_base, ntiles, r->d_out1, r->out1_bytes));
     HIP_TRY(hipEventRecord(r->ev[1], st));
     r->ev_ok = true;
     r->ev_epi = false;
-    if (!(r->flags & PG_ANCHOR_ROWS_ONLY)) {
+    if (whole && !(r->flags & PG_ANCHOR_ROWS_ONLY)) {
         // the streaming statistics pass runs on the side stream, ordered behind the probe kernels by
         // an event, so that it overlaps the next result's probe kernels
         HIP_TRY(hipStreamWaitEvent(aux, r->ev[1], 0));
@@ -1361,14 +1518,28 @@ extern "C" int pg_anchor_run(pg_result *r) {
         if (int e = enqueue_epilogue(r, aux)) return e;
         HIP_TRY(hipEventRecord(r->ev[3], aux));
         r->ev_epi = true;
+        r->ev_hist.back().epi = true;
     }
     return PG_OK;
+}
+
+extern "C" int pg_anchor_run(pg_result *r) {
+    if (!r) return fail(PG_E_INVALID, "result is NULL");
+    return anchor_run(r, 0, r->ntiles, true);
+}
+
+extern "C" int pg_anchor_run_range(pg_result *r, uint32_t first_contig, uint32_t ncontigs) {
+    if (!r) return fail(PG_E_INVALID, "result is NULL");
+    if (!(r->flags & PG_ANCHOR_ROWS_ONLY)) return fail(PG_E_INVALID, "pg_anchor_run_range needs a PG_ANCHOR_ROWS_ONLY result");
+    uint32_t t0, nt;
+    if (int e = contig_tiles(r, first_contig, ncontigs, &t0, &nt)) return e;
+    return anchor_run(r, t0, nt, false);
 }
 
 extern "C" int pg_result_timing(pg_result *r, float *probe_ms, float *epilogue_ms) {
     if (!r) return fail(PG_E_INVALID, "result is NULL");
     if (!r->ev_ok) return fail(PG_E_INVALID, "pg_anchor_run has not been called on this result");
-    if (int e = use_device(r->tbl->ctx)) return e;
+    if (int e = use_device(r->ctx)) return e;
     HIP_TRY(hipEventSynchronize(r->ev[r->ev_epi ? 3 : 1]));
     float a = 0, b = 0;
     HIP_TRY(hipEventElapsedTime(&a, r->ev[0], r->ev[1]));
@@ -1378,6 +1549,39 @@ extern "C" int pg_result_timing(pg_result *r, float *probe_ms, float *epilogue_m
     return PG_OK;
 }
 
+extern "C" int pg_result_timing_reset(pg_result *r) {
+    if (!r) return fail(PG_E_INVALID, "result is NULL");
+    // the latest set stays alive (r->ev[] and the writers' stream waits refer to it) but no longer counts
+    while (r->ev_hist.size() > 1) {
+        r->ev_free.push_back(r->ev_hist.front());
+        r->ev_hist.erase(r->ev_hist.begin());
+    }
+    r->hist_skip = r->ev_hist.size();
+    r->probe_ms_sum = r->epi_ms_sum = 0;
+    r->probe_runs = r->epi_runs = 0;
+    return PG_OK;
+}
+
+extern "C" int pg_result_timing_mean(pg_result *r, double *probe_ms, double *epilogue_ms, uint32_t *nruns) {
+    if (!r) return fail(PG_E_INVALID, "result is NULL");
+    if (int e = use_device(r->ctx)) return e;
+    // sums of the sets that left the ring + the sets still in it (waits for the last of them)
+    const double a0 = r->probe_ms_sum, b0 = r->epi_ms_sum;
+    const uint32_t pn0 = r->probe_runs, en0 = r->epi_runs;
+    int rc = PG_OK;
+    for (size_t i = r->hist_skip; i < r->ev_hist.size() && !rc; ++i) rc = fold_timing(r, r->ev_hist[i]);
+    if (!rc) {
+        if (probe_ms) *probe_ms = r->probe_runs ? r->probe_ms_sum / r->probe_runs : 0.0;
+        if (epilogue_ms) *epilogue_ms = r->epi_runs ? r->epi_ms_sum / r->epi_runs : 0.0;
+        if (nruns) *nruns = r->probe_runs;
+    }
+    r->probe_ms_sum = a0;  // (the ring's sets are folded for good only when they leave it)
+    r->epi_ms_sum = b0;
+    r->probe_runs = pn0;
+    r->epi_runs = en0;
+    return rc;
+}
+
 // ---------------------------------------------------------------------------
 // genome-sharded exchange: compact bit columns out of / back into the rows
 // ---------------------------------------------------------------------------
@@ -1385,30 +1589,63 @@ extern "C" uint64_t pg_result_columns_bytes(const pg_result *r, uint32_t width) 
     return r ? (uint64_t)r->ntiles * 64ull * width : 0;
 }
 
-extern "C" int pg_result_extract_columns(pg_result *r, uint32_t g0, uint32_t width, void *d_dst) {
+extern "C" uint64_t pg_result_columns_bytes_range(const pg_result *r, uint32_t width, uint32_t first_contig, uint32_t ncontigs) {
+    uint32_t t0, nt;
+    if (!r || contig_tiles(r, first_contig, ncontigs, &t0, &nt)) return 0;
+    return (uint64_t)nt * 64ull * width;
+}
+
+extern "C" int pg_result_extract_columns_range(pg_result *r, uint32_t g0, uint32_t width, uint32_t first_contig,
+                                               uint32_t ncontigs, void *d_dst) {
     if (!r || !d_dst) return fail(PG_E_INVALID, "pg_result_extract_columns: NULL argument");
-    if (!r->ev_ok) return fail(PG_E_INVALID, "pg_anchor_run has not been called on this result");
-    if (int e = use_device(r->tbl->ctx)) return e;
-    HIP_TRY(launch_cols_extract(r->tbl->ctx->stream, r->tbl->ngenomes, r->d_ad, r->d_tile_contig, r->ntiles, r->d_out1, g0,
-                                width, d_dst));
+    if (!r->ev_ok && !r->rows_valid) return fail(PG_E_INVALID, "the result holds no rows yet");
+    uint32_t t0, nt;
+    if (int e = contig_tiles(r, first_contig, ncontigs, &t0, &nt)) return e;
+    if (int e = use_device(r->ctx)) return e;
+    HIP_TRY(launch_cols_extract(r->ctx->stream, r->N, r->d_ad, r->d_tile_contig, t0, nt, r->d_out1, g0, width, d_dst));
+    return PG_OK;
+}
+
+extern "C" int pg_result_extract_columns(pg_result *r, uint32_t g0, uint32_t width, void *d_dst) {
+    if (!r) return fail(PG_E_INVALID, "pg_result_extract_columns: NULL argument");
+    return pg_result_extract_columns_range(r, g0, width, 0, (uint32_t)r->ad.size(), d_dst);
+}
+
+extern "C" int pg_result_merge_columns_range(pg_result *r, const void *d_src, uint32_t part0, uint32_t nparts, uint32_t per,
+                                             uint32_t first_contig, uint32_t ncontigs, int accumulate) {
+    if (!r || !d_src) return fail(PG_E_INVALID, "pg_result_merge_columns: NULL argument");
+    if (per == 0 || nparts == 0) return fail(PG_E_INVALID, "pg_result_merge_columns: empty partition");
+    uint32_t t0, nt;
+    if (int e = contig_tiles(r, first_contig, ncontigs, &t0, &nt)) return e;
+    if (int e = use_device(r->ctx)) return e;
+    if (int e = join_result(r)) return e;
+    HIP_TRY(launch_cols_merge(r->ctx->stream, r->N, r->d_ad, r->d_tile_contig, t0, nt, r->d_out1, d_src, part0, nparts,
+                              (uint64_t)nt * 8ull * per, per, accumulate ? 1u : 0u));
+    r->rows_valid = true;
     return PG_OK;
 }
 
 extern "C" int pg_result_merge_columns(pg_result *r, const void *d_src, uint32_t nparts, uint32_t per) {
-    if (!r || !d_src) return fail(PG_E_INVALID, "pg_result_merge_columns: NULL argument");
-    if (per == 0 || nparts == 0) return fail(PG_E_INVALID, "pg_result_merge_columns: empty partition");
-    if (int e = use_device(r->tbl->ctx)) return e;
-    HIP_TRY(launch_cols_merge(r->tbl->ctx->stream, r->tbl->ngenomes, r->d_ad, r->d_tile_contig, r->ntiles, r->d_out1, d_src,
-                              nparts, (uint64_t)r->ntiles * 8ull * per, per));
-    return PG_OK;
+    if (!r) return fail(PG_E_INVALID, "pg_result_merge_columns: NULL argument");
+    return pg_result_merge_columns_range(r, d_src, 0, nparts, per, 0, (uint32_t)r->ad.size(), 0);
 }
 
 extern "C" int pg_rows_epilogue(pg_result *r) {
     if (!r) return fail(PG_E_INVALID, "result is NULL");
-    if (int e = use_device(r->tbl->ctx)) return e;
+    if (int e = use_device(r->ctx)) return e;
     if (int e = join_result(r)) return e;
-    r->ev_epi = false;
-    return enqueue_epilogue(r, r->tbl->ctx->stream);  // explicit call (genome-sharded mode): main stream
+    hipStream_t st = r->ctx->stream;
+    // an event set of its own (a rows container never ran a probe): what the readers / writers wait on
+    if (int e = next_events(r, false)) return e;
+    HIP_TRY(hipEventRecord(r->ev[0], st));
+    HIP_TRY(hipEventRecord(r->ev[1], st));
+    HIP_TRY(hipEventRecord(r->ev[2], st));
+    if (int e = enqueue_epilogue(r, st)) return e;  // explicit call (genome-sharded mode): main stream
+    HIP_TRY(hipEventRecord(r->ev[3], st));
+    r->ev_ok = true;
+    r->ev_epi = true;
+    r->ev_hist.back().epi = true;
+    return PG_OK;
 }
 
 // ---------------------------------------------------------------------------
@@ -1452,24 +1689,45 @@ static const uint32_t *crc_tables_host() {
 static constexpr uint32_t DF_BATCH = PG_DF_BATCH;  // BGZF blocks per k_row_deflate launch (64 KiB slot each)
 
 static pg_ctx::DfSet *df_acquire(pg_ctx *ctx) {
+    std::unique_lock<std::mutex> lk(ctx->df_mu);
     for (;;) {
-        {
-            std::lock_guard<std::mutex> lk(ctx->df_mu);
-            for (auto &d : ctx->df)
-                if (!d.busy) {
-                    d.busy = true;
-                    return &d;
-                }
-        }
-        std::this_thread::yield();
+        for (auto &d : ctx->df)
+            if (!d.busy) {
+                d.busy = true;
+                return &d;
+            }
+        ctx->df_cv.wait(lk);  // more writer threads than staging sets: wait for one to be released
     }
+}
+static void df_release(pg_ctx *ctx, pg_ctx::DfSet *D) {
+    {
+        std::lock_guard<std::mutex> lk(ctx->df_mu);
+        D->busy = false;
+    }
+    ctx->df_cv.notify_one();
+}
+// device + pinned buffers of a staging set (all or nothing: a partial set is given back at once)
+static void df_free_buffers(pg_ctx::DfSet &d) {
+    for (int i = 0; i < 2; ++i) {
+        if (d.d_slots[i]) hipFree(d.d_slots[i]);
+        if (d.d_packed[i]) hipFree(d.d_packed[i]);
+        if (d.d_sizes[i]) hipFree(d.d_sizes[i]);
+        if (d.d_offs[i]) hipFree(d.d_offs[i]);
+        if (d.h_slots[i]) hipHostFree(d.h_slots[i]);
+        if (d.h_sizes[i]) hipHostFree(d.h_sizes[i]);
+        d.d_slots[i] = d.d_packed[i] = d.h_slots[i] = nullptr;
+        d.d_sizes[i] = d.d_offs[i] = d.h_sizes[i] = nullptr;
+    }
+    if (d.d_crc) hipFree(d.d_crc);
+    d.d_crc = nullptr;
+    d.ready = false;
 }
 
 static int write_bgzf_gpu(pg_result *r, const uint8_t *src, const std::vector<std::pair<uint64_t, uint64_t>> &segs_in,
                           uint64_t total, uint32_t row, const char *gz_path, const char *gzi_path) {
     static const unsigned char EOF_BLOCK[28] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0x00, 0x42, 0x43,
                                                 0x02, 0x00, 0x1b, 0x00, 0x03, 0x00, 0, 0, 0, 0, 0, 0, 0, 0};
-    pg_ctx *ctx = r->tbl->ctx;
+    pg_ctx *ctx = r->ctx;
     const uint64_t nblocks = (total + 65279) / 65280;
     std::vector<PaySeg> segs;
     uint64_t l = 0;
@@ -1504,6 +1762,7 @@ static int write_bgzf_gpu(pg_result *r, const uint8_t *src, const std::vector<st
             ok(hipStreamSynchronize(cs));
         }
         D->ready = e == hipSuccess;
+        if (!D->ready) df_free_buffers(*D);  // never keep half a set: the next call would overwrite (leak) its pointers
     }
     ok(hipMalloc(reinterpret_cast<void **>(&d_segs), segs.size() * sizeof(PaySeg)));
     for (int i = 0; i < 2; ++i) {
@@ -1557,10 +1816,7 @@ static int write_bgzf_gpu(pg_result *r, const uint8_t *src, const std::vector<st
     }
     if (e != hipSuccess) rc = fail(PG_E_HIP, "pg_result_write_bgzf (GPU deflate): %s", hipGetErrorString(e));
     if (cs) hipStreamSynchronize(cs);
-    {
-        std::lock_guard<std::mutex> lk(ctx->df_mu);
-        D->busy = false;
-    }
+    df_release(ctx, D);
     const std::string keep = rc ? g_err : std::string();
     if (!rc && fwrite(EOF_BLOCK, 1, sizeof EOF_BLOCK, f) != sizeof EOF_BLOCK) rc = fail(PG_E_IO, "short write of BGZF EOF block");
     if (fclose(f) != 0 && !rc) rc = fail(PG_E_IO, "fclose failed on BGZF file");
@@ -1601,14 +1857,15 @@ extern "C" int pg_result_write_bgzf_range(pg_result *r, int step, uint32_t first
     if (!r || !gz_path) return fail(PG_E_INVALID, "pg_result_write_bgzf: NULL argument");
     if ((uint64_t)first_contig + ncontigs > r->ad.size())
         return fail(PG_E_INVALID, "contigs %u..%u out of range", first_contig, first_contig + ncontigs);
-    if (step != 1 && step != 100) return fail(PG_E_INVALID, "step must be 1 or 100");
+    if (step != 1 && step != 100 && (uint32_t)step != r->lowres_step)
+        return fail(PG_E_INVALID, "step must be 1 or the result's low-resolution step (%u; 100 is accepted as its alias)", r->lowres_step);
     if (!r->ev_ok) return fail(PG_E_INVALID, "pg_anchor_run has not been called on this result");
     if (step == 100 && (r->flags & PG_ANCHOR_ROWS_ONLY) && !r->ev_epi)
         return fail(PG_E_INVALID, "rows-only result: bitmap.100 needs pg_rows_epilogue first");
-    if (int e = use_device(r->tbl->ctx)) return e;
+    if (int e = use_device(r->ctx)) return e;
     // the payload is the contigs' segments back to back (their device buffers are padded apart)
     const uint8_t *src = step == 1 ? r->d_out1 : r->d_out100;
-    const uint32_t nbytes_row = (r->tbl->ngenomes + 7) / 8;
+    const uint32_t nbytes_row = (r->N + 7) / 8;
     std::vector<std::pair<uint64_t, uint64_t>> segs;  // (device offset, length)
     uint64_t total = 0;
     for (size_t i = first_contig; i < (size_t)first_contig + ncontigs; ++i) {
@@ -1689,13 +1946,14 @@ extern "C" int pg_result_window_stats(pg_result *r, uint32_t idx, int step, uint
                                       const uint64_t *ends, uint64_t *hist, uint64_t *colsums) {
     if (!r || (nwin && (!starts || !ends || !hist))) return fail(PG_E_INVALID, "pg_result_window_stats: NULL argument");
     if (idx >= r->ad.size()) return fail(PG_E_INVALID, "contig %u out of range", idx);
-    if (step != 1 && step != 100) return fail(PG_E_INVALID, "step must be 1 or 100");
+    if (step != 1 && step != 100 && (uint32_t)step != r->lowres_step)
+        return fail(PG_E_INVALID, "step must be 1 or the result's low-resolution step (%u; 100 is accepted as its alias)", r->lowres_step);
     if (!r->ev_ok) return fail(PG_E_INVALID, "pg_anchor_run has not been called on this result");
     if (nwin == 0) return PG_OK;
-    if (int e = use_device(r->tbl->ctx)) return e;
+    if (int e = use_device(r->ctx)) return e;
     if (int e = join_result(r)) return e;
-    hipStream_t st = r->tbl->ctx->stream;
-    const uint32_t N = r->tbl->ngenomes;
+    hipStream_t st = r->ctx->stream;
+    const uint32_t N = r->N;
     const AnchorDesc &a = r->ad[idx];
     const uint8_t *rows = step == 1 ? r->d_out1 + a.out_off : r->d_out100 + a.out100_off;
     const uint64_t nrows = step == 1 ? (uint64_t)a.nkmers : r->nrows100[idx];
@@ -1737,11 +1995,11 @@ extern "C" int pg_result_contig_info(const pg_result *r, uint32_t idx, uint64_t 
 extern "C" int pg_result_download(pg_result *r, uint32_t idx, uint8_t *bitmap1, uint8_t *bitmap100, uint32_t *bins) {
     if (!r) return fail(PG_E_INVALID, "result is NULL");
     if (idx >= r->ad.size()) return fail(PG_E_INVALID, "contig %u out of range", idx);
-    if (int e = use_device(r->tbl->ctx)) return e;
+    if (int e = use_device(r->ctx)) return e;
     if (int e = join_result(r)) return e;
-    hipStream_t st = r->tbl->ctx->stream;
+    hipStream_t st = r->ctx->stream;
     const AnchorDesc &a = r->ad[idx];
-    const uint32_t N = r->tbl->ngenomes, nbytes = (N + 7) / 8;
+    const uint32_t N = r->N, nbytes = (N + 7) / 8;
     if (bitmap1 && a.nkmers)
         HIP_TRY(hipMemcpyAsync(bitmap1, r->d_out1 + a.out_off, (uint64_t)a.nkmers * nbytes, hipMemcpyDeviceToHost, st));
     if (bitmap100 && r->nrows100[idx])
@@ -1755,10 +2013,10 @@ extern "C" int pg_result_download(pg_result *r, uint32_t idx, uint8_t *bitmap1, 
 extern "C" int pg_result_colsums(pg_result *r, uint64_t *colsums) {
     if (!r || !colsums) return fail(PG_E_INVALID, "pg_result_colsums: NULL argument");
     if (!(r->flags & PG_ANCHOR_COLSUMS)) return fail(PG_E_INVALID, "result was created without PG_ANCHOR_COLSUMS");
-    if (int e = use_device(r->tbl->ctx)) return e;
+    if (int e = use_device(r->ctx)) return e;
     if (int e = join_result(r)) return e;
-    hipStream_t st = r->tbl->ctx->stream;
-    const size_t N = r->tbl->ngenomes, nc = r->ad.size();
+    hipStream_t st = r->ctx->stream;
+    const size_t N = r->N, nc = r->ad.size();
     std::vector<uint64_t> all(std::max<size_t>(1, nc) * N, 0);  // the device keeps them per contig
     if (nc) {
         HIP_TRY(hipMemcpyAsync(all.data(), r->d_colsums, nc * N * 8, hipMemcpyDeviceToHost, st));
@@ -1775,10 +2033,10 @@ extern "C" int pg_result_contig_colsums(pg_result *r, uint32_t idx, uint32_t nco
     if (!(r->flags & PG_ANCHOR_COLSUMS)) return fail(PG_E_INVALID, "result was created without PG_ANCHOR_COLSUMS");
     if ((uint64_t)idx + ncontigs > r->ad.size()) return fail(PG_E_INVALID, "contigs %u..%u out of range", idx, idx + ncontigs);
     if (ncontigs == 0) return PG_OK;
-    if (int e = use_device(r->tbl->ctx)) return e;
+    if (int e = use_device(r->ctx)) return e;
     if (int e = join_result(r)) return e;
-    hipStream_t st = r->tbl->ctx->stream;
-    const size_t N = r->tbl->ngenomes;
+    hipStream_t st = r->ctx->stream;
+    const size_t N = r->N;
     HIP_TRY(hipMemcpyAsync(colsums, r->d_colsums + (size_t)idx * N, (size_t)ncontigs * N * 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     return PG_OK;

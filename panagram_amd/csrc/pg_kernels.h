@@ -82,12 +82,17 @@ hipError_t launch_counters(hipStream_t st, const SubTable &t, int w, int k, cons
                            const uint32_t *nmw, const uint32_t *has_n, uint64_t nkmers, uint32_t *out);
 hipError_t launch_anchor(hipStream_t st, const TableDesc &T, const uint64_t *seqw, const uint32_t *nmw,
                          const uint32_t *has_n, const SeqDesc *sd, const AnchorDesc *ad,
-                         const uint32_t *tile_contig, const uint32_t *sched, uint32_t ntiles, uint8_t *out1, uint64_t out1_bytes);
+                         const uint32_t *tile_contig, const uint32_t *sched, uint32_t tile_base, uint32_t ntiles, uint8_t *out1,
+                         uint64_t out1_bytes);
+// genome-sharded exchange over the tiles [tile_base, tile_base + ntiles) of a result (a contig range)
 hipError_t launch_cols_extract(hipStream_t st, uint32_t ngenomes, const AnchorDesc *ad, const uint32_t *tile_contig,
-                               uint32_t ntiles, const uint8_t *out1, uint32_t g0, uint32_t width, void *dst);
+                               uint32_t tile_base, uint32_t ntiles, const uint8_t *out1, uint32_t g0, uint32_t width, void *dst);
 hipError_t launch_cols_merge(hipStream_t st, uint32_t ngenomes, const AnchorDesc *ad, const uint32_t *tile_contig,
-                             uint32_t ntiles, uint8_t *out1, const void *src, uint32_t nparts, uint64_t part_words,
-                             uint32_t per);
+                             uint32_t tile_base, uint32_t ntiles, uint8_t *out1, const void *src, uint32_t part0,
+                             uint32_t nparts, uint64_t part_words, uint32_t per, uint32_t accumulate);
+// every step-th row of bitmap.1 -> low-resolution bitmap (steps other than 100)
+hipError_t launch_lowres(hipStream_t st, uint32_t ngenomes, const AnchorDesc *ad, const uint32_t *tile_contig,
+                         uint32_t ntiles, const uint8_t *out1, uint8_t *outlow, uint32_t step);
 // GPU-side BGZF compression of a payload (pg_deflate.hip): the payload is the concatenation of
 // segments of device memory; segs[nseg] is a sentinel with lstart = total
 struct PaySeg {

@@ -7,13 +7,19 @@
    that owns a genome assembles that genome's files in FASTA order.  No data-path
    collective — one barrier between the two phases.  Outputs do not depend on the GPU count.
 
-2. **Genome-sharded** (config 5: the union of k-mer tables exceeds one GPU's 288 GB): rank r
-   holds the table of ITS genomes only (full-width rows, the other genomes' bits zero);
-   every rank anchors every position; the partial rows are combined over xGMI and the
-   row statistics are taken from the combined rows (``pg_rows_epilogue``).  Because ranks own
-   disjoint bits, a uint8 SUM all-reduce equals the bitwise OR (no carries) — RCCL has no
-   bitwise reductions — and moves 2(n-1)/n bytes per row byte, less than all-gathering n
-   partial copies.  ``all_gather`` + local OR is kept as the reference formulation.
+2. **Genome-sharded** (config 5: the union of k-mer tables exceeds one GPU's 288 GB;
+   ``run_genome_sharded``, reached from ``Index.run()``): the genomes are cut into contiguous
+   blocks; a GPU holds the table of ONE block at a time (narrow: only that block's genomes) and
+   probes every anchor position against it, chunk of contigs by chunk of contigs.  Per chunk the
+   block's COMPACT BIT COLUMNS (one u64 per genome per 64 positions, ``k_cols_extract``) are
+   all-gathered over RCCL/xGMI on a side stream while the next chunk is probed; the rank that
+   writes the anchor merges the gathered blocks into full rows (``k_cols_merge``), takes the
+   statistics from them (``pg_rows_epilogue``) and streams them into the BGZF files.  Per position
+   a rank receives (n-1)/n row bytes.  More blocks than GPUs run as passes (one GPU: all of them),
+   the blocks' bits OR-ed into the writers' rows pass by pass.
+   (``combine_rows_``: a uint8 SUM all-reduce of full-width partial rows — ranks own disjoint bits,
+   so SUM == OR; RCCL has no bitwise reductions — moves 2(n-1)/n bytes per row byte; kept as the
+   reference formulation the column exchange is tested against.)
 """
 from __future__ import annotations
 
@@ -195,3 +201,214 @@ def anchor_genome_sharded(table, seqs: Sequence[bytes], group=None, rank: Option
     res.close()
     ss.close()
     return out, cs
+
+
+# ---------------------------------------------------------------------------
+# genome-sharded index build: the product path for pangenomes whose table exceeds one GPU
+# ---------------------------------------------------------------------------
+CHUNK_POSITIONS = int(os.environ.get("PG_SHARD_CHUNK", str(1 << 27)))  # positions per exchanged chunk (about)
+
+
+class _Pipe:
+    """Stream plumbing of the chunk pipeline.  On a GPU: the library's kernels run on ``main`` (the context is
+    pointed at it), the collectives on ``comm``; events order them, the host never waits inside the loop.  On
+    CPU tensors (the gloo tests) everything is synchronous and these are no-ops."""
+
+    def __init__(self, ctx, dev):
+        import torch
+        self.gpu = dev.type == "cuda"
+        self.ctx = ctx
+        if self.gpu:
+            self.torch = torch
+            self.main = torch.cuda.Stream(dev)
+            self.comm = torch.cuda.Stream(dev)
+            ctx.set_stream(self.main.cuda_stream)
+
+    def mark_main(self):
+        if not self.gpu:
+            return None
+        ev = self.torch.cuda.Event()
+        ev.record(self.main)
+        return ev
+
+    def zero(self, t):
+        if self.gpu:
+            with self.torch.cuda.stream(self.main):
+                t.zero_()
+        else:
+            t.zero_()
+
+    def main_waits(self, ev):
+        if self.gpu and ev is not None:
+            self.main.wait_event(ev)
+
+    def on_comm(self, after, fn):
+        """run ``fn`` (a collective) on the side stream once ``after`` has happened; returns its completion event"""
+        if not self.gpu:
+            fn()
+            return None
+        with self.torch.cuda.stream(self.comm):
+            self.comm.wait_event(after)
+            fn()
+            ev = self.torch.cuda.Event()
+            ev.record(self.comm)
+        return ev
+
+    def close(self):
+        if self.gpu:
+            self.ctx.synchronize()
+            self.torch.cuda.synchronize()
+            self.ctx.set_stream(None)
+
+
+def contig_chunks(lens: Sequence[int], k: int, limit: int = CHUNK_POSITIONS) -> List[Tuple[int, int]]:
+    """Contiguous contig ranges ``(first, count)`` of about ``limit`` k-mer positions each (a contig is never cut)."""
+    out, first, acc = [], 0, 0
+    for ci, ln in enumerate(lens):
+        nk = max(0, int(ln) - k + 1)
+        if ci > first and acc + nk > limit:
+            out.append((first, ci - first))
+            first, acc = ci, 0
+        acc += nk
+    if len(lens) > first:
+        out.append((first, len(lens) - first))
+    return out
+
+
+def run_genome_sharded(index, nblocks: int, group=None, exchange_stats: Optional[dict] = None) -> None:
+    """Every rank calls this (``Index.run()`` does, when ``plan_sharding`` says so).
+
+    Genome block b = genomes [b*per, (b+1)*per), per = ceil(N / nblocks).  Pass p: rank r builds the table of block
+    p*world + r — a table of that block's genomes only — and probes EVERY anchor genome against it, chunk by chunk:
+
+        probe chunk c (rows of the block's genomes)  ->  extract its bit columns  ->  all-gather (side stream)
+                                                           probe chunk c+1 ...    ->  merge on the anchor's writer
+
+    The anchor genomes are dealt to the ranks as in the replicated mode (``Index.writer_of_anchor``); a writer keeps
+    the full rows of its anchors (``AnchorResult.rows_container``) across the passes and finishes each — statistics,
+    BGZF files, tables — as soon as its last chunk of the last pass has been merged.  The files are the ones a
+    single table of all genomes gives (``tests/test_gpu_genome_shard.py``, ``tests/test_distributed_cpu.py``)."""
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
+    from . import index as pidx
+    engine = pidx.engine
+    rank, world = index.rank, max(1, index.world)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            raise RuntimeError("genome-sharded mode on several ranks needs torch.distributed initialised "
+                               "(python -m torch.distributed.run ... -m panagram_amd index ...)")
+    N, k = index.ngenomes, index.k
+    per = (N + nblocks - 1) // nblocks
+    nblocks = (N + per - 1) // per
+    passes = (nblocks + world - 1) // world
+    ctx = index.context
+    dev = ctx.torch_device()
+    inputs = {i[1].id: i for i in index.load_inputs()}
+    anchors = list(index.anchor_genomes)
+    writer = index.writer_of_anchor() if world > 1 else {a: 0 for a in anchors}
+    seqs = {a: index.seqset_for(a) for a in anchors}
+    for a in anchors:
+        for nm, ln in zip(seqs[a].names, seqs[a].lens):
+            if int(ln) < k and writer[a] == rank:
+                index.genomes[a].log.warning(f"Contig {nm} is shorter than k={k}: 0 k-mers (the reference underflows here)")
+    # the work list: (anchor, first contig, contig count), the same on every rank
+    work = [(a, c0, nc) for a in anchors for c0, nc in contig_chunks(seqs[a].lens, k)]
+    last_of = {a: max(i for i, w in enumerate(work) if w[0] == a) for a in anchors if any(w[0] == a for w in work)}
+    tile = engine.tile_positions()
+    def cols_bytes(a, c0, nc):  # what AnchorResult.columns_bytes_range answers, without a result
+        return sum(((max(0, int(ln) - k + 1) + tile - 1) // tile) for ln in seqs[a].lens[c0:c0 + nc]) * 64 * per
+    biggest = max([cols_bytes(*w) for w in work] or [0])
+    send = [torch.zeros(max(biggest, 8), dtype=torch.uint8, device=dev) for _ in range(2)]
+    # (one rank: its own block is all there is — merged straight out of the send buffer)
+    recv = [torch.zeros(max(biggest, 8) * world, dtype=torch.uint8, device=dev) for _ in range(2)] if world > 1 else send
+    if dev.type == "cuda":
+        torch.cuda.synchronize(dev)  # the buffers were zeroed on torch's stream; the kernels run on the pipe's
+    pipe = _Pipe(ctx, dev)
+    full: Dict[str, object] = {}
+    payload = sum(int(seqs[a].lens.sum()) for a in anchors if writer[a] == rank) * ((N + 7) // 8)
+    pool = ThreadPoolExecutor(max_workers=index.writer_jobs(payload))
+    jobs = []
+    moved = 0
+    try:
+        for p in range(passes):
+            b = p * world + rank
+            g_lo, g_hi = b * per, min(N, (b + 1) * per)
+            nparts = min(world, nblocks - p * world)
+            tbl = None
+            if b < nblocks:
+                blk = [inputs[g] for g in range(g_lo, g_hi) if g in inputs]
+                tbl = engine.PanTable(ctx, k, g_hi - g_lo, expected_keys=index._expected_keys(blk))
+                for name, g, ss, min_count, _ in blk:
+                    tbl.insert_seqset(g.id - g_lo, ss, min_count=min_count)
+                logger_info(index, "pass %d: table of genomes %d..%d: %s", p, g_lo, g_hi - 1, tbl.stats())
+            part, part_of = None, None
+            pending = None  # (work index, slot, bytes, gather-done event) of the chunk whose gather is in flight
+            def settle(pend):
+                i, slot, nbytes, ev = pend
+                a, c0, nc = work[i]
+                pipe.main_waits(ev)  # also what frees send[slot] for the next extract into it
+                if writer[a] == rank:
+                    if a not in full:
+                        full[a] = engine.AnchorResult.rows_container(ctx, k, N, seqs[a], colsums=True, **index.result_geometry)
+                    # recv holds `world` blocks of nbytes each, block j from rank j = genome block p*world + j
+                    full[a].merge_columns_range(recv[slot].data_ptr(), p * world, nparts, per, c0, nc,
+                                                accumulate=passes > 1)
+                    if p == passes - 1 and last_of.get(a) == i:
+                        jobs.append(_finish_anchor(index, a, full[a], pool))
+            for i, (a, c0, nc) in enumerate(work):
+                slot = i & 1
+                nbytes = cols_bytes(a, c0, nc)
+                if tbl is not None:
+                    if part_of != a:
+                        if part is not None:
+                            part.close()
+                        part, part_of = engine.AnchorResult(tbl, seqs[a], colsums=False, rows_only=True), a
+                    part.run_range(c0, nc)
+                    part.extract_columns_range(0, per, c0, nc, send[slot].data_ptr())
+                else:
+                    pipe.zero(send[slot][:nbytes])  # a rank without a block in this pass contributes zeros
+                ready = pipe.mark_main()
+                if world > 1:
+                    out_t, in_t = recv[slot][:nbytes * world], send[slot][:nbytes]
+                    ev = pipe.on_comm(ready, lambda o=out_t, t=in_t: dist.all_gather_into_tensor(o, t, group=group))
+                    moved += nbytes * (world - 1)
+                else:
+                    ev = ready
+                if pending is not None:
+                    settle(pending)
+                pending = (i, slot, nbytes, ev)
+            if pending is not None:
+                settle(pending)
+            if part is not None:
+                part.close()
+            if tbl is not None:
+                ctx.synchronize()
+                tbl.close()
+        for j in jobs:
+            j()
+    finally:
+        pool.shutdown(wait=True)
+        for r in full.values():
+            r.close()
+        pipe.close()
+    if exchange_stats is not None:
+        exchange_stats.update(bytes_received=moved, passes=passes, nblocks=nblocks, per=per, chunks=len(work))
+    if dist is not None:
+        dist.barrier(group=group)
+
+
+def logger_info(index, fmt, *args):
+    import logging
+    logging.getLogger("panagram_amd.index").info(fmt, *args)
+
+
+def _finish_anchor(index, name: str, res, pool):
+    """statistics from the completed rows, then the genome's files on a writer thread; returns the join"""
+    g = index.genomes[name]
+    g.log.info("Anchoring Started")
+    res.rows_epilogue()
+    job = dict(res=res, merged=None, genomes=[g.tabulate(res, 0, len(res.seqs.names), list(res.seqs.names))])
+    fut = pool.submit(g.write_from_result, job, 0)
+    return fut.result

@@ -30,6 +30,11 @@ def usable_cpus() -> int:
     return max(1, n)
 
 
+def tile_positions() -> int:
+    """k-mer positions per tile (launch unit; a bit-column block holds 64 bytes per tile and genome)"""
+    return int(_lib.load().pg_tile_positions())
+
+
 class _Owner:
     """Handles are destroyed children first (the C-ABI's rule): a parent remembers its live
     children weakly and closes them before itself, so that garbage collection — which finalises
@@ -92,6 +97,11 @@ class Context(_Owner):
     def trim(self) -> None:
         """give back device memory kept for reuse (row buffers of closed results)"""
         check(self._lib.pg_ctx_trim(self._h))
+
+    def torch_device(self):
+        """the torch device the context's buffers live on (torch only carries the collectives' buffers)"""
+        import torch
+        return torch.device("cuda", self.device)
 
     def close(self) -> None:
         if self._h:
@@ -225,6 +235,20 @@ class KmerSketch:
         check(self._lib.pg_sketch_registers(self._h, _ptr(out)))
         return out
 
+    def reset(self) -> None:
+        check(self._lib.pg_sketch_reset(self._h))
+
+    @staticmethod
+    def estimate_registers(regs: np.ndarray) -> int:
+        """estimate for register values held on the host — e.g. the register-wise maximum of several sketches
+        (= the sketch of the union of their inputs)"""
+        regs = np.ascontiguousarray(regs, np.uint8)
+        if regs.size != 65536:
+            raise ValueError("a sketch has 65536 registers")
+        n = C.c_uint64()
+        check(_lib.load().pg_sketch_estimate_registers(_ptr(regs), C.byref(n)))
+        return int(n.value)
+
     def close(self) -> None:
         if self._h:
             self._lib.pg_sketch_destroy(self._h)
@@ -251,6 +275,13 @@ class PanTable(_Owner):
         self._h = h
         ctx._adopt(self)
 
+    @staticmethod
+    def bytes_for(k: int, ngenomes: int, expected_keys: int) -> int:
+        """device bytes a table created for that many keys takes"""
+        b = C.c_uint64()
+        check(_lib.load().pg_table_bytes_for(k, ngenomes, expected_keys, C.byref(b)))
+        return int(b.value)
+
     def insert_seqset(self, genome_idx: int, seqs: SeqSet, min_count: int = 1) -> None:
         """OR genome ``genome_idx``'s bit into every canonical k-mer of ``seqs`` that occurs at least
         ``min_count`` times in it (kmc -ci<min_count>; 2 for read sets)"""
@@ -268,6 +299,13 @@ class PanTable(_Owner):
 
     def load_kmc1(self, db_idx: int, pre: bytes, suf: bytes) -> None:
         check(self._lib.pg_table_load_kmc1(self._h, db_idx, pre, len(pre), suf, len(suf)))
+
+    def load_kmc_files(self, db_idx: int, prefix: str) -> None:
+        """``prefix.kmc_pre`` / ``prefix.kmc_suf`` as 32-genome group ``db_idx`` (CKMCFile::OpenForRA,
+        cpp/anchor.cpp:29): the files are mapped, not read into Python"""
+        pre = np.memmap(prefix + ".kmc_pre", dtype=np.uint8, mode="r")
+        suf = np.memmap(prefix + ".kmc_suf", dtype=np.uint8, mode="r")
+        check(self._lib.pg_table_load_kmc1(self._h, db_idx, _ptr(pre), pre.size, _ptr(suf), suf.size))
 
     def stats(self) -> dict:
         v = [C.c_uint64() for _ in range(4)]
@@ -344,15 +382,37 @@ class PanTable(_Owner):
 class AnchorResult:
     """Device-resident outputs of anchoring one SeqSet against one PanTable."""
 
-    def __init__(self, table: PanTable, seqs: SeqSet, colsums: bool = True, rows_only: bool = False):
-        self.table, self.seqs = table, seqs
+    def __init__(self, table: PanTable, seqs: SeqSet, colsums: bool = True, rows_only: bool = False,
+                 lowres_step: int = 100, max_bin_len: int = 200000, min_bin_count: int = 100):
+        """``lowres_step`` / ``max_bin_len`` / ``min_bin_count``: the Python path's parameters
+        (index.py:101-106, 1169-1172); the defaults are what cpp/anchor.cpp hard-codes."""
+        self.table, self.seqs, self.ctx = table, seqs, table.ctx
+        self.ngenomes, self.nbytes, self.lowres_step = table.ngenomes, table.nbytes, lowres_step
         self._lib = table._lib
         h = C.c_void_p()
         self.flags = (PG_ANCHOR_COLSUMS if colsums else 0) | (PG_ANCHOR_ROWS_ONLY if rows_only else 0)
-        check(self._lib.pg_result_create(table._h, seqs._h, self.flags, C.byref(h)))
+        check(self._lib.pg_result_create_ex(table._h, seqs._h, self.flags, lowres_step, max_bin_len, min_bin_count,
+                                            C.byref(h)))
         self._h = h
         table._adopt(self)   # a result dies before its table and before its sequences
         seqs._adopt(self)
+
+    @classmethod
+    def rows_container(cls, ctx: Context, k: int, ngenomes: int, seqs: SeqSet, colsums: bool = True,
+                       lowres_step: int = 100, max_bin_len: int = 200000, min_bin_count: int = 100) -> "AnchorResult":
+        """A result without a table: ``ngenomes``-wide rows over ``seqs`` (zeroed), filled by
+        ``merge_columns_range`` and finished by ``rows_epilogue`` — the writer's side of the genome-sharded mode."""
+        r = cls.__new__(cls)
+        r.table, r.seqs, r.ctx = None, seqs, ctx
+        r.ngenomes, r.nbytes, r.lowres_step = ngenomes, (ngenomes + 7) // 8, lowres_step
+        r._lib = ctx._lib
+        r.flags = (PG_ANCHOR_COLSUMS if colsums else 0) | PG_ANCHOR_ROWS_ONLY
+        h = C.c_void_p()
+        check(r._lib.pg_result_create_rows(ctx._h, k, ngenomes, seqs._h, r.flags, lowres_step, max_bin_len,
+                                           min_bin_count, C.byref(h)))
+        r._h = h
+        seqs._adopt(r)
+        return r
 
     def coschedule(self, contig_group, piece_tiles: int = 0) -> None:
         """Interleave the tiles of several anchor genomes (``contig_group[c]`` = genome of contig c;
@@ -367,7 +427,7 @@ class AnchorResult:
 
     def contig_colsums(self, idx: int = 0, ncontigs: Optional[int] = None) -> np.ndarray:
         n = len(self.seqs.lens) - idx if ncontigs is None else ncontigs
-        out = np.zeros((n, self.table.ngenomes), np.uint64)
+        out = np.zeros((n, self.ngenomes), np.uint64)
         check(self._lib.pg_result_contig_colsums(self._h, idx, n, _ptr(out)))
         return out
 
@@ -375,11 +435,24 @@ class AnchorResult:
         """Enqueue the anchor kernels (asynchronous)."""
         check(self._lib.pg_anchor_run(self._h))
 
+    def run_range(self, first_contig: int, ncontigs: int) -> None:
+        """rows-only results: probe a contig range only (asynchronous)"""
+        check(self._lib.pg_anchor_run_range(self._h, first_contig, ncontigs))
+
     def timing(self):
         """(probe_ms, epilogue_ms) of the last run(), from HIP events on the context's stream."""
         a, b = C.c_float(), C.c_float()
         check(self._lib.pg_result_timing(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def timing_reset(self) -> None:
+        check(self._lib.pg_result_timing_reset(self._h))
+
+    def timing_mean(self):
+        """(mean probe_ms, mean epilogue_ms, runs) over every run() since ``timing_reset()``"""
+        a, b, n = C.c_double(), C.c_double(), C.c_uint32()
+        check(self._lib.pg_result_timing_mean(self._h, C.byref(a), C.byref(b), C.byref(n)))
+        return a.value, b.value, int(n.value)
 
     def rows_epilogue(self) -> None:
         """bitmap.100 / bins / column sums from the (combined) rows in the device buffer (async)."""
@@ -396,6 +469,19 @@ class AnchorResult:
         """all ranks' column blocks (block i = genomes from i*per) -> full rows (async)"""
         check(self._lib.pg_result_merge_columns(self._h, C.c_void_p(dev_ptr), nparts, per))
 
+    def columns_bytes_range(self, width: int, first_contig: int, ncontigs: int) -> int:
+        return int(self._lib.pg_result_columns_bytes_range(self._h, width, first_contig, ncontigs))
+
+    def extract_columns_range(self, g0: int, width: int, first_contig: int, ncontigs: int, dev_ptr: int) -> None:
+        check(self._lib.pg_result_extract_columns_range(self._h, g0, width, first_contig, ncontigs, C.c_void_p(dev_ptr)))
+
+    def merge_columns_range(self, dev_ptr: int, part0: int, nparts: int, per: int, first_contig: int, ncontigs: int,
+                            accumulate: bool = False) -> None:
+        """genome blocks part0 .. part0+nparts-1 (``per`` genomes each) of a contig range -> rows (async);
+        ``accumulate`` ORs them into the rows instead of writing the rows whole"""
+        check(self._lib.pg_result_merge_columns_range(self._h, C.c_void_p(dev_ptr), part0, nparts, per, first_contig,
+                                                      ncontigs, 1 if accumulate else 0))
+
     def rows_tensor(self):
         """Zero-copy torch uint8 view of the device bitmap.1 buffer (for RCCL collectives)."""
         import torch
@@ -404,7 +490,7 @@ class AnchorResult:
         class _Wrap:
             __cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 3}
 
-        return torch.as_tensor(_Wrap(), device=torch.device("cuda", self.table.ctx.device))
+        return torch.as_tensor(_Wrap(), device=torch.device("cuda", self.ctx.device))
 
     def contig_info(self, idx: int) -> dict:
         nk, n100 = C.c_uint64(), C.c_uint64()
@@ -416,7 +502,7 @@ class AnchorResult:
         """(hist [nwin, N+1], colsums [nwin, N] or None) of row windows [start, end) of contig idx"""
         starts = np.ascontiguousarray(starts, np.uint64)
         ends = np.ascontiguousarray(ends, np.uint64)
-        n, N = len(starts), self.table.ngenomes
+        n, N = len(starts), self.ngenomes
         hist = np.zeros((n, N + 1), np.uint64)
         cs = np.zeros((n, N), np.uint64) if colsums else None
         check(self._lib.pg_result_window_stats(self._h, idx, step, n, _ptr(starts), _ptr(ends), _ptr(hist), _ptr(cs)))
@@ -433,15 +519,15 @@ class AnchorResult:
 
     def download(self, idx: int, want_bitmap1: bool = True, want_bitmap100: bool = True):
         info = self.contig_info(idx)
-        nb = self.table.nbytes
+        nb = self.nbytes
         rows = np.empty((info["nkmers"], nb), np.uint8) if want_bitmap1 else None
         rows100 = np.empty((info["nrows100"], nb), np.uint8) if want_bitmap100 else None
-        bins = np.empty((info["nbins"], self.table.ngenomes + 1), np.uint32)
+        bins = np.empty((info["nbins"], self.ngenomes + 1), np.uint32)
         check(self._lib.pg_result_download(self._h, idx, _ptr(rows), _ptr(rows100), _ptr(bins)))
         return rows, rows100, bins, info
 
     def colsums(self) -> np.ndarray:
-        cs = np.zeros(self.table.ngenomes, np.uint64)
+        cs = np.zeros(self.ngenomes, np.uint64)
         check(self._lib.pg_result_colsums(self._h, _ptr(cs)))
         return cs
 

@@ -222,62 +222,83 @@ class Index:
     rank: int = dataclasses.field(default_factory=lambda: int(os.environ.get("RANK", "0")))
     world: int = dataclasses.field(default_factory=lambda: int(os.environ.get("WORLD_SIZE", "1")))
 
-    _EXTRA = ("device", "export_kmc", "rank", "world")
+    # how a multi-process run divides the work (see run()): None = decide from the table's size
+    shard: Optional[str] = dataclasses.field(default_factory=lambda: os.environ.get("PG_SHARD") or None)
+    genome_blocks: int = dataclasses.field(default_factory=lambda: int(os.environ.get("PG_GENOME_BLOCKS", "0")))
 
+    _EXTRA = ("device", "export_kmc", "rank", "world", "shard", "genome_blocks")
+    # keys of config.yaml that describe one invocation, not the index: not taken over when a directory is re-opened
+    # (`prepare` is written for schema compatibility, but a later `index <dir>` run must not stop at "Prepared")
+    _NOT_IN_CONFIG = ("input", "mode", "prefix", "prepare")
+    SAMPLE_COLUMNS = ("fasta", "gff", "id", "anchor")  # after the index column `name` (index.py:282-293)
+
+    # ---- opening an index: three ways in (index.py:196-268), one handler each ----
     def __post_init__(self):
-        if not (self.mode is None or self.mode in {"r", "w"}):
+        if self.mode not in (None, "r", "w"):
             raise ValueError(f"Invalid mode '{self.mode}', must be 'r' or 'w'")
-        if self.lowres_step != 100 or self.max_bin_kbp != 200 or self.min_bin_count != 100:
-            # the kernels fuse the reference's defaults (cpp/anchor.cpp hard-codes them too)
-            raise ValueError("lowres_step / max_bin_kbp / min_bin_count other than 100 / 200 / 100 "
-                             "are not supported by the GPU path")
-        self.write_mode = os.path.isfile(self.input) if self.mode is None else self.mode == "w"
-        if self.write_mode:
-            if os.path.isdir(self.input):
-                self.prefix = self.input
-                if not (os.path.isfile(self.config_fname) and os.path.isfile(self.samples_fname)):
-                    raise ValueError("Index write directory not initialized")
-                self.input = self.samples_fname
-                self.load_config()
-            elif os.path.isfile(self.input):
-                if self.prefix is None:
-                    self.prefix = os.path.dirname(self.input)
-                if len(self.prefix) == 0:
-                    self.prefix = "."
-                os.makedirs(self.prefix, exist_ok=True)
-                self.init_config()
-            else:
-                raise ValueError("Index input must be sample TSV or initialized directory")
-        else:
-            if not os.path.isdir(self.input):
-                raise ValueError("Index input must be directory mode='r'")
-            self.prefix = self.input
-            self.load_config()
+        kind = "dir" if os.path.isdir(self.input) else "file" if os.path.isfile(self.input) else None
+        self.write_mode = kind == "file" if self.mode is None else self.mode == "w"
+        opener = {(True, "dir"): self._reopen_prepared, (True, "file"): self._create_from_samples,
+                  (False, "dir"): self._open_readonly}.get((self.write_mode, kind))
+        if opener is None:
+            raise ValueError("Index input must be sample TSV or initialized directory" if self.write_mode
+                             else "Index input must be directory mode='r'")
+        opener()
+        self._check_geometry()  # (after the config file has had its say)
+        self._load_samples()
+        self._ctx = None
+        self._table = None
+        self._seqsets: Dict[str, engine.SeqSet] = {}
 
+    def _reopen_prepared(self):
+        self.prefix = self.input
+        if not all(os.path.isfile(f) for f in (self.config_fname, self.samples_fname)):
+            raise ValueError("Index write directory not initialized")
+        self.input = self.samples_fname
+        self.load_config()
+
+    def _create_from_samples(self):
+        self.prefix = self.prefix if self.prefix is not None else os.path.dirname(self.input)
+        self.prefix = self.prefix or "."
+        os.makedirs(self.prefix, exist_ok=True)
+        self.init_config()
+
+    def _open_readonly(self):
+        self.prefix = self.input
+        self.load_config()
+
+    def _check_geometry(self):
+        for nm in ("lowres_step", "max_bin_kbp", "min_bin_count"):
+            v = getattr(self, nm)
+            if not isinstance(v, (int, np.integer)) or v < 1:
+                raise ValueError(f"{nm} must be a positive integer, got {v!r}")
+        if self.lowres_step == 1:
+            raise ValueError("lowres_step=1 would name the low-resolution bitmap like the full one (bitmap.1)")
+
+    @property
+    def result_geometry(self) -> dict:
+        """what every AnchorResult of this index is created with (index.py:101-106, 1169-1172)"""
+        return dict(lowres_step=int(self.lowres_step), max_bin_len=int(self.max_bin_kbp) * 1000,
+                    min_bin_count=int(self.min_bin_count))
+
+    def _load_samples(self):
         self.samples = pd.read_table(self.samples_fname)
-        missing = {"name", "id"}.difference(self.samples.columns)
+        missing = {"name", "id"} - set(self.samples.columns)
         if missing:
             raise ValueError(f"{self.samples_fname} is missing required column(s): {', '.join(sorted(missing))}. "
                              "This directory does not look like a prepared Panagram index.")
         self.samples = self.samples.set_index("name")
         self.ngenomes = len(self.samples)
-        self.genomes: Dict[str, Genome] = {}
-        for name, row in self.samples.iterrows():
-            self.genomes[name] = Genome(self, int(row["id"]), name, row["fasta"], row.get("gff"),
-                                        bool(row["anchor"]), write=self.write_mode)
+        self.genomes: Dict[str, Genome] = {
+            name: Genome(self, int(row["id"]), name, row["fasta"], row.get("gff"), bool(row["anchor"]), write=self.write_mode)
+            for name, row in self.samples.iterrows()}
         if self.anchor_genomes is None:
             self.anchor_genomes = [n for n, g in self.genomes.items() if g.anchored]
-        self._ctx = None
-        self._table = None
-        self._seqsets: Dict[str, engine.SeqSet] = {}
 
     # ---- naming (index.py:155-165, 359-405) ----
     @property
     def params(self):
-        d = dataclasses.asdict(self)
-        for e in self._EXTRA:
-            d.pop(e, None)
-        return d
+        return {k_: v for k_, v in dataclasses.asdict(self).items() if k_ not in self._EXTRA}
 
     @property
     def config_fname(self):
@@ -299,7 +320,7 @@ class Index:
 
     @property
     def kmc_bitvec_count(self):
-        return int(np.ceil(len(self.samples) / 32.0))
+        return (len(self.samples) + 31) // 32
 
     @property
     def bitvec_prefixes(self):
@@ -313,49 +334,53 @@ class Index:
         return self.genomes[genome]
 
     # ---- config files (index.py:269-295, 347-357) ----
-    def init_config(self):
-        samples = pd.read_table(self.input)
-        if "name" not in samples.columns or "fasta" not in samples.columns:
+    @staticmethod
+    def _write_atomically(path: str, write) -> None:
+        """several ranks of one multi-GPU job write the same bytes: write-then-rename keeps readers whole"""
+        tmp = f"{path}.{os.getpid()}.tmp"
+        write(tmp)
+        os.replace(tmp, path)
+
+    def _normalised_samples(self, table: pd.DataFrame) -> pd.DataFrame:
+        """The user's table -> the schema samples.tsv is stored in: index ``name``; columns fasta, gff, id, anchor."""
+        if not {"name", "fasta"} <= set(table.columns):
             raise ValueError("Input samples must contain 'name' and 'fasta' column headers")
-        if "gff" not in samples:
-            samples["gff"] = pd.NA
-        invalid = ~samples["name"].astype(str).str.fullmatch(NAME_REGEX)
-        if np.any(invalid):
-            bad = "', '".join(samples["name"][invalid])
-            raise ValueError(f"Invalid genome names: '{bad}'\nMust match r'{NAME_REGEX}'.")
-        keep = ["name", "fasta", "gff"] + (["anchor"] if "anchor" in samples else [])
-        samples = samples[keep].set_index("name").dropna(how="all")
-        samples["id"] = np.arange(len(samples), dtype=int)
-        if self.anchor_genomes is None:
-            if "anchor" in samples:
-                self.anchor_genomes = list(samples.index[samples["anchor"].astype(bool)])
-            else:
-                self.anchor_genomes = list(samples["fasta"].dropna().index)
-        samples["anchor"] = samples.index.isin(self.anchor_genomes)
-        # (several ranks of one multi-GPU job write the same bytes: write-then-rename keeps readers whole)
-        tmp = f"{self.samples_fname}.{os.getpid()}.tmp"
-        samples[["fasta", "gff", "id", "anchor"]].to_csv(tmp, sep="\t")
-        os.replace(tmp, self.samples_fname)
+        bad = [str(n) for n in table["name"] if not re.fullmatch(NAME_REGEX, str(n))]
+        if bad:
+            raise ValueError("Invalid genome names: '" + "', '".join(bad) + f"'\nMust match r'{NAME_REGEX}'.")
+        out = table.reindex(columns=["name", "fasta", "gff"] + (["anchor"] if "anchor" in table else []))
+        out = out.set_index("name").dropna(how="all")
+        out["id"] = np.arange(len(out), dtype=int)
+        if self.anchor_genomes is None:  # the table's own anchor column, else every sample with a FASTA
+            chosen = out["anchor"].astype(bool) if "anchor" in out else out["fasta"].notna()
+            self.anchor_genomes = list(out.index[chosen])
+        out["anchor"] = out.index.isin(self.anchor_genomes)
+        return out[list(self.SAMPLE_COLUMNS)]
+
+    def init_config(self):
+        samples = self._normalised_samples(pd.read_table(self.input))
+        self._write_atomically(self.samples_fname, lambda tmp: samples.to_csv(tmp, sep="\t"))
         self.write_config()
 
     def write_config(self, exclude=("prefix",)):
-        prms = self.params
-        for p in exclude:
-            del prms[p]
-        tmp = f"{self.config_fname}.{os.getpid()}.tmp"
-        with open(tmp, "w") as conf_out:
-            yaml.dump(prms, conf_out)
-        os.replace(tmp, self.config_fname)
+        prms = {k_: v for k_, v in self.params.items() if k_ not in exclude}
+
+        def dump(tmp):
+            with open(tmp, "w") as f:
+                yaml.dump(prms, f)
+        self._write_atomically(self.config_fname, dump)
 
     def load_config(self):
         with open(self.config_fname) as f:
-            vals = yaml.load(f, yaml.SafeLoader) or {}
-        for key, val in vals.items():
-            cur = getattr(self, key, None)
-            if dataclasses.is_dataclass(cur) and isinstance(val, dict):
-                for k2, v2 in val.items():
-                    setattr(cur, k2, v2)
-            elif key not in ("input", "mode", "prefix"):
+            stored = yaml.load(f, yaml.SafeLoader) or {}
+        for key, val in stored.items():
+            if key in self._NOT_IN_CONFIG:
+                continue
+            section = getattr(self, key, None)
+            if dataclasses.is_dataclass(section) and isinstance(val, dict):
+                for sub, v in val.items():  # nested sections (kmc, genome_umap, chrom_umap) are updated in place
+                    setattr(section, sub, v)
+            else:
                 setattr(self, key, val)
 
     # ---- the table: replaces rules kmc_count / opdefs / kmc_bitvec (workflow/Snakefile:54-110) ----
@@ -364,6 +389,56 @@ class Index:
         if self._ctx is None:
             self._ctx = engine.Context(self.device)
         return self._ctx
+
+    def load_inputs(self):
+        """Every sample's sequence parsed and packed on the GPU (0.375 byte per base), with the HyperLogLog
+        registers of its distinct canonical k-mers.  Returns ``[(name, genome, seqset, min_count, registers)]`` in
+        sample order.  Sketches merge by register-wise maximum, so the distinct k-mers of any union of samples —
+        the whole pangenome, or one block of genomes — can be estimated before a table is allocated."""
+        if getattr(self, "_inputs", None) is not None:
+            return self._inputs
+        from concurrent.futures import ThreadPoolExecutor
+        inputs = []
+        sketch = engine.KmerSketch(self.context, self.k)
+        # the FASTA files are read a few ahead by host threads while the GPU parses and sketches
+        todo = [n for n, g in self.genomes.items() if not pd.isna(g.fasta) and not is_fastq(g.fasta) and n not in self._seqsets]
+        nread = max(2, min(6, engine.usable_cpus() // 2))
+        reader = ThreadPoolExecutor(max_workers=nread)
+        ahead = {n: reader.submit(_read_fasta_image, self.genomes[n].fasta) for n in todo[:nread + 2]}
+        nxt = nread + 2
+        for name, g in self.genomes.items():
+            if pd.isna(g.fasta):
+                continue
+            if name in ahead:
+                self._seqsets[name] = engine.SeqSet.from_fasta(self.context, ahead.pop(name).result())
+                if nxt < len(todo):
+                    ahead[todo[nxt]] = reader.submit(_read_fasta_image, self.genomes[todo[nxt]].fasta)
+                    nxt += 1
+            if is_fastq(g.fasta):
+                # read sets: kmc -ci2 -fq (workflow/Snakefile:88-89) — k-mers seen once are dropped
+                # (the sketch counts them too: the table is sized from above)
+                if name in self.anchor_genomes:
+                    raise ValueError(f"{name}: a FASTQ sample cannot be an anchor genome")
+                ss, min_count = engine.SeqSet.from_host(self.context, [read_fastq_joined(g.fasta)]), 2
+            else:
+                ss, min_count = self.seqset_for(name), 1
+            sketch.reset()
+            sketch.add(ss)
+            inputs.append((name, g, ss, min_count, sketch.registers()))
+        reader.shutdown()
+        sketch.close()
+        self.context.trim()  # (the FASTA text buffer the parser kept for the next file)
+        self._inputs = inputs
+        return inputs
+
+    @staticmethod
+    def _expected_keys(inputs) -> int:
+        """distinct canonical k-mers of the union of ``inputs`` (+3 %: the sketch's standard error is 0.4 %)"""
+        if not inputs:
+            return 1024
+        regs = np.maximum.reduce([i[4] for i in inputs])
+        est = engine.KmerSketch.estimate_registers(regs)
+        return est + est // 32 + 1024
 
     def build_table(self, keep: Optional[Sequence[str]] = None) -> engine.PanTable:
         """``keep``: the genomes whose packed sequences stay resident for the anchor step (default: all anchors)"""
@@ -374,55 +449,23 @@ class Index:
         if self.kmc.use_existing and have:
             tbl = engine.PanTable(self.context, self.k, self.ngenomes)
             for i, p in enumerate(self.bitvec_prefixes):
-                with open(p + ".kmc_pre", "rb") as f:
-                    pre = f.read()
-                with open(p + ".kmc_suf", "rb") as f:
-                    suf = f.read()
-                tbl.load_kmc1(i, pre, suf)
+                tbl.load_kmc_files(i, p)
             logger.info("KMC Database Loaded")
         else:
             # every input is parsed and packed once on the GPU (0.375 byte per base) and stays
             # resident through the build; a sketch of the distinct k-mers over all of them sizes the
             # table (and settles its minimizer length) once: no re-hash while it grows, no second
             # copy of the table in HBM.  Anchors keep their sequences for the anchor step.
-            inputs = []
-            sketch = engine.KmerSketch(self.context, self.k)
-            # the FASTA files are read a few ahead by host threads while the GPU parses and sketches
-            from concurrent.futures import ThreadPoolExecutor
-            todo = [n for n, g in self.genomes.items() if not pd.isna(g.fasta) and not is_fastq(g.fasta) and n not in self._seqsets]
-            nread = max(2, min(6, engine.usable_cpus() // 2))
-            reader = ThreadPoolExecutor(max_workers=nread)
-            ahead = {n: reader.submit(_read_fasta_image, self.genomes[n].fasta) for n in todo[:nread + 2]}
-            nxt = nread + 2
-            for name, g in self.genomes.items():
-                if pd.isna(g.fasta):
-                    continue
-                if name in ahead:
-                    self._seqsets[name] = engine.SeqSet.from_fasta(self.context, ahead.pop(name).result())
-                    if nxt < len(todo):
-                        ahead[todo[nxt]] = reader.submit(_read_fasta_image, self.genomes[todo[nxt]].fasta)
-                        nxt += 1
-                if is_fastq(g.fasta):
-                    # read sets: kmc -ci2 -fq (workflow/Snakefile:88-89) — k-mers seen once are dropped
-                    # (the sketch counts them too: the table is sized from above)
-                    if name in self.anchor_genomes:
-                        raise ValueError(f"{name}: a FASTQ sample cannot be an anchor genome")
-                    ss = engine.SeqSet.from_host(self.context, [read_fastq_joined(g.fasta)])
-                    inputs.append((name, g, ss, 2))
-                else:
-                    inputs.append((name, g, self.seqset_for(name), 1))
-                sketch.add(inputs[-1][2])
-            reader.shutdown()
-            expected = sketch.estimate()
-            sketch.close()
-            self.context.trim()  # (the FASTA text buffer the parser kept for the next file)
-            tbl = engine.PanTable(self.context, self.k, self.ngenomes, expected_keys=expected + expected // 32 + 1024)
-            for name, g, ss, min_count in inputs:
+            inputs = self.load_inputs()
+            expected = self._expected_keys(inputs)
+            tbl = engine.PanTable(self.context, self.k, self.ngenomes, expected_keys=expected)
+            for name, g, ss, min_count, _ in inputs:
                 tbl.insert_seqset(g.id, ss, min_count=min_count)
                 if min_count > 1:
                     ss.close()
                 elif name not in keep:
                     self.drop_seqset(name)
+            self._inputs = None
             logger.info("k-mer table built on GPU (sketch: %d distinct k-mers): %s", expected, tbl.stats())
             if self.export_kmc:
                 os.makedirs(self.get_subdir("kmc"), exist_ok=True)
@@ -444,21 +487,75 @@ class Index:
         if ss is not None:
             ss.close()
 
+    # ---- which multi-GPU mode ----
+    HBM_RESERVE = 8 << 30  # left alone next to the table: packed sequences, descriptors, the writers' staging
+
+    def plan_sharding(self):
+        """("replicated", 1) — one table of all genomes on every GPU, anchor genomes dealt to the ranks, no
+        collective — or ("genome", nblocks): the pangenome's tables do not fit one GPU next to a working set of
+        rows, so the genomes are cut into ``nblocks`` contiguous blocks, a GPU holds the table of ONE block at a
+        time, every GPU probes every anchor position against its block and the blocks' bit columns are
+        all-gathered (``distributed.run_genome_sharded``).  ``nblocks`` is the smallest multiple of the world
+        size whose largest block fits; more blocks than GPUs run as passes.  ``shard`` / ``genome_blocks``
+        (``PG_SHARD``, ``PG_GENOME_BLOCKS``) override the choice."""
+        if self.shard not in (None, "replicated", "genome"):
+            raise ValueError(f"shard must be 'replicated' or 'genome', got {self.shard!r}")
+        if self.shard == "replicated":
+            return "replicated", 1
+        have = all(os.path.exists(p + ".kmc_pre") and os.path.exists(p + ".kmc_suf") for p in self.bitvec_prefixes)
+        if self.kmc.use_existing and have and self.shard is None:
+            return "replicated", 1  # merged bitvec databases cannot be cut into genome blocks
+        N = self.ngenomes
+        if self.shard == "genome" and self.genome_blocks > 0:
+            return "genome", min(N, self.genome_blocks)
+        inputs = self.load_inputs()
+        free, _total = self.context.mem_info()
+        nb = (N + 7) // 8
+        longest = max([int(i[2].lens.sum()) for i in inputs if i[0] in self.anchor_genomes] or [0])
+        # next to the table: two batches of rows (one being written, one being anchored), at least one anchor each
+        budget = free - self.HBM_RESERVE - 2 * min(self.batch_bytes, max(longest * nb, 1 << 30))
+        by_id = {i[1].id: i for i in inputs}
+        if self.shard is None and engine.PanTable.bytes_for(self.k, N, self._expected_keys(inputs)) <= budget:
+            return "replicated", 1
+        nblocks = max(1, self.world)
+        while True:
+            nblocks = min(nblocks, N)
+            per = (N + nblocks - 1) // nblocks
+            worst = 0
+            for b0 in range(0, N, per):
+                blk = [by_id[g] for g in range(b0, min(N, b0 + per)) if g in by_id]
+                worst = max(worst, engine.PanTable.bytes_for(self.k, min(per, N - b0), self._expected_keys(blk)))
+            # a block's table sits next to the anchors' rows of ITS genomes only (ceil(per/8) bytes) and the
+            # writers' full rows of one anchor
+            if worst <= free - self.HBM_RESERVE - 2 * longest * nb or nblocks >= N:
+                return "genome", (N + per - 1) // per
+            nblocks += max(1, self.world)
+
     # ---- panagram index command (index.py:172-191) ----
     def run(self):
         """Table build, then the anchors in batches: the anchor genomes of a batch share ONE
         co-scheduled launch (homologous regions side by side, table lines shared in L2 — the
         reference runs one thread per anchor FASTA instead, cpp/anchor.cpp:217-223), and host threads
-        stream each genome's rows out of HBM into its BGZF files while the next batch is anchored."""
+        stream each genome's rows out of HBM into its BGZF files while the next batch is anchored.
+        A pangenome whose table does not fit one GPU goes through the genome-sharded mode instead
+        (``plan_sharding``)."""
         print("Wrote config.yaml and samples.tsv")
         if self.prepare:
             print("Prepared. Run 'python -m panagram_amd index <dir>' to build the index")
             return
         from concurrent.futures import ThreadPoolExecutor
         os.makedirs(self.get_subdir("logs"), exist_ok=True)
+        mode, nblocks = self.plan_sharding()
+        if mode == "genome":
+            from .distributed import run_genome_sharded
+            logger.info("genome-sharded mode: %d genome blocks over %d GPU(s)", nblocks, self.world)
+            run_genome_sharded(self, nblocks)
+            self.close()
+            return
         mine = self.my_anchor_genomes()
         if not mine:  # more ranks than anchor genomes
             logger.info("rank %d of %d: no anchor genome to write", self.rank, self.world)
+            self.close()
             return
         tbl = self.build_table(keep=mine)
         nb = (self.ngenomes + 7) // 8
@@ -479,12 +576,9 @@ class Index:
         # (a writer job is bound by the file system — about 1.5 GB/s of compressed bytes each — not by the GPU;
         # each concurrent job pins its own staging at first use, which only pays for itself on big outputs)
         payload = sum(int(self.seqset_for(n).lens.sum()) for n in mine) * nb
-        writers = int(os.environ.get("PG_WRITERS", "4" if payload > (4 << 30) else "2"))
-        with ThreadPoolExecutor(max_workers=writers) as pool:
+        with ThreadPoolExecutor(max_workers=self.writer_jobs(payload)) as pool:
             previous = None
             for batch in batches:
-                for name in batch:
-                    self.genomes[name].setup_log(os.path.join(self.get_subdir("logs"), f"anchor.{name}.log.txt"))
                 job = self._anchor_batch(tbl, batch)
                 futs = [pool.submit(self.genomes[name].write_from_result, job, gi) for gi, name in enumerate(batch)]
                 if previous is not None:  # at most two batches of rows resident
@@ -494,6 +588,17 @@ class Index:
                 self._finish_batch(*previous)
         self.close()
 
+    @staticmethod
+    def writer_jobs(payload_bytes: int) -> int:
+        return int(os.environ.get("PG_WRITERS", "4" if payload_bytes > (4 << 30) else "2"))
+
+    def writer_of_anchor(self) -> Dict[str, int]:
+        """anchor genome -> the rank that writes its directory: dealt longest-first (FASTA size), the same answer
+        in every process"""
+        from .distributed import plan_shards
+        units = [(n, 0, os.path.getsize(self.genomes[n].fasta)) for n in self.anchor_genomes]
+        return {u[0]: r for r, sh in enumerate(plan_shards(units, max(1, self.world))) for u in sh}
+
     def my_anchor_genomes(self) -> List[str]:
         """Multi-GPU (one process per GPU, e.g. under torchrun: RANK / WORLD_SIZE): the table is
         replicated — every rank builds it from all inputs — and the anchor GENOMES are dealt to the
@@ -502,10 +607,8 @@ class Index:
         and the files do not depend on the GPU count."""
         if self.world <= 1:
             return list(self.anchor_genomes)
-        from .distributed import plan_shards
-        units = [(n, 0, os.path.getsize(self.genomes[n].fasta)) for n in self.anchor_genomes]
-        mine = {u[0] for u in plan_shards(units, self.world)[self.rank]}
-        return [n for n in self.anchor_genomes if n in mine]
+        w = self.writer_of_anchor()
+        return [n for n in self.anchor_genomes if w[n] == self.rank]
 
     batch_bytes = 32 << 30  # rows of one batch of anchor genomes held in HBM (bitmap.1 payload bytes)
     # BGZF compression of the bitmaps: a zlib level (host threads), or -2 = on the GPU (k_row_deflate)
@@ -518,21 +621,14 @@ class Index:
             if int(ln) < tbl.k:
                 logger.warning(f"Contig {nm} is shorter than k={tbl.k}: 0 k-mers (the reference underflows here)")
         logger.info("Anchoring Started")
-        res = engine.AnchorResult(tbl, merged, colsums=True)
+        res = engine.AnchorResult(tbl, merged, colsums=True, **self.result_geometry)
         first = np.cumsum([0] + [len(s.names) for s in sets])
         if len(sets) > 1:
             res.coschedule(np.repeat(np.arange(len(sets)), [len(s.names) for s in sets]))
         res.run()
-        small = [res.download(ci, want_bitmap1=False, want_bitmap100=False) for ci in range(len(merged.names))]
-        ccs = res.contig_colsums().astype(np.int64)
-        per_genome = []
-        for gi, name in enumerate(batch):
-            lo, hi = int(first[gi]), int(first[gi + 1])
-            g = self.genomes[name]
-            names = list(merged.names[lo:hi])
-            gene_hists = g._tabulate_genes(res, names, small[lo:hi], lo) if g.annotated else None
-            per_genome.append((lo, hi, names, small[lo:hi], ccs[lo:hi].sum(axis=0), gene_hists))
-        return dict(res=res, merged=merged if len(sets) > 1 else None, genomes=per_genome)
+        return dict(res=res, merged=merged if len(sets) > 1 else None,
+                    genomes=[self.genomes[name].tabulate(res, int(first[gi]), int(first[gi + 1]), list(merged.names[first[gi]:first[gi + 1]]))
+                             for gi, name in enumerate(batch)])
 
     def _finish_batch(self, job, batch, futs):
         try:
@@ -619,6 +715,10 @@ class Genome:
         self.steps = list(idx.steps)
         self.chrs = None
         self.blocks = None
+        # this genome's own log (logs/anchor.<name>.log.txt when set up): the reference ran one process — and so
+        # one basicConfig — per genome; here many genomes share a process, each with a handler of its own
+        self.log = logging.getLogger(f"{__name__}.genome.{name}")
+        self._log_handler = None
         if self.anchored and os.path.exists(self.chrs_fname):
             self.load_chrs()
 
@@ -713,23 +813,43 @@ class Genome:
         self._write_tables(names, [(b, info) for _, _, b, info in results], paircount_sums)
 
     def setup_log(self, logfile: Optional[str]):
+        """route this genome's messages to ``logfile`` (same line format as the reference's anchor logs)"""
+        self.close_log()
         if logfile:
-            logging.basicConfig(filename=logfile, level=logging.INFO,
-                                format="[ %(asctime)s %(levelname)7s ] %(message)s", datefmt="%Y-%m-%d %H:%M:%S")
+            h = logging.FileHandler(logfile)
+            h.setFormatter(logging.Formatter("[ %(asctime)s %(levelname)7s ] %(message)s", datefmt="%Y-%m-%d %H:%M:%S"))
+            self.log.addHandler(h)
+            self.log.setLevel(logging.INFO)
+            self._log_handler = h
+
+    def close_log(self):
+        if self._log_handler is not None:
+            self.log.removeHandler(self._log_handler)
+            self._log_handler.close()
+            self._log_handler = None
 
     def anchor_on_gpu(self, table: engine.PanTable, ss: engine.SeqSet):
         """Enqueue the anchor kernels for a packed FASTA and fetch the small outputs (bins, column
         sums); the bitmap rows stay in HBM for ``write_from_result``."""
         for nm, ln in zip(ss.names, ss.lens):
             if int(ln) < table.k:
-                logger.warning(f"Contig {nm} is shorter than k={table.k}: 0 k-mers (the reference underflows here)")
-        logger.info("Anchoring Started")
-        res = engine.AnchorResult(table, ss, colsums=True)
+                self.log.warning(f"Contig {nm} is shorter than k={table.k}: 0 k-mers (the reference underflows here)")
+        self.log.info("Anchoring Started")
+        res = engine.AnchorResult(table, ss, colsums=True, **self.index.result_geometry)
         res.run()
-        small = [res.download(ci, want_bitmap1=False, want_bitmap100=False) for ci in range(len(ss.names))]
-        cs = res.colsums().astype(np.int64)
-        gene_hists = self._tabulate_genes(res, list(ss.names), small) if self.annotated else None
-        return dict(res=res, merged=None, genomes=[(0, len(ss.names), list(ss.names), small, cs, gene_hists)])
+        return dict(res=res, merged=None, genomes=[self.tabulate(res, 0, len(ss.names), list(ss.names))])
+
+    def tabulate(self, res, lo: int, hi: int, names: List[str]):
+        """The small outputs of this genome's contigs ``lo..hi-1`` of a finished result — per-contig bins and
+        geometry, column sums, per-gene occupancy — as the tuple ``write_from_result`` takes; the bitmap rows
+        stay in HBM."""
+        if self._log_handler is None and self.index.write_mode:
+            os.makedirs(self.index.get_subdir("logs"), exist_ok=True)
+            self.setup_log(os.path.join(self.index.get_subdir("logs"), f"anchor.{self.name}.log.txt"))
+        small = [res.download(ci, want_bitmap1=False, want_bitmap100=False) for ci in range(lo, hi)]
+        cs = res.contig_colsums(lo, hi - lo).astype(np.int64).sum(axis=0)
+        gene_hists = self._tabulate_genes(res, names, small, lo) if self.annotated else None
+        return (lo, hi, names, small, cs, gene_hists)
 
     def _tabulate_genes(self, res, names, small, first_contig: int = 0):
         """occupancy histogram of every gene's positions, summed per chromosome (index.py:1055-1064,
@@ -745,13 +865,13 @@ class Genome:
             st, en = grp["start"].to_numpy(np.int64), grp["end"].to_numpy(np.int64)
             ok = (en > st) & (st >= 0) & (en <= size)
             for s_, e_ in zip(st[~ok], en[~ok]):
-                logger.warning(f"Skipping gene at {chrom}:{s_}-{e_}, coordinates out-of-bounds")
+                self.log.warning(f"Skipping gene at {chrom}:{s_}-{e_}, coordinates out-of-bounds")
             hist = np.zeros(self.ngenomes + 1, np.int64)
             if ok.any():
                 h, _ = res.window_stats(first_contig + ci, st[ok], en[ok], step=1, colsums=False)
                 hist = h.sum(axis=0).astype(np.int64)
             out[chrom] = (len(grp), hist)
-            logger.info(f"Annotated {chrom}")
+            self.log.info(f"Annotated {chrom}")
         return out
 
     def write_from_result(self, job, gi: int = 0, bgzf_threads: Optional[int] = None):
@@ -769,6 +889,7 @@ class Genome:
             os.replace(gz + ".tmp", gz)
             os.replace(gzi + ".tmp", gzi)
         self._write_tables(names, [(b, info) for _, _, b, info in small], cs, gene_hists)
+        self.close_log()
 
     def _bgzf_threads(self) -> int:
         return max(1, min(64, self.index.cores if self.index.cores > 1 else engine.usable_cpus()))
@@ -783,7 +904,7 @@ class Genome:
             bins_rows.extend("\t".join(map(str, row)) + "\n" for row in body.tolist())
             gene_count = gene_hists[chrom][0] if gene_hists and chrom in gene_hists else 0
             chr_rows.append((chrom, ci, info["nkmers"], gene_count))
-            logger.info(f"Anchored {chrom}")
+            self.log.info(f"Anchored {chrom}")
         with open(self.bins_fname, "w") as f:
             f.writelines(bins_rows)
         if gene_hists is not None:  # bitsum.genes.tsv: one row per annotated chromosome (index.py:1079-1082)

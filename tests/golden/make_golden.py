@@ -110,31 +110,41 @@ def make_case(name, ngenomes, k, contig_lens, d, seed, anchors, wrap=(80, 70, 60
         shutil.rmtree(root)
 
 
+ONLY = set(sys.argv[1:])  # optional: fixture names to (re)generate; default all
+
+
+def make_case_if(name, *a, **kw):
+    if not ONLY or name in ONLY:
+        make_case(name, *a, **kw)
+
+
 def main():
     if not os.path.exists(RUN_ANCHOR):
         sys.exit("reference binary not found (run in the build container)")
     # N=2, k=21: N-run, lower case, IUPAC byte, description in header, ragged wrap
-    make_case("n2_k21", 2, 21, [1700, 1300], 0.02, 11, [0, 1], lut=5)
+    make_case_if("n2_k21", 2, 21, [1700, 1300], 0.02, 11, [0, 1], lut=5)
     # nbytes=2
-    make_case("n9_k21", 9, 21, [2500, 900], 0.03, 12, [0, 4, 8], lut=5)
+    make_case_if("n9_k21", 9, 21, [2500, 900], 0.03, 12, [0, 4, 8], lut=5)
     # two DBs, nbytes=5 -> rows [db0 b0..b3][db1 b0]
-    make_case("n40_k31", 40, 31, [2500], 0.01, 13, [0, 39], lut=7)
+    make_case_if("n40_k31", 40, 31, [2500], 0.01, 13, [0, 39], lut=7)
     # even k (palindromic k-mers exist), nbytes=5 with N=33
-    make_case("n33_k16", 33, 16, [3000, 400], 0.05, 14, [1, 32], lut=4)
+    make_case_if("n33_k16", 33, 16, [3000, 400], 0.05, 14, [1, 32], lut=4)
     # k=32 (largest single-word k), N=3
-    make_case("n3_k32", 3, 32, [2200], 0.02, 15, [0, 2], lut=8)
+    make_case_if("n3_k32", 3, 32, [2200], 0.02, 15, [0, 2], lut=8)
     # N=64: nbytes=8, both DBs give 4 bytes;  N=65: 3 DBs, rows 4+4+1
-    make_case("n64_k31", 64, 31, [1500], 0.01, 16, [0, 63], lut=7)
-    make_case("n65_k21", 65, 21, [1500, 700], 0.01, 17, [64, 5], lut=5)
+    make_case_if("n64_k31", 64, 31, [1500], 0.01, 16, [0, 63], lut=7)
+    make_case_if("n65_k21", 65, 21, [1500, 700], 0.01, 17, [64, 5], lut=5)
     # min/max counter filter in the DB header (counters outside read as 0)
-    make_case("n4_k21_minmax", 4, 21, [2000], 0.05, 18, [0, 3], lut=5, min_count=2, max_count=7)
+    make_case_if("n4_k21_minmax", 4, 21, [2000], 0.05, 18, [0, 3], lut=5, min_count=2, max_count=7)
     # small k, heavy collisions between strands / genomes
-    make_case("n5_k9", 5, 9, [5000], 0.1, 19, [0, 2], lut=5)
+    make_case_if("n5_k9", 5, 9, [5000], 0.1, 19, [0, 2], lut=5)
     # config-1 shaped (2 x 1 Mb, k=21, d=0.01, seed 1234): seed-only fixture, sha256 of payloads
-    make_case("c1_2x1mb_k21", 2, 21, [1000000], 0.01, 1234, [0, 1], wrap=(80,), messy=False,
+    make_case_if("c1_2x1mb_k21", 2, 21, [1000000], 0.01, 1234, [0, 1], wrap=(80,), messy=False,
               store_payload=False, lut=9)
+    # config-5 shaped (8 genomes, k=21, one-byte rows): the genome-sharded mode's one-genome-per-GPU layout
+    make_case_if("n8_k21", 8, 21, [3000, 1200], 0.02, 20, [0, 3, 7], lut=5)
     # >= 100 bins of 200000: exercises binlen=200000 + tail bin + multi-block .gzi
-    make_case("big_n3_k21", 3, 21, [20300000, 150000], 0.01, 4321, [1], wrap=(80,), messy=False,
+    make_case_if("big_n3_k21", 3, 21, [20300000, 150000], 0.01, 4321, [1], wrap=(80,), messy=False,
               store_payload=False, lut=9)
 
 

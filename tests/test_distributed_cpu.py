@@ -134,3 +134,98 @@ def test_index_deals_anchor_genomes_to_ranks(tmp_path, monkeypatch):
             assert abs(loads[0] - loads[1]) <= 150
         if world == 8:
             assert sum(1 for m in dealt if not m) == 1  # 7 genomes on 8 ranks
+
+
+# ---------------------------------------------------------------------------
+# Index.run() itself on 2 ranks over gloo: the engine is swapped for the oracle-backed stand-in
+# (tests/fake_engine.py), everything above it is the product's own code — mode choice, genome blocks,
+# chunk pipeline, all-gather of bit columns, merge on the writer rank, files.
+# ---------------------------------------------------------------------------
+def _prepare_index(tmp_path, fx, **kw):
+    from panagram_amd import index as pidx
+    n = int(fx["ngenomes"])
+    rows = ["name\tfasta"]
+    for g in range(n):
+        fa = tmp_path / f"g{g}.fa"
+        fa.write_bytes(fx[f"fasta_{g}"].tobytes())
+        rows.append(f"g{g}\t{fa}")
+    s = tmp_path / "samples.tsv"
+    s.write_text("\n".join(rows) + "\n")
+    pidx.Index(str(s), prefix=str(tmp_path / "idx"), k=int(fx["k"]), prepare=True,
+               anchor_genomes=[f"g{g}" for g in fx["anchors"]], **kw)
+    return str(tmp_path / "idx")
+
+
+def _check_tree(idx_dir, fx):
+    import pandas as pd
+    n, k = int(fx["ngenomes"]), int(fx["k"])
+    for g in fx["anchors"]:
+        adir = os.path.join(idx_dir, "anchor", f"g{g}")
+        assert gzip.open(os.path.join(adir, "bitmap.1.gz"), "rb").read() == fx[f"a{g}_bitmap1"].tobytes()
+        assert gzip.open(os.path.join(adir, "bitmap.100.gz"), "rb").read() == fx[f"a{g}_bitmap100"].tobytes()
+        assert open(os.path.join(adir, "bitsum.bins.tsv"), "rb").read() == fx[f"a{g}_bitsum.bins.tsv"].tobytes()
+        assert open(os.path.join(adir, "chrs.tsv"), "rb").read() == fx[f"a{g}_chrs.tsv"].tobytes()
+        ora = po.anchor_fasta(H.case_dbs(fx), fx[f"fasta_{g}"].tobytes(), k, n)
+        tp = pd.read_csv(os.path.join(adir, "total_paircounts.csv"), index_col="name")
+        assert np.array_equal(tp["count"].to_numpy(), ora["colsums"])
+        assert os.path.exists(os.path.join(idx_dir, "logs", f"anchor.g{g}.log.txt"))
+
+
+def _index_run_worker(rank, world, port, idx_dir, shard, nblocks, chunk):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from panagram_amd import distributed as pdist
+        from panagram_amd import index as pidx
+        from tests import fake_engine
+        pidx.engine = fake_engine
+        pdist.CHUNK_POSITIONS = chunk  # several chunks per anchor: the pipeline's double buffering is exercised
+        idx = pidx.Index(idx_dir, mode="w", shard=shard, genome_blocks=nblocks)
+        assert (idx.rank, idx.world) == (rank, world)
+        idx.run()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name,nblocks", [("n8_k21", 2), ("n8_k21", 8), ("n9_k21", 4), ("n65_k21", 2)])
+def test_world2_index_run_genome_sharded(name, nblocks, tmp_path):
+    """genome blocks = ranks (one pass), more blocks than ranks (passes, accumulate), one genome per block
+    (config 5's layout), a last block that is short (9 genomes in blocks of 3 -> 3 blocks on 2 ranks: the second
+    pass has an idle rank sending zeros), rows wider than a word"""
+    fx = H.load_case(name)
+    idx_dir = _prepare_index(tmp_path, fx)
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_index_run_worker, args=(2, port, idx_dir, "genome", nblocks, 1500), nprocs=2, join=True)
+    _check_tree(idx_dir, fx)
+
+
+def test_world2_index_run_replicated(tmp_path):
+    fx = H.load_case("n9_k21")
+    idx_dir = _prepare_index(tmp_path, fx)
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_index_run_worker, args=(2, port, idx_dir, "replicated", 0, 1 << 27), nprocs=2, join=True)
+    _check_tree(idx_dir, fx)
+
+
+def test_single_process_passes_and_mode_choice(tmp_path, monkeypatch):
+    """One process: the planner picks the genome-sharded mode when the table would not fit, with as many genome
+    blocks (passes) as it takes; the files are the same."""
+    from panagram_amd import index as pidx
+    from tests import fake_engine
+    fx = H.load_case("n8_k21")
+    idx_dir = _prepare_index(tmp_path, fx)
+    monkeypatch.setattr(pidx, "engine", fake_engine)
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    monkeypatch.setenv("RANK", "0")
+    idx = pidx.Index(idx_dir, mode="w")
+    assert idx.plan_sharding() == ("replicated", 1)
+    idx._inputs = None
+    # shrink the "HBM": the whole table (about 3e4 keys x 43 B) no longer fits next to the reserve, a block of 2 does
+    monkeypatch.setattr(pidx.Index, "HBM_RESERVE", 0)
+    monkeypatch.setattr(pidx.Index, "batch_bytes", 0)
+    keys_all = pidx.Index._expected_keys(idx.load_inputs())
+    monkeypatch.setattr(fake_engine, "HBM_FREE", int(keys_all * fake_engine.BYTES_PER_KEY * 0.45) + 2 * 4200)
+    mode, nblocks = idx.plan_sharding()
+    assert mode == "genome" and 2 <= nblocks <= 8
+    idx.run()
+    _check_tree(idx_dir, fx)
