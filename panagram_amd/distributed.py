@@ -275,131 +275,173 @@ def contig_chunks(lens: Sequence[int], k: int, limit: int = CHUNK_POSITIONS) -> 
     return out
 
 
+class ShardedAnchoring:
+    """The chunk pipeline of the genome-sharded mode for ONE process (rank): persistent exchange buffers, the
+    narrow per-anchor results against the current block table, the writers' full-row containers.
+
+        pipe = ShardedAnchoring(engine, ctx, k, N, per, rank, world, seqs, writer, geometry, group)
+        pipe.run_pass(table_of_my_block, part0, nparts, accumulate, on_anchor_complete)
+
+    ``seqs``: anchor name -> SeqSet (every rank holds every anchor's sequence); ``writer``: anchor name -> rank
+    that assembles its rows.  ``run_pass`` probes every anchor against ``table`` (None: this rank has no block in
+    the pass and contributes zeros), chunk by chunk:
+
+        probe chunk c  ->  extract its bit columns  ->  all-gather on the side stream  ->  merge on the writer
+                           probe chunk c+1 ...
+
+    and calls ``on_anchor_complete(name, rows_container)`` on the writer once an anchor's last chunk is merged."""
+
+    def __init__(self, engine, ctx, k: int, ngenomes: int, per: int, rank: int, world: int, seqs: Dict[str, object],
+                 writer: Dict[str, int], geometry: Optional[dict] = None, group=None):
+        import torch
+        self.engine, self.ctx, self.k, self.N, self.per = engine, ctx, k, ngenomes, per
+        self.rank, self.world, self.seqs, self.writer, self.group = rank, max(1, world), seqs, writer, group
+        self.geometry = geometry or {}
+        self.dist = None
+        if self.world > 1:
+            import torch.distributed as dist
+            if not dist.is_initialized():
+                raise RuntimeError("genome-sharded mode on several ranks needs torch.distributed initialised "
+                                   "(python -m torch.distributed.run ... -m panagram_amd index ...)")
+            self.dist = dist
+        # the work list: (anchor, first contig, contig count), the same on every rank
+        self.work = [(a, c0, nc) for a in seqs for c0, nc in contig_chunks(seqs[a].lens, k)]
+        self.last_of = {a: i for i, (a, _, _) in enumerate(self.work)}
+        tile = engine.tile_positions()
+        self._nbytes = [sum((max(0, int(ln) - k + 1) + tile - 1) // tile for ln in seqs[a].lens[c0:c0 + nc]) * 64 * per
+                        for a, c0, nc in self.work]  # (= AnchorResult.columns_bytes_range, without a result)
+        biggest = max(self._nbytes or [0])
+        dev = ctx.torch_device()
+        self.send = [torch.zeros(max(biggest, 8), dtype=torch.uint8, device=dev) for _ in range(2)]
+        # (one rank: its own block is all there is — merged straight out of the send buffer)
+        self.recv = ([torch.zeros(max(biggest, 8) * self.world, dtype=torch.uint8, device=dev) for _ in range(2)]
+                     if self.world > 1 else self.send)
+        if dev.type == "cuda":
+            torch.cuda.synchronize(dev)  # the buffers were zeroed on torch's stream; the kernels run on the pipe's
+        self.pipe = _Pipe(ctx, dev)
+        self.full: Dict[str, object] = {}  # writer side: anchor -> rows container (kept across passes)
+        self.bytes_received = 0
+
+    def container(self, a: str):
+        if a not in self.full:
+            self.full[a] = self.engine.AnchorResult.rows_container(self.ctx, self.k, self.N, self.seqs[a], colsums=True,
+                                                                   **self.geometry)
+        return self.full[a]
+
+    def run_pass(self, table, part0: int, nparts: int, accumulate: bool, on_anchor_complete=None) -> None:
+        pipe, work, per = self.pipe, self.work, self.per
+        part, part_of = None, None
+        pending = None  # (work index, slot, gather-done event) of the chunk whose gather is in flight
+
+        def settle(pend):
+            i, slot, ev = pend
+            a, c0, nc = work[i]
+            pipe.main_waits(ev)  # (also what frees send[slot] for the next extract into it)
+            if self.writer[a] == self.rank:
+                # recv holds `world` blocks of the chunk's size, block j from rank j = genome block part0 + j
+                self.container(a).merge_columns_range(self.recv[slot].data_ptr(), part0, nparts, per, c0, nc,
+                                                      accumulate=accumulate)
+                if on_anchor_complete is not None and self.last_of[a] == i:
+                    on_anchor_complete(a, self.full[a])
+
+        for i, (a, c0, nc) in enumerate(work):
+            slot, nbytes = i & 1, self._nbytes[i]
+            if table is not None:
+                if part_of != a:
+                    if part is not None:
+                        part.close()
+                    part, part_of = self.engine.AnchorResult(table, self.seqs[a], colsums=False, rows_only=True), a
+                part.run_range(c0, nc)
+                part.extract_columns_range(0, per, c0, nc, self.send[slot].data_ptr())
+            else:
+                pipe.zero(self.send[slot][:nbytes])  # a rank without a block in this pass contributes zeros
+            ready = pipe.mark_main()
+            if self.world > 1:
+                out_t, in_t = self.recv[slot][:nbytes * self.world], self.send[slot][:nbytes]
+                ev = pipe.on_comm(ready, lambda o=out_t, t=in_t: self.dist.all_gather_into_tensor(o, t, group=self.group))
+                self.bytes_received += nbytes * (self.world - 1)
+            else:
+                ev = ready
+            if pending is not None:
+                settle(pending)
+            pending = (i, slot, ev)
+        if pending is not None:
+            settle(pending)
+        if part is not None:
+            part.close()
+
+    def close(self):
+        for r in self.full.values():
+            r.close()
+        self.full = {}
+        self.pipe.close()
+
+
 def run_genome_sharded(index, nblocks: int, group=None, exchange_stats: Optional[dict] = None) -> None:
     """Every rank calls this (``Index.run()`` does, when ``plan_sharding`` says so).
 
     Genome block b = genomes [b*per, (b+1)*per), per = ceil(N / nblocks).  Pass p: rank r builds the table of block
-    p*world + r — a table of that block's genomes only — and probes EVERY anchor genome against it, chunk by chunk:
-
-        probe chunk c (rows of the block's genomes)  ->  extract its bit columns  ->  all-gather (side stream)
-                                                           probe chunk c+1 ...    ->  merge on the anchor's writer
-
-    The anchor genomes are dealt to the ranks as in the replicated mode (``Index.writer_of_anchor``); a writer keeps
-    the full rows of its anchors (``AnchorResult.rows_container``) across the passes and finishes each — statistics,
-    BGZF files, tables — as soon as its last chunk of the last pass has been merged.  The files are the ones a
-    single table of all genomes gives (``tests/test_gpu_genome_shard.py``, ``tests/test_distributed_cpu.py``)."""
-    import torch
+    p*world + r — a table of that block's genomes only — and probes EVERY anchor genome against it through the
+    chunk pipeline of ``ShardedAnchoring``.  The anchor genomes are dealt to the ranks as in the replicated mode
+    (``Index.writer_of_anchor``); a writer keeps the full rows of its anchors across the passes and finishes each —
+    statistics, BGZF files, tables — as soon as its last chunk of the last pass has been merged.  The files are the
+    ones a single table of all genomes gives (``tests/test_gpu_genome_shard.py``, ``tests/test_distributed_cpu.py``)."""
     from concurrent.futures import ThreadPoolExecutor
     from . import index as pidx
     engine = pidx.engine
     rank, world = index.rank, max(1, index.world)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        if not dist.is_initialized():
-            raise RuntimeError("genome-sharded mode on several ranks needs torch.distributed initialised "
-                               "(python -m torch.distributed.run ... -m panagram_amd index ...)")
     N, k = index.ngenomes, index.k
     per = (N + nblocks - 1) // nblocks
     nblocks = (N + per - 1) // per
     passes = (nblocks + world - 1) // world
     ctx = index.context
-    dev = ctx.torch_device()
     inputs = {i[1].id: i for i in index.load_inputs()}
     anchors = list(index.anchor_genomes)
     writer = index.writer_of_anchor() if world > 1 else {a: 0 for a in anchors}
     seqs = {a: index.seqset_for(a) for a in anchors}
     for a in anchors:
+        if writer[a] != rank:
+            continue
+        index.genomes[a].ensure_log()
         for nm, ln in zip(seqs[a].names, seqs[a].lens):
-            if int(ln) < k and writer[a] == rank:
+            if int(ln) < k:
                 index.genomes[a].log.warning(f"Contig {nm} is shorter than k={k}: 0 k-mers (the reference underflows here)")
-    # the work list: (anchor, first contig, contig count), the same on every rank
-    work = [(a, c0, nc) for a in anchors for c0, nc in contig_chunks(seqs[a].lens, k)]
-    last_of = {a: max(i for i, w in enumerate(work) if w[0] == a) for a in anchors if any(w[0] == a for w in work)}
-    tile = engine.tile_positions()
-    def cols_bytes(a, c0, nc):  # what AnchorResult.columns_bytes_range answers, without a result
-        return sum(((max(0, int(ln) - k + 1) + tile - 1) // tile) for ln in seqs[a].lens[c0:c0 + nc]) * 64 * per
-    biggest = max([cols_bytes(*w) for w in work] or [0])
-    send = [torch.zeros(max(biggest, 8), dtype=torch.uint8, device=dev) for _ in range(2)]
-    # (one rank: its own block is all there is — merged straight out of the send buffer)
-    recv = [torch.zeros(max(biggest, 8) * world, dtype=torch.uint8, device=dev) for _ in range(2)] if world > 1 else send
-    if dev.type == "cuda":
-        torch.cuda.synchronize(dev)  # the buffers were zeroed on torch's stream; the kernels run on the pipe's
-    pipe = _Pipe(ctx, dev)
-    full: Dict[str, object] = {}
+        index.genomes[a].log.info("Anchoring Started")
+    sh = ShardedAnchoring(engine, ctx, k, N, per, rank, world, seqs, writer, index.result_geometry, group)
     payload = sum(int(seqs[a].lens.sum()) for a in anchors if writer[a] == rank) * ((N + 7) // 8)
     pool = ThreadPoolExecutor(max_workers=index.writer_jobs(payload))
-    jobs = []
-    moved = 0
+    joins = []
     try:
         for p in range(passes):
             b = p * world + rank
             g_lo, g_hi = b * per, min(N, (b + 1) * per)
-            nparts = min(world, nblocks - p * world)
             tbl = None
             if b < nblocks:
                 blk = [inputs[g] for g in range(g_lo, g_hi) if g in inputs]
                 tbl = engine.PanTable(ctx, k, g_hi - g_lo, expected_keys=index._expected_keys(blk))
                 for name, g, ss, min_count, _ in blk:
                     tbl.insert_seqset(g.id - g_lo, ss, min_count=min_count)
-                logger_info(index, "pass %d: table of genomes %d..%d: %s", p, g_lo, g_hi - 1, tbl.stats())
-            part, part_of = None, None
-            pending = None  # (work index, slot, bytes, gather-done event) of the chunk whose gather is in flight
-            def settle(pend):
-                i, slot, nbytes, ev = pend
-                a, c0, nc = work[i]
-                pipe.main_waits(ev)  # also what frees send[slot] for the next extract into it
-                if writer[a] == rank:
-                    if a not in full:
-                        full[a] = engine.AnchorResult.rows_container(ctx, k, N, seqs[a], colsums=True, **index.result_geometry)
-                    # recv holds `world` blocks of nbytes each, block j from rank j = genome block p*world + j
-                    full[a].merge_columns_range(recv[slot].data_ptr(), p * world, nparts, per, c0, nc,
-                                                accumulate=passes > 1)
-                    if p == passes - 1 and last_of.get(a) == i:
-                        jobs.append(_finish_anchor(index, a, full[a], pool))
-            for i, (a, c0, nc) in enumerate(work):
-                slot = i & 1
-                nbytes = cols_bytes(a, c0, nc)
-                if tbl is not None:
-                    if part_of != a:
-                        if part is not None:
-                            part.close()
-                        part, part_of = engine.AnchorResult(tbl, seqs[a], colsums=False, rows_only=True), a
-                    part.run_range(c0, nc)
-                    part.extract_columns_range(0, per, c0, nc, send[slot].data_ptr())
-                else:
-                    pipe.zero(send[slot][:nbytes])  # a rank without a block in this pass contributes zeros
-                ready = pipe.mark_main()
-                if world > 1:
-                    out_t, in_t = recv[slot][:nbytes * world], send[slot][:nbytes]
-                    ev = pipe.on_comm(ready, lambda o=out_t, t=in_t: dist.all_gather_into_tensor(o, t, group=group))
-                    moved += nbytes * (world - 1)
-                else:
-                    ev = ready
-                if pending is not None:
-                    settle(pending)
-                pending = (i, slot, nbytes, ev)
-            if pending is not None:
-                settle(pending)
-            if part is not None:
-                part.close()
+                logger_info("pass %d: table of genomes %d..%d: %s", p, g_lo, g_hi - 1, tbl.stats())
+            done = (lambda a, res: joins.append(_finish_anchor(index, a, res, pool))) if p == passes - 1 else None
+            sh.run_pass(tbl, p * world, min(world, nblocks - p * world), passes > 1, done)
             if tbl is not None:
                 ctx.synchronize()
                 tbl.close()
-        for j in jobs:
+        for a in anchors:  # an anchor FASTA without a record: nothing was exchanged, its (empty) files are still due
+            if a not in sh.last_of and writer[a] == rank:
+                joins.append(_finish_anchor(index, a, sh.container(a), pool))
+        for j in joins:
             j()
     finally:
         pool.shutdown(wait=True)
-        for r in full.values():
-            r.close()
-        pipe.close()
+        sh.close()
     if exchange_stats is not None:
-        exchange_stats.update(bytes_received=moved, passes=passes, nblocks=nblocks, per=per, chunks=len(work))
-    if dist is not None:
-        dist.barrier(group=group)
+        exchange_stats.update(bytes_received=sh.bytes_received, passes=passes, nblocks=nblocks, per=per, chunks=len(sh.work))
+    if sh.dist is not None:
+        sh.dist.barrier(group=group)
 
 
-def logger_info(index, fmt, *args):
+def logger_info(fmt, *args):
     import logging
     logging.getLogger("panagram_amd.index").info(fmt, *args)
 
@@ -407,7 +449,6 @@ def logger_info(index, fmt, *args):
 def _finish_anchor(index, name: str, res, pool):
     """statistics from the completed rows, then the genome's files on a writer thread; returns the join"""
     g = index.genomes[name]
-    g.log.info("Anchoring Started")
     res.rows_epilogue()
     job = dict(res=res, merged=None, genomes=[g.tabulate(res, 0, len(res.seqs.names), list(res.seqs.names))])
     fut = pool.submit(g.write_from_result, job, 0)

@@ -617,10 +617,13 @@ class Index:
     def _anchor_batch(self, tbl, batch):
         sets = [self.seqset_for(name) for name in batch]
         merged = engine.SeqSet.concat(self.context, sets) if len(sets) > 1 else sets[0]
-        for nm, ln in zip(merged.names, merged.lens):
-            if int(ln) < tbl.k:
-                logger.warning(f"Contig {nm} is shorter than k={tbl.k}: 0 k-mers (the reference underflows here)")
-        logger.info("Anchoring Started")
+        for name, ss in zip(batch, sets):
+            g = self.genomes[name]
+            g.ensure_log()
+            for nm, ln in zip(ss.names, ss.lens):
+                if int(ln) < tbl.k:
+                    g.log.warning(f"Contig {nm} is shorter than k={tbl.k}: 0 k-mers (the reference underflows here)")
+            g.log.info("Anchoring Started")
         res = engine.AnchorResult(tbl, merged, colsums=True, **self.result_geometry)
         first = np.cumsum([0] + [len(s.names) for s in sets])
         if len(sets) > 1:
@@ -822,6 +825,12 @@ class Genome:
             self.log.setLevel(logging.INFO)
             self._log_handler = h
 
+    def ensure_log(self):
+        """logs/anchor.<name>.log.txt, unless a log has been set up already"""
+        if self._log_handler is None and self.index.write_mode:
+            os.makedirs(self.index.get_subdir("logs"), exist_ok=True)
+            self.setup_log(os.path.join(self.index.get_subdir("logs"), f"anchor.{self.name}.log.txt"))
+
     def close_log(self):
         if self._log_handler is not None:
             self.log.removeHandler(self._log_handler)
@@ -831,6 +840,7 @@ class Genome:
     def anchor_on_gpu(self, table: engine.PanTable, ss: engine.SeqSet):
         """Enqueue the anchor kernels for a packed FASTA and fetch the small outputs (bins, column
         sums); the bitmap rows stay in HBM for ``write_from_result``."""
+        self.ensure_log()
         for nm, ln in zip(ss.names, ss.lens):
             if int(ln) < table.k:
                 self.log.warning(f"Contig {nm} is shorter than k={table.k}: 0 k-mers (the reference underflows here)")
@@ -843,9 +853,7 @@ class Genome:
         """The small outputs of this genome's contigs ``lo..hi-1`` of a finished result — per-contig bins and
         geometry, column sums, per-gene occupancy — as the tuple ``write_from_result`` takes; the bitmap rows
         stay in HBM."""
-        if self._log_handler is None and self.index.write_mode:
-            os.makedirs(self.index.get_subdir("logs"), exist_ok=True)
-            self.setup_log(os.path.join(self.index.get_subdir("logs"), f"anchor.{self.name}.log.txt"))
+        self.ensure_log()
         small = [res.download(ci, want_bitmap1=False, want_bitmap100=False) for ci in range(lo, hi)]
         cs = res.contig_colsums(lo, hi - lo).astype(np.int64).sum(axis=0)
         gene_hists = self._tabulate_genes(res, names, small, lo) if self.annotated else None

@@ -134,3 +134,75 @@ def test_more_than_2_32_positions_in_one_result(ctx):
     big.close()
     one.close()
     ctx.trim()  # give the cached row buffers back
+
+
+def _fullsize_pangenome_properties(ctx, G, contig_lens, k, d, seed, picks, sample_n=2_000_000):
+    """A BASELINE config at FULL size, every genome anchored in one co-scheduled result (the bench's mode):
+    size-independent properties over all of it + the CPU oracle on the first ``sample_n`` positions of the ``picks``
+    genomes, its k-mer DB built by brute force with torch (bench.sample_db_by_brute_force: no HIP kernel involved)."""
+    import bench
+    from oracle import coracle
+    from panagram_amd import engine
+    dev = torch.device("cuda", 0)
+    pg = bench.Pangenome(ctx, dev, G, contig_lens, d, seed, k, keep_ascii=True)
+    C = len(contig_lens)
+    samples = [pg.ascii[g][0][:sample_n] for g in picks]
+    dbs = bench.sample_db_by_brute_force(pg.ascii, samples, k, G)
+    samples_host = [s.cpu().numpy() for s in samples]
+    pg.ascii = None
+    torch.cuda.empty_cache()
+    merged = engine.SeqSet.concat(ctx, pg.seqsets)
+    res = engine.AnchorResult(pg.table, merged, colsums=True)
+    res.coschedule(np.repeat(np.arange(G), C))
+    res.run()
+    ccs = res.contig_colsums().astype(np.int64)          # [G*C, G]
+    nk = np.array([L - k + 1 for L in contig_lens], np.int64)
+    nb = (G + 7) // 8
+    total_bits = 0
+    for g in range(G):
+        own = ccs[g * C:(g + 1) * C]
+        assert np.array_equal(own[:, g], nk), f"anchor genome {g} must hold every one of its own k-mers"
+        assert (own <= nk[:, None]).all() and (own.sum(axis=0) > 0).all()
+    # bins: every contig's histogram sums to its bin lengths; sum_p p * hist[p] == sum of the column sums
+    for ci in range(G * C):
+        _, _, bins, info = res.download(ci, want_bitmap1=False, want_bitmap100=False)
+        n = int(nk[ci % C])
+        assert info["nkmers"] == n and info["binlen"] == (200000 if n // 200000 >= 100 else n // 100)
+        lens = np.minimum(info["binlen"], n - np.arange(info["nbins"], dtype=np.int64) * info["binlen"])
+        assert np.array_equal(bins.sum(axis=1), lens)
+        total_bits += int((bins.astype(np.int64) * np.arange(G + 1)).sum())
+    assert total_bits == int(ccs.sum())
+    # rows of the sampled genomes: bitmap.100 == bitmap.1[::100]; first sample_n rows == the CPU oracle's
+    odbs = [coracle.OracleDB.from_arrays(kk, mm, k) for kk, mm in dbs]
+    for g, s in zip(picks, samples_host):
+        rows, rows100, _, _ = res.download(g * C)
+        assert rows.shape == (nk[0], nb) and np.array_equal(rows100, rows[::100])
+        want = coracle.write_bits(odbs, G, s, k)[0]
+        assert np.array_equal(rows[:len(want)], want), f"genome {g}: GPU rows differ from the CPU oracle's"
+        del rows, rows100
+    for o in odbs:
+        o.close()
+    # idempotence of the whole launch: same column sums again
+    res.run()
+    assert np.array_equal(res.contig_colsums().astype(np.int64), ccs)
+    st = pg.stats
+    res.close()
+    merged.close()
+    pg.close()
+    ctx.trim()
+    return st
+
+
+def test_config3_fullsize_properties(ctx):
+    """BASELINE.json configs[2]: 27 Arabidopsis-scale (~135 Mb) genomes, k=21, all 27 anchored (3.6e9 positions, 4-byte
+    rows) on one GPU"""
+    st = _fullsize_pangenome_properties(ctx, 27, [34_000_000, 23_000_000, 26_000_000, 21_000_000, 31_000_000], 21, 0.01,
+                                        2718, picks=(0, 19))
+    assert 6.5e8 < st["nkeys"] < 9.5e8
+
+
+def test_config4_fullsize_properties(ctx):
+    """BASELINE.json configs[3]: 64 synthetic 200 Mb genomes, k=31, all 64 anchored (1.28e10 positions, 8-byte rows:
+    about 90 GB of table + 102 GB of rows in one GPU's HBM)"""
+    st = _fullsize_pangenome_properties(ctx, 64, [20_000_000] * 10, 31, 0.005, 3141, picks=(0, 41), sample_n=1_000_000)
+    assert 1.5e9 < st["nkeys"] < 2.4e9

@@ -1,6 +1,9 @@
 """GPU: genome-sharded mode on one device — per-"rank" partial tables (disjoint genome bits),
 rows-only anchoring, SUM-combine of the partial rows, statistics from the combined rows.
-Must equal the fused single-table result and the reference's golden outputs."""
+Must equal the fused single-table result and the reference's golden outputs.
+("n8_k21", 8) is BASELINE config 5's layout: 8 genomes, k=21, ONE genome per rank — columns of width 1, per = 1.)
+The product path (Index.run() -> plan_sharding -> run_genome_sharded: narrow block tables, chunk pipeline, rows
+containers, passes) runs on the one GPU with as many genome blocks as the case asks for."""
 import numpy as np
 import pytest
 import torch
@@ -12,7 +15,7 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("mode", ["columns", "sum"])
-@pytest.mark.parametrize("name,world", [("n9_k21", 2), ("n65_k21", 4), ("n40_k31", 8)])
+@pytest.mark.parametrize("name,world", [("n9_k21", 2), ("n65_k21", 4), ("n40_k31", 8), ("n8_k21", 8)])
 def test_partial_tables_combine_equals_reference(ctx, name, world, mode):
     from panagram_amd import engine
     from panagram_amd.distributed import genome_owner, genomes_per_rank
@@ -100,3 +103,120 @@ def test_rccl_code_path_world1(ctx):
         tbl.close()
     finally:
         dist.destroy_process_group()
+
+
+def _write_case(tmp_path, fx):
+    n = int(fx["ngenomes"])
+    rows = ["name\tfasta"]
+    for g in range(n):
+        fa = tmp_path / f"g{g}.fa"
+        fa.write_bytes(fx[f"fasta_{g}"].tobytes())
+        rows.append(f"g{g}\t{fa}")
+    s = tmp_path / "samples.tsv"
+    s.write_text("\n".join(rows) + "\n")
+    return s
+
+
+def _check_tree(out, fx):
+    import gzip
+    import pandas as pd
+    n, k = int(fx["ngenomes"]), int(fx["k"])
+    dbs = H.case_dbs(fx)
+    for g in fx["anchors"]:
+        adir = out / "anchor" / f"g{g}"
+        for step in (1, 100):
+            assert gzip.open(adir / f"bitmap.{step}.gz", "rb").read() == fx[f"a{g}_bitmap{step}"].tobytes()
+            gzi = np.fromfile(adir / f"bitmap.{step}.gzi", "<u8")
+            assert gzi[0] == np.frombuffer(fx[f"a{g}_gzi{step}"].tobytes(), "<u8")[0]
+        assert (adir / "bitsum.bins.tsv").read_bytes() == fx[f"a{g}_bitsum.bins.tsv"].tobytes()
+        assert (adir / "chrs.tsv").read_bytes() == fx[f"a{g}_chrs.tsv"].tobytes()
+        ora = po.anchor_fasta(dbs, fx[f"fasta_{g}"].tobytes(), k, n)
+        tp = pd.read_csv(adir / "total_paircounts.csv", index_col="name")
+        assert np.array_equal(tp["count"].to_numpy(), ora["colsums"])
+
+
+@pytest.mark.parametrize("name,nblocks,chunk", [("n8_k21", 8, 1500), ("n8_k21", 1, 1 << 27), ("n9_k21", 4, 700),
+                                                ("n65_k21", 4, 1 << 27), ("n40_k31", 3, 900), ("n2_k21", 2, 512)])
+def test_index_run_genome_sharded_on_one_gpu(name, nblocks, chunk, tmp_path, monkeypatch):
+    """Index.run() in the genome-sharded mode: one GPU works the genome blocks off as passes.  ("n8_k21", 8): one
+    genome per block — config 5's layout; chunk: positions per exchanged chunk, small ones make every anchor
+    several chunks (double-buffered pipeline) whose last ones are short."""
+    from panagram_amd import distributed as pdist
+    from panagram_amd import index as pidx
+    fx = H.load_case(name)
+    s = _write_case(tmp_path, fx)
+    out = tmp_path / "idx"
+    monkeypatch.setattr(pdist, "CHUNK_POSITIONS", chunk)
+    idx = pidx.Index(str(s), prefix=str(out), k=int(fx["k"]), anchor_genomes=[f"g{g}" for g in fx["anchors"]],
+                     shard="genome", genome_blocks=nblocks)
+    assert idx.plan_sharding() == ("genome", nblocks)
+    idx.run()
+    _check_tree(out, fx)
+
+
+def test_planner_switches_to_genome_blocks_when_the_table_does_not_fit(tmp_path, monkeypatch):
+    """the decision itself: with the HBM budget shrunk below the pangenome's table, plan_sharding answers
+    ("genome", blocks) with blocks whose tables fit, and the run writes the reference's tree"""
+    from panagram_amd import engine
+    from panagram_amd import index as pidx
+    fx = H.load_case("n9_k21")
+    s = _write_case(tmp_path, fx)
+    out = tmp_path / "idx"
+    idx = pidx.Index(str(s), prefix=str(out), k=int(fx["k"]), anchor_genomes=[f"g{g}" for g in fx["anchors"]])
+    assert idx.plan_sharding() == ("replicated", 1)
+    whole = engine.PanTable.bytes_for(idx.k, idx.ngenomes, idx._expected_keys(idx.load_inputs()))
+    free = idx.context.mem_info()[0]
+    # (small fixtures sit at pg_table_create's floor of 2^18 keys: make the reserve eat everything but half a table)
+    monkeypatch.setattr(pidx.Index, "batch_bytes", 0)
+    monkeypatch.setattr(pidx.Index, "HBM_RESERVE", free - whole // 2)
+    mode, nblocks = idx.plan_sharding()
+    assert mode == "genome" and nblocks >= 1
+    idx.shard, idx.genome_blocks = "genome", 3
+    idx.run()
+    _check_tree(out, fx)
+
+
+def test_range_probe_extract_merge_equals_whole(ctx):
+    """contig-range calls (the pipeline's units) against the whole-result calls: same rows, same columns"""
+    from panagram_amd import engine
+    fx = H.load_case("n9_k21")
+    n, k = int(fx["ngenomes"]), int(fx["k"])
+    dbs = H.case_dbs(fx)
+    g = int(fx["anchors"][1])
+    seqs = [s_ for _, s_ in po.parse_fasta_cpp(fx[f"fasta_{g}"].tobytes())]
+    seqs = seqs + [seqs[0][:777], seqs[-1][5:1900]]  # four contigs, ragged tile counts
+    t = engine.PanTable(ctx, k, n)
+    for d, (keys, masks) in enumerate(dbs):
+        t.insert_keys(d, keys, masks)
+    ss = engine.SeqSet.from_host(ctx, seqs)
+    whole = engine.AnchorResult(t, ss, colsums=True, rows_only=True)
+    whole.run()
+    piece = engine.AnchorResult(t, ss, colsums=True, rows_only=True)
+    for c0, nc in [(2, 2), (0, 1), (1, 1)]:
+        piece.run_range(c0, nc)
+    ctx.synchronize()
+    for ci in range(len(seqs)):
+        assert np.array_equal(piece.download(ci, want_bitmap100=False)[0], whole.download(ci, want_bitmap100=False)[0])
+    per = 4
+    allc = torch.zeros(whole.columns_bytes(per), dtype=torch.uint8, device="cuda")
+    whole.extract_columns(4, per, allc.data_ptr())
+    full = engine.AnchorResult.rows_container(ctx, k, n, ss, colsums=True)
+    off = 0
+    for c0, nc in [(0, 1), (1, 2), (3, 1)]:
+        nb_ = piece.columns_bytes_range(per, c0, nc)
+        buf = torch.zeros(nb_, dtype=torch.uint8, device="cuda")
+        piece.extract_columns_range(4, per, c0, nc, buf.data_ptr())
+        ctx.synchronize()
+        assert torch.equal(buf, allc[off:off + nb_])
+        off += nb_
+        # genome block 1 (genomes 4..7) OR-ed into a zeroed container
+        full.merge_columns_range(buf.data_ptr(), 1, 1, per, c0, nc, accumulate=True)
+        ctx.synchronize()
+    assert off == allc.numel()
+    keep = np.zeros(((n + 7) // 8) * 8, np.uint8)
+    keep[4:8] = 1
+    mask = np.packbits(keep.reshape(-1, 8), axis=1, bitorder="little").reshape(-1)
+    for ci in range(len(seqs)):
+        assert np.array_equal(full.download(ci, want_bitmap100=False)[0], whole.download(ci, want_bitmap100=False)[0] & mask)
+    for x in (full, piece, whole, ss, t):
+        x.close()

@@ -515,3 +515,114 @@ def test_degenerate_inputs_produce_valid_empty_outputs(tmp_path):
             assert not any(payload)
     tp = pd.read_csv(tmp_path / "o" / "anchor" / "a" / "total_paircounts.csv", index_col="name")
     assert int(tp.loc["a", "count"]) == 2980 and int(tp.loc["alln", "count"]) == 0
+
+
+def _bars_loop(occ, num_samples, bin_size, step):
+    """scripts/make_bins_bits.py:34-59 as the plain loop it is"""
+    x, cntr = [], bin_size
+    while cntr < len(occ) * step:
+        x.append(cntr)
+        cntr += bin_size
+    z_unique, z_univ = [0] * (len(x) + 1), [0] * (len(x) + 1)
+    c = 0
+    for i in occ:
+        t = int(c / bin_size)
+        if i == 1:
+            z_unique[t] += 1
+        elif i == num_samples:
+            z_univ[t] += 1
+        c += step
+    return x, z_univ[:len(x)], z_unique[:len(x)]
+
+
+@pytest.mark.parametrize("name", ["n9_k21", "n2_k21"])
+def test_bins_bits_on_a_hip_written_index(name, tmp_path, capsys):
+    """the make_bins_bits.py counterpart reads an index the HIP path wrote (bitmap.100.gz / .gzi
+    through the reference's addressing rule) and must give what the script's loop gives on the golden
+    bitmap.100 payload of the reference binary."""
+    from panagram_amd import bins_bits
+    from panagram_amd import index as pidx
+    fx = H.load_case(name)
+    n, k = int(fx["ngenomes"]), int(fx["k"])
+    s = _write_case(tmp_path, fx)
+    out = tmp_path / "idx"
+    pidx.Index(str(s), prefix=str(out), k=k, anchor_genomes=[f"g{g}" for g in fx["anchors"]]).run()
+    ridx = pidx.Index(str(out), mode="r")
+    nb = (n + 7) // 8
+    for g in fx["anchors"]:
+        rows100 = np.frombuffer(fx[f"a{g}_bitmap100"].tobytes(), np.uint8).reshape(-1, nb)
+        occ_all = np.unpackbits(rows100, axis=1, bitorder="little")[:, :n].sum(axis=1)
+        off = 0
+        for nm, seq in po.parse_fasta_cpp(fx[f"fasta_{g}"].tobytes()):
+            n100 = (len(seq) - k + 1 + 99) // 100
+            occ = occ_all[off:off + n100]
+            off += n100
+            for bin_size in (200000, 1000, 300):
+                assert bins_bits.chromosome_bars(ridx, f"g{g}", nm, bin_size, 100) == _bars_loop(occ, n, bin_size, 100)
+    # the command-line form prints the script's three comma-terminated lines per chromosome
+    g0 = f"g{int(fx['anchors'][0])}"
+    assert bins_bits.main([str(out), g0]) == 0
+    lines = capsys.readouterr().out.strip("\n").split("\n")
+    assert len(lines) == 3 * len(po.parse_fasta_cpp(fx[f"fasta_{int(fx['anchors'][0])}"].tobytes()))
+
+
+@pytest.mark.parametrize("name,step,kbp,minbins", [("n9_k21", 10, 1, 7), ("n40_k31", 250, 2, 3), ("n2_k21", 7, 200, 100)])
+def test_index_run_with_non_default_resolution_and_bins(name, step, kbp, minbins, tmp_path):
+    """lowres_step / max_bin_kbp / min_bin_count of the Python path (index.py:101-106, 1169-1183): bitmap.<step> =
+    every step-th row of the golden bitmap.1, bins of max_bin_kbp*1000 positions unless the contig would get fewer
+    than min_bin_count of them; the read side addresses bitmap.<step> by the same rule."""
+    from panagram_amd import index as pidx
+    fx = H.load_case(name)
+    n, k = int(fx["ngenomes"]), int(fx["k"])
+    s = _write_case(tmp_path, fx)
+    out = tmp_path / "idx"
+    idx = pidx.Index(str(s), prefix=str(out), k=k, anchor_genomes=[f"g{g}" for g in fx["anchors"]],
+                     lowres_step=step, max_bin_kbp=kbp, min_bin_count=minbins)
+    idx.run()
+    ridx = pidx.Index(str(out), mode="r")
+    assert ridx.steps == (1, step)
+    nb = (n + 7) // 8
+    for g in fx["anchors"]:
+        adir = out / "anchor" / f"g{g}"
+        rows = np.frombuffer(fx[f"a{g}_bitmap1"].tobytes(), np.uint8).reshape(-1, nb)
+        assert gzip.open(adir / "bitmap.1.gz", "rb").read() == rows.tobytes()
+        low, lines, off = [], ["chr\tstart" + "".join(f"\t{i}" for i in range(n + 1)) + "\n"], 0
+        for ci, (nm, seq) in enumerate(po.parse_fasta_cpp(fx[f"fasta_{g}"].tobytes())):
+            nk = len(seq) - k + 1
+            r = rows[off:off + nk]
+            off += nk
+            low.append(r[::step].tobytes())
+            binlen = kbp * 1000
+            if nk // binlen < minbins:
+                binlen = nk // minbins
+            popc = np.unpackbits(r, axis=1, bitorder="little")[:, :n].sum(axis=1)
+            for b0 in range(0, nk, binlen):
+                h = np.bincount(popc[b0:b0 + binlen], minlength=n + 1)
+                lines.append(f"{ci}\t{b0}" + "".join(f"\t{c}" for c in h) + "\n")
+            df = ridx.query_bitmap(f"g{g}", nm, 0, nk, step)
+            assert np.array_equal(df.to_numpy(), np.unpackbits(r[::step], axis=1, bitorder="little")[:, :n])
+        assert gzip.open(adir / f"bitmap.{step}.gz", "rb").read() == b"".join(low)
+        assert (adir / "bitsum.bins.tsv").read_text() == "".join(lines)
+
+
+def test_mean_launch_timing_over_several_runs(ctx):
+    """pg_result_timing_mean: every run since the reset is counted (bench.py's avg_launch_ms)"""
+    from panagram_amd import engine
+    fx = H.load_case("n9_k21")
+    t = engine.PanTable(ctx, int(fx["k"]), int(fx["ngenomes"]))
+    for d, (keys, masks) in enumerate(H.case_dbs(fx)):
+        t.insert_keys(d, keys, masks)
+    ss = engine.SeqSet.from_fasta(ctx, fx["fasta_0"].tobytes())
+    res = engine.AnchorResult(t, ss, colsums=True)
+    for _ in range(3):
+        res.run()
+    res.timing_reset()
+    assert res.timing_mean()[2] == 0
+    for _ in range(150):  # more than the event ring holds
+        res.run()
+    p_ms, e_ms, n = res.timing_mean()
+    assert n == 150 and p_ms > 0 and e_ms > 0
+    last = res.timing()
+    assert 0 < last[0] < 50 * p_ms
+    assert res.timing_mean()[2] == 150  # reading does not consume
+    res.close(); ss.close(); t.close()
