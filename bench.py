@@ -382,7 +382,7 @@ def sharded_leg(ctx, dev, args, rank, world, dist, steps, warmup, nblocks=None):
         "value": pos * steps / dt, "unit": "k-mers/s", "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * dt / steps,
         "positions_per_step": pos, "genome_blocks": nblocks, "genomes_per_block": per,
         "block_table_keys": pg.stats["nkeys"], "block_table_bytes": pg.stats["bytes"],
-        "chunks_per_step": len(sh.work),
+        "chunk_groups_per_step": len(sh.groups),
         "collective": "all_gather_into_tensor of bit columns (RCCL over xGMI)" if world > 1 else "none (one rank)",
         "collective_bytes_received_per_rank_per_step": sh.bytes_received / max(1, steps + warmup),
         "parallelism": f"genome-sharded x{world}: {nblocks} genome blocks of {per}, every rank probes every position, "

@@ -174,6 +174,11 @@ int pg_seqset_from_fasta(pg_ctx *ctx, const void *text, uint64_t nbytes, pg_seqs
 /* one seqset holding the contigs of all `sets`, in order (packed planes copied device to device):
  * lets ONE result anchor every anchor genome of a pangenome, see pg_result_coschedule */
 int pg_seqset_concat(pg_ctx *ctx, const pg_seqset *const *sets, uint32_t nsets, pg_seqset **out);
+/* the same from contig ranges: contigs first_contig[i] .. first_contig[i]+ncontigs[i]-1 of sets[i], in order (a set may
+ * appear several times): the genome-sharded pipeline lays the anchors' contigs out chunk group by chunk group, so
+ * that one launch covers the homologous pieces of every anchor */
+int pg_seqset_concat_ranges(pg_ctx *ctx, const pg_seqset *const *sets, const uint32_t *first_contig,
+                            const uint32_t *ncontigs, uint32_t nsets, pg_seqset **out);
 uint32_t pg_seqset_ncontigs(const pg_seqset *s);
 /* record id ("" unless parsed from FASTA; owned by the seqset) and length in bases of contig idx */
 int pg_seqset_contig(const pg_seqset *s, uint32_t idx, const char **name, uint64_t *len);
@@ -230,12 +235,14 @@ int pg_result_extract_columns(pg_result *r, uint32_t g0, uint32_t width, void *d
 int pg_result_merge_columns(pg_result *r, const void *d_src, uint32_t nparts, uint32_t per);
 /* the same over a contig range (the pipeline's chunk): the block then holds only that range's tiles.  merge:
  * the nparts blocks are genome blocks part0 .. part0+nparts-1 of `per` genomes each; accumulate != 0 ORs their bits
- * into the rows (blocks arriving pass by pass — more genome blocks than GPUs), 0 writes the rows whole. */
+ * into the rows (blocks arriving pass by pass — more genome blocks than GPUs), 0 writes the rows whole.
+ * part_stride_bytes: distance between consecutive blocks in d_src (0: the range's own block size) — larger when the
+ * range is a slice of a bigger exchanged chunk (d_src then points at the slice inside the first block). */
 uint64_t pg_result_columns_bytes_range(const pg_result *r, uint32_t width, uint32_t first_contig, uint32_t ncontigs);
 int pg_result_extract_columns_range(pg_result *r, uint32_t g0, uint32_t width, uint32_t first_contig, uint32_t ncontigs,
                                     void *d_dst);
 int pg_result_merge_columns_range(pg_result *r, const void *d_src, uint32_t part0, uint32_t nparts, uint32_t per,
-                                  uint32_t first_contig, uint32_t ncontigs, int accumulate);
+                                  uint32_t first_contig, uint32_t ncontigs, int accumulate, uint64_t part_stride_bytes);
 /* bitmap.100 rows, bin histograms and column sums from the (combined) bitmap.1 rows in the
  * result's device buffer; async.  Same outputs as the fused pg_anchor_run path. */
 int pg_rows_epilogue(pg_result *r);
@@ -275,6 +282,11 @@ int pg_result_write_bgzf_range(pg_result *r, int step, uint32_t first_contig, ui
  * and the lines are fetched from HBM once instead of once per genome.  Results do not depend on
  * the schedule. */
 int pg_result_coschedule(pg_result *r, const uint32_t *contig_group, uint32_t piece_tiles);
+/* the same with the contigs cut into nranges consecutive ranges (range i starts at contig range_first_contig[i];
+ * the first at 0) that are scheduled independently: pg_anchor_run_range over one or several whole ranges then
+ * follows the schedule too (any other range runs in launch order) */
+int pg_result_coschedule_ranges(pg_result *r, const uint32_t *contig_group, uint32_t piece_tiles,
+                                const uint32_t *range_first_contig, uint32_t nranges);
 /* column sums of contigs idx .. idx+ncontigs-1 (ncontigs x ngenomes u64); pg_result_colsums is
  * their total */
 int pg_result_contig_colsums(pg_result *r, uint32_t idx, uint32_t ncontigs, uint64_t *colsums);

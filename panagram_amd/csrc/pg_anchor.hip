@@ -265,7 +265,8 @@ __global__ __launch_bounds__(64) void k_probe(const SubTable st, const uint64_t 
     const int k = (int)st.k;
     // tiles run in launch order unless the result carries a schedule (co-scheduled anchor genomes:
     // homologous regions of all genomes next to each other, so that table lines are shared in L2)
-    const uint32_t tile = sched ? sched[blockIdx.x] : blockIdx.x + tile_base;  // (tile_base: a contig range of the result)
+    // (tile_base: the launch covers a contig range of the result; a schedule is a permutation within such ranges)
+    const uint32_t tile = sched ? sched[blockIdx.x + tile_base] : blockIdx.x + tile_base;
     const uint32_t c = tile_contig[tile];
     const AnchorDesc a = ad[c];
     const SeqDesc s = sd[c];

@@ -139,6 +139,7 @@ struct pg_result {
     AnchorDesc *d_ad;
     uint32_t *d_tile_contig;
     uint32_t *d_sched = nullptr;  // optional launch order of the tiles (pg_result_coschedule)
+    std::vector<uint32_t> sched_bounds;  // tile indices at which independently scheduled ranges begin / end
     uint32_t ntiles;
     uint8_t *d_out1;
     uint64_t out1_bytes;
@@ -1136,13 +1137,17 @@ extern "C" int pg_seqset_from_fasta(pg_ctx *ctx, const void *text_, uint64_t nby
     return PG_OK;
 }
 
-// one seqset holding the contigs of all `sets` in order (device-to-device copy of the packed planes)
-extern "C" int pg_seqset_concat(pg_ctx *ctx, const pg_seqset *const *sets, uint32_t nsets, pg_seqset **out) {
+// one seqset holding contigs [first[i], first[i] + count[i]) of sets[i], in order (device-to-device copy of the packed
+// planes); first == NULL: every contig of every set
+static int seqset_concat(pg_ctx *ctx, const pg_seqset *const *sets, const uint32_t *first, const uint32_t *count,
+                         uint32_t nsets, pg_seqset **out) {
     if (!ctx || !out || (nsets && !sets)) return fail(PG_E_INVALID, "pg_seqset_concat: NULL argument");
     std::vector<uint64_t> lens;
     for (uint32_t i = 0; i < nsets; ++i) {
         if (!sets[i] || sets[i]->ctx != ctx) return fail(PG_E_INVALID, "pg_seqset_concat: seqset %u is NULL or of another context", i);
-        for (auto &d : sets[i]->desc) lens.push_back(d.len);
+        const uint32_t f = first ? first[i] : 0, n = first ? count[i] : sets[i]->n;
+        if ((uint64_t)f + n > sets[i]->n) return fail(PG_E_INVALID, "pg_seqset_concat_ranges: contigs %u..%u of seqset %u out of range", f, f + n, i);
+        for (uint32_t j = f; j < f + n; ++j) lens.push_back(sets[i]->desc[j].len);
     }
     pg_seqset *s = nullptr;
     if (int r = pg_seqset_create(ctx, (uint32_t)lens.size(), lens.data(), &s)) return r;
@@ -1151,7 +1156,8 @@ extern "C" int pg_seqset_concat(pg_ctx *ctx, const pg_seqset *const *sets, uint3
     uint32_t c = 0;
     for (uint32_t i = 0; i < nsets && e == hipSuccess; ++i) {
         const pg_seqset *src = sets[i];
-        for (uint32_t j = 0; j < src->n && e == hipSuccess; ++j, ++c) {
+        const uint32_t f = first ? first[i] : 0, n = first ? count[i] : src->n;
+        for (uint32_t j = f; j < f + n && e == hipSuccess; ++j, ++c) {
             const uint64_t nw = std::min(src->desc[j].nwords, s->desc[c].nwords);
             e = hipMemcpyAsync(s->d_seqw + s->desc[c].seq_off, src->d_seqw + src->desc[j].seq_off, nw * 8,
                                hipMemcpyDeviceToDevice, st);
@@ -1170,6 +1176,16 @@ extern "C" int pg_seqset_concat(pg_ctx *ctx, const pg_seqset *const *sets, uint3
     }
     *out = s;
     return PG_OK;
+}
+
+extern "C" int pg_seqset_concat(pg_ctx *ctx, const pg_seqset *const *sets, uint32_t nsets, pg_seqset **out) {
+    return seqset_concat(ctx, sets, nullptr, nullptr, nsets, out);
+}
+
+extern "C" int pg_seqset_concat_ranges(pg_ctx *ctx, const pg_seqset *const *sets, const uint32_t *first_contig,
+                                       const uint32_t *ncontigs, uint32_t nsets, pg_seqset **out) {
+    if (nsets && (!first_contig || !ncontigs)) return fail(PG_E_INVALID, "pg_seqset_concat_ranges: NULL argument");
+    return seqset_concat(ctx, sets, first_contig, ncontigs, nsets, out);
 }
 
 extern "C" uint32_t pg_seqset_ncontigs(const pg_seqset *s) { return s ? s->n : 0; }
@@ -1380,8 +1396,8 @@ extern "C" int pg_result_destroy(pg_result *r) {
 // tiles, every genome traversed at the same relative pace) lets the later genomes find the lines in
 // L2 / Infinity Cache.  Only the launch order changes — results are identical for any schedule.
 // ---------------------------------------------------------------------------
-extern "C" int pg_result_coschedule(pg_result *r, const uint32_t *contig_group, uint32_t piece_tiles) {
-    if (!r) return fail(PG_E_INVALID, "result is NULL");
+static int coschedule(pg_result *r, const uint32_t *contig_group, uint32_t piece_tiles, const uint32_t *range_first,
+                      uint32_t nranges) {
     if (int e = use_device(r->ctx)) return e;
     hipStream_t st = r->ctx->stream;
     HIP_TRY(hipStreamSynchronize(st));
@@ -1389,37 +1405,66 @@ extern "C" int pg_result_coschedule(pg_result *r, const uint32_t *contig_group, 
         hipFree(r->d_sched);
         r->d_sched = nullptr;
     }
+    r->sched_bounds.clear();
     if (!contig_group || r->ntiles == 0) return PG_OK;  // NULL: back to launch order
     if (piece_tiles == 0) piece_tiles = 64;
     const size_t nc = r->ad.size();
-    uint32_t ngroups = 0;
-    for (size_t c = 0; c < nc; ++c) ngroups = std::max(ngroups, contig_group[c] + 1);
-    std::vector<std::vector<uint32_t>> tiles(ngroups);  // every group's tiles, contig after contig
-    for (size_t c = 0; c < nc; ++c) {
-        const uint32_t nt = (uint32_t)(((uint64_t)r->ad[c].nkmers + PROBE_TILE - 1) / PROBE_TILE);
-        for (uint32_t i = 0; i < nt; ++i) tiles[contig_group[c]].push_back(r->ad[c].tile0 + i);
+    // contig ranges scheduled independently of each other (default: one range = the whole result)
+    std::vector<uint32_t> firsts;
+    if (range_first && nranges) {
+        for (uint32_t i = 0; i < nranges; ++i) {
+            if (range_first[i] >= nc || (i && range_first[i] <= range_first[i - 1]) || (!i && range_first[0] != 0))
+                return fail(PG_E_INVALID, "pg_result_coschedule_ranges: range starts must begin at contig 0 and increase");
+            firsts.push_back(range_first[i]);
+        }
+    } else {
+        firsts.push_back(0);
     }
+    firsts.push_back((uint32_t)nc);
     struct Piece {
         double at;
         uint32_t g, first;
     };
-    std::vector<Piece> pieces;
-    for (uint32_t g = 0; g < ngroups; ++g) {
-        const size_t np = (tiles[g].size() + piece_tiles - 1) / piece_tiles;
-        for (size_t i = 0; i < np; ++i) pieces.push_back({(double)i / (double)np, g, (uint32_t)(i * piece_tiles)});
-    }
-    std::stable_sort(pieces.begin(), pieces.end(), [](const Piece &x, const Piece &y) { return x.at < y.at; });
     std::vector<uint32_t> sched;
     sched.reserve(r->ntiles);
-    for (const Piece &p : pieces) {
-        const size_t end = std::min<size_t>(tiles[p.g].size(), (size_t)p.first + piece_tiles);
-        for (size_t i = p.first; i < end; ++i) sched.push_back(tiles[p.g][i]);
+    for (size_t ri = 0; ri + 1 < firsts.size(); ++ri) {
+        const size_t c_lo = firsts[ri], c_hi = firsts[ri + 1];
+        r->sched_bounds.push_back(r->ad[c_lo].tile0);
+        uint32_t ngroups = 0;
+        for (size_t c = c_lo; c < c_hi; ++c) ngroups = std::max(ngroups, contig_group[c] + 1);
+        std::vector<std::vector<uint32_t>> tiles(ngroups);  // every group's tiles, contig after contig
+        for (size_t c = c_lo; c < c_hi; ++c) {
+            const uint32_t nt = (uint32_t)(((uint64_t)r->ad[c].nkmers + PROBE_TILE - 1) / PROBE_TILE);
+            for (uint32_t i = 0; i < nt; ++i) tiles[contig_group[c]].push_back(r->ad[c].tile0 + i);
+        }
+        std::vector<Piece> pieces;
+        for (uint32_t g = 0; g < ngroups; ++g) {
+            const size_t np = (tiles[g].size() + piece_tiles - 1) / piece_tiles;
+            for (size_t i = 0; i < np; ++i) pieces.push_back({(double)i / (double)np, g, (uint32_t)(i * piece_tiles)});
+        }
+        std::stable_sort(pieces.begin(), pieces.end(), [](const Piece &x, const Piece &y) { return x.at < y.at; });
+        for (const Piece &p : pieces) {
+            const size_t end = std::min<size_t>(tiles[p.g].size(), (size_t)p.first + piece_tiles);
+            for (size_t i = p.first; i < end; ++i) sched.push_back(tiles[p.g][i]);
+        }
     }
+    r->sched_bounds.push_back(r->ntiles);
     if (sched.size() != r->ntiles) return fail(PG_E_INVALID, "internal: schedule does not cover the tiles");
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&r->d_sched), (size_t)r->ntiles * 4));
     HIP_TRY(hipMemcpyAsync(r->d_sched, sched.data(), (size_t)r->ntiles * 4, hipMemcpyHostToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));
     return PG_OK;
+}
+
+extern "C" int pg_result_coschedule(pg_result *r, const uint32_t *contig_group, uint32_t piece_tiles) {
+    if (!r) return fail(PG_E_INVALID, "result is NULL");
+    return coschedule(r, contig_group, piece_tiles, nullptr, 0);
+}
+
+extern "C" int pg_result_coschedule_ranges(pg_result *r, const uint32_t *contig_group, uint32_t piece_tiles,
+                                           const uint32_t *range_first_contig, uint32_t nranges) {
+    if (!r) return fail(PG_E_INVALID, "result is NULL");
+    return coschedule(r, contig_group, piece_tiles, range_first_contig, nranges);
 }
 
 static int enqueue_epilogue(pg_result *r, hipStream_t st) {
@@ -1496,6 +1541,13 @@ static int contig_tiles(const pg_result *r, uint32_t first, uint32_t n, uint32_t
     return PG_OK;
 }
 
+// may the launch over tiles [t0, t0 + nt) follow the schedule?  (it is a permutation within each scheduled range)
+static bool sched_covers(const pg_result *r, uint32_t t0, uint32_t nt) {
+    if (!r->d_sched) return false;
+    const auto &b = r->sched_bounds;
+    return std::binary_search(b.begin(), b.end(), t0) && std::binary_search(b.begin(), b.end(), t0 + nt);
+}
+
 static int anchor_run(pg_result *r, uint32_t tile_base, uint32_t ntiles, bool whole) {
     pg_table *t = r->tbl;
     if (!t) return fail(PG_E_INVALID, "this result is a rows container (pg_result_create_rows): it has no table to probe");
@@ -1506,7 +1558,8 @@ static int anchor_run(pg_result *r, uint32_t tile_base, uint32_t ntiles, bool wh
     TableDesc T = make_desc(t);
     HIP_TRY(hipEventRecord(r->ev[0], st));
     HIP_TRY(launch_anchor(st, T, r->seqs->d_seqw, r->seqs->d_nmw, r->seqs->d_has_n, r->seqs->d_desc, r->d_ad,
-                          r->d_tile_contig, whole ? r->d_sched : nullptr, tile_base, ntiles, r->d_out1, r->out1_bytes));
+                          r->d_tile_contig, sched_covers(r, tile_base, ntiles) ? r->d_sched : nullptr, tile_base, ntiles,
+                          r->d_out1, r->out1_bytes));
     HIP_TRY(hipEventRecord(r->ev[1], st));
     r->ev_ok = true;
     r->ev_epi = false;
@@ -1612,22 +1665,26 @@ extern "C" int pg_result_extract_columns(pg_result *r, uint32_t g0, uint32_t wid
 }
 
 extern "C" int pg_result_merge_columns_range(pg_result *r, const void *d_src, uint32_t part0, uint32_t nparts, uint32_t per,
-                                             uint32_t first_contig, uint32_t ncontigs, int accumulate) {
+                                             uint32_t first_contig, uint32_t ncontigs, int accumulate,
+                                             uint64_t part_stride_bytes) {
     if (!r || !d_src) return fail(PG_E_INVALID, "pg_result_merge_columns: NULL argument");
     if (per == 0 || nparts == 0) return fail(PG_E_INVALID, "pg_result_merge_columns: empty partition");
     uint32_t t0, nt;
     if (int e = contig_tiles(r, first_contig, ncontigs, &t0, &nt)) return e;
+    const uint64_t own = (uint64_t)nt * 64ull * per;
+    if (part_stride_bytes == 0) part_stride_bytes = own;
+    if (part_stride_bytes < own || part_stride_bytes % 8) return fail(PG_E_INVALID, "pg_result_merge_columns_range: bad block stride");
     if (int e = use_device(r->ctx)) return e;
     if (int e = join_result(r)) return e;
     HIP_TRY(launch_cols_merge(r->ctx->stream, r->N, r->d_ad, r->d_tile_contig, t0, nt, r->d_out1, d_src, part0, nparts,
-                              (uint64_t)nt * 8ull * per, per, accumulate ? 1u : 0u));
+                              part_stride_bytes / 8, per, accumulate ? 1u : 0u));
     r->rows_valid = true;
     return PG_OK;
 }
 
 extern "C" int pg_result_merge_columns(pg_result *r, const void *d_src, uint32_t nparts, uint32_t per) {
     if (!r) return fail(PG_E_INVALID, "pg_result_merge_columns: NULL argument");
-    return pg_result_merge_columns_range(r, d_src, 0, nparts, per, 0, (uint32_t)r->ad.size(), 0);
+    return pg_result_merge_columns_range(r, d_src, 0, nparts, per, 0, (uint32_t)r->ad.size(), 0, 0);
 }
 
 extern "C" int pg_rows_epilogue(pg_result *r) {

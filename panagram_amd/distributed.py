@@ -276,18 +276,21 @@ def contig_chunks(lens: Sequence[int], k: int, limit: int = CHUNK_POSITIONS) -> 
 
 
 class ShardedAnchoring:
-    """The chunk pipeline of the genome-sharded mode for ONE process (rank): persistent exchange buffers, the
-    narrow per-anchor results against the current block table, the writers' full-row containers.
+    """The chunk pipeline of the genome-sharded mode for ONE process (rank): persistent exchange buffers, one
+    narrow result (rows of the block's genomes only) over ALL anchors' sequences, the writers' full-row containers.
 
         pipe = ShardedAnchoring(engine, ctx, k, N, per, rank, world, seqs, writer, geometry, group)
         pipe.run_pass(table_of_my_block, part0, nparts, accumulate, on_anchor_complete)
 
     ``seqs``: anchor name -> SeqSet (every rank holds every anchor's sequence); ``writer``: anchor name -> rank
-    that assembles its rows.  ``run_pass`` probes every anchor against ``table`` (None: this rank has no block in
-    the pass and contributes zeros), chunk by chunk:
+    that assembles its rows.  Every anchor's contigs are cut into chunks of about CHUNK_POSITIONS positions; chunk
+    GROUP i = the i-th chunk of every anchor — homologous stretches of the pangenome, probed in ONE co-scheduled
+    launch so that the anchors share their table lines in L2 exactly as in the replicated mode (the anchors'
+    sequences are laid out group by group in one merged seqset for this).  ``run_pass`` probes every group against
+    ``table`` (None: this rank has no block in the pass and contributes zeros):
 
-        probe chunk c  ->  extract its bit columns  ->  all-gather on the side stream  ->  merge on the writer
-                           probe chunk c+1 ...
+        probe group i  ->  extract its bit columns  ->  all-gather on the side stream  ->  merge on the writers
+                           probe group i+1 ...
 
     and calls ``on_anchor_complete(name, rows_container)`` on the writer once an anchor's last chunk is merged."""
 
@@ -304,13 +307,29 @@ class ShardedAnchoring:
                 raise RuntimeError("genome-sharded mode on several ranks needs torch.distributed initialised "
                                    "(python -m torch.distributed.run ... -m panagram_amd index ...)")
             self.dist = dist
-        # the work list: (anchor, first contig, contig count), the same on every rank
-        self.work = [(a, c0, nc) for a in seqs for c0, nc in contig_chunks(seqs[a].lens, k)]
-        self.last_of = {a: i for i, (a, _, _) in enumerate(self.work)}
         tile = engine.tile_positions()
-        self._nbytes = [sum((max(0, int(ln) - k + 1) + tile - 1) // tile for ln in seqs[a].lens[c0:c0 + nc]) * 64 * per
-                        for a, c0, nc in self.work]  # (= AnchorResult.columns_bytes_range, without a result)
-        biggest = max(self._nbytes or [0])
+        names = list(seqs)
+        chunks = {a: contig_chunks(seqs[a].lens, k) for a in names}
+        # groups[i] = [(anchor, first contig, count, tile offset inside the group)], the same on every rank
+        self.groups, parts, self.group_first, self.group_tiles = [], [], [], []
+        contig_anchor = []
+        for i in range(max([len(c) for c in chunks.values()] or [0])):
+            members, toff = [], 0
+            self.group_first.append(len(contig_anchor))
+            for ai, a in enumerate(names):
+                if i < len(chunks[a]):
+                    c0, nc = chunks[a][i]
+                    members.append((a, c0, nc, toff))
+                    toff += sum((max(0, int(ln) - k + 1) + tile - 1) // tile for ln in seqs[a].lens[c0:c0 + nc])
+                    parts.append((seqs[a], c0, nc))
+                    contig_anchor += [ai] * nc
+            self.groups.append(members)
+            self.group_tiles.append(toff)
+        self.last_group = {a: max(i for i, m in enumerate(self.groups) if any(x[0] == a for x in m))
+                           for a in names if chunks[a]}
+        self.merged = engine.SeqSet.concat_ranges(ctx, parts) if parts else None
+        self._contig_anchor = np.asarray(contig_anchor, np.uint32)
+        biggest = max(self.group_tiles or [0]) * 64 * per
         dev = ctx.torch_device()
         self.send = [torch.zeros(max(biggest, 8), dtype=torch.uint8, device=dev) for _ in range(2)]
         # (one rank: its own block is all there is — merged straight out of the send buffer)
@@ -320,6 +339,7 @@ class ShardedAnchoring:
             torch.cuda.synchronize(dev)  # the buffers were zeroed on torch's stream; the kernels run on the pipe's
         self.pipe = _Pipe(ctx, dev)
         self.full: Dict[str, object] = {}  # writer side: anchor -> rows container (kept across passes)
+        self._part, self._part_table = None, None  # the narrow result, kept while the table stays the same
         self.bytes_received = 0
 
     def container(self, a: str):
@@ -328,31 +348,41 @@ class ShardedAnchoring:
                                                                    **self.geometry)
         return self.full[a]
 
+    def _narrow(self, table):
+        if self._part is None or self._part_table is not table:
+            if self._part is not None:
+                self._part.close()
+            self._part = self.engine.AnchorResult(table, self.merged, colsums=False, rows_only=True)
+            if len(self.seqs) > 1:
+                self._part.coschedule_ranges(self._contig_anchor, self.group_first)
+            self._part_table = table
+        return self._part
+
     def run_pass(self, table, part0: int, nparts: int, accumulate: bool, on_anchor_complete=None) -> None:
-        pipe, work, per = self.pipe, self.work, self.per
-        part, part_of = None, None
-        pending = None  # (work index, slot, gather-done event) of the chunk whose gather is in flight
+        pipe, per = self.pipe, self.per
+        part = self._narrow(table) if (table is not None and self.merged is not None) else None
+        ncontigs = len(self._contig_anchor)
+        pending = None  # (group, slot, gather-done event) of the group whose gather is in flight
 
         def settle(pend):
             i, slot, ev = pend
-            a, c0, nc = work[i]
             pipe.main_waits(ev)  # (also what frees send[slot] for the next extract into it)
-            if self.writer[a] == self.rank:
-                # recv holds `world` blocks of the chunk's size, block j from rank j = genome block part0 + j
-                self.container(a).merge_columns_range(self.recv[slot].data_ptr(), part0, nparts, per, c0, nc,
-                                                      accumulate=accumulate)
-                if on_anchor_complete is not None and self.last_of[a] == i:
+            stride = self.group_tiles[i] * 64 * per  # recv holds `world` blocks of this size, block j = genome block part0 + j
+            for a, c0, nc, toff in self.groups[i]:
+                if self.writer[a] != self.rank:
+                    continue
+                self.container(a).merge_columns_range(self.recv[slot].data_ptr() + toff * 64 * per, part0, nparts, per,
+                                                      c0, nc, accumulate=accumulate, part_stride_bytes=stride)
+                if on_anchor_complete is not None and self.last_group[a] == i:
                     on_anchor_complete(a, self.full[a])
 
-        for i, (a, c0, nc) in enumerate(work):
-            slot, nbytes = i & 1, self._nbytes[i]
-            if table is not None:
-                if part_of != a:
-                    if part is not None:
-                        part.close()
-                    part, part_of = self.engine.AnchorResult(table, self.seqs[a], colsums=False, rows_only=True), a
-                part.run_range(c0, nc)
-                part.extract_columns_range(0, per, c0, nc, self.send[slot].data_ptr())
+        for i in range(len(self.groups)):
+            slot, nbytes = i & 1, self.group_tiles[i] * 64 * per
+            m0 = self.group_first[i]
+            cnt = (self.group_first[i + 1] if i + 1 < len(self.groups) else ncontigs) - m0
+            if part is not None:
+                part.run_range(m0, cnt)
+                part.extract_columns_range(0, per, m0, cnt, self.send[slot].data_ptr())
             else:
                 pipe.zero(self.send[slot][:nbytes])  # a rank without a block in this pass contributes zeros
             ready = pipe.mark_main()
@@ -367,14 +397,22 @@ class ShardedAnchoring:
             pending = (i, slot, ev)
         if pending is not None:
             settle(pending)
-        if part is not None:
-            part.close()
+
+    def drop_table(self):
+        """the block table is about to be closed: its narrow result goes first"""
+        if self._part is not None:
+            self._part.close()
+        self._part, self._part_table = None, None
 
     def close(self):
+        self.drop_table()
         for r in self.full.values():
             r.close()
         self.full = {}
         self.pipe.close()
+        if self.merged is not None:
+            self.merged.close()
+            self.merged = None
 
 
 def run_genome_sharded(index, nblocks: int, group=None, exchange_stats: Optional[dict] = None) -> None:
@@ -426,9 +464,10 @@ def run_genome_sharded(index, nblocks: int, group=None, exchange_stats: Optional
             sh.run_pass(tbl, p * world, min(world, nblocks - p * world), passes > 1, done)
             if tbl is not None:
                 ctx.synchronize()
+                sh.drop_table()
                 tbl.close()
         for a in anchors:  # an anchor FASTA without a record: nothing was exchanged, its (empty) files are still due
-            if a not in sh.last_of and writer[a] == rank:
+            if a not in sh.last_group and writer[a] == rank:
                 joins.append(_finish_anchor(index, a, sh.container(a), pool))
         for j in joins:
             j()
@@ -436,7 +475,7 @@ def run_genome_sharded(index, nblocks: int, group=None, exchange_stats: Optional
         pool.shutdown(wait=True)
         sh.close()
     if exchange_stats is not None:
-        exchange_stats.update(bytes_received=sh.bytes_received, passes=passes, nblocks=nblocks, per=per, chunks=len(sh.work))
+        exchange_stats.update(bytes_received=sh.bytes_received, passes=passes, nblocks=nblocks, per=per, chunks=len(sh.groups))
     if sh.dist is not None:
         sh.dist.barrier(group=group)
 

@@ -182,6 +182,24 @@ class SeqSet(_Owner):
         ss.lens = np.concatenate([x.lens for x in sets]) if sets else np.zeros(0, np.uint64)
         return ss
 
+    @classmethod
+    def concat_ranges(cls, ctx: Context, parts: Sequence[Tuple["SeqSet", int, int]]) -> "SeqSet":
+        """One seqset from contig ranges ``(set, first contig, count)``, in order (a set may appear several times)."""
+        ss = cls.__new__(cls)
+        ss.ctx, ss._lib = ctx, ctx._lib
+        n = len(parts)
+        arr = (C.c_void_p * n)(*[p[0]._h for p in parts])
+        first = np.array([p[1] for p in parts], np.uint32)
+        cnt = np.array([p[2] for p in parts], np.uint32)
+        h = C.c_void_p()
+        check(ss._lib.pg_seqset_concat_ranges(ctx._h, arr, _ptr(first), _ptr(cnt), n, C.byref(h)))
+        ss._h = h
+        ctx._adopt(ss)
+        ss.names = [nm for s_, f, c in parts for nm in s_.names[f:f + c]]
+        ss.lens = (np.concatenate([np.asarray(s_.lens[f:f + c], np.uint64) for s_, f, c in parts])
+                   if parts else np.zeros(0, np.uint64))
+        return ss
+
     def load_host(self, idx: int, seq) -> None:
         v = _bytes_view(seq)
         check(self._lib.pg_seqset_load_host(self._h, idx, _ptr(v), len(v)))
@@ -425,6 +443,15 @@ class AnchorResult:
             raise ValueError("contig_group needs one entry per contig")
         check(self._lib.pg_result_coschedule(self._h, _ptr(grp), piece_tiles))
 
+    def coschedule_ranges(self, contig_group, range_first_contig, piece_tiles: int = 0) -> None:
+        """``coschedule`` with the contigs cut into consecutive ranges (starting at the given contigs, the first at 0)
+        that are scheduled independently, so that ``run_range`` over whole ranges follows the schedule"""
+        grp = np.ascontiguousarray(contig_group, np.uint32)
+        rf = np.ascontiguousarray(range_first_contig, np.uint32)
+        if len(grp) != len(self.seqs.lens):
+            raise ValueError("contig_group needs one entry per contig")
+        check(self._lib.pg_result_coschedule_ranges(self._h, _ptr(grp), piece_tiles, _ptr(rf), len(rf)))
+
     def contig_colsums(self, idx: int = 0, ncontigs: Optional[int] = None) -> np.ndarray:
         n = len(self.seqs.lens) - idx if ncontigs is None else ncontigs
         out = np.zeros((n, self.ngenomes), np.uint64)
@@ -476,11 +503,12 @@ class AnchorResult:
         check(self._lib.pg_result_extract_columns_range(self._h, g0, width, first_contig, ncontigs, C.c_void_p(dev_ptr)))
 
     def merge_columns_range(self, dev_ptr: int, part0: int, nparts: int, per: int, first_contig: int, ncontigs: int,
-                            accumulate: bool = False) -> None:
+                            accumulate: bool = False, part_stride_bytes: int = 0) -> None:
         """genome blocks part0 .. part0+nparts-1 (``per`` genomes each) of a contig range -> rows (async);
-        ``accumulate`` ORs them into the rows instead of writing the rows whole"""
+        ``accumulate`` ORs them into the rows instead of writing the rows whole; ``part_stride_bytes``: distance
+        between the blocks at ``dev_ptr`` (0: the range's own block size)"""
         check(self._lib.pg_result_merge_columns_range(self._h, C.c_void_p(dev_ptr), part0, nparts, per, first_contig,
-                                                      ncontigs, 1 if accumulate else 0))
+                                                      ncontigs, 1 if accumulate else 0, part_stride_bytes))
 
     def rows_tensor(self):
         """Zero-copy torch uint8 view of the device bitmap.1 buffer (for RCCL collectives)."""

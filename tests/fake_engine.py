@@ -82,6 +82,10 @@ class SeqSet:
     def concat(cls, ctx, sets):
         return cls(ctx, [n for s in sets for n in s.names], [q for s in sets for q in s.seqs])
 
+    @classmethod
+    def concat_ranges(cls, ctx, parts):
+        return cls(ctx, [n for s, f, c in parts for n in s.names[f:f + c]], [q for s, f, c in parts for q in s.seqs[f:f + c]])
+
     def total_kmers(self, k):
         return int(sum(max(0, len(s) - k + 1) for s in self.seqs))
 
@@ -168,6 +172,9 @@ class AnchorResult:
     def coschedule(self, groups, piece_tiles=0):
         pass
 
+    def coschedule_ranges(self, groups, range_first, piece_tiles=0):
+        assert len(groups) == len(self._nk) and list(range_first) == sorted(set(range_first)) and range_first[0] == 0
+
     def run_range(self, c0, nc):
         for ci in range(c0, c0 + nc):
             if self._nk[ci]:
@@ -188,10 +195,11 @@ class AnchorResult:
         blk = po.extract_columns(self._rows[c0:c0 + nc], self.ngenomes, g0, width)
         _view(ptr, len(blk))[:] = blk
 
-    def merge_columns_range(self, ptr, part0, nparts, per, c0, nc, accumulate=False):
+    def merge_columns_range(self, ptr, part0, nparts, per, c0, nc, accumulate=False, part_stride_bytes=0):
         nb = self.columns_bytes_range(per, c0, nc)
-        src = _view(ptr, nb * nparts).copy()
-        blocks = [np.zeros(nb, np.uint8)] * part0 + [src[i * nb:(i + 1) * nb] for i in range(nparts)]
+        stride = part_stride_bytes or nb
+        src = _view(ptr, stride * (nparts - 1) + nb).copy()
+        blocks = [np.zeros(nb, np.uint8)] * part0 + [src[i * stride:i * stride + nb] for i in range(nparts)]
         merged = po.merge_columns(blocks, self._nk[c0:c0 + nc], self.ngenomes, per)
         for ci, m in zip(range(c0, c0 + nc), merged):
             self._rows[ci] = (self._rows[ci] | m) if accumulate else m

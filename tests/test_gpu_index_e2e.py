@@ -561,6 +561,7 @@ def test_bins_bits_on_a_hip_written_index(name, tmp_path, capsys):
                 assert bins_bits.chromosome_bars(ridx, f"g{g}", nm, bin_size, 100) == _bars_loop(occ, n, bin_size, 100)
     # the command-line form prints the script's three comma-terminated lines per chromosome
     g0 = f"g{int(fx['anchors'][0])}"
+    capsys.readouterr()  # (drop what Index.run() printed)
     assert bins_bits.main([str(out), g0]) == 0
     lines = capsys.readouterr().out.strip("\n").split("\n")
     assert len(lines) == 3 * len(po.parse_fasta_cpp(fx[f"fasta_{int(fx['anchors'][0])}"].tobytes()))
