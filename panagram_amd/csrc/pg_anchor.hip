@@ -1233,6 +1233,72 @@ __global__ __launch_bounds__(256) void k_window_stats(uint32_t N, const uint8_t 
 // Layout: tile t (512 positions) owns 8 slots of `width` u64 words: word (8t + s) * width + j =
 // genome g0 + j at positions 64 s .. 64 s + 63 of the tile.
 // ---------------------------------------------------------------------------
+// One-byte rows (a block of up to 8 genomes — config 5: ONE genome per GPU): a lane takes 8 consecutive positions
+// (one 8-byte load, the wave a whole tile) and gathers bit g of its 8 row bytes into one byte with a multiply;
+// byte (lane % 8) of word (slot = lane / 8, genome j).  10 instructions per genome and 8 positions instead of a
+// ballot per genome and position.
+__global__ __launch_bounds__(256) void k_cols_extract_b1(uint32_t N, const AnchorDesc *__restrict__ ad,
+                                                         const uint32_t *__restrict__ tile_contig, uint32_t tile_base,
+                                                         uint32_t ntiles, const uint8_t *__restrict__ out1, uint32_t g0,
+                                                         uint32_t width, uint8_t *__restrict__ dst) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t trel = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (trel >= ntiles) return;  // wave-uniform
+    const uint32_t tile = tile_base + trel;
+    const AnchorDesc a = ad[tile_contig[tile]];
+    const uint32_t p0 = (tile - a.tile0) * PROBE_TILE + 8 * lane;
+    uint32_t lo = 0, hi = 0;
+    if (p0 < a.nkmers) {  // (rows are padded to 16 bytes per contig: the 8-byte load stays inside)
+        const uint2 v = *reinterpret_cast<const uint2 *>(out1 + a.out_off + p0);
+        const uint32_t valid = min(8u, a.nkmers - p0);
+        lo = valid >= 4 ? v.x : (v.x & ((1u << (8 * valid)) - 1u));
+        hi = valid >= 8 ? v.y : (valid > 4 ? (v.y & ((1u << (8 * (valid - 4))) - 1u)) : 0u);
+    }
+    uint8_t *o = dst + ((uint64_t)trel * 8 + (lane >> 3)) * width * 8 + (lane & 7);
+    for (uint32_t j = 0; j < width; ++j) {
+        const uint32_t g = g0 + j;
+        uint32_t b = 0;
+        if (g < N) {  // bit g of rows 0..3 / 4..7 -> bits 0..3 / 4..7 (0x01020408: the four bits meet in bits 24..27)
+            const uint32_t a0 = ((lo >> g) & 0x01010101u) * 0x01020408u, a1 = ((hi >> g) & 0x01010101u) * 0x01020408u;
+            b = ((a0 >> 24) & 0xFu) | ((a1 >> 20) & 0xF0u);
+        }
+        o[8 * j] = (uint8_t)b;
+    }
+}
+
+// the reverse for one-byte rows (N <= 8): a lane rebuilds the rows of 8 consecutive positions — byte (lane % 8) of
+// each genome's word spread over 8 row bytes — and stores (or ORs) them as one 8-byte word
+__global__ __launch_bounds__(256) void k_cols_merge_b1(uint32_t N, const AnchorDesc *__restrict__ ad,
+                                                       const uint32_t *__restrict__ tile_contig, uint32_t tile_base,
+                                                       uint32_t ntiles, uint8_t *__restrict__ out1,
+                                                       const uint8_t *__restrict__ src, uint32_t part0, uint32_t nparts,
+                                                       uint64_t part_bytes, uint32_t per, uint32_t accumulate) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t trel = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (trel >= ntiles) return;
+    const uint32_t tile = tile_base + trel;
+    const AnchorDesc a = ad[tile_contig[tile]];
+    const uint32_t p0 = (tile - a.tile0) * PROBE_TILE + 8 * lane;
+    if (p0 >= a.nkmers) return;
+    const uint32_t gfirst = part0 * per, gend = min(N, (part0 + nparts) * per);
+    const uint8_t *in = src + ((uint64_t)trel * 8 + (lane >> 3)) * per * 8 + (lane & 7);
+    uint32_t lo = 0, hi = 0;
+    for (uint32_t g = gfirst; g < gend; ++g) {
+        const uint32_t part = g / per - part0, j = g % per;
+        const uint32_t b = in[(uint64_t)part * part_bytes + 8 * j];
+        const uint32_t rep = b * 0x01010101u;  // bit i of b -> bit 0 of byte i
+        lo |= ((((rep & 0x08040201u) + 0x7F7F7F7Fu) >> 7) & 0x01010101u) << g;
+        hi |= ((((rep & 0x80402010u) + 0x7F7F7F7Fu) >> 7) & 0x01010101u) << g;
+    }
+    uint2 *row = reinterpret_cast<uint2 *>(out1 + a.out_off + p0);
+    if (accumulate) {
+        const uint2 old = *row;
+        lo |= old.x;
+        hi |= old.y;
+    }
+    *row = make_uint2(lo, hi);  // (bits of positions past nkmers are zero in the blocks: the padding stays zero)
+}
+
 __global__ __launch_bounds__(256) void k_cols_extract(uint32_t N, const AnchorDesc *__restrict__ ad,
                                                       const uint32_t *__restrict__ tile_contig, uint32_t tile_base,
                                                       uint32_t ntiles, const uint8_t *__restrict__ out1, uint32_t g0,
@@ -1246,17 +1312,6 @@ __global__ __launch_bounds__(256) void k_cols_extract(uint32_t N, const AnchorDe
     const uint32_t p = (tile - a.tile0) * PROBE_TILE + sub * 64 + lane;
     const bool active = p < a.nkmers;
     const uint8_t *row = out1 + a.out_off + (uint64_t)p * nbytes;
-    if (nbytes == 1 && width <= 8) {  // one-byte rows (a block of up to 8 genomes): one load per position
-        const uint32_t v = active ? (uint32_t)row[0] : 0u;
-        unsigned long long mine = 0;
-        for (uint32_t j = 0; j < width; ++j) {
-            const uint32_t g = g0 + j;
-            const unsigned long long m = __ballot(g < N && ((v >> g) & 1u));
-            if ((uint32_t)lane == j) mine = m;
-        }
-        if ((uint32_t)lane < width) dst[slot * width + lane] = mine;
-        return;
-    }
     for (uint32_t j0 = 0; j0 < width; j0 += 64) {
         unsigned long long mine = 0;
         const uint32_t jn = min(64u, width - j0);
@@ -1464,8 +1519,12 @@ hipError_t launch_window_stats(hipStream_t st, uint32_t ngenomes, const uint8_t 
 hipError_t launch_cols_extract(hipStream_t st, uint32_t ngenomes, const AnchorDesc *ad, const uint32_t *tile_contig,
                                uint32_t tile_base, uint32_t ntiles, const uint8_t *out1, uint32_t g0, uint32_t width, void *dst) {
     if (ntiles == 0 || width == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_cols_extract, dim3((unsigned)(((uint64_t)ntiles * 8 + 3) / 4)), dim3(256), 0, st, ngenomes, ad,
-                       tile_contig, tile_base, ntiles, out1, g0, width, static_cast<unsigned long long *>(dst));
+    if (ngenomes <= 8 && g0 < 8)  // one-byte rows
+        hipLaunchKernelGGL(k_cols_extract_b1, dim3((ntiles + 3) / 4), dim3(256), 0, st, ngenomes, ad, tile_contig, tile_base,
+                           ntiles, out1, g0, width, static_cast<uint8_t *>(dst));
+    else
+        hipLaunchKernelGGL(k_cols_extract, dim3((unsigned)(((uint64_t)ntiles * 8 + 3) / 4)), dim3(256), 0, st, ngenomes, ad,
+                           tile_contig, tile_base, ntiles, out1, g0, width, static_cast<unsigned long long *>(dst));
     return hipGetLastError();
 }
 
@@ -1473,9 +1532,13 @@ hipError_t launch_cols_merge(hipStream_t st, uint32_t ngenomes, const AnchorDesc
                              uint32_t tile_base, uint32_t ntiles, uint8_t *out1, const void *src, uint32_t part0,
                              uint32_t nparts, uint64_t part_words, uint32_t per, uint32_t accumulate) {
     if (ntiles == 0 || per == 0 || nparts == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_cols_merge, dim3((unsigned)(((uint64_t)ntiles * 8 + 3) / 4)), dim3(256), 0, st, ngenomes, ad,
-                       tile_contig, tile_base, ntiles, out1, static_cast<const unsigned long long *>(src), part0, nparts,
-                       part_words, per, accumulate);
+    if (ngenomes <= 8)  // one-byte rows
+        hipLaunchKernelGGL(k_cols_merge_b1, dim3((ntiles + 3) / 4), dim3(256), 0, st, ngenomes, ad, tile_contig, tile_base,
+                           ntiles, out1, static_cast<const uint8_t *>(src), part0, nparts, part_words * 8, per, accumulate);
+    else
+        hipLaunchKernelGGL(k_cols_merge, dim3((unsigned)(((uint64_t)ntiles * 8 + 3) / 4)), dim3(256), 0, st, ngenomes, ad,
+                           tile_contig, tile_base, ntiles, out1, static_cast<const unsigned long long *>(src), part0, nparts,
+                           part_words, per, accumulate);
     return hipGetLastError();
 }
 
