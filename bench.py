@@ -420,6 +420,10 @@ def main():
     ap.add_argument("--no-other-shapes", action="store_true", help="skip the north-star-shape leg (64 x 200 Mb, k=21)")
     ap.add_argument("--no-sharded-leg", action="store_true", help="skip the genome-sharded pipeline leg")
     ap.add_argument("--cpu-sample-mb", type=float, default=20.0, help="bases per thread of the CPU baseline leg (about 12 s of CPU work)")
+    ap.add_argument("--emulate-rank", type=str, default="", metavar="R/N",
+                    help="one process plays rank R of an N-rank contig-sharded run (no collective): the N x longer "
+                         "pangenome, the replicated table and rank R's contig group, for checking the multi-GPU "
+                         "set-up on a one-GPU box; the reported value is this rank's alone")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -441,6 +445,9 @@ def main():
     G, k, C = args.genomes, args.k, args.contigs
     L = int(args.genome_mb * 1e6)
     contig_lens = [L // C] * C
+    groups, my_group = world, rank
+    if args.emulate_rank and world == 1:
+        my_group, groups = (int(x) for x in args.emulate_rank.split("/"))
     default_shape = (G, round(args.genome_mb), k, C, args.d) == (8, 100, 21, 5, 0.01)
 
     if args.mode == "genome-sharded":
@@ -460,8 +467,8 @@ def main():
 
     # ---- k-mer set construction on the GPU (replaces kmc + kmc_tools; timed separately) ----
     keep_ascii = rank == 0 and world == 1 and not args.no_cpu_baseline
-    pg = Pangenome(ctx, dev, G, contig_lens, args.d, args.seed, k, groups=world, my_group=rank, keep_ascii=keep_ascii,
-                   minimizer=args.minimizer, rehash_kpb=None if (args.no_rehash or world > 1) else args.keys_per_bucket)
+    pg = Pangenome(ctx, dev, G, contig_lens, args.d, args.seed, k, groups=groups, my_group=my_group, keep_ascii=keep_ascii,
+                   minimizer=args.minimizer, rehash_kpb=None if (args.no_rehash or groups > 1) else args.keys_per_bucket)
     st = pg.stats
     pos_per_step = sum(pg.pos_per_genome)
 
@@ -500,7 +507,11 @@ def main():
                        (64, 200, 31): "BASELINE.json configs[3] at full size, all 64 genomes anchored",
                        (8, 3000, 21): "the shape of BASELINE.json configs[4] on ONE GPU, at a divergence whose table fits"
                        }.get(shape, "not a BASELINE.json config")
-    if world == 1:
+    if groups > 1 and world == 1:
+        workload = (f"EMULATED rank {my_group} of {groups}: {G} synthetic {args.genome_mb * groups:g} Mb genomes, table of all of it, "
+                    f"this rank's {C} contigs of every genome anchored")
+        parallelism = f"one GPU playing rank {my_group} of a contig-sharded x{groups} run"
+    elif world == 1:
         workload = (f"{G} synthetic {args.genome_mb:g} Mb genomes ({C} contigs each), k={k}, d={args.d}, all {G} genomes "
                     f"anchored per step, table resident in one GPU's HBM ({baseline_config})")
         parallelism = "one GPU"

@@ -47,21 +47,42 @@ constexpr int PROBE_SEQW = ((PROBE_TILE + 31) / 32 + 6 + 3) & ~3;  // staged 32-
 // returns 1 = found, 0 = absent (line not full), -1 = absent from a full line
 template <bool TWO, int SLOTS>
 __device__ __forceinline__ int scan_line_lds(const uint4 *line, uint64_t key, uint32_t &m0, uint32_t &m1) {
-    // all SLOTS key reads are issued together (one LDS wait), the hit slot is selected in
-    // registers, and only the masks of that one slot are read afterwards
+    // all SLOTS key reads are issued together (one LDS wait); one compare per slot into a scalar lane mask;
+    // the scalar unit folds the masks into the three bits of the hit slot's number (at most one slot holds the
+    // key), three v_cndmask turn them into the slot's byte offset, and only that slot's masks are read
     uint64_t kk[SLOTS];
 #pragma unroll
     for (int sl = 0; sl < SLOTS; ++sl) kk[sl] = *reinterpret_cast<const uint64_t *>(line + sl);
-    int hit = -1;
-#pragma unroll
-    for (int sl = 0; sl < SLOTS; ++sl) hit = (kk[sl] == key) ? sl : hit;
     m0 = m1 = 0;
-    if (hit >= 0) {
-        const uint2 mk = *reinterpret_cast<const uint2 *>(reinterpret_cast<const uint8_t *>(line + hit) + 8);
-        m0 = mk.x;
-        if (TWO) m1 = mk.y;
+    if constexpr (SLOTS == 8) {
+        // (ballot of a compare = v_cmp_eq_u64 with a scalar destination; inverse_ballot = the SGPR pair used as a
+        // v_cndmask selector / exec mask: the compiler's lowering of `kk == key ? sl : hit` goes through VCC with
+        // two VALU instructions and a wait state per slot)
+        unsigned long long e[8];
+#pragma unroll
+        for (int sl = 0; sl < 8; ++sl) e[sl] = __builtin_amdgcn_ballot_w64(kk[sl] == key);
+        const unsigned long long b0 = e[1] | e[3] | e[5] | e[7], b1 = e[2] | e[3] | e[6] | e[7], b2 = e[4] | e[5] | e[6] | e[7];
+        const unsigned long long any = b0 | b1 | b2 | e[0];
+        const bool hit = __builtin_amdgcn_inverse_ballot_w64(any);
+        if (hit) {
+            const uint32_t off = (__builtin_amdgcn_inverse_ballot_w64(b0) ? 16u : 0u) | (__builtin_amdgcn_inverse_ballot_w64(b1) ? 32u : 0u) |
+                                 (__builtin_amdgcn_inverse_ballot_w64(b2) ? 64u : 0u);
+            const uint2 mk = *reinterpret_cast<const uint2 *>(reinterpret_cast<const uint8_t *>(line) + off + 8);
+            m0 = mk.x;
+            if (TWO) m1 = mk.y;
+        }
+        return hit ? 1 : (kk[SLOTS - 1] == EMPTY_KEY ? 0 : -1);
+    } else {
+        int hit = -1;
+#pragma unroll
+        for (int sl = 0; sl < SLOTS; ++sl) hit = (kk[sl] == key) ? sl : hit;
+        if (hit >= 0) {
+            const uint2 mk = *reinterpret_cast<const uint2 *>(reinterpret_cast<const uint8_t *>(line + hit) + 8);
+            m0 = mk.x;
+            if (TWO) m1 = mk.y;
+        }
+        return hit >= 0 ? 1 : (kk[SLOTS - 1] == EMPTY_KEY ? 0 : -1);
     }
-    return hit >= 0 ? 1 : (kk[SLOTS - 1] == EMPTY_KEY ? 0 : -1);
 }
 
 // one line straight from global memory: the 8 slot loads are issued together (one latency)
@@ -155,6 +176,26 @@ __device__ __forceinline__ void store_row(uint8_t *row, uint32_t m0, uint32_t m1
 __device__ __forceinline__ uint32_t lane_up1(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
 }
+// Sliding minimum over the last W lanes (lanes below W-1 see shorter windows): m <- min(own, m of the lane below),
+// W-1 times, each step ONE instruction — the DPP shift is the min's own source modifier; lane 0, which has no lane
+// below, is left alone and keeps its m.  6 instructions for W = 7 where shuffle-doubling took 6 moves + 3 min +
+// 3 selects.  (s_nop 1: a DPP source written by the previous VALU instruction needs two wait states; one asm
+// block, so that the compiler does not pad every step once more)
+#define PG_DPPMIN "s_nop 1\n\tv_min_u32_dpp %0, %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+template <int W>
+__device__ __forceinline__ uint32_t sliding_min(uint32_t x) {
+    uint32_t m = x;
+    if constexpr (W == 2) asm(PG_DPPMIN : "+v"(m) : "v"(x));
+    if constexpr (W == 3) asm(PG_DPPMIN PG_DPPMIN : "+v"(m) : "v"(x));
+    if constexpr (W == 4) asm(PG_DPPMIN PG_DPPMIN PG_DPPMIN : "+v"(m) : "v"(x));
+    if constexpr (W == 5) asm(PG_DPPMIN PG_DPPMIN PG_DPPMIN PG_DPPMIN : "+v"(m) : "v"(x));
+    if constexpr (W == 6) asm(PG_DPPMIN PG_DPPMIN PG_DPPMIN PG_DPPMIN PG_DPPMIN : "+v"(m) : "v"(x));
+    if constexpr (W == 7) asm(PG_DPPMIN PG_DPPMIN PG_DPPMIN PG_DPPMIN PG_DPPMIN PG_DPPMIN : "+v"(m) : "v"(x));
+    if constexpr (W == 8) asm(PG_DPPMIN PG_DPPMIN PG_DPPMIN PG_DPPMIN PG_DPPMIN PG_DPPMIN PG_DPPMIN : "+v"(m) : "v"(x));
+    static_assert(W >= 1 && W <= 8, "minimizer window");
+    return m;
+}
+#undef PG_DPPMIN
 // inclusive count of set bits of `mask` at lanes <= this lane
 __device__ __forceinline__ uint32_t lanes_le_count(unsigned long long mask, bool own) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u)) + (own ? 1u : 0u);
@@ -193,7 +234,7 @@ __device__ __forceinline__ void drain_queue(const SubTable &st, uint32_t qn, con
             const uint32_t ec = act ? e : qn - 1;
             const uint32_t line = q_line[ec], step = q_step[ec];
             const uint32_t pl = q_pl[ec];
-            const uint64_t key = canonical_from_le(extract_bases(sw, pl), k);
+            const uint64_t key = canonical_from_le(extract_bases32(reinterpret_cast<const uint32_t *>(sw), pl), k);
             const uint32_t prev_line = lane_up1(line);
             const bool leader = act && (lane == 0 || line != prev_line);
             const unsigned long long lmask = __ballot(leader);
@@ -206,11 +247,10 @@ __device__ __forceinline__ void drain_queue(const SubTable &st, uint32_t qn, con
                 if (leader && rid - r0 < nl) lines_w[rid - r0] = line;
                 __syncthreads();
                 uint4 v[STAGE_ITERS];
-                const uint32_t total = nl * SLOTS;
 #pragma unroll
                 for (int u = 0; u < STAGE_ITERS; ++u) {
-                    const uint32_t idx = min((uint32_t)(u * 64 + lane), total - 1);
-                    v[u] = *reinterpret_cast<const uint4 *>(st.buckets + (uint64_t)lines_w[idx / SLOTS] * BUCKET_BYTES + (idx % SLOTS) * 16);
+                    const uint32_t ls = min((uint32_t)(u * (64 / SLOTS) + lane / SLOTS), nl - 1u);
+                    v[u] = *reinterpret_cast<const uint4 *>(st.buckets + (((uint64_t)lines_w[ls] * BUCKET_BYTES) | ((lane % SLOTS) * 16u)));
                 }
 #pragma unroll
                 for (int u = 0; u < STAGE_ITERS; ++u) {
@@ -242,7 +282,7 @@ __device__ __forceinline__ void drain_queue(const SubTable &st, uint32_t qn, con
     }
 }
 
-template <int W_C, bool TWO, int ROWMODE, int SLOTS>
+template <int W_C, bool TWO, int ROWMODE, int SLOTS, bool M64>  // M64: m-mers longer than 16 bases
 __global__ __launch_bounds__(64) void k_probe(const SubTable st, const uint64_t *__restrict__ seqw,
                                               const uint32_t *__restrict__ nmw, const uint32_t *__restrict__ has_n,
                                               const SeqDesc *__restrict__ sd, const AnchorDesc *__restrict__ ad,
@@ -316,32 +356,25 @@ __global__ __launch_bounds__(64) void k_probe(const SubTable st, const uint64_t 
                 // tile, which have no k-mer, take theirs out of the tile's first k-mer): forward strand
                 // from X, reverse complement from B — no second pass over the sequence words
                 const uint32_t off = (uint32_t)(pl[u] + HALO) - pq;  // m-mer's offset inside the k-mer, 0..HALO
-                {
-                    const uint64_t fa = (X >> (2 * off)) & mm64;             // one path for every m: for m <= 16
-                    const uint64_t fr = (B >> (2 * (HALO - off))) & mm64;   // the high halves are zero and
-                    grp[u] = mmer_rank(fa < fr ? fa : fr);                   // mmer_rank is mz_order of the m-mer
+                if constexpr (!M64) {  // m-mers of up to 32 bits: one funnel shift each, no 64-bit arithmetic
+                    const uint32_t mm32 = (uint32_t)mm64;
+                    const uint32_t fa = __builtin_amdgcn_alignbit((uint32_t)(X >> 32), (uint32_t)X, 2 * off) & mm32;
+                    const uint32_t fr = __builtin_amdgcn_alignbit((uint32_t)(B >> 32), (uint32_t)B, 2 * (HALO - off)) & mm32;
+                    grp[u] = mz_order(min(fa, fr));  // (= mmer_rank: its fold of the high half is the identity here)
+                } else {
+                    const uint64_t fa = (X >> (2 * off)) & mm64;
+                    const uint64_t fr = (B >> (2 * (HALO - off))) & mm64;
+                    grp[u] = mmer_rank(fa < fr ? fa : fr);
                 }
             } else {
                 grp[u] = group_of_key(key[u]);
             }
         }
         if (W_C) {
-            // sliding minimum over lanes [lane-W_C+1, lane] by doubling (lanes below the halo
-            // read their own value back: they are never active)
+            // sliding minimum over lanes [lane-W_C+1, lane]: m <- min(own rank, m of the lane below), W_C-1 times
+            // (the first lanes of the wave see shorter windows: they are halo lanes, never active)
 #pragma unroll
-            for (int off = 1; off < W_C; off <<= 1) {
-                const int d = (2 * off <= W_C) ? off : (W_C - off);  // 3: 1,1  5: 1,2,1  6: 1,2,2  7: 1,2,3  8: 1,2,4
-                // (d DPP moves per shift: one ds_bpermute instead measured 1 % slower — the LDS pipe is
-                // as busy as the VALU here)
-                uint32_t up[NB];
-#pragma unroll
-                for (int u = 0; u < NB; ++u) {
-                    up[u] = grp[u];
-                    for (int i = 0; i < d; ++i) up[u] = lane_up1(up[u]);
-                }
-#pragma unroll
-                for (int u = 0; u < NB; ++u) grp[u] = min(grp[u], lane >= d ? up[u] : grp[u]);
-            }
+            for (int u = 0; u < NB; ++u) grp[u] = sliding_min<W_C ? W_C : 1>(grp[u]);
         }
         // ---- runs of equal home line among the active lanes ----
         uint32_t prev_line[NB];
@@ -374,15 +407,17 @@ __global__ __launch_bounds__(64) void k_probe(const SubTable st, const uint64_t 
             // Loads AND LDS writes are unconditional (chunks past the last line re-copy its last
             // chunk into unused buffer lines): any predicate here makes the compiler sink each load
             // into its own branch and wait for it there
+            // (a lane always fetches chunk lane % SLOTS of a line — an invariant offset OR-ed into line << 7 — and
+            // only the line's number is clamped: three address instructions per load)
             uint4 v[NB][STAGE_ITERS];
 #pragma unroll
             for (int u = 0; u < NB; ++u) {
-                const uint32_t total = max(nl[u], 1u) * SLOTS;
+                const uint32_t last = max(nl[u], 1u) - 1u;
 #pragma unroll
                 for (int it = 0; it < STAGE_ITERS; ++it) {
-                    const uint32_t idx = min((uint32_t)(it * 64 + lane), total - 1);
-                    const uint32_t ln = nl[u] ? lines_w[u][idx / SLOTS] : 0u;
-                    v[u][it] = *reinterpret_cast<const uint4 *>(st.buckets + (uint64_t)ln * BUCKET_BYTES + (idx % SLOTS) * 16);
+                    const uint32_t ls = min((uint32_t)(it * (64 / SLOTS) + lane / SLOTS), last);
+                    const uint32_t ln = nl[u] ? lines_w[u][ls] : 0u;
+                    v[u][it] = *reinterpret_cast<const uint4 *>(st.buckets + (((uint64_t)ln * BUCKET_BYTES) | ((lane % SLOTS) * 16u)));
                 }
             }
 #pragma unroll
@@ -1391,8 +1426,12 @@ template <int W_C, bool TWO, int ROWMODE, int SLOTS>
 static hipError_t probe_t(hipStream_t s, uint32_t ntiles, const SubTable &st, const uint64_t *seqw, const uint32_t *nmw,
                           const uint32_t *has_n, const SeqDesc *sd, const AnchorDesc *ad, const uint32_t *tile_contig,
                           const uint32_t *sched, uint32_t tile_base, uint8_t *out1, uint32_t nbytes, const RowCols &rc) {
-    hipLaunchKernelGGL((k_probe<W_C, TWO, ROWMODE, SLOTS>), dim3(ntiles), dim3(64), 0, s, st, seqw, nmw, has_n, sd, ad,
-                       tile_contig, sched, tile_base, out1, nbytes, rc);
+    if (W_C && st.m > 16)
+        hipLaunchKernelGGL((k_probe<W_C, TWO, ROWMODE, SLOTS, true>), dim3(ntiles), dim3(64), 0, s, st, seqw, nmw, has_n, sd, ad,
+                           tile_contig, sched, tile_base, out1, nbytes, rc);
+    else
+        hipLaunchKernelGGL((k_probe<W_C, TWO, ROWMODE, SLOTS, false>), dim3(ntiles), dim3(64), 0, s, st, seqw, nmw, has_n, sd, ad,
+                           tile_contig, sched, tile_base, out1, nbytes, rc);
     return hipGetLastError();
 }
 

@@ -261,8 +261,10 @@ class _Pipe:
             self.ctx.set_stream(None)
 
 
-def contig_chunks(lens: Sequence[int], k: int, limit: int = CHUNK_POSITIONS) -> List[Tuple[int, int]]:
-    """Contiguous contig ranges ``(first, count)`` of about ``limit`` k-mer positions each (a contig is never cut)."""
+def contig_chunks(lens: Sequence[int], k: int, limit: Optional[int] = None) -> List[Tuple[int, int]]:
+    """Contiguous contig ranges ``(first, count)`` of about ``limit`` (default CHUNK_POSITIONS) k-mer positions each
+    (a contig is never cut)."""
+    limit = CHUNK_POSITIONS if limit is None else limit
     out, first, acc = [], 0, 0
     for ci, ln in enumerate(lens):
         nk = max(0, int(ln) - k + 1)
@@ -295,13 +297,16 @@ class ShardedAnchoring:
     and calls ``on_anchor_complete(name, rows_container)`` on the writer once an anchor's last chunk is merged."""
 
     def __init__(self, engine, ctx, k: int, ngenomes: int, per: int, rank: int, world: int, seqs: Dict[str, object],
-                 writer: Dict[str, int], geometry: Optional[dict] = None, group=None):
+                 writer: Dict[str, int], geometry: Optional[dict] = None, group=None, always_gather: bool = False):
+        """``always_gather``: issue the collective even with one rank (a process group of size 1) — the side-stream
+        and RCCL code path on a single GPU."""
         import torch
         self.engine, self.ctx, self.k, self.N, self.per = engine, ctx, k, ngenomes, per
         self.rank, self.world, self.seqs, self.writer, self.group = rank, max(1, world), seqs, writer, group
         self.geometry = geometry or {}
         self.dist = None
-        if self.world > 1:
+        self.collective = self.world > 1 or always_gather
+        if self.collective:
             import torch.distributed as dist
             if not dist.is_initialized():
                 raise RuntimeError("genome-sharded mode on several ranks needs torch.distributed initialised "
@@ -334,7 +339,7 @@ class ShardedAnchoring:
         self.send = [torch.zeros(max(biggest, 8), dtype=torch.uint8, device=dev) for _ in range(2)]
         # (one rank: its own block is all there is — merged straight out of the send buffer)
         self.recv = ([torch.zeros(max(biggest, 8) * self.world, dtype=torch.uint8, device=dev) for _ in range(2)]
-                     if self.world > 1 else self.send)
+                     if self.collective else self.send)
         if dev.type == "cuda":
             torch.cuda.synchronize(dev)  # the buffers were zeroed on torch's stream; the kernels run on the pipe's
         self.pipe = _Pipe(ctx, dev)
@@ -386,7 +391,7 @@ class ShardedAnchoring:
             else:
                 pipe.zero(self.send[slot][:nbytes])  # a rank without a block in this pass contributes zeros
             ready = pipe.mark_main()
-            if self.world > 1:
+            if self.collective:
                 out_t, in_t = self.recv[slot][:nbytes * self.world], self.send[slot][:nbytes]
                 ev = pipe.on_comm(ready, lambda o=out_t, t=in_t: self.dist.all_gather_into_tensor(o, t, group=self.group))
                 self.bytes_received += nbytes * (self.world - 1)

@@ -220,3 +220,51 @@ def test_range_probe_extract_merge_equals_whole(ctx):
         assert np.array_equal(full.download(ci, want_bitmap100=False)[0], whole.download(ci, want_bitmap100=False)[0] & mask)
     for x in (full, piece, whole, ss, t):
         x.close()
+
+
+def test_sharded_pipeline_through_rccl_on_one_rank(ctx):
+    """The pipeline's collective path on the one GPU of the test box: a process group of size 1 over "nccl"
+    (= RCCL), all_gather_into_tensor issued on the side stream for every chunk group, merged rows == golden."""
+    import os
+    import torch.distributed as dist
+    from panagram_amd import distributed as pdist
+    from panagram_amd import engine
+    fx = H.load_case("n8_k21")
+    n, k = int(fx["ngenomes"]), int(fx["k"])
+    anchors = [int(g) for g in fx["anchors"]]
+    seqs = {f"g{g}": engine.SeqSet.from_fasta(ctx, fx[f"fasta_{g}"].tobytes()) for g in anchors}
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29600 + os.getpid() % 300))
+    torch.cuda.set_device(0)
+    started = not dist.is_initialized()
+    if started:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    old = pdist.CHUNK_POSITIONS
+    try:
+        pdist.CHUNK_POSITIONS = 1000  # several chunk groups: double buffering across the two streams
+        tbl = engine.PanTable(ctx, k, n)
+        for g in range(n):
+            ss = engine.SeqSet.from_fasta(ctx, fx[f"fasta_{g}"].tobytes())
+            tbl.insert_seqset(g, ss)
+            ss.close()
+        sh = pdist.ShardedAnchoring(engine, ctx, k, n, n, 0, 1, seqs, {a: 0 for a in seqs}, None, None, always_gather=True)
+        assert len(sh.groups) > 1
+        done = []
+        for _ in range(2):  # the second pass overwrites the first: same rows
+            sh.run_pass(tbl, 0, 1, False, lambda a, res: (res.rows_epilogue(), done.append(a)))
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        assert sh.bytes_received == 0 and sorted(set(done)) == sorted(seqs)
+        for g in anchors:
+            res = sh.full[f"g{g}"]
+            b1 = b"".join(res.download(ci)[0].tobytes() for ci in range(len(res.seqs.names)))
+            b100 = b"".join(res.download(ci)[1].tobytes() for ci in range(len(res.seqs.names)))
+            assert b1 == fx[f"a{g}_bitmap1"].tobytes() and b100 == fx[f"a{g}_bitmap100"].tobytes()
+        sh.close()
+        tbl.close()
+    finally:
+        pdist.CHUNK_POSITIONS = old
+        for s_ in seqs.values():
+            s_.close()
+        if started:
+            dist.destroy_process_group()

@@ -54,12 +54,28 @@
 #define A_XAD(n) asm volatile("v_xad_u32 %0, %0, %1, %1" : "+v"(r##n) : "v"(seed));
 #define A_PERM(n) asm volatile("v_perm_b32 %0, %0, %1, %1" : "+v"(r##n) : "v"(seed));
 #define A_BCNT(n) asm volatile("v_bcnt_u32_b32 %0, %0, %1" : "+v"(r##n) : "v"(seed));
+#define A_MINDPP(n) asm volatile("s_nop 1\n v_min_u32_dpp %0, %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(r##n) : "v"(seed));
+#define A_MINDPPROW(n) asm volatile("s_nop 1\n v_min_u32_dpp %0, %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(r##n) : "v"(seed));
+#define A_CMP64S(n) asm volatile("v_cmp_ne_u64_e64 %0, %1, %2" : "=s"(mask) : "v"(q##n), "v"(q0));
+#define A_CMP32S(n) asm volatile("v_cmp_ne_u32_e64 %0, %1, %2" : "=s"(mask) : "v"(r##n), "v"(seed));
+#define A_NOT(n) asm volatile("v_not_b32 %0, %0" : "+v"(r##n));
+#define A_LSHL(n) asm volatile("v_lshlrev_b32 %0, 3, %0" : "+v"(r##n));
+#define A_LSHLADD(n) asm volatile("v_lshl_add_u32 %0, %0, 3, %1" : "+v"(r##n) : "v"(seed));
+#define A_ADD3(n) asm volatile("v_add3_u32 %0, %0, %1, %1" : "+v"(r##n) : "v"(seed));
+#define A_OR3(n) asm volatile("v_or3_b32 %0, %0, %1, %1" : "+v"(r##n) : "v"(seed));
+#define A_AND(n) asm volatile("v_and_b32 %0, %0, %1" : "+v"(r##n) : "v"(seed));
+#define A_BFE(n) asm volatile("v_bfe_u32 %0, %0, 3, 5" : "+v"(r##n));
+#define A_LSHLADD64(n) asm volatile("v_lshl_add_u64 %0, %0, 2, %1" : "+v"(q##n) : "v"(q0));
+#define A_SHL64(n) asm volatile("v_lshlrev_b64 %0, 7, %0" : "+v"(q##n));
 
 KERNEL(k_add, A_ADD) KERNEL(k_xor, A_XOR) KERNEL(k_mullo, A_MULLO) KERNEL(k_mulhi, A_MULHI) KERNEL(k_mul24, A_MUL24)
 KERNEL(k_align, A_ALIGN) KERNEL(k_bfrev, A_BFREV) KERNEL(k_bfi, A_BFI) KERNEL(k_min, A_MIN) KERNEL(k_dpp, A_DPP)
 KERNEL(k_dpprow, A_DPPROW) KERNEL(k_shr64, A_SHR64) KERNEL(k_shr64v, A_SHR64V) KERNEL(k_add64, A_ADD64)
 KERNEL(k_cmp64, A_CMP64) KERNEL(k_cmp32, A_CMP32) KERNEL(k_cndm, A_CNDM) KERNEL(k_mad64, A_MAD64) KERNEL(k_mbcnt, A_MBCNT)
 KERNEL(k_mov64, A_MOV64) KERNEL(k_pkadd, A_PKADD) KERNEL(k_andor, A_AND_OR) KERNEL(k_xad, A_XAD) KERNEL(k_perm, A_PERM)
+KERNEL(k_mindpp, A_MINDPP) KERNEL(k_mindpprow, A_MINDPPROW) KERNEL(k_cmp64s, A_CMP64S) KERNEL(k_cmp32s, A_CMP32S) KERNEL(k_not, A_NOT)
+KERNEL(k_lshl, A_LSHL) KERNEL(k_lshladd, A_LSHLADD) KERNEL(k_add3, A_ADD3) KERNEL(k_or3, A_OR3) KERNEL(k_and, A_AND) KERNEL(k_bfe, A_BFE)
+KERNEL(k_lshladd64, A_LSHLADD64) KERNEL(k_shl64, A_SHL64)
 KERNEL(k_bcnt, A_BCNT) KERNEL(k_cndm2, A_CNDM2) KERNEL(k_cndms, A_CNDMS) KERNEL(k_cmpcnd, A_CMPCND) KERNEL(k_cmpcnds, A_CMPCNDS) KERNEL(k_cmp64cnd, A_CMP64CND)
 
 template <typename K>
@@ -93,5 +109,7 @@ int main() {
     RUN(k_dpprow) RUN(k_shr64) RUN(k_shr64v) RUN(k_add64) RUN(k_cmp64) RUN(k_cmp32) RUN(k_cndm) RUN(k_mad64) RUN(k_mbcnt)
     RUN(k_cndm2) RUN(k_cndms) RUN(k_cmpcnd) RUN(k_cmpcnds) RUN(k_cmp64cnd) RUN(k_add) RUN(k_xor)
     RUN(k_mov64) RUN(k_pkadd) RUN(k_andor) RUN(k_xad) RUN(k_perm) RUN(k_bcnt)
+    RUN(k_mindpp) RUN(k_mindpprow) RUN(k_cmp64s) RUN(k_cmp32s) RUN(k_not) RUN(k_lshl) RUN(k_lshladd) RUN(k_add3) RUN(k_or3) RUN(k_and)
+    RUN(k_bfe) RUN(k_lshladd64) RUN(k_shl64)
     return 0;
 }
