@@ -104,13 +104,20 @@ int pg_table_insert_seqset_min(pg_table *tbl, int genome_idx, const pg_seqset *s
 int pg_table_insert_keys(pg_table *tbl, int db_idx, const uint64_t *keys,
                          const uint32_t *counters, uint64_t n);
 
-/* load a real KMC1-layout database (kmc_tools output) as
- * group db_idx: the in-memory images of X.kmc_pre / X.kmc_suf.  Counters outside
- * the header's [min_count,max_count] read as 0 as in KMC.  Replaces
- * CKMCFile::OpenForRA (cpp/anchor.cpp:29, index.py:859-860) — but returns
- * PG_E_FORMAT instead of silently yielding zeros. */
+/* load a real KMC database as group db_idx: the images of X.kmc_pre / X.kmc_suf (host memory; a read-only
+ * memory map of the files is fine, they are only read once, chunk by chunk).  Both layouts
+ * CKMCFile::OpenForRA accepts (cpp/anchor.cpp:29, index.py:859-860): KMC1 (kmc_version 0: kmc_tools output,
+ * SURVEY.md Appendix A) and KMC2 (kmc_version 0x200: what `kmc` itself writes, workflow/Snakefile:101-104 —
+ * one prefix LUT per signature bin).  The records are turned into table inserts on the GPU (k_import_kmc);
+ * counters outside the header's [min_count,max_count] read as 0 as in KMC.  Returns PG_E_FORMAT on an
+ * ill-formed database instead of silently yielding zeros like the reference.  pg_table_load_kmc1 is the same
+ * function under its first name. */
+int pg_table_load_kmc(pg_table *tbl, int db_idx, const void *pre, size_t pre_len,
+                      const void *suf, size_t suf_len);
 int pg_table_load_kmc1(pg_table *tbl, int db_idx, const void *pre, size_t pre_len,
                        const void *suf, size_t suf_len);
+/* k-mer length of a KMC database from its .kmc_pre image (host only) */
+int pg_kmc_kmer_length(const void *pre, size_t pre_len, uint32_t *k);
 
 /* statistics: distinct keys, slot capacity, bucket count, bytes, summed over sub-tables */
 int pg_table_stats(pg_table *tbl, uint64_t *nkeys, uint64_t *nslots, uint64_t *nbuckets,

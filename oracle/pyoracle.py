@@ -270,6 +270,131 @@ def parse_kmc1(pre: bytes, suf: bytes):
 
 
 # ---------------------------------------------------------------------------
+# KMC2 layout (kmc_version 0x200: what `kmc` itself writes, workflow/Snakefile:101-104).  KMC is an un-vendored
+# third-party dependency (refresh-bio/KMC v3.2.1, setup.py:28-31); this restates its published file description
+# (kmc_api: [marker][one prefix LUT per bin][signature map][header][header position][marker]) and its signature
+# rule (kmc_api/mmer.h).  PINNED the only way available here: databases written by write_kmc2 are READ BY THE
+# REFERENCE BINARY (cpp/run_anchor links KMC's reader), whose outputs must equal the ones it gives for the same
+# k-mers in KMC1 files (tests/golden/make_golden.py: kmc2_* fixtures).
+# ---------------------------------------------------------------------------
+def _mmer_allowed(mmer: int, length: int) -> bool:
+    """KMC's restriction on signatures: no m-mer starting with AAA or ACA, none with AA anywhere but at its start"""
+    if (mmer & 0x3F) == 0x3F:   # ends with TTT
+        return False
+    if (mmer & 0x3F) == 0x3B:   # ends with TGT
+        return False
+    if (mmer & 0x3C) == 0x3C:   # TT before the last symbol
+        return False
+    for _ in range(length - 3):
+        if (mmer & 0xF) == 0:   # AA inside
+            return False
+        mmer >>= 2
+    if mmer == 0 or mmer == 0x04 or (mmer & 0xF) == 0:  # AAA / ACA / *AA at the start
+        return False
+    return True
+
+
+def kmc_signature_norm(length: int) -> np.ndarray:
+    """norm[m-mer] = min(allowed(m-mer) ? m-mer : special, allowed(revcomp) ? revcomp : special), special = 4^len"""
+    special = 1 << (2 * length)
+    allowed = np.array([_mmer_allowed(i, length) for i in range(special)])
+    idx = np.arange(special, dtype=np.int64)
+    rev = np.zeros(special, np.int64)
+    for j in range(length):
+        rev |= (3 - ((idx >> (2 * j)) & 3)) << (2 * (length - 1 - j))
+    a = np.where(allowed, idx, special)
+    b = np.where(allowed[rev], rev, special)
+    return np.minimum(a, b)
+
+
+def kmc_signatures(keys: np.ndarray, k: int, sig_len: int) -> np.ndarray:
+    """signature of every k-mer value = the smallest norm over its k - sig_len + 1 m-mers"""
+    norm = kmc_signature_norm(sig_len)
+    keys = np.asarray(keys, np.uint64)
+    best = np.full(len(keys), 1 << (2 * sig_len), np.int64)
+    mask = np.uint64((1 << (2 * sig_len)) - 1)
+    for j in range(k - sig_len + 1):
+        mm = ((keys >> np.uint64(2 * j)) & mask).astype(np.int64)
+        best = np.minimum(best, norm[mm])
+    return best
+
+
+def write_kmc2(prefix: str, keys: np.ndarray, counters: np.ndarray, k: int, lut_prefix_len: int,
+               sig_len: int = 7, nbins: int = 13, counter_size: int = 4, min_count: int = 1,
+               max_count: int = 0xFFFFFFFF, guard: bool = False) -> None:
+    """``prefix.kmc_pre`` / ``.kmc_suf`` in the KMC2 layout: signature -> bin through an (arbitrary but
+    recorded) map, every bin sorted and given its own prefix LUT, the suffix file = the bins one after another."""
+    keys = np.asarray(keys, np.uint64)
+    counters = np.asarray(counters, np.uint32)
+    p = lut_prefix_len
+    assert (k - p) % 4 == 0
+    sig = kmc_signatures(keys, k, sig_len)
+    sig_map = (np.arange((1 << (2 * sig_len)) + 1, dtype=np.int64) * 2654435761 % nbins).astype(np.uint32)
+    bins = sig_map[sig].astype(np.int64)
+    order = np.lexsort((keys, bins))
+    keys, counters, bins = keys[order], counters[order], bins[order]
+    suf_syms = k - p
+    suf_bytes = suf_syms // 4
+    pref = (keys >> np.uint64(2 * suf_syms)).astype(np.int64)
+    # record number of the first record of (bin b, prefix x) = records with (bin, prefix) < (b, x)
+    combined = bins * (4 ** p) + pref
+    lut = np.searchsorted(combined, np.arange(nbins * 4 ** p, dtype=np.int64), side="left").astype(np.uint64)
+    with open(prefix + ".kmc_pre", "wb") as f:
+        f.write(b"KMCP")
+        f.write(lut.tobytes())
+        if guard:
+            f.write(struct.pack("<Q", len(keys)))
+        f.write(sig_map.tobytes())
+        hdr = struct.pack("<IIIIIIIQB3x24xI", k, 0, counter_size, p, sig_len, min_count, max_count & 0xFFFFFFFF,
+                          len(keys), 0, 0x200)
+        assert len(hdr) == 68
+        f.write(hdr)
+        f.write(struct.pack("<I", 68))
+        f.write(b"KMCP")
+    rec = np.zeros((len(keys), suf_bytes + counter_size), np.uint8)
+    for b in range(suf_bytes):
+        rec[:, b] = ((keys >> np.uint64(8 * (suf_bytes - 1 - b))) & np.uint64(0xFF)).astype(np.uint8)
+    for b in range(counter_size):
+        rec[:, suf_bytes + b] = ((counters >> np.uint32(8 * b)) & np.uint32(0xFF)).astype(np.uint8)
+    with open(prefix + ".kmc_suf", "wb") as f:
+        f.write(b"KMCS")
+        f.write(rec.tobytes())
+        f.write(b"KMCS")
+
+
+def parse_kmc2(pre: bytes, suf: bytes):
+    """KMC2 images -> dict(k, keys sorted, counters, ...): every record's prefix from its (bin, prefix) LUT slot"""
+    if pre[:4] != b"KMCP" or pre[-4:] != b"KMCP" or suf[:4] != b"KMCS" or suf[-4:] != b"KMCS":
+        raise ValueError("not a KMC database (bad markers)")
+    (hoff,) = struct.unpack("<I", pre[-8:-4])
+    hdr = pre[len(pre) - 8 - hoff:len(pre) - 8]
+    k, mode, csz, p, sig_len, minc, maxc, total = struct.unpack("<IIIIIIIQ", hdr[:36])
+    (ver,) = struct.unpack("<I", hdr[-4:])
+    if ver != 0x200:
+        raise ValueError("not the KMC2 layout")
+    map_bytes = ((1 << (2 * sig_len)) + 1) * 4
+    lut_bytes = len(pre) - 4 - map_bytes - hoff - 8
+    nlut = lut_bytes // 8
+    if nlut % (4 ** p):
+        nlut -= 1  # a guard entry
+    lut = np.frombuffer(pre, np.uint64, nlut, 4).astype(np.int64)
+    suf_bytes = (k - p) // 4
+    rec = np.frombuffer(suf, np.uint8, total * (suf_bytes + csz), 4).reshape(total, suf_bytes + csz)
+    keys = np.zeros(total, np.uint64)
+    for b in range(suf_bytes):
+        keys |= rec[:, b].astype(np.uint64) << np.uint64(8 * (suf_bytes - 1 - b))
+    bounds = np.concatenate([lut, [total]])
+    slot = np.repeat(np.arange(nlut, dtype=np.int64), np.diff(bounds))
+    keys |= (slot % (4 ** p)).astype(np.uint64) << np.uint64(2 * (k - p))
+    counters = np.zeros(total, np.uint32)
+    for b in range(csz):
+        counters |= rec[:, suf_bytes + b].astype(np.uint32) << np.uint32(8 * b)
+    order = np.argsort(keys, kind="stable")
+    return dict(k=k, keys=keys[order], counters=counters[order], min_count=minc, max_count=maxc,
+                lut_prefix_len=p, counter_size=csz, signature_len=sig_len, nbins=nlut // (4 ** p))
+
+
+# ---------------------------------------------------------------------------
 # lookup = GetCountersForRead
 # ---------------------------------------------------------------------------
 def counters_for_read(db: Tuple[np.ndarray, np.ndarray], seq: bytes, k: int,

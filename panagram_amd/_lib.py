@@ -42,6 +42,8 @@ PROTOTYPES = {
     "pg_table_insert_seqset_min": (C.c_int, [_vp, C.c_int, _vp, C.c_uint32]),
     "pg_table_insert_keys": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_uint64]),
     "pg_table_load_kmc1": (C.c_int, [_vp, C.c_int, _vp, C.c_size_t, _vp, C.c_size_t]),
+    "pg_table_load_kmc": (C.c_int, [_vp, C.c_int, _vp, C.c_size_t, _vp, C.c_size_t]),
+    "pg_kmc_kmer_length": (C.c_int, [_vp, C.c_size_t, _u32p]),
     "pg_table_stats": (C.c_int, [_vp, _u64p, _u64p, _u64p, _u64p]),
     "pg_table_rehash": (C.c_int, [_vp, C.c_double]),
     "pg_table_spill": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]),

@@ -657,66 +657,184 @@ extern "C" int pg_table_insert_keys(pg_table *t, int db_idx, const uint64_t *key
     return r;
 }
 
-// KMC1 layout, SURVEY.md Appendix A
-extern "C" int pg_table_load_kmc1(pg_table *t, int db_idx, const void *pre_, size_t pre_len, const void *suf_,
-                                  size_t suf_len) {
-    if (!t || !pre_ || !suf_) return fail(PG_E_INVALID, "pg_table_load_kmc1: NULL argument");
+// ---------------------------------------------------------------------------
+// KMC databases.  Both layouts CKMCFile::OpenForRA accepts (cpp/anchor.cpp:29, index.py:859-860):
+//   KMC1 (kmc_version 0; kmc_tools output):
+//       pre = "KMCP" | u64 LUT[4^p] | header(64) | u32 header_offset | "KMCP"
+//   KMC2 (kmc_version 0x200; what `kmc` itself writes, workflow/Snakefile:101-104):
+//       pre = "KMCP" | u64 LUT[bins][4^p] (+ one guard entry) | u32 signature_map[4^s + 1] | header(68) | u32 header_offset | "KMCP"
+//       header = k, mode, counter_size, lut_prefix_length, signature_len, min_count, max_count, u64 total, both_strands, ...
+//       the suffix file holds the bins one after the other, each sorted; LUT[b][x] = number of the first record of
+//       bin b whose first p symbols are x.  (The signature map only serves random access by signature: a bulk
+//       import needs the LUTs alone.)
+//   suf = "KMCS" | records (suffix bytes, counter) | "KMCS"   in both.
+// The records never pass through host containers: the suffix file image is uploaded in chunks (from wherever the
+// caller holds it — a memory map is fine) and k_import_kmc turns records into table inserts on the GPU.
+// ---------------------------------------------------------------------------
+struct KmcHeader {
+    uint32_t k, mode, csz, lut_p, sig_len, minc, maxc, ver, hoff;
+    uint64_t total, nlut;  // nlut: LUT entries (bins x 4^lut_p), without the guard
+};
+
+static int parse_kmc_pre(const uint8_t *pre, size_t pre_len, KmcHeader *H) {
+    if (pre_len < 4 + 8 + 64 + 8 || memcmp(pre, "KMCP", 4) || memcmp(pre + pre_len - 4, "KMCP", 4))
+        return fail(PG_E_FORMAT, "kmc_pre: missing KMCP markers");
+    memcpy(&H->hoff, pre + pre_len - 8, 4);
+    if (H->hoff < 64 || (size_t)H->hoff + 8 + 4 > pre_len) return fail(PG_E_FORMAT, "kmc_pre: bad header offset %u", H->hoff);
+    const uint8_t *h = pre + pre_len - 8 - H->hoff;
+    memcpy(&H->ver, pre + pre_len - 12, 4);  // last field of the header in both layouts
+    if (H->ver != 0 && H->ver != 0x200)
+        return fail(PG_E_FORMAT, "kmc_pre: kmc_version=0x%x; the KMC1 (0) and KMC2 (0x200) layouts are supported", H->ver);
+    memcpy(&H->k, h, 4);
+    memcpy(&H->mode, h + 4, 4);
+    memcpy(&H->csz, h + 8, 4);
+    memcpy(&H->lut_p, h + 12, 4);
+    const uint8_t *q = h + 16;
+    H->sig_len = 0;
+    if (H->ver == 0x200) {
+        if (H->hoff < 68) return fail(PG_E_FORMAT, "kmc_pre: KMC2 header of %u bytes is too short", H->hoff);
+        memcpy(&H->sig_len, q, 4);
+        q += 4;
+    }
+    memcpy(&H->minc, q, 4);
+    memcpy(&H->maxc, q + 4, 4);
+    memcpy(&H->total, q + 8, 8);
+    if (H->mode != 0) return fail(PG_E_FORMAT, "kmc_pre: quality-mode databases are not supported");
+    if (H->k < 1 || H->k > 32) return fail(PG_E_FORMAT, "kmc_pre: k=%u unsupported (1..32)", H->k);
+    if (H->csz > 4) return fail(PG_E_FORMAT, "kmc_pre: counter_size=%u unsupported", H->csz);
+    if (H->ver == 0 && H->csz < 1) return fail(PG_E_FORMAT, "kmc_pre: counter_size=0 in a KMC1 database");
+    if (H->lut_p < 1 || H->lut_p > 15 || H->lut_p > H->k || (H->k - H->lut_p) % 4)
+        return fail(PG_E_FORMAT, "kmc_pre: lut_prefix_length=%u invalid for k=%u", H->lut_p, H->k);
+    const uint64_t per_bin = 1ull << (2 * H->lut_p);
+    uint64_t lut_bytes = pre_len - 4 - (H->hoff + 8);
+    if (H->ver == 0x200) {
+        if (H->sig_len < 5 || H->sig_len > 11) return fail(PG_E_FORMAT, "kmc_pre: signature_len=%u out of range (5..11)", H->sig_len);
+        const uint64_t map_bytes = ((1ull << (2 * H->sig_len)) + 1) * 4;
+        if (lut_bytes < map_bytes + 8) return fail(PG_E_FORMAT, "kmc_pre: truncated (no room for the signature map)");
+        lut_bytes -= map_bytes;
+        // bins x 4^p entries, with or without one guard entry behind them (the reference's reader — which puts a
+        // guard of its own behind whatever it read — accepts both: tests/golden/make_golden.py, kmc2_* fixtures)
+        const uint64_t entries = lut_bytes / 8;
+        if (lut_bytes % 8 || entries < per_bin || (entries % per_bin != 0 && (entries - 1) % per_bin != 0))
+            return fail(PG_E_FORMAT, "kmc_pre: prefix area of %llu bytes is not bins x 4^%u entries (+ guard)", (unsigned long long)lut_bytes, H->lut_p);
+        H->nlut = entries % per_bin == 0 ? entries : entries - 1;
+    } else {
+        if (lut_bytes < per_bin * 8) return fail(PG_E_FORMAT, "kmc_pre: truncated prefix table");
+        H->nlut = per_bin;
+    }
+    return PG_OK;
+}
+
+extern "C" int pg_table_load_kmc(pg_table *t, int db_idx, const void *pre_, size_t pre_len, const void *suf_,
+                                 size_t suf_len) {
+    if (!t || !pre_ || !suf_) return fail(PG_E_INVALID, "pg_table_load_kmc: NULL argument");
     if (db_idx < 0 || db_idx >= t->ndbs) return fail(PG_E_INVALID, "db index %d out of range (0..%d)", db_idx, t->ndbs - 1);
     const uint8_t *pre = static_cast<const uint8_t *>(pre_);
     const uint8_t *suf = static_cast<const uint8_t *>(suf_);
-    if (pre_len < 4 + 8 + 64 + 8 || memcmp(pre, "KMCP", 4) || memcmp(pre + pre_len - 4, "KMCP", 4))
-        return fail(PG_E_FORMAT, "kmc_pre: missing KMCP markers");
+    KmcHeader H;
+    if (int r = parse_kmc_pre(pre, pre_len, &H)) return r;
     if (suf_len < 8 || memcmp(suf, "KMCS", 4) || memcmp(suf + suf_len - 4, "KMCS", 4))
         return fail(PG_E_FORMAT, "kmc_suf: missing KMCS markers");
-    uint32_t hoff;
-    memcpy(&hoff, pre + pre_len - 8, 4);
-    if (hoff < 64 || (size_t)hoff + 8 + 4 > pre_len) return fail(PG_E_FORMAT, "kmc_pre: bad header offset %u", hoff);
-    const uint8_t *h = pre + pre_len - 8 - hoff;
-    uint32_t kk, mode, csz, lut_p, minc, maxc, ver;
-    uint64_t total;
-    memcpy(&kk, h, 4);
-    memcpy(&mode, h + 4, 4);
-    memcpy(&csz, h + 8, 4);
-    memcpy(&lut_p, h + 12, 4);
-    memcpy(&minc, h + 16, 4);
-    memcpy(&maxc, h + 20, 4);
-    memcpy(&total, h + 24, 8);
-    memcpy(&ver, h + 60, 4);
-    if (ver != 0) return fail(PG_E_FORMAT, "kmc_pre: kmc_version=0x%x; only the KMC1 layout (kmc_tools output) is supported", ver);
-    if (mode != 0) return fail(PG_E_FORMAT, "kmc_pre: quality-mode databases are not supported");
-    if ((int)kk != t->k) return fail(PG_E_FORMAT, "database k=%u but table k=%d", kk, t->k);
-    if (csz < 1 || csz > 4) return fail(PG_E_FORMAT, "kmc_pre: counter_size=%u unsupported", csz);
-    if (lut_p < 1 || lut_p > 15 || lut_p > kk || (kk - lut_p) % 4) return fail(PG_E_FORMAT, "kmc_pre: lut_prefix_length=%u invalid for k=%u", lut_p, kk);
-    const uint64_t nlut = 1ull << (2 * lut_p);
-    if (4 + nlut * 8 + hoff + 8 > pre_len) return fail(PG_E_FORMAT, "kmc_pre: truncated prefix table");
-    const uint32_t sb = (kk - lut_p) / 4, rec = sb + csz;
-    if (8 + total * rec > suf_len) return fail(PG_E_FORMAT, "kmc_suf: truncated (%llu records of %u bytes expected)", (unsigned long long)total, rec);
-    std::vector<uint64_t> keys;
-    std::vector<uint32_t> vals;
-    keys.reserve(total);
-    vals.reserve(total);
-    const uint8_t *lutp = pre + 4;
-    const uint8_t *r = suf + 4;
-    uint64_t prev_end = 0;
-    for (uint64_t p = 0; p < nlut; ++p) {
-        uint64_t beg, end;
-        memcpy(&beg, lutp + p * 8, 8);
-        if (p + 1 < nlut) memcpy(&end, lutp + (p + 1) * 8, 8);
-        else end = total;
-        if (beg != prev_end || end < beg || end > total) return fail(PG_E_FORMAT, "kmc_pre: prefix table not monotone at %llu", (unsigned long long)p);
-        prev_end = end;
-        for (uint64_t i = beg; i < end; ++i) {
-            const uint8_t *q = r + i * rec;
-            uint64_t sfx = 0;
-            for (uint32_t b = 0; b < sb; ++b) sfx = (sfx << 8) | q[b];
-            uint32_t c = 0;
-            for (uint32_t b = 0; b < csz; ++b) c |= (uint32_t)q[sb + b] << (8 * b);
-            if (c < minc || c > maxc || c == 0) continue;  // KMC: outside [min,max] reads as 0
-            keys.push_back((p << (2 * (kk - lut_p))) | sfx);
-            vals.push_back(c);
-        }
+    if ((int)H.k != t->k) return fail(PG_E_FORMAT, "database k=%u but table k=%d", H.k, t->k);
+    const uint32_t sb = (H.k - H.lut_p) / 4, rec = sb + H.csz;
+    if (rec && 8 + H.total * rec > suf_len)
+        return fail(PG_E_FORMAT, "kmc_suf: truncated (%llu records of %u bytes expected)", (unsigned long long)H.total, rec);
+    // the LUT must be monotone from 0 to total: it is what maps a record number to its prefix
+    std::vector<uint64_t> lut(H.nlut);
+    memcpy(lut.data(), pre + 4, H.nlut * 8);
+    uint64_t prev = 0;
+    if (H.nlut && lut[0] != 0) return fail(PG_E_FORMAT, "kmc_pre: prefix table does not start at record 0");
+    for (uint64_t i = 0; i < H.nlut; ++i) {
+        if (lut[i] < prev || lut[i] > H.total) return fail(PG_E_FORMAT, "kmc_pre: prefix table not monotone at entry %llu", (unsigned long long)i);
+        prev = lut[i];
     }
-    return pg_table_insert_keys(t, db_idx, keys.data(), vals.data(), keys.size());
+    if (H.total == 0) return PG_OK;
+    if (rec == 0) return fail(PG_E_FORMAT, "kmc_pre: records of zero bytes (k == lut_prefix_length without counters)");
+    if (int r = use_device(t->ctx)) return r;
+    TABLE_WRITER(t);
+    const int si = db_idx / 2, w = db_idx % 2;
+    if (int r = ensure_room(t, si, H.total)) return r;
+    hipStream_t st = t->ctx->stream;
+    // chunks of whole records, about 256 MiB each, through two device buffers: the upload of chunk c+1 (pageable or
+    // mapped host memory: HIP stages it) runs behind the import kernel of chunk c
+    const uint64_t chunk_recs = std::max<uint64_t>(1, (256ull << 20) / rec);
+    uint64_t *d_lut = nullptr;
+    uint8_t *d_rec[2] = {nullptr, nullptr};
+    hipStream_t up = nullptr;
+    hipEvent_t ev_up[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
+    int rc = PG_OK;
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&d_lut), H.nlut * 8);
+    const uint64_t buf_bytes = std::min<uint64_t>(chunk_recs, H.total) * rec;
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) {
+        e = hipMalloc(reinterpret_cast<void **>(&d_rec[i]), buf_bytes);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ev_up[i], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ev_done[i], hipEventDisableTiming);
+    }
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&up, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_lut, lut.data(), H.nlut * 8, hipMemcpyHostToDevice, st);
+    const uint8_t *recs = suf + 4;
+    const uint64_t nchunks = (H.total + chunk_recs - 1) / chunk_recs;
+    auto upload = [&](uint64_t c) {
+        const int b = (int)(c & 1);
+        const uint64_t r0 = c * chunk_recs, n = std::min(chunk_recs, H.total - r0);
+        hipError_t x = c >= 2 ? hipStreamWaitEvent(up, ev_done[b], 0) : hipSuccess;  // the buffer's previous kernel
+        if (x == hipSuccess) x = hipMemcpyAsync(d_rec[b], recs + r0 * rec, n * rec, hipMemcpyHostToDevice, up);
+        if (x == hipSuccess) x = hipEventRecord(ev_up[b], up);
+        return x;
+    };
+    for (int attempt = 0; attempt < 8 && e == hipSuccess && rc == PG_OK; ++attempt) {
+        // (inserts are idempotent: a pass that overflowed the probe bound is simply run again on the grown table)
+        e = hipMemsetAsync(t->d_counters, 0, 2 * sizeof(unsigned long long), st);
+        if (e == hipSuccess) e = upload(0);
+        for (uint64_t c = 0; c < nchunks && e == hipSuccess; ++c) {
+            const int b = (int)(c & 1);
+            const uint64_t r0 = c * chunk_recs, n = std::min(chunk_recs, H.total - r0);
+            if (c + 1 < nchunks) e = upload(c + 1);
+            if (e == hipSuccess) e = hipStreamWaitEvent(st, ev_up[b], 0);
+            if (e == hipSuccess)
+                e = launch_import_kmc(st, t->subs[si].d, w, d_rec[b], r0, n, d_lut, H.nlut, 1u << (2 * H.lut_p), sb, H.csz,
+                                      H.minc, H.maxc, t->d_counters, MAX_PROBE);
+            if (e == hipSuccess) e = hipEventRecord(ev_done[b], st);
+        }
+        if (e != hipSuccess) break;
+        unsigned long long cnt[2];
+        if ((rc = read_counters(t, cnt))) break;
+        t->subs[si].count += cnt[0];
+        if (cnt[1] == 0) {
+            rc = after_insert(t, si);
+            break;
+        }
+        if ((rc = grow_after_overflow(t, si, H.total))) break;
+        if (attempt == 7) rc = fail(PG_E_CAPACITY, "k-mer table keeps overflowing");
+        if (up) hipStreamSynchronize(up);
+    }
+    if (e != hipSuccess) rc = fail(PG_E_HIP, "pg_table_load_kmc: %s", hipGetErrorString(e));
+    hipStreamSynchronize(st);
+    if (up) {
+        hipStreamSynchronize(up);
+        hipStreamDestroy(up);
+    }
+    for (int i = 0; i < 2; ++i) {
+        if (d_rec[i]) hipFree(d_rec[i]);
+        if (ev_up[i]) hipEventDestroy(ev_up[i]);
+        if (ev_done[i]) hipEventDestroy(ev_done[i]);
+    }
+    if (d_lut) hipFree(d_lut);
+    return rc;
+}
+
+// (kept under its round-1 name: the KMC1 layout was the only one read then)
+extern "C" int pg_table_load_kmc1(pg_table *t, int db_idx, const void *pre, size_t pre_len, const void *suf, size_t suf_len) {
+    return pg_table_load_kmc(t, db_idx, pre, pre_len, suf, suf_len);
+}
+
+// k of a KMC database from its .kmc_pre image (either layout): what a caller needs before it can create the table
+extern "C" int pg_kmc_kmer_length(const void *pre, size_t pre_len, uint32_t *k) {
+    if (!pre || !k) return fail(PG_E_INVALID, "pg_kmc_kmer_length: NULL argument");
+    KmcHeader H;
+    if (int r = parse_kmc_pre(static_cast<const uint8_t *>(pre), pre_len, &H)) return r;
+    *k = H.k;
+    return PG_OK;
 }
 
 extern "C" int pg_table_stats(pg_table *t, uint64_t *nkeys, uint64_t *nslots, uint64_t *nbuckets, uint64_t *bytes) {

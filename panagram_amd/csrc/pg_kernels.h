@@ -74,6 +74,11 @@ hipError_t launch_merge_min(hipStream_t st, const SubTable &src, const SubTable 
 hipError_t launch_insert_keys(hipStream_t st, const SubTable &t, int w, const uint64_t *keys,
                               const uint32_t *vals, uint64_t n, unsigned long long *counters,
                               uint32_t max_probe);
+// records [first_record, first_record + nrec) of a KMC suffix file (resident at `rec`) into group word w
+hipError_t launch_import_kmc(hipStream_t st, const SubTable &t, int w, const uint8_t *rec, uint64_t first_record, uint64_t nrec,
+                             const uint64_t *lut, uint64_t nlut, uint32_t prefixes_per_bin, uint32_t suffix_bytes,
+                             uint32_t counter_bytes, uint32_t min_count, uint32_t max_count, unsigned long long *counters,
+                             uint32_t max_probe);
 hipError_t launch_rehash(hipStream_t st, const SubTable &src, const SubTable &dst,
                          unsigned long long *counters, uint32_t max_probe);
 hipError_t launch_export(hipStream_t st, const SubTable &t, int w, uint64_t *keys, uint32_t *vals,

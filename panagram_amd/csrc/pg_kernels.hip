@@ -274,6 +274,47 @@ __global__ __launch_bounds__(256) void k_insert_keys(SubTable st, int w, const u
     if (claimed) atomicAdd(&counters[0], (unsigned long long)claimed);
 }
 
+// ---------------------------------------------------------------------------
+// KMC database import on the GPU.  A .kmc_suf file is an array of records (suffix bytes, most significant
+// symbol first, then the counter, little-endian), sorted inside each bin; the .kmc_pre file gives, for every
+// (bin, prefix) pair, the index of its first record — `nlut` monotone entries, bin-major, prefix-minor; the KMC1
+// layout (kmc_tools output) is the one-bin case, the KMC2 layout (kmc output) has one LUT per signature bin.
+// A thread takes one record: its prefix is (index of the last LUT entry <= record number) mod prefixes-per-bin
+// (binary search over the LUT, which stays in L2), key = prefix : suffix, counter filtered by [min, max] as
+// CKMCFile::GetCountersForRead does; insert-or-OR into 32-genome group word w.
+// Replaces CKMCFile::OpenForRA (cpp/anchor.cpp:29, index.py:859-860), which reads the whole file to host RAM.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_import_kmc(SubTable st, int w, const uint8_t *__restrict__ rec,
+                                                    uint64_t first_record, uint64_t nrec,
+                                                    const unsigned long long *__restrict__ lut, uint64_t nlut,
+                                                    uint32_t prefixes_per_bin, uint32_t suffix_bytes, uint32_t counter_bytes,
+                                                    uint32_t min_count, uint32_t max_count,
+                                                    unsigned long long *counters, uint32_t max_probe) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint32_t rb = suffix_bytes + counter_bytes;
+    uint32_t claimed = 0;
+    for (; i < nrec; i += stride) {
+        const uint8_t *q = rec + i * rb;
+        uint32_t c = counter_bytes ? 0u : 1u;  // (KMC writes no counter bytes when every count is 1)
+        for (uint32_t b = 0; b < counter_bytes; ++b) c |= (uint32_t)q[suffix_bytes + b] << (8 * b);
+        if (c == 0 || c < min_count || c > max_count) continue;  // outside [min, max] reads as absent
+        const uint64_t r = first_record + i;
+        uint64_t lo = 0, hi = nlut;  // last entry <= r  (lut[0] = 0 <= r always)
+        while (hi - lo > 1) {
+            const uint64_t mid = (lo + hi) >> 1;
+            if (lut[mid] <= r) lo = mid;
+            else hi = mid;
+        }
+        uint64_t key = lo & (uint64_t)(prefixes_per_bin - 1);
+        for (uint32_t b = 0; b < suffix_bytes; ++b) key = (key << 8) | q[b];
+        int res = lane_insert<false, true>(st, key, w, c, max_probe);
+        if (res < 0) atomicOr(reinterpret_cast<unsigned int *>(&counters[1]), 1u);
+        else claimed += res;
+    }
+    if (claimed) atomicAdd(&counters[0], (unsigned long long)claimed);
+}
+
 // re-hash every occupied slot of `src` into `dst` (same W)
 __global__ __launch_bounds__(256) void k_rehash(SubTable src, SubTable dst, unsigned long long *counters,
                                                 uint32_t max_probe) {
@@ -441,6 +482,17 @@ hipError_t launch_insert_keys(hipStream_t st, const SubTable &t, int w, const ui
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(k_insert_keys, dim3(grid_for(n, 256, 256 * 64)), dim3(256), 0, st, t, w, keys, vals, n,
                        counters, max_probe);
+    return hipGetLastError();
+}
+
+hipError_t launch_import_kmc(hipStream_t st, const SubTable &t, int w, const uint8_t *rec, uint64_t first_record, uint64_t nrec,
+                             const uint64_t *lut, uint64_t nlut, uint32_t prefixes_per_bin, uint32_t suffix_bytes,
+                             uint32_t counter_bytes, uint32_t min_count, uint32_t max_count, unsigned long long *counters,
+                             uint32_t max_probe) {
+    if (nrec == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_import_kmc, dim3(grid_for(nrec, 256, 256 * 64)), dim3(256), 0, st, t, w, rec, first_record, nrec,
+                       reinterpret_cast<const unsigned long long *>(lut), nlut, prefixes_per_bin, suffix_bytes, counter_bytes,
+                       min_count, max_count, counters, max_probe);
     return hipGetLastError();
 }
 

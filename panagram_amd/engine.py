@@ -30,6 +30,14 @@ def usable_cpus() -> int:
     return max(1, n)
 
 
+def kmc_kmer_length(pre) -> int:
+    """k of a KMC database from the image of its .kmc_pre file (either layout)"""
+    v = _bytes_view(pre)
+    k = C.c_uint32()
+    check(_lib.load().pg_kmc_kmer_length(_ptr(v), v.size, C.byref(k)))
+    return int(k.value)
+
+
 def tile_positions() -> int:
     """k-mer positions per tile (launch unit; a bit-column block holds 64 bytes per tile and genome)"""
     return int(_lib.load().pg_tile_positions())
@@ -316,14 +324,17 @@ class PanTable(_Owner):
         check(self._lib.pg_table_insert_keys(self._h, db_idx, _ptr(keys), _ptr(counters), len(keys)))
 
     def load_kmc1(self, db_idx: int, pre: bytes, suf: bytes) -> None:
-        check(self._lib.pg_table_load_kmc1(self._h, db_idx, pre, len(pre), suf, len(suf)))
+        """images of X.kmc_pre / X.kmc_suf (KMC1 or KMC2 layout) as 32-genome group ``db_idx``"""
+        check(self._lib.pg_table_load_kmc(self._h, db_idx, pre, len(pre), suf, len(suf)))
+
+    load_kmc = load_kmc1
 
     def load_kmc_files(self, db_idx: int, prefix: str) -> None:
         """``prefix.kmc_pre`` / ``prefix.kmc_suf`` as 32-genome group ``db_idx`` (CKMCFile::OpenForRA,
         cpp/anchor.cpp:29): the files are mapped, not read into Python"""
         pre = np.memmap(prefix + ".kmc_pre", dtype=np.uint8, mode="r")
         suf = np.memmap(prefix + ".kmc_suf", dtype=np.uint8, mode="r")
-        check(self._lib.pg_table_load_kmc1(self._h, db_idx, _ptr(pre), pre.size, _ptr(suf), suf.size))
+        check(self._lib.pg_table_load_kmc(self._h, db_idx, _ptr(pre), pre.size, _ptr(suf), suf.size))
 
     def stats(self) -> dict:
         v = [C.c_uint64() for _ in range(4)]

@@ -986,9 +986,13 @@ class Genome:
 # ---------------------------------------------------------------------------
 def run_anchor_cli(argv: Sequence[str], device: int = 0) -> int:
     """Same argv and file contract as the reference's ``cpp/run_anchor`` binary: reads
-    ``root/kmc/bitvec{i}`` (KMC1), writes ``root/anchor/<name>/{bitmap.1,bitmap.100}.gz(.gzi)``,
-    ``bitsum.bins.tsv``, ``chrs.tsv``.  Unlike the reference, a missing or ill-formed DB is an
-    error (cpp/anchor.cpp:29 ignores OpenForRA's result)."""
+    ``root/kmc/bitvec{i}`` (KMC1 or KMC2 layout, memory-mapped and imported on the GPU), writes
+    ``root/anchor/<name>/{bitmap.1,bitmap.100}.gz(.gzi)``, ``bitsum.bins.tsv``, ``chrs.tsv``.  The reference runs
+    its anchors as concurrent OpenMP iterations (cpp/anchor.cpp:217-223); here they share co-scheduled launches
+    (batches bounded by the HBM their rows take) and their bitmaps are compressed on the GPU and streamed to the
+    files by writer threads — the rows never visit the host uncompressed.  Unlike the reference, a missing or
+    ill-formed DB is an error (cpp/anchor.cpp:29 ignores OpenForRA's result)."""
+    from concurrent.futures import ThreadPoolExecutor
     ngenomes = int(argv[0])
     root = argv[1]
     pairs = argv[2:]
@@ -997,47 +1001,73 @@ def run_anchor_cli(argv: Sequence[str], device: int = 0) -> int:
         return 1
     ndbs = (ngenomes + 31) // 32
     ctx = engine.Context(device)
-    k = None
-    images = []
-    for i in range(ndbs):
-        p = os.path.join(root, "kmc", f"bitvec{i}")
-        with open(p + ".kmc_pre", "rb") as f:
-            pre = f.read()
-        with open(p + ".kmc_suf", "rb") as f:
-            suf = f.read()
-        hoff = struct.unpack("<I", pre[-8:-4])[0]
-        k = struct.unpack("<I", pre[len(pre) - 8 - hoff:len(pre) - 4 - hoff])[0]
-        images.append((pre, suf))
+    prefixes = [os.path.join(root, "kmc", f"bitvec{i}") for i in range(ndbs)]
+    k = engine.kmc_kmer_length(np.memmap(prefixes[0] + ".kmc_pre", dtype=np.uint8, mode="r"))
     tbl = engine.PanTable(ctx, k, ngenomes)
-    for i, (pre, suf) in enumerate(images):
-        tbl.load_kmc1(i, pre, suf)
-    nbytes = (ngenomes + 7) // 8
-    for name, fasta in zip(pairs[0::2], pairs[1::2]):
-        print(f"Anchoring {name} {fasta}")
+    for i, p in enumerate(prefixes):
+        tbl.load_kmc_files(i, p)
+    nb_row = (ngenomes + 7) // 8
+    anchors = list(zip(pairs[0::2], pairs[1::2]))
+    bgzf_level = int(os.environ.get("PG_BGZF_LEVEL", "-2"))
+
+    def write_anchor(res, name, lo, names):
         adir = os.path.join(root, "anchor", name)
         os.makedirs(adir, exist_ok=True)
-        recs = list(read_fasta(fasta))
-        ss = engine.SeqSet.from_host(ctx, [s for _, s in recs])
-        res = engine.AnchorResult(tbl, ss, colsums=False)
-        res.run()
-        nb_row = (ngenomes + 7) // 8
-        level = 6 | (engine.BgzfWriter.RLE if nb_row == 1 else engine.BgzfWriter.ROWS(nb_row) if nb_row < 256 else 0)
-        w1 = engine.BgzfWriter(os.path.join(adir, "bitmap.1.gz"), level=level, threads=engine.usable_cpus())
-        w100 = engine.BgzfWriter(os.path.join(adir, "bitmap.100.gz"), level=level, threads=2)
+        for step in (1, 100):
+            res.write_bgzf(step, os.path.join(adir, f"bitmap.{step}.gz"), os.path.join(adir, f"bitmap.{step}.gzi"),
+                           level=bgzf_level, threads=max(1, engine.usable_cpus() // 2), first_contig=lo, ncontigs=len(names))
         with open(os.path.join(adir, "bitsum.bins.tsv"), "w") as fb, open(os.path.join(adir, "chrs.tsv"), "w") as fc:
             fb.write("chr\tstart" + "".join(f"\t{i}" for i in range(ngenomes + 1)) + "\n")
             fc.write("name\tid\tsize\tgene_count\n")
-            for ci, (chrom, _) in enumerate(recs):
-                rows, rows100, bins, info = res.download(ci)
-                w1.write(rows)
-                w100.write(rows100)
+            for ci, chrom in enumerate(names):
+                _, _, bins, info = res.download(lo + ci, want_bitmap1=False, want_bitmap100=False)
                 for b in range(info["nbins"]):
                     fb.write(f"{ci}\t{b * info['binlen']}" + "".join(f"\t{int(c)}" for c in bins[b]) + "\n")
                 fc.write(f"{chrom}\t{ci}\t{info['nkmers']}\t0\n")
-        w1.close(os.path.join(adir, "bitmap.1.gzi"))
-        w100.close(os.path.join(adir, "bitmap.100.gzi"))
-        res.close()
-        ss.close()
+
+    free = ctx.mem_info()[0]
+    batch_bytes = int(min(Index.batch_bytes, max(1 << 30, (free - (6 << 30)) / 2.3)))
+    with ThreadPoolExecutor(max_workers=2) as pool:
+        previous = None  # (result, merged seqset, seqsets, futures) of the batch being written
+        i = 0
+        while i < len(anchors):
+            batch, sets, rows = [], [], 0
+            while i < len(anchors):
+                name, fasta = anchors[i]
+                ss = engine.SeqSet.from_fasta(ctx, fasta)
+                need = int(ss.lens.sum()) * nb_row
+                if batch and rows + need > batch_bytes:
+                    ss.close()
+                    break
+                print(f"Anchoring {name} {fasta}")
+                batch.append(name)
+                sets.append(ss)
+                rows += need
+                i += 1
+            merged = engine.SeqSet.concat(ctx, sets) if len(sets) > 1 else sets[0]
+            res = engine.AnchorResult(tbl, merged, colsums=False)
+            if len(sets) > 1:
+                res.coschedule(np.repeat(np.arange(len(sets)), [len(x.names) for x in sets]))
+            res.run()
+            first = np.cumsum([0] + [len(x.names) for x in sets])
+            futs = [pool.submit(write_anchor, res, nm, int(first[j]), list(sets[j].names)) for j, nm in enumerate(batch)]
+            if previous is not None:
+                _join_cli_batch(*previous)
+            previous = (res, merged if len(sets) > 1 else None, sets, futs)
+        if previous is not None:
+            _join_cli_batch(*previous)
     tbl.close()
     ctx.close()
     return 0
+
+
+def _join_cli_batch(res, merged, sets, futs):
+    try:
+        for f in futs:
+            f.result()
+    finally:
+        res.close()
+        if merged is not None:
+            merged.close()
+        for x in sets:
+            x.close()

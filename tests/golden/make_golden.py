@@ -113,6 +113,44 @@ def make_case(name, ngenomes, k, contig_lens, d, seed, anchors, wrap=(80, 70, 60
 ONLY = set(sys.argv[1:])  # optional: fixture names to (re)generate; default all
 
 
+def make_kmc2_case(name, ref_case, lut, sig_len=7, nbins=13, guard=False):
+    """KMC2-LAYOUT databases (kmc_version 0x200, what `kmc` itself writes) holding the k-mers of an existing
+    fixture, written by oracle.pyoracle.write_kmc2 and READ BY THE REFERENCE BINARY: its outputs over them must be
+    the ones it gave over the KMC1 files of `ref_case` (stored there).  Only then are the file images committed —
+    they are what the product's KMC2 reader is tested on."""
+    fx = np.load(os.path.join(HERE, ref_case + ".npz"))
+    n, k = int(fx["ngenomes"]), int(fx["k"])
+    ndbs = (n + 31) // 32
+    root = tempfile.mkdtemp(prefix="golden_kmc2_")
+    try:
+        os.makedirs(os.path.join(root, "kmc"))
+        out = dict(ref_case=ref_case, ngenomes=n, k=k, lut_prefix_len=lut, signature_len=sig_len, nbins=nbins, guard=guard)
+        for i in range(ndbs):
+            pre = os.path.join(root, "kmc", f"bitvec{i}")
+            po.write_kmc2(pre, fx[f"db{i}_keys"], fx[f"db{i}_masks"], k, lut, sig_len=sig_len, nbins=nbins, guard=guard)
+            out[f"db{i}_pre"] = np.fromfile(pre + ".kmc_pre", np.uint8)
+            out[f"db{i}_suf"] = np.fromfile(pre + ".kmc_suf", np.uint8)
+        args = [RUN_ANCHOR, str(n), root]
+        for g in fx["anchors"]:
+            os.makedirs(os.path.join(root, "anchor", f"g{g}"))
+            fa = os.path.join(root, f"g{g}.fa")
+            with open(fa, "wb") as f:
+                f.write(fx[f"fasta_{g}"].tobytes())
+            args += [f"g{g}", fa]
+        subprocess.run(args, check=True, stdout=subprocess.DEVNULL, env=dict(os.environ, OMP_NUM_THREADS="1"))
+        for g in fx["anchors"]:
+            adir = os.path.join(root, "anchor", f"g{g}")
+            for step in (1, 100):
+                with gzip.open(os.path.join(adir, f"bitmap.{step}.gz"), "rb") as f:
+                    assert f.read() == fx[f"a{g}_bitmap{step}"].tobytes(), "the reference reads our KMC2 files differently"
+            with open(os.path.join(adir, "bitsum.bins.tsv"), "rb") as f:
+                assert f.read() == fx[f"a{g}_bitsum.bins.tsv"].tobytes()
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+        print("wrote", name, "(reference binary's outputs over the KMC2 files == its outputs over the KMC1 files)")
+    finally:
+        shutil.rmtree(root)
+
+
 def make_case_if(name, *a, **kw):
     if not ONLY or name in ONLY:
         make_case(name, *a, **kw)
@@ -143,6 +181,11 @@ def main():
               store_payload=False, lut=9)
     # config-5 shaped (8 genomes, k=21, one-byte rows): the genome-sharded mode's one-genome-per-GPU layout
     make_case_if("n8_k21", 8, 21, [3000, 1200], 0.02, 20, [0, 3, 7], lut=5)
+    # KMC2-layout databases of two of the cases above, accepted by the reference's own KMC reader
+    if not ONLY or "kmc2_n9_k21" in ONLY:
+        make_kmc2_case("kmc2_n9_k21", "n9_k21", lut=5, sig_len=7, nbins=13)
+    if not ONLY or "kmc2_n40_k31" in ONLY:
+        make_kmc2_case("kmc2_n40_k31", "n40_k31", lut=7, sig_len=9, nbins=64, guard=True)
     # >= 100 bins of 200000: exercises binlen=200000 + tail bin + multi-block .gzi
     make_case_if("big_n3_k21", 3, 21, [20300000, 150000], 0.01, 4321, [1], wrap=(80,), messy=False,
               store_payload=False, lut=9)

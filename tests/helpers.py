@@ -10,14 +10,21 @@ from oracle import pyoracle as po
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
+def _anchor_fixtures():
+    return [f for f in glob.glob(os.path.join(GOLDEN, "*.npz")) if not os.path.basename(f).startswith("kmc2_")]
+
+
 def payload_cases():
-    return sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(GOLDEN, "*.npz"))
-                  if bool(np.load(f)["store_payload"]))
+    return sorted(os.path.basename(f)[:-4] for f in _anchor_fixtures() if bool(np.load(f)["store_payload"]))
 
 
 def seed_cases():
-    return sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(GOLDEN, "*.npz"))
-                  if not bool(np.load(f)["store_payload"]))
+    return sorted(os.path.basename(f)[:-4] for f in _anchor_fixtures() if not bool(np.load(f)["store_payload"]))
+
+
+def kmc2_cases():
+    """KMC2-layout database images accepted by the reference binary (tests/golden/make_golden.py)"""
+    return sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(GOLDEN, "kmc2_*.npz")))
 
 
 def load_case(name):

@@ -88,15 +88,28 @@ def test_index_run_writes_reference_identical_tree(name, batch_bytes, tmp_path):
     idx2.close()
 
 
-def test_run_anchor_cli_matches_reference_binary(tmp_path):
-    """same argv + file contract as cpp/run_anchor, fed the same KMC1 files"""
+@pytest.mark.parametrize("layout,batch_bytes", [("kmc1", None), ("kmc2", None), ("kmc2", 1)])
+def test_run_anchor_cli_matches_reference_binary(layout, batch_bytes, tmp_path, monkeypatch):
+    """same argv + file contract as cpp/run_anchor, fed the same KMC files (either layout); the anchors share one
+    co-scheduled launch (or, with a tiny HBM budget, one launch each, written while the next is anchored)"""
+    from panagram_amd import index as pidx
     from panagram_amd.__main__ import main
-    fx = H.load_case("n33_k16")
+    if batch_bytes is not None:
+        monkeypatch.setattr(pidx.Index, "batch_bytes", batch_bytes)
+    if layout == "kmc1":
+        fx = H.load_case("n33_k16")
+    else:
+        k2 = H.load_case("kmc2_n40_k31")
+        fx = H.load_case(str(k2["ref_case"]))
     n, k = int(fx["ngenomes"]), int(fx["k"])
     root = tmp_path / "root"
     (root / "kmc").mkdir(parents=True)
     for i, (keys, masks) in enumerate(H.case_dbs(fx)):
-        po.write_kmc1(str(root / "kmc" / f"bitvec{i}"), keys, masks, k, lut_prefix_len=4)
+        if layout == "kmc1":
+            po.write_kmc1(str(root / "kmc" / f"bitvec{i}"), keys, masks, k, lut_prefix_len=4)
+        else:  # the very images the reference binary accepted
+            k2[f"db{i}_pre"].tofile(str(root / "kmc" / f"bitvec{i}.kmc_pre"))
+            k2[f"db{i}_suf"].tofile(str(root / "kmc" / f"bitvec{i}.kmc_suf"))
     args = ["run_anchor", str(n), str(root)]
     for g in fx["anchors"]:
         fa = tmp_path / f"g{g}.fa"
@@ -109,6 +122,8 @@ def test_run_anchor_cli_matches_reference_binary(tmp_path):
         assert gzip.open(adir / "bitmap.100.gz", "rb").read() == fx[f"a{g}_bitmap100"].tobytes()
         assert (adir / "bitsum.bins.tsv").read_bytes() == fx[f"a{g}_bitsum.bins.tsv"].tobytes()
         assert (adir / "chrs.tsv").read_bytes() == fx[f"a{g}_chrs.tsv"].tobytes()
+        gzi = np.fromfile(adir / "bitmap.1.gzi", "<u8")
+        assert gzi[0] == np.frombuffer(fx[f"a{g}_gzi1"].tobytes(), "<u8")[0]
 
 
 def test_kmc_api_mirror(tmp_path):

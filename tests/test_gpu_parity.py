@@ -625,3 +625,54 @@ def test_random_shapes_against_oracle(ctx, seed):
         res.close()
         ss.close()
     tbl.close()
+
+
+@pytest.mark.parametrize("name", H.kmc2_cases())
+def test_kmc2_layout_databases_load_on_the_gpu(ctx, name, tmp_path):
+    """KMC2-layout databases (kmc_version 0x200: one prefix LUT per signature bin, what `kmc` itself writes) —
+    file images the reference binary's own KMC reader accepted — through k_import_kmc: the table then anchors to the
+    reference's golden outputs, and exports exactly the databases' k-mers.  Also through memory-mapped files
+    (PanTable.load_kmc_files), the way Index.build_table and the run_anchor CLI open them."""
+    from panagram_amd import engine
+    fx = H.load_case(name)
+    ref = H.load_case(str(fx["ref_case"]))
+    n, k = int(ref["ngenomes"]), int(ref["k"])
+    for via_files in (False, True):
+        tbl = engine.PanTable(ctx, k, n)
+        for i in range((n + 31) // 32):
+            if via_files:
+                p = str(tmp_path / f"bitvec{i}")
+                fx[f"db{i}_pre"].tofile(p + ".kmc_pre")
+                fx[f"db{i}_suf"].tofile(p + ".kmc_suf")
+                tbl.load_kmc_files(i, p)
+            else:
+                tbl.load_kmc(i, fx[f"db{i}_pre"].tobytes(), fx[f"db{i}_suf"].tobytes())
+        for i, (keys, masks) in enumerate(H.case_dbs(ref)):
+            gk, gm = tbl.export(i)
+            order = np.argsort(gk)
+            assert np.array_equal(gk[order], keys) and np.array_equal(gm[order], masks)
+        for g in ref["anchors"]:
+            got = _anchor_fasta_gpu(ctx, tbl, ref[f"fasta_{g}"].tobytes())
+            assert got["bitmap1"] == ref[f"a{g}_bitmap1"].tobytes()
+            assert got["bitmap100"] == ref[f"a{g}_bitmap100"].tobytes()
+        tbl.close()
+
+
+def test_kmc_import_streams_in_chunks(ctx, tmp_path):
+    """A database larger than one upload chunk (several import launches, double-buffered) and with a one-byte
+    counter: every key arrives, none twice."""
+    from panagram_amd import engine
+    rng = np.random.default_rng(3)
+    k, n = 27, 5
+    nkeys = 45_000_000  # x (5 suffix bytes + 1 counter byte) = 270 MB > the 256 MiB chunk
+    keys = np.unique(rng.integers(0, 1 << 54, nkeys, dtype=np.uint64))
+    masks = rng.integers(1, 32, len(keys), dtype=np.uint32)
+    p = str(tmp_path / "big")
+    po.write_kmc1(p, keys, masks, k, lut_prefix_len=7, counter_size=1)
+    tbl = engine.PanTable(ctx, k, n, expected_keys=len(keys))
+    tbl.load_kmc_files(0, p)
+    assert tbl.stats()["nkeys"] == len(keys)
+    gk, gm = tbl.export(0)
+    order = np.argsort(gk)
+    assert np.array_equal(gk[order], keys) and np.array_equal(gm[order], masks)
+    tbl.close()

@@ -58,3 +58,17 @@ def test_row_byte_counts():
     assert po.row_byte_counts(1) == [1] and po.row_byte_counts(9) == [2] and po.row_byte_counts(32) == [4]
     assert po.row_byte_counts(33) == [4, 1] and po.row_byte_counts(40) == [4, 1]
     assert po.row_byte_counts(64) == [4, 4] and po.row_byte_counts(65) == [4, 4, 1]
+
+
+@pytest.mark.parametrize("name", H.kmc2_cases())
+def test_kmc2_layout_restatement_reads_the_reference_accepted_files(name):
+    """The KMC2-layout images (kmc_version 0x200) the reference binary accepted hold exactly the k-mers of their
+    KMC1 twin; the library's header parser (host only) agrees on k."""
+    from panagram_amd import engine
+    fx = H.load_case(name)
+    ref = H.load_case(str(fx["ref_case"]))
+    for i, (keys, masks) in enumerate(H.case_dbs(ref)):
+        d = po.parse_kmc2(fx[f"db{i}_pre"].tobytes(), fx[f"db{i}_suf"].tobytes())
+        assert d["k"] == int(ref["k"]) and d["signature_len"] == int(fx["signature_len"]) and d["nbins"] == int(fx["nbins"])
+        assert np.array_equal(d["keys"], keys) and np.array_equal(d["counters"], masks)
+        assert engine.kmc_kmer_length(fx[f"db{i}_pre"]) == int(ref["k"])
