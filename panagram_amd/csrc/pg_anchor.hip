@@ -116,6 +116,99 @@ __device__ __forceinline__ void lane_chase(const SubTable &st, uint64_t key, uin
     m0 = m1 = 0;
 }
 
+// ---- split layout (more than 64 genomes: 16 bare keys per line, mask words in a second array) ----
+// A hit is reported as (line, slot + 1) — slot1 == 0: absent — and the row is copied from the mask array afterwards.
+// scan of a key line staged in LDS: 1 = found, 0 = absent (line not full), -1 = absent from a full line
+__device__ __forceinline__ int scan_keys16_lds(const uint4 *line, uint64_t key, uint32_t &slot1) {
+    uint64_t kk[16];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const uint4 v = line[c];
+        kk[2 * c] = (uint64_t)v.x | ((uint64_t)v.y << 32);
+        kk[2 * c + 1] = (uint64_t)v.z | ((uint64_t)v.w << 32);
+    }
+    unsigned long long e[16];
+#pragma unroll
+    for (int sl = 0; sl < 16; ++sl) e[sl] = __builtin_amdgcn_ballot_w64(kk[sl] == key);
+    unsigned long long b[4] = {0, 0, 0, 0}, any = e[0];
+#pragma unroll
+    for (int sl = 1; sl < 16; ++sl) {
+        any |= e[sl];
+#pragma unroll
+        for (int bit = 0; bit < 4; ++bit)
+            if (sl & (1 << bit)) b[bit] |= e[sl];
+    }
+    const bool hit = __builtin_amdgcn_inverse_ballot_w64(any);
+    slot1 = 0;
+    if (hit)
+        slot1 = 1u + ((__builtin_amdgcn_inverse_ballot_w64(b[0]) ? 1u : 0u) | (__builtin_amdgcn_inverse_ballot_w64(b[1]) ? 2u : 0u) |
+                      (__builtin_amdgcn_inverse_ballot_w64(b[2]) ? 4u : 0u) | (__builtin_amdgcn_inverse_ballot_w64(b[3]) ? 8u : 0u));
+    return hit ? 1 : (kk[15] == EMPTY_KEY ? 0 : -1);
+}
+
+// follow a key's probe sequence through key lines in global memory (16 key loads in flight per line)
+__device__ __forceinline__ void lane_chase_wide(const SubTable &st, uint64_t key, uint32_t level, uint32_t b, uint32_t step,
+                                                uint32_t &hline, uint32_t &slot1) {
+    hline = slot1 = 0;
+    for (uint64_t n = 0; n < st.nbuckets + GROUP_CHAIN; ++n) {
+        const uint4 *line = reinterpret_cast<const uint4 *>(st.buckets + (uint64_t)b * (8u * SPLIT_KEYS));
+        uint4 v[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[c] = line[c];
+        uint32_t found = 0;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            if (((uint64_t)v[c].x | ((uint64_t)v[c].y << 32)) == key) found = 2 * c + 1;
+            if (((uint64_t)v[c].z | ((uint64_t)v[c].w << 32)) == key) found = 2 * c + 2;
+        }
+        if (found) {
+            hline = b;
+            slot1 = found;
+            return;
+        }
+        if (((uint64_t)v[7].z | ((uint64_t)v[7].w << 32)) == EMPTY_KEY) return;  // line not full: absent
+        level = min(level + 1, GROUP_CHAIN + 1);
+        advance_line(key, level, st.nbuckets, b, step);
+    }
+}
+__device__ __attribute__((noinline)) uint2 lane_chase_wide_cold(uint8_t *buckets, uint64_t nbuckets, uint64_t key, uint32_t level,
+                                                                uint32_t b, uint32_t step) {
+    SubTable t;
+    t.buckets = buckets;
+    t.masks = nullptr;
+    t.nbuckets = nbuckets;
+    t.W = 0;
+    t.word0 = 0;
+    t.k = t.m = 0;
+    t.slots = SPLIT_KEYS;
+    t.layout = LAYOUT_SPLIT;
+    uint32_t hl, s1;
+    lane_chase_wide(t, key, level, b, step, hl, s1);
+    return make_uint2(hl, s1);
+}
+
+// the row of a position: the W mask words of (line, slot1 - 1), or zeros (slot1 == 0); nbytes = ceil(N / 8)
+__device__ __forceinline__ void store_row_wide(const uint8_t *masks, uint32_t W, uint32_t nbytes, uint8_t *row, uint32_t hline,
+                                               uint32_t slot1) {
+    const bool hit = slot1 != 0;
+    const uint32_t *mp = reinterpret_cast<const uint32_t *>(masks) + ((uint64_t)hline * SPLIT_KEYS + (slot1 - 1u)) * W;
+    if (nbytes % 16 == 0) {  // (wave-uniform) rows and mask blocks are whole 16-byte chunks, both aligned
+        for (uint32_t q = 0; q < nbytes / 16; ++q) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (hit) v = reinterpret_cast<const uint4 *>(mp)[q];
+            reinterpret_cast<uint4 *>(row)[q] = v;
+        }
+        return;
+    }
+    struct __attribute__((packed)) U32 { uint32_t v; };
+    const uint32_t full = nbytes / 4;
+    for (uint32_t d = 0; d < full; ++d) reinterpret_cast<U32 *>(row + 4 * d)->v = hit ? mp[d] : 0u;
+    if (nbytes % 4) {
+        const uint32_t v = hit ? mp[full] : 0u;
+        for (uint32_t bb = 0; bb < nbytes % 4; ++bb) row[4 * full + bb] = (uint8_t)(v >> (8 * bb));
+    }
+}
+
 // the same out of line, everything by value (nothing of the caller is forced into scratch): for call
 // sites on a hot path where the chase itself is rare — inlined, its hash set-up gets hoisted into the
 // common path
@@ -129,7 +222,8 @@ __device__ __attribute__((noinline)) uint2 lane_chase_cold(uint8_t *buckets, uin
     t.word0 = 0;
     t.k = t.m = 0;
     t.slots = SLOTS;
-    t.pad_ = 0;
+    t.layout = LAYOUT_SLOTS;
+    t.masks = nullptr;
     uint32_t m0, m1;
     lane_chase<TWO, SLOTS>(t, key, level, b, step, m0, m1);
     return make_uint2(m0, m1);
@@ -204,7 +298,7 @@ __device__ __forceinline__ uint32_t lanes_le_count(unsigned long long mask, bool
 // Overflow levels of a tile: dense 64-entry batches out of the wave's LDS queue, staged exactly
 // like the main batches (neighbouring entries belong to the same group and share their next
 // line); entries that overflow again are compacted in place for the next level.
-template <bool TWO, int ROWMODE, int SLOTS, int MAXRUN>
+template <bool TWO, int ROWMODE, int SLOTS, int MAXRUN, bool WIDE>
 __device__ __forceinline__ void drain_queue(const SubTable &st, uint32_t qn, const uint64_t *sw, uint32_t *q_line,
                                             uint32_t *q_step, uint16_t *q_pl, uint32_t *lines_w, uint4 *buf,
                                             uint8_t *tile_rows, uint32_t nbytes, const RowCols rc, int lane) {
@@ -222,8 +316,14 @@ __device__ __forceinline__ void drain_queue(const SubTable &st, uint32_t qn, con
             // 8 slot loads in flight per line, no staging overhead
             for (uint32_t e = lane; e < qn; e += 64) {
                 uint32_t m0, m1;
-                lane_chase<TWO, SLOTS>(st, canonical_from_le(extract_bases(sw, q_pl[e]), k), (uint32_t)level, q_line[e], q_step[e], m0, m1);
-                if (m0 | m1) store_row<ROWMODE>(tile_rows + (uint64_t)q_pl[e] * nbytes, m0, m1, rc);
+                const uint64_t key = canonical_from_le(extract_bases(sw, q_pl[e]), k);
+                if constexpr (WIDE) {
+                    lane_chase_wide(st, key, (uint32_t)level, q_line[e], q_step[e], m0, m1);
+                    if (m1) store_row_wide(st.masks, st.W, nbytes, tile_rows + (uint64_t)q_pl[e] * nbytes, m0, m1);
+                } else {
+                    lane_chase<TWO, SLOTS>(st, key, (uint32_t)level, q_line[e], q_step[e], m0, m1);
+                    if (m0 | m1) store_row<ROWMODE>(tile_rows + (uint64_t)q_pl[e] * nbytes, m0, m1, rc);
+                }
             }
             break;
         }
@@ -258,11 +358,22 @@ __device__ __forceinline__ void drain_queue(const SubTable &st, uint32_t qn, con
                     buf[(idx / SLOTS) * LDS_LINE_U4 + (idx % SLOTS)] = v[u];
                 }
                 __syncthreads();
-                if (act && rid - r0 < nl) rcode = scan_line_lds<TWO, SLOTS>(buf + (rid - r0) * LDS_LINE_U4, key, m0, m1);
+                if (act && rid - r0 < nl) {
+                    if constexpr (WIDE) {
+                        rcode = scan_keys16_lds(buf + (rid - r0) * LDS_LINE_U4, key, m1);
+                        m0 = line;
+                    } else {
+                        rcode = scan_line_lds<TWO, SLOTS>(buf + (rid - r0) * LDS_LINE_U4, key, m0, m1);
+                    }
+                }
                 __syncthreads();
             }
             const bool again = act && rcode < 0;
-            if (act && (m0 | m1)) store_row<ROWMODE>(tile_rows + (uint64_t)pl * nbytes, m0, m1, rc);
+            if constexpr (WIDE) {
+                if (act && m1) store_row_wide(st.masks, st.W, nbytes, tile_rows + (uint64_t)pl * nbytes, m0, m1);
+            } else {
+                if (act && (m0 | m1)) store_row<ROWMODE>(tile_rows + (uint64_t)pl * nbytes, m0, m1, rc);
+            }
             const unsigned long long kmask2 = __ballot(again);
             if (again) {  // in-place compaction: slot <= e, and this batch's reads are already done
                 const uint32_t slot = kept + lanes_le_count(kmask2, true) - 1;
@@ -282,7 +393,9 @@ __device__ __forceinline__ void drain_queue(const SubTable &st, uint32_t qn, con
     }
 }
 
-template <int W_C, bool TWO, int ROWMODE, int SLOTS, bool M64>  // M64: m-mers longer than 16 bases
+// M64: m-mers longer than 16 bases.  WIDE: split layout (SLOTS = 8 then counts the 16-byte chunks of a key line: the
+// staging geometry is the same, a line holds 16 bare keys; m0 / m1 carry the hit's line and slot + 1)
+template <int W_C, bool TWO, int ROWMODE, int SLOTS, bool M64, bool WIDE = false>
 __global__ __launch_bounds__(64) void k_probe(const SubTable st, const uint64_t *__restrict__ seqw,
                                               const uint32_t *__restrict__ nmw, const uint32_t *__restrict__ has_n,
                                               const SeqDesc *__restrict__ sd, const AnchorDesc *__restrict__ ad,
@@ -431,7 +544,14 @@ __global__ __launch_bounds__(64) void k_probe(const SubTable st, const uint64_t 
 #pragma unroll
             for (int u = 0; u < NB; ++u)
                 if (act[u] && rid[u] - r0 < nl[u])
-                    rcode[u] = scan_line_lds<TWO, SLOTS>(buf[u] + (rid[u] - r0) * LDS_LINE_U4, key[u], m0[u], m1[u]);
+                {
+                    if constexpr (WIDE) {
+                        rcode[u] = scan_keys16_lds(buf[u] + (rid[u] - r0) * LDS_LINE_U4, key[u], m1[u]);
+                        m0[u] = line[u];
+                    } else {
+                        rcode[u] = scan_line_lds<TWO, SLOTS>(buf[u] + (rid[u] - r0) * LDS_LINE_U4, key[u], m0[u], m1[u]);
+                    }
+                }
             __syncthreads();
         }
 
@@ -450,7 +570,8 @@ __global__ __launch_bounds__(64) void k_probe(const SubTable st, const uint64_t 
                         q_step[slot] = step;
                         q_pl[slot] = (uint16_t)pl[u];
                     } else {
-                        const uint2 mm2 = lane_chase_cold<TWO, SLOTS>(st.buckets, st.nbuckets, key[u], 1u, nx, step);  // queue full
+                        const uint2 mm2 = WIDE ? lane_chase_wide_cold(st.buckets, st.nbuckets, key[u], 1u, nx, step)
+                                               : lane_chase_cold<TWO, SLOTS>(st.buckets, st.nbuckets, key[u], 1u, nx, step);  // queue full
                         m0[u] = mm2.x;
                         m1[u] = mm2.y;
                     }
@@ -458,11 +579,15 @@ __global__ __launch_bounds__(64) void k_probe(const SubTable st, const uint64_t 
                 qn = min(qn + (uint32_t)__popcll(omask), (uint32_t)PROBE_QCAP);
             }
             // (32-bit offset from the tile's uniform base: one store with a scalar base address)
-            if (inrange[u]) store_row<ROWMODE>(tile_rows + (ROWMODE == 1 ? (uint32_t)pl[u] : (uint32_t)pl[u] * nbytes), m0[u], m1[u], rc);
+            if constexpr (WIDE) {
+                if (inrange[u]) store_row_wide(st.masks, st.W, nbytes, tile_rows + (uint64_t)(uint32_t)pl[u] * nbytes, m0[u], m1[u]);
+            } else {
+                if (inrange[u]) store_row<ROWMODE>(tile_rows + (ROWMODE == 1 ? (uint32_t)pl[u] : (uint32_t)pl[u] * nbytes), m0[u], m1[u], rc);
+            }
         }
     }
 
-    drain_queue<TWO, ROWMODE, SLOTS, PROBE_MAXRUN>(st, qn, sw, q_line, q_step, q_pl, lines_w[0], buf[0], tile_rows, nbytes, rc, lane);
+    drain_queue<TWO, ROWMODE, SLOTS, PROBE_MAXRUN, WIDE>(st, qn, sw, q_line, q_step, q_pl, lines_w[0], buf[0], tile_rows, nbytes, rc, lane);
 }
 
 // ---------------------------------------------------------------------------
@@ -1440,6 +1565,15 @@ static hipError_t probe_w(hipStream_t s, uint32_t ntiles, const SubTable &st, co
                           const uint32_t *has_n, const SeqDesc *sd, const AnchorDesc *ad, const uint32_t *tile_contig,
                           const uint32_t *sched, uint32_t tile_base, uint8_t *out1, uint32_t nbytes, const RowCols &rc, int rowmode) {
 #define PG_A s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, sched, tile_base, out1, nbytes, rc
+    if (st.layout == LAYOUT_SPLIT) {  // more than 64 genomes: key lines + mask array
+        if (W_C && st.m > 16)
+            hipLaunchKernelGGL((k_probe<W_C, false, 0, 8, true, true>), dim3(ntiles), dim3(64), 0, s, st, seqw, nmw, has_n, sd, ad,
+                               tile_contig, sched, tile_base, out1, nbytes, rc);
+        else
+            hipLaunchKernelGGL((k_probe<W_C, false, 0, 8, false, true>), dim3(ntiles), dim3(64), 0, s, st, seqw, nmw, has_n, sd, ad,
+                               tile_contig, sched, tile_base, out1, nbytes, rc);
+        return hipGetLastError();
+    }
     if (st.slots == 16) {
         if (st.W == 2) {
             if (rowmode == 2) return probe_t<W_C, true, 2, 16>(PG_A);

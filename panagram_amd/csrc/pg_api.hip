@@ -323,7 +323,14 @@ static uint64_t next_prime(uint64_t n) {
     }
 }
 
-static int alloc_sub(pg_ctx *ctx, uint32_t W, uint32_t word0, uint32_t k, uint32_t m, uint32_t slots, uint64_t nbuckets, SubTable *out) {
+static void free_sub(SubTable &d) {
+    if (d.buckets) hipFree(d.buckets);
+    if (d.masks) hipFree(d.masks);
+    d.buckets = d.masks = nullptr;
+}
+
+static int alloc_sub(pg_ctx *ctx, uint32_t W, uint32_t word0, uint32_t k, uint32_t m, uint32_t slots, uint64_t nbuckets,
+                     uint32_t layout, SubTable *out) {
     if (nbuckets < 64) nbuckets = 64;
     nbuckets = next_prime(nbuckets);
     if (nbuckets > 0xFFFFFFFFull) return fail(PG_E_CAPACITY, "sub-table would exceed 2^32 lines (512 GB)");
@@ -333,37 +340,55 @@ static int alloc_sub(pg_ctx *ctx, uint32_t W, uint32_t word0, uint32_t k, uint32
     t.k = k;
     t.m = m;
     t.slots = slots;
-    t.pad_ = 0;
+    t.layout = layout;
     t.nbuckets = nbuckets;
-    void *p = nullptr;
-    hipError_t e = hipMalloc(&p, nbuckets * 16ull * slots);
-    if (e != hipSuccess) {  // the context may be sitting on cached row buffers: give them back and try once more
-        (void)hipGetLastError();
-        row_cache_trim(ctx);
-        e = hipMalloc(&p, nbuckets * 16ull * slots);
+    t.buckets = t.masks = nullptr;
+    auto grab = [&](uint64_t bytes, uint8_t **p) {
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(p), bytes);
+        if (e != hipSuccess) {  // the context may be sitting on cached row buffers: give them back and try once more
+            (void)hipGetLastError();
+            row_cache_trim(ctx);
+            e = hipMalloc(reinterpret_cast<void **>(p), bytes);
+        }
+        return e;
+    };
+    const uint64_t key_bytes = nbuckets * line_bytes(t), mask_bytes = layout == LAYOUT_SPLIT ? nbuckets * slots * 4ull * W : 0;
+    hipError_t e = grab(key_bytes, &t.buckets);
+    if (e == hipSuccess && mask_bytes) e = grab(mask_bytes, &t.masks);
+    if (e != hipSuccess) {
+        free_sub(t);
+        return fail(PG_E_HIP, "hipMalloc(%llu bytes) for k-mer table failed: %s", (unsigned long long)(key_bytes + mask_bytes),
+                    hipGetErrorString(e));
     }
-    if (e != hipSuccess)
-        return fail(PG_E_HIP, "hipMalloc(%llu bytes) for k-mer table failed: %s",
-                    (unsigned long long)(nbuckets * 16ull * slots), hipGetErrorString(e));
-    t.buckets = static_cast<uint8_t *>(p);
-    HIP_TRY(launch_table_init(ctx->stream, t));
+    e = launch_table_init(ctx->stream, t);
+    if (e != hipSuccess) {
+        free_sub(t);
+        return fail(PG_E_HIP, "table initialisation failed: %s", hipGetErrorString(e));
+    }
     *out = t;
     return PG_OK;
 }
 
-// lines a sub-table is created with for `want` expected keys (pg_table_create) — also what pg_table_bytes_for prices
-static uint64_t lines_for(uint64_t want, uint32_t slots) {
-    uint64_t nb = (uint64_t)((double)want / (TARGET_LOAD * slots)) + 1;
-    return next_prime(std::max<uint64_t>(nb, 64));
+// Geometry of a table for `ngenomes`: up to 64 genomes ONE sub-table of 16-byte slots {key, mask0, mask1}; more
+// genomes ONE sub-table in the split layout (16 bare keys per 128-byte line + W = ceil(N/32) mask words per slot in
+// a second array): one line fetch and one probe per position whatever N, where one 64-genome sub-table per pass
+// repeated the whole front end per pass.
+struct TableGeom {
+    uint32_t W, slots, layout;
+};
+static TableGeom geom_for(int ngenomes) {
+    const uint32_t ndbs = (uint32_t)(ngenomes + 31) / 32;
+    if (ndbs <= 2) return {ndbs, 8u, LAYOUT_SLOTS};
+    return {ndbs, SPLIT_KEYS, LAYOUT_SPLIT};
 }
 
 extern "C" int pg_table_bytes_for(int k, int ngenomes, uint64_t expected_keys, uint64_t *bytes) {
     if (!bytes) return fail(PG_E_INVALID, "pg_table_bytes_for: NULL argument");
     if (k < 1 || k > 32 || ngenomes < 1) return fail(PG_E_INVALID, "pg_table_bytes_for: bad k / ngenomes");
-    const int ndbs = (ngenomes + 31) / 32, nsub = (ndbs + 1) / 2;
+    const TableGeom g = geom_for(ngenomes);
     // (an estimate: one prime search less — the line count itself, not the next prime above it)
-    const uint64_t nb = (uint64_t)((double)std::max<uint64_t>(expected_keys, 1ull << 18) / (TARGET_LOAD * 8)) + 1;
-    *bytes = (uint64_t)nsub * std::max<uint64_t>(nb, 64) * 128ull;
+    const uint64_t nb = std::max<uint64_t>((uint64_t)((double)std::max<uint64_t>(expected_keys, 1ull << 18) / (TARGET_LOAD * g.slots)) + 1, 64);
+    *bytes = g.layout == LAYOUT_SPLIT ? nb * g.slots * (8ull + 4ull * g.W) : nb * 16ull * g.slots;
     return PG_OK;
 }
 
@@ -372,8 +397,7 @@ extern "C" int pg_table_create(pg_ctx *ctx, int k, int ngenomes, uint64_t expect
     if (k < 1 || k > 32) return fail(PG_E_INVALID, "k=%d unsupported (1..32)", k);
     if (ngenomes < 1) return fail(PG_E_INVALID, "ngenomes must be >= 1");
     int ndbs = (ngenomes + 31) / 32;
-    int nsub = (ndbs + 1) / 2;
-    if (nsub > MAX_SUB) return fail(PG_E_INVALID, "ngenomes=%d exceeds the supported %d", ngenomes, MAX_SUB * 64);
+    if (ndbs > (int)MAX_WORDS) return fail(PG_E_INVALID, "ngenomes=%d exceeds the supported %u", ngenomes, MAX_WORDS * 32);
     if (int r = use_device(ctx)) return r;
     pg_table *t = new pg_table();
     t->ctx = ctx;
@@ -391,16 +415,14 @@ extern "C" int pg_table_create(pg_ctx *ctx, int k, int ngenomes, uint64_t expect
         return fail(PG_E_HIP, "hipMalloc failed: %s", hipGetErrorString(e));
     }
     hipMemsetAsync(t->d_counters, 0, 2 * sizeof(unsigned long long), ctx->stream);
-    for (int s = 0; s < nsub; ++s) {
-        uint32_t W = (2 * s + 1 < ndbs) ? 2 : 1;
-        uint64_t want = expected_keys ? expected_keys : (1ull << 18);
-        // 256-byte lines where a minimizer group is expected to exceed 8 keys: many genomes'
-        // variants per locus
-        const uint32_t slots = 8u;  // pg_table_rehash widens the lines when the keys call for it
-        uint64_t nb = (uint64_t)((double)want / (TARGET_LOAD * slots)) + 1;
+    {
+        const TableGeom g = geom_for(ngenomes);
+        const uint64_t want = expected_keys ? expected_keys : (1ull << 18);
+        // (pg_table_rehash may widen the lines of the slots layout when the keys call for it)
+        const uint64_t nb = (uint64_t)((double)want / (TARGET_LOAD * g.slots)) + 1;
         SubHost sh;
         sh.count = 0;
-        int r = alloc_sub(ctx, W, 2 * s, (uint32_t)k, t->m, slots, nb, &sh.d);
+        int r = alloc_sub(ctx, g.W, 0, (uint32_t)k, t->m, g.slots, nb, g.layout, &sh.d);
         if (r) {
             pg_table_destroy(t);
             return r;
@@ -414,7 +436,7 @@ extern "C" int pg_table_create(pg_ctx *ctx, int k, int ngenomes, uint64_t expect
 static void table_free(pg_table *t) {
     hipSetDevice(t->ctx->device);
     hipStreamSynchronize(t->ctx->stream);
-    for (auto &s : t->subs) hipFree(s.d.buckets);
+    for (auto &s : t->subs) free_sub(s.d);
     if (t->d_counters) hipFree(t->d_counters);
     pg_ctx *c = t->ctx;
     delete t;
@@ -462,21 +484,21 @@ static int regrow(pg_table *t, int si, uint64_t nb, uint32_t slots = 0) {
     if (slots == 0) slots = t->subs[si].d.slots;
     for (int attempt = 0; attempt < 8; ++attempt) {
         SubTable nt;
-        if (int r = alloc_sub(ctx, t->subs[si].d.W, t->subs[si].d.word0, (uint32_t)t->k, t->m, slots, nb, &nt)) return r;
+        if (int r = alloc_sub(ctx, t->subs[si].d.W, t->subs[si].d.word0, (uint32_t)t->k, t->m, slots, nb, t->subs[si].d.layout, &nt)) return r;
         HIP_TRY(hipMemsetAsync(t->d_counters, 0, 2 * sizeof(unsigned long long), ctx->stream));
         HIP_TRY(launch_rehash(ctx->stream, t->subs[si].d, nt, t->d_counters, MAX_PROBE));
         unsigned long long c[2];
         if (int r = read_counters(t, c)) {
-            hipFree(nt.buckets);
+            free_sub(nt);
             return r;
         }
         if (c[1] == 0) {
-            hipFree(t->subs[si].d.buckets);
+            free_sub(t->subs[si].d);
             t->subs[si].d = nt;
             t->subs[si].count = c[0];
             return PG_OK;
         }
-        hipFree(nt.buckets);
+        free_sub(nt);
         nb *= 2;
     }
     return fail(PG_E_CAPACITY, "re-hash keeps overflowing");
@@ -525,7 +547,7 @@ extern "C" int pg_table_insert_seqset(pg_table *t, int g, const pg_seqset *sq) {
     if (t->ctx != sq->ctx) return fail(PG_E_INVALID, "table and seqset belong to different contexts");
     if (int r = use_device(t->ctx)) return r;
     TABLE_WRITER(t);
-    const int d = g / 32, si = d / 2, w = d % 2;
+    const int d = g / 32, si = 0, w = d;  // (one sub-table: the group's mask word)
     const uint32_t bits = 1u << (g % 32);
     uint64_t total = 0;
     for (auto &c : sq->desc)
@@ -559,7 +581,7 @@ extern "C" int pg_table_insert_seqset_min(pg_table *t, int g, const pg_seqset *s
     if (g < 0 || g >= t->ngenomes) return fail(PG_E_INVALID, "genome index %d out of range (0..%d)", g, t->ngenomes - 1);
     if (t->ctx != sq->ctx) return fail(PG_E_INVALID, "table and seqset belong to different contexts");
     if (int r = use_device(t->ctx)) return r;
-    const int d = g / 32, si = d / 2, w = d % 2;
+    const int d = g / 32, si = 0, w = d;  // (one sub-table: the group's mask word)
     const uint32_t bits = 1u << (g % 32);
     uint64_t total = 0;
     for (auto &c : sq->desc)
@@ -616,7 +638,7 @@ extern "C" int pg_table_insert_seqset_min(pg_table *t, int g, const pg_seqset *s
 }
 
 static int insert_keys_dev(pg_table *t, int db_idx, const uint64_t *d_keys, const uint32_t *d_vals, uint64_t n) {
-    const int si = db_idx / 2, w = db_idx % 2;
+    const int si = 0, w = db_idx;
     if (int r = ensure_room(t, si, n)) return r;
     for (int attempt = 0; attempt < 8; ++attempt) {
         hipStream_t st = t->ctx->stream;
@@ -752,7 +774,7 @@ extern "C" int pg_table_load_kmc(pg_table *t, int db_idx, const void *pre_, size
     if (rec == 0) return fail(PG_E_FORMAT, "kmc_pre: records of zero bytes (k == lut_prefix_length without counters)");
     if (int r = use_device(t->ctx)) return r;
     TABLE_WRITER(t);
-    const int si = db_idx / 2, w = db_idx % 2;
+    const int si = 0, w = db_idx;
     if (int r = ensure_room(t, si, H.total)) return r;
     hipStream_t st = t->ctx->stream;
     // chunks of whole records, about 256 MiB each, through two device buffers: the upload of chunk c+1 (pageable or
@@ -850,7 +872,7 @@ extern "C" int pg_table_stats(pg_table *t, uint64_t *nkeys, uint64_t *nslots, ui
     if (nbuckets) *nbuckets = c;
     if (bytes) {
         uint64_t by = 0;
-        for (auto &s2 : t->subs) by += s2.d.nbuckets * 16ull * s2.d.slots;
+        for (auto &s2 : t->subs) by += table_bytes(s2.d);
         *bytes = by;
     }
     return PG_OK;
@@ -886,6 +908,7 @@ extern "C" int pg_table_rehash(pg_table *t, double keys_per_bucket) {
         if (atoi(e) == 16) slots = 16;
     uint64_t keys = 0, spilled = 0;
     for (size_t si = 0; si < t->subs.size(); ++si) {
+        if (t->subs[si].d.layout == LAYOUT_SPLIT) slots = SPLIT_KEYS;
         const double kpb = std::min(keys_per_bucket * (slots / 8.0), 0.8 * slots);  // keys per line
         if (int r = regrow(t, (int)si, (uint64_t)((double)t->subs[si].count / kpb) + 1, slots)) return r;
         uint64_t sp = 0;
@@ -908,7 +931,7 @@ extern "C" int pg_table_export(pg_table *t, int db_idx, uint64_t *keys, uint32_t
     if (!t || !n) return fail(PG_E_INVALID, "pg_table_export: NULL argument");
     if (db_idx < 0 || db_idx >= t->ndbs) return fail(PG_E_INVALID, "db index %d out of range", db_idx);
     if (int r = use_device(t->ctx)) return r;
-    const int si = db_idx / 2, w = db_idx % 2;
+    const int si = 0, w = db_idx;
     hipStream_t st = t->ctx->stream;
     uint64_t *dk = nullptr;
     uint32_t *dv = nullptr;
@@ -2258,7 +2281,7 @@ extern "C" int pg_counters_for_read(pg_table *t, int db_idx, const char *ascii, 
     if (!rc && hipMalloc(reinterpret_cast<void **>(&d_out), nk * 4) != hipSuccess) rc = fail(PG_E_HIP, "hipMalloc failed");
     if (!rc) {
         hipStream_t st = t->ctx->stream;
-        const int si = db_idx / 2, w = db_idx % 2;
+        const int si = 0, w = db_idx;
         if (launch_counters(st, t->subs[si].d, w, t->k, sq->d_seqw, sq->d_nmw, sq->d_has_n, nk, d_out) != hipSuccess ||
             hipMemcpyAsync(out, d_out, nk * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
             hipStreamSynchronize(st) != hipSuccess)

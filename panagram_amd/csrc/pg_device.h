@@ -1,6 +1,7 @@
 // pg_device.h — device-side building blocks shared by the gfx950 kernels.
 //
-// Table layout (one sub-table covers W = 1 or 2 consecutive 32-genome groups):
+// Table layout (up to 64 genomes: one sub-table of W = 1 or 2 mask words per slot, described here; more genomes: ONE
+// table in the split layout — bare keys in the lines, all mask words of a slot in a second array — see SubTable):
 //   line   = 128 bytes, 128-byte aligned: MI355X moves 128 B per random HBM access whatever
 //            the request size (tools/gather_bench.hip: 32/64/128-B random gathers all run at
 //            ~50 G requests/s), so a probe fetches — and uses — a whole line
@@ -29,8 +30,14 @@ namespace pg {
 constexpr uint64_t EMPTY_KEY = ~0ull;
 // slots per table line: 8 (128-byte lines) or 16 (256-byte lines, tuning knob); a property of the
 // sub-table (SubTable::slots)
-constexpr int MAX_SUB = 8;  // sub-tables per pan table => up to 512 genomes
+constexpr int MAX_SUB = 1;           // a pan table is ONE sub-table (slots layout up to 64 genomes, split layout beyond)
+constexpr uint32_t MAX_WORDS = 64;   // mask words per slot of the split layout => up to 2048 genomes
 
+// Two layouts of a sub-table:
+//   LAYOUT_SLOTS (up to 64 genomes per sub-table): line = `slots` 16-byte slots {u64 key, u32 mask0, u32 mask1}
+//   LAYOUT_SPLIT (more than 64 genomes, ONE table whatever N): line = 16 bare keys (128 bytes) in `buckets`; the
+//                W = ceil(N/32) mask words of slot s of line l live in a second array, at word (l * 16 + s) * W —
+//                a probe fetches (and scans) key lines only and then reads exactly the mask words of its hit
 struct SubTable {
     uint8_t *buckets;
     uint64_t nbuckets;  // lines
@@ -38,9 +45,24 @@ struct SubTable {
     uint32_t word0;     // first 32-genome group covered
     uint32_t k;
     uint32_t m;         // minimizer length (0 = hash the whole k-mer)
-    uint32_t slots;     // 16-byte slots per line: 8 or 16
-    uint32_t pad_;
+    uint32_t slots;     // slots (keys) per line: 8 or 16
+    uint32_t layout;    // LAYOUT_SLOTS / LAYOUT_SPLIT
+    uint8_t *masks;     // LAYOUT_SPLIT only
 };
+constexpr uint32_t LAYOUT_SLOTS = 0, LAYOUT_SPLIT = 1;
+constexpr uint32_t SPLIT_KEYS = 16;  // keys per line of the split layout
+
+__host__ __device__ __forceinline__ uint32_t line_bytes(const SubTable &st) { return (st.layout == LAYOUT_SPLIT ? 8u : 16u) * st.slots; }
+__host__ __device__ __forceinline__ uint64_t table_bytes(const SubTable &st) {
+    return st.nbuckets * line_bytes(st) + (st.layout == LAYOUT_SPLIT ? st.nbuckets * st.slots * 4ull * st.W : 0ull);
+}
+__device__ __forceinline__ unsigned long long *key_ptr(const SubTable &st, uint64_t line, uint32_t s) {
+    return reinterpret_cast<unsigned long long *>(st.buckets + line * line_bytes(st) + (st.layout == LAYOUT_SPLIT ? 8u : 16u) * s);
+}
+__device__ __forceinline__ uint32_t *mask_ptr(const SubTable &st, uint64_t line, uint32_t s, uint32_t w) {
+    if (st.layout == LAYOUT_SPLIT) return reinterpret_cast<uint32_t *>(st.masks) + (line * st.slots + s) * st.W + w;
+    return reinterpret_cast<uint32_t *>(st.buckets + line * (16u * st.slots) + 16u * s + 8u) + w;
+}
 
 struct TableDesc {
     SubTable sub[MAX_SUB];
@@ -50,8 +72,6 @@ struct TableDesc {
     uint32_t ngenomes;
 };
 
-__host__ __device__ __forceinline__ uint32_t key_off(uint32_t, int s) { return 16u * s; }
-__host__ __device__ __forceinline__ uint32_t mask_off(uint32_t, int s, int w) { return 16u * s + 8u + 4u * w; }
 
 // Minimizer geometry of a table: w m-mers of m = k-w+1 bases per k-mer (m = 0: hash the k-mer
 // itself, k < 20).  Two forces (measured on MI355X):
@@ -246,19 +266,17 @@ __device__ __forceinline__ uint64_t extract_nmask64(P words, uint64_t p) {
     return (lo >> sh) | ((hi << 1) << (63 - sh));
 }
 
-// Single-lane lookup (GetCountersForRead kernel).
-__device__ __forceinline__ bool lane_lookup(const SubTable &st, uint64_t key, uint32_t &m0, uint32_t &m1) {
+// Single-lane lookup (GetCountersForRead kernel): mask word w of `key`, 0 if absent.
+__device__ __forceinline__ bool lane_lookup(const SubTable &st, uint64_t key, uint32_t w, uint32_t &out) {
     const uint32_t grp = group_of(st, key);
     uint32_t b = home_of_group(grp, st.nbuckets);
     uint32_t step = step_of_group(grp, st.nbuckets);
     for (uint64_t probes = 0; probes < st.nbuckets + GROUP_CHAIN; ++probes) {
-        const uint8_t *base = st.buckets + (uint64_t)b * (16u * st.slots);
         bool empty_seen = false;
-        for (int s = 0; s < (int)st.slots; ++s) {
-            uint64_t cur = *reinterpret_cast<const uint64_t *>(base + key_off(st.W, s));
+        for (uint32_t s = 0; s < st.slots; ++s) {
+            const uint64_t cur = *key_ptr(st, b, s);
             if (cur == key) {
-                m0 = *reinterpret_cast<const uint32_t *>(base + mask_off(st.W, s, 0));
-                m1 = st.W == 2 ? *reinterpret_cast<const uint32_t *>(base + mask_off(st.W, s, 1)) : 0u;
+                out = *mask_ptr(st, b, s, w);
                 return true;
             }
             empty_seen |= (cur == EMPTY_KEY);
@@ -266,7 +284,7 @@ __device__ __forceinline__ bool lane_lookup(const SubTable &st, uint64_t key, ui
         if (empty_seen) break;
         advance_line(key, (uint32_t)min(probes + 1, (uint64_t)GROUP_CHAIN + 1), st.nbuckets, b, step);
     }
-    m0 = m1 = 0;
+    out = 0;
     return false;
 }
 
@@ -279,13 +297,14 @@ __device__ __forceinline__ int lane_insert(const SubTable &st, uint64_t key, int
     const uint32_t grp = group_of(st, key);
     uint32_t b = home_of_group(grp, st.nbuckets);
     uint32_t step = step_of_group(grp, st.nbuckets);
+    const uint32_t kstride = st.layout == LAYOUT_SPLIT ? 8u : 16u;  // bytes from one key of a line to the next
     for (uint32_t probes = 0; probes < max_probe; ++probes) {
-        uint8_t *base = st.buckets + (uint64_t)b * (16u * st.slots);
+        uint8_t *base = st.buckets + (uint64_t)b * line_bytes(st);
         for (uint32_t s0 = 0; s0 < st.slots; s0 += 8) {  // 8 slots at a time: all key loads in flight together
-            uint8_t *grp8 = base + 16u * s0;
+            uint8_t *grp8 = base + kstride * s0;
             uint64_t kk[8];
 #pragma unroll
-            for (int s = 0; s < 8; ++s) kk[s] = *reinterpret_cast<const volatile unsigned long long *>(grp8 + 16 * s);
+            for (int s = 0; s < 8; ++s) kk[s] = *reinterpret_cast<const volatile unsigned long long *>(grp8 + kstride * s);
             int hit = -1, free_s = -1;
 #pragma unroll
             for (int s = 7; s >= 0; --s) {
@@ -296,7 +315,7 @@ __device__ __forceinline__ int lane_insert(const SubTable &st, uint64_t key, int
             // slots before the first empty one hold other keys for good; from there on a slot may be
             // taken by a concurrent insert between our read and our CAS: walk on, one CAS per slot
             for (int s = (hit >= 0 ? hit : free_s); hit < 0 && s >= 0 && s < 8; ++s) {
-                unsigned long long *kp = reinterpret_cast<unsigned long long *>(grp8 + 16 * s);
+                unsigned long long *kp = reinterpret_cast<unsigned long long *>(grp8 + kstride * s);
                 const unsigned long long cur = atomicCAS(kp, (unsigned long long)EMPTY_KEY, (unsigned long long)key);
                 if (cur == EMPTY_KEY) {
                     hit = s;
@@ -306,7 +325,7 @@ __device__ __forceinline__ int lane_insert(const SubTable &st, uint64_t key, int
                 }
             }
             if (hit >= 0) {
-                uint32_t *mp = reinterpret_cast<uint32_t *>(grp8 + 16 * hit + 8 + 4 * w);
+                uint32_t *mp = mask_ptr(st, b, s0 + (uint32_t)hit, (uint32_t)w);
                 if (COUNT) {
                     if (*mp < 0xFFFFFF00u) atomicAdd(mp, bits);  // saturates far above any -ci threshold
                 } else {

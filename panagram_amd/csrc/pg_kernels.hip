@@ -18,11 +18,12 @@ namespace pg {
 // ---------------------------------------------------------------------------
 // table init: every thread writes one 16-byte chunk of a bucket
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_table_init(uint4 *chunks, uint64_t nchunks, uint32_t W) {
+__global__ __launch_bounds__(256) void k_table_init(uint4 *chunks, uint64_t nchunks, uint32_t split) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (; i < nchunks; i += stride) {
-        chunks[i] = make_uint4(~0u, ~0u, 0u, 0u);  // {EMPTY key, mask0 = 0, mask1 = 0}
+        // slots layout: {EMPTY key, mask0 = 0, mask1 = 0}; split layout: two EMPTY keys (the mask array is memset)
+        chunks[i] = split ? make_uint4(~0u, ~0u, ~0u, ~0u) : make_uint4(~0u, ~0u, 0u, 0u);
     }
 }
 
@@ -326,11 +327,10 @@ __global__ __launch_bounds__(256) void k_rehash(SubTable src, SubTable dst, unsi
     for (; i < nslots; i += stride) {
         uint64_t b = i / ns;
         int s = (int)(i - b * ns);
-        const uint8_t *base = src.buckets + b * (16u * src.slots);
-        uint64_t key = *reinterpret_cast<const uint64_t *>(base + key_off(src.W, s));
+        uint64_t key = *key_ptr(src, b, (uint32_t)s);
         if (key == EMPTY_KEY) continue;
         for (uint32_t w = 0; w < src.W; ++w) {
-            uint32_t m = *reinterpret_cast<const uint32_t *>(base + mask_off(src.W, s, w));
+            uint32_t m = *mask_ptr(src, b, (uint32_t)s, w);
             if (m == 0 && w > 0) continue;
             int r = lane_insert(dst, key, (int)w, m, max_probe);
             if (r < 0) atomicOr(reinterpret_cast<unsigned int *>(&counters[1]), 1u);
@@ -352,10 +352,9 @@ __global__ __launch_bounds__(256) void k_merge_min(SubTable src, SubTable dst, i
     for (; i < nslots; i += stride) {
         uint64_t b = i / ns;
         int s = (int)(i - b * ns);
-        const uint8_t *base = src.buckets + b * (16u * src.slots);
-        uint64_t key = *reinterpret_cast<const uint64_t *>(base + key_off(src.W, s));
+        uint64_t key = *key_ptr(src, b, (uint32_t)s);
         if (key == EMPTY_KEY) continue;
-        if (*reinterpret_cast<const uint32_t *>(base + mask_off(src.W, s, 0)) < min_count) continue;
+        if (*mask_ptr(src, b, (uint32_t)s, 0) < min_count) continue;
         int r = lane_insert(dst, key, w, bits, max_probe);
         if (r < 0) atomicOr(reinterpret_cast<unsigned int *>(&counters[1]), 1u);
         else claimed += r;
@@ -373,7 +372,7 @@ __global__ __launch_bounds__(256) void k_count_spill(SubTable st, unsigned long 
     for (; i < nslots; i += stride) {
         const uint64_t b = i / ns;
         const int s = (int)(i - b * ns);
-        const uint64_t key = *reinterpret_cast<const uint64_t *>(st.buckets + b * (16u * st.slots) + key_off(st.W, s));
+        const uint64_t key = *key_ptr(st, b, (uint32_t)s);
         if (key == EMPTY_KEY) continue;
         if (home_of_group(group_of(st, key), st.nbuckets) != (uint32_t)b) ++spilled;
     }
@@ -390,10 +389,9 @@ __global__ __launch_bounds__(256) void k_export(SubTable st, int w, uint64_t *ke
     for (; i < nslots; i += stride) {
         uint64_t b = i / ns;
         int s = (int)(i - b * ns);
-        const uint8_t *base = st.buckets + b * (16u * st.slots);
-        uint64_t key = *reinterpret_cast<const uint64_t *>(base + key_off(st.W, s));
+        uint64_t key = *key_ptr(st, b, (uint32_t)s);
         if (key == EMPTY_KEY) continue;
-        uint32_t m = *reinterpret_cast<const uint32_t *>(base + mask_off(st.W, s, w));
+        uint32_t m = *mask_ptr(st, b, (uint32_t)s, (uint32_t)w);
         if (m == 0) continue;
         unsigned long long idx = atomicAdd(count, 1ull);
         if (keys && idx < cap) {
@@ -414,8 +412,7 @@ __global__ __launch_bounds__(256) void k_counters(SubTable st, int w, int k, con
         uint32_t r = 0;
         if (!(hasn && extract_nmask(nmw, p, k))) {
             uint64_t key = canonical_from_le(extract_bases(seqw, p), k);
-            uint32_t m0, m1;
-            if (lane_lookup(st, key, m0, m1)) r = w ? m1 : m0;
+            lane_lookup(st, key, (uint32_t)w, r);
         }
         out[p] = r;
     }
@@ -432,10 +429,13 @@ static inline unsigned grid_for(uint64_t n, unsigned block, unsigned cap) {
 }
 
 hipError_t launch_table_init(hipStream_t st, const SubTable &t) {
-    uint64_t nchunks = t.nbuckets * t.slots;
+    const uint64_t nchunks = t.nbuckets * line_bytes(t) / 16;
     hipLaunchKernelGGL(k_table_init, dim3(grid_for(nchunks, 256, 256 * 32)), dim3(256), 0, st,
-                       reinterpret_cast<uint4 *>(t.buckets), nchunks, t.W);
-    return hipGetLastError();
+                       reinterpret_cast<uint4 *>(t.buckets), nchunks, t.layout == LAYOUT_SPLIT ? 1u : 0u);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && t.layout == LAYOUT_SPLIT)
+        e = hipMemsetAsync(t.masks, 0, t.nbuckets * t.slots * 4ull * t.W, st);
+    return e;
 }
 
 hipError_t launch_pack(hipStream_t st, const void *d_ascii, uint64_t len, uint64_t *seqw, uint32_t *nmw,
