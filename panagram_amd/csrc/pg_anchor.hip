@@ -187,22 +187,32 @@ __device__ __attribute__((noinline)) uint2 lane_chase_wide_cold(uint8_t *buckets
     return make_uint2(hl, s1);
 }
 
-// the row of a position: the W mask words of (line, slot1 - 1), or zeros (slot1 == 0); nbytes = ceil(N / 8)
+// the row of a position: the W mask words of (line, slot1 - 1), or zeros (slot1 == 0); nbytes = ceil(N / 8).
+// Rows and mask blocks are contiguous, so the copy goes in the widest pieces the width allows — one dwordx4 / x3 /
+// x2 access per lane covers the wave's rows back to back (word-by-word stores at a 12- or 20-byte lane stride
+// ran 2x slower); only 4-byte alignment is needed for them (gfx950 global memory takes unaligned wide accesses).
+template <int NW>
+struct __attribute__((packed, aligned(4))) WordsN {
+    uint32_t w[NW];
+};
+template <int NW>
+__device__ __forceinline__ void copy_words(const uint32_t *src, uint8_t *dst, bool hit) {
+    WordsN<NW> v;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) v.w[i] = 0;
+    if (hit) v = *reinterpret_cast<const WordsN<NW> *>(src);
+    *reinterpret_cast<WordsN<NW> *>(dst) = v;
+}
 __device__ __forceinline__ void store_row_wide(const uint8_t *masks, uint32_t W, uint32_t nbytes, uint8_t *row, uint32_t hline,
                                                uint32_t slot1) {
     const bool hit = slot1 != 0;
     const uint32_t *mp = reinterpret_cast<const uint32_t *>(masks) + ((uint64_t)hline * SPLIT_KEYS + (slot1 - 1u)) * W;
-    if (nbytes % 16 == 0) {  // (wave-uniform) rows and mask blocks are whole 16-byte chunks, both aligned
-        for (uint32_t q = 0; q < nbytes / 16; ++q) {
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (hit) v = reinterpret_cast<const uint4 *>(mp)[q];
-            reinterpret_cast<uint4 *>(row)[q] = v;
-        }
-        return;
-    }
-    struct __attribute__((packed)) U32 { uint32_t v; };
-    const uint32_t full = nbytes / 4;
-    for (uint32_t d = 0; d < full; ++d) reinterpret_cast<U32 *>(row + 4 * d)->v = hit ? mp[d] : 0u;
+    uint32_t d = 0;
+    const uint32_t full = nbytes / 4;  // (wave-uniform loop bounds)
+    for (; d + 4 <= full; d += 4) copy_words<4>(mp + d, row + 4 * d, hit);
+    if (full - d == 3) copy_words<3>(mp + d, row + 4 * d, hit);
+    else if (full - d == 2) copy_words<2>(mp + d, row + 4 * d, hit);
+    else if (full - d == 1) copy_words<1>(mp + d, row + 4 * d, hit);
     if (nbytes % 4) {
         const uint32_t v = hit ? mp[full] : 0u;
         for (uint32_t bb = 0; bb < nbytes % 4; ++bb) row[4 * full + bb] = (uint8_t)(v >> (8 * bb));
@@ -1305,6 +1315,7 @@ __global__ __launch_bounds__(EPI_THREADS) void k_epilogue_words(uint32_t N, cons
         if (r0 < npos) {  // (block-uniform)
             uint32_t *hrow = hist + rel_base * (N + 1);
             const uint32_t lim = max(min(a.nkmers - tile_start, 2u * (uint32_t)PROBE_TILE) * nbytes, 4u) - 4u;  // as in issue()
+
 #pragma unroll
             for (uint32_t j = 0; j < NJ; ++j) {
                 const uint32_t pl = r0 + j * RPS + rsub;
