@@ -24,7 +24,7 @@ ks["Name"] = ks["Name"].str.slice(0, 60)
 out.append("\n## `rocprofv3 --kernel-trace --stats` (top kernels)\n")
 out.append("```\n" + ks.head(8).to_string(index=False) + "\n```\n")
 out.append("\n## PMC passes (mean per dispatch of the dominant kernel, separate runs per counter set)\n")
-for d in ("pmc_fetch", "pmc_write", "pmc_ea", "pmc_sq"):
+for d in ("pmc_fetch", "pmc_write", "pmc_ea", "pmc_misc", "pmc_sq"):
     f = os.path.join(src, d, "pmc_counter_collection.csv")
     if not os.path.exists(f):
         continue
