@@ -601,6 +601,198 @@ __global__ __launch_bounds__(64) void k_probe(const SubTable st, const uint64_t 
 }
 
 // ---------------------------------------------------------------------------
+// k-mer set construction, wave-cooperative (replaces one thread per k-mer with a per-thread minimizer loop and eight
+// volatile key loads each): the SAME front end as k_probe — one wave per tile of 512 positions, per 64-lane batch
+// canonical keys, minimizer by the sliding DPP minimum, runs of equal home line, the batch's lines staged into LDS
+// with coalesced 128-byte fetches — then every lane scans its line's snapshot:
+//   key found (every later genome's common case: 85-99 % of its k-mers exist already)  ->  OR the genome's bit into
+//       the slot's mask word (a plain store when the snapshot shows the bit missing: see lane_insert_grp's note on
+//       the one-writer invariant) or, in counting mode, atomicAdd
+//   key absent in the snapshot  ->  (position, group) goes to the wave's LDS queue; the queue is worked off densely,
+//       64 entries at a time, by the CAS-claiming single-lane insert (lane_insert_grp: claims race correctly against
+//       other waves; the group id is handed over, not recomputed)
+// counters[0] += newly claimed keys; counters[1] = overflow flag (a probe sequence exceeded max_probe lines).
+// ---------------------------------------------------------------------------
+constexpr int INSERT_QCAP = 256;
+
+template <int W_C, bool M64>
+__global__ __launch_bounds__(64) void k_insert_tile(const SubTable st, int w, uint32_t bits, uint32_t count_mode,
+                                                    const uint64_t *__restrict__ seqw, const uint32_t *__restrict__ nmw,
+                                                    const uint32_t *__restrict__ has_n, const SeqDesc *__restrict__ sd,
+                                                    const uint32_t *__restrict__ tile0, uint32_t ncontigs,
+                                                    unsigned long long *__restrict__ counters, uint32_t max_probe) {
+    constexpr int SLOTS = 8;  // 16-byte chunks of a 128-byte line (8 slots, or 16 bare keys in the split layout)
+    constexpr int LDS_LINE_U4 = SLOTS + 1;
+    constexpr int STAGE_ITERS = (PROBE_MAXRUN * SLOTS + 63) / 64;
+    __shared__ uint64_t sw[PROBE_SEQW];
+    __shared__ uint32_t nw[PROBE_SEQW];
+    __shared__ uint32_t lines_w[PROBE_MAXRUN];
+    __shared__ uint4 buf[((STAGE_ITERS * 64 + SLOTS - 1) / SLOTS) * LDS_LINE_U4];
+    __shared__ uint32_t q_grp[INSERT_QCAP];
+    __shared__ uint16_t q_pl[INSERT_QCAP];
+    const int lane = threadIdx.x;
+    const int k = (int)st.k;
+    const bool split = st.layout == LAYOUT_SPLIT;  // (uniform)
+    const uint32_t tile = blockIdx.x;
+    uint32_t c = 0;  // contig of the tile: last c with tile0[c] <= tile (uniform binary search)
+    {
+        uint32_t lo = 0, hi = ncontigs;
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (tile0[mid] <= tile) lo = mid;
+            else hi = mid;
+        }
+        c = lo;
+    }
+    const SeqDesc s = sd[c];
+    const uint32_t nkmers = (uint32_t)(s.len - (uint64_t)k + 1);
+    const uint32_t tile_start = (tile - tile0[c]) * PROBE_TILE;
+    const uint32_t npos = min((uint32_t)PROBE_TILE, nkmers - tile_start);
+    const bool hasn = has_n[c] != 0;
+    for (int i = lane; i < PROBE_SEQW; i += 64) {
+        const uint64_t wi = (uint64_t)(tile_start >> 5) + i;
+        sw[i] = wi < s.nwords ? seqw[s.seq_off + wi] : 0ull;
+        nw[i] = (hasn && wi < s.nwords) ? nmw[s.seq_off + wi] : 0u;
+    }
+    __syncthreads();
+    const uint64_t kmask = kmer_mask(k);
+    constexpr int HALO = W_C ? W_C - 1 : 0;
+    constexpr int STRIDE = 64 - HALO;
+    const uint32_t m = W_C ? (uint32_t)k - W_C + 1 : 0;
+    const uint64_t mm64 = (m >= 32) ? ~0ull : ((1ull << (2 * (m ? m : 1))) - 1);
+    uint32_t qn = 0, claimed = 0;  // (wave-uniform)
+    bool overflowed = false;
+
+    auto drain = [&]() {  // the queued (absent) keys through the claiming insert, 64 at a time
+        __syncthreads();
+        for (uint32_t e0 = 0; e0 < qn; e0 += 64) {
+            const uint32_t e = e0 + lane;
+            int r = 0;
+            if (e < qn) {
+                const uint64_t key = canonical_from_le(extract_bases32(reinterpret_cast<const uint32_t *>(sw), q_pl[e]), k);
+                r = count_mode ? lane_insert_grp<true>(st, key, w, bits, max_probe, q_grp[e])
+                               : lane_insert_grp<false>(st, key, w, bits, max_probe, q_grp[e]);
+            }
+            overflowed |= __ballot(r < 0) != 0;
+            claimed += (uint32_t)__popcll(__ballot(r > 0));
+        }
+        qn = 0;
+        __syncthreads();
+    };
+
+    for (uint32_t b = 0; b < npos; b += STRIDE) {
+        const int32_t pl = (int32_t)(b + lane) - HALO;
+        const bool inrange = pl >= (int32_t)b && pl < (int32_t)npos;
+        const uint32_t pq = (uint32_t)max(pl, 0);
+        const uint64_t X = extract_bases32(reinterpret_cast<const uint32_t *>(sw), pq) & kmask;
+        const uint64_t B = revcomp_le(X, k);
+        const uint64_t key = canonical_from_xb(X, B, k);
+        bool act = inrange;
+        if (hasn) act = act && (extract_nmask(nw, pq, k) == 0);
+        uint32_t grp;
+        if (W_C) {
+            const uint32_t off = (uint32_t)(pl + HALO) - pq;
+            if constexpr (!M64) {
+                const uint32_t mm32 = (uint32_t)mm64;
+                const uint32_t fa = __builtin_amdgcn_alignbit((uint32_t)(X >> 32), (uint32_t)X, 2 * off) & mm32;
+                const uint32_t fr = __builtin_amdgcn_alignbit((uint32_t)(B >> 32), (uint32_t)B, 2 * (HALO - off)) & mm32;
+                grp = mz_order(min(fa, fr));
+            } else {
+                const uint64_t fa = (X >> (2 * off)) & mm64;
+                const uint64_t fr = (B >> (2 * (HALO - off))) & mm64;
+                grp = mmer_rank(fa < fr ? fa : fr);
+            }
+            grp = sliding_min<W_C ? W_C : 1>(grp);
+        } else {
+            grp = group_of_key(key);
+        }
+        const uint32_t line = home_of_group(grp, st.nbuckets);
+        const uint32_t prev_line = lane_up1(line);
+        const bool prev_act = lane > 0 && lane_up1(act ? 1u : 0u) != 0;
+        const bool leader = act && (!prev_act || line != prev_line);
+        const unsigned long long lmask = __ballot(leader);
+        const uint32_t rid = lanes_le_count(lmask, leader) - 1;
+        const uint32_t nruns = (uint32_t)__popcll(lmask);
+        bool found = false;
+        for (uint32_t r0 = 0; r0 < nruns; r0 += PROBE_MAXRUN) {
+            const uint32_t nl = min((uint32_t)PROBE_MAXRUN, nruns - r0);
+            if (leader && rid - r0 < nl) lines_w[rid - r0] = line;
+            __syncthreads();
+            uint4 v[STAGE_ITERS];
+#pragma unroll
+            for (int it = 0; it < STAGE_ITERS; ++it) {
+                const uint32_t ls = min((uint32_t)(it * (64 / SLOTS) + lane / SLOTS), nl - 1u);
+                v[it] = *reinterpret_cast<const uint4 *>(st.buckets + (((uint64_t)lines_w[ls] * 128u) | ((lane % SLOTS) * 16u)));
+            }
+#pragma unroll
+            for (int it = 0; it < STAGE_ITERS; ++it) {
+                const uint32_t idx = it * 64 + lane;
+                buf[(idx / SLOTS) * LDS_LINE_U4 + (idx % SLOTS)] = v[it];
+            }
+            __syncthreads();
+            if (act && rid - r0 < nl) {
+                const uint4 *ln = buf + (rid - r0) * LDS_LINE_U4;
+                uint32_t *mp = nullptr;
+                uint32_t cur = 0;
+                if (split) {
+                    uint32_t slot1;
+                    scan_keys16_lds(ln, key, slot1);
+                    if (slot1) {
+                        found = true;
+                        mp = reinterpret_cast<uint32_t *>(st.masks) + ((uint64_t)line * SPLIT_KEYS + (slot1 - 1u)) * st.W + (uint32_t)w;
+                        cur = *reinterpret_cast<const volatile uint32_t *>(mp);
+                    }
+                } else {
+                    uint32_t m0, m1;
+                    // (the slot's byte offset is what is needed here: scan the keys like scan_line_lds does)
+                    uint64_t kk[8];
+#pragma unroll
+                    for (int sl = 0; sl < 8; ++sl) kk[sl] = *reinterpret_cast<const uint64_t *>(ln + sl);
+                    unsigned long long e[8];
+#pragma unroll
+                    for (int sl = 0; sl < 8; ++sl) e[sl] = __builtin_amdgcn_ballot_w64(kk[sl] == key);
+                    const unsigned long long b0 = e[1] | e[3] | e[5] | e[7], b1 = e[2] | e[3] | e[6] | e[7], b2 = e[4] | e[5] | e[6] | e[7];
+                    (void)m0;
+                    (void)m1;
+                    if (__builtin_amdgcn_inverse_ballot_w64(b0 | b1 | b2 | e[0])) {
+                        found = true;
+                        const uint32_t off = (__builtin_amdgcn_inverse_ballot_w64(b0) ? 16u : 0u) | (__builtin_amdgcn_inverse_ballot_w64(b1) ? 32u : 0u) |
+                                             (__builtin_amdgcn_inverse_ballot_w64(b2) ? 64u : 0u);
+                        cur = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(ln) + off + 8 + 4 * w);
+                        mp = reinterpret_cast<uint32_t *>(st.buckets + (uint64_t)line * 128u + off + 8 + 4 * w);
+                    }
+                }
+                if (found) {
+                    if (count_mode) {
+                        if (cur < 0xFFFFFF00u) atomicAdd(mp, bits);
+                    } else if ((cur & bits) != bits) {
+                        *reinterpret_cast<volatile uint32_t *>(mp) = cur | bits;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        // absent from the snapshot of its line (or the line was not reached): queue for the claiming insert
+        const bool todo = act && !found;
+        const unsigned long long tmask = __ballot(todo);
+        if (tmask) {
+            if (qn + 64 > (uint32_t)INSERT_QCAP) drain();
+            if (todo) {
+                const uint32_t slot = qn + lanes_le_count(tmask, true) - 1;
+                q_grp[slot] = grp;
+                q_pl[slot] = (uint16_t)pl;
+            }
+            qn += (uint32_t)__popcll(tmask);
+        }
+    }
+    if (qn) drain();
+    if (lane == 0) {
+        if (claimed) atomicAdd(&counters[0], (unsigned long long)claimed);
+        if (overflowed) atomicOr(reinterpret_cast<unsigned int *>(&counters[1]), 1u);
+    }
+}
+
+// ---------------------------------------------------------------------------
 // statistics from finished rows: bitmap.100, per-bin popcount histogram, column sums.
 // A workgroup (256 threads) walks a CONTIGUOUS range of tiles (PT consecutive positions per
 // thread and tile); histogram counters stay in LDS until the bin changes and column sums until
@@ -1731,6 +1923,39 @@ hipError_t launch_lowres(hipStream_t st, uint32_t ngenomes, const AnchorDesc *ad
     if (ntiles == 0) return hipSuccess;
     hipLaunchKernelGGL(k_lowres, dim3(ntiles), dim3(64), 0, st, ngenomes, ad, tile_contig, out1, outlow, step);
     return hipGetLastError();
+}
+
+template <int W_C>
+static hipError_t insert_tiles_w(hipStream_t s, uint32_t ntiles, const SubTable &st, int w, uint32_t bits, uint32_t count_mode,
+                                 const uint64_t *seqw, const uint32_t *nmw, const uint32_t *has_n, const SeqDesc *sd,
+                                 const uint32_t *tile0, uint32_t ncontigs, unsigned long long *counters, uint32_t max_probe) {
+    if (W_C && st.m > 16)
+        hipLaunchKernelGGL((k_insert_tile<W_C, true>), dim3(ntiles), dim3(64), 0, s, st, w, bits, count_mode, seqw, nmw, has_n, sd,
+                           tile0, ncontigs, counters, max_probe);
+    else
+        hipLaunchKernelGGL((k_insert_tile<W_C, false>), dim3(ntiles), dim3(64), 0, s, st, w, bits, count_mode, seqw, nmw, has_n, sd,
+                           tile0, ncontigs, counters, max_probe);
+    return hipGetLastError();
+}
+
+// every k-mer of the contigs described by sd / tile0 (tile0[c] = first tile of contig c; tile0[ncontigs] = ntiles)
+hipError_t launch_insert_tiles(hipStream_t s, const SubTable &st, int w, uint32_t bits, int count_mode, const uint64_t *seqw,
+                               const uint32_t *nmw, const uint32_t *has_n, const SeqDesc *sd, const uint32_t *tile0,
+                               uint32_t ncontigs, uint32_t ntiles, unsigned long long *counters, uint32_t max_probe) {
+    if (ntiles == 0) return hipSuccess;
+    const uint32_t win = st.m ? st.k - st.m + 1 : 0;
+#define PG_I s, ntiles, st, w, bits, (uint32_t)count_mode, seqw, nmw, has_n, sd, tile0, ncontigs, counters, max_probe
+    switch (win) {
+        case 0: return insert_tiles_w<0>(PG_I);
+        case 3: return insert_tiles_w<3>(PG_I);
+        case 4: return insert_tiles_w<4>(PG_I);
+        case 5: return insert_tiles_w<5>(PG_I);
+        case 6: return insert_tiles_w<6>(PG_I);
+        case 7: return insert_tiles_w<7>(PG_I);
+        case 8: return insert_tiles_w<8>(PG_I);
+        default: return hipErrorInvalidValue;
+    }
+#undef PG_I
 }
 
 }  // namespace pg

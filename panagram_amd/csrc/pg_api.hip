@@ -541,6 +541,42 @@ static int after_insert(pg_table *t, int si) {
     return PG_OK;
 }
 
+// enqueue the insertion of every k-mer of `sq` into sub-table `d` (word w, `bits`; count_mode: occurrences are added):
+// ONE launch of the wave-cooperative kernel over all contigs for tables of 128-byte lines, else one launch of the
+// thread-per-k-mer kernel per contig (256-byte lines: the PG_TABLE_SLOTS=16 tuning knob).  *d_tile0 is a small
+// device array the caller frees once the stream has been synchronised.
+static int enqueue_insert(pg_table *t, const SubTable &d, int w, uint32_t bits, int count_mode, const pg_seqset *sq,
+                          unsigned long long *counters, uint32_t **d_tile0) {
+    hipStream_t st = t->ctx->stream;
+    *d_tile0 = nullptr;
+    const bool tiles_ok = d.layout == LAYOUT_SPLIT || d.slots == 8;
+    if (!tiles_ok || getenv("PG_INSERT_PER_THREAD")) {
+        for (uint32_t c = 0; c < sq->n; ++c) {
+            const SeqDesc &sd = sq->desc[c];
+            if (sd.len < (uint64_t)t->k) continue;
+            HIP_TRY(launch_insert_seq(st, d, w, bits, t->k, sq->d_seqw + sd.seq_off, sq->d_nmw + sd.seq_off, sq->d_has_n + c,
+                                      sd.len - t->k + 1, counters, MAX_PROBE, count_mode));
+        }
+        return PG_OK;
+    }
+    std::vector<uint32_t> tile0(sq->n + 1, 0);
+    uint64_t tiles = 0;
+    for (uint32_t c = 0; c < sq->n; ++c) {
+        tile0[c] = (uint32_t)tiles;
+        const uint64_t len = sq->desc[c].len;
+        if (len >= (uint64_t)t->k) tiles += (len - t->k + 1 + PROBE_TILE - 1) / PROBE_TILE;
+        if (tiles > 0x7FFFFFFFull) return fail(PG_E_INVALID, "too many tiles in one insert launch");
+    }
+    tile0[sq->n] = (uint32_t)tiles;
+    if (tiles == 0) return PG_OK;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(d_tile0), tile0.size() * 4));
+    HIP_TRY(hipMemcpyAsync(*d_tile0, tile0.data(), tile0.size() * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));  // (tile0 is a host temporary)
+    HIP_TRY(launch_insert_tiles(st, d, w, bits, count_mode, sq->d_seqw, sq->d_nmw, sq->d_has_n, sq->d_desc, *d_tile0, sq->n,
+                                (uint32_t)tiles, counters, MAX_PROBE));
+    return PG_OK;
+}
+
 extern "C" int pg_table_insert_seqset(pg_table *t, int g, const pg_seqset *sq) {
     if (!t || !sq) return fail(PG_E_INVALID, "pg_table_insert_seqset: NULL argument");
     if (g < 0 || g >= t->ngenomes) return fail(PG_E_INVALID, "genome index %d out of range (0..%d)", g, t->ngenomes - 1);
@@ -556,15 +592,12 @@ extern "C" int pg_table_insert_seqset(pg_table *t, int g, const pg_seqset *sq) {
     for (int attempt = 0; attempt < 8; ++attempt) {
         hipStream_t st = t->ctx->stream;
         HIP_TRY(hipMemsetAsync(t->d_counters, 0, 2 * sizeof(unsigned long long), st));
-        for (uint32_t c = 0; c < sq->n; ++c) {
-            const SeqDesc &sd = sq->desc[c];
-            if (sd.len < (uint64_t)t->k) continue;
-            HIP_TRY(launch_insert_seq(st, t->subs[si].d, w, bits, t->k, sq->d_seqw + sd.seq_off,
-                                      sq->d_nmw + sd.seq_off, sq->d_has_n + c, sd.len - t->k + 1,
-                                      t->d_counters, MAX_PROBE));
-        }
-        unsigned long long cnt[2];
-        if (int r = read_counters(t, cnt)) return r;
+        uint32_t *d_tile0 = nullptr;
+        const int er = enqueue_insert(t, t->subs[si].d, w, bits, 0, sq, t->d_counters, &d_tile0);
+        unsigned long long cnt[2] = {0, 0};
+        const int rr = er ? er : read_counters(t, cnt);  // (synchronises)
+        if (d_tile0) hipFree(d_tile0);
+        if (rr) return rr;
         t->subs[si].count += cnt[0];
         if (cnt[1] == 0) return after_insert(t, si);
         // a probe chain exceeded MAX_PROBE buckets: grow and redo (inserts are idempotent)
@@ -600,14 +633,13 @@ extern "C" int pg_table_insert_seqset_min(pg_table *t, int g, const pg_seqset *s
                 rc = fail(PG_E_HIP, "hipMemsetAsync failed");
                 break;
             }
-            for (uint32_t c = 0; c < sq->n && !rc; ++c) {
-                const SeqDesc &sd = sq->desc[c];
-                if (sd.len < (uint64_t)t->k) continue;
-                if (launch_insert_seq(st, cnt->subs[0].d, 0, 1u, t->k, sq->d_seqw + sd.seq_off, sq->d_nmw + sd.seq_off,
-                                      sq->d_has_n + c, sd.len - t->k + 1, cnt->d_counters, MAX_PROBE, 1) != hipSuccess)
-                    rc = fail(PG_E_HIP, "counting kernel failed");
-            }
+            uint32_t *d_tile0 = nullptr;
+            rc = enqueue_insert(t, cnt->subs[0].d, 0, 1u, 1, sq, cnt->d_counters, &d_tile0);
             if (!rc) rc = read_counters(cnt, c2);
+            if (d_tile0) {
+                hipStreamSynchronize(st);
+                hipFree(d_tile0);
+            }
         } while (0);
         // counting is not idempotent: a table that overflowed (or ran too full) is thrown away and
         // the pass repeated in a bigger one

@@ -292,9 +292,8 @@ __device__ __forceinline__ bool lane_lookup(const SubTable &st, uint64_t key, ui
 // 1 = newly claimed, -1 = gave up after max_probe lines (table must grow).
 // COUNT: mask word w is an occurrence counter (bits is added) instead of a presence mask (OR-ed)
 template <bool COUNT = false, bool ATOMIC_OR = false>
-__device__ __forceinline__ int lane_insert(const SubTable &st, uint64_t key, int w, uint32_t bits,
-                                           uint32_t max_probe) {
-    const uint32_t grp = group_of(st, key);
+__device__ __forceinline__ int lane_insert_grp(const SubTable &st, uint64_t key, int w, uint32_t bits, uint32_t max_probe,
+                                               uint32_t grp) {
     uint32_t b = home_of_group(grp, st.nbuckets);
     uint32_t step = step_of_group(grp, st.nbuckets);
     const uint32_t kstride = st.layout == LAYOUT_SPLIT ? 8u : 16u;  // bytes from one key of a line to the next
@@ -346,6 +345,10 @@ __device__ __forceinline__ int lane_insert(const SubTable &st, uint64_t key, int
         advance_line(key, probes + 1, st.nbuckets, b, step);
     }
     return -1;
+}
+template <bool COUNT = false, bool ATOMIC_OR = false>
+__device__ __forceinline__ int lane_insert(const SubTable &st, uint64_t key, int w, uint32_t bits, uint32_t max_probe) {
+    return lane_insert_grp<COUNT, ATOMIC_OR>(st, key, w, bits, max_probe, group_of(st, key));
 }
 
 }  // namespace pg

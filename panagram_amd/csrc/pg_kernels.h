@@ -68,6 +68,10 @@ hipError_t launch_sketch(hipStream_t st, int k, const uint64_t *seqw, const uint
 hipError_t launch_insert_seq(hipStream_t st, const SubTable &t, int w, uint32_t bits, int k,
                              const uint64_t *seqw, const uint32_t *nmw, const uint32_t *has_n,
                              uint64_t nkmers, unsigned long long *counters, uint32_t max_probe, int count_mode = 0);
+// the wave-cooperative build (pg_anchor.hip: k_insert_tile); tables of 128-byte lines only (8 slots, or the split layout)
+hipError_t launch_insert_tiles(hipStream_t st, const SubTable &t, int w, uint32_t bits, int count_mode, const uint64_t *seqw,
+                               const uint32_t *nmw, const uint32_t *has_n, const SeqDesc *sd, const uint32_t *tile0,
+                               uint32_t ncontigs, uint32_t ntiles, unsigned long long *counters, uint32_t max_probe);
 hipError_t launch_count_spill(hipStream_t st, const SubTable &t, unsigned long long *counters);
 hipError_t launch_merge_min(hipStream_t st, const SubTable &src, const SubTable &dst, int w, uint32_t bits,
                             uint32_t min_count, unsigned long long *counters, uint32_t max_probe);
