@@ -59,51 +59,113 @@ def _parts_dir(genome) -> str:
     return os.path.join(genome.prefix, ".parts")
 
 
-def run_index_sharded(index, rank: int, world: int, barrier: Callable[[], None],
-                      anchor_fn: Optional[Callable] = None) -> None:
-    """Every rank calls this.  ``anchor_fn(genome, seqs) -> ([(rows, rows100, bins, info)], colsums)``
-    defaults to the GPU path (``Genome.anchor_contigs`` against this rank's replica of the table)."""
-    from .index import read_fasta
+BGZF_EOF = bytes([0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0x00, 0x42, 0x43, 0x02, 0x00, 0x1b, 0x00, 0x03, 0x00,
+                  0, 0, 0, 0, 0, 0, 0, 0])
+
+
+def concat_bgzf(parts: Sequence[Tuple[str, str]], out_gz: str, out_gzi: str) -> None:
+    """BGZF files are block-concatenable: the fragments ``(gz, gzi)`` — each a complete BGZF file ending in the EOF
+    block — become ONE file (their blocks back to back, one EOF block at the end) with one ``.gzi`` whose entries
+    are the fragments' own, re-based, plus one for every fragment's first block.  The payload is the fragments'
+    payloads in order; block boundaries fall where the fragments' did (a reader goes by the .gzi, index.py:793-845)."""
+    entries: List[Tuple[int, int]] = []
+    cpos = upos = 0
+    with open(out_gz + ".tmp", "wb") as out:
+        for gz, gzi in parts:
+            with open(gz, "rb") as f:
+                data = f.read()
+            if not data.endswith(BGZF_EOF):
+                raise ValueError(f"{gz}: not a complete BGZF file")
+            data = data[:-len(BGZF_EOF)]
+            if not data:
+                continue  # an empty fragment (a contig without k-mers)
+            raw = np.fromfile(gzi, "<u8")
+            n = int(raw[0])
+            own = raw[1:1 + 2 * n].reshape(n, 2)
+            # uncompressed size of the fragment: start of its last block + that block's ISIZE (last 4 bytes)
+            last_u = int(own[-1, 1]) if n else 0
+            usize = last_u + int.from_bytes(data[-4:], "little")
+            if cpos:
+                entries.append((cpos, upos))
+            entries += [(cpos + int(c), upos + int(u)) for c, u in own]
+            out.write(data)
+            cpos += len(data)
+            upos += usize
+        out.write(BGZF_EOF)
+    with open(out_gzi + ".tmp", "wb") as g:
+        g.write(np.array([len(entries)] + [x for e in entries for x in e], "<u8").tobytes())
+    os.replace(out_gz + ".tmp", out_gz)
+    os.replace(out_gzi + ".tmp", out_gzi)
+
+
+def run_index_sharded(index, rank: int, world: int, barrier: Callable[[], None]) -> None:
+    """The fine-grained contig-sharded mode: ``(genome, contig)`` units dealt to the ranks longest-first,
+    the table replicated.  Every rank calls this.  Phase 1: a rank anchors ALL its units in one co-scheduled launch
+    (its contigs of every genome side by side, like ``Index.run()``'s batches) and leaves, per unit, finished BGZF
+    fragments — compressed on the GPU straight out of HBM (``pg_result_write_bgzf_range``) — plus the unit's bins and
+    column sums.  One barrier.  Phase 2: the owner of a genome concatenates its contigs' fragments in FASTA order
+    (``concat_bgzf``) and writes the tables.  No data-path collective; the decompressed outputs do not depend on the
+    GPU count (the BGZF block boundaries follow the fragments)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from . import index as pidx
+    engine = pidx.engine
     k = index.k
-    recs: Dict[str, List[Tuple[str, bytes]]] = {}
+    ctx = index.context
     units: List[Unit] = []
+    seqs = {}
     for name in index.anchor_genomes:
-        recs[name] = list(read_fasta(index.genomes[name].fasta))
-        units += [(name, ci, max(0, len(s) - k + 1)) for ci, (_, s) in enumerate(recs[name])]
+        seqs[name] = index.seqset_for(name)
+        units += [(name, ci, max(0, int(ln) - k + 1)) for ci, ln in enumerate(seqs[name].lens)]
+    for name in index.anchor_genomes:  # a stale .parts of an aborted run must not leak into this one
+        if index.anchor_genomes.index(name) % world == rank:
+            shutil.rmtree(_parts_dir(index.genomes[name]), ignore_errors=True)
+    barrier()
     mine = plan_shards(units, world)[rank]
-    if anchor_fn is None:
+    if mine:
         table = index.build_table()  # replicated: every rank builds (or loads) the whole table
-        anchor_fn = lambda genome, seqs: genome.anchor_contigs(table, seqs)  # noqa: E731
-    by_genome: Dict[str, List[int]] = {}
-    for name, ci, _ in mine:
-        by_genome.setdefault(name, []).append(ci)
-    for name, cis in by_genome.items():
-        g = index.genomes[name]
-        os.makedirs(_parts_dir(g), exist_ok=True)
-        results, cs = anchor_fn(g, [recs[name][ci][1] for ci in cis])
-        for ci, (rows, rows100, bins, info) in zip(cis, results):
-            np.savez(os.path.join(_parts_dir(g), f"{ci}.tmp.npz"), rows=rows, rows100=rows100, bins=bins,
-                     nkmers=info["nkmers"], nbins=info["nbins"], binlen=info["binlen"], nrows100=info["nrows100"])
-            os.replace(os.path.join(_parts_dir(g), f"{ci}.tmp.npz"), os.path.join(_parts_dir(g), f"{ci}.npz"))
-        np.save(os.path.join(_parts_dir(g), f"colsums.{rank}.npy"), np.asarray(cs, dtype=np.int64))
+        parts = [(seqs[name], ci, 1) for name, ci, _ in mine]
+        merged = engine.SeqSet.concat_ranges(ctx, parts)
+        res = engine.AnchorResult(table, merged, colsums=True, **index.result_geometry)
+        gid = {n: i for i, n in enumerate(index.anchor_genomes)}
+        if len({u[0] for u in mine}) > 1:
+            res.coschedule(np.array([gid[u[0]] for u in mine], np.uint32))
+        res.run()
+        ccs = res.contig_colsums().astype(np.int64)
+
+        def write_unit(i, name, ci):
+            g = index.genomes[name]
+            os.makedirs(_parts_dir(g), exist_ok=True)
+            base = os.path.join(_parts_dir(g), str(ci))
+            for s_ in index.steps:
+                res.write_bgzf(s_, f"{base}.{s_}.gz", f"{base}.{s_}.gzi", level=index.bgzf_level, threads=2, first_contig=i, ncontigs=1)
+            _, _, bins, info = res.download(i, want_bitmap1=False, want_bitmap100=False)
+            np.savez(base + ".tmp.npz", bins=bins, colsums=ccs[i], nkmers=info["nkmers"], nbins=info["nbins"],
+                     binlen=info["binlen"], nrows100=info["nrows100"])
+            os.replace(base + ".tmp.npz", base + ".npz")  # written last: the unit's completion marker
+
+        with ThreadPoolExecutor(max_workers=index.writer_jobs(int(merged.lens.sum()) * ((index.ngenomes + 7) // 8))) as pool:
+            for f in [pool.submit(write_unit, i, name, ci) for i, (name, ci, _) in enumerate(mine)]:
+                f.result()
+        res.close()
+        merged.close()
     barrier()
     # phase 2: the owner of a genome assembles its files in FASTA order
     for gi, name in enumerate(index.anchor_genomes):
         if gi % world != rank:
             continue
         g = index.genomes[name]
-        results = []
-        for ci in range(len(recs[name])):
-            z = np.load(os.path.join(_parts_dir(g), f"{ci}.npz"))
-            info = dict(nkmers=int(z["nkmers"]), nbins=int(z["nbins"]), binlen=int(z["binlen"]),
-                        nrows100=int(z["nrows100"]))
-            results.append((z["rows"], z["rows100"], z["bins"], info))
-        cs = np.zeros(index.ngenomes, np.int64)
-        for r in range(world):
-            p = os.path.join(_parts_dir(g), f"colsums.{r}.npy")
-            if os.path.exists(p):
-                cs += np.load(p)
-        g.write_outputs([nm for nm, _ in recs[name]], results, cs)
+        g.ensure_log()
+        os.makedirs(g.prefix, exist_ok=True)
+        names = list(seqs[name].names)
+        metas = [np.load(os.path.join(_parts_dir(g), f"{ci}.npz")) for ci in range(len(names))]
+        for s_ in index.steps:
+            concat_bgzf([(os.path.join(_parts_dir(g), f"{ci}.{s_}.gz"), os.path.join(_parts_dir(g), f"{ci}.{s_}.gzi"))
+                         for ci in range(len(names))], g.bitmap_gz_fname(s_), g.bitmap_gzi_fname(s_))
+        bins_infos = [(z["bins"], dict(nkmers=int(z["nkmers"]), nbins=int(z["nbins"]), binlen=int(z["binlen"]),
+                                       nrows100=int(z["nrows100"]))) for z in metas]
+        cs = np.sum([z["colsums"] for z in metas], axis=0) if metas else np.zeros(index.ngenomes, np.int64)
+        g._write_tables(names, bins_infos, cs)
+        g.close_log()
         shutil.rmtree(_parts_dir(g))
     barrier()
 

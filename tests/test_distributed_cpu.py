@@ -1,6 +1,6 @@
-"""CPU, world_size 2 over gloo: the multi-GPU host logic (sharding plan, part-file assembly,
-row combine).  The per-contig compute is injected (the oracle stands in for the GPU) so the
-N>1 control path runs here without a device."""
+"""CPU, world_size 2 over gloo: the multi-GPU host logic (sharding plan, BGZF fragment assembly, row combine,
+the genome-sharded pipeline).  The engine layer is swapped for an oracle-backed stand-in (tests/fake_engine.py) so
+the N>1 control paths run here without a device."""
 import gzip
 import os
 
@@ -25,18 +25,6 @@ def test_plan_shards_is_balanced_and_deterministic():
         assert sh == plan_shards(list(reversed(units)), world)
 
 
-def _oracle_anchor_fn(dbs, k, n):
-    def fn(genome, seqs):
-        out, cs = [], np.zeros(n, np.int64)
-        for s in seqs:
-            rows, rows100, bins, starts, c = po.anchor_contig(dbs, s, k, n)
-            info = dict(nkmers=len(rows), nbins=len(bins), binlen=po.bin_length(len(rows)), nrows100=len(rows100))
-            out.append((rows, rows100, bins, info))
-            cs += c
-        return out, cs
-    return fn
-
-
 def _worker(rank, world, port, root, name):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -46,8 +34,10 @@ def _worker(rank, world, port, root, name):
         fx = H.load_case(name)
         n, k = int(fx["ngenomes"]), int(fx["k"])
         dbs = H.case_dbs(fx)
+        from tests import fake_engine
+        pidx.engine = fake_engine  # the oracle stands in for the GPU below the engine layer; everything above is the product's
         idx = pidx.Index(os.path.join(root, "idx"), mode="w")
-        run_index_sharded(idx, rank, world, dist.barrier, anchor_fn=_oracle_anchor_fn(dbs, k, n))
+        run_index_sharded(idx, rank, world, dist.barrier)
         # genome-sharded combine: each rank holds rows with only its genomes' bits
         g = int(fx["anchors"][0])
         full = np.frombuffer(fx[f"a{g}_bitmap1"].tobytes(), np.uint8).copy()

@@ -642,3 +642,40 @@ def test_mean_launch_timing_over_several_runs(ctx):
     assert 0 < last[0] < 50 * p_ms
     assert res.timing_mean()[2] == 150  # reading does not consume
     res.close(); ss.close(); t.close()
+
+
+@pytest.mark.parametrize("name", ["n9_k21", "n65_k21", "n2_k21"])
+def test_contig_sharded_fragments_on_the_gpu(name, tmp_path):
+    """run_index_sharded (fine-grained contig-sharded mode) with one rank: every (genome, contig) unit leaves BGZF
+    fragments compressed on the GPU out of HBM, the owner concatenates them; decompressed payloads, tables and the
+    read side equal the reference's"""
+    from panagram_amd import index as pidx
+    from panagram_amd.distributed import run_index_sharded
+    fx = H.load_case(name)
+    n, k = int(fx["ngenomes"]), int(fx["k"])
+    s = _write_case(tmp_path, fx)
+    out = tmp_path / "idx"
+    idx = pidx.Index(str(s), prefix=str(out), k=k, anchor_genomes=[f"g{g}" for g in fx["anchors"]])
+    run_index_sharded(idx, 0, 1, lambda: None)
+    idx.close()
+    dbs = H.case_dbs(fx)
+    for g in fx["anchors"]:
+        adir = out / "anchor" / f"g{g}"
+        for step in (1, 100):
+            assert gzip.open(adir / f"bitmap.{step}.gz", "rb").read() == fx[f"a{g}_bitmap{step}"].tobytes()
+        assert (adir / "bitsum.bins.tsv").read_bytes() == fx[f"a{g}_bitsum.bins.tsv"].tobytes()
+        assert (adir / "chrs.tsv").read_bytes() == fx[f"a{g}_chrs.tsv"].tobytes()
+        ora = po.anchor_fasta(dbs, fx[f"fasta_{g}"].tobytes(), k, n)
+        tp = pd.read_csv(adir / "total_paircounts.csv", index_col="name")
+        assert np.array_equal(tp["count"].to_numpy(), ora["colsums"])
+        assert not (adir / ".parts").exists()
+    ridx = pidx.Index(str(out), mode="r")
+    g = int(fx["anchors"][0])
+    nb = (n + 7) // 8
+    rows = np.frombuffer(fx[f"a{g}_bitmap1"].tobytes(), np.uint8).reshape(-1, nb)
+    bits = np.unpackbits(rows, axis=1, bitorder="little")[:, :n]
+    off = 0
+    for nm, seq in po.parse_fasta_cpp(fx[f"fasta_{g}"].tobytes()):
+        nk = len(seq) - k + 1
+        assert np.array_equal(ridx.query_bitmap(f"g{g}", nm, 5, nk - 3).to_numpy(), bits[off + 5: off + nk - 3])
+        off += nk

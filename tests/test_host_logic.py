@@ -251,3 +251,32 @@ def test_oracle_sketch_against_pure_python_and_exact_count():
     exact = len(np.unique(vals[valid]))
     est = po.sketch_estimate(po.sketch_registers(big, 21))
     assert abs(est - exact) <= 0.02 * exact  # 5 standard errors
+
+
+def test_concat_bgzf_fragments(tmp_path):
+    """BGZF fragments (whole files incl. EOF block, some empty, some multi-block) -> one file + one .gzi that the
+    read side addresses like any other (index.py:793-845)"""
+    import gzip
+    from panagram_amd import engine
+    from panagram_amd.distributed import concat_bgzf
+    rng = np.random.default_rng(4)
+    payloads = [rng.integers(0, 3, n, dtype=np.uint8).tobytes() for n in (70000, 0, 5, 200000, 65280, 0)]
+    parts = []
+    for i, pl in enumerate(payloads):
+        p = str(tmp_path / f"f{i}.gz")
+        w = engine.BgzfWriter(p, threads=1)
+        if pl:
+            w.write(pl)
+        w.close(p + "i")
+        parts.append((p, p + "i"))
+    out = str(tmp_path / "all.gz")
+    concat_bgzf(parts, out, out + "i")
+    whole = b"".join(payloads)
+    assert gzip.open(out, "rb").read() == whole
+    blocks = pidx.load_bgz_blocks(out + "i")
+    raw = open(out, "rb").read()
+    for c, u in blocks[1:]:
+        assert raw[int(c):int(c) + 4] == b"\x1f\x8b\x08\x04" and 0 < u < len(whole)
+    assert list(blocks[:, 1]) == sorted(set(blocks[:, 1]))
+    for start, ln in [(0, 10), (69990, 30), (70004, 100), (270000, 65285), (len(whole) - 7, 7)]:
+        assert pidx.bgzf_read(out, blocks, start, ln) == whole[start:start + ln]
