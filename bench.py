@@ -359,7 +359,8 @@ def sharded_leg(ctx, dev, args, rank, world, dist, steps, warmup, nblocks=None):
     nblocks = min(G, nblocks or world)
     per = (G + nblocks - 1) // nblocks
     nblocks = (G + per - 1) // per
-    if nblocks > world:
+    emulated = world == 1 and nblocks > 1  # one GPU plays rank 0 of `nblocks`: its block's table, no collective
+    if nblocks > world and not emulated:
         raise SystemExit("bench.py times one pass: --blocks must not exceed the number of GPUs")
     blk = (rank * per, min(G, (rank + 1) * per)) if rank < nblocks else None
     pg = Pangenome(ctx, dev, G, contig_lens, args.d, args.seed, k, keep_ascii=False,
@@ -371,11 +372,11 @@ def sharded_leg(ctx, dev, args, rank, world, dist, steps, warmup, nblocks=None):
     table = pg.table if blk is not None else None
 
     def step():
-        sh.run_pass(table, 0, nblocks, False, lambda a, res: res.rows_epilogue())
+        sh.run_pass(table, 0, 1 if emulated else nblocks, False, lambda a, res: res.rows_epilogue())
     dt = timed_steps(step, steps, warmup, world, dev, dist)
     pos = sum(pg.pos_per_genome)
     mine = [a for a in names if writer[a] == rank]
-    if mine:  # the writer's completed rows: the anchor holds all of its own k-mers
+    if mine and not emulated:  # the writer's completed rows: the anchor holds all of its own k-mers
         cs = sh.full[mine[0]].colsums()
         assert int(cs[names.index(mine[0])]) == pg.pos_per_genome[names.index(mine[0])]
     out = {
@@ -385,8 +386,11 @@ def sharded_leg(ctx, dev, args, rank, world, dist, steps, warmup, nblocks=None):
         "chunk_groups_per_step": len(sh.groups),
         "collective": "all_gather_into_tensor of bit columns (RCCL over xGMI)" if world > 1 else "none (one rank)",
         "collective_bytes_received_per_rank_per_step": sh.bytes_received / max(1, steps + warmup),
-        "parallelism": f"genome-sharded x{world}: {nblocks} genome blocks of {per}, every rank probes every position, "
-                       f"columns all-gathered, anchors' rows merged + statistics on their writer rank",
+        "parallelism": (f"EMULATED rank 0 of {nblocks}: the table of genome block 0 ({per} genome(s)) only, every position probed, "
+                        f"columns extracted and merged, no collective" if emulated else
+                        f"genome-sharded x{world}: {nblocks} genome blocks of {per}, every rank probes every position, "
+                        f"columns all-gathered, anchors' rows merged + statistics on their writer rank"),
+        "columns_from_the_probe": bool(getattr(sh, "_direct", False)),
     }
     sh.close()
     pg.close()

@@ -201,6 +201,7 @@ int pg_seqset_unpack(const pg_seqset *s, uint32_t idx, char *out);
  * a multiple of 100 (bitmap.100), the per-bin popcount histogram (N+1 counters
  * per bin; bin length 200000 or nkmers/100) and per-genome column sums. */
 #define PG_ANCHOR_COLSUMS 1u   /* also accumulate per-genome column sums */
+#define PG_ANCHOR_COLUMNS_ONLY 4u /* (with ROWS_ONLY) no row buffer: the result only emits bit columns (pg_anchor_run_columns_range) */
 #define PG_ANCHOR_ROWS_ONLY 2u /* genome-sharded mode: pg_anchor_run writes only the bitmap.1 rows (this
                                 * GPU's genomes' bits); after the rows of all GPUs have been combined in
                                 * place (RCCL) pg_rows_epilogue derives the rest */
@@ -223,6 +224,13 @@ int pg_anchor_run(pg_result *r);
  * statistics); async.  The unit of the genome-sharded pipeline: probe a chunk, extract its columns, exchange them
  * while the next chunk is probed. */
 int pg_anchor_run_range(pg_result *r, uint32_t first_contig, uint32_t ncontigs);
+/* the same, emitting the contig range's compact bit columns (`width` genomes wide, the layout of
+ * pg_result_extract_columns_range) STRAIGHT from the probe into d_dst — no rows are written or read back.  For the
+ * narrow block tables of the genome-sharded mode: pg_result_columns_direct() says whether the result's table
+ * qualifies (up to 8 genomes, width in ngenomes..8); config 5 — one genome per GPU — does.  A result created with
+ * PG_ANCHOR_COLUMNS_ONLY allocates no row buffer at all and only takes this call.  async */
+int pg_result_columns_direct(const pg_result *r, uint32_t width);
+int pg_anchor_run_columns_range(pg_result *r, uint32_t first_contig, uint32_t ncontigs, uint32_t width, void *d_dst);
 /* HIP-event durations of the last pg_anchor_run on this result, measured on the context's
  * stream: the probe kernels (k_probe, one per sub-table) and the statistics kernel
  * (k_epilogue; 0 in rows-only mode).  Synchronises on the run's last event. */

@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libpanagram_hip.so")
 
 PG_ANCHOR_COLSUMS = 1
 PG_ANCHOR_ROWS_ONLY = 2
+PG_ANCHOR_COLUMNS_ONLY = 4
 
 
 class PanagramHipError(RuntimeError):
@@ -76,6 +77,8 @@ PROTOTYPES = {
     "pg_result_destroy": (C.c_int, [_vp]),
     "pg_anchor_run": (C.c_int, [_vp]),
     "pg_anchor_run_range": (C.c_int, [_vp, C.c_uint32, C.c_uint32]),
+    "pg_result_columns_direct": (C.c_int, [_vp, C.c_uint32]),
+    "pg_anchor_run_columns_range": (C.c_int, [_vp, C.c_uint32, C.c_uint32, C.c_uint32, _vp]),
     "pg_result_timing_reset": (C.c_int, [_vp]),
     "pg_result_timing_mean": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double), _u32p]),
     "pg_result_columns_bytes_range": (C.c_uint64, [_vp, C.c_uint32, C.c_uint32, C.c_uint32]),

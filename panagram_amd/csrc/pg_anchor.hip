@@ -305,6 +305,20 @@ __device__ __forceinline__ uint32_t lanes_le_count(unsigned long long mask, bool
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u)) + (own ? 1u : 0u);
 }
 
+// ROWMODE 3 — the genome-sharded mode's narrow tables (a block of up to 8 genomes): the probe emits the block's
+// COMPACT BIT COLUMNS directly — per tile 8 x u64 per genome, bit l of word s = position 64 s + l — instead of one-byte
+// rows that k_cols_extract would read back: the tile's columns are assembled in LDS (one ballot per genome and batch,
+// shifted to the batch's place by the scalar unit; positions resolved by the overflow levels OR their bits in) and
+// written once, 64 bytes per genome and tile.
+constexpr int COLS_G = 8;  // genomes per block in columns mode
+__device__ __forceinline__ void cols_or_position(unsigned long long *cols, uint32_t pl, uint32_t m0) {
+    while (m0) {  // (rare path: a lane per resolved position, an LDS atomic per set bit)
+        const uint32_t j = (uint32_t)__ffs((int)m0) - 1u;
+        m0 &= m0 - 1u;
+        atomicOr(&cols[(pl >> 6) * COLS_G + j], 1ull << (pl & 63u));
+    }
+}
+
 // Overflow levels of a tile: dense 64-entry batches out of the wave's LDS queue, staged exactly
 // like the main batches (neighbouring entries belong to the same group and share their next
 // line); entries that overflow again are compacted in place for the next level.
@@ -332,7 +346,8 @@ __device__ __forceinline__ void drain_queue(const SubTable &st, uint32_t qn, con
                     if (m1) store_row_wide(st.masks, st.W, nbytes, tile_rows + (uint64_t)q_pl[e] * nbytes, m0, m1);
                 } else {
                     lane_chase<TWO, SLOTS>(st, key, (uint32_t)level, q_line[e], q_step[e], m0, m1);
-                    if (m0 | m1) store_row<ROWMODE>(tile_rows + (uint64_t)q_pl[e] * nbytes, m0, m1, rc);
+                    if constexpr (ROWMODE == 3) cols_or_position(reinterpret_cast<unsigned long long *>(tile_rows), q_pl[e], m0);
+                    else if (m0 | m1) store_row<ROWMODE>(tile_rows + (uint64_t)q_pl[e] * nbytes, m0, m1, rc);
                 }
             }
             break;
@@ -382,7 +397,11 @@ __device__ __forceinline__ void drain_queue(const SubTable &st, uint32_t qn, con
             if constexpr (WIDE) {
                 if (act && m1) store_row_wide(st.masks, st.W, nbytes, tile_rows + (uint64_t)pl * nbytes, m0, m1);
             } else {
-                if (act && (m0 | m1)) store_row<ROWMODE>(tile_rows + (uint64_t)pl * nbytes, m0, m1, rc);
+                if constexpr (ROWMODE == 3) {
+                    if (act) cols_or_position(reinterpret_cast<unsigned long long *>(tile_rows), pl, m0);
+                } else {
+                    if (act && (m0 | m1)) store_row<ROWMODE>(tile_rows + (uint64_t)pl * nbytes, m0, m1, rc);
+                }
             }
             const unsigned long long kmask2 = __ballot(again);
             if (again) {  // in-place compaction: slot <= e, and this batch's reads are already done
@@ -450,7 +469,14 @@ __global__ __launch_bounds__(64) void k_probe(const SubTable st, const uint64_t 
     constexpr int STRIDE = 64 - HALO;        // new positions per batch
     const uint32_t m = W_C ? (uint32_t)k - W_C + 1 : 0;
     const uint64_t mm64 = (m >= 32) ? ~0ull : ((1ull << (2 * (m ? m : 1))) - 1);
-    uint8_t *tile_rows = out1 + a.out_off + (uint64_t)tile_start * nbytes;
+    // (columns mode: `out1` is the block's column buffer, `nbytes` its width in genomes; the "rows" of the tile are
+    // the LDS words the columns are assembled in)
+    __shared__ unsigned long long cols[ROWMODE == 3 ? 8 * COLS_G : 1];
+    if constexpr (ROWMODE == 3) {
+        cols[lane] = 0;
+        __syncthreads();
+    }
+    uint8_t *tile_rows = ROWMODE == 3 ? reinterpret_cast<uint8_t *>(cols) : out1 + a.out_off + (uint64_t)tile_start * nbytes;
     uint32_t qn = 0;  // wave-uniform: overflow entries of this tile so far
 
     // NB independent 64-lane batches are carried through every stage together, so that the
@@ -592,12 +618,31 @@ __global__ __launch_bounds__(64) void k_probe(const SubTable st, const uint64_t 
             if constexpr (WIDE) {
                 if (inrange[u]) store_row_wide(st.masks, st.W, nbytes, tile_rows + (uint64_t)(uint32_t)pl[u] * nbytes, m0[u], m1[u]);
             } else {
-                if (inrange[u]) store_row<ROWMODE>(tile_rows + (ROWMODE == 1 ? (uint32_t)pl[u] : (uint32_t)pl[u] * nbytes), m0[u], m1[u], rc);
+                if constexpr (ROWMODE == 3) {
+                    const uint32_t b = b0 + u * STRIDE;
+                    const uint32_t w0 = b >> 6, sh = b & 63u;
+                    for (uint32_t j = 0; j < rc.col0; ++j) {  // (uniform) one ballot per genome of the block
+                        const unsigned long long shifted = __ballot(inrange[u] && ((m0[u] >> j) & 1u)) >> HALO;  // bit i = position b + i
+                        if (lane == 0 && shifted) {
+                            cols[w0 * COLS_G + j] |= shifted << sh;
+                            if (sh && (shifted >> (64u - sh))) cols[(w0 + 1) * COLS_G + j] |= shifted >> (64u - sh);
+                        }
+                    }
+                } else {
+                    if (inrange[u]) store_row<ROWMODE>(tile_rows + (ROWMODE == 1 ? (uint32_t)pl[u] : (uint32_t)pl[u] * nbytes), m0[u], m1[u], rc);
+                }
             }
         }
     }
 
     drain_queue<TWO, ROWMODE, SLOTS, PROBE_MAXRUN, WIDE>(st, qn, sw, q_line, q_step, q_pl, lines_w[0], buf[0], tile_rows, nbytes, rc, lane);
+    if constexpr (ROWMODE == 3) {
+        // the tile's columns: 8 slots x `width` (= nbytes) genomes, slot-major — what k_cols_extract would have written
+        __syncthreads();
+        const uint32_t width = nbytes, trel = tile - tile_base;
+        unsigned long long *dst = reinterpret_cast<unsigned long long *>(out1) + (uint64_t)trel * 8u * width;
+        if ((uint32_t)lane < 8u * width) dst[lane] = cols[((uint32_t)lane / width) * COLS_G + (uint32_t)lane % width];
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -1789,6 +1834,7 @@ static hipError_t probe_w(hipStream_t s, uint32_t ntiles, const SubTable &st, co
         if (rowmode == 2) return probe_t<W_C, true, 2, 8>(PG_A);
         return probe_t<W_C, true, 0, 8>(PG_A);
     }
+    if (rowmode == 3) return probe_t<W_C, false, 3, 8>(PG_A);
     if (rowmode == 1) return probe_t<W_C, false, 1, 8>(PG_A);
     return probe_t<W_C, false, 0, 8>(PG_A);
 #undef PG_A
@@ -1800,13 +1846,36 @@ static int row_mode(uint32_t nbytes, const RowCols &rc) {
     return 0;
 }
 
+// columns_width != 0: the genome-sharded mode's narrow tables (up to 8 genomes, 8-slot lines) emit the block's bit
+// columns (`columns_width` genomes wide) into `out1` instead of rows
 hipError_t launch_anchor(hipStream_t s, const TableDesc &T, const uint64_t *seqw, const uint32_t *nmw,
                          const uint32_t *has_n, const SeqDesc *sd, const AnchorDesc *ad, const uint32_t *tile_contig,
-                         const uint32_t *sched, uint32_t tile_base, uint32_t ntiles, uint8_t *out1, uint64_t out1_bytes) {
+                         const uint32_t *sched, uint32_t tile_base, uint32_t ntiles, uint8_t *out1, uint64_t out1_bytes,
+                         uint32_t columns_width) {
     if (ntiles == 0) return hipSuccess;
     const uint32_t nbytes = (T.ngenomes + 7) / 8;
     hipError_t e = hipSuccess;
     (void)out1_bytes;
+    if (columns_width) {
+        const SubTable &st = T.sub[0];
+        if (T.nsub != 1 || st.layout != LAYOUT_SLOTS || st.W != 1 || st.slots != 8 || T.ngenomes > (uint32_t)COLS_G ||
+            columns_width > (uint32_t)COLS_G || columns_width < T.ngenomes)
+            return hipErrorInvalidValue;
+        RowCols rc;
+        rc.col0 = T.ngenomes;  // (genomes of the block)
+        rc.nb0 = rc.nb1 = rc.words = 0;
+        const uint32_t w = st.m ? st.k - st.m + 1 : 0;
+        switch (w) {
+            case 0: return probe_w<0>(s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, sched, tile_base, out1, columns_width, rc, 3);
+            case 3: return probe_w<3>(s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, sched, tile_base, out1, columns_width, rc, 3);
+            case 4: return probe_w<4>(s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, sched, tile_base, out1, columns_width, rc, 3);
+            case 5: return probe_w<5>(s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, sched, tile_base, out1, columns_width, rc, 3);
+            case 6: return probe_w<6>(s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, sched, tile_base, out1, columns_width, rc, 3);
+            case 7: return probe_w<7>(s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, sched, tile_base, out1, columns_width, rc, 3);
+            case 8: return probe_w<8>(s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, sched, tile_base, out1, columns_width, rc, 3);
+            default: return hipErrorInvalidValue;
+        }
+    }
     for (uint32_t si = 0; si < T.nsub; ++si) {
         const SubTable &st = T.sub[si];
         RowCols rc;  // every sub-table writes all bytes of the columns it owns, so rows need no zero fill

@@ -1488,7 +1488,7 @@ static int result_create(pg_ctx *ctx, pg_table *t, int k, uint32_t N, const pg_s
     hipError_t e;
     if ((e = hipMalloc(reinterpret_cast<void **>(&r->d_ad), std::max<size_t>(1, r->ad.size()) * sizeof(AnchorDesc))) == hipSuccess &&
         (e = hipMalloc(reinterpret_cast<void **>(&r->d_tile_contig), std::max<size_t>(1, tile_contig.size()) * 4)) == hipSuccess &&
-        (e = row_alloc(ctx, std::max<uint64_t>(16, o1), &r->d_out1, &r->out1_cap)) == hipSuccess &&
+        (e = row_alloc(ctx, (flags & PG_ANCHOR_COLUMNS_ONLY) ? 16 : std::max<uint64_t>(16, o1), &r->d_out1, &r->out1_cap)) == hipSuccess &&
         (e = hipMalloc(reinterpret_cast<void **>(&r->d_out100), std::max<uint64_t>(16, o100))) == hipSuccess &&
         (e = hipMalloc(reinterpret_cast<void **>(&r->d_bins), std::max<uint64_t>(1, bins) * (N + 1) * 4)) == hipSuccess &&
         (e = hipMalloc(reinterpret_cast<void **>(&r->d_colsums), std::max<size_t>(1, r->ad.size()) * N * 8)) == hipSuccess) {
@@ -1721,7 +1721,8 @@ static bool sched_covers(const pg_result *r, uint32_t t0, uint32_t nt) {
     return std::binary_search(b.begin(), b.end(), t0) && std::binary_search(b.begin(), b.end(), t0 + nt);
 }
 
-static int anchor_run(pg_result *r, uint32_t tile_base, uint32_t ntiles, bool whole) {
+static int anchor_run(pg_result *r, uint32_t tile_base, uint32_t ntiles, bool whole, uint32_t columns_width = 0,
+                      void *d_columns = nullptr) {
     pg_table *t = r->tbl;
     if (!t) return fail(PG_E_INVALID, "this result is a rows container (pg_result_create_rows): it has no table to probe");
     if (int e = use_device(r->ctx)) return e;
@@ -1732,7 +1733,7 @@ static int anchor_run(pg_result *r, uint32_t tile_base, uint32_t ntiles, bool wh
     HIP_TRY(hipEventRecord(r->ev[0], st));
     HIP_TRY(launch_anchor(st, T, r->seqs->d_seqw, r->seqs->d_nmw, r->seqs->d_has_n, r->seqs->d_desc, r->d_ad,
                           r->d_tile_contig, sched_covers(r, tile_base, ntiles) ? r->d_sched : nullptr, tile_base, ntiles,
-                          r->d_out1, r->out1_bytes));
+                          columns_width ? static_cast<uint8_t *>(d_columns) : r->d_out1, r->out1_bytes, columns_width));
     HIP_TRY(hipEventRecord(r->ev[1], st));
     r->ev_ok = true;
     r->ev_epi = false;
@@ -1751,15 +1752,33 @@ static int anchor_run(pg_result *r, uint32_t tile_base, uint32_t ntiles, bool wh
 
 extern "C" int pg_anchor_run(pg_result *r) {
     if (!r) return fail(PG_E_INVALID, "result is NULL");
+    if (r->flags & PG_ANCHOR_COLUMNS_ONLY) return fail(PG_E_INVALID, "a PG_ANCHOR_COLUMNS_ONLY result has no rows: use pg_anchor_run_columns_range");
     return anchor_run(r, 0, r->ntiles, true);
 }
 
 extern "C" int pg_anchor_run_range(pg_result *r, uint32_t first_contig, uint32_t ncontigs) {
     if (!r) return fail(PG_E_INVALID, "result is NULL");
+    if (r->flags & PG_ANCHOR_COLUMNS_ONLY) return fail(PG_E_INVALID, "a PG_ANCHOR_COLUMNS_ONLY result has no rows: use pg_anchor_run_columns_range");
     if (!(r->flags & PG_ANCHOR_ROWS_ONLY)) return fail(PG_E_INVALID, "pg_anchor_run_range needs a PG_ANCHOR_ROWS_ONLY result");
     uint32_t t0, nt;
     if (int e = contig_tiles(r, first_contig, ncontigs, &t0, &nt)) return e;
     return anchor_run(r, t0, nt, false);
+}
+
+extern "C" int pg_result_columns_direct(const pg_result *r, uint32_t width) {
+    if (!r || !r->tbl) return 0;
+    const pg_table *t = r->tbl;
+    return t->subs.size() == 1 && t->subs[0].d.layout == LAYOUT_SLOTS && t->subs[0].d.W == 1 && t->subs[0].d.slots == 8 &&
+           t->ngenomes <= 8 && width <= 8 && (int)width >= t->ngenomes;
+}
+
+extern "C" int pg_anchor_run_columns_range(pg_result *r, uint32_t first_contig, uint32_t ncontigs, uint32_t width, void *d_dst) {
+    if (!r || !d_dst) return fail(PG_E_INVALID, "pg_anchor_run_columns_range: NULL argument");
+    if (!pg_result_columns_direct(r, width))
+        return fail(PG_E_INVALID, "pg_anchor_run_columns_range: needs a table of up to 8 genomes (8-slot lines) and width in ngenomes..8");
+    uint32_t t0, nt;
+    if (int e = contig_tiles(r, first_contig, ncontigs, &t0, &nt)) return e;
+    return anchor_run(r, t0, nt, false, width, d_dst);
 }
 
 extern "C" int pg_result_timing(pg_result *r, float *probe_ms, float *epilogue_ms) {

@@ -92,7 +92,7 @@ hipError_t launch_counters(hipStream_t st, const SubTable &t, int w, int k, cons
 hipError_t launch_anchor(hipStream_t st, const TableDesc &T, const uint64_t *seqw, const uint32_t *nmw,
                          const uint32_t *has_n, const SeqDesc *sd, const AnchorDesc *ad,
                          const uint32_t *tile_contig, const uint32_t *sched, uint32_t tile_base, uint32_t ntiles, uint8_t *out1,
-                         uint64_t out1_bytes);
+                         uint64_t out1_bytes, uint32_t columns_width = 0);
 // genome-sharded exchange over the tiles [tile_base, tile_base + ntiles) of a result (a contig range)
 hipError_t launch_cols_extract(hipStream_t st, uint32_t ngenomes, const AnchorDesc *ad, const uint32_t *tile_contig,
                                uint32_t tile_base, uint32_t ntiles, const uint8_t *out1, uint32_t g0, uint32_t width, void *dst);

@@ -358,6 +358,12 @@ class ShardedAnchoring:
 
     and calls ``on_anchor_complete(name, rows_container)`` on the writer once an anchor's last chunk is merged."""
 
+    # widest block whose columns the probe assembles itself (a ballot + two LDS words per genome and batch): one genome
+    # per block — config 5's layout — where it also spares the narrow row buffer (one byte per anchor position: 24 GB
+    # at config 5); wider blocks are faster through rows + k_cols_extract (measured per rank on the configs[1]
+    # pangenome, G k-mers/s: 1 genome per block 123.5 direct vs 121.6; 2: 114.9 vs 118.9; 8: 82 vs 109)
+    DIRECT_MAX_WIDTH = int(os.environ.get("PG_DIRECT_MAX_WIDTH", "1"))
+
     def __init__(self, engine, ctx, k: int, ngenomes: int, per: int, rank: int, world: int, seqs: Dict[str, object],
                  writer: Dict[str, int], geometry: Optional[dict] = None, group=None, always_gather: bool = False):
         """``always_gather``: issue the collective even with one rank (a process group of size 1) — the side-stream
@@ -419,7 +425,14 @@ class ShardedAnchoring:
         if self._part is None or self._part_table is not table:
             if self._part is not None:
                 self._part.close()
-            self._part = self.engine.AnchorResult(table, self.merged, colsums=False, rows_only=True)
+            # a block of up to 8 genomes (config 5: ONE genome per GPU): the probe emits the bit columns itself, the
+            # narrow result needs no row buffer
+            self._direct = (getattr(self.engine, "COLUMNS_DIRECT", False) and table.ngenomes <= 8 and self.per <= self.DIRECT_MAX_WIDTH
+                            and table.spill()[1] == 8)  # (8-slot lines: what pg_result_columns_direct asks for)
+            self._part = self.engine.AnchorResult(table, self.merged, colsums=False, rows_only=True,
+                                                  **({"columns_only": True} if self._direct else {}))
+            if self._direct and not self._part.columns_direct(self.per):
+                raise RuntimeError("internal: the block table does not qualify for direct columns")
             if len(self.seqs) > 1:
                 self._part.coschedule_ranges(self._contig_anchor, self.group_first)
             self._part_table = table
@@ -447,7 +460,9 @@ class ShardedAnchoring:
             slot, nbytes = i & 1, self.group_tiles[i] * 64 * per
             m0 = self.group_first[i]
             cnt = (self.group_first[i + 1] if i + 1 < len(self.groups) else ncontigs) - m0
-            if part is not None:
+            if part is not None and self._direct:
+                part.run_columns_range(m0, cnt, per, self.send[slot].data_ptr())
+            elif part is not None:
                 part.run_range(m0, cnt)
                 part.extract_columns_range(0, per, m0, cnt, self.send[slot].data_ptr())
             else:

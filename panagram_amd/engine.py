@@ -13,7 +13,7 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 
 from . import _lib
-from ._lib import PG_ANCHOR_COLSUMS, PG_ANCHOR_ROWS_ONLY, PanagramHipError, check  # noqa: F401
+from ._lib import PG_ANCHOR_COLSUMS, PG_ANCHOR_COLUMNS_ONLY, PG_ANCHOR_ROWS_ONLY, PanagramHipError, check  # noqa: F401
 
 
 def usable_cpus() -> int:
@@ -36,6 +36,9 @@ def kmc_kmer_length(pre) -> int:
     k = C.c_uint32()
     check(_lib.load().pg_kmc_kmer_length(_ptr(v), v.size, C.byref(k)))
     return int(k.value)
+
+
+COLUMNS_DIRECT = os.environ.get("PG_COLUMNS_DIRECT", "1") != "0"  # k_probe may emit bit columns itself (narrow block tables)
 
 
 def tile_positions() -> int:
@@ -412,14 +415,15 @@ class AnchorResult:
     """Device-resident outputs of anchoring one SeqSet against one PanTable."""
 
     def __init__(self, table: PanTable, seqs: SeqSet, colsums: bool = True, rows_only: bool = False,
-                 lowres_step: int = 100, max_bin_len: int = 200000, min_bin_count: int = 100):
+                 lowres_step: int = 100, max_bin_len: int = 200000, min_bin_count: int = 100, columns_only: bool = False):
         """``lowres_step`` / ``max_bin_len`` / ``min_bin_count``: the Python path's parameters
         (index.py:101-106, 1169-1172); the defaults are what cpp/anchor.cpp hard-codes."""
         self.table, self.seqs, self.ctx = table, seqs, table.ctx
         self.ngenomes, self.nbytes, self.lowres_step = table.ngenomes, table.nbytes, lowres_step
         self._lib = table._lib
         h = C.c_void_p()
-        self.flags = (PG_ANCHOR_COLSUMS if colsums else 0) | (PG_ANCHOR_ROWS_ONLY if rows_only else 0)
+        self.flags = (PG_ANCHOR_COLSUMS if colsums else 0) | (PG_ANCHOR_ROWS_ONLY if rows_only or columns_only else 0) | \
+                     (PG_ANCHOR_COLUMNS_ONLY if columns_only else 0)
         check(self._lib.pg_result_create_ex(table._h, seqs._h, self.flags, lowres_step, max_bin_len, min_bin_count,
                                             C.byref(h)))
         self._h = h
@@ -476,6 +480,14 @@ class AnchorResult:
     def run_range(self, first_contig: int, ncontigs: int) -> None:
         """rows-only results: probe a contig range only (asynchronous)"""
         check(self._lib.pg_anchor_run_range(self._h, first_contig, ncontigs))
+
+    def columns_direct(self, width: int) -> bool:
+        """can ``run_columns_range`` emit ``width``-genome columns straight from the probe for this table?"""
+        return bool(self._lib.pg_result_columns_direct(self._h, width))
+
+    def run_columns_range(self, first_contig: int, ncontigs: int, width: int, dev_ptr: int) -> None:
+        """probe a contig range and write its compact bit columns to ``dev_ptr`` — no rows in between (async)"""
+        check(self._lib.pg_anchor_run_columns_range(self._h, first_contig, ncontigs, width, C.c_void_p(dev_ptr)))
 
     def timing(self):
         """(probe_ms, epilogue_ms) of the last run(), from HIP events on the context's stream."""

@@ -268,3 +268,41 @@ def test_sharded_pipeline_through_rccl_on_one_rank(ctx):
             s_.close()
         if started:
             dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("block", [(0, 8), (3, 4), (5, 6)])
+def test_probe_emits_columns_directly(ctx, block):
+    """pg_anchor_run_columns_range (the probe assembling the bit columns of a narrow block table itself) against
+    rows + k_cols_extract, over co-scheduled contig ranges of several anchors: the same bytes.  Blocks: all 8
+    genomes (width 8), genome 3 alone (config 5's one genome per GPU, width 1), genome 5 in a wider slot (width 3)."""
+    from panagram_amd import engine
+    g_lo, g_hi = block
+    width = {(0, 8): 8, (3, 4): 1, (5, 6): 3}[block]
+    fx = H.load_case("n8_k21")
+    k = int(fx["k"])
+    tbl = engine.PanTable(ctx, k, g_hi - g_lo)
+    for g in range(g_lo, g_hi):
+        ss = engine.SeqSet.from_fasta(ctx, fx[f"fasta_{g}"].tobytes())
+        tbl.insert_seqset(g - g_lo, ss)
+        ss.close()
+    sets = [engine.SeqSet.from_fasta(ctx, fx[f"fasta_{g}"].tobytes()) for g in (0, 3, 7)]
+    # chunk groups as the pipeline lays them out: contig 0 of every anchor, then contig 1 of every anchor
+    merged = engine.SeqSet.concat_ranges(ctx, [(s_, 0, 1) for s_ in sets] + [(s_, 1, 1) for s_ in sets])
+    rows = engine.AnchorResult(tbl, merged, colsums=False, rows_only=True)
+    cols = engine.AnchorResult(tbl, merged, colsums=False, columns_only=True)
+    assert cols.columns_direct(width)
+    for r_ in (rows, cols):
+        r_.coschedule_ranges([0, 1, 2, 0, 1, 2], [0, 3], 2)
+    for c0, nc in [(0, 3), (3, 3)]:
+        nb_ = rows.columns_bytes_range(width, c0, nc)
+        a = torch.zeros(nb_, dtype=torch.uint8, device="cuda")
+        b = torch.full((nb_,), 0xAB, dtype=torch.uint8, device="cuda")
+        rows.run_range(c0, nc)
+        rows.extract_columns_range(0, width, c0, nc, a.data_ptr())
+        cols.run_columns_range(c0, nc, width, b.data_ptr())
+        ctx.synchronize()
+        assert a.any() and torch.equal(a, b)
+    with pytest.raises(engine.PanagramHipError):
+        cols.run_range(0, 1)
+    for x in (rows, cols, merged, *sets, tbl):
+        x.close()
