@@ -174,7 +174,7 @@ def test_one_shot_contig_and_edge_cases(ctx):
     # all-N contig: all zero rows
     r = tbl.anchor_contig(b"N" * 300)
     assert not r[0].any() and r[2][:, 0].sum() == 300 - k + 1
-    # tile boundary sizes (TILE = 2048 positions)
+    # sizes around multiples of the tile (PROBE_TILE = 512 positions: 2048 and 4096 are tile boundaries too)
     for L in (2048 + k - 1, 2049 + k - 1, 4096 + k - 1 - 1):
         s = genomes[1][0][:L]
         got = tbl.anchor_contig(s)
