@@ -87,6 +87,9 @@ int pg_table_create(pg_ctx *ctx, int k, int ngenomes, uint64_t expected_keys, pg
  * replicated table and the genome-sharded mode before allocating anything */
 int pg_table_bytes_for(int k, int ngenomes, uint64_t expected_keys, uint64_t *bytes);
 int pg_table_destroy(pg_table *tbl);
+/* empty the table, keeping its allocation and geometry (async): the genome-sharded mode builds its genome blocks'
+ * tables one after the other in the same memory */
+int pg_table_clear(pg_table *tbl);
 
 /* k-mer set construction from sequence, replacing `kmc -ci1 -fm` +
  * `kmc_tools transform set_counts` + `kmc_tools complex -ocsum`

@@ -39,6 +39,7 @@ PROTOTYPES = {
     "pg_ctx_synchronize": (C.c_int, [_vp]),
     "pg_table_create": (C.c_int, [_vp, C.c_int, C.c_int, C.c_uint64, _vpp]),
     "pg_table_destroy": (C.c_int, [_vp]),
+    "pg_table_clear": (C.c_int, [_vp]),
     "pg_table_insert_seqset": (C.c_int, [_vp, C.c_int, _vp]),
     "pg_table_insert_seqset_min": (C.c_int, [_vp, C.c_int, _vp, C.c_uint32]),
     "pg_table_insert_keys": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_uint64]),
@@ -108,6 +109,33 @@ PROTOTYPES = {
 }
 
 
+def _share_torch_hip_runtime() -> None:
+    """PyTorch-ROCm wheels bundle their own libamdhip64 / libhsa-runtime64.  Two HIP runtimes in one process do not
+    share the device: whichever initialises second finds "no HIP GPUs".  The multi-GPU modes hand torch tensors and
+    streams to this library (torch.distributed over RCCL), so both must sit on ONE runtime whatever the import
+    order: when torch is installed and not yet imported, its bundled runtime is loaded first (by path, globally), and
+    the dynamic linker then resolves this library's libamdhip64 dependency to that copy — as it does when torch was
+    imported first.  Without torch installed the system runtime (/opt/rocm) is used."""
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        libdir = os.path.join(os.path.dirname(spec.origin), "lib") if spec and spec.origin else None
+    except (ImportError, ValueError):
+        libdir = None
+    if not libdir:
+        return
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        path = os.path.join(libdir, name)
+        if os.path.exists(path):
+            try:
+                C.CDLL(path, mode=C.RTLD_GLOBAL)
+            except OSError:
+                return
+
+
 def load():
     """Load the shared library (once).  Raises if it has not been built."""
     global _lib
@@ -117,6 +145,7 @@ def load():
         raise ImportError(
             f"{LIB_PATH} not found: build it with `python -m panagram_amd.build` "
             "(hipcc --offload-arch=gfx950).  panagram_amd has no CPU fallback.")
+    _share_torch_hip_runtime()
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported

@@ -453,6 +453,24 @@ extern "C" int pg_table_destroy(pg_table *t) {
     return PG_OK;
 }
 
+// every line EMPTY again, the allocation kept: the genome-sharded mode builds one block table after the other in the
+// same memory (freeing and re-allocating tens of GB costs about 40 ms per GB on this stack)
+extern "C" int pg_table_clear(pg_table *t) {
+    if (!t) return fail(PG_E_INVALID, "table is NULL");
+    if (t->refs > 0) {
+        // (results of this table only hold geometry and their own buffers: they stay valid, their rows are stale)
+    }
+    if (int r = use_device(t->ctx)) return r;
+    TABLE_WRITER(t);
+    for (auto &s : t->subs) {
+        HIP_TRY(launch_table_init(t->ctx->stream, s.d));
+        s.count = 0;
+    }
+    HIP_TRY(hipMemsetAsync(t->d_counters, 0, 2 * sizeof(unsigned long long), t->ctx->stream));
+    t->spill = 0;
+    return PG_OK;
+}
+
 extern "C" int pg_table_k(const pg_table *t) { return t ? t->k : 0; }
 extern "C" int pg_table_ngenomes(const pg_table *t) { return t ? t->ngenomes : 0; }
 extern "C" int pg_table_minimizer(const pg_table *t) { return t ? (int)t->m : 0; }

@@ -531,23 +531,28 @@ def run_genome_sharded(index, nblocks: int, group=None, exchange_stats: Optional
     payload = sum(int(seqs[a].lens.sum()) for a in anchors if writer[a] == rank) * ((N + 7) // 8)
     pool = ThreadPoolExecutor(max_workers=index.writer_jobs(payload))
     joins = []
+    # ONE table allocation for all of this rank's blocks, sized for the largest and emptied between the passes
+    my_blocks = [b for b in range(rank, nblocks, world)]
+    blocks = {b: [inputs[g] for g in range(b * per, min(N, (b + 1) * per)) if g in inputs] for b in my_blocks}
+    tbl_mem = None
+    if my_blocks:
+        tbl_mem = engine.PanTable(ctx, k, per, expected_keys=max(index._expected_keys(blk) for blk in blocks.values()))
     try:
         for p in range(passes):
             b = p * world + rank
             g_lo, g_hi = b * per, min(N, (b + 1) * per)
             tbl = None
             if b < nblocks:
-                blk = [inputs[g] for g in range(g_lo, g_hi) if g in inputs]
-                tbl = engine.PanTable(ctx, k, g_hi - g_lo, expected_keys=index._expected_keys(blk))
-                for name, g, ss, min_count, _ in blk:
+                tbl = tbl_mem
+                if p:
+                    tbl.clear()
+                for name, g, ss, min_count, _ in blocks[b]:
                     tbl.insert_seqset(g.id - g_lo, ss, min_count=min_count)
                 logger_info("pass %d: table of genomes %d..%d: %s", p, g_lo, g_hi - 1, tbl.stats())
             done = (lambda a, res: joins.append(_finish_anchor(index, a, res, pool))) if p == passes - 1 else None
             sh.run_pass(tbl, p * world, min(world, nblocks - p * world), passes > 1, done)
             if tbl is not None:
-                ctx.synchronize()
-                sh.drop_table()
-                tbl.close()
+                ctx.synchronize()  # (the pass's probes are done before the table is emptied for the next block)
         for a in anchors:  # an anchor FASTA without a record: nothing was exchanged, its (empty) files are still due
             if a not in sh.last_group and writer[a] == rank:
                 joins.append(_finish_anchor(index, a, sh.container(a), pool))
@@ -556,6 +561,8 @@ def run_genome_sharded(index, nblocks: int, group=None, exchange_stats: Optional
     finally:
         pool.shutdown(wait=True)
         sh.close()
+        if tbl_mem is not None:
+            tbl_mem.close()
     if exchange_stats is not None:
         exchange_stats.update(bytes_received=sh.bytes_received, passes=passes, nblocks=nblocks, per=per, chunks=len(sh.groups))
     if sh.dist is not None:

@@ -319,6 +319,10 @@ class PanTable(_Owner):
             return
         check(self._lib.pg_table_insert_seqset(self._h, genome_idx, seqs._h))
 
+    def clear(self) -> None:
+        """empty the table, keeping its allocation (the next genome block is built in the same memory)"""
+        check(self._lib.pg_table_clear(self._h))
+
     def insert_keys(self, db_idx: int, keys: np.ndarray, counters: np.ndarray) -> None:
         keys = np.ascontiguousarray(keys, np.uint64)
         counters = np.ascontiguousarray(counters, np.uint32)

@@ -129,6 +129,14 @@ class PanTable:
     def bytes_for(k, ngenomes, expected_keys):
         return int(expected_keys) * BYTES_PER_KEY * ((((ngenomes + 31) // 32) + 1) // 2)
 
+    def clear(self):
+        self._genomes = [[] for _ in range(self.ngenomes)]
+        self._min = [1] * self.ngenomes
+        self._dbs = None
+
+    def spill(self):
+        return 0.0, 8
+
     def insert_seqset(self, g, ss: SeqSet, min_count=1):
         self._genomes[g] = list(ss.seqs)
         self._min[g] = min_count
