@@ -73,6 +73,11 @@ int pg_ctx_mem_info(pg_ctx *ctx, uint64_t *free_bytes, uint64_t *total_bytes);
  * restores the context's own non-blocking stream instead. */
 int pg_ctx_set_stream(pg_ctx *ctx, void *hip_stream, int use_own);
 int pg_ctx_synchronize(pg_ctx *ctx);
+/* plain device buffers (zeroed; memset is async on the context's stream) for callers without an allocator of their
+ * own: the genome-sharded pipeline's exchange buffers in a single-process run */
+int pg_device_alloc(pg_ctx *ctx, uint64_t bytes, void **out);
+int pg_device_memset(pg_ctx *ctx, void *ptr, int value, uint64_t bytes);
+int pg_device_free(pg_ctx *ctx, void *ptr);
 
 /* ---- pan-kmer table: replaces the merged KMC "bitvec" databases --------
  * Reference: KMCdb::KMCdb opens root/kmc/bitvec{i} with CKMCFile::OpenForRA

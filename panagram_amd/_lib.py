@@ -37,6 +37,9 @@ PROTOTYPES = {
     "pg_ctx_mem_info": (C.c_int, [_vp, _u64p, _u64p]),
     "pg_ctx_set_stream": (C.c_int, [_vp, _vp, C.c_int]),
     "pg_ctx_synchronize": (C.c_int, [_vp]),
+    "pg_device_alloc": (C.c_int, [_vp, C.c_uint64, _vpp]),
+    "pg_device_memset": (C.c_int, [_vp, _vp, C.c_int, C.c_uint64]),
+    "pg_device_free": (C.c_int, [_vp, _vp]),
     "pg_table_create": (C.c_int, [_vp, C.c_int, C.c_int, C.c_uint64, _vpp]),
     "pg_table_destroy": (C.c_int, [_vp]),
     "pg_table_clear": (C.c_int, [_vp]),

@@ -290,6 +290,36 @@ extern "C" int pg_ctx_destroy(pg_ctx *c) {
     return PG_OK;
 }
 
+// plain device buffers for a caller that has no other allocator at hand (the genome-sharded pipeline's exchange
+// buffers in a single-process run; with several ranks torch owns them, because the collective takes tensors)
+extern "C" int pg_device_alloc(pg_ctx *c, uint64_t bytes, void **out) {
+    if (!c || !out) return fail(PG_E_INVALID, "pg_device_alloc: NULL argument");
+    if (int r = use_device(c)) return r;
+    void *p = nullptr;
+    HIP_TRY(hipMalloc(&p, std::max<uint64_t>(bytes, 16)));
+    hipError_t e = hipMemsetAsync(p, 0, std::max<uint64_t>(bytes, 16), c->stream);
+    if (e != hipSuccess) {
+        hipFree(p);
+        return fail(PG_E_HIP, "hipMemsetAsync failed: %s", hipGetErrorString(e));
+    }
+    *out = p;
+    return PG_OK;
+}
+extern "C" int pg_device_memset(pg_ctx *c, void *p, int value, uint64_t bytes) {
+    if (!c || (!p && bytes)) return fail(PG_E_INVALID, "pg_device_memset: NULL argument");
+    if (int r = use_device(c)) return r;
+    if (bytes) HIP_TRY(hipMemsetAsync(p, value, bytes, c->stream));
+    return PG_OK;
+}
+extern "C" int pg_device_free(pg_ctx *c, void *p) {
+    if (!c) return fail(PG_E_INVALID, "ctx is NULL");
+    if (!p) return PG_OK;
+    if (int r = use_device(c)) return r;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipFree(p));
+    return PG_OK;
+}
+
 extern "C" int pg_ctx_set_stream(pg_ctx *c, void *s, int use_own) {
     if (!c) return fail(PG_E_INVALID, "ctx is NULL");
     c->stream = use_own ? c->own_stream : reinterpret_cast<hipStream_t>(s);

@@ -272,15 +272,16 @@ CHUNK_POSITIONS = int(os.environ.get("PG_SHARD_CHUNK", str(1 << 27)))  # positio
 
 
 class _Pipe:
-    """Stream plumbing of the chunk pipeline.  On a GPU: the library's kernels run on ``main`` (the context is
-    pointed at it), the collectives on ``comm``; events order them, the host never waits inside the loop.  On
-    CPU tensors (the gloo tests) everything is synchronous and these are no-ops."""
+    """Stream plumbing of the chunk pipeline.  With a collective on a GPU: the library's kernels run on ``main`` (the
+    context is pointed at it), the collectives on ``comm``; events order them, the host never waits inside the loop.
+    Without a collective (one process) everything runs in order on the context's own stream and torch is not even
+    imported; on CPU tensors (the gloo tests) everything is synchronous."""
 
     def __init__(self, ctx, dev):
-        import torch
-        self.gpu = dev.type == "cuda"
         self.ctx = ctx
+        self.gpu = dev is not None and dev.type == "cuda"
         if self.gpu:
+            import torch
             self.torch = torch
             self.main = torch.cuda.Stream(dev)
             self.comm = torch.cuda.Stream(dev)
@@ -292,13 +293,6 @@ class _Pipe:
         ev = self.torch.cuda.Event()
         ev.record(self.main)
         return ev
-
-    def zero(self, t):
-        if self.gpu:
-            with self.torch.cuda.stream(self.main):
-                t.zero_()
-        else:
-            t.zero_()
 
     def main_waits(self, ev):
         if self.gpu and ev is not None:
@@ -321,6 +315,28 @@ class _Pipe:
             self.ctx.synchronize()
             self.torch.cuda.synchronize()
             self.ctx.set_stream(None)
+
+
+class _TorchBuffer:
+    """exchange buffer owned by torch (the collective takes tensors); same face as engine.DeviceBuffer"""
+
+    def __init__(self, torch, nbytes, dev, stream=None):
+        self.t = torch.zeros(max(int(nbytes), 8), dtype=torch.uint8, device=dev)
+        self._torch, self._stream = torch, stream
+
+    def data_ptr(self):
+        return self.t.data_ptr()
+
+    def zero(self, nbytes=None):
+        v = self.t if nbytes is None else self.t[:nbytes]
+        if self._stream is not None:
+            with self._torch.cuda.stream(self._stream):
+                v.zero_()
+        else:
+            v.zero_()
+
+    def close(self):
+        self.t = None
 
 
 def contig_chunks(lens: Sequence[int], k: int, limit: Optional[int] = None) -> List[Tuple[int, int]]:
@@ -368,7 +384,6 @@ class ShardedAnchoring:
                  writer: Dict[str, int], geometry: Optional[dict] = None, group=None, always_gather: bool = False):
         """``always_gather``: issue the collective even with one rank (a process group of size 1) — the side-stream
         and RCCL code path on a single GPU."""
-        import torch
         self.engine, self.ctx, self.k, self.N, self.per = engine, ctx, k, ngenomes, per
         self.rank, self.world, self.seqs, self.writer, self.group = rank, max(1, world), seqs, writer, group
         self.geometry = geometry or {}
@@ -403,14 +418,20 @@ class ShardedAnchoring:
         self.merged = engine.SeqSet.concat_ranges(ctx, parts) if parts else None
         self._contig_anchor = np.asarray(contig_anchor, np.uint32)
         biggest = max(self.group_tiles or [0]) * 64 * per
-        dev = ctx.torch_device()
-        self.send = [torch.zeros(max(biggest, 8), dtype=torch.uint8, device=dev) for _ in range(2)]
-        # (one rank: its own block is all there is — merged straight out of the send buffer)
-        self.recv = ([torch.zeros(max(biggest, 8) * self.world, dtype=torch.uint8, device=dev) for _ in range(2)]
-                     if self.collective else self.send)
-        if dev.type == "cuda":
-            torch.cuda.synchronize(dev)  # the buffers were zeroed on torch's stream; the kernels run on the pipe's
-        self.pipe = _Pipe(ctx, dev)
+        if self.collective:  # torch owns the buffers (the collective takes tensors) and the two streams
+            import torch
+            dev = ctx.torch_device()
+            self.send = [_TorchBuffer(torch, biggest, dev) for _ in range(2)]
+            self.recv = [_TorchBuffer(torch, biggest * self.world, dev) for _ in range(2)]
+            if dev.type == "cuda":
+                torch.cuda.synchronize(dev)  # the buffers were zeroed on torch's stream; the kernels run on the pipe's
+            self.pipe = _Pipe(ctx, dev)
+            for b_ in self.send:
+                b_._stream = getattr(self.pipe, "main", None)
+        else:  # one process: its own block is all there is — merged straight out of the send buffer; no torch
+            self.send = [engine.DeviceBuffer(ctx, biggest) for _ in range(2)]
+            self.recv = self.send
+            self.pipe = _Pipe(ctx, None)
         self.full: Dict[str, object] = {}  # writer side: anchor -> rows container (kept across passes)
         self._part, self._part_table = None, None  # the narrow result, kept while the table stays the same
         self.bytes_received = 0
@@ -466,10 +487,10 @@ class ShardedAnchoring:
                 part.run_range(m0, cnt)
                 part.extract_columns_range(0, per, m0, cnt, self.send[slot].data_ptr())
             else:
-                pipe.zero(self.send[slot][:nbytes])  # a rank without a block in this pass contributes zeros
+                self.send[slot].zero(nbytes)  # a rank without a block in this pass contributes zeros
             ready = pipe.mark_main()
             if self.collective:
-                out_t, in_t = self.recv[slot][:nbytes * self.world], self.send[slot][:nbytes]
+                out_t, in_t = self.recv[slot].t[:nbytes * self.world], self.send[slot].t[:nbytes]
                 ev = pipe.on_comm(ready, lambda o=out_t, t=in_t: self.dist.all_gather_into_tensor(o, t, group=self.group))
                 self.bytes_received += nbytes * (self.world - 1)
             else:
@@ -492,6 +513,8 @@ class ShardedAnchoring:
             r.close()
         self.full = {}
         self.pipe.close()
+        for b_ in {id(x): x for x in self.send + self.recv}.values():
+            b_.close()
         if self.merged is not None:
             self.merged.close()
             self.merged = None

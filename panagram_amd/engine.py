@@ -127,6 +127,34 @@ class Context(_Owner):
             pass
 
 
+class DeviceBuffer:
+    """a plain (zeroed) device buffer of the library's own — what the single-process genome-sharded pipeline exchanges
+    its bit columns through (several ranks use torch tensors: the collective takes those)"""
+
+    def __init__(self, ctx: Context, nbytes: int):
+        self.ctx, self._lib, self.nbytes = ctx, ctx._lib, int(nbytes)
+        p = C.c_void_p()
+        check(self._lib.pg_device_alloc(ctx._h, self.nbytes, C.byref(p)))
+        self._p = p
+
+    def data_ptr(self) -> int:
+        return int(self._p.value)
+
+    def zero(self, nbytes: Optional[int] = None) -> None:
+        check(self._lib.pg_device_memset(self.ctx._h, self._p, 0, self.nbytes if nbytes is None else nbytes))
+
+    def close(self) -> None:
+        if self._p:
+            self._lib.pg_device_free(self.ctx._h, self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class SeqSet(_Owner):
     """The contigs of one FASTA, 2-bit packed in HBM."""
 

@@ -59,6 +59,20 @@ class Context:
         pass
 
 
+class DeviceBuffer:
+    def __init__(self, ctx, nbytes):
+        self._a = np.zeros(max(int(nbytes), 16), np.uint8)
+
+    def data_ptr(self):
+        return self._a.ctypes.data
+
+    def zero(self, nbytes=None):
+        self._a[:len(self._a) if nbytes is None else nbytes] = 0
+
+    def close(self):
+        pass
+
+
 class SeqSet:
     def __init__(self, ctx, names: Sequence[str], seqs: Sequence[bytes]):
         self.ctx, self.names, self.seqs = ctx, list(names), [bytes(s) for s in seqs]
