@@ -305,6 +305,12 @@ int pg_result_write_bgzf_range(pg_result *r, int step, uint32_t first_contig, ui
  * and the lines are fetched from HBM once instead of once per genome.  Results do not depend on
  * the schedule. */
 int pg_result_coschedule(pg_result *r, const uint32_t *contig_group, uint32_t piece_tiles);
+/* the same when the genomes do not list their contigs in corresponding order: contig_class[c] names the homology
+ * class of contig c (e.g. the chromosome: equal record ids in different FASTAs); the classes are scheduled one after
+ * the other, within a class the genomes' contigs side by side as above.  (With shuffled contig order the plain
+ * co-schedule degrades to the one-launch-per-genome rate: tools/indel_cosched.py --shuffle-contigs.) */
+int pg_result_coschedule_classes(pg_result *r, const uint32_t *contig_group, const uint32_t *contig_class,
+                                 uint32_t piece_tiles);
 /* the same with the contigs cut into nranges consecutive ranges (range i starts at contig range_first_contig[i];
  * the first at 0) that are scheduled independently: pg_anchor_run_range over one or several whole ranges then
  * follows the schedule too (any other range runs in launch order) */

@@ -89,6 +89,7 @@ PROTOTYPES = {
     "pg_result_extract_columns_range": (C.c_int, [_vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _vp]),
     "pg_result_merge_columns_range": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_uint64]),
     "pg_result_coschedule_ranges": (C.c_int, [_vp, _vp, C.c_uint32, _vp, C.c_uint32]),
+    "pg_result_coschedule_classes": (C.c_int, [_vp, _vp, _vp, C.c_uint32]),
     "pg_seqset_concat_ranges": (C.c_int, [_vp, _vp, _vp, _vp, C.c_uint32, _vpp]),
     "pg_rows_epilogue": (C.c_int, [_vp]),
     "pg_result_timing": (C.c_int, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]),

@@ -1618,7 +1618,7 @@ extern "C" int pg_result_destroy(pg_result *r) {
 // L2 / Infinity Cache.  Only the launch order changes — results are identical for any schedule.
 // ---------------------------------------------------------------------------
 static int coschedule(pg_result *r, const uint32_t *contig_group, uint32_t piece_tiles, const uint32_t *range_first,
-                      uint32_t nranges) {
+                      uint32_t nranges, const uint32_t *contig_class = nullptr) {
     if (int e = use_device(r->ctx)) return e;
     hipStream_t st = r->ctx->stream;
     HIP_TRY(hipStreamSynchronize(st));
@@ -1648,13 +1648,30 @@ static int coschedule(pg_result *r, const uint32_t *contig_group, uint32_t piece
     };
     std::vector<uint32_t> sched;
     sched.reserve(r->ntiles);
-    for (size_t ri = 0; ri + 1 < firsts.size(); ++ri) {
-        const size_t c_lo = firsts[ri], c_hi = firsts[ri + 1];
-        r->sched_bounds.push_back(r->ad[c_lo].tile0);
+    // classes of contigs (homologous chromosomes: the same class in every genome, whatever order a genome lists them
+    // in) are scheduled one after the other, each like a range of its own; without classes a range is one class
+    std::vector<std::vector<uint32_t>> members;  // contigs of every (range, class), in contig order
+    if (contig_class) {
+        std::vector<std::pair<uint32_t, uint32_t>> byclass;
+        for (size_t c = 0; c < nc; ++c) byclass.emplace_back(contig_class[c], (uint32_t)c);
+        std::stable_sort(byclass.begin(), byclass.end(), [](auto &x, auto &y) { return x.first < y.first; });
+        for (size_t i = 0; i < byclass.size(); ++i) {
+            if (i == 0 || byclass[i].first != byclass[i - 1].first) members.emplace_back();
+            members.back().push_back(byclass[i].second);
+        }
+        r->sched_bounds.push_back(0);
+    } else {
+        for (size_t ri = 0; ri + 1 < firsts.size(); ++ri) {
+            members.emplace_back();
+            for (uint32_t c = firsts[ri]; c < firsts[ri + 1]; ++c) members.back().push_back(c);
+            r->sched_bounds.push_back(r->ad[firsts[ri]].tile0);
+        }
+    }
+    for (const auto &mem : members) {
         uint32_t ngroups = 0;
-        for (size_t c = c_lo; c < c_hi; ++c) ngroups = std::max(ngroups, contig_group[c] + 1);
+        for (uint32_t c : mem) ngroups = std::max(ngroups, contig_group[c] + 1);
         std::vector<std::vector<uint32_t>> tiles(ngroups);  // every group's tiles, contig after contig
-        for (size_t c = c_lo; c < c_hi; ++c) {
+        for (uint32_t c : mem) {
             const uint32_t nt = (uint32_t)(((uint64_t)r->ad[c].nkmers + PROBE_TILE - 1) / PROBE_TILE);
             for (uint32_t i = 0; i < nt; ++i) tiles[contig_group[c]].push_back(r->ad[c].tile0 + i);
         }
@@ -1680,6 +1697,13 @@ static int coschedule(pg_result *r, const uint32_t *contig_group, uint32_t piece
 extern "C" int pg_result_coschedule(pg_result *r, const uint32_t *contig_group, uint32_t piece_tiles) {
     if (!r) return fail(PG_E_INVALID, "result is NULL");
     return coschedule(r, contig_group, piece_tiles, nullptr, 0);
+}
+
+extern "C" int pg_result_coschedule_classes(pg_result *r, const uint32_t *contig_group, const uint32_t *contig_class,
+                                            uint32_t piece_tiles) {
+    if (!r) return fail(PG_E_INVALID, "result is NULL");
+    if (contig_group && !contig_class) return fail(PG_E_INVALID, "pg_result_coschedule_classes: contig_class is NULL");
+    return coschedule(r, contig_group, piece_tiles, nullptr, 0, contig_class);
 }
 
 extern "C" int pg_result_coschedule_ranges(pg_result *r, const uint32_t *contig_group, uint32_t piece_tiles,

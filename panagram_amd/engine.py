@@ -443,6 +443,18 @@ class PanTable(_Owner):
             pass
 
 
+def homology_classes(name_lists: Sequence[Sequence[str]]) -> np.ndarray:
+    """``contig_class`` for ``AnchorResult.coschedule`` from the genomes' record ids: contigs with the same id (the same
+    chromosome name in different FASTAs) form one class, classes numbered in order of first appearance; a genome whose
+    ids match nobody else's keeps its own contig order (class = position)."""
+    seen, out = {}, []
+    for names in name_lists:
+        for i, nm in enumerate(names):
+            key = nm if nm else ("", i)
+            out.append(seen.setdefault(key, len(seen)))
+    return np.asarray(out, np.uint32)
+
+
 class AnchorResult:
     """Device-resident outputs of anchoring one SeqSet against one PanTable."""
 
@@ -479,16 +491,24 @@ class AnchorResult:
         seqs._adopt(r)
         return r
 
-    def coschedule(self, contig_group, piece_tiles: int = 0) -> None:
+    def coschedule(self, contig_group, piece_tiles: int = 0, contig_class=None) -> None:
         """Interleave the tiles of several anchor genomes (``contig_group[c]`` = genome of contig c;
-        None: launch order) so that homologous regions share their table lines in L2."""
+        None: launch order) so that homologous regions share their table lines in L2.  ``contig_class[c]``:
+        homology class of contig c (e.g. the chromosome) when the genomes list their contigs in different orders."""
         if contig_group is None:
             check(self._lib.pg_result_coschedule(self._h, None, 0))
             return
         grp = np.ascontiguousarray(contig_group, np.uint32)
         if len(grp) != len(self.seqs.lens):
             raise ValueError("contig_group needs one entry per contig")
-        check(self._lib.pg_result_coschedule(self._h, _ptr(grp), piece_tiles))
+        if contig_class is None:
+            check(self._lib.pg_result_coschedule(self._h, _ptr(grp), piece_tiles))
+            return
+        cls = np.ascontiguousarray(contig_class, np.uint32)
+        if len(cls) != len(grp):
+            raise ValueError("contig_class needs one entry per contig")
+        check(self._lib.pg_result_coschedule_classes(self._h, _ptr(grp), _ptr(cls), piece_tiles))
+
 
     def coschedule_ranges(self, contig_group, range_first_contig, piece_tiles: int = 0) -> None:
         """``coschedule`` with the contigs cut into consecutive ranges (starting at the given contigs, the first at 0)

@@ -626,8 +626,9 @@ class Index:
             g.log.info("Anchoring Started")
         res = engine.AnchorResult(tbl, merged, colsums=True, **self.result_geometry)
         first = np.cumsum([0] + [len(s.names) for s in sets])
-        if len(sets) > 1:
-            res.coschedule(np.repeat(np.arange(len(sets)), [len(s.names) for s in sets]))
+        if len(sets) > 1:  # homologous chromosomes side by side, matched by record id whatever order a FASTA lists them in
+            res.coschedule(np.repeat(np.arange(len(sets)), [len(s.names) for s in sets]),
+                           contig_class=engine.homology_classes([s.names for s in sets]))
         res.run()
         return dict(res=res, merged=merged if len(sets) > 1 else None,
                     genomes=[self.genomes[name].tabulate(res, int(first[gi]), int(first[gi + 1]), list(merged.names[first[gi]:first[gi + 1]]))
@@ -1047,7 +1048,8 @@ def run_anchor_cli(argv: Sequence[str], device: int = 0) -> int:
             merged = engine.SeqSet.concat(ctx, sets) if len(sets) > 1 else sets[0]
             res = engine.AnchorResult(tbl, merged, colsums=False)
             if len(sets) > 1:
-                res.coschedule(np.repeat(np.arange(len(sets)), [len(x.names) for x in sets]))
+                res.coschedule(np.repeat(np.arange(len(sets)), [len(x.names) for x in sets]),
+                               contig_class=engine.homology_classes([x.names for x in sets]))
             res.run()
             first = np.cumsum([0] + [len(x.names) for x in sets])
             futs = [pool.submit(write_anchor, res, nm, int(first[j]), list(sets[j].names)) for j, nm in enumerate(batch)]

@@ -31,6 +31,9 @@ def tile_positions() -> int:
     return 512
 
 
+from panagram_amd.engine import homology_classes  # noqa: E402,F401  (pure host logic)
+
+
 def _view(ptr: int, nbytes: int) -> np.ndarray:
     return np.ctypeslib.as_array((C.c_uint8 * nbytes).from_address(ptr))
 
@@ -191,8 +194,8 @@ class AnchorResult:
         return r
 
     # ---- probing ----
-    def coschedule(self, groups, piece_tiles=0):
-        pass
+    def coschedule(self, groups, piece_tiles=0, contig_class=None):
+        assert contig_class is None or len(contig_class) == len(groups)
 
     def coschedule_ranges(self, groups, range_first, piece_tiles=0):
         assert len(groups) == len(self._nk) and list(range_first) == sorted(set(range_first)) and range_first[0] == 0

@@ -465,8 +465,11 @@ def test_coscheduled_result_over_all_anchor_genomes(ctx, n, k, piece):
     assert [int(x) for x in merged.lens] == lens * len(anchors)
     res = engine.AnchorResult(tbl, merged)
     groups = np.repeat(np.arange(len(anchors)), len(lens))
-    for grp in (groups, None, (groups + 1) % 2, np.zeros(len(groups), int)):
-        res.coschedule(grp, piece)
+    rng = np.random.default_rng(n)
+    classes = [None, None, None, None, np.tile(np.arange(len(lens)), len(anchors)), rng.integers(0, 3, len(groups)),
+               rng.permutation(len(groups))]  # homology classes: by contig number, arbitrary, all distinct
+    for grp, cls in zip((groups, None, (groups + 1) % 2, np.zeros(len(groups), int), groups, groups, groups), classes):
+        res.coschedule(grp, piece, contig_class=cls)
         res.run()
         for gi, g in enumerate(anchors):
             for ci in range(len(lens)):

@@ -280,3 +280,11 @@ def test_concat_bgzf_fragments(tmp_path):
     assert list(blocks[:, 1]) == sorted(set(blocks[:, 1]))
     for start, ln in [(0, 10), (69990, 30), (70004, 100), (270000, 65285), (len(whole) - 7, 7)]:
         assert pidx.bgzf_read(out, blocks, start, ln) == whole[start:start + ln]
+
+
+def test_homology_classes_from_record_ids():
+    from panagram_amd.engine import homology_classes
+    c = homology_classes([["chr1", "chr2", "chrM"], ["chr2", "chr1", "scaf9"], ["", ""], ["chrM"]])
+    assert list(c[:3]) == [0, 1, 2] and list(c[3:6]) == [1, 0, 3]
+    assert c[6] != c[7] and len({int(c[6]), int(c[7])} & {0, 1, 2, 3}) == 0  # unnamed contigs stay on their own
+    assert c[8] == 2
