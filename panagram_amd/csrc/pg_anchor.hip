@@ -26,8 +26,8 @@
 //                rows), per-bin popcount histogram, per-contig column sums — persistent
 //                workgroups, register accumulators, one instantiation per row width (1..8 bytes;
 //                16 consecutive rows per thread over 4 full tiles of one bin).
-//   k_epilogue_words   the same for rows wider than 8 bytes (more than 64 genomes): a lane owns one
-//                32-bit word of the rows it visits, one launch reads every row once.
+//   k_epilogue_chunks  the same for rows wider than 8 bytes (more than 64 genomes): a lane owns one
+//                16-byte chunk of the rows it visits, one launch reads every row once.
 //   k_window_stats, k_cols_extract / k_cols_merge: side paths (gene / bin windows; the
 //                genome-sharded exchange).
 //
@@ -203,19 +203,37 @@ __device__ __forceinline__ void copy_words(const uint32_t *src, uint8_t *dst, bo
     if (hit) v = *reinterpret_cast<const WordsN<NW> *>(src);
     *reinterpret_cast<WordsN<NW> *>(dst) = v;
 }
+template <int NS>  // NS whole words and `tail` bytes of the next one: NS + 1 words in one load
+__device__ __forceinline__ void copy_words_tail(const uint32_t *src, uint8_t *dst, bool hit, uint32_t tail) {
+    WordsN<NS + 1> v;
+#pragma unroll
+    for (int i = 0; i <= NS; ++i) v.w[i] = 0;
+    if (hit) v = *reinterpret_cast<const WordsN<NS + 1> *>(src);
+    if constexpr (NS > 0) {
+        WordsN<NS> o;
+#pragma unroll
+        for (int i = 0; i < NS; ++i) o.w[i] = v.w[i];
+        *reinterpret_cast<WordsN<NS> *>(dst) = o;
+    }
+    for (uint32_t bb = 0; bb < tail; ++bb) dst[4 * NS + bb] = (uint8_t)(v.w[NS] >> (8 * bb));
+}
 __device__ __forceinline__ void store_row_wide(const uint8_t *masks, uint32_t W, uint32_t nbytes, uint8_t *row, uint32_t hline,
                                                uint32_t slot1) {
     const bool hit = slot1 != 0;
     const uint32_t *mp = reinterpret_cast<const uint32_t *>(masks) + ((uint64_t)hline * SPLIT_KEYS + (slot1 - 1u)) * W;
     uint32_t d = 0;
     const uint32_t full = nbytes / 4;  // (wave-uniform loop bounds)
+    const uint32_t tail = nbytes % 4;  // bytes of a last, partial word: fetched with the piece before it (one request)
     for (; d + 4 <= full; d += 4) copy_words<4>(mp + d, row + 4 * d, hit);
-    if (full - d == 3) copy_words<3>(mp + d, row + 4 * d, hit);
-    else if (full - d == 2) copy_words<2>(mp + d, row + 4 * d, hit);
-    else if (full - d == 1) copy_words<1>(mp + d, row + 4 * d, hit);
-    if (nbytes % 4) {
-        const uint32_t v = hit ? mp[full] : 0u;
-        for (uint32_t bb = 0; bb < nbytes % 4; ++bb) row[4 * full + bb] = (uint8_t)(v >> (8 * bb));
+    if (!tail) {
+        if (full - d == 3) copy_words<3>(mp + d, row + 4 * d, hit);
+        else if (full - d == 2) copy_words<2>(mp + d, row + 4 * d, hit);
+        else if (full - d == 1) copy_words<1>(mp + d, row + 4 * d, hit);
+    } else {
+        if (full - d == 3) copy_words_tail<3>(mp + d, row + 4 * d, hit, tail);
+        else if (full - d == 2) copy_words_tail<2>(mp + d, row + 4 * d, hit, tail);
+        else if (full - d == 1) copy_words_tail<1>(mp + d, row + 4 * d, hit, tail);
+        else copy_words_tail<0>(mp + d, row + 4 * d, hit, tail);
     }
 }
 
@@ -922,7 +940,7 @@ __device__ __forceinline__ void flush_hist(uint32_t N, uint32_t *hist, uint32_t 
 }
 
 // MODE 0: one-byte rows (N <= 8), 1: rows of 2..8 bytes (N <= 64); wider rows go through
-// k_epilogue_words below.  One instantiation per mode so that each carries only its own accumulators
+// k_epilogue_chunks below.  One instantiation per mode so that each carries only its own accumulators
 // in registers.
 template <int MODE, int NBT>  // NBT = bytes per row (1..8): one instantiation, and one register allocation, per width
 __global__ __launch_bounds__(EPI_THREADS) void k_epilogue(uint32_t N, const AnchorDesc *__restrict__ ad,
@@ -1386,34 +1404,47 @@ __global__ __launch_bounds__(EPI_THREADS) void k_epilogue(uint32_t N, const Anch
 }
 
 // ---------------------------------------------------------------------------
-// Rows wider than 8 bytes (more than 64 genomes): the same statistics WORD-PARALLEL.  A lane owns one
-// 32-bit word d of the rows it visits (lanes d = 0..W-1 of consecutive lanes share a row, 64 / W rows
-// per wave and step, loads contiguous over the wave), so every lane carries the vertical counters of
-// ONE word whatever the row width, the whole row is read once, and one launch does all columns (the
-// earlier scheme ran one pass per 64 genomes, each re-reading every row).
-//   popcount of a row   W - 1 shuffles to its first lane, one LDS atomic into the bin window
-//   bitmap.100          each lane copies its word of the 1-in-100 rows
-//   column sums         carry-save vertical counters per lane (4 rows at a time), byte-sliced
-//                       accumulators, LDS atomics every 248 rows, per contig to global
+// Rows wider than 8 bytes (more than 64 genomes): the same statistics CHUNK-PARALLEL.  A lane owns one
+// 16-byte chunk c of the rows it visits (C = ceil(nbytes / 16) consecutive lanes share a row, 64 / C
+// rows per wave and step; one 16-byte load per lane and row, contiguous over the wave, at whatever byte
+// alignment the row stride gives), so the per-row work (addressing, tail masking, histogram, the
+// 1-in-100 test) is paid once per 16 bytes and every lane carries the vertical counters of FOUR words
+// whatever the row width.  (Round 2's first version gave every lane one 32-bit word: 45 VALU
+// instructions per word, 2.8 wave-instructions per 16-byte row, issue-bound at 2.7 TB/s.)
+//   popcount of a row   4 v_bcnt per lane, C - 1 shuffles to the row's first lane, one LDS atomic
+//   bitmap.100          each lane copies its chunk of the 1-in-100 rows
+//   column sums         carry-save vertical counters per word (4 rows at a time, 12 rows per
+//                       flush), byte-sliced accumulators, LDS atomics every 252 rows, per contig to global
+// EXACT: nbytes == 16 C (N a multiple of 128): aligned loads, no tail mask.
 // ---------------------------------------------------------------------------
-template <int W_T>  // words per row known at compile time (3..8), or 0: any
-__global__ __launch_bounds__(EPI_THREADS) void k_epilogue_words(uint32_t N, const AnchorDesc *__restrict__ ad,
-                                                                const uint32_t *__restrict__ tile_contig, uint32_t ntiles,
-                                                                const uint8_t *__restrict__ out1, uint8_t *__restrict__ out100,
-                                                                uint32_t *__restrict__ bins,
-                                                                unsigned long long *__restrict__ colsums, uint32_t flags) {
+template <int C_T, bool EXACT>  // chunks per row known at compile time (1..4), or 0: any
+__global__ __launch_bounds__(EPI_THREADS) void k_epilogue_chunks(uint32_t N, const AnchorDesc *__restrict__ ad,
+                                                                 const uint32_t *__restrict__ tile_contig, uint32_t ntiles,
+                                                                 const uint8_t *__restrict__ out1, uint8_t *__restrict__ out100,
+                                                                 uint32_t *__restrict__ bins,
+                                                                 unsigned long long *__restrict__ colsums, uint32_t flags) {
     extern __shared__ uint4 smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t nbytes = (N + 7) / 8, W = W_T ? (uint32_t)W_T : (nbytes + 3) / 4;
-    const uint32_t RPW = 64u / W, RPS = RPW * (EPI_THREADS / 64);  // rows per wave / per workgroup and step
-    const uint32_t d = (uint32_t)lane % W, rsub = (uint32_t)wave * RPW + (uint32_t)lane / W;
-    const bool lane_on = (uint32_t)lane < RPW * W;
-    const uint32_t wbytes = min(4u, nbytes - 4u * d);  // bytes of this lane's word (the last one may be short)
-    const uint32_t wmask = wbytes == 4 ? 0xFFFFFFFFu : (1u << (8 * wbytes)) - 1u;
+    const uint32_t nbytes = (N + 7) / 8, C = C_T ? (uint32_t)C_T : (nbytes + 15) / 16;
+    const uint32_t RPW = 64u / C, RPS = RPW * (EPI_THREADS / 64);  // rows per wave / per workgroup and step
+    const uint32_t c = (uint32_t)lane % C, rsub = (uint32_t)wave * RPW + (uint32_t)lane / C;
+    const bool lane_on = (uint32_t)lane < RPW * C;
+    const uint32_t vb = EXACT ? 16u : min(16u, nbytes - 16u * c);  // bytes of this lane's chunk (the row's last one may be short)
+    // column counters in LDS: one copy per 16 rows of a wave's step, so that at most 16 lanes add to a word
+    // at a time (and the address is lane-dependent: on a wave-uniform address the compiler's atomic
+    // optimizer would sum the lanes' values one by one, 64 rounds per counter)
+    const uint32_t K = (RPW + 15u) / 16u, cs_words = 128u * C;
+    uint32_t wm[4];                                  // ... as masks of its four words
+#pragma unroll
+    for (uint32_t w = 0; w < 4; ++w) {
+        const uint32_t nb = vb > 4u * w ? min(4u, vb - 4u * w) : 0u;
+        wm[w] = nb == 4 ? 0xFFFFFFFFu : (1u << (8 * nb)) - 1u;
+    }
     uint32_t *hist = reinterpret_cast<uint32_t *>(smem);
     uint32_t *cs = hist + ((EPI_MAXB * (N + 1) + 3) & ~3u);
     for (uint32_t i = tid; i < EPI_MAXB * (N + 1); i += EPI_THREADS) hist[i] = 0;
-    for (uint32_t i = tid; i < 32u * W; i += EPI_THREADS) cs[i] = 0;
+    for (uint32_t i = tid; i < K * cs_words; i += EPI_THREADS) cs[i] = 0;
+    uint32_t *cs_mine = cs + ((uint32_t)lane / C / 16u) * cs_words + 128u * c;
     __syncthreads();
     const bool want_cs = (flags & 1u) != 0;
     const bool want100 = (flags & 2u) == 0;
@@ -1425,109 +1456,131 @@ __global__ __launch_bounds__(EPI_THREADS) void k_epilogue_words(uint32_t N, cons
     AnchorDesc a;
     a.out_off = a.out100_off = a.bin_off = 0;
     a.nkmers = a.binlen = a.tile0 = a.nbins = 0;
-    uint32_t vp[4] = {0, 0, 0, 0}, bacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t vp[4][4], bacc[4][8];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) vp[w][q] = 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) bacc[w][q] = 0;
+    }
     uint32_t vrows = 0, brounds = 0;
-    auto vadd4 = [&](uint32_t r0, uint32_t r1, uint32_t r2, uint32_t r3) {
-        const uint32_t x = vp[0];
+    auto vadd4 = [&](uint32_t (&p)[4], uint32_t r0, uint32_t r1, uint32_t r2, uint32_t r3) {
+        const uint32_t x = p[0];
         const uint32_t t1 = x ^ r0, s1 = t1 ^ r1, ca = (t1 & r1) | (~t1 & x);
         const uint32_t t2 = s1 ^ r2, s2 = t2 ^ r3, cb = (t2 & r3) | (~t2 & s1);
-        vp[0] = s2;
-        const uint32_t y = vp[1];
+        p[0] = s2;
+        const uint32_t y = p[1];
         const uint32_t t3 = y ^ ca, cc = (t3 & cb) | (~t3 & y);
-        vp[1] = t3 ^ cb;
-        const uint32_t c4 = vp[2] & cc;
-        vp[2] ^= cc;
-        vp[3] ^= c4;
+        p[1] = t3 ^ cb;
+        const uint32_t c4 = p[2] & cc;
+        p[2] ^= cc;
+        p[3] ^= c4;
     };
-    auto bflush = [&]() {  // byte-sliced accumulators -> the workgroup's LDS counters of this lane's word
-        for (int q = 0; q < 8; ++q) {  // (not unrolled: rare)
-            const uint32_t v = bacc[q];
-            for (int b = 0; b < 4; ++b) {
-                const uint32_t cnt = (v >> (8 * b)) & 255u;
-                if (cnt) atomicAdd(&cs[32u * d + 8u * b + q], cnt);
-            }
-        }
+    auto bflush = [&]() __attribute__((always_inline)) {  // byte-sliced accumulators -> the workgroup's LDS counters of this lane's words
 #pragma unroll
-        for (int q = 0; q < 8; ++q) bacc[q] = 0;
+        for (int w = 0; w < 4; ++w)  // (static register indices: a rolled loop would put bacc in scratch)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const uint32_t v = bacc[w][q];
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const uint32_t cnt = (v >> (8 * b)) & 255u;
+                    if (cnt) atomicAdd(&cs_mine[32 * w + 8 * b + q], cnt);
+                }
+            }
+#pragma unroll
+        for (int w = 0; w < 4; ++w)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) bacc[w][q] = 0;
         brounds = 0;
     };
-    auto vflush = [&]() {
+    auto vflush = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const uint32_t M = 0x11111111u;
-            const uint32_t nib = ((vp[0] >> j) & M) | (((vp[1] >> j) & M) << 1) | (((vp[2] >> j) & M) << 2) | (((vp[3] >> j) & M) << 3);
-            bacc[j] += nib & 0x0F0F0F0Fu;
-            bacc[4 + j] += (nib >> 4) & 0x0F0F0F0Fu;
+        for (int w = 0; w < 4; ++w) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t M = 0x11111111u;
+                const uint32_t nib = ((vp[w][0] >> j) & M) | (((vp[w][1] >> j) & M) << 1) | (((vp[w][2] >> j) & M) << 2) |
+                                     (((vp[w][3] >> j) & M) << 3);
+                bacc[w][j] += nib & 0x0F0F0F0Fu;
+                bacc[w][4 + j] += (nib >> 4) & 0x0F0F0F0Fu;
+            }
+            vp[w][0] = vp[w][1] = vp[w][2] = vp[w][3] = 0;
         }
-        vp[0] = vp[1] = vp[2] = vp[3] = 0;
         vrows = 0;
-        if (++brounds == 31) bflush();  // 31 x 8 rows: the byte counters are about to fill
+        ++brounds;
     };
-    auto flush_colsums = [&](uint32_t contig) {
+    auto flush_colsums = [&](uint32_t contig) __attribute__((always_inline)) {
         if (vrows) vflush();
         if (brounds) bflush();
         __syncthreads();
         for (uint32_t i = tid; i < N; i += EPI_THREADS) {
-            const uint32_t v = cs[i];
-            if (v) {
-                atomicAdd(&colsums[(uint64_t)contig * N + i], (unsigned long long)v);
-                cs[i] = 0;
+            uint32_t v = 0;
+            for (uint32_t kk = 0; kk < K; ++kk) {
+                v += cs[kk * cs_words + i];
+                cs[kk * cs_words + i] = 0;
             }
+            if (v) atomicAdd(&colsums[(uint64_t)contig * N + i], (unsigned long long)v);
         }
         __syncthreads();
     };
     struct __attribute__((packed)) U32 { uint32_t v; };
-    // popcount of a whole row from its lanes' words, valid (at least) in the row's first lane
-    auto row_popc = [&](uint32_t pc) -> uint32_t {
-        if (W_T == 1) return pc;
-        if (W_T == 2) return pc + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pc, 0xB1, 0xF, 0xF, false);  // quad_perm [1,0,3,2]
-        if (W_T == 4) {
+    struct __attribute__((packed)) U128 { uint32_t x, y, z, w; };
+    // popcount of a whole row from its lanes' chunks, valid (at least) in the row's first lane
+    auto row_popc = [&](uint32_t pc) __attribute__((always_inline)) -> uint32_t {
+        if (C_T == 1) return pc;
+        if (C_T == 2) return pc + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pc, 0xB1, 0xF, 0xF, false);  // quad_perm [1,0,3,2]
+        if (C_T == 4) {
             pc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pc, 0xB1, 0xF, 0xF, false);
             return pc + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pc, 0x4E, 0xF, 0xF, false);  // quad_perm [2,3,0,1]
         }
         uint32_t tot = pc;
-        for (uint32_t q = 1; q < W; ++q) tot += (uint32_t)__shfl_down((int)pc, q);
+        for (uint32_t q = 1; q < C; ++q) tot += (uint32_t)__shfl_down((int)pc, q);
         return tot;
     };
-    // The rows are streamed in iterations of 8 steps (8 x RPS rows), the loads of iteration i + 1 issued
-    // before iteration i is worked on — also across tiles: 16 loads per lane in flight keep enough
-    // bytes on their way to cover HBM latency (with 4 the kernel ran at 1.5 TB/s).
-    constexpr uint32_t NJ = 8;
+    // The rows are streamed in iterations of 4 steps (4 x RPS rows), the loads of iteration i + 1 issued
+    // before iteration i is worked on — also across tiles: 8 x 16 bytes per lane in flight.
+    constexpr uint32_t NJ = 4;
     const uint32_t iter_rows = NJ * RPS, IPT = ((uint32_t)PROBE_TILE + iter_rows - 1) / iter_rows;
     const uint32_t nit = t_end > t_begin ? (t_end - t_begin) * IPT : 0u;
-    auto issue = [&](uint32_t it, uint32_t (&out)[NJ]) {
+    auto issue = [&](uint32_t it, uint4 (&out)[NJ]) {
         const uint32_t tile = t_begin + it / IPT, r0 = (it % IPT) * iter_rows;
         const AnchorDesc A = ad[tile_contig[tile]];  // (uniform: scalar loads)
         const uint32_t ts = (tile - A.tile0) * PROBE_TILE;
-        const uint32_t rows_left = A.nkmers - ts, npos = min((uint32_t)PROBE_TILE, rows_left);
-        const uint8_t *g = out1 + A.out_off + (uint64_t)ts * nbytes;
-        // branch-free: every lane always loads 4 bytes from a clamped, valid address (a predicated load per
-        // row makes the compiler wait for each load in turn); a short last word that would read past the
-        // contig's rows is fetched from 1..3 bytes earlier and shifted down
-        const uint32_t lim = max(min(rows_left, 2u * (uint32_t)PROBE_TILE) * nbytes, 4u) - 4u;  // (contig regions are 16-byte padded)
+        const uint32_t npos = min((uint32_t)PROBE_TILE, A.nkmers - ts);
+        const uint8_t *g = out1 + A.out_off + (uint64_t)ts * nbytes + 16u * c;
+        // branch-free: every lane always loads 16 bytes from a valid row (a predicated load per row makes
+        // the compiler wait for each load in turn); a short last chunk reads into the next row — or, at the
+        // very end, into the 16 bytes of slack every row buffer carries
 #pragma unroll
         for (uint32_t j = 0; j < NJ; ++j) {
             const uint32_t pl = r0 + j * RPS + rsub;
-            const uint32_t want = min(pl, npos - 1u) * nbytes + 4u * d;
-            const uint32_t o = min(want, lim);
-            out[j] = reinterpret_cast<const U32 *>(g + o)->v;  // raw: shifted / masked when it is consumed
+            const uint8_t *q = g + min(pl, npos - 1u) * nbytes;
+            if (EXACT) out[j] = *reinterpret_cast<const uint4 *>(q);
+            else {
+                const U128 t = *reinterpret_cast<const U128 *>(q);
+                out[j] = make_uint4(t.x, t.y, t.z, t.w);
+            }
         }
     };
-    uint32_t v[NJ], vn[NJ];
+    uint4 v[NJ], vn[NJ];
     if (nit) issue(0, v);
     // per-tile state (block-uniform), set when an iteration starts a tile
     uint32_t tile_start = 0, npos = 0, binlen = 1, bin0 = 0, bin0_start = 0, binv = 0, rel_base = 0;
     bool big = false, windowed = false;
-    for (uint32_t it = 0; it < nit; ++it) {
+    for (uint32_t it = 0; it <= nit; ++it) {  // (one more round: the last contig's column sums, flushed at ONE site)
+        const bool fin = it == nit;
         if (it + 1 < nit) issue(it + 1, vn);
-        const uint32_t tile = t_begin + it / IPT, r0 = (it % IPT) * iter_rows;
+        const uint32_t tile = t_begin + it / IPT, r0 = fin ? 0u : (it % IPT) * iter_rows;
         if (r0 == 0) {
-            const uint32_t c = tile_contig[tile];
-            if (c != cur_c) {
+            const uint32_t cg = fin ? ~0u : tile_contig[tile];
+            if (cg != cur_c) {
                 if (want_cs && cur_c != ~0u) flush_colsums(cur_c);
-                a = ad[c];
-                cur_c = c;
+                if (!fin) a = ad[cg];
+                cur_c = cg;
             }
+            if (fin) break;
             tile_start = (tile - a.tile0) * PROBE_TILE;
             npos = min((uint32_t)PROBE_TILE, a.nkmers - tile_start);
             binlen = a.binlen;
@@ -1551,43 +1604,58 @@ __global__ __launch_bounds__(EPI_THREADS) void k_epilogue_words(uint32_t N, cons
         }
         if (r0 < npos) {  // (block-uniform)
             uint32_t *hrow = hist + rel_base * (N + 1);
-            const uint32_t lim = max(min(a.nkmers - tile_start, 2u * (uint32_t)PROBE_TILE) * nbytes, 4u) - 4u;  // as in issue()
-
+            const bool full = EXACT && C_T && (64 % (C_T ? C_T : 1) == 0) && r0 + iter_rows <= npos;  // (block-uniform) no row to mask
 #pragma unroll
             for (uint32_t j = 0; j < NJ; ++j) {
                 const uint32_t pl = r0 + j * RPS + rsub;
-                const bool on = lane_on && pl < npos;
-                const uint32_t want = min(pl, npos - 1u) * nbytes + 4u * d;
-                v[j] = on ? (v[j] >> (8u * (want - min(want, lim)))) & wmask : 0u;
-                const uint32_t tot = row_popc(__popc(v[j]));
+                const bool on = full || (lane_on && pl < npos);
+                if (!full) {
+                    const uint32_t keep = on ? 0xFFFFFFFFu : 0u;
+                    v[j].x &= EXACT ? keep : keep & wm[0];
+                    v[j].y &= EXACT ? keep : keep & wm[1];
+                    v[j].z &= EXACT ? keep : keep & wm[2];
+                    v[j].w &= EXACT ? keep : keep & wm[3];
+                }
+                const uint32_t tot = row_popc(__popc(v[j].x) + __popc(v[j].y) + __popc(v[j].z) + __popc(v[j].w));
                 const uint32_t pos = tile_start + pl;
                 if (windowed) {
-                    if (on && d == 0) {
+                    if (on && c == 0) {
                         const uint32_t dpos = pos - bin0_start;
                         const uint32_t rel = big ? (dpos >= binlen ? 1u : 0u) : __umulhi(dpos, binv);
                         atomicAdd(&hrow[rel * (N + 1) + min(tot, N)], 1u);
                     }
                 } else {
-                    hist_position(on && d == 0, pos, tot, N, binlen, bin0, bin0_start, rel_base, hist, bins, a.bin_off, lane);
+                    hist_position(on && c == 0, pos, tot, N, binlen, bin0, bin0_start, rel_base, hist, bins, a.bin_off, lane);
                 }
-                if (want100 && on && pos % 100u == 0) {  // 1-in-100 rows: every lane copies its word
-                    uint8_t *o = out100 + a.out100_off + (uint64_t)(pos / 100u) * nbytes + 4u * d;
-                    if (wbytes == 4) reinterpret_cast<U32 *>(o)->v = v[j];
-                    else
-                        for (uint32_t bb = 0; bb < wbytes; ++bb) o[bb] = (uint8_t)(v[j] >> (8 * bb));
+                if (want100 && on && pos % 100u == 0) {  // 1-in-100 rows: every lane copies its chunk
+                    uint8_t *o = out100 + a.out100_off + (uint64_t)(pos / 100u) * nbytes + 16u * c;
+                    if (EXACT) *reinterpret_cast<uint4 *>(o) = v[j];
+                    else {
+                        const uint32_t xw[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+#pragma unroll
+                        for (uint32_t w = 0; w < 4; ++w) {
+                            if (vb >= 4u * w + 4u) reinterpret_cast<U32 *>(o + 4u * w)->v = xw[w];
+                            else if (vb > 4u * w)
+                                for (uint32_t bb = 0; bb < vb - 4u * w; ++bb) o[4u * w + bb] = (uint8_t)(xw[w] >> (8 * bb));
+                        }
+                    }
                 }
             }
             if (want_cs) {  // rows beyond npos are zero: adding them is harmless
-                vadd4(v[0], v[1], v[2], v[3]);
-                vadd4(v[4], v[5], v[6], v[7]);
-                vrows += 8;
-                if (vrows >= 8) vflush();  // (the 4 planes count to 15)
+                vadd4(vp[0], v[0].x, v[1].x, v[2].x, v[3].x);
+                vadd4(vp[1], v[0].y, v[1].y, v[2].y, v[3].y);
+                vadd4(vp[2], v[0].z, v[1].z, v[2].z, v[3].z);
+                vadd4(vp[3], v[0].w, v[1].w, v[2].w, v[3].w);
+                vrows += 4;
+                if (vrows == 12) {  // (the 4 planes count to 15)
+                    vflush();
+                    if (brounds == 21) bflush();  // 21 x 12 rows: the byte counters are about to fill
+                }
             }
         }
 #pragma unroll
         for (uint32_t j = 0; j < NJ; ++j) v[j] = vn[j];
     }
-    if (want_cs && cur_c != ~0u) flush_colsums(cur_c);
     __syncthreads();
     if (cur_row0 != ~0ull) flush_hist(N, hist, bins, cur_row0, tid);
 }
@@ -1932,21 +2000,20 @@ hipError_t launch_rows_epilogue(hipStream_t st, uint32_t ngenomes, const AnchorD
         hipLaunchKernelGGL(kern, dim3(grid), dim3(EPI_THREADS), lds, st, ngenomes, ad, tile_contig, ntiles, out1, out100, bins,
                            colsums, flags);
     }
-    else {  // word-parallel: one launch, every row read once
-        const uint32_t W = (nbytes + 3) / 4;
-        if (W > 64) return hipErrorInvalidValue;
-        const size_t lds_w = (((EPI_MAXB * (ngenomes + 1) + 3) & ~3u) + 32u * W) * 4 + 16;
-        auto kern = k_epilogue_words<0>;  // (compile-time W: the lanes-per-row shuffles and index arithmetic unroll; 2x at W=5)
-        switch (W) {
-            case 3: kern = k_epilogue_words<3>; break;
-            case 4: kern = k_epilogue_words<4>; break;
-            case 5: kern = k_epilogue_words<5>; break;
-            case 6: kern = k_epilogue_words<6>; break;
-            case 7: kern = k_epilogue_words<7>; break;
-            case 8: kern = k_epilogue_words<8>; break;
+    else {  // chunk-parallel: one launch, every row read once
+        const uint32_t C = (nbytes + 15) / 16;
+        if (C > 64) return hipErrorInvalidValue;
+        const size_t lds_c = (((EPI_MAXB * (ngenomes + 1) + 3) & ~3u) + ((64u / C + 15u) / 16u) * 128u * C) * 4 + 16;
+        const bool exact = nbytes == 16u * C;
+        auto kern = k_epilogue_chunks<0, false>;  // (compile-time C: the lanes-per-row shuffles and index arithmetic unroll)
+        switch (C) {
+            case 1: kern = exact ? k_epilogue_chunks<1, true> : k_epilogue_chunks<1, false>; break;
+            case 2: kern = exact ? k_epilogue_chunks<2, true> : k_epilogue_chunks<2, false>; break;
+            case 3: kern = k_epilogue_chunks<3, false>; break;
+            case 4: kern = exact ? k_epilogue_chunks<4, true> : k_epilogue_chunks<4, false>; break;
             default: break;
         }
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(EPI_THREADS), lds_w, st, ngenomes, ad, tile_contig, ntiles, out1, out100, bins,
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(EPI_THREADS), lds_c, st, ngenomes, ad, tile_contig, ntiles, out1, out100, bins,
                            colsums, flags);
     }
     return hipGetLastError();

@@ -1536,7 +1536,8 @@ static int result_create(pg_ctx *ctx, pg_table *t, int k, uint32_t N, const pg_s
     hipError_t e;
     if ((e = hipMalloc(reinterpret_cast<void **>(&r->d_ad), std::max<size_t>(1, r->ad.size()) * sizeof(AnchorDesc))) == hipSuccess &&
         (e = hipMalloc(reinterpret_cast<void **>(&r->d_tile_contig), std::max<size_t>(1, tile_contig.size()) * 4)) == hipSuccess &&
-        (e = row_alloc(ctx, (flags & PG_ANCHOR_COLUMNS_ONLY) ? 16 : std::max<uint64_t>(16, o1), &r->d_out1, &r->out1_cap)) == hipSuccess &&
+        // (+ 16: k_epilogue_chunks reads whole 16-byte chunks, the last one of the last row may start at its last byte)
+        (e = row_alloc(ctx, (flags & PG_ANCHOR_COLUMNS_ONLY) ? 16 : std::max<uint64_t>(16, o1) + 16, &r->d_out1, &r->out1_cap)) == hipSuccess &&
         (e = hipMalloc(reinterpret_cast<void **>(&r->d_out100), std::max<uint64_t>(16, o100))) == hipSuccess &&
         (e = hipMalloc(reinterpret_cast<void **>(&r->d_bins), std::max<uint64_t>(1, bins) * (N + 1) * 4)) == hipSuccess &&
         (e = hipMalloc(reinterpret_cast<void **>(&r->d_colsums), std::max<size_t>(1, r->ad.size()) * N * 8)) == hipSuccess) {

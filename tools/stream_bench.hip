@@ -35,12 +35,48 @@ __global__ __launch_bounds__(128) void kR(const uint8_t *p, uint64_t range, uint
                 const uint2 v = *reinterpret_cast<const uint2 *>(b + off + 8 * t + 1024 * j);
                 acc += __popc(v.x) + __popc(v.y);
             }
-        } else {
+        } else if (MODE == 2) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const uint4 v = *reinterpret_cast<const uint4 *>(b + off + 16 * t + 2048 * j);
                 acc += __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
             }
+        } else if (MODE == 3) {  // E: 4 B per lane, 512 B per workgroup and load, 8 loads (k_epilogue_words at 16-byte rows)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc += __popc(*reinterpret_cast<const uint32_t *>(b + off + 4 * t + 512 * j));
+        }
+    }
+    if (acc == 0x12345) out[0] = acc;
+}
+// deeper pipelines over the same ranges: NL loads of VB bytes per lane issued per step, DEPTH steps in flight
+template <int VB, int NL, int DEPTH>
+__global__ __launch_bounds__(128) void kP(const uint8_t *p, uint64_t range, uint32_t *out) {
+    const uint8_t *b = p + (uint64_t)blockIdx.x * range;
+    const int t = threadIdx.x;
+    constexpr uint64_t STEP = (uint64_t)128 * VB * NL;
+    constexpr int NW = VB / 4;
+    uint32_t buf[DEPTH][NL][NW];
+    uint32_t acc = 0;
+    auto issue = [&](uint64_t off, uint32_t (&o)[NL][NW]) {
+#pragma unroll
+        for (int j = 0; j < NL; ++j) {
+            const uint8_t *q = b + off + (uint64_t)VB * t + (uint64_t)128 * VB * j;
+            if (NW == 1) o[j][0] = *reinterpret_cast<const uint32_t *>(q);
+            else if (NW == 2) { const uint2 v = *reinterpret_cast<const uint2 *>(q); o[j][0] = v.x; o[j][1] = v.y; }
+            else { const uint4 v = *reinterpret_cast<const uint4 *>(q); o[j][0] = v.x; o[j][1] = v.y; o[j][2] = v.z; o[j][3] = v.w; }
+        }
+    };
+#pragma unroll
+    for (int d = 0; d < DEPTH - 1; ++d) issue(d * STEP, buf[d]);
+    for (uint64_t off = 0; off < range; off += STEP * DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            const uint64_t nxt = off + (uint64_t)(d + DEPTH - 1) * STEP;
+            issue(nxt < range ? nxt : 0, buf[(d + DEPTH - 1) % DEPTH]);
+#pragma unroll
+            for (int j = 0; j < NL; ++j)
+#pragma unroll
+                for (int w = 0; w < NW; ++w) acc += __popc(buf[d][j][w]);
         }
     }
     if (acc == 0x12345) out[0] = acc;
@@ -76,7 +112,16 @@ int main() {
     hipEventElapsedTime(&ms, a, b);                                                           \
     snprintf(nm, sizeof nm, "%s range %llu KB", LABEL, (unsigned long long)(range >> 10));    \
     report(nm, ms);
-            RUNR(0, "B 4x8B at stride 32") RUNR(1, "C 8B coalesced x4") RUNR(2, "D 16B coalesced x2")
+            RUNR(0, "B 4x8B at stride 32") RUNR(1, "C 8B coalesced x4") RUNR(2, "D 16B coalesced x2") RUNR(3, "E 4B coalesced x8")
+#define RUNP(VB, NL, DEPTH)                                                                   \
+    hipEventRecord(a);                                                                        \
+    hipLaunchKernelGGL((kP<VB, NL, DEPTH>), dim3(grid), dim3(128), 0, 0, d, range, o);        \
+    hipEventRecord(b);                                                                        \
+    hipEventSynchronize(b);                                                                   \
+    hipEventElapsedTime(&ms, a, b);                                                           \
+    snprintf(nm, sizeof nm, "P %d B x %d loads, %d steps ahead, %llu KB", VB, NL, DEPTH - 1, (unsigned long long)(range >> 10)); \
+    report(nm, ms);
+            RUNP(4, 8, 2) RUNP(4, 16, 2) RUNP(4, 8, 4) RUNP(8, 8, 2) RUNP(16, 2, 2) RUNP(16, 4, 2) RUNP(16, 8, 2) RUNP(16, 4, 4) RUNP(16, 2, 4)
         }
     }
     return 0;
