@@ -34,6 +34,9 @@
 // Bytes from HBM per position: 0.25 (sequence) + 128 x (lines missed in L2 per
 // position: 0.34 with one launch per genome, 0.095 co-scheduled) + row bytes written + re-read.
 #include "pg_kernels.h"
+#include <map>
+#include <mutex>
+#include <utility>
 #include <type_traits>
 
 #include <algorithm>
@@ -962,10 +965,11 @@ __global__ __launch_bounds__(EPI_THREADS) void k_epilogue(uint32_t N, const Anch
     __syncthreads();
     const bool want_cs = (flags & 1u) != 0;
     const bool want100 = (flags & 2u) == 0;  // bit 1: the low-resolution rows are taken by k_lowres (step != 100)
-    // contiguous tile ranges, cut in units of 4 tiles (the 16-rows-per-thread group path)
-    const uint32_t ngroups = (ntiles + 3) / 4;
-    const uint32_t t_begin = 4u * (uint32_t)((uint64_t)ngroups * blockIdx.x / gridDim.x);
-    const uint32_t t_end = min(ntiles, 4u * (uint32_t)((uint64_t)ngroups * (blockIdx.x + 1) / gridDim.x));
+    // contiguous tile ranges, cut in units of the group paths' 4 tiles (16 rows per thread; one-byte rows: 8 tiles, 32 rows)
+    constexpr uint32_t GT = MODE == 0 ? 8u : 4u;
+    const uint32_t ngroups = (ntiles + GT - 1) / GT;
+    const uint32_t t_begin = GT * (uint32_t)((uint64_t)ngroups * blockIdx.x / gridDim.x);
+    const uint32_t t_end = min(ntiles, GT * (uint32_t)((uint64_t)ngroups * (blockIdx.x + 1) / gridDim.x));
     uint64_t cur_row0 = ~0ull;  // bins row the accumulators currently stand for
     uint32_t cur_c = ~0u;
     AnchorDesc a;
@@ -973,10 +977,12 @@ __global__ __launch_bounds__(EPI_THREADS) void k_epilogue(uint32_t N, const Anch
     a.nkmers = a.binlen = a.tile0 = a.nbins = 0;
     const uint32_t p0 = tid * PT;
     // fast path (N <= 8) per-thread accumulators, reduced over the workgroup only when the bin
-    // changes / at the end: 9 popcount classes as 7-bit fields of one u64 (spilled to u32 counters
-    // every 31 tiles), 8 column counters
+    // changes / at the end: 9 popcount classes as 7-bit fields of one u64 (spilled to the u32 counters
+    // below every 31 tiles), 8 column counters
     unsigned long long hacc = 0;
-    uint32_t hc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    // ... and of the group path: thr[i] = rows seen with MORE than i bits set (the histogram classes are their
+    // differences), grows = rows seen
+    uint32_t thr[8] = {0, 0, 0, 0, 0, 0, 0, 0}, grows = 0;
     uint32_t cacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t since_spill = 0;
     uint32_t next_packed = 0;  // software prefetch of the next tile's rows
@@ -1052,20 +1058,37 @@ __global__ __launch_bounds__(EPI_THREADS) void k_epilogue(uint32_t N, const Anch
         if (++brounds == 21) wave_colsums();  // 21 x 12 rows: the byte counters are about to fill
     };
 
-    auto spill = [&]() {
+    auto spill = [&]() {  // the per-tile path's classes (7-bit fields of hacc) join the thresholds: thr[i] += rows of class > i
+        uint32_t run = 0;
 #pragma unroll
-        for (int v = 0; v < 9; ++v) hc[v] += (uint32_t)(hacc >> (7 * v)) & 127u;
+        for (int v = 8; v >= 1; --v) {
+            run += (uint32_t)(hacc >> (7 * v)) & 127u;
+            thr[v - 1] += run;
+        }
+        grows += run + ((uint32_t)hacc & 127u);
         hacc = 0;
         since_spill = 0;
     };
-    auto reduce_hist = [&]() {  // per-thread classes -> LDS histogram (bin-relative row 0)
+    auto reduce_hist = [&]() {  // per-thread thresholds -> classes -> LDS histogram (bin-relative row 0)
         if constexpr (MODE != 0) return;
         spill();
+        uint32_t hc[9];
+        hc[0] = grows - thr[0];
 #pragma unroll
-        for (int v = 0; v < 9; ++v) {
+        for (int v = 1; v < 8; ++v) hc[v] = thr[v - 1] - thr[v];
+        hc[8] = thr[7];
+#pragma unroll
+        for (int v = 8; v >= 1; --v)  // (junk bits beyond ngenomes count as class N, as on the per-tile path)
+            if ((uint32_t)v > N) {
+                hc[v - 1] += hc[v];
+                hc[v] = 0;
+            }
+        grows = 0;
+#pragma unroll
+        for (int v = 0; v < 8; ++v) thr[v] = 0;
+#pragma unroll
+        for (int v = 0; v < 9; ++v)
             if ((uint32_t)v <= N && hc[v]) atomicAdd(&hist[v], hc[v]);
-            hc[v] = 0;
-        }
     };
 
     // column sums are kept per contig (colsums[contig][N]): register / LDS accumulators are emptied
@@ -1093,7 +1116,7 @@ __global__ __launch_bounds__(EPI_THREADS) void k_epilogue(uint32_t N, const Anch
         __syncthreads();
     };
 
-    uint4 gq_next = make_uint4(0, 0, 0, 0);  // group path: prefetched rows of the next group
+    uint4 gq_next = make_uint4(0, 0, 0, 0), gq_next2 = make_uint4(0, 0, 0, 0);  // group path: prefetched rows of the next group
     bool gq_valid = false;
     for (uint32_t tile = t_begin; tile < t_end; ++tile) {
         const uint32_t c = tile_contig[tile];
@@ -1102,12 +1125,16 @@ __global__ __launch_bounds__(EPI_THREADS) void k_epilogue(uint32_t N, const Anch
             a = ad[c];
             cur_c = c;
         }
-        // ---- group path (N <= 8): 4 full tiles of one contig inside one bin = 16 one-byte rows
-        // per thread in one 16-byte load; same accumulators as the per-tile fast path ----
+        // ---- group path (N <= 8): 8 full tiles of one contig inside one bin = 32 one-byte rows per thread in two
+        // 16-byte loads, worked on BIT-SLICED: a three-stage butterfly between the 8 words regroups their 256 bits so
+        // that word g holds bit g of all 32 rows (same row, same bit position in every word: 4 instructions per word
+        // pair and stage); an 8-input sorting network on those planes (19 compare-exchanges = AND / OR pairs) turns
+        // them into thresholds "row has more than i bits"; popcounts of the planes are the column sums, popcounts of
+        // the thresholds the cumulative histogram.  3.2 instructions per row, where one-hot adds per row took 13 ----
         if constexpr (MODE == 0) {
             const uint32_t ts = (tile - a.tile0) * PROBE_TILE;
-            const uint32_t span = 4u * PROBE_TILE;
-            const bool grp_ok = tile + 3 < t_end && tile_contig[tile + 3] == c &&
+            const uint32_t span = 8u * PROBE_TILE;
+            const bool grp_ok = tile + 7 < t_end && tile_contig[tile + 7] == c &&
                                 ts + span <= a.nkmers && a.binlen >= span &&
                                 (ts / a.binlen) == ((ts + span - 1) / a.binlen);
             if (grp_ok) {
@@ -1121,30 +1148,59 @@ __global__ __launch_bounds__(EPI_THREADS) void k_epilogue(uint32_t N, const Anch
                     }
                     cur_row0 = row0g;
                 }
-                const uint8_t *gg = out1 + a.out_off + (uint64_t)ts;
-                const uint4 q = gq_valid ? gq_next : *reinterpret_cast<const uint4 *>(gg + 16u * tid);
+                const uint4 *gg = reinterpret_cast<const uint4 *>(out1 + a.out_off + (uint64_t)ts + 32u * tid);
+                const uint4 qa = gq_valid ? gq_next : gg[0];
+                const uint4 qb = gq_valid ? gq_next2 : gg[1];
                 // prefetch the next group when it is an equally regular one right behind
-                gq_valid = tile + 7 < t_end && tile_contig[tile + 7] == c && ts + 2u * span <= a.nkmers &&
+                gq_valid = tile + 15 < t_end && tile_contig[tile + 15] == c && ts + 2u * span <= a.nkmers &&
                            ((ts + span) / a.binlen) == ((ts + 2u * span - 1) / a.binlen);
-                if (gq_valid) gq_next = *reinterpret_cast<const uint4 *>(gg + span + 16u * tid);
-                const uint32_t wq[4] = {q.x, q.y, q.z, q.w};
-                if (since_spill + 4 > 31) spill();
-#pragma unroll
-                for (int wi = 0; wi < 4; ++wi) {
-                    if (want_cs) {
-#pragma unroll
-                        for (int gb = 0; gb < 8; ++gb) cacc[gb] += __popc(wq[wi] & (0x01010101u << gb));
-                    }
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) hacc += 1ull << (7 * min((uint32_t)__popc((wq[wi] >> (8 * j)) & 0xFFu), N));
+                if (gq_valid) {
+                    gq_next = gg[span / 16u];
+                    gq_next2 = gg[span / 16u + 1];
                 }
-                since_spill += 4;
-                const uint32_t pos0 = ts + 16u * tid;  // at most one multiple of 100 among 16 positions
+                uint32_t w[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
+                const uint32_t pos0 = ts + 32u * tid;  // at most one multiple of 100 among 32 positions
                 const uint32_t r100 = (pos0 + 99u) / 100u;
                 const uint32_t first = r100 * 100u - pos0;
-                if (want100 && first < 16u) out100[a.out100_off + r100] = (uint8_t)(wq[first >> 2] >> (8 * (first & 3)));
+                if (want100 && first < 32u) {
+                    uint32_t sel = w[0];
+#pragma unroll
+                    for (uint32_t i = 1; i < 8; ++i) sel = (first >> 2) == i ? w[i] : sel;
+                    out100[a.out100_off + r100] = (uint8_t)(sel >> (8 * (first & 3)));
+                }
+#pragma unroll
+                for (int kb = 0; kb < 3; ++kb) {
+                    const uint32_t m0 = kb == 0 ? 0x55555555u : kb == 1 ? 0x33333333u : 0x0F0F0F0Fu;
+                    const int sh = 1 << kb;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        if (i & sh) continue;
+                        const uint32_t x = w[i], y = w[i | sh];
+                        w[i] = (x & m0) | ((y << sh) & ~m0);       // the pair's bits with bit kb of g clear
+                        w[i | sh] = ((x >> sh) & m0) | (y & ~m0);  // ... and set
+                    }
+                }
+                if (want_cs) {
+#pragma unroll
+                    for (int gb = 0; gb < 8; ++gb) cacc[gb] += __popc(w[gb]);
+                }
+                auto cx = [&](int i, int j) __attribute__((always_inline)) {
+                    const uint32_t lo = w[i] & w[j], hi = w[i] | w[j];
+                    w[i] = lo;
+                    w[j] = hi;
+                };
+                cx(0, 1), cx(2, 3), cx(4, 5), cx(6, 7);
+                cx(0, 2), cx(1, 3), cx(4, 6), cx(5, 7);
+                cx(1, 2), cx(5, 6), cx(0, 4), cx(3, 7);
+                cx(1, 5), cx(2, 6);
+                cx(1, 4), cx(3, 6);
+                cx(2, 4), cx(3, 5);
+                cx(3, 4);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) thr[i] += __popc(w[7 - i]);  // ascending order: w[7] = any bit set
+                grows += 32;
                 next_valid = false;
-                tile += 3;
+                tile += 7;
                 continue;
             }
             gq_valid = false;
@@ -1984,6 +2040,23 @@ hipError_t launch_rows_epilogue(hipStream_t st, uint32_t ngenomes, const AnchorD
     uint32_t grid = (ntiles + PG_EPI_MIN_TILES - 1) / PG_EPI_MIN_TILES;
     grid = std::max(grid, std::min(1024u, ntiles / 16u));
     grid = grid < 1 ? 1 : (grid > maxg ? maxg : grid);
+    // persistent workgroups: no more of them than the device holds at once (a second, partly filled round of
+    // workgroups would leave CUs idle at the end: 8192 waves over 5120 slots cost the one-byte kernel 20 %)
+    auto fit = [&](const void *kern, size_t lds_bytes) {
+        static std::mutex mu;
+        static std::map<std::pair<const void *, size_t>, uint32_t> caps;  // (the query is a driver call: once per kernel and LDS size)
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = caps.find({kern, lds_bytes});
+        if (it == caps.end()) {
+            int per_cu = 0, dev = 0, cus = 0;
+            uint32_t cap = ~0u;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, EPI_THREADS, lds_bytes) == hipSuccess && per_cu >= 1 &&
+                hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess)
+                cap = (uint32_t)per_cu * (uint32_t)cus;
+            it = caps.emplace(std::make_pair(kern, lds_bytes), cap).first;
+        }
+        if (grid > it->second) grid = it->second;
+    };
     const uint32_t nbytes = (ngenomes + 7) / 8;
     if (nbytes <= 8) {
         auto kern = k_epilogue<0, 1>;
@@ -1997,6 +2070,7 @@ hipError_t launch_rows_epilogue(hipStream_t st, uint32_t ngenomes, const AnchorD
             case 8: kern = k_epilogue<1, 8>; break;
             default: break;
         }
+        fit(reinterpret_cast<const void *>(kern), lds);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(EPI_THREADS), lds, st, ngenomes, ad, tile_contig, ntiles, out1, out100, bins,
                            colsums, flags);
     }
@@ -2013,6 +2087,7 @@ hipError_t launch_rows_epilogue(hipStream_t st, uint32_t ngenomes, const AnchorD
             case 4: kern = exact ? k_epilogue_chunks<4, true> : k_epilogue_chunks<4, false>; break;
             default: break;
         }
+        fit(reinterpret_cast<const void *>(kern), lds_c);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(EPI_THREADS), lds_c, st, ngenomes, ad, tile_contig, ntiles, out1, out100, bins,
                            colsums, flags);
     }
