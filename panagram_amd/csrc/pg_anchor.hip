@@ -44,6 +44,21 @@
 namespace pg {
 
 constexpr int PROBE_SEQW = ((PROBE_TILE + 31) / 32 + 6 + 3) & ~3;  // staged 32-base words per tile
+// The tile's packed bases are staged TWICE: as they are (sw) and reverse-complemented (rw: base j of rw = complement of
+// base 32 PROBE_SEQW - 1 - j of sw).  The reverse complement of the k-mer at base p is then the k bases of rw from
+// 32 PROBE_SEQW - p - k on — the same three LDS reads and two funnel shifts as the forward window, instead of a
+// 64-bit bit reversal, pair swap, complement and shift per position (14 instructions).
+#ifndef PG_RC_LDS
+#define PG_RC_LDS 1
+#endif
+constexpr uint32_t PROBE_SEQ_BASES = 32u * PROBE_SEQW;
+__device__ __forceinline__ uint64_t revcomp_window(const uint64_t *rw, uint64_t X, uint32_t p, int k, uint64_t kmask) {
+#if PG_RC_LDS
+    return extract_bases32(reinterpret_cast<const uint32_t *>(rw), PROBE_SEQ_BASES - p - (uint32_t)k) & kmask;
+#else
+    return revcomp_le(X, k);
+#endif
+}
 
 // scan the 8 slots of a line staged in LDS.  Lines fill front to back without holes (an insert
 // claims the first EMPTY slot and slots never revert), so "full" == last slot used.
@@ -344,7 +359,7 @@ __device__ __forceinline__ void cols_or_position(unsigned long long *cols, uint3
 // like the main batches (neighbouring entries belong to the same group and share their next
 // line); entries that overflow again are compacted in place for the next level.
 template <bool TWO, int ROWMODE, int SLOTS, int MAXRUN, bool WIDE>
-__device__ __forceinline__ void drain_queue(const SubTable &st, uint32_t qn, const uint64_t *sw, uint32_t *q_line,
+__device__ __forceinline__ void drain_queue(const SubTable &st, uint32_t qn, const uint64_t *sw, const uint64_t *rw, uint32_t *q_line,
                                             uint32_t *q_step, uint16_t *q_pl, uint32_t *lines_w, uint4 *buf,
                                             uint8_t *tile_rows, uint32_t nbytes, const RowCols rc, int lane) {
     // a queue entry is (position in the tile, next line to try, step of its sequence): the key is
@@ -380,7 +395,9 @@ __device__ __forceinline__ void drain_queue(const SubTable &st, uint32_t qn, con
             const uint32_t ec = act ? e : qn - 1;
             const uint32_t line = q_line[ec], step = q_step[ec];
             const uint32_t pl = q_pl[ec];
-            const uint64_t key = canonical_from_le(extract_bases32(reinterpret_cast<const uint32_t *>(sw), pl), k);
+            const uint64_t kmask = kmer_mask(k);
+            const uint64_t X = extract_bases32(reinterpret_cast<const uint32_t *>(sw), pl) & kmask;
+            const uint64_t key = canonical_from_xb(X, revcomp_window(rw, X, pl, k, kmask), k);
             const uint32_t prev_line = lane_up1(line);
             const bool leader = act && (lane == 0 || line != prev_line);
             const unsigned long long lmask = __ballot(leader);
@@ -453,6 +470,7 @@ __global__ __launch_bounds__(64) void k_probe(const SubTable st, const uint64_t 
                                               const uint32_t *__restrict__ sched, uint32_t tile_base,
                                               uint8_t *__restrict__ out1, uint32_t nbytes, const RowCols rc) {
     __shared__ uint64_t sw[PROBE_SEQW];
+    __shared__ uint64_t rw[PROBE_SEQW + 1];
     __shared__ uint32_t nw[PROBE_SEQW];
     // A staged line occupies 16*SLOTS + 16 bytes of LDS: the pad keeps the lanes' ds_read_b128 of
     // "their" lines off a common bank group (a power-of-two stride would be a 32-way conflict)
@@ -480,9 +498,12 @@ __global__ __launch_bounds__(64) void k_probe(const SubTable st, const uint64_t 
     // packed bases of the tile (+ halo), the only sequence traffic: 0.25 B per position
     for (int i = lane; i < PROBE_SEQW; i += 64) {
         const uint64_t wi = (uint64_t)(tile_start >> 5) + i;
-        sw[i] = wi < s.nwords ? seqw[s.seq_off + wi] : 0ull;
+        const uint64_t wv = wi < s.nwords ? seqw[s.seq_off + wi] : 0ull;
+        sw[i] = wv;
+        rw[PROBE_SEQW - 1 - i] = pair_reverse64(~wv);
         nw[i] = (hasn && wi < s.nwords) ? nmw[s.seq_off + wi] : 0u;
     }
+    if (lane == 0) rw[PROBE_SEQW] = 0;  // (a window's three dwords may reach one word past the end)
     __syncthreads();  // single wave: compiles to a wave-level wait, not an s_barrier
 
     const uint64_t kmask = kmer_mask(k);
@@ -517,7 +538,7 @@ __global__ __launch_bounds__(64) void k_probe(const SubTable st, const uint64_t 
             inrange[u] = pl[u] >= (int32_t)b && pl[u] < (int32_t)npos;
             const uint32_t pq = (uint32_t)max(pl[u], 0);
             const uint64_t X = extract_bases32(reinterpret_cast<const uint32_t *>(sw), pq) & kmask;
-            const uint64_t B = revcomp_le(X, k);
+            const uint64_t B = revcomp_window(rw, X, pq, k, kmask);
             key[u] = canonical_from_xb(X, B, k);
             act[u] = inrange[u];
             if (hasn) act[u] = act[u] && (extract_nmask(nw, pq, k) == 0);
@@ -656,7 +677,7 @@ __global__ __launch_bounds__(64) void k_probe(const SubTable st, const uint64_t 
         }
     }
 
-    drain_queue<TWO, ROWMODE, SLOTS, PROBE_MAXRUN, WIDE>(st, qn, sw, q_line, q_step, q_pl, lines_w[0], buf[0], tile_rows, nbytes, rc, lane);
+    drain_queue<TWO, ROWMODE, SLOTS, PROBE_MAXRUN, WIDE>(st, qn, sw, rw, q_line, q_step, q_pl, lines_w[0], buf[0], tile_rows, nbytes, rc, lane);
     if constexpr (ROWMODE == 3) {
         // the tile's columns: 8 slots x `width` (= nbytes) genomes, slot-major — what k_cols_extract would have written
         __syncthreads();
@@ -691,6 +712,7 @@ __global__ __launch_bounds__(64) void k_insert_tile(const SubTable st, int w, ui
     constexpr int LDS_LINE_U4 = SLOTS + 1;
     constexpr int STAGE_ITERS = (PROBE_MAXRUN * SLOTS + 63) / 64;
     __shared__ uint64_t sw[PROBE_SEQW];
+    __shared__ uint64_t rw[PROBE_SEQW + 1];
     __shared__ uint32_t nw[PROBE_SEQW];
     __shared__ uint32_t lines_w[PROBE_MAXRUN];
     __shared__ uint4 buf[((STAGE_ITERS * 64 + SLOTS - 1) / SLOTS) * LDS_LINE_U4];
@@ -717,9 +739,12 @@ __global__ __launch_bounds__(64) void k_insert_tile(const SubTable st, int w, ui
     const bool hasn = has_n[c] != 0;
     for (int i = lane; i < PROBE_SEQW; i += 64) {
         const uint64_t wi = (uint64_t)(tile_start >> 5) + i;
-        sw[i] = wi < s.nwords ? seqw[s.seq_off + wi] : 0ull;
+        const uint64_t wv = wi < s.nwords ? seqw[s.seq_off + wi] : 0ull;
+        sw[i] = wv;
+        rw[PROBE_SEQW - 1 - i] = pair_reverse64(~wv);
         nw[i] = (hasn && wi < s.nwords) ? nmw[s.seq_off + wi] : 0u;
     }
+    if (lane == 0) rw[PROBE_SEQW] = 0;  // (a window's three dwords may reach one word past the end)
     __syncthreads();
     const uint64_t kmask = kmer_mask(k);
     constexpr int HALO = W_C ? W_C - 1 : 0;
@@ -751,7 +776,7 @@ __global__ __launch_bounds__(64) void k_insert_tile(const SubTable st, int w, ui
         const bool inrange = pl >= (int32_t)b && pl < (int32_t)npos;
         const uint32_t pq = (uint32_t)max(pl, 0);
         const uint64_t X = extract_bases32(reinterpret_cast<const uint32_t *>(sw), pq) & kmask;
-        const uint64_t B = revcomp_le(X, k);
+        const uint64_t B = revcomp_window(rw, X, pq, k, kmask);
         const uint64_t key = canonical_from_xb(X, B, k);
         bool act = inrange;
         if (hasn) act = act && (extract_nmask(nw, pq, k) == 0);
