@@ -611,11 +611,21 @@ def main():
     ctx.trim()
 
     # ---- further legs, outside the timed region of `value` ----
+    # (the line so far goes to stderr first: should a further leg die, the measured value is still on record; stdout
+    # carries the ONE complete line at the end)
+    if rank == 0:
+        print("[bench] timed region done, before the further legs: " + json.dumps(out), file=sys.stderr, flush=True)
     if not args.no_sharded_leg and (world > 1 or default_shape):
         # the one mode with a data-path collective (BASELINE.json configs[4]); with one rank: the pipeline's own cost
-        out["config"]["genome_sharded_leg"] = sharded_leg(ctx, dev, args, rank, world, dist, 3, 1, args.blocks)
+        try:
+            out["config"]["genome_sharded_leg"] = sharded_leg(ctx, dev, args, rank, world, dist, 3, 1, args.blocks)
+        except Exception as e:  # a failed extra leg must not take the measured line with it
+            out["config"]["genome_sharded_leg"] = {"error": f"{type(e).__name__}: {e}"}
     if world == 1 and default_shape and not args.no_other_shapes:
-        out["config"]["other_shapes"] = [north_star_leg(ctx, dev, args)]
+        try:
+            out["config"]["other_shapes"] = [north_star_leg(ctx, dev, args)]
+        except Exception as e:
+            out["config"]["other_shapes"] = [{"error": f"{type(e).__name__}: {e}"}]
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
