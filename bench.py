@@ -435,13 +435,22 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback)")
+    # (test knobs, for checking the N > 1 code path on a ONE-GPU box: all ranks on device 0 and a gloo process group —
+    # RCCL refuses two ranks on one device.  The numbers of such a run mean nothing.)
+    one_device = os.environ.get("PG_BENCH_ONE_DEVICE", "") not in ("", "0")
+    backend = os.environ.get("PG_BENCH_BACKEND", "nccl")
+    if one_device:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from panagram_amd import engine
     ctx = engine.Context(local)

@@ -306,3 +306,42 @@ def test_probe_emits_columns_directly(ctx, block):
         cols.run_range(0, 1)
     for x in (rows, cols, merged, *sets, tbl):
         x.close()
+
+
+# ---------------------------------------------------------------------------
+# TWO processes on the one GPU: the product's own multi-rank path — Index.run() under RANK / WORLD_SIZE, the real
+# engine and kernels in both processes, the chunk pipeline with its side stream, a real collective between them.
+# RCCL refuses two ranks on one device, so the process group is gloo (it stages the CUDA tensors through the host);
+# everything else is what runs under torchrun on a multi-GPU node.
+# ---------------------------------------------------------------------------
+def _two_rank_worker(rank, world, port, samples, out, k, anchors, shard, nblocks, chunk):
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from panagram_amd import distributed as pdist
+        from panagram_amd import index as pidx
+        pdist.CHUNK_POSITIONS = chunk
+        idx = pidx.Index(samples, prefix=out, k=k, anchor_genomes=anchors, shard=shard, genome_blocks=nblocks)
+        assert (idx.rank, idx.world) == (rank, world)
+        idx.run()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name,shard,nblocks,chunk", [("n8_k21", "genome", 2, 1500), ("n8_k21", "genome", 8, 1 << 27),
+                                                      ("n9_k21", "genome", 4, 700), ("n9_k21", "replicated", 0, 1 << 27)])
+def test_two_processes_on_one_gpu(name, shard, nblocks, chunk, tmp_path):
+    """("n8_k21", genome, 2): one pass, each rank one block of 4 genomes; (…, 8): four passes of one-genome blocks
+    (config 5's layout; columns straight from the probe); ("n9_k21", 4): blocks of 3, 3, 3 on two ranks — the second
+    pass has an idle rank; replicated: the anchor genomes dealt to the two ranks, no collective."""
+    import torch.multiprocessing as mp
+    import os
+    fx = H.load_case(name)
+    s = _write_case(tmp_path, fx)
+    out = tmp_path / "idx"
+    port = 29600 + (os.getpid() % 2000)
+    mp.spawn(_two_rank_worker, args=(2, port, str(s), str(out), int(fx["k"]), [f"g{g}" for g in fx["anchors"]], shard, nblocks, chunk),
+             nprocs=2, join=True)
+    _check_tree(out, fx)

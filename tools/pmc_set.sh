@@ -4,7 +4,7 @@ CNT=$1; shift
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 OUT=/tmp/pmcset; rm -rf $OUT; mkdir -p $OUT
-timeout ${PMC_TIMEOUT:-150} rocprofv3 --kernel-include-regex "k_probe|k_epilogue" --pmc $CNT --output-format csv -d $OUT -o pmc -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-compare --no-other-shapes --no-sharded-leg "$@" > /dev/null 2> $OUT/err || tail -5 $OUT/err
+timeout ${PMC_TIMEOUT:-150} rocprofv3 --kernel-include-regex "k_probe|k_epilogue|k_insert_tile" --pmc $CNT --output-format csv -d $OUT -o pmc -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-compare --no-other-shapes --no-sharded-leg "$@" > /dev/null 2> $OUT/err || tail -5 $OUT/err
 python - <<PY
 import pandas as pd, glob
 pd.set_option("display.width", 250); pd.set_option("display.max_columns", 30)
