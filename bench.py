@@ -267,9 +267,10 @@ def roofline_block(pos_per_launch, avg_launch_s, avg_epi_s, G, value_per_gpu, co
         "traffic": None, "hbm_counter_frac": None, "valu_frac": None,
     }
     if counters is not None:
-        traffic = counters["hbm_bytes_per_launch"]
-        out["traffic"] = traffic
-        out["hbm_counter_frac"] = traffic / avg_launch_s / HBM_PEAK
+        if counters.get("hbm_bytes_per_launch"):
+            traffic = counters["hbm_bytes_per_launch"]
+            out["traffic"] = traffic
+            out["hbm_counter_frac"] = traffic / avg_launch_s / HBM_PEAK
         if counters.get("SQ_INSTS_VALU"):
             out["valu_wave_instructions_per_launch"] = counters["SQ_INSTS_VALU"]
             out["valu_wave_instructions_per_position"] = counters["SQ_INSTS_VALU"] / pos_per_launch
@@ -514,7 +515,11 @@ def main():
         assert int(cs[0]) == pg.pos_per_genome[0], "anchor genome 0 must contain every one of its k-mers"
 
     value = world * pos_per_step * args.steps / elapsed
-    counters = load_counters(pos_per_launch, k, G) if (world == 1 and not args.per_genome_launches) else None
+    counters = load_counters(pos_per_launch, k, G) if not args.per_genome_launches else None
+    if counters is not None and groups > 1:
+        # a rank of a multi-GPU run launches the profiled kernel over as many positions, against an N x larger table:
+        # the instruction count per position carries over, the HBM traffic of the one-GPU profile does not
+        counters = {"SQ_INSTS_VALU": counters.get("SQ_INSTS_VALU"), "profiled_on": "one GPU (profiles/traffic.json)"}
     shape = (G, round(args.genome_mb), k)
     baseline_config = {(8, 100, 21): "BASELINE.json configs[1]", (27, 135, 21): "BASELINE.json configs[2] at full size",
                        (64, 200, 31): "BASELINE.json configs[3] at full size, all 64 genomes anchored",

@@ -580,6 +580,47 @@ def test_kmer_sketch_registers_equal_oracle(ctx, k):
     tbl.close()
 
 
+@pytest.mark.parametrize("n,k,lens", [(1, 21, [700_123]), (5, 21, [520_000, 9_000]), (8, 31, [900_077, 450_321])])
+def test_one_byte_rows_long_contigs_against_oracle(ctx, n, k, lens):
+    """contigs long enough for the bit-sliced statistics path of one-byte rows (32 rows per thread over 8 whole tiles
+    inside one bin) next to its per-tile neighbours: bins of nkmers / 100 = 4.5-12.5 k positions, so groups of 4096
+    rows alternate with tiles that straddle a bin boundary; N runs and lower case included.  Rows, bitmap.100, bins and
+    per-contig column sums against the oracle."""
+    from panagram_amd import engine
+    rng = np.random.default_rng(n * 1000 + k)
+    gen = po.synth_genomes(n, lens, 0.01, 31 + n)
+    genomes = [[bytearray(po.codes_to_ascii(c)) for c in g] for g in gen]
+    for g in range(n):
+        for c in genomes[g]:
+            for _ in range(3):
+                p, run = int(rng.integers(0, len(c) - 5000)), int(rng.integers(1, 3000))
+                c[p:p + run] = b"N" * run
+            q = int(rng.integers(0, len(c) - 500))
+            c[q:q + 400] = bytes(c[q:q + 400]).lower()
+    genomes = [[bytes(c) for c in g] for g in genomes]
+    dbs = po.build_bitvec_dbs(genomes, k)
+    tbl = engine.PanTable(ctx, k, n)
+    for g in range(n):
+        ss = engine.SeqSet.from_host(ctx, genomes[g])
+        tbl.insert_seqset(g, ss)
+        ss.close()
+    for g in {0, n - 1}:
+        ss = engine.SeqSet.from_host(ctx, genomes[g])
+        res = engine.AnchorResult(tbl, ss, colsums=True)
+        res.run()
+        ccs = res.contig_colsums().astype(np.int64)
+        for ci, seq in enumerate(genomes[g]):
+            rows, rows100, bins, info = res.download(ci)
+            o_rows, o_rows100, o_bins, _, o_cs = po.anchor_contig(dbs, seq, k, n)
+            assert np.array_equal(rows, o_rows)
+            assert np.array_equal(rows100, o_rows100)
+            assert np.array_equal(bins.astype(np.int64), o_bins), np.argwhere(bins.astype(np.int64) != o_bins)[:5]
+            assert np.array_equal(ccs[ci], o_cs)
+        res.close()
+        ss.close()
+    tbl.close()
+
+
 _FUZZ_N = [2, 8, 9, 16, 17, 24, 25, 32, 33, 40, 63, 64, 65, 72, 96, 97, 127, 128, 129, 160, 193, 256, 257, 300]
 
 
