@@ -38,7 +38,10 @@ def kmc_kmer_length(pre) -> int:
     return int(k.value)
 
 
-COLUMNS_DIRECT = os.environ.get("PG_COLUMNS_DIRECT", "1") != "0"  # k_probe may emit bit columns itself (narrow block tables)
+# k_probe can emit a one-genome block's bit columns itself (ROWMODE 3: no row buffer at all).  Off by default: since the
+# probe's round-2 diet the rows + k_cols_extract_b1 route is the faster one (one GPU as rank 0 of 8, 8 x 10^8 positions:
+# 6.50 ms per step against 7.15, tools/ab_sharded.sh); PG_COLUMNS_DIRECT=1 turns it on where the row buffer's HBM matters.
+COLUMNS_DIRECT = os.environ.get("PG_COLUMNS_DIRECT", "0") not in ("", "0")
 
 
 def tile_positions() -> int:

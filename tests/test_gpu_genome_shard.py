@@ -135,9 +135,10 @@ def _check_tree(out, fx):
         assert np.array_equal(tp["count"].to_numpy(), ora["colsums"])
 
 
+@pytest.mark.parametrize("direct", [False, True])
 @pytest.mark.parametrize("name,nblocks,chunk", [("n8_k21", 8, 1500), ("n8_k21", 1, 1 << 27), ("n9_k21", 4, 700),
                                                 ("n65_k21", 4, 1 << 27), ("n40_k31", 3, 900), ("n2_k21", 2, 512)])
-def test_index_run_genome_sharded_on_one_gpu(name, nblocks, chunk, tmp_path, monkeypatch):
+def test_index_run_genome_sharded_on_one_gpu(name, nblocks, chunk, direct, tmp_path, monkeypatch):
     """Index.run() in the genome-sharded mode: one GPU works the genome blocks off as passes.  ("n8_k21", 8): one
     genome per block — config 5's layout; chunk: positions per exchanged chunk, small ones make every anchor
     several chunks (double-buffered pipeline) whose last ones are short."""
@@ -146,6 +147,10 @@ def test_index_run_genome_sharded_on_one_gpu(name, nblocks, chunk, tmp_path, mon
     fx = H.load_case(name)
     s = _write_case(tmp_path, fx)
     out = tmp_path / "idx"
+    if direct and (name, nblocks) not in (("n8_k21", 8), ("n2_k21", 2)):
+        pytest.skip("columns straight from the probe only exist for one-genome blocks")
+    from panagram_amd import engine
+    monkeypatch.setattr(engine, "COLUMNS_DIRECT", direct)  # (PG_COLUMNS_DIRECT: off by default)
     monkeypatch.setattr(pdist, "CHUNK_POSITIONS", chunk)
     idx = pidx.Index(str(s), prefix=str(out), k=int(fx["k"]), anchor_genomes=[f"g{g}" for g in fx["anchors"]],
                      shard="genome", genome_blocks=nblocks)
