@@ -696,11 +696,99 @@ __global__ __launch_bounds__(64) void k_probe(const SubTable st, const uint64_t 
 //       the slot's mask word (a plain store when the snapshot shows the bit missing: see lane_insert_grp's note on
 //       the one-writer invariant) or, in counting mode, atomicAdd
 //   key absent in the snapshot  ->  (position, group) goes to the wave's LDS queue; the queue is worked off densely,
-//       64 entries at a time, by the CAS-claiming single-lane insert (lane_insert_grp: claims race correctly against
-//       other waves; the group id is handed over, not recomputed)
+//       64 entries at a time, by the CAS-claiming insert (wave_insert_batch: lane_insert_grp's protocol — claims race
+//       correctly against other waves — with one compare-and-swap per address and round; the group id is handed over)
 // counters[0] += newly claimed keys; counters[1] = overflow flag (a probe sequence exceeded max_probe lines).
 // ---------------------------------------------------------------------------
 constexpr int INSERT_QCAP = 256;
+
+// The claiming insert for a batch of 64 queue entries, wave-cooperative.  The protocol is lane_insert_grp's (a key may
+// be claimed in a slot only by someone who has seen every earlier slot of its sequence hold OTHER keys; slots never
+// revert), but the lanes of a run — neighbouring queue entries of one minimizer group walk the same lines in step —
+// no longer each throw their own compare-and-swap at the run's next free slot: per round only the FIRST of the lanes
+// that aim at an address issues the CAS, and what the slot holds afterwards (its own key if it won, else the key it
+// found there) is handed to the others, who compare and move on.  A device-scope CAS costs far more than anything
+// else here (3.2 of them per new key were 11 of the first genome's 13 ms at config 2); now about one per new key.
+// A line is read with 8 relaxed atomic loads in flight together (volatile loads are waited for one by one).
+// r: 0 = existed, 1 = newly claimed, -1 = gave up after max_probe lines.
+template <bool COUNT>
+__device__ __forceinline__ int wave_insert_batch(const SubTable &st, bool valid, uint64_t key, uint32_t grp, int w, uint32_t bits,
+                                                 uint32_t max_probe, int lane) {
+    const uint32_t kstride = st.layout == LAYOUT_SPLIT ? 8u : 16u, slots = st.slots;
+    uint32_t b = home_of_group(grp, st.nbuckets), step = step_of_group(grp, st.nbuckets), probes = 0;
+    int s = -1;  // slot to try next in line b; -1: the line has not been read yet; slots: the line is full
+    bool done = !valid;
+    int r = 0;
+    auto resolve = [&](uint32_t sl, bool claimed) __attribute__((always_inline)) {
+        uint32_t *mp = mask_ptr(st, b, sl, (uint32_t)w);
+        if (COUNT) {
+            if (*mp < 0xFFFFFF00u) atomicAdd(mp, bits);  // saturates far above any -ci threshold
+        } else if (claimed) {
+            *reinterpret_cast<volatile uint32_t *>(mp) = bits;  // a fresh slot's mask words are zero (lane_insert_grp's note on racing writers applies)
+        } else {
+            const uint32_t cur = *mp;
+            if ((cur & bits) != bits) *reinterpret_cast<volatile uint32_t *>(mp) = cur | bits;
+        }
+        r = claimed ? 1 : 0;
+        done = true;
+    };
+    while (__ballot(!done)) {
+        if (!done && s >= (int)slots) {  // on to the next line of the sequence
+            if (++probes >= max_probe) {
+                done = true;
+                r = -1;
+            } else {
+                advance_line(key, probes, st.nbuckets, b, step);
+                s = -1;
+            }
+        }
+        if (!done && s < 0) {  // read the line: the key itself, or the first empty slot (lines fill front to back)
+            uint8_t *base = st.buckets + (uint64_t)b * line_bytes(st);
+            int hit = -1, fr = -1;
+            for (uint32_t s0 = 0; s0 < slots; s0 += 8) {
+                uint64_t kk[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    kk[i] = __hip_atomic_load(reinterpret_cast<unsigned long long *>(base + kstride * (s0 + i)), __ATOMIC_RELAXED,
+                                              __HIP_MEMORY_SCOPE_AGENT);
+                int h8 = -1, f8 = -1;
+#pragma unroll
+                for (int i = 7; i >= 0; --i) {
+                    h8 = (kk[i] == key) ? i : h8;
+                    f8 = (kk[i] == EMPTY_KEY) ? i : f8;
+                }
+                if (hit < 0 && h8 >= 0) hit = (int)s0 + h8;
+                if (fr < 0 && f8 >= 0) fr = (int)s0 + f8;
+            }
+            if (hit >= 0) resolve((uint32_t)hit, false);
+            else s = fr >= 0 ? fr : (int)slots;
+        }
+        // one compare-and-swap round among the lanes that have a slot to try
+        const bool want = !done && s >= 0 && s < (int)slots;
+        unsigned long long *kp = want ? key_ptr(st, b, (uint32_t)s) : nullptr;
+        const uint64_t addr = reinterpret_cast<uint64_t>(kp);
+        const uint64_t prev = (uint64_t)(uint32_t)__shfl_up((int)(uint32_t)addr, 1) | ((uint64_t)(uint32_t)__shfl_up((int)(uint32_t)(addr >> 32), 1) << 32);
+        const bool leader = want && (lane == 0 || prev != addr);  // (a lane without a slot to try carries address 0)
+        uint64_t content = 0;
+        bool won = false;
+        if (leader) {
+            const unsigned long long cur = atomicCAS(kp, (unsigned long long)EMPTY_KEY, (unsigned long long)key);
+            won = cur == EMPTY_KEY;
+            content = won ? key : cur;
+        }
+        const unsigned long long lmask = __ballot(leader);
+        if (__ballot(want)) {
+            const unsigned long long below = lmask & ((2ull << lane) - 1ull);
+            const int mine = below ? 63 - __builtin_clzll(below) : lane;  // the leader this lane follows
+            const uint64_t got = (uint64_t)(uint32_t)__shfl((int)(uint32_t)content, mine) | ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(content >> 32), mine) << 32);
+            if (want) {
+                if (got == key) resolve((uint32_t)s, leader && won);
+                else ++s;
+            }
+        }
+    }
+    return r;
+}
 
 template <int W_C, bool M64>
 __global__ __launch_bounds__(64) void k_insert_tile(const SubTable st, int w, uint32_t bits, uint32_t count_mode,
@@ -758,12 +846,11 @@ __global__ __launch_bounds__(64) void k_insert_tile(const SubTable st, int w, ui
         __syncthreads();
         for (uint32_t e0 = 0; e0 < qn; e0 += 64) {
             const uint32_t e = e0 + lane;
-            int r = 0;
-            if (e < qn) {
-                const uint64_t key = canonical_from_le(extract_bases32(reinterpret_cast<const uint32_t *>(sw), q_pl[e]), k);
-                r = count_mode ? lane_insert_grp<true>(st, key, w, bits, max_probe, q_grp[e])
-                               : lane_insert_grp<false>(st, key, w, bits, max_probe, q_grp[e]);
-            }
+            const bool valid = e < qn;
+            const uint32_t ec = valid ? e : qn - 1;
+            const uint64_t key = canonical_from_le(extract_bases32(reinterpret_cast<const uint32_t *>(sw), q_pl[ec]), k);
+            const int r = count_mode ? wave_insert_batch<true>(st, valid, key, q_grp[ec], w, bits, max_probe, lane)
+                                     : wave_insert_batch<false>(st, valid, key, q_grp[ec], w, bits, max_probe, lane);
             overflowed |= __ballot(r < 0) != 0;
             claimed += (uint32_t)__popcll(__ballot(r > 0));
         }
