@@ -701,6 +701,9 @@ __global__ __launch_bounds__(64) void k_probe(const SubTable st, const uint64_t 
 // counters[0] += newly claimed keys; counters[1] = overflow flag (a probe sequence exceeded max_probe lines).
 // ---------------------------------------------------------------------------
 constexpr int INSERT_QCAP = 256;
+#ifndef PG_INSERT_SPREAD
+#define PG_INSERT_SPREAD 1
+#endif
 
 // The claiming insert for a batch of 64 queue entries, wave-cooperative.  The protocol is lane_insert_grp's (a key may
 // be claimed in a slot only by someone who has seen every earlier slot of its sequence hold OTHER keys; slots never
@@ -717,8 +720,11 @@ __device__ __forceinline__ int wave_insert_batch(const SubTable &st, bool valid,
     const uint32_t kstride = st.layout == LAYOUT_SPLIT ? 8u : 16u, slots = st.slots;
     uint32_t b = home_of_group(grp, st.nbuckets), step = step_of_group(grp, st.nbuckets), probes = 0;
     int s = -1;  // slot to try next in line b; -1: the line has not been read yet; slots: the line is full
-    bool done = !valid;
+    bool done = !valid, fresh = false;  // fresh: the line has just been read, s is its first empty slot
     int r = 0;
+    auto shfl64 = [](uint64_t v, int src) __attribute__((always_inline)) {
+        return (uint64_t)(uint32_t)__shfl((int)(uint32_t)v, src) | ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(v >> 32), src) << 32);
+    };
     auto resolve = [&](uint32_t sl, bool claimed) __attribute__((always_inline)) {
         uint32_t *mp = mask_ptr(st, b, sl, (uint32_t)w);
         if (COUNT) {
@@ -761,8 +767,61 @@ __device__ __forceinline__ int wave_insert_batch(const SubTable &st, bool valid,
                 if (fr < 0 && f8 >= 0) fr = (int)s0 + f8;
             }
             if (hit >= 0) resolve((uint32_t)hit, false);
-            else s = fr >= 0 ? fr : (int)slots;
+            else {
+                s = fr >= 0 ? fr : (int)slots;
+                fresh = true;
+            }
         }
+#if PG_INSERT_SPREAD
+        // The lanes of a run that have just read their line claim DISTINCT slots in one round: first empty slot + rank
+        // in the run.  A claim made this way has not yet seen the slots below it; it sees them right after — every slot
+        // of the run's range is occupied once the round is over, and what each holds comes back with its lane's CAS —
+        // and if a LOWER one turns out to hold the same key (an equal key further up in the run, or another wave's
+        // claim that landed in between), the claim is retired (TOMB_KEY) and the key counts as found below.  Two
+        // racing claims of one key in one line always see each other from the higher slot (its range reaches down to
+        // what was the first empty slot when it read the line, and the lower claim was not there yet or it would
+        // have been found), so exactly the lower copy survives.  Not in counting mode: a count added to a copy that
+        // is retired afterwards would be lost.
+        if (!COUNT) {
+            const bool sp = !done && fresh && s < (int)slots;
+            const unsigned long long spmask = __ballot(sp);
+            if (spmask) {
+                const uint64_t gaddr = sp ? reinterpret_cast<uint64_t>(key_ptr(st, b, (uint32_t)s)) : 0;  // (line, first empty slot)
+                const uint64_t gprev = (uint64_t)(uint32_t)__shfl_up((int)(uint32_t)gaddr, 1) | ((uint64_t)(uint32_t)__shfl_up((int)(uint32_t)(gaddr >> 32), 1) << 32);
+                const bool gl = sp && (lane == 0 || gprev != gaddr);
+                const unsigned long long glmask = __ballot(gl);
+                const unsigned long long below = glmask & ((2ull << lane) - 1ull);
+                const int g0 = below ? 63 - __builtin_clzll(below) : lane;  // first lane of this lane's group
+                const unsigned long long ends = (glmask | ~spmask) & ~((2ull << g0) - 1ull);
+                const int gend = ends ? __builtin_ctzll(ends) : 64;
+                const uint32_t mm = sp ? min((uint32_t)(gend - g0), slots - (uint32_t)s) : 0u;  // slots the group goes for
+                const int t = s + (lane - g0);
+                const bool part = sp && t < (int)slots;
+                uint64_t content = 0;
+                bool won = false;
+                if (part) {
+                    const unsigned long long cur = atomicCAS(key_ptr(st, b, (uint32_t)t), (unsigned long long)EMPTY_KEY, (unsigned long long)key);
+                    won = cur == EMPTY_KEY;
+                    content = won ? key : cur;
+                }
+                int pos = -1;  // lowest slot of the group's range that holds this lane's key
+                for (uint32_t i = 0; i < slots; ++i) {  // (wave-uniform trip count)
+                    const uint64_t c = shfl64(content, min(g0 + (int)i, 63));
+                    if (i < mm && pos < 0 && c == key) pos = s + (int)i;
+                }
+                if (sp) {
+                    if (pos >= 0) {
+                        const bool mine = part && won && pos == t;
+                        if (part && won && pos != t) *reinterpret_cast<volatile unsigned long long *>(key_ptr(st, b, (uint32_t)t)) = TOMB_KEY;
+                        resolve((uint32_t)pos, mine);
+                    } else {
+                        s += (int)mm;  // other keys all the way: on behind them, one slot per round from here
+                    }
+                }
+            }
+        }
+        fresh = false;
+#endif
         // one compare-and-swap round among the lanes that have a slot to try
         const bool want = !done && s >= 0 && s < (int)slots;
         unsigned long long *kp = want ? key_ptr(st, b, (uint32_t)s) : nullptr;

@@ -28,6 +28,10 @@
 namespace pg {
 
 constexpr uint64_t EMPTY_KEY = ~0ull;
+// A retired slot: holds no key and is not empty either (lines keep filling front to back behind it).  Written by
+// wave_insert_batch over the later of two copies of a key that two racing claims put into one line.  Like EMPTY_KEY it
+// can never be a canonical k-mer: ~0 is TT..T and ~0 - 1 is TT..TG, whose reverse complements AA..A / CAA..A are smaller.
+constexpr uint64_t TOMB_KEY = ~0ull - 1;
 // slots per table line: 8 (128-byte lines) or 16 (256-byte lines, tuning knob); a property of the
 // sub-table (SubTable::slots)
 constexpr int MAX_SUB = 1;           // a pan table is ONE sub-table (slots layout up to 64 genomes, split layout beyond)

@@ -328,7 +328,7 @@ __global__ __launch_bounds__(256) void k_rehash(SubTable src, SubTable dst, unsi
         uint64_t b = i / ns;
         int s = (int)(i - b * ns);
         uint64_t key = *key_ptr(src, b, (uint32_t)s);
-        if (key == EMPTY_KEY) continue;
+        if (key >= TOMB_KEY) continue;  // empty, or a retired copy
         for (uint32_t w = 0; w < src.W; ++w) {
             uint32_t m = *mask_ptr(src, b, (uint32_t)s, w);
             if (m == 0 && w > 0) continue;
@@ -373,7 +373,7 @@ __global__ __launch_bounds__(256) void k_count_spill(SubTable st, unsigned long 
         const uint64_t b = i / ns;
         const int s = (int)(i - b * ns);
         const uint64_t key = *key_ptr(st, b, (uint32_t)s);
-        if (key == EMPTY_KEY) continue;
+        if (key >= TOMB_KEY) continue;
         if (home_of_group(group_of(st, key), st.nbuckets) != (uint32_t)b) ++spilled;
     }
     if (spilled) atomicAdd(&counters[0], (unsigned long long)spilled);
@@ -390,7 +390,7 @@ __global__ __launch_bounds__(256) void k_export(SubTable st, int w, uint64_t *ke
         uint64_t b = i / ns;
         int s = (int)(i - b * ns);
         uint64_t key = *key_ptr(st, b, (uint32_t)s);
-        if (key == EMPTY_KEY) continue;
+        if (key >= TOMB_KEY) continue;  // empty, or a retired copy (whose mask a racing finder may have written before it was retired)
         uint32_t m = *mask_ptr(st, b, (uint32_t)s, (uint32_t)w);
         if (m == 0) continue;
         unsigned long long idx = atomicAdd(count, 1ull);

@@ -438,6 +438,44 @@ def test_repeat_family_heavy_minimizer_groups(ctx, k):
     tbl.close()
 
 
+@pytest.mark.parametrize("k,period", [(21, 7), (21, 30), (31, 45), (21, 200)])
+def test_tandem_repeats_equal_kmers_within_a_batch(ctx, k, period):
+    """tandem repeats put EQUAL new k-mers side by side — into one 64-lane batch of the table build, whose lanes claim
+    distinct slots of a line at once (the later copy of a key is retired) — and into neighbouring tiles, built by
+    different waves at the same time.  The exported key set must be the oracle's, each key once; anchoring too."""
+    from panagram_amd import engine
+    rng = np.random.default_rng(period)
+    n = 3
+    genomes = []
+    for g in range(n):
+        parts = []
+        for _ in range(12):
+            unit = rng.integers(0, 4, period, dtype=np.uint8)
+            parts.append(np.tile(unit, int(rng.integers(300, 3000)) // period + 2))
+            parts.append(rng.integers(0, 4, int(rng.integers(50, 600)), dtype=np.uint8))
+        genomes.append([po.codes_to_ascii(np.concatenate(parts)), po.codes_to_ascii(np.tile(rng.integers(0, 4, period, dtype=np.uint8), 40000 // period))])
+    dbs = po.build_bitvec_dbs(genomes, k)
+    tbl = engine.PanTable(ctx, k, n)
+    for g in range(n):
+        ss = engine.SeqSet.from_host(ctx, genomes[g])
+        tbl.insert_seqset(g, ss)
+        ss.close()
+    keys, vals = tbl.export(0)
+    o = np.argsort(keys)
+    assert np.array_equal(keys[o], dbs[0][0]) and np.array_equal(vals[o], dbs[0][1])
+    assert tbl.stats()["nkeys"] == len(dbs[0][0])
+    for g in range(n):
+        for seq in genomes[g]:
+            rows, rows100, bins, cs = tbl.anchor_contig(seq)
+            o_rows, o_rows100, o_bins, _, o_cs = po.anchor_contig(dbs, seq, k, n)
+            assert np.array_equal(rows, o_rows) and np.array_equal(bins.astype(np.int64), o_bins)
+    tbl.rehash(3.0)  # retired copies stay behind
+    keys, vals = tbl.export(0)
+    o = np.argsort(keys)
+    assert np.array_equal(keys[o], dbs[0][0]) and np.array_equal(vals[o], dbs[0][1])
+    tbl.close()
+
+
 @pytest.mark.parametrize("n,k,piece", [(5, 21, 3), (40, 31, 0), (9, 21, 1)])
 def test_coscheduled_result_over_all_anchor_genomes(ctx, n, k, piece):
     """one result over the concatenated contigs of every anchor genome, tiles interleaved genome by
