@@ -137,6 +137,9 @@ __device__ __forceinline__ void lane_chase(const SubTable &st, uint64_t key, uin
 // ---- split layout (more than 64 genomes: 16 bare keys per line, mask words in a second array) ----
 // A hit is reported as (line, slot + 1) — slot1 == 0: absent — and the row is copied from the mask array afterwards.
 // scan of a key line staged in LDS: 1 = found, 0 = absent (line not full), -1 = absent from a full line
+// FIRST: several slots may hold the key (k_insert_tile's snapshots: a claim that is about to be retired, see
+// wave_insert_batch) — report the lowest; otherwise at most one does
+template <bool FIRST = false>
 __device__ __forceinline__ int scan_keys16_lds(const uint4 *line, uint64_t key, uint32_t &slot1) {
     uint64_t kk[16];
 #pragma unroll
@@ -148,6 +151,15 @@ __device__ __forceinline__ int scan_keys16_lds(const uint4 *line, uint64_t key, 
     unsigned long long e[16];
 #pragma unroll
     for (int sl = 0; sl < 16; ++sl) e[sl] = __builtin_amdgcn_ballot_w64(kk[sl] == key);
+    if constexpr (FIRST) {  // (scalar unit: a lane's match in a lower slot masks its later ones)
+        unsigned long long seen = e[0];
+#pragma unroll
+        for (int sl = 1; sl < 16; ++sl) {
+            const unsigned long long m = e[sl];
+            e[sl] = m & ~seen;
+            seen |= m;
+        }
+    }
     unsigned long long b[4] = {0, 0, 0, 0}, any = e[0];
 #pragma unroll
     for (int sl = 1; sl < 16; ++sl) {
@@ -973,7 +985,7 @@ __global__ __launch_bounds__(64) void k_insert_tile(const SubTable st, int w, ui
                 uint32_t cur = 0;
                 if (split) {
                     uint32_t slot1;
-                    scan_keys16_lds(ln, key, slot1);
+                    scan_keys16_lds<true>(ln, key, slot1);
                     if (slot1) {
                         found = true;
                         mp = reinterpret_cast<uint32_t *>(st.masks) + ((uint64_t)line * SPLIT_KEYS + (slot1 - 1u)) * st.W + (uint32_t)w;
@@ -988,6 +1000,16 @@ __global__ __launch_bounds__(64) void k_insert_tile(const SubTable st, int w, ui
                     unsigned long long e[8];
 #pragma unroll
                     for (int sl = 0; sl < 8; ++sl) e[sl] = __builtin_amdgcn_ballot_w64(kk[sl] == key);
+                    {  // a snapshot taken during this launch may show a key twice (a claim about to be retired, see
+                       // wave_insert_batch): the LOWEST slot counts — a lane's match there masks its later ones (scalar unit)
+                        unsigned long long seen = e[0];
+#pragma unroll
+                        for (int sl = 1; sl < 8; ++sl) {
+                            const unsigned long long m = e[sl];
+                            e[sl] = m & ~seen;
+                            seen |= m;
+                        }
+                    }
                     const unsigned long long b0 = e[1] | e[3] | e[5] | e[7], b1 = e[2] | e[3] | e[6] | e[7], b2 = e[4] | e[5] | e[6] | e[7];
                     (void)m0;
                     (void)m1;
