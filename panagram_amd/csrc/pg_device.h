@@ -307,7 +307,8 @@ __device__ __forceinline__ int lane_insert_grp(const SubTable &st, uint64_t key,
             uint8_t *grp8 = base + kstride * s0;
             uint64_t kk[8];
 #pragma unroll
-            for (int s = 0; s < 8; ++s) kk[s] = *reinterpret_cast<const volatile unsigned long long *>(grp8 + kstride * s);
+            for (int s = 0; s < 8; ++s)  // (relaxed atomic loads: all eight in flight together; volatile ones are waited for one by one)
+                kk[s] = __hip_atomic_load(reinterpret_cast<unsigned long long *>(grp8 + kstride * s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             int hit = -1, free_s = -1;
 #pragma unroll
             for (int s = 7; s >= 0; --s) {
@@ -331,6 +332,10 @@ __device__ __forceinline__ int lane_insert_grp(const SubTable &st, uint64_t key,
                 uint32_t *mp = mask_ptr(st, b, s0 + (uint32_t)hit, (uint32_t)w);
                 if (COUNT) {
                     if (*mp < 0xFFFFFF00u) atomicAdd(mp, bits);  // saturates far above any -ci threshold
+                } else if (claimed && !ATOMIC_OR) {
+                    // a slot claimed just now has zero mask words (tables start zeroed, slots never revert), and whoever
+                    // finds the key there meanwhile ORs in the same bits (see below): no read needed
+                    *reinterpret_cast<volatile uint32_t *>(mp) = bits;
                 } else {
                     // A plain store, not an atomic OR (7 % of the table build): every writer of this word during
                     // one launch ORs in the SAME bits — one genome per insert launch, one writer per key in
