@@ -476,6 +476,56 @@ def test_tandem_repeats_equal_kmers_within_a_batch(ctx, k, period):
     tbl.close()
 
 
+@pytest.mark.parametrize("k", [21, 31])
+def test_cooperative_build_equals_per_thread_build(ctx, k, monkeypatch):
+    """k_insert_tile (a run's lanes claim distinct slots in one round, later copies of a key retired) against the
+    one-thread-per-k-mer build (PG_INSERT_PER_THREAD) on repeat-rich genomes — identical and diverged copies of
+    elements, tandem arrays of periods 2..700, at a size where many waves build at once: the same (key, mask) set, every
+    key once, the same key count (tools/insert_equiv.py is the larger version)."""
+    from panagram_amd import engine
+    rng = np.random.default_rng(70 + k)
+    G = 3
+    elems = [rng.integers(0, 4, n, dtype=np.uint8) for n in (300, 1100, 5000)]
+    genomes = []
+    for g in range(G):
+        parts = []
+        for _ in range(900):
+            kind = rng.integers(0, 4)
+            if kind == 0:
+                parts.append(elems[int(rng.integers(0, 3))])
+            elif kind == 1:
+                e = elems[int(rng.integers(0, 3))].copy()
+                mut = rng.random(len(e)) < 0.02
+                e[mut] = (e[mut] + rng.integers(1, 4, int(mut.sum()), dtype=np.uint8)) % 4
+                parts.append(e)
+            elif kind == 2:
+                period = int(rng.choice([2, 5, 13, 40, 150, 700]))
+                parts.append(np.tile(rng.integers(0, 4, period, dtype=np.uint8), int(rng.integers(200, 4000)) // period + 2))
+            else:
+                parts.append(rng.integers(0, 4, int(rng.integers(100, 3000)), dtype=np.uint8))
+        genomes.append([po.codes_to_ascii(np.concatenate(parts))])
+
+    def build():
+        tbl = engine.PanTable(ctx, k, G)
+        for g in range(G):
+            ss = engine.SeqSet.from_host(ctx, genomes[g])
+            tbl.insert_seqset(g, ss)
+            ss.close()
+        keys, vals = tbl.export(0)
+        o = np.argsort(keys, kind="stable")
+        nk = tbl.stats()["nkeys"]
+        tbl.close()
+        return keys[o], vals[o], nk
+
+    monkeypatch.delenv("PG_INSERT_PER_THREAD", raising=False)
+    ka, va, na = build()
+    monkeypatch.setenv("PG_INSERT_PER_THREAD", "1")
+    kb, vb, nb = build()
+    assert len(np.unique(ka)) == len(ka)
+    assert np.array_equal(ka, kb) and np.array_equal(va, vb)
+    assert na == nb == len(ka)
+
+
 @pytest.mark.parametrize("n,k,piece", [(5, 21, 3), (40, 31, 0), (9, 21, 1)])
 def test_coscheduled_result_over_all_anchor_genomes(ctx, n, k, piece):
     """one result over the concatenated contigs of every anchor genome, tiles interleaved genome by
