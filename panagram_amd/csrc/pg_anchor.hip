@@ -370,7 +370,11 @@ __device__ __forceinline__ void cols_or_position(unsigned long long *cols, uint3
 // Overflow levels of a tile: dense 64-entry batches out of the wave's LDS queue, staged exactly
 // like the main batches (neighbouring entries belong to the same group and share their next
 // line); entries that overflow again are compacted in place for the next level.
-template <bool TWO, int ROWMODE, int SLOTS, int MAXRUN, bool WIDE>
+// LEVELS: overflow levels worked off with staged lines; entries still unresolved after them chase their sequences lane
+// by lane.  Two for many-genome tables (narrow windows, big groups: a third of the overflowing keys overflow again); ONE
+// for the wide-window tables of up to 8 genomes, where the second staged level costs more than the few lanes it saves
+// (+1.5 % at configs 1-2, tools/ab_one.sh; -1 % at 64 genomes).
+template <bool TWO, int ROWMODE, int SLOTS, int MAXRUN, bool WIDE, int LEVELS>
 __device__ __forceinline__ void drain_queue(const SubTable &st, uint32_t qn, const uint64_t *sw, const uint64_t *rw, uint32_t *q_line,
                                             uint32_t *q_step, uint16_t *q_pl, uint32_t *lines_w, uint4 *buf,
                                             uint8_t *tile_rows, uint32_t nbytes, const RowCols rc, int lane) {
@@ -383,7 +387,7 @@ __device__ __forceinline__ void drain_queue(const SubTable &st, uint32_t qn, con
     constexpr int STAGE_ITERS = (MAXRUN * SLOTS + 63) / 64;
     for (int level = 1; qn > 0; ++level) {
         __syncthreads();
-        if (level > PROBE_STAGED_LEVELS) {
+        if (level > LEVELS) {
             // the few entries still unresolved (long chains) walk their sequences lane by lane:
             // 8 slot loads in flight per line, no staging overhead
             for (uint32_t e = lane; e < qn; e += 64) {
@@ -459,7 +463,7 @@ __device__ __forceinline__ void drain_queue(const SubTable &st, uint32_t qn, con
                 uint32_t nl2 = line, ns2 = step;
                 // (staged levels end before the group's chain does: no switch to the key's own sequence
                 // here, and none of its hashing on this path)
-                if constexpr (PROBE_STAGED_LEVELS + 1 < (int)GROUP_CHAIN) nl2 = next_line(line, step, st.nbuckets);
+                if constexpr (LEVELS + 1 < (int)GROUP_CHAIN) nl2 = next_line(line, step, st.nbuckets);
                 else advance_line(key, (uint32_t)level + 1, st.nbuckets, nl2, ns2);
                 q_line[slot] = nl2;
                 q_step[slot] = ns2;
@@ -689,7 +693,8 @@ __global__ __launch_bounds__(64) void k_probe(const SubTable st, const uint64_t 
         }
     }
 
-    drain_queue<TWO, ROWMODE, SLOTS, PROBE_MAXRUN, WIDE>(st, qn, sw, rw, q_line, q_step, q_pl, lines_w[0], buf[0], tile_rows, nbytes, rc, lane);
+    constexpr int LEVELS = (W_C >= 6 && !TWO && !WIDE && PROBE_STAGED_LEVELS > 1) ? 1 : PROBE_STAGED_LEVELS;  // (W_C >= 6: tables of up to 8 genomes)
+    drain_queue<TWO, ROWMODE, SLOTS, PROBE_MAXRUN, WIDE, LEVELS>(st, qn, sw, rw, q_line, q_step, q_pl, lines_w[0], buf[0], tile_rows, nbytes, rc, lane);
     if constexpr (ROWMODE == 3) {
         // the tile's columns: 8 slots x `width` (= nbytes) genomes, slot-major — what k_cols_extract would have written
         __syncthreads();
