@@ -1065,8 +1065,15 @@ __global__ __launch_bounds__(64) void k_insert_tile(const SubTable st, int w, ui
 // ---------------------------------------------------------------------------
 // A workgroup keeps the histograms of EPI_MAXB consecutive bins in LDS at a time (rows relative to
 // cur_row0): contigs of a few kb .. Mb have bins of nkmers/100 positions, far shorter than a tile.
-constexpr uint32_t EPI_MAXB = 16;
-constexpr uint32_t EPI_MINBIN = (PROBE_TILE + EPI_MAXB - 3) / (EPI_MAXB - 2);  // a tile then spans <= EPI_MAXB bins
+// The window is 16..64 bins wide, as many as about 12 KB of LDS hold at N + 1 counters per bin (chosen by the launcher,
+// handed over in bits 8..15 of `flags`): with 16 bins a contig of a few kb — bins of 50 rows, a tile spans 11 of them —
+// flushed its window to global memory after nearly every tile (4 x 100 Mb in 20 000 contigs: 1.45 ms for 4 x 10^8 rows).
+constexpr uint32_t EPI_MAXB = 16;  // (the least)
+__host__ __device__ __forceinline__ uint32_t epi_maxb_for(uint32_t ngenomes) {
+    const uint32_t b = 3072u / (ngenomes + 1u);
+    return b < EPI_MAXB ? EPI_MAXB : (b > 64u ? 64u : b);
+}
+__host__ __device__ __forceinline__ uint32_t epi_minbin(uint32_t maxb) { return ((uint32_t)PROBE_TILE + maxb - 3u) / (maxb - 2u); }  // a tile then spans <= maxb bins
 // column sums: one ballot + popcount per genome bit, accumulated in LDS by lane 0
 __device__ __forceinline__ void colsum_word(uint32_t wv, uint32_t d, uint32_t N, uint32_t *cs, int lane) {
     const uint32_t ng = min(32u, N - 32 * d);
@@ -1078,7 +1085,7 @@ __device__ __forceinline__ void colsum_word(uint32_t wv, uint32_t d, uint32_t N,
 // wave-aggregated histogram of (bin, popcount): LDS for the first EPI_MAXB bins from bin0, global beyond
 __device__ __forceinline__ void hist_position(bool active, uint32_t pos, uint32_t popc, uint32_t N, uint32_t binlen,
                                               uint32_t bin0, uint32_t bin0_start, uint32_t rel_base, uint32_t *hist,
-                                              uint32_t *bins, uint64_t bin_off, int lane) {
+                                              uint32_t *bins, uint64_t bin_off, int lane, uint32_t maxb) {
     if (popc > N) popc = N;  // junk bits beyond ngenomes: the reference indexes out of bounds here
     const uint32_t dpos = pos - bin0_start;
     const uint32_t rel = (binlen >= (uint32_t)PROBE_TILE) ? (dpos >= binlen ? 1u : 0u) : dpos / binlen;
@@ -1090,7 +1097,7 @@ __device__ __forceinline__ void hist_position(bool active, uint32_t pos, uint32_
         const unsigned long long mk = __ballot(active && hk == lk) & todo;
         if (lane == leader) {
             const uint32_t cnt = (uint32_t)__popcll(mk);
-            if (rel_base + rel < EPI_MAXB) atomicAdd(&hist[rel_base * (N + 1) + hk], cnt);
+            if (rel_base + rel < maxb) atomicAdd(&hist[rel_base * (N + 1) + hk], cnt);
             else atomicAdd(&bins[(bin_off + bin0 + rel) * (uint64_t)(N + 1) + popc], cnt);
         }
         todo &= ~mk;
@@ -1129,8 +1136,8 @@ constexpr int EPI_THREADS = PROBE_TILE / 4;
 
 static_assert(EPI_THREADS >= 64 && EPI_THREADS % 64 == 0, "PROBE_TILE must be a multiple of 256");
 
-__device__ __forceinline__ void flush_hist(uint32_t N, uint32_t *hist, uint32_t *bins, uint64_t bin_row0, int tid) {
-    for (uint32_t i = tid; i < EPI_MAXB * (N + 1); i += EPI_THREADS) {
+__device__ __forceinline__ void flush_hist(uint32_t N, uint32_t *hist, uint32_t *bins, uint64_t bin_row0, int tid, uint32_t maxb) {
+    for (uint32_t i = tid; i < maxb * (N + 1); i += EPI_THREADS) {
         const uint32_t hv = hist[i];
         if (hv) {
             const uint32_t rel = i / (N + 1), pc2 = i - rel * (N + 1);
@@ -1157,8 +1164,9 @@ __global__ __launch_bounds__(EPI_THREADS) void k_epilogue(uint32_t N, const Anch
     const uint32_t Nw = N;
     const uint32_t ndbs = (N + 31) / 32;
     uint32_t *hist = reinterpret_cast<uint32_t *>(smem);
-    uint32_t *cs = hist + ((EPI_MAXB * (N + 1) + 3) & ~3u);
-    for (uint32_t i = tid; i < EPI_MAXB * (N + 1); i += EPI_THREADS) hist[i] = 0;
+    const uint32_t MAXB = max(EPI_MAXB, (flags >> 8) & 0xFFu), MINBIN = epi_minbin(MAXB);  // bins in the LDS window (launcher's choice)
+    uint32_t *cs = hist + ((MAXB * (N + 1) + 3) & ~3u);
+    for (uint32_t i = tid; i < MAXB * (N + 1); i += EPI_THREADS) hist[i] = 0;
     for (uint32_t i = tid; i < N; i += EPI_THREADS) cs[i] = 0;
     __syncthreads();
     const bool want_cs = (flags & 1u) != 0;
@@ -1341,7 +1349,7 @@ __global__ __launch_bounds__(EPI_THREADS) void k_epilogue(uint32_t N, const Anch
                     if (cur_row0 != ~0ull) {
                         reduce_hist();
                         __syncthreads();
-                        flush_hist(N, hist, bins, cur_row0, tid);
+                        flush_hist(N, hist, bins, cur_row0, tid, MAXB);
                         __syncthreads();
                     }
                     cur_row0 = row0g;
@@ -1415,10 +1423,10 @@ __global__ __launch_bounds__(EPI_THREADS) void k_epilogue(uint32_t N, const Anch
                                 (ts / a.binlen) == ((ts + span - 1) / a.binlen);
             if (grp_ok) {
                 const uint64_t row0g = a.bin_off + ts / a.binlen;
-                if (cur_row0 == ~0ull || row0g < cur_row0 || row0g >= cur_row0 + EPI_MAXB) {
+                if (cur_row0 == ~0ull || row0g < cur_row0 || row0g >= cur_row0 + MAXB) {
                     if (cur_row0 != ~0ull) {
                         __syncthreads();
-                        flush_hist(N, hist, bins, cur_row0, tid);
+                        flush_hist(N, hist, bins, cur_row0, tid, MAXB);
                         __syncthreads();
                     }
                     cur_row0 = row0g;
@@ -1477,7 +1485,7 @@ __global__ __launch_bounds__(EPI_THREADS) void k_epilogue(uint32_t N, const Anch
         const uint64_t row0 = a.bin_off + bin0;
         const bool onebin = (tile_start + npos) <= (bin0_start + binlen);  // block-uniform
         const bool big = binlen >= (uint32_t)PROBE_TILE;                    // a tile spans at most 2 bins
-        const bool windowed = binlen >= EPI_MINBIN;                         // ... at most EPI_MAXB bins
+        const bool windowed = binlen >= MINBIN;                             // ... at most MAXB bins
         const uint32_t last_rel = (tile_start + npos - 1 - bin0_start) / binlen;
         // (bin - bin0) of a position for short bins: exact for pos - bin0_start < 2^16 > tile + bin
         const uint32_t binv = big ? 0u : 0xFFFFFFFFu / binlen + 1u;
@@ -1485,12 +1493,12 @@ __global__ __launch_bounds__(EPI_THREADS) void k_epilogue(uint32_t N, const Anch
         // accumulators stand for the window's first bin, so a one-bin tile needs row0 == cur_row0.
         const bool reg_tile = MODE == 0 && big && onebin;
         const bool fits = cur_row0 != ~0ull && (reg_tile || !windowed ? row0 == cur_row0
-                                                : (row0 >= cur_row0 && row0 + last_rel < cur_row0 + EPI_MAXB));
+                                                : (row0 >= cur_row0 && row0 + last_rel < cur_row0 + MAXB));
         if (!fits) {
             if (cur_row0 != ~0ull) {
                 reduce_hist();
                 __syncthreads();
-                flush_hist(N, hist, bins, cur_row0, tid);
+                flush_hist(N, hist, bins, cur_row0, tid, MAXB);
                 __syncthreads();
             }
             cur_row0 = row0;
@@ -1647,14 +1655,14 @@ __global__ __launch_bounds__(EPI_THREADS) void k_epilogue(uint32_t N, const Anch
                     }
                     if (want_cs) colsum_word(wv, d, N, cs, lane);
                 }
-                hist_position(active, pos, popc, N, binlen, bin0, bin0_start, rel_base, hist, bins, a.bin_off, lane);
+                hist_position(active, pos, popc, N, binlen, bin0, bin0_start, rel_base, hist, bins, a.bin_off, lane, MAXB);
             }
         }
     }
     if (want_cs && cur_c != ~0u) flush_colsums(cur_c);
     reduce_hist();
     __syncthreads();
-    if (cur_row0 != ~0ull) flush_hist(N, hist, bins, cur_row0, tid);
+    if (cur_row0 != ~0ull) flush_hist(N, hist, bins, cur_row0, tid, MAXB);
 }
 
 // ---------------------------------------------------------------------------
@@ -1695,8 +1703,9 @@ __global__ __launch_bounds__(EPI_THREADS) void k_epilogue_chunks(uint32_t N, con
         wm[w] = nb == 4 ? 0xFFFFFFFFu : (1u << (8 * nb)) - 1u;
     }
     uint32_t *hist = reinterpret_cast<uint32_t *>(smem);
-    uint32_t *cs = hist + ((EPI_MAXB * (N + 1) + 3) & ~3u);
-    for (uint32_t i = tid; i < EPI_MAXB * (N + 1); i += EPI_THREADS) hist[i] = 0;
+    const uint32_t MAXB = max(EPI_MAXB, (flags >> 8) & 0xFFu), MINBIN = epi_minbin(MAXB);  // bins in the LDS window (launcher's choice)
+    uint32_t *cs = hist + ((MAXB * (N + 1) + 3) & ~3u);
+    for (uint32_t i = tid; i < MAXB * (N + 1); i += EPI_THREADS) hist[i] = 0;
     for (uint32_t i = tid; i < K * cs_words; i += EPI_THREADS) cs[i] = 0;
     uint32_t *cs_mine = cs + ((uint32_t)lane / C / 16u) * cs_words + 128u * c;
     __syncthreads();
@@ -1842,14 +1851,14 @@ __global__ __launch_bounds__(EPI_THREADS) void k_epilogue_chunks(uint32_t N, con
             bin0_start = bin0 * binlen;
             const uint64_t row0 = a.bin_off + bin0;
             big = binlen >= (uint32_t)PROBE_TILE;
-            windowed = binlen >= EPI_MINBIN;
+            windowed = binlen >= MINBIN;
             const uint32_t last_rel = (tile_start + npos - 1 - bin0_start) / binlen;
             binv = big ? 0u : 0xFFFFFFFFu / binlen + 1u;
-            const bool fits = cur_row0 != ~0ull && (!windowed ? row0 == cur_row0 : (row0 >= cur_row0 && row0 + last_rel < cur_row0 + EPI_MAXB));
+            const bool fits = cur_row0 != ~0ull && (!windowed ? row0 == cur_row0 : (row0 >= cur_row0 && row0 + last_rel < cur_row0 + MAXB));
             if (!fits) {
                 if (cur_row0 != ~0ull) {
                     __syncthreads();
-                    flush_hist(N, hist, bins, cur_row0, tid);
+                    flush_hist(N, hist, bins, cur_row0, tid, MAXB);
                     __syncthreads();
                 }
                 cur_row0 = row0;
@@ -1879,7 +1888,7 @@ __global__ __launch_bounds__(EPI_THREADS) void k_epilogue_chunks(uint32_t N, con
                         atomicAdd(&hrow[rel * (N + 1) + min(tot, N)], 1u);
                     }
                 } else {
-                    hist_position(on && c == 0, pos, tot, N, binlen, bin0, bin0_start, rel_base, hist, bins, a.bin_off, lane);
+                    hist_position(on && c == 0, pos, tot, N, binlen, bin0, bin0_start, rel_base, hist, bins, a.bin_off, lane, MAXB);
                 }
                 if (want100 && on && pos % 100u == 0) {  // 1-in-100 rows: every lane copies its chunk
                     uint8_t *o = out100 + a.out100_off + (uint64_t)(pos / 100u) * nbytes + 16u * c;
@@ -1911,7 +1920,7 @@ __global__ __launch_bounds__(EPI_THREADS) void k_epilogue_chunks(uint32_t N, con
         for (uint32_t j = 0; j < NJ; ++j) v[j] = vn[j];
     }
     __syncthreads();
-    if (cur_row0 != ~0ull) flush_hist(N, hist, bins, cur_row0, tid);
+    if (cur_row0 != ~0ull) flush_hist(N, hist, bins, cur_row0, tid, MAXB);
 }
 
 // ---------------------------------------------------------------------------
@@ -2228,7 +2237,9 @@ hipError_t launch_rows_epilogue(hipStream_t st, uint32_t ngenomes, const AnchorD
                                 uint32_t ntiles, const uint8_t *out1, uint8_t *out100, uint32_t *bins,
                                 unsigned long long *colsums, uint32_t flags) {
     if (ntiles == 0) return hipSuccess;
-    size_t lds = (((EPI_MAXB * (ngenomes + 1) + 3) & ~3u) + ((ngenomes + 3) & ~3u)) * 4 + 16;
+    const uint32_t maxb = epi_maxb_for(ngenomes);
+    flags = (flags & 0xFFFF00FFu) | (maxb << 8);
+    size_t lds = (((maxb * (ngenomes + 1) + 3) & ~3u) + ((ngenomes + 3) & ~3u)) * 4 + 16;
     // contiguous tile ranges per workgroup: enough workgroups to fill every CU, but no fewer than
     // a minimum number of tiles each so that the end-of-range reductions stay amortised
     const uint32_t maxg = 256u * (2048u / EPI_THREADS);
@@ -2275,7 +2286,7 @@ hipError_t launch_rows_epilogue(hipStream_t st, uint32_t ngenomes, const AnchorD
     else {  // chunk-parallel: one launch, every row read once
         const uint32_t C = (nbytes + 15) / 16;
         if (C > 64) return hipErrorInvalidValue;
-        const size_t lds_c = (((EPI_MAXB * (ngenomes + 1) + 3) & ~3u) + ((64u / C + 15u) / 16u) * 128u * C) * 4 + 16;
+        const size_t lds_c = (((maxb * (ngenomes + 1) + 3) & ~3u) + ((64u / C + 15u) / 16u) * 128u * C) * 4 + 16;
         const bool exact = nbytes == 16u * C;
         auto kern = k_epilogue_chunks<0, false>;  // (compile-time C: the lanes-per-row shuffles and index arithmetic unroll)
         switch (C) {
