@@ -1337,15 +1337,27 @@ __global__ __launch_bounds__(EPI_THREADS) void k_epilogue(uint32_t N, const Anch
         // pair and stage); an 8-input sorting network on those planes (19 compare-exchanges = AND / OR pairs) turns
         // them into thresholds "row has more than i bits"; popcounts of the planes are the column sums, popcounts of
         // the thresholds the cumulative histogram.  3.2 instructions per row, where one-hot adds per row took 13 ----
+        // Two kinds of group: (1) all 4096 rows inside ONE bin — thresholds and rows counted in registers, reduced when the
+        // bin changes; (2) several bins (contigs of a few kb .. Mb have bins of nkmers / 100 rows): bins of at least 32
+        // rows, so that a thread's 32 rows meet at most one bin boundary, and all of the group's bins inside the LDS window —
+        // the thread splits its threshold popcounts at the boundary (a mask over the planes' bit positions) and adds the
+        // classes of its one or two bins to the window with up to 9 LDS atomics each, where the per-tile path does one per row.
         if constexpr (MODE == 0) {
             const uint32_t ts = (tile - a.tile0) * PROBE_TILE;
             const uint32_t span = 8u * PROBE_TILE;
-            const bool grp_ok = tile + 7 < t_end && tile_contig[tile + 7] == c &&
-                                ts + span <= a.nkmers && a.binlen >= span &&
-                                (ts / a.binlen) == ((ts + span - 1) / a.binlen);
+            auto group_kind = [&](uint32_t t0) -> int {  // (block-uniform) 8 full tiles from row t0 of this contig on: 1, 2 or 0
+                const uint32_t bl = a.binlen, ba = t0 / bl, bz = (t0 + span - 1) / bl;
+                if (ba == bz) return 1;
+                return (bl >= 32u && bz - ba + 1u <= MAXB) ? 2 : 0;
+            };
+            const bool full8 = tile + 7 < t_end && tile_contig[tile + 7] == c && ts + span <= a.nkmers;
+            const int kind = full8 ? group_kind(ts) : 0;
+            const bool grp_ok = kind != 0;
             if (grp_ok) {
                 const uint64_t row0g = a.bin_off + ts / a.binlen;
-                if (row0g != cur_row0) {
+                const uint32_t nbg = (ts + span - 1) / a.binlen - ts / a.binlen + 1u;  // bins of the group
+                const bool keep = cur_row0 != ~0ull && (kind == 1 ? row0g == cur_row0 : (row0g >= cur_row0 && row0g + nbg <= cur_row0 + MAXB));
+                if (!keep) {
                     if (cur_row0 != ~0ull) {
                         reduce_hist();
                         __syncthreads();
@@ -1357,9 +1369,8 @@ __global__ __launch_bounds__(EPI_THREADS) void k_epilogue(uint32_t N, const Anch
                 const uint4 *gg = reinterpret_cast<const uint4 *>(out1 + a.out_off + (uint64_t)ts + 32u * tid);
                 const uint4 qa = gq_valid ? gq_next : gg[0];
                 const uint4 qb = gq_valid ? gq_next2 : gg[1];
-                // prefetch the next group when it is an equally regular one right behind
-                gq_valid = tile + 15 < t_end && tile_contig[tile + 15] == c && ts + 2u * span <= a.nkmers &&
-                           ((ts + span) / a.binlen) == ((ts + 2u * span - 1) / a.binlen);
+                // prefetch the next group when it is a group too, right behind
+                gq_valid = tile + 15 < t_end && tile_contig[tile + 15] == c && ts + 2u * span <= a.nkmers && group_kind(ts + span) != 0;
                 if (gq_valid) {
                     gq_next = gg[span / 16u];
                     gq_next2 = gg[span / 16u + 1];
@@ -1402,9 +1413,45 @@ __global__ __launch_bounds__(EPI_THREADS) void k_epilogue(uint32_t N, const Anch
                 cx(1, 4), cx(3, 6);
                 cx(2, 4), cx(3, 5);
                 cx(3, 4);
+                if (kind == 1) {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) thr[i] += __popc(w[7 - i]);  // ascending order: w[7] = any bit set
-                grows += 32;
+                    for (int i = 0; i < 8; ++i) thr[i] += __popc(w[7 - i]);  // ascending order: w[7] = any bit set
+                    grows += 32;
+                } else {
+                    // this thread's rows pos0 .. pos0 + 31: bin of the first one (relative to the window) and rows until the
+                    // next bin boundary; row j = 4 * word + byte sits at bit 8 * byte + word of every plane
+                    const uint32_t bl = a.binlen, bin0s = (ts / bl) * bl, d0 = pos0 - bin0s;
+                    const uint32_t rel0 = bl >= span ? (d0 >= bl ? 1u : 0u) : __umulhi(d0, 0xFFFFFFFFu / bl + 1u);  // (d0 < 2^16)
+                    const uint32_t jb = min(32u, (rel0 + 1u) * bl - d0);  // rows of the first bin
+                    uint32_t mlo = 0;
+#pragma unroll
+                    for (uint32_t rb = 0; rb < 4; ++rb) {
+                        const uint32_t nw = jb > rb ? min(8u, (jb - rb + 3u) >> 2) : 0u;  // words whose byte rb is below the boundary
+                        mlo |= ((1u << nw) - 1u) << (8u * rb);
+                    }
+                    uint32_t *h0 = hist + ((uint32_t)(row0g - cur_row0) + rel0) * (N + 1);
+                    auto add_classes = [&](uint32_t *h, uint32_t mask, uint32_t rows) __attribute__((always_inline)) {
+                        uint32_t cl[9], above = rows;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            const uint32_t t = (uint32_t)__popc(w[7 - i] & mask);  // rows of this bin with more than i bits
+                            cl[i] = above - t;
+                            above = t;
+                        }
+                        cl[8] = above;
+#pragma unroll
+                        for (int v = 8; v >= 1; --v)  // (junk bits beyond ngenomes count as class N)
+                            if ((uint32_t)v > N) {
+                                cl[v - 1] += cl[v];
+                                cl[v] = 0;
+                            }
+#pragma unroll
+                        for (int v = 0; v < 9; ++v)
+                            if ((uint32_t)v <= N && cl[v]) atomicAdd(&h[v], cl[v]);
+                    };
+                    add_classes(h0, mlo, jb);
+                    if (jb < 32u) add_classes(h0 + (N + 1), ~mlo, 32u - jb);
+                }
                 next_valid = false;
                 tile += 7;
                 continue;

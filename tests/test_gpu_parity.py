@@ -668,12 +668,13 @@ def test_kmer_sketch_registers_equal_oracle(ctx, k):
     tbl.close()
 
 
-@pytest.mark.parametrize("n,k,lens", [(1, 21, [700_123]), (5, 21, [520_000, 9_000]), (8, 31, [900_077, 450_321])])
+@pytest.mark.parametrize("n,k,lens", [(1, 21, [700_123]), (5, 21, [520_000, 9_000]), (8, 31, [900_077, 450_321]),
+                                      (8, 21, [50_020, 12_345, 7_000, 33_333]), (3, 21, [204_900, 6_700])])
 def test_one_byte_rows_long_contigs_against_oracle(ctx, n, k, lens):
-    """contigs long enough for the bit-sliced statistics path of one-byte rows (32 rows per thread over 8 whole tiles
-    inside one bin) next to its per-tile neighbours: bins of nkmers / 100 = 4.5-12.5 k positions, so groups of 4096
-    rows alternate with tiles that straddle a bin boundary; N runs and lower case included.  Rows, bitmap.100, bins and
-    per-contig column sums against the oracle."""
+    """contigs long enough for the bit-sliced statistics path of one-byte rows (32 rows per thread over 8 whole tiles)
+    in both of its kinds — all 4096 rows inside one bin; several bins of 66..2049 rows each, a thread's rows split at
+    the boundary — next to the per-tile path (contig ends, bins under 66 rows): bins of nkmers / 100 = 67 rows .. 12.5 k;
+    N runs and lower case included.  Rows, bitmap.100, bins and per-contig column sums against the oracle."""
     from panagram_amd import engine
     rng = np.random.default_rng(n * 1000 + k)
     gen = po.synth_genomes(n, lens, 0.01, 31 + n)
