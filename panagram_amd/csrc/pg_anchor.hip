@@ -1465,12 +1465,14 @@ __global__ __launch_bounds__(EPI_THREADS) void k_epilogue(uint32_t N, const Anch
         if constexpr (MODE == 1) {
             const uint32_t ts = (tile - a.tile0) * PROBE_TILE;
             const uint32_t span = 4u * PROBE_TILE;
-            const bool grp_ok = tile + 3 < t_end && tile_contig[tile + 3] == c &&
-                                ts + span <= a.nkmers && a.binlen >= span &&
-                                (ts / a.binlen) == ((ts + span - 1) / a.binlen);
+            // (the group may span several bins — contigs under 20 Mb have bins of nkmers / 100 rows — as long as a bin holds
+            // at least 16 rows, so that a thread's 16 rows meet at most one boundary, and the group's bins fit the LDS window)
+            const uint32_t nbg = (ts + span - 1) / a.binlen - ts / a.binlen + 1u;  // bins of the group
+            const bool grp_ok = tile + 3 < t_end && tile_contig[tile + 3] == c && ts + span <= a.nkmers &&
+                                (nbg == 1u || (a.binlen >= 16u && nbg <= MAXB));
             if (grp_ok) {
                 const uint64_t row0g = a.bin_off + ts / a.binlen;
-                if (cur_row0 == ~0ull || row0g < cur_row0 || row0g >= cur_row0 + MAXB) {
+                if (cur_row0 == ~0ull || row0g < cur_row0 || row0g + nbg > cur_row0 + MAXB) {
                     if (cur_row0 != ~0ull) {
                         __syncthreads();
                         flush_hist(N, hist, bins, cur_row0, tid, MAXB);
@@ -1478,7 +1480,14 @@ __global__ __launch_bounds__(EPI_THREADS) void k_epilogue(uint32_t N, const Anch
                     }
                     cur_row0 = row0g;
                 }
-                uint32_t *hrow = hist + (uint32_t)(row0g - cur_row0) * (N + 1);
+                // this thread's 16 rows: bin of the first one (relative to the group's first bin) and rows until the boundary
+                uint32_t rel0 = 0, jb = 16;
+                if (nbg > 1u) {
+                    const uint32_t bl = a.binlen, d0 = ts + 16u * tid - (ts / bl) * bl;
+                    rel0 = bl >= span ? (d0 >= bl ? 1u : 0u) : __umulhi(d0, 0xFFFFFFFFu / bl + 1u);  // (d0 < 2^16)
+                    jb = min(16u, (rel0 + 1u) * bl - d0);
+                }
+                uint32_t *hrow = hist + ((uint32_t)(row0g - cur_row0) + rel0) * (N + 1);
                 const uint8_t *gt = out1 + a.out_off + ((uint64_t)ts + 16u * tid) * nbytes;
                 auto rows16 = [&](auto nbc) {
                     constexpr int NB = decltype(nbc)::value;
@@ -1493,7 +1502,8 @@ __global__ __launch_bounds__(EPI_THREADS) void k_epilogue(uint32_t N, const Anch
                         cut4_rows<NB>(raw[q], w0, w1);
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
-                            atomicAdd(&hrow[min((uint32_t)(__popc(w0[j]) + (NB > 4 ? __popc(w1[j]) : 0)), N)], 1u);
+                            atomicAdd(&hrow[((uint32_t)(4 * q + j) >= jb ? N + 1 : 0u) +
+                                            min((uint32_t)(__popc(w0[j]) + (NB > 4 ? __popc(w1[j]) : 0)), N)], 1u);
                         if (want_cs) {
                             vadd4(0, w0[0], w0[1], w0[2], w0[3]);
                             if (NB > 4) vadd4(1, w1[0], w1[1], w1[2], w1[3]);
