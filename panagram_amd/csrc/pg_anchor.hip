@@ -1065,13 +1065,13 @@ __global__ __launch_bounds__(64) void k_insert_tile(const SubTable st, int w, ui
 // ---------------------------------------------------------------------------
 // A workgroup keeps the histograms of EPI_MAXB consecutive bins in LDS at a time (rows relative to
 // cur_row0): contigs of a few kb .. Mb have bins of nkmers/100 positions, far shorter than a tile.
-// The window is 16..64 bins wide, as many as about 12 KB of LDS hold at N + 1 counters per bin (chosen by the launcher,
+// The window is 16..128 bins wide, as many as about 12 KB of LDS hold at N + 1 counters per bin (chosen by the launcher,
 // handed over in bits 8..15 of `flags`): with 16 bins a contig of a few kb — bins of 50 rows, a tile spans 11 of them —
 // flushed its window to global memory after nearly every tile (4 x 100 Mb in 20 000 contigs: 1.45 ms for 4 x 10^8 rows).
 constexpr uint32_t EPI_MAXB = 16;  // (the least)
 __host__ __device__ __forceinline__ uint32_t epi_maxb_for(uint32_t ngenomes) {
     const uint32_t b = 3072u / (ngenomes + 1u);
-    return b < EPI_MAXB ? EPI_MAXB : (b > 64u ? 64u : b);
+    return b < EPI_MAXB ? EPI_MAXB : (b > 128u ? 128u : b);
 }
 __host__ __device__ __forceinline__ uint32_t epi_minbin(uint32_t maxb) { return ((uint32_t)PROBE_TILE + maxb - 3u) / (maxb - 2u); }  // a tile then spans <= maxb bins
 // column sums: one ballot + popcount per genome bit, accumulated in LDS by lane 0
