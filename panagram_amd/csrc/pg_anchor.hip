@@ -1342,20 +1342,27 @@ __global__ __launch_bounds__(EPI_THREADS) void k_epilogue(uint32_t N, const Anch
         // rows, so that a thread's 32 rows meet at most one bin boundary, and all of the group's bins inside the LDS window —
         // the thread splits its threshold popcounts at the boundary (a mask over the planes' bit positions) and adds the
         // classes of its one or two bins to the window with up to 9 LDS atomics each, where the per-tile path does one per row.
+        // A group need not be whole: a contig's last tiles (and a workgroup's last ones) form a group of fewer rows — a thread
+        // then holds nv < 32 valid rows (possibly none) and masks the planes with the same kind of position mask.
         if constexpr (MODE == 0) {
             const uint32_t ts = (tile - a.tile0) * PROBE_TILE;
             const uint32_t span = 8u * PROBE_TILE;
-            auto group_kind = [&](uint32_t t0) -> int {  // (block-uniform) 8 full tiles from row t0 of this contig on: 1, 2 or 0
-                const uint32_t bl = a.binlen, ba = t0 / bl, bz = (t0 + span - 1) / bl;
+            // rows of this contig from ts on that belong to this workgroup's tile range, at most a whole group's
+            auto rows_at = [&](uint32_t tl, uint32_t t0) -> uint32_t {  // (block-uniform)
+                if (tl >= t_end || tile_contig[tl] != c || t0 >= a.nkmers) return 0u;
+                return min(min(span, a.nkmers - t0), (t_end - tl) * (uint32_t)PROBE_TILE);
+            };
+            auto group_kind = [&](uint32_t t0, uint32_t rows) -> int {  // (block-uniform) 1: one bin, 2: several bins, 0: not a group
+                if (rows == 0) return 0;
+                const uint32_t bl = a.binlen, ba = t0 / bl, bz = (t0 + rows - 1) / bl;
                 if (ba == bz) return 1;
                 return (bl >= 32u && bz - ba + 1u <= MAXB) ? 2 : 0;
             };
-            const bool full8 = tile + 7 < t_end && tile_contig[tile + 7] == c && ts + span <= a.nkmers;
-            const int kind = full8 ? group_kind(ts) : 0;
-            const bool grp_ok = kind != 0;
-            if (grp_ok) {
+            const uint32_t grows_n = rows_at(tile, ts);  // (>= 1: this tile has rows)
+            const int kind = group_kind(ts, grows_n);
+            if (kind != 0) {
                 const uint64_t row0g = a.bin_off + ts / a.binlen;
-                const uint32_t nbg = (ts + span - 1) / a.binlen - ts / a.binlen + 1u;  // bins of the group
+                const uint32_t nbg = (ts + grows_n - 1) / a.binlen - ts / a.binlen + 1u;  // bins of the group
                 const bool keep = cur_row0 != ~0ull && (kind == 1 ? row0g == cur_row0 : (row0g >= cur_row0 && row0g + nbg <= cur_row0 + MAXB));
                 if (!keep) {
                     if (cur_row0 != ~0ull) {
@@ -1366,11 +1373,15 @@ __global__ __launch_bounds__(EPI_THREADS) void k_epilogue(uint32_t N, const Anch
                     }
                     cur_row0 = row0g;
                 }
+                const uint32_t nv = 32u * tid < grows_n ? min(32u, grows_n - 32u * tid) : 0u;  // this thread's valid rows
+                // (a 16-byte load that begins on a valid row ends inside the contig's 16-byte padded region)
                 const uint4 *gg = reinterpret_cast<const uint4 *>(out1 + a.out_off + (uint64_t)ts + 32u * tid);
-                const uint4 qa = gq_valid ? gq_next : gg[0];
-                const uint4 qb = gq_valid ? gq_next2 : gg[1];
-                // prefetch the next group when it is a group too, right behind
-                gq_valid = tile + 15 < t_end && tile_contig[tile + 15] == c && ts + 2u * span <= a.nkmers && group_kind(ts + span) != 0;
+                const uint4 z4 = make_uint4(0, 0, 0, 0);
+                const uint4 qa = gq_valid ? gq_next : (nv > 0u ? gg[0] : z4);
+                const uint4 qb = gq_valid ? gq_next2 : (nv > 16u ? gg[1] : z4);
+                // prefetch the next group when this one is whole and a whole group follows right behind
+                const uint32_t tiles_here = (grows_n + PROBE_TILE - 1) / PROBE_TILE;
+                gq_valid = grows_n == span && rows_at(tile + 8, ts + span) == span && group_kind(ts + span, span) != 0;
                 if (gq_valid) {
                     gq_next = gg[span / 16u];
                     gq_next2 = gg[span / 16u + 1];
@@ -1379,7 +1390,7 @@ __global__ __launch_bounds__(EPI_THREADS) void k_epilogue(uint32_t N, const Anch
                 const uint32_t pos0 = ts + 32u * tid;  // at most one multiple of 100 among 32 positions
                 const uint32_t r100 = (pos0 + 99u) / 100u;
                 const uint32_t first = r100 * 100u - pos0;
-                if (want100 && first < 32u) {
+                if (want100 && first < nv) {
                     uint32_t sel = w[0];
 #pragma unroll
                     for (uint32_t i = 1; i < 8; ++i) sel = (first >> 2) == i ? w[i] : sel;
@@ -1396,6 +1407,22 @@ __global__ __launch_bounds__(EPI_THREADS) void k_epilogue(uint32_t N, const Anch
                         w[i] = (x & m0) | ((y << sh) & ~m0);       // the pair's bits with bit kb of g clear
                         w[i | sh] = ((x >> sh) & m0) | (y & ~m0);  // ... and set
                     }
+                }
+                // row j = 4 * word + byte of the thread sits at bit 8 * byte + word of every plane: the rows below j
+                auto rows_below = [](uint32_t j) __attribute__((always_inline)) -> uint32_t {
+                    uint32_t m = 0;
+#pragma unroll
+                    for (uint32_t rb = 0; rb < 4; ++rb) {
+                        const uint32_t nw = j > rb ? min(8u, (j - rb + 3u) >> 2) : 0u;  // words whose byte rb is below row j
+                        m |= ((1u << nw) - 1u) << (8u * rb);
+                    }
+                    return m;
+                };
+                const bool whole = grows_n == span;  // (block-uniform)
+                const uint32_t mval = whole ? 0xFFFFFFFFu : rows_below(nv);
+                if (!whole) {
+#pragma unroll
+                    for (int gb = 0; gb < 8; ++gb) w[gb] &= mval;  // rows past the group hold whatever follows in memory
                 }
                 if (want_cs) {
 #pragma unroll
@@ -1416,19 +1443,14 @@ __global__ __launch_bounds__(EPI_THREADS) void k_epilogue(uint32_t N, const Anch
                 if (kind == 1) {
 #pragma unroll
                     for (int i = 0; i < 8; ++i) thr[i] += __popc(w[7 - i]);  // ascending order: w[7] = any bit set
-                    grows += 32;
+                    grows += nv;
                 } else {
-                    // this thread's rows pos0 .. pos0 + 31: bin of the first one (relative to the window) and rows until the
-                    // next bin boundary; row j = 4 * word + byte sits at bit 8 * byte + word of every plane
+                    // this thread's rows pos0 .. pos0 + nv - 1: bin of the first one (relative to the group's first bin) and
+                    // rows until the next bin boundary
                     const uint32_t bl = a.binlen, bin0s = (ts / bl) * bl, d0 = pos0 - bin0s;
                     const uint32_t rel0 = bl >= span ? (d0 >= bl ? 1u : 0u) : __umulhi(d0, 0xFFFFFFFFu / bl + 1u);  // (d0 < 2^16)
-                    const uint32_t jb = min(32u, (rel0 + 1u) * bl - d0);  // rows of the first bin
-                    uint32_t mlo = 0;
-#pragma unroll
-                    for (uint32_t rb = 0; rb < 4; ++rb) {
-                        const uint32_t nw = jb > rb ? min(8u, (jb - rb + 3u) >> 2) : 0u;  // words whose byte rb is below the boundary
-                        mlo |= ((1u << nw) - 1u) << (8u * rb);
-                    }
+                    const uint32_t jb = min(nv, (rel0 + 1u) * bl - d0);  // valid rows of the first bin
+                    const uint32_t mlo = rows_below(jb);
                     uint32_t *h0 = hist + ((uint32_t)(row0g - cur_row0) + rel0) * (N + 1);
                     auto add_classes = [&](uint32_t *h, uint32_t mask, uint32_t rows) __attribute__((always_inline)) {
                         uint32_t cl[9], above = rows;
@@ -1449,11 +1471,11 @@ __global__ __launch_bounds__(EPI_THREADS) void k_epilogue(uint32_t N, const Anch
                         for (int v = 0; v < 9; ++v)
                             if ((uint32_t)v <= N && cl[v]) atomicAdd(&h[v], cl[v]);
                     };
-                    add_classes(h0, mlo, jb);
-                    if (jb < 32u) add_classes(h0 + (N + 1), ~mlo, 32u - jb);
+                    if (jb) add_classes(h0, mlo, jb);
+                    if (jb < nv) add_classes(h0 + (N + 1), mval & ~mlo, nv - jb);
                 }
                 next_valid = false;
-                tile += 7;
+                tile += tiles_here - 1;
                 continue;
             }
             gq_valid = false;
