@@ -372,7 +372,7 @@ __device__ __forceinline__ void cols_or_position(unsigned long long *cols, uint3
 // line); entries that overflow again are compacted in place for the next level.
 // LEVELS: overflow levels worked off with staged lines; entries still unresolved after them chase their sequences lane
 // by lane.  Two for many-genome tables (narrow windows, big groups: a third of the overflowing keys overflow again); ONE
-// for the wide-window tables of up to 8 genomes, where the second staged level costs more than the few lanes it saves
+// for the wide-window tables of up to 16 genomes, where the second staged level costs more than the few lanes it saves
 // (+1.5 % at configs 1-2, tools/ab_one.sh; -1 % at 64 genomes).
 template <bool TWO, int ROWMODE, int SLOTS, int MAXRUN, bool WIDE, int LEVELS>
 __device__ __forceinline__ void drain_queue(const SubTable &st, uint32_t qn, const uint64_t *sw, const uint64_t *rw, uint32_t *q_line,
@@ -693,7 +693,7 @@ __global__ __launch_bounds__(64) void k_probe(const SubTable st, const uint64_t 
         }
     }
 
-    constexpr int LEVELS = (W_C >= 6 && !TWO && !WIDE && PROBE_STAGED_LEVELS > 1) ? 1 : PROBE_STAGED_LEVELS;  // (W_C >= 6: tables of up to 8 genomes)
+    constexpr int LEVELS = (W_C >= 6 && !TWO && !WIDE && PROBE_STAGED_LEVELS > 1) ? 1 : PROBE_STAGED_LEVELS;  // (W_C >= 6: the wide-window tables of up to 16 genomes)
     drain_queue<TWO, ROWMODE, SLOTS, PROBE_MAXRUN, WIDE, LEVELS>(st, qn, sw, rw, q_line, q_step, q_pl, lines_w[0], buf[0], tile_rows, nbytes, rc, lane);
     if constexpr (ROWMODE == 3) {
         // the tile's columns: 8 slots x `width` (= nbytes) genomes, slot-major — what k_cols_extract would have written

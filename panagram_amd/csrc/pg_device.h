@@ -87,7 +87,7 @@ struct TableDesc {
 //  * the m-mers must stay long enough that distinct loci rarely share one: with 4^m below ~4x the
 //    number of keys the groups merge and throughput collapses (k=21, 100 Mb genomes: m=15 100 G
 //    k-mers/s, m=14 84 G, m=13 23 G).
-// So m = max(k - w_target + 1, ceil(log4(4 * keys))) with w_target = 8 up to 8 genomes and 4 beyond,
+// So m = max(k - w_target + 1, ceil(log4(4 * keys))) with w_target = 8 up to 16 genomes and 4 beyond,
 // w = k-m+1 kept in 3..8.  m-mers longer than 16 bases use 64-bit arithmetic.
 constexpr uint32_t MZ_WMIN = 3, MZ_WMAX = 8;
 __host__ __device__ __forceinline__ uint32_t minimizer_length(uint32_t k, uint64_t expected_keys, uint32_t ngenomes) {
@@ -97,7 +97,7 @@ __host__ __device__ __forceinline__ uint32_t minimizer_length(uint32_t k, uint64
         m_need = 15;
         while (m_need < 27 && (1ull << (2 * m_need)) < 4 * expected_keys) ++m_need;
     }
-    const uint32_t w_target = ngenomes <= 8 ? MZ_WMAX : 4u;
+    const uint32_t w_target = ngenomes <= 16 ? MZ_WMAX : 4u;  // (re-measured in round 2, tools/w_sweep.sh: 12 and 16 genomes w=7 120 G k-mers/s, w=4 116-118; 27 genomes 112 / 117)
     uint32_t m = k - (w_target - 1);
     if (m < m_need) m = m_need;
     if (m > k - (MZ_WMIN - 1)) m = k - (MZ_WMIN - 1);
