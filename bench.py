@@ -151,14 +151,17 @@ class Pangenome:
         L = sum(contig_lens)
         novel = 1.0 - (1.0 - d) ** k
         g_lo, g_hi = (0, G) if block is None else block  # genome block of the table (genome-sharded mode)
-        est = int(L * (1 + max(0, g_hi - g_lo - 1) * novel) * 1.05) * groups
+        # a rank's table holds the k-mers of ITS contig group (what its anchoring can ask for); the other groups' sequences
+        # only set their bits in it (pg_table_update_seqset) — Index.build_table does the same with the genomes a rank anchors
+        self.filtered = groups > 1 and os.environ.get("PG_FULL_TABLE", "") in ("", "0")
+        est = int(L * (1 + max(0, g_hi - g_lo - 1) * novel) * 1.05) * (1 if self.filtered else groups)
         t0 = time.perf_counter()
         self.table = engine.PanTable(ctx, k, g_hi - g_lo, expected_keys=est)
         if minimizer >= 0:
             self.table.set_minimizer(minimizer)
         self.seqsets, self.ascii = None, None
         self.build_s = 0.0
-        for j in range(groups):
+        for j in ([my_group] + [x for x in range(groups) if x != my_group]):
             genomes = synth_genomes_device(G, contig_lens, d, seed + 7919 * j, dev)
             torch.cuda.synchronize()
             seqsets = []
@@ -170,7 +173,10 @@ class Pangenome:
             ctx.synchronize()
             tb = time.perf_counter()
             for g in range(g_lo, g_hi):
-                self.table.insert_seqset(g - g_lo, seqsets[g])
+                if self.filtered and j != my_group:
+                    self.table.update_seqset(g - g_lo, seqsets[g])
+                else:
+                    self.table.insert_seqset(g - g_lo, seqsets[g])
             ctx.synchronize()
             self.build_s += time.perf_counter() - tb
             if j == my_group:
@@ -526,7 +532,9 @@ def main():
                        (8, 3000, 21): "the shape of BASELINE.json configs[4] on ONE GPU, at a divergence whose table fits"
                        }.get(shape, "not a BASELINE.json config")
     if groups > 1 and world == 1:
-        workload = (f"EMULATED rank {my_group} of {groups}: {G} synthetic {args.genome_mb * groups:g} Mb genomes, table of all of it, "
+        tbl_txt = ("the table of the k-mers of this rank's contigs (the rest of the pangenome only sets bits in it)"
+                   if pg.filtered else "table of all of it")
+        workload = (f"EMULATED rank {my_group} of {groups}: {G} synthetic {args.genome_mb * groups:g} Mb genomes, {tbl_txt}, "
                     f"this rank's {C} contigs of every genome anchored")
         parallelism = f"one GPU playing rank {my_group} of a contig-sharded x{groups} run"
     elif world == 1:
@@ -534,10 +542,12 @@ def main():
                     f"anchored per step, table resident in one GPU's HBM ({baseline_config})")
         parallelism = "one GPU"
     else:
+        tbl_txt = ("every GPU's table built from the contigs it anchors, the rest of the pangenome only setting bits in it"
+                   if pg.filtered else "one table of all of it replicated on every GPU")
         workload = (f"{G} synthetic {args.genome_mb * world:g} Mb genomes ({C * world} contigs of {L // C / 1e6:g} Mb each), k={k}, "
-                    f"d={args.d}: the configs[1] pangenome made {world}x longer, one table of all of it replicated on every GPU, "
+                    f"d={args.d}: the configs[1] pangenome made {world}x longer, {tbl_txt}, "
                     f"the {C * world} contig groups dealt to the {world} ranks ({C} contigs of every genome each)")
-        parallelism = f"contig-sharded x{world}: disjoint contigs per rank, replicated table, no data-path collective"
+        parallelism = f"contig-sharded x{world}: disjoint contigs per rank, a table per rank, no data-path collective"
     out = {
         "metric": "anchored k-mers/sec building pan-kmer bitmap",
         "value": value,

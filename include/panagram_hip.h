@@ -102,6 +102,11 @@ int pg_table_clear(pg_table *tbl);
  * contig of `seqs` gets bit genome_idx%32 set in group genome_idx/32.
  * Grows the table as needed.  Synchronises. */
 int pg_table_insert_seqset(pg_table *tbl, int genome_idx, const pg_seqset *seqs);
+/* bits only: bit genome_idx goes into the k-mers of `seqs` that the table ALREADY holds, no key is added.  Building the
+ * table from the genomes a process anchors (pg_table_insert_seqset) and updating it with all the others gives every
+ * look-up of the anchor step (cpp/anchor.cpp:148: the k-mers of the anchor FASTA itself) the answer the table of all
+ * genomes gives, in a fraction of its memory.  Synchronises. */
+int pg_table_update_seqset(pg_table *tbl, int genome_idx, const pg_seqset *seqs);
 /* same with KMC's -ci<min_count> cut-off: only canonical k-mers occurring at least min_count times
  * in the seqset enter the table (the reference counts FASTQ samples with -ci2,
  * workflow/Snakefile:88-89; min_count <= 1 is pg_table_insert_seqset) */

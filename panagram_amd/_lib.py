@@ -45,6 +45,7 @@ PROTOTYPES = {
     "pg_table_clear": (C.c_int, [_vp]),
     "pg_table_insert_seqset": (C.c_int, [_vp, C.c_int, _vp]),
     "pg_table_insert_seqset_min": (C.c_int, [_vp, C.c_int, _vp, C.c_uint32]),
+    "pg_table_update_seqset": (C.c_int, [_vp, C.c_int, _vp]),
     "pg_table_insert_keys": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_uint64]),
     "pg_table_load_kmc1": (C.c_int, [_vp, C.c_int, _vp, C.c_size_t, _vp, C.c_size_t]),
     "pg_table_load_kmc": (C.c_int, [_vp, C.c_int, _vp, C.c_size_t, _vp, C.c_size_t]),

@@ -731,7 +731,9 @@ constexpr int INSERT_QCAP = 256;
 // else here (3.2 of them per new key were 11 of the first genome's 13 ms at config 2); now about one per new key.
 // A line is read with 8 relaxed atomic loads in flight together (volatile loads are waited for one by one).
 // r: 0 = existed, 1 = newly claimed, -1 = gave up after max_probe lines.
-template <bool COUNT>
+// CLAIM = false (update-only builds, pg_table_update_seqset): a key the table does not hold is left out — the walk ends at
+// the first line that is not full, nothing is claimed.
+template <bool COUNT, bool CLAIM = true>
 __device__ __forceinline__ int wave_insert_batch(const SubTable &st, bool valid, uint64_t key, uint32_t grp, int w, uint32_t bits,
                                                  uint32_t max_probe, int lane) {
     const uint32_t kstride = st.layout == LAYOUT_SPLIT ? 8u : 16u, slots = st.slots;
@@ -784,11 +786,13 @@ __device__ __forceinline__ int wave_insert_batch(const SubTable &st, bool valid,
                 if (fr < 0 && f8 >= 0) fr = (int)s0 + f8;
             }
             if (hit >= 0) resolve((uint32_t)hit, false);
+            else if (!CLAIM && fr >= 0) done = true;  // not in a line that is not full: the table does not hold it
             else {
                 s = fr >= 0 ? fr : (int)slots;
                 fresh = true;
             }
         }
+        if constexpr (!CLAIM) continue;  // (s is -1 or slots here: read the next line, or finished)
 #if PG_INSERT_SPREAD
         // The lanes of a run that have just read their line claim DISTINCT slots in one round: first empty slot + rank
         // in the run.  A claim made this way has not yet seen the slots below it; it sees them right after — every slot
@@ -885,6 +889,8 @@ __global__ __launch_bounds__(64) void k_insert_tile(const SubTable st, int w, ui
     const int lane = threadIdx.x;
     const int k = (int)st.k;
     const bool split = st.layout == LAYOUT_SPLIT;  // (uniform)
+    const bool update_only = (count_mode & 2u) != 0;  // pg_table_update_seqset: bits for keys already there, no new keys
+    count_mode &= 1u;
     const uint32_t tile = blockIdx.x;
     uint32_t c = 0;  // contig of the tile: last c with tile0[c] <= tile (uniform binary search)
     {
@@ -925,8 +931,9 @@ __global__ __launch_bounds__(64) void k_insert_tile(const SubTable st, int w, ui
             const bool valid = e < qn;
             const uint32_t ec = valid ? e : qn - 1;
             const uint64_t key = canonical_from_le(extract_bases32(reinterpret_cast<const uint32_t *>(sw), q_pl[ec]), k);
-            const int r = count_mode ? wave_insert_batch<true>(st, valid, key, q_grp[ec], w, bits, max_probe, lane)
-                                     : wave_insert_batch<false>(st, valid, key, q_grp[ec], w, bits, max_probe, lane);
+            const int r = update_only ? wave_insert_batch<false, false>(st, valid, key, q_grp[ec], w, bits, max_probe, lane)
+                          : count_mode ? wave_insert_batch<true>(st, valid, key, q_grp[ec], w, bits, max_probe, lane)
+                                       : wave_insert_batch<false>(st, valid, key, q_grp[ec], w, bits, max_probe, lane);
             overflowed |= __ballot(r < 0) != 0;
             claimed += (uint32_t)__popcll(__ballot(r > 0));
         }
@@ -967,7 +974,7 @@ __global__ __launch_bounds__(64) void k_insert_tile(const SubTable st, int w, ui
         const unsigned long long lmask = __ballot(leader);
         const uint32_t rid = lanes_le_count(lmask, leader) - 1;
         const uint32_t nruns = (uint32_t)__popcll(lmask);
-        bool found = false;
+        bool found = false, full = true;  // full: the staged home line had no empty slot (or was not reached)
         for (uint32_t r0 = 0; r0 < nruns; r0 += PROBE_MAXRUN) {
             const uint32_t nl = min((uint32_t)PROBE_MAXRUN, nruns - r0);
             if (leader && rid - r0 < nl) lines_w[rid - r0] = line;
@@ -990,7 +997,7 @@ __global__ __launch_bounds__(64) void k_insert_tile(const SubTable st, int w, ui
                 uint32_t cur = 0;
                 if (split) {
                     uint32_t slot1;
-                    scan_keys16_lds<true>(ln, key, slot1);
+                    full = scan_keys16_lds<true>(ln, key, slot1) < 0;
                     if (slot1) {
                         found = true;
                         mp = reinterpret_cast<uint32_t *>(st.masks) + ((uint64_t)line * SPLIT_KEYS + (slot1 - 1u)) * st.W + (uint32_t)w;
@@ -1016,6 +1023,7 @@ __global__ __launch_bounds__(64) void k_insert_tile(const SubTable st, int w, ui
                         }
                     }
                     const unsigned long long b0 = e[1] | e[3] | e[5] | e[7], b1 = e[2] | e[3] | e[6] | e[7], b2 = e[4] | e[5] | e[6] | e[7];
+                    full = kk[7] != EMPTY_KEY;
                     (void)m0;
                     (void)m1;
                     if (__builtin_amdgcn_inverse_ballot_w64(b0 | b1 | b2 | e[0])) {
@@ -1037,7 +1045,8 @@ __global__ __launch_bounds__(64) void k_insert_tile(const SubTable st, int w, ui
             __syncthreads();
         }
         // absent from the snapshot of its line (or the line was not reached): queue for the claiming insert
-        const bool todo = act && !found;
+        // (update-only: a key missing from a home line that is not full is not in the table — lines fill front to back)
+        const bool todo = act && !found && (!update_only || full);
         const unsigned long long tmask = __ballot(todo);
         if (tmask) {
             if (qn + 64 > (uint32_t)INSERT_QCAP) drain();

@@ -674,6 +674,30 @@ extern "C" int pg_table_insert_seqset(pg_table *t, int g, const pg_seqset *sq) {
     return fail(PG_E_CAPACITY, "k-mer table keeps overflowing");
 }
 
+// Bits only: genome g's bit goes into the keys of `sq`'s k-mers that the table ALREADY holds; no key is added.  A table
+// built from the genomes a process anchors and then updated with all the others answers every look-up the anchoring
+// makes exactly as the table of all genomes does — a position's k-mer is one of the anchors' own — at a fraction of its
+// size.  (Tables of 256-byte lines, PG_TABLE_SLOTS=16 / PG_INSERT_PER_THREAD, have no such kernel: they insert.)
+extern "C" int pg_table_update_seqset(pg_table *t, int g, const pg_seqset *sq) {
+    if (!t || !sq) return fail(PG_E_INVALID, "pg_table_update_seqset: NULL argument");
+    if (g < 0 || g >= t->ngenomes) return fail(PG_E_INVALID, "genome index %d out of range (0..%d)", g, t->ngenomes - 1);
+    if (t->ctx != sq->ctx) return fail(PG_E_INVALID, "table and seqset belong to different contexts");
+    const SubTable &d0 = t->subs[0].d;
+    if (!(d0.layout == LAYOUT_SPLIT || d0.slots == 8) || getenv("PG_INSERT_PER_THREAD")) return pg_table_insert_seqset(t, g, sq);
+    if (int r = use_device(t->ctx)) return r;
+    TABLE_WRITER(t);
+    const int w = g / 32;
+    const uint32_t bits = 1u << (g % 32);
+    hipStream_t st = t->ctx->stream;
+    HIP_TRY(hipMemsetAsync(t->d_counters, 0, 2 * sizeof(unsigned long long), st));
+    uint32_t *d_tile0 = nullptr;
+    const int er = enqueue_insert(t, t->subs[0].d, w, bits, 2 /* update only */, sq, t->d_counters, &d_tile0);
+    unsigned long long cnt[2] = {0, 0};
+    const int rr = er ? er : read_counters(t, cnt);  // (synchronises)
+    if (d_tile0) hipFree(d_tile0);
+    return rr;
+}
+
 // kmc -ci<min_count> (workflow/Snakefile:88-89: -ci2 for FASTQ samples): occurrences are counted in
 // a private table first; the keys seen at least min_count times then enter the pan table.
 extern "C" int pg_table_insert_seqset_min(pg_table *t, int g, const pg_seqset *sq, uint32_t min_count) {

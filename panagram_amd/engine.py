@@ -350,6 +350,11 @@ class PanTable(_Owner):
             return
         check(self._lib.pg_table_insert_seqset(self._h, genome_idx, seqs._h))
 
+    def update_seqset(self, genome_idx: int, seqs: SeqSet) -> None:
+        """OR genome ``genome_idx``'s bit into the k-mers of ``seqs`` that the table ALREADY holds; no key is added
+        (a table of the anchors' k-mers only answers the anchor step like the table of all genomes)"""
+        check(self._lib.pg_table_update_seqset(self._h, genome_idx, seqs._h))
+
     def clear(self) -> None:
         """empty the table, keeping its allocation (the next genome block is built in the same memory)"""
         check(self._lib.pg_table_clear(self._h))

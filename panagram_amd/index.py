@@ -225,8 +225,10 @@ class Index:
     # how a multi-process run divides the work (see run()): None = decide from the table's size
     shard: Optional[str] = dataclasses.field(default_factory=lambda: os.environ.get("PG_SHARD") or None)
     genome_blocks: int = dataclasses.field(default_factory=lambda: int(os.environ.get("PG_GENOME_BLOCKS", "0")))
+    # build the replicated table from the genomes this process anchors, the other samples only set bits (PG_FULL_TABLE=1: all k-mers)
+    filtered_table: bool = dataclasses.field(default_factory=lambda: os.environ.get("PG_FULL_TABLE", "") in ("", "0"))
 
-    _EXTRA = ("device", "export_kmc", "rank", "world", "shard", "genome_blocks")
+    _EXTRA = ("device", "export_kmc", "rank", "world", "shard", "genome_blocks", "filtered_table")
     # keys of config.yaml that describe one invocation, not the index: not taken over when a directory is re-opened
     # (`prepare` is written for schema compatibility, but a later `index <dir>` run must not stop at "Prepared")
     _NOT_IN_CONFIG = ("input", "mode", "prefix", "prepare")
@@ -440,6 +442,19 @@ class Index:
         est = engine.KmerSketch.estimate_registers(regs)
         return est + est // 32 + 1024
 
+    def _replicated_keys(self, inputs) -> int:
+        """distinct k-mers of the largest table a rank holds in the replicated mode: the union of the genomes it anchors
+        (``build_table``'s filtered build) — or of all samples where that build does not apply.  The same answer in
+        every process."""
+        if not (self.filtered_table and not self.export_kmc and all(i[3] <= 1 for i in inputs)):
+            return self._expected_keys(inputs)
+        writer = self.writer_of_anchor() if self.world > 1 else {a: 0 for a in self.anchor_genomes}
+        worst = 0
+        for r in range(max(1, self.world)):
+            mine = [i for i in inputs if writer.get(i[0]) == r]
+            worst = max(worst, self._expected_keys(mine) if mine else 0)
+        return worst or self._expected_keys(inputs)
+
     def build_table(self, keep: Optional[Sequence[str]] = None) -> engine.PanTable:
         """``keep``: the genomes whose packed sequences stay resident for the anchor step (default: all anchors)"""
         keep = set(self.anchor_genomes if keep is None else keep)
@@ -457,16 +472,28 @@ class Index:
             # table (and settles its minimizer length) once: no re-hash while it grows, no second
             # copy of the table in HBM.  Anchors keep their sequences for the anchor step.
             inputs = self.load_inputs()
-            expected = self._expected_keys(inputs)
+            # The anchor step only ever asks for k-mers of the genomes THIS process anchors (``keep``): the table is
+            # built from those and the other samples only set their bits in it (pg_table_update_seqset) — the rows are
+            # the ones the table of all genomes gives, the table is as small as the anchors' own k-mer set (a rank of a
+            # multi-GPU run, or a pangenome in which only some genomes are anchors).  Not when the merged databases
+            # are to be exported, nor with read-set samples (their -ci2 count tables merge through the inserting path).
+            first = [i for i in inputs if i[0] in keep]
+            rest = [i for i in inputs if i[0] not in keep]
+            filtered = (self.filtered_table and not self.export_kmc and first and rest and all(i[3] <= 1 for i in inputs))
+            expected = self._expected_keys(first if filtered else inputs)
             tbl = engine.PanTable(self.context, self.k, self.ngenomes, expected_keys=expected)
-            for name, g, ss, min_count, _ in inputs:
-                tbl.insert_seqset(g.id, ss, min_count=min_count)
+            for name, g, ss, min_count, _ in (first + rest if filtered else inputs):
+                if filtered and name not in keep:
+                    tbl.update_seqset(g.id, ss)
+                else:
+                    tbl.insert_seqset(g.id, ss, min_count=min_count)
                 if min_count > 1:
                     ss.close()
                 elif name not in keep:
                     self.drop_seqset(name)
             self._inputs = None
-            logger.info("k-mer table built on GPU (sketch: %d distinct k-mers): %s", expected, tbl.stats())
+            logger.info("k-mer table built on GPU (sketch: %d distinct k-mers%s): %s", expected,
+                        f" of the {len(first)} genomes anchored here" if filtered else "", tbl.stats())
             if self.export_kmc:
                 os.makedirs(self.get_subdir("kmc"), exist_ok=True)
                 for i, p in enumerate(self.bitvec_prefixes):
@@ -515,7 +542,7 @@ class Index:
         # next to the table: two batches of rows (one being written, one being anchored), at least one anchor each
         budget = free - self.HBM_RESERVE - 2 * min(self.batch_bytes, max(longest * nb, 1 << 30))
         by_id = {i[1].id: i for i in inputs}
-        if self.shard is None and engine.PanTable.bytes_for(self.k, N, self._expected_keys(inputs)) <= budget:
+        if self.shard is None and engine.PanTable.bytes_for(self.k, N, self._replicated_keys(inputs)) <= budget:
             return "replicated", 1
         nblocks = max(1, self.world)
         while True:

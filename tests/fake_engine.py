@@ -159,6 +159,10 @@ class PanTable:
         self._min[g] = min_count
         self._dbs = None
 
+    def update_seqset(self, g, ss: SeqSet):
+        # (bits for keys already present only; the stand-in keeps whole k-mer sets — rows of anchored positions are the same)
+        self.insert_seqset(g, ss)
+
     def dbs(self):
         if self._dbs is None:
             self._dbs = po.build_bitvec_dbs(self._genomes, self.k, self._min)

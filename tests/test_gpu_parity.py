@@ -476,6 +476,46 @@ def test_tandem_repeats_equal_kmers_within_a_batch(ctx, k, period):
     tbl.close()
 
 
+@pytest.mark.parametrize("n,k,dense", [(9, 21, False), (40, 31, False), (70, 21, False), (9, 21, True)])
+def test_table_of_the_anchors_kmers_only(ctx, n, k, dense):
+    """pg_table_update_seqset: a table built from the anchor genomes, the other genomes only setting bits in it, holds
+    exactly the anchors' k-mers (each with the full presence mask) and anchors those genomes like the table of all
+    genomes — also when it is dense enough for keys to sit in overflow lines (the update follows the chain)."""
+    from panagram_amd import engine
+    gen = po.synth_genomes(n, [6000, 1800, 300], 0.03, 4100 + n)
+    genomes = [[po.codes_to_ascii(c) for c in g] for g in gen]
+    anchors = [1, n - 1]
+    dbs = po.build_bitvec_dbs(genomes, k)
+    sets = [engine.SeqSet.from_host(ctx, g) for g in genomes]
+    own = engine.KmerSketch(ctx, k)
+    for g in anchors:
+        own.add(sets[g])
+    tbl = engine.PanTable(ctx, k, n, expected_keys=max(1024, own.estimate() // (6 if dense else 1)))
+    own.close()
+    for g in anchors:
+        tbl.insert_seqset(g, sets[g])
+    nk = tbl.stats()["nkeys"]
+    for g in range(n):
+        if g not in anchors:
+            tbl.update_seqset(g, sets[g])
+    assert tbl.stats()["nkeys"] == nk  # nothing was added
+    akeys = np.unique(np.concatenate([po.build_bitvec_dbs([genomes[g]], k)[0][0] for g in anchors]))
+    for d, (fk, fm) in enumerate(dbs):
+        keys, vals = tbl.export(d)
+        o = np.argsort(keys)
+        sel = np.isin(fk, akeys) & (fm != 0)
+        assert np.array_equal(keys[o], fk[sel]) and np.array_equal(vals[o], fm[sel])
+    for g in anchors:
+        for seq in genomes[g]:
+            rows, rows100, bins, cs = tbl.anchor_contig(seq)
+            o_rows, o_rows100, o_bins, _, o_cs = po.anchor_contig(dbs, seq, k, n)
+            assert np.array_equal(rows, o_rows) and np.array_equal(bins.astype(np.int64), o_bins)
+            assert np.array_equal(cs.astype(np.int64), o_cs)
+    for ss in sets:
+        ss.close()
+    tbl.close()
+
+
 @pytest.mark.parametrize("k", [21, 31])
 def test_cooperative_build_equals_per_thread_build(ctx, k, monkeypatch):
     """k_insert_tile (a run's lanes claim distinct slots in one round, later copies of a key retired) against the
