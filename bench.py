@@ -418,10 +418,14 @@ def main():
     ap.add_argument("--k", type=int, default=21)
     ap.add_argument("--d", type=float, default=0.01)
     ap.add_argument("--seed", type=int, default=1234)
-    ap.add_argument("--keys-per-bucket", type=float, default=2.0)
+    ap.add_argument("--keys-per-bucket", type=float, default=0.0,
+                    help="re-hash the built table to this many keys per 128-byte line (tuning experiments; default 0: keep the "
+                         "table as the library builds it from its expected key count, as Index.run() does — in insertion "
+                         "order the keys that most genomes share sit in their minimizer's home line, a re-hash scatters them: "
+                         "167 vs 155 G k-mers/s)")
     ap.add_argument("--minimizer", type=int, default=-1, help="pin the table's minimizer length (tuning; default: library's choice)")
     ap.add_argument("--no-colsums", action="store_true")
-    ap.add_argument("--no-rehash", action="store_true",
+    ap.add_argument("--no-rehash", action="store_true",  # (the default now; kept for older command lines)
                     help="keep the table as created from the expected key count (a re-hash holds the table twice in HBM)")
     ap.add_argument("--per-genome-launches", action="store_true",
                     help="one launch per anchor genome instead of one co-scheduled launch over all of them")
@@ -488,8 +492,9 @@ def main():
     # ---- k-mer set construction on the GPU (replaces kmc + kmc_tools; timed separately) ----
     keep_ascii = rank == 0 and world == 1 and not args.no_cpu_baseline
     pg = Pangenome(ctx, dev, G, contig_lens, args.d, args.seed, k, groups=groups, my_group=my_group, keep_ascii=keep_ascii,
-                   minimizer=args.minimizer, rehash_kpb=None if (args.no_rehash or groups > 1) else args.keys_per_bucket)
+                   minimizer=args.minimizer, rehash_kpb=None if (args.no_rehash or groups > 1 or args.keys_per_bucket <= 0) else args.keys_per_bucket)
     st = pg.stats
+    pg_rehashed = not (args.no_rehash or groups > 1 or args.keys_per_bucket <= 0)
     pos_per_step = sum(pg.pos_per_genome)
 
     results, merged = make_results(ctx, pg, not args.no_colsums, args.per_genome_launches, args.piece_tiles)
@@ -564,7 +569,8 @@ def main():
         "config": {
             "workload": workload,
             "positions_per_step_per_gpu": pos_per_step,
-            "table_keys": st["nkeys"], "table_bytes": st["bytes"], "keys_per_128B_line": args.keys_per_bucket,
+            "table_keys": st["nkeys"], "table_bytes": st["bytes"], "keys_per_128B_line": round(st["nkeys"] / max(1, st["nbuckets"]), 3),
+            "table_rehashed": bool(pg_rehashed),
             "table_build_s": pg.build_s, "table_spill_fraction": pg.table.spill()[0], "table_slots_per_line": pg.table.spill()[1],
             "probes_per_position": (G + 63) // 64, "nbytes": (G + 7) // 8,
             "colsums": not args.no_colsums,
