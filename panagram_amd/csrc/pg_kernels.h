@@ -82,9 +82,9 @@ hipError_t launch_insert_keys(hipStream_t st, const SubTable &t, int w, const ui
 hipError_t launch_import_kmc(hipStream_t st, const SubTable &t, int w, const uint8_t *rec, uint64_t first_record, uint64_t nrec,
                              const uint64_t *lut, uint64_t nlut, uint32_t prefixes_per_bin, uint32_t suffix_bytes,
                              uint32_t counter_bytes, uint32_t min_count, uint32_t max_count, unsigned long long *counters,
-                             uint32_t max_probe);
+                             uint32_t max_probe, uint32_t phase = 2, uint32_t dense_above = 0);
 hipError_t launch_rehash(hipStream_t st, const SubTable &src, const SubTable &dst,
-                         unsigned long long *counters, uint32_t max_probe);
+                         unsigned long long *counters, uint32_t max_probe, uint32_t ngenomes);
 hipError_t launch_export(hipStream_t st, const SubTable &t, int w, uint64_t *keys, uint32_t *vals,
                          uint64_t cap, unsigned long long *count);
 hipError_t launch_counters(hipStream_t st, const SubTable &t, int w, int k, const uint64_t *seqw,

@@ -290,7 +290,10 @@ __global__ __launch_bounds__(256) void k_import_kmc(SubTable st, int w, const ui
                                                     const unsigned long long *__restrict__ lut, uint64_t nlut,
                                                     uint32_t prefixes_per_bin, uint32_t suffix_bytes, uint32_t counter_bytes,
                                                     uint32_t min_count, uint32_t max_count,
-                                                    unsigned long long *counters, uint32_t max_probe) {
+                                                    unsigned long long *counters, uint32_t max_probe, uint32_t phase,
+                                                    uint32_t dense_above) {
+    // phase 0: only records whose mask has more than dense_above bits; 1: only the others; 2: all.  The keys most genomes
+    // share go in first and take their minimizer's home line — they are the ones most look-ups ask for
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     const uint32_t rb = suffix_bytes + counter_bytes;
@@ -300,6 +303,7 @@ __global__ __launch_bounds__(256) void k_import_kmc(SubTable st, int w, const ui
         uint32_t c = counter_bytes ? 0u : 1u;  // (KMC writes no counter bytes when every count is 1)
         for (uint32_t b = 0; b < counter_bytes; ++b) c |= (uint32_t)q[suffix_bytes + b] << (8 * b);
         if (c == 0 || c < min_count || c > max_count) continue;  // outside [min, max] reads as absent
+        if (phase < 2u && ((uint32_t)__popc(c) > dense_above) != (phase == 0u)) continue;
         const uint64_t r = first_record + i;
         uint64_t lo = 0, hi = nlut;  // last entry <= r  (lut[0] = 0 <= r always)
         while (hi - lo > 1) {
@@ -317,8 +321,9 @@ __global__ __launch_bounds__(256) void k_import_kmc(SubTable st, int w, const ui
 }
 
 // re-hash every occupied slot of `src` into `dst` (same W)
+// (phase / dense_above as in k_import_kmc: the keys of most genomes first)
 __global__ __launch_bounds__(256) void k_rehash(SubTable src, SubTable dst, unsigned long long *counters,
-                                                uint32_t max_probe) {
+                                                uint32_t max_probe, uint32_t phase, uint32_t dense_above) {
     const int ns = (int)src.slots;
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
@@ -329,6 +334,11 @@ __global__ __launch_bounds__(256) void k_rehash(SubTable src, SubTable dst, unsi
         int s = (int)(i - b * ns);
         uint64_t key = *key_ptr(src, b, (uint32_t)s);
         if (key >= TOMB_KEY) continue;  // empty, or a retired copy
+        if (phase < 2u) {
+            uint32_t pc = 0;
+            for (uint32_t w = 0; w < src.W; ++w) pc += (uint32_t)__popc(*mask_ptr(src, b, (uint32_t)s, w));
+            if ((pc > dense_above) != (phase == 0u)) continue;
+        }
         for (uint32_t w = 0; w < src.W; ++w) {
             uint32_t m = *mask_ptr(src, b, (uint32_t)s, w);
             if (m == 0 && w > 0) continue;
@@ -488,19 +498,24 @@ hipError_t launch_insert_keys(hipStream_t st, const SubTable &t, int w, const ui
 hipError_t launch_import_kmc(hipStream_t st, const SubTable &t, int w, const uint8_t *rec, uint64_t first_record, uint64_t nrec,
                              const uint64_t *lut, uint64_t nlut, uint32_t prefixes_per_bin, uint32_t suffix_bytes,
                              uint32_t counter_bytes, uint32_t min_count, uint32_t max_count, unsigned long long *counters,
-                             uint32_t max_probe) {
+                             uint32_t max_probe, uint32_t phase, uint32_t dense_above) {
     if (nrec == 0) return hipSuccess;
     hipLaunchKernelGGL(k_import_kmc, dim3(grid_for(nrec, 256, 256 * 64)), dim3(256), 0, st, t, w, rec, first_record, nrec,
                        reinterpret_cast<const unsigned long long *>(lut), nlut, prefixes_per_bin, suffix_bytes, counter_bytes,
-                       min_count, max_count, counters, max_probe);
+                       min_count, max_count, counters, max_probe, phase, dense_above);
     return hipGetLastError();
 }
 
 hipError_t launch_rehash(hipStream_t st, const SubTable &src, const SubTable &dst,
-                         unsigned long long *counters, uint32_t max_probe) {
+                         unsigned long long *counters, uint32_t max_probe, uint32_t ngenomes) {
     uint64_t nslots = src.nbuckets * src.slots;
-    hipLaunchKernelGGL(k_rehash, dim3(grid_for(nslots, 256, 256 * 64)), dim3(256), 0, st, src, dst, counters,
-                       max_probe);
+    if (ngenomes < 4) {
+        hipLaunchKernelGGL(k_rehash, dim3(grid_for(nslots, 256, 256 * 64)), dim3(256), 0, st, src, dst, counters, max_probe, 2u, 0u);
+        return hipGetLastError();
+    }
+    for (uint32_t phase = 0; phase < 2; ++phase)  // two passes over the old table: the widely shared keys first
+        hipLaunchKernelGGL(k_rehash, dim3(grid_for(nslots, 256, 256 * 64)), dim3(256), 0, st, src, dst, counters, max_probe, phase,
+                           ngenomes / 2);
     return hipGetLastError();
 }
 
