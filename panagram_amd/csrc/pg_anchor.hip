@@ -2446,6 +2446,11 @@ static hipError_t insert_tiles_w(hipStream_t s, uint32_t ntiles, const SubTable 
     return hipGetLastError();
 }
 
+hipError_t preload_anchor_kernels() {
+    hipFuncAttributes fa;
+    return hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(k_insert_tile<7, false>));
+}
+
 // every k-mer of the contigs described by sd / tile0 (tile0[c] = first tile of contig c; tile0[ncontigs] = ntiles)
 hipError_t launch_insert_tiles(hipStream_t s, const SubTable &st, int w, uint32_t bits, int count_mode, const uint64_t *seqw,
                                const uint32_t *nmw, const uint32_t *has_n, const SeqDesc *sd, const uint32_t *tile0,

@@ -98,6 +98,9 @@ struct pg_table {
     uint64_t expected = 0;  // pg_table_create's expected_keys (0: unknown)
     std::vector<SubHost> subs;
     unsigned long long *d_counters;  // [0] newly claimed, [1] overflow flag
+    unsigned long long *h_counters = nullptr;  // pinned landing place of d_counters (read_counters)
+    uint32_t *d_tile0 = nullptr;     // first tile of every contig of the seqset being inserted (k_tile0), grown on demand
+    size_t tile0_cap = 0;
     double spill = 0;                // keys outside their home line / keys, as of the last pg_table_rehash
     std::atomic<int> refs{0};        // results on this table
     bool dead = false;
@@ -124,12 +127,6 @@ struct pg_seqset {
     std::vector<std::string> names;  // record ids when the seqset was parsed from FASTA text
     std::atomic<int> refs{0};        // results on these sequences
     bool dead = false;
-    // first tile of every contig (+ the total) for the k it was first inserted with, kept on the device: an insert of
-    // this seqset then needs no allocation, upload wait or free of its own (0.4 ms of host time per insert before)
-    mutable std::mutex tile_mu;
-    mutable std::vector<uint32_t> tile0_host;
-    mutable uint32_t *d_tile0 = nullptr;
-    mutable int tile0_k = 0;
 };
 
 struct pg_result {
@@ -208,6 +205,16 @@ extern "C" int pg_ctx_create(int device_id, pg_ctx **out) {
         hipStreamDestroy(c->own_stream);
         delete c;
         return fail(PG_E_HIP, "hipStreamCreate failed: %s", hipGetErrorString(se));
+    }
+    // load the three code objects now (first-launch cost otherwise: ≈ 5 ms inside the first table insert)
+    hipError_t pe = preload_table_kernels();
+    if (pe == hipSuccess) pe = preload_anchor_kernels();
+    if (pe == hipSuccess) pe = preload_deflate_kernels();
+    if (pe != hipSuccess) {
+        hipStreamDestroy(c->aux_stream);
+        hipStreamDestroy(c->own_stream);
+        delete c;
+        return fail(PG_E_HIP, "loading the gfx950 kernels failed: %s (is this an MI355X?)", hipGetErrorString(pe));
     }
     *out = c;
     return PG_OK;
@@ -451,6 +458,10 @@ extern "C" int pg_table_create(pg_ctx *ctx, int k, int ngenomes, uint64_t expect
         return fail(PG_E_HIP, "hipMalloc failed: %s", hipGetErrorString(e));
     }
     hipMemsetAsync(t->d_counters, 0, 2 * sizeof(unsigned long long), ctx->stream);
+    if (hipHostMalloc(reinterpret_cast<void **>(&t->h_counters), 2 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        t->h_counters = nullptr;  // (read_counters then lands in the caller's pageable memory)
+    }
     {
         const TableGeom g = geom_for(ngenomes);
         const uint64_t want = expected_keys ? expected_keys : (1ull << 18);
@@ -474,6 +485,8 @@ static void table_free(pg_table *t) {
     hipStreamSynchronize(t->ctx->stream);
     for (auto &s : t->subs) free_sub(s.d);
     if (t->d_counters) hipFree(t->d_counters);
+    if (t->h_counters) hipHostFree(t->h_counters);
+    if (t->d_tile0) hipFree(t->d_tile0);
     pg_ctx *c = t->ctx;
     delete t;
     ctx_release(c);
@@ -526,9 +539,11 @@ extern "C" int pg_table_set_minimizer(pg_table *t, int m) {
 }
 
 static int read_counters(pg_table *t, unsigned long long out[2]) {
-    HIP_TRY(hipMemcpyAsync(out, t->d_counters, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost,
+    unsigned long long *land = t->h_counters ? t->h_counters : out;
+    HIP_TRY(hipMemcpyAsync(land, t->d_counters, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost,
                            t->ctx->stream));
     HIP_TRY(hipStreamSynchronize(t->ctx->stream));
+    if (land != out) out[0] = land[0], out[1] = land[1];
     return PG_OK;
 }
 
@@ -597,12 +612,12 @@ static int after_insert(pg_table *t, int si) {
 
 // enqueue the insertion of every k-mer of `sq` into sub-table `d` (word w, `bits`; count_mode: occurrences are added):
 // ONE launch of the wave-cooperative kernel over all contigs for tables of 128-byte lines, else one launch of the
-// thread-per-k-mer kernel per contig (256-byte lines: the PG_TABLE_SLOTS=16 tuning knob).  *d_tile0 is a small
-// device array the caller frees once the stream has been synchronised.
+// thread-per-k-mer kernel per contig (256-byte lines: the PG_TABLE_SLOTS=16 tuning knob).  The launch's contig → first
+// tile array is computed on the device into `t`'s own scratch (k_tile0): no allocation, upload or wait per call — the
+// caller holds t's writer lock and everything is ordered on the context's stream.
 static int enqueue_insert(pg_table *t, const SubTable &d, int w, uint32_t bits, int count_mode, const pg_seqset *sq,
-                          unsigned long long *counters, uint32_t **d_tile0) {
+                          unsigned long long *counters) {
     hipStream_t st = t->ctx->stream;
-    *d_tile0 = nullptr;
     const bool tiles_ok = d.layout == LAYOUT_SPLIT || d.slots == 8;
     if (!tiles_ok || getenv("PG_INSERT_PER_THREAD")) {
         for (uint32_t c = 0; c < sq->n; ++c) {
@@ -613,34 +628,25 @@ static int enqueue_insert(pg_table *t, const SubTable &d, int w, uint32_t bits, 
         }
         return PG_OK;
     }
-    std::vector<uint32_t> tile0(sq->n + 1, 0);
     uint64_t tiles = 0;
     for (uint32_t c = 0; c < sq->n; ++c) {
-        tile0[c] = (uint32_t)tiles;
         const uint64_t len = sq->desc[c].len;
         if (len >= (uint64_t)t->k) tiles += (len - t->k + 1 + PROBE_TILE - 1) / PROBE_TILE;
-        if (tiles > 0x7FFFFFFFull) return fail(PG_E_INVALID, "too many tiles in one insert launch");
     }
-    tile0[sq->n] = (uint32_t)tiles;
+    if (tiles > 0x7FFFFFFFull) return fail(PG_E_INVALID, "too many tiles in one insert launch");
     if (tiles == 0) return PG_OK;
-    const uint32_t *dev_tile0 = nullptr;
-    {
-        std::lock_guard<std::mutex> lk(sq->tile_mu);
-        if (!sq->d_tile0) {  // first insert of this seqset: the array stays with it
-            sq->tile0_host = tile0;  // (the upload's source must outlive it)
-            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&sq->d_tile0), tile0.size() * 4));
-            HIP_TRY(hipMemcpyAsync(sq->d_tile0, sq->tile0_host.data(), tile0.size() * 4, hipMemcpyHostToDevice, st));
-            sq->tile0_k = t->k;
+    if (t->tile0_cap < (size_t)sq->n + 1) {
+        if (t->d_tile0) {
+            HIP_TRY(hipStreamSynchronize(st));  // (an earlier launch may still read the old array)
+            hipFree(t->d_tile0);
+            t->d_tile0 = nullptr, t->tile0_cap = 0;
         }
-        if (sq->tile0_k == t->k) dev_tile0 = sq->d_tile0;
+        const size_t cap = std::max<size_t>(1024, ((size_t)sq->n + 1) * 2);
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&t->d_tile0), cap * 4));
+        t->tile0_cap = cap;
     }
-    if (!dev_tile0) {  // the same sequences under another k: an array of this call's own (the caller frees it)
-        HIP_TRY(hipMalloc(reinterpret_cast<void **>(d_tile0), tile0.size() * 4));
-        HIP_TRY(hipMemcpyAsync(*d_tile0, tile0.data(), tile0.size() * 4, hipMemcpyHostToDevice, st));
-        HIP_TRY(hipStreamSynchronize(st));  // (tile0 is a host temporary)
-        dev_tile0 = *d_tile0;
-    }
-    HIP_TRY(launch_insert_tiles(st, d, w, bits, count_mode, sq->d_seqw, sq->d_nmw, sq->d_has_n, sq->d_desc, dev_tile0, sq->n,
+    HIP_TRY(launch_tile0(st, sq->d_desc, sq->n, (uint32_t)t->k, (uint32_t)PROBE_TILE, t->d_tile0));
+    HIP_TRY(launch_insert_tiles(st, d, w, bits, count_mode, sq->d_seqw, sq->d_nmw, sq->d_has_n, sq->d_desc, t->d_tile0, sq->n,
                                 (uint32_t)tiles, counters, MAX_PROBE));
     return PG_OK;
 }
@@ -660,11 +666,9 @@ extern "C" int pg_table_insert_seqset(pg_table *t, int g, const pg_seqset *sq) {
     for (int attempt = 0; attempt < 8; ++attempt) {
         hipStream_t st = t->ctx->stream;
         HIP_TRY(hipMemsetAsync(t->d_counters, 0, 2 * sizeof(unsigned long long), st));
-        uint32_t *d_tile0 = nullptr;
-        const int er = enqueue_insert(t, t->subs[si].d, w, bits, 0, sq, t->d_counters, &d_tile0);
+        const int er = enqueue_insert(t, t->subs[si].d, w, bits, 0, sq, t->d_counters);
         unsigned long long cnt[2] = {0, 0};
         const int rr = er ? er : read_counters(t, cnt);  // (synchronises)
-        if (d_tile0) hipFree(d_tile0);
         if (rr) return rr;
         t->subs[si].count += cnt[0];
         if (cnt[1] == 0) return after_insert(t, si);
@@ -690,12 +694,9 @@ extern "C" int pg_table_update_seqset(pg_table *t, int g, const pg_seqset *sq) {
     const uint32_t bits = 1u << (g % 32);
     hipStream_t st = t->ctx->stream;
     HIP_TRY(hipMemsetAsync(t->d_counters, 0, 2 * sizeof(unsigned long long), st));
-    uint32_t *d_tile0 = nullptr;
-    const int er = enqueue_insert(t, t->subs[0].d, w, bits, 2 /* update only */, sq, t->d_counters, &d_tile0);
+    const int er = enqueue_insert(t, t->subs[0].d, w, bits, 2 /* update only */, sq, t->d_counters);
     unsigned long long cnt[2] = {0, 0};
-    const int rr = er ? er : read_counters(t, cnt);  // (synchronises)
-    if (d_tile0) hipFree(d_tile0);
-    return rr;
+    return er ? er : read_counters(t, cnt);  // (synchronises)
 }
 
 // kmc -ci<min_count> (workflow/Snakefile:88-89: -ci2 for FASTQ samples): occurrences are counted in
@@ -725,13 +726,8 @@ extern "C" int pg_table_insert_seqset_min(pg_table *t, int g, const pg_seqset *s
                 rc = fail(PG_E_HIP, "hipMemsetAsync failed");
                 break;
             }
-            uint32_t *d_tile0 = nullptr;
-            rc = enqueue_insert(t, cnt->subs[0].d, 0, 1u, 1, sq, cnt->d_counters, &d_tile0);
+            rc = enqueue_insert(t, cnt->subs[0].d, 0, 1u, 1, sq, cnt->d_counters);
             if (!rc) rc = read_counters(cnt, c2);
-            if (d_tile0) {
-                hipStreamSynchronize(st);
-                hipFree(d_tile0);
-            }
         } while (0);
         // counting is not idempotent: a table that overflowed (or ran too full) is thrown away and
         // the pass repeated in a bigger one
@@ -1247,7 +1243,6 @@ static void seqset_free(pg_seqset *s) {
     hipFree(s->d_has_n);
     hipFree(s->d_desc);
     if (s->d_stage) hipFree(s->d_stage);
-    if (s->d_tile0) hipFree(s->d_tile0);
     pg_ctx *c = s->ctx;
     delete s;
     ctx_release(c);

@@ -551,6 +551,11 @@ __global__ __launch_bounds__(256) void k_bgzf_pack(const uint8_t *__restrict__ s
     if (threadIdx.x < (sz & 3u)) dst[4 * nw + threadIdx.x] = reinterpret_cast<const uint8_t *>(src)[4 * nw + threadIdx.x];
 }
 
+hipError_t preload_deflate_kernels() {
+    hipFuncAttributes fa;
+    return hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(k_bgzf_offsets));
+}
+
 hipError_t launch_row_deflate(hipStream_t st, const uint8_t *base, const PaySeg *segs, uint32_t nseg, uint64_t total,
                               uint64_t first_block, uint32_t nblocks, uint32_t row, const uint32_t *crc_tabs, uint8_t *slots,
                               uint32_t *sizes, uint32_t force_stored, uint32_t *offs, uint8_t *packed) {

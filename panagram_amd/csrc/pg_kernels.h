@@ -72,6 +72,13 @@ hipError_t launch_insert_seq(hipStream_t st, const SubTable &t, int w, uint32_t 
 hipError_t launch_insert_tiles(hipStream_t st, const SubTable &t, int w, uint32_t bits, int count_mode, const uint64_t *seqw,
                                const uint32_t *nmw, const uint32_t *has_n, const SeqDesc *sd, const uint32_t *tile0,
                                uint32_t ncontigs, uint32_t ntiles, unsigned long long *counters, uint32_t max_probe);
+// Each .hip file is one code object, loaded by the HIP runtime when the first of its kernels is launched — for the anchor
+// kernels' file ≈ 5 ms, which used to land on the first genome's insert.  pg_ctx_create calls these instead.
+hipError_t preload_table_kernels();
+hipError_t preload_anchor_kernels();
+hipError_t preload_deflate_kernels();
+// first tile of every contig (+ the total) of a launch over all contigs of a seqset, computed on the device
+hipError_t launch_tile0(hipStream_t st, const SeqDesc *sd, uint32_t n, uint32_t k, uint32_t tile, uint32_t *tile0);
 hipError_t launch_count_spill(hipStream_t st, const SubTable &t, unsigned long long *counters);
 hipError_t launch_merge_min(hipStream_t st, const SubTable &src, const SubTable &dst, int w, uint32_t bits,
                             uint32_t min_count, unsigned long long *counters, uint32_t max_probe);

@@ -527,6 +527,44 @@ hipError_t launch_merge_min(hipStream_t st, const SubTable &src, const SubTable 
     return hipGetLastError();
 }
 
+// tile0[c] = first 512-position tile of contig c in a launch over all contigs, tile0[n] = their number: the exclusive
+// prefix sum of ceil(nkmers(c) / tile) — one block, each thread a contiguous share of the contigs, the shares' totals
+// scanned through LDS (a build launch's only per-call array: computed where it is used, no allocation or upload)
+__global__ void __launch_bounds__(1024) k_tile0(const SeqDesc *__restrict__ sd, uint32_t n, uint32_t k, uint32_t tile, uint32_t *__restrict__ tile0) {
+    __shared__ uint32_t part[1024];
+    const uint32_t per = (n + 1023) / 1024, lo = min(n, threadIdx.x * per), hi = min(n, lo + per);
+    uint32_t mine = 0;
+    for (uint32_t c = lo; c < hi; ++c) {
+        const uint64_t len = sd[c].len;
+        mine += len >= k ? (uint32_t)((len - k + 1 + tile - 1) / tile) : 0u;
+    }
+    part[threadIdx.x] = mine;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+        const uint32_t v = threadIdx.x >= d ? part[threadIdx.x - d] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t at = part[threadIdx.x] - mine;
+    for (uint32_t c = lo; c < hi; ++c) {
+        tile0[c] = at;
+        const uint64_t len = sd[c].len;
+        at += len >= k ? (uint32_t)((len - k + 1 + tile - 1) / tile) : 0u;
+    }
+    if (threadIdx.x == 1023) tile0[n] = part[1023];
+}
+
+hipError_t preload_table_kernels() {
+    hipFuncAttributes fa;
+    return hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(k_tile0));
+}
+
+hipError_t launch_tile0(hipStream_t st, const SeqDesc *sd, uint32_t n, uint32_t k, uint32_t tile, uint32_t *tile0) {
+    hipLaunchKernelGGL(k_tile0, dim3(1), dim3(1024), 0, st, sd, n, k, tile, tile0);
+    return hipGetLastError();
+}
+
 hipError_t launch_count_spill(hipStream_t st, const SubTable &t, unsigned long long *counters) {
     uint64_t nslots = t.nbuckets * t.slots;
     hipLaunchKernelGGL(k_count_spill, dim3(grid_for(nslots, 256, 256 * 64)), dim3(256), 0, st, t, counters);
