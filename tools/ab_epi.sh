@@ -1,0 +1,9 @@
+#!/bin/bash
+# value, probe ms, statistics-pass ms for the one-byte-row shapes:  bash tools/ab_libs.sh tools/ab_epi.sh tagA tagB
+cd ${GRAFT_REPO_ROOT:-/root/repo}
+for A in "" "--genomes 2 --genome-mb 400" "--genomes 4 --genome-mb 100 --contigs 20000" "--genomes 8 --genome-mb 50 --contigs 500"; do
+  timeout 600 python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-compare --no-other-shapes --no-sharded-leg $A 2>gpurun_out/ab.err | python -c "
+import sys,json
+d=json.loads(sys.stdin.read()); r=d['roofline']
+print('[$1] [$A]', round(d['value']/1e9,1), round(r['avg_launch_ms'],3), round(r['epilogue_kernel_ms'],3))"
+done

@@ -82,7 +82,65 @@ __global__ __launch_bounds__(128) void kP(const uint8_t *p, uint64_t range, uint
     if (acc == 0x12345) out[0] = acc;
 }
 
-int main() {
+// the one-byte statistics pass's geometry: a PERSISTENT grid of 128-thread workgroups over contiguous ranges of a 0.8 GB
+// buffer, lane t reads 2 x 16 B at 32 t per 4 KB step, DEPTH - 1 steps ahead in registers; the grid sets the resident
+// waves (3072 workgroups = 6 waves per SIMD, k_epilogue<0>'s occupancy)
+template <int DEPTH>
+__global__ __launch_bounds__(128) void kE(const uint8_t *p, uint64_t bytes, uint32_t *out) {
+    const uint64_t steps = bytes / 4096;
+    const uint64_t s0 = steps * blockIdx.x / gridDim.x, s1 = steps * (blockIdx.x + 1) / gridDim.x;
+    const int t = threadIdx.x;
+    uint4 buf[DEPTH][2];
+    uint32_t acc = 0;
+    auto issue = [&](uint64_t st, uint4 (&o)[2]) {
+        const uint4 *q = reinterpret_cast<const uint4 *>(p + st * 4096 + 32 * t);
+        o[0] = q[0];
+        o[1] = q[1];
+    };
+#pragma unroll
+    for (int d = 0; d < DEPTH - 1; ++d) issue(s0 + d < s1 ? s0 + d : s0, buf[d]);
+    for (uint64_t st = s0; st < s1; st += DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            const uint64_t nxt = st + d + DEPTH - 1;
+            issue(nxt < s1 ? nxt : s0, buf[(d + DEPTH - 1) % DEPTH]);
+            const uint4 x = buf[d][0], y = buf[d][1];
+            acc += __popc(x.x) + __popc(x.y) + __popc(x.z) + __popc(x.w) + __popc(y.x) + __popc(y.y) + __popc(y.z) + __popc(y.w);
+        }
+    }
+    if (acc == 0x12345) out[0] = acc;
+}
+
+int main(int argc, char **argv) {
+    if (argc > 1 && argv[1][0] == 'e') {
+        const uint64_t bytes = 800ull << 20;
+        uint8_t *d;
+        uint32_t *o;
+        hipMalloc(&d, bytes);
+        hipMalloc(&o, 4);
+        hipEvent_t a, b;
+        hipEventCreate(&a);
+        hipEventCreate(&b);
+        for (int dirty = 0; dirty < 2; ++dirty)
+            for (unsigned grid : {1024u, 2048u, 3072u, 4096u, 8192u}) {
+                float ms[3] = {0, 0, 0};
+                for (int rep = 0; rep < 6; ++rep) {
+#define RUNE(D, SLOT)                                                                         \
+    if (dirty) hipMemsetAsync(d, rep + 1, bytes, 0);                                          \
+    hipEventRecord(a);                                                                        \
+    hipLaunchKernelGGL(kE<D>, dim3(grid), dim3(128), 0, 0, d, bytes, o);                      \
+    hipEventRecord(b);                                                                        \
+    hipEventSynchronize(b);                                                                   \
+    { float m; hipEventElapsedTime(&m, a, b); if (rep) ms[SLOT] += m / 5; }
+                    RUNE(2, 0) RUNE(3, 1) RUNE(4, 2)
+                }
+                printf("E %s grid %5u (%.1f waves/SIMD)  1 ahead %.3f ms %.2f TB/s | 2 ahead %.3f ms %.2f TB/s | 3 ahead %.3f ms %.2f TB/s\n",
+                       dirty ? "just written" : "read before ", grid, grid * 2 / 1024.0, ms[0], bytes / ms[0] / 1e9, ms[1], bytes / ms[1] / 1e9,
+                       ms[2], bytes / ms[2] / 1e9);
+            }
+        return 0;
+    }
+
     const uint64_t bytes = 10ull << 30;
     uint8_t *d;
     uint32_t *o;
