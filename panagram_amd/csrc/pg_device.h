@@ -79,16 +79,21 @@ struct TableDesc {
 
 // Minimizer geometry of a table: w m-mers of m = k-w+1 bases per k-mer (m = 0: hash the k-mer
 // itself, k < 20).  Two forces (measured on MI355X):
-//  * a wide window gives long runs of positions per fetched line, a narrow one gives small
-//    minimizer groups (a group = all variants of a locus, from every genome) that fit their home
-//    line.  With few genomes the fetches weigh more: w = 8 (k=31, 8 genomes: 138 G k-mers/s vs 127 at
-//    w = 4).  With many genomes the groups outgrow a line and, co-scheduled, the lines come from L2
-//    anyway: w = 4 (64 genomes k=21: 89 G vs 61 at w = 7; 40 genomes: 63 vs 48; 16: 89 vs 86).
+//  * a wide window gives long runs of positions per fetched line — at w = 7 / 8 a 64-lane batch
+//    meets about 13 distinct lines, which ONE staging step (16 lines) takes; w = 4 meets 24 (two
+//    steps), and w = 5 / 6 sit just above 16 and pay the second step for a few lines (measured
+//    worse than w = 4) — a narrow one gives small minimizer groups (a group = all variants of a
+//    locus, from every genome) that fit their home line.  Since the overflow levels are staged and
+//    the build claims a run's slots in one round, the wide window wins whatever the genome count
+//    (tools/w_sweep_wide.sh, profiles/r2_w_sweep.txt; G k-mers/s at w = 8 / 7 / 6 / 5 / 4 —
+//    k=31: 27 genomes 136 / 133 / 120 / 114 / 118, 64: 123 / 126 / 113 / 110 / 116, 128: 69 / 69 / 65 / 63 / 63;
+//    k=21 (m >= 15: w <= 7): 27 genomes - / 133 / 123 / 116 / 119, 64: - / 118 / 112 / 109 / 111).  Round 1's kernels
+//    had it the other way round for more than 16 genomes (64 genomes k=21: 89 G at w = 4, 61 at w = 7).
 //  * the m-mers must stay long enough that distinct loci rarely share one: with 4^m below ~4x the
 //    number of keys the groups merge and throughput collapses (k=21, 100 Mb genomes: m=15 100 G
-//    k-mers/s, m=14 84 G, m=13 23 G).
-// So m = max(k - w_target + 1, ceil(log4(4 * keys))) with w_target = 8 up to 16 genomes and 4 beyond,
-// w = k-m+1 kept in 3..8.  m-mers longer than 16 bases use 64-bit arithmetic.
+//    k-mers/s, m=14 84 G, m=13 23 G; 27 x 40 Mb: m=14 123 G against 133 at m=15).
+// So m = max(k - 7, ceil(log4(4 * keys))), w = k-m+1 kept in 3..8, and a window that would come out as 5 is
+// narrowed to 4.  m-mers longer than 16 bases use 64-bit arithmetic.
 constexpr uint32_t MZ_WMIN = 3, MZ_WMAX = 8;
 __host__ __device__ __forceinline__ uint32_t minimizer_length(uint32_t k, uint64_t expected_keys, uint32_t ngenomes) {
     if (k < 20 || k > 32) return 0;
@@ -97,9 +102,10 @@ __host__ __device__ __forceinline__ uint32_t minimizer_length(uint32_t k, uint64
         m_need = 15;
         while (m_need < 27 && (1ull << (2 * m_need)) < 4 * expected_keys) ++m_need;
     }
-    const uint32_t w_target = ngenomes <= 16 ? MZ_WMAX : 4u;  // (re-measured in round 2, tools/w_sweep.sh: 12 and 16 genomes w=7 120 G k-mers/s, w=4 116-118; 27 genomes 112 / 117)
-    uint32_t m = k - (w_target - 1);
+    (void)ngenomes;  // (the rule no longer depends on it)
+    uint32_t m = k - (MZ_WMAX - 1);
     if (m < m_need) m = m_need;
+    if (k - m + 1 == 5) ++m;
     if (m > k - (MZ_WMIN - 1)) m = k - (MZ_WMIN - 1);
     return m;
 }
