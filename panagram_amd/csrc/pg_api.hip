@@ -96,6 +96,7 @@ struct pg_table {
     uint32_t m;  // minimizer length of every sub-table (0 = direct hashing)
     bool m_pinned = false;  // set by pg_table_set_minimizer: re-hashing keeps m
     uint64_t expected = 0;  // pg_table_create's expected_keys (0: unknown)
+    uint64_t first_len = 0;  // k-mer positions of the first sequence set inserted into the empty table (settle_minimizer)
     std::vector<SubHost> subs;
     unsigned long long *d_counters;  // [0] newly claimed, [1] overflow flag
     unsigned long long *h_counters = nullptr;  // pinned landing place of d_counters (read_counters)
@@ -448,7 +449,7 @@ extern "C" int pg_table_create(pg_ctx *ctx, int k, int ngenomes, uint64_t expect
     t->k = k;
     t->ngenomes = ngenomes;
     t->ndbs = ndbs;
-    t->m = minimizer_length((uint32_t)k, expected_keys, (uint32_t)ngenomes);
+    t->m = minimizer_length((uint32_t)k, expected_keys);
     t->expected = expected_keys;
     t->d_counters = nullptr;
     hipError_t e = hipMalloc(reinterpret_cast<void **>(&t->d_counters), 2 * sizeof(unsigned long long));
@@ -517,6 +518,7 @@ extern "C" int pg_table_clear(pg_table *t) {
     }
     HIP_TRY(hipMemsetAsync(t->d_counters, 0, 2 * sizeof(unsigned long long), t->ctx->stream));
     t->spill = 0;
+    t->first_len = 0;
     return PG_OK;
 }
 
@@ -536,6 +538,18 @@ extern "C" int pg_table_set_minimizer(pg_table *t, int m) {
     t->m_pinned = true;
     for (auto &s : t->subs) s.d.m = (uint32_t)m;
     return PG_OK;
+}
+
+// The first sequence set that goes into an EMPTY table tells what the expected key count cannot: the non-redundant
+// length of the pangenome (distinct loci; a locus of a many-genome pangenome holds a key per variant).  The minimizer
+// length is settled again from it (minimizer_length, pg_device.h) — free while no key has a home line yet.
+static void settle_minimizer(pg_table *t, uint64_t positions) {
+    if (t->m_pinned || t->first_len || positions == 0) return;
+    for (auto &s : t->subs)
+        if (s.count) return;
+    t->first_len = positions;
+    t->m = minimizer_length((uint32_t)t->k, t->expected, positions);
+    for (auto &s : t->subs) s.d.m = t->m;
 }
 
 static int read_counters(pg_table *t, unsigned long long out[2]) {
@@ -662,6 +676,7 @@ extern "C" int pg_table_insert_seqset(pg_table *t, int g, const pg_seqset *sq) {
     uint64_t total = 0;
     for (auto &c : sq->desc)
         if (c.len >= (uint64_t)t->k) total += c.len - t->k + 1;
+    settle_minimizer(t, total);
     if (int r = ensure_room(t, si, total)) return r;
     for (int attempt = 0; attempt < 8; ++attempt) {
         hipStream_t st = t->ctx->stream;
@@ -1027,7 +1042,7 @@ extern "C" int pg_table_rehash(pg_table *t, double keys_per_bucket) {
     if (!t->m_pinned) {  // the key count is known now: settle the minimizer length for it
         uint64_t most = 0;
         for (auto &s : t->subs) most = std::max<uint64_t>(most, s.count);
-        t->m = minimizer_length((uint32_t)t->k, most, (uint32_t)t->ngenomes);
+        t->m = minimizer_length((uint32_t)t->k, most, t->first_len);
     }
     // Line width: 128-byte lines of 8 slots.  256-byte lines of 16 slots (PG_TABLE_SLOTS=16, a tuning
     // knob) keep a many-variant locus in ONE place at the price of two requests per line; measured,

@@ -92,17 +92,30 @@ struct TableDesc {
 //  * the m-mers must stay long enough that distinct loci rarely share one: with 4^m below ~4x the
 //    number of keys the groups merge and throughput collapses (k=21, 100 Mb genomes: m=15 100 G
 //    k-mers/s, m=14 84 G, m=13 23 G; 27 x 40 Mb: m=14 123 G against 133 at m=15).
-// So m = max(k - 7, ceil(log4(4 * keys))), w = k-m+1 kept in 3..8, and a window that would come out as 5 is
-// narrowed to 4.  m-mers longer than 16 bases use 64-bit arithmetic.
+//    What merges groups is the number of distinct LOCI per m-mer, i.e. the non-redundant length L of the
+//    pangenome, not its key count (a locus of a many-genome pangenome contributes a key per variant): at full size
+//    (tools/m_sweep_full.sh, profiles/r2_m_sweep_full.txt, k=21, G k-mers/s at m = 15 / 16 / 18) 27 x 135 Mb
+//    (7.8e8 keys, 4^15 = 8 L) 130 / 123 / 121; 64 x 200 Mb (2.4e9 keys, 4^15 = 5.4 L) 100 / 114 / 115;
+//    8 x 3 Gb (3.4e9 keys; m = 16 / 17 / 18) 120 / 134 / 140.  L is known to the library as the length of the FIRST
+//    sequence set inserted into an empty table (pg_table_insert_seqset settles m again then).
+// So m = max(k - 7, m_need), w = k-m+1 kept in 3..8, a window that would come out as 5 narrowed to 4, with
+//   m_need = ceil(log4(4 * keys))                                    while no sequence has been inserted,
+//   m_need = max(ceil(log4(7.5 * L)), ceil(log4(4 * keys)) - 2)      once L is known
+// (the second term: a first sequence set much shorter than the genomes that follow must not talk m down).
+// m-mers longer than 16 bases use 64-bit arithmetic.
 constexpr uint32_t MZ_WMIN = 3, MZ_WMAX = 8;
-__host__ __device__ __forceinline__ uint32_t minimizer_length(uint32_t k, uint64_t expected_keys, uint32_t ngenomes) {
+__host__ __device__ __forceinline__ uint32_t minimizer_length(uint32_t k, uint64_t expected_keys, uint64_t first_len = 0) {
     if (k < 20 || k > 32) return 0;
     uint32_t m_need = 16;  // unknown cardinality: good up to ~1e9 keys
     if (expected_keys) {
         m_need = 15;
         while (m_need < 27 && (1ull << (2 * m_need)) < 4 * expected_keys) ++m_need;
     }
-    (void)ngenomes;  // (the rule no longer depends on it)
+    if (first_len) {
+        uint32_t m_len = 15;
+        while (m_len < 27 && (double)(1ull << (2 * m_len)) < 7.5 * (double)first_len) ++m_len;
+        m_need = m_need >= m_len + 2 ? m_need - 2 : m_len;
+    }
     uint32_t m = k - (MZ_WMAX - 1);
     if (m < m_need) m = m_need;
     if (k - m + 1 == 5) ++m;
