@@ -492,8 +492,12 @@ __global__ __launch_bounds__(64) void k_probe(const SubTable st, const uint64_t 
     // "their" lines off a common bank group (a power-of-two stride would be a 32-way conflict)
     constexpr int LDS_LINE_U4 = SLOTS + 1;
     constexpr int BUCKET_BYTES = 16 * SLOTS;
-    constexpr int STAGE_ITERS = (PROBE_MAXRUN * SLOTS + 63) / 64;  // 16-byte loads per lane per staging step
-    __shared__ uint32_t lines_w[PROBE_NB][PROBE_MAXRUN];
+    // lines staged per step: 16 take the ~13 distinct lines a batch meets at w = 7 / 8 in ONE step; at w = 6 (what k=21
+    // gets on 150-570 Mb genomes) a batch meets ~17 and paid a second step for the last few — 24 there (9.01 -> 8.66 ms
+    // on 64 x 20 Mb, 92.0 -> 89.7 on 64 x 200 Mb; everywhere else 24 costs 8-10 %: LDS, occupancy; tools/ab_maxrun.sh)
+    constexpr int MAXRUN = W_C == 6 ? (PROBE_MAXRUN * 3) / 2 : PROBE_MAXRUN;
+    constexpr int STAGE_ITERS = (MAXRUN * SLOTS + 63) / 64;  // 16-byte loads per lane per staging step
+    __shared__ uint32_t lines_w[PROBE_NB][MAXRUN];
     __shared__ uint4 buf[PROBE_NB][((STAGE_ITERS * 64 + SLOTS - 1) / SLOTS) * LDS_LINE_U4];  // room for every staged chunk slot
     __shared__ uint32_t q_line[PROBE_QCAP];  // overflow queue of the tile (position order): next line to try,
     __shared__ uint32_t q_step[PROBE_QCAP];  // step of the entry's sequence
@@ -602,11 +606,11 @@ __global__ __launch_bounds__(64) void k_probe(const SubTable st, const uint64_t 
             m0[u] = m1[u] = 0;
             rcode[u] = 0;
         }
-        for (uint32_t r0 = 0; r0 < maxruns; r0 += PROBE_MAXRUN) {  // one trip unless a batch has > MAXRUN lines
+        for (uint32_t r0 = 0; r0 < maxruns; r0 += MAXRUN) {  // one trip unless a batch has > MAXRUN lines
             uint32_t nl[NB];
 #pragma unroll
             for (int u = 0; u < NB; ++u) {
-                nl[u] = nruns[u] > r0 ? min((uint32_t)PROBE_MAXRUN, nruns[u] - r0) : 0u;
+                nl[u] = nruns[u] > r0 ? min((uint32_t)MAXRUN, nruns[u] - r0) : 0u;
                 if (leader[u] && rid[u] - r0 < nl[u]) lines_w[u][rid[u] - r0] = line[u];
             }
             __syncthreads();
@@ -694,7 +698,7 @@ __global__ __launch_bounds__(64) void k_probe(const SubTable st, const uint64_t 
     }
 
     constexpr int LEVELS = (W_C >= 6 && !TWO && !WIDE && PROBE_STAGED_LEVELS > 1) ? 1 : PROBE_STAGED_LEVELS;  // (W_C >= 6: the wide-window tables of up to 16 genomes)
-    drain_queue<TWO, ROWMODE, SLOTS, PROBE_MAXRUN, WIDE, LEVELS>(st, qn, sw, rw, q_line, q_step, q_pl, lines_w[0], buf[0], tile_rows, nbytes, rc, lane);
+    drain_queue<TWO, ROWMODE, SLOTS, MAXRUN, WIDE, LEVELS>(st, qn, sw, rw, q_line, q_step, q_pl, lines_w[0], buf[0], tile_rows, nbytes, rc, lane);
     if constexpr (ROWMODE == 3) {
         // the tile's columns: 8 slots x `width` (= nbytes) genomes, slot-major — what k_cols_extract would have written
         __syncthreads();
