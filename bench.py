@@ -287,9 +287,8 @@ def roofline_block(pos_per_launch, avg_launch_s, avg_epi_s, G, value_per_gpu, co
     elif out["hbm_counter_frac"] is not None:
         out.update(bound="hbm", achieved=out["traffic"] / avg_launch_s / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s",
                    frac=out["hbm_counter_frac"])
-    else:  # no committed counters for this workload: only the contract figure can be stated
-        out.update(bound="hbm", achieved=out["contract_hbm_GBps"], peak=HBM_PEAK / 1e9, unit="GB/s",
-                   frac=out["contract_hbm_frac"])
+    else:  # no committed counter pass for this workload: no fraction is claimed (contract_* above is not a bound)
+        out.update(bound="unmeasured (no committed --pmc pass for this workload)", achieved=None, peak=None, unit=None, frac=None)
     out["note"] = ("frac is the binding ceiling: VALU issue (SQ_INSTS_VALU of the committed rocprofv3 --pmc pass x 4 issue "
                    "cycles / (1024 SIMDs x 2.4 GHz x launch time)) or counter-measured HBM bytes / 8 TB/s; contract_* price one "
                    "64-byte table fetch per position (SURVEY 8d) — the kernel moves far fewer bytes (traffic), so that "

@@ -16,7 +16,7 @@ bench = open(os.path.join(src, "trace_bench.json")).read().strip()
 if bench:
     b = json.loads(bench.splitlines()[-1])
     out.append(f"bench.py line under the profiler: value={b['value']:.4g} {b['unit']}, "
-               f"avg_launch_ms={b['roofline']['avg_launch_ms']:.4f}, frac={b['roofline']['frac']:.4f}\n")
+               f"avg_launch_ms={b['roofline']['avg_launch_ms']:.4f}, frac={b['roofline']['frac']}\n")
     out.append(f"workload: {b['config']['workload']}\n")
 ks = pd.read_csv(os.path.join(src, "trace", "trace_kernel_stats.csv"))
 ks.to_csv(os.path.join(dst, f"{tag}_kernel_stats.csv"), index=False)

@@ -8,6 +8,6 @@ for A in "" "--k 31" "--genomes 27 --genome-mb 40" "--genomes 64 --genome-mb 20 
   timeout 600 python bench.py --steps 5 --warmup 1 --no-cpu-baseline $A 2>gpurun_out/shapes.err | python -c "
 import sys,json
 d=json.loads(sys.stdin.read())
-print(round(d['value']/1e9,1), round(d['config'].get('per_genome_launches_value',0)/1e9,1), round(d['roofline']['avg_launch_ms'],3), round(d['roofline']['frac'],3), round(d['config']['table_bytes']/1e9,1))" >> gpurun_out/t.txt 2>&1
+print(round(d['value']/1e9,1), round(d['config'].get('per_genome_launches_value',0)/1e9,1), round(d['roofline']['avg_launch_ms'],3), d['roofline']['frac'], round(d['config']['table_bytes']/1e9,1))" >> gpurun_out/t.txt 2>&1
 done
 cat gpurun_out/t.txt

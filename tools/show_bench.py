@@ -5,7 +5,7 @@ import sys
 
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
 r = d["roofline"]
-print("value G/s", round(d["value"] / 1e9, 2), "ms/step", round(d["ms_per_step"], 3), "frac", r and round(r["frac"], 3), r and r["bound"],
+print("value G/s", round(d["value"] / 1e9, 2), "ms/step", round(d["ms_per_step"], 3), "frac", r and r["frac"] is not None and round(r["frac"], 3), r and r["bound"],
       "valu", r and r.get("valu_frac"), "hbm", r and r.get("hbm_counter_frac"), "probe ms", r and round(r["avg_launch_ms"], 3),
       "stats ms", r and round(r["epilogue_kernel_ms"], 3))
 c = d.get("cpu_baseline")
