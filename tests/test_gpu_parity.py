@@ -229,6 +229,41 @@ def test_every_minimizer_window_and_direct_mode(ctx, k, w):
     tbl.close()
 
 
+def test_minimizer_settles_on_the_first_sequence_set(ctx):
+    """A table created for many keys picks m from the key count (k=21, 3e8 keys: m = 16); the first sequence set that
+    goes into the EMPTY table tells the pangenome's non-redundant length and m is settled again from it (short
+    genomes: the widest window the key rule allows, m = 15 — never more than two bases under the key rule); a pinned
+    m stays; pg_table_clear starts over.  Answers are the oracle's either way."""
+    from panagram_amd import engine
+    k, n = 21, 20
+    gen = po.synth_genomes(n, [5000, 900], 0.02, 77)
+    genomes = [[po.codes_to_ascii(c) for c in g] for g in gen]
+    dbs = po.build_bitvec_dbs(genomes, k)
+
+    def fill_and_check(tbl):
+        for g in range(n):
+            ss = engine.SeqSet.from_host(ctx, genomes[g])
+            tbl.insert_seqset(g, ss)
+            ss.close()
+        for seq_ in genomes[7]:
+            rows = tbl.anchor_contig(seq_)[0]
+            assert np.array_equal(rows, po.anchor_contig(dbs, seq_, k, n)[0])
+
+    tbl = engine.PanTable(ctx, k, n, expected_keys=300_000_000)
+    assert tbl.minimizer == 16
+    fill_and_check(tbl)
+    assert tbl.minimizer == 15
+    tbl.clear()
+    fill_and_check(tbl)
+    assert tbl.minimizer == 15
+    tbl.close()
+    tbl = engine.PanTable(ctx, k, n, expected_keys=300_000_000)
+    tbl.set_minimizer(18)
+    fill_and_check(tbl)
+    assert tbl.minimizer == 18
+    tbl.close()
+
+
 def test_three_subtables_n130(ctx):
     """N = 130 -> 5 bitvec groups -> 3 sub-tables (64 + 64 + 2 genomes), 17-byte rows"""
     from panagram_amd import engine
