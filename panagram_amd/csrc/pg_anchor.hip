@@ -225,13 +225,22 @@ template <int NW>
 struct __attribute__((packed, aligned(4))) WordsN {
     uint32_t w[NW];
 };
-template <int NW>
+#ifndef PG_NT_ROWS
+#define PG_NT_ROWS 1  // non-temporal stores for rows that ONE store instruction covers (8 and 16 bytes): see store_row
+#endif
+template <int NW, bool NT = false>
 __device__ __forceinline__ void copy_words(const uint32_t *src, uint8_t *dst, bool hit) {
     WordsN<NW> v;
 #pragma unroll
     for (int i = 0; i < NW; ++i) v.w[i] = 0;
     if (hit) v = *reinterpret_cast<const WordsN<NW> *>(src);
-    *reinterpret_cast<WordsN<NW> *>(dst) = v;
+    if constexpr (NW == 4 && NT && PG_NT_ROWS) {  // (non-temporal, like the 8-byte rows of store_row)
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 q = {v.w[0], v.w[1], v.w[2], v.w[3]};
+        __builtin_nontemporal_store(q, reinterpret_cast<u32x4 *>(dst));
+    } else {
+        *reinterpret_cast<WordsN<NW> *>(dst) = v;
+    }
 }
 template <int NS>  // NS whole words and `tail` bytes of the next one: NS + 1 words in one load
 __device__ __forceinline__ void copy_words_tail(const uint32_t *src, uint8_t *dst, bool hit, uint32_t tail) {
@@ -254,6 +263,10 @@ __device__ __forceinline__ void store_row_wide(const uint8_t *masks, uint32_t W,
     uint32_t d = 0;
     const uint32_t full = nbytes / 4;  // (wave-uniform loop bounds)
     const uint32_t tail = nbytes % 4;  // bytes of a last, partial word: fetched with the piece before it (one request)
+    if (nbytes == 16) {  // (wave-uniform) the whole row in one store: non-temporal
+        copy_words<4, true>(mp, row, hit);
+        return;
+    }
     for (; d + 4 <= full; d += 4) copy_words<4>(mp + d, row + 4 * d, hit);
     if (!tail) {
         if (full - d == 3) copy_words<3>(mp + d, row + 4 * d, hit);
@@ -292,13 +305,20 @@ __device__ __attribute__((noinline)) uint2 lane_chase_cold(uint8_t *buckets, uin
 // 0: generic byte loop.
 template <int ROWMODE>
 __device__ __forceinline__ void store_row(uint8_t *row, uint32_t m0, uint32_t m1, const RowCols rc) {
+    // Rows of 8 and of 16 bytes are written NON-TEMPORALLY: they are not read again before the statistics pass, and as
+    // ordinary stores they push table lines out of the L2 (64 x 20 Mb k=21 8.1-8.4 -> 7.8 ms, k=31 7.22 -> 6.98,
+    // 128 genomes 14.0-14.7 -> 13.1-13.9; profiles/r2_ab_nt_rows.txt).  Only where ONE store instruction covers the
+    // row, so that a wave writes whole lines: one- and four-byte rows lose 3-5 % that way, rows of two 16-byte pieces
+    // 25 % (256 genomes: 24.8 -> 32.2 ms — each piece leaves the L2 as a partial line).
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
     if (ROWMODE == 1) {
         row[0] = (uint8_t)m0;
-    } else if (ROWMODE == 2) {
-        *reinterpret_cast<uint2 *>(row) = make_uint2(m0, m1);
-    } else if (rc.words == 4) {  // both words of the sub-table at an 8-byte aligned column: one store
-        *reinterpret_cast<uint2 *>(row + rc.col0) = make_uint2(m0, m1);
-    } else if (rc.words == 1) {  // wave-uniform
+    } else if (ROWMODE == 2 || rc.words == 4) {  // (rc.words == 4: both words at an 8-byte aligned column: one store)
+        u32x2 q = {m0, m1};
+        uint8_t *p = row + (ROWMODE == 2 ? 0u : rc.col0);
+        if (PG_NT_ROWS) __builtin_nontemporal_store(q, reinterpret_cast<u32x2 *>(p));
+        else *reinterpret_cast<u32x2 *>(p) = q;
+    } else if  (rc.words == 1) {  // wave-uniform
         *reinterpret_cast<uint32_t *>(row + rc.col0) = m0;
         if (rc.nb1) *reinterpret_cast<uint32_t *>(row + rc.col0 + 4) = m1;
     } else if (rc.words == 2) {  // two-byte rows (9..16 genomes): one aligned 16-bit store
