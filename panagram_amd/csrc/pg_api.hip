@@ -97,6 +97,7 @@ struct pg_table {
     bool m_pinned = false;  // set by pg_table_set_minimizer: re-hashing keeps m
     uint64_t expected = 0;  // pg_table_create's expected_keys (0: unknown)
     uint64_t first_len = 0;  // k-mer positions of the first sequence set inserted into the empty table (settle_minimizer)
+    uint64_t max_len = 0;    // ... of the longest one inserted so far (what a re-hash settles m from)
     std::vector<SubHost> subs;
     unsigned long long *d_counters;  // [0] newly claimed, [1] overflow flag
     unsigned long long *h_counters = nullptr;  // pinned landing place of d_counters (read_counters)
@@ -518,7 +519,7 @@ extern "C" int pg_table_clear(pg_table *t) {
     }
     HIP_TRY(hipMemsetAsync(t->d_counters, 0, 2 * sizeof(unsigned long long), t->ctx->stream));
     t->spill = 0;
-    t->first_len = 0;
+    t->first_len = t->max_len = 0;
     return PG_OK;
 }
 
@@ -677,6 +678,7 @@ extern "C" int pg_table_insert_seqset(pg_table *t, int g, const pg_seqset *sq) {
     for (auto &c : sq->desc)
         if (c.len >= (uint64_t)t->k) total += c.len - t->k + 1;
     settle_minimizer(t, total);
+    t->max_len = std::max(t->max_len, total);
     if (int r = ensure_room(t, si, total)) return r;
     for (int attempt = 0; attempt < 8; ++attempt) {
         hipStream_t st = t->ctx->stream;
@@ -1042,7 +1044,7 @@ extern "C" int pg_table_rehash(pg_table *t, double keys_per_bucket) {
     if (!t->m_pinned) {  // the key count is known now: settle the minimizer length for it
         uint64_t most = 0;
         for (auto &s : t->subs) most = std::max<uint64_t>(most, s.count);
-        t->m = minimizer_length((uint32_t)t->k, most, t->first_len);
+        t->m = minimizer_length((uint32_t)t->k, most, t->max_len);
     }
     // Line width: 128-byte lines of 8 slots.  256-byte lines of 16 slots (PG_TABLE_SLOTS=16, a tuning
     // knob) keep a many-variant locus in ONE place at the price of two requests per line; measured,

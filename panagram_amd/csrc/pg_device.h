@@ -163,7 +163,10 @@ __device__ __forceinline__ uint32_t next_line(uint32_t line, uint32_t step, uint
 // thousands of distinct k-mers behind one minimizer, and without this bound their chain — walked
 // by every insert and every lookup of the family — grows to hundreds of lines.
 // Line number `level` (0 = home) of a key's probe sequence, given the line before it:
-constexpr uint32_t GROUP_CHAIN = 4;
+#ifndef PG_GROUP_CHAIN
+#define PG_GROUP_CHAIN 4
+#endif
+constexpr uint32_t GROUP_CHAIN = PG_GROUP_CHAIN;
 __device__ __forceinline__ void key_sequence(uint64_t key, uint64_t nlines, uint32_t &home, uint32_t &step) {
     const uint32_t g2 = fmix32(group_of_key(key) ^ 0x7feb352du);
     home = home_of_group(g2, nlines);
