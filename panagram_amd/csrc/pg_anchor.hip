@@ -601,6 +601,14 @@ __global__ __launch_bounds__(64) void k_probe(const SubTable st, const uint64_t 
                 grp[u] = group_of_key(key[u]);
             }
         }
+#ifdef PG_DUMMY_VALU
+        {   // (experiment: PG_DUMMY_VALU extra full-rate-class VALU instructions per batch, nothing else changed)
+            uint32_t dm = grp[0];
+#pragma unroll
+            for (int i = 0; i < PG_DUMMY_VALU; ++i) asm volatile("v_alignbit_b32 %0, %0, %1, 3" : "+v"(dm) : "v"((uint32_t)lane));
+            if (dm == 0x12345u && lane == 77) out1[0] = 1;
+        }
+#endif
         if (W_C) {
             // sliding minimum over lanes [lane-W_C+1, lane]: m <- min(own rank, m of the lane below), W_C-1 times
             // (the first lanes of the wave see shorter windows: they are halo lanes, never active)
