@@ -48,6 +48,9 @@ constexpr int PROBE_SEQW = ((PROBE_TILE + 31) / 32 + 6 + 3) & ~3;  // staged 32-
 // base 32 PROBE_SEQW - 1 - j of sw).  The reverse complement of the k-mer at base p is then the k bases of rw from
 // 32 PROBE_SEQW - p - k on — the same three LDS reads and two funnel shifts as the forward window, instead of a
 // 64-bit bit reversal, pair swap, complement and shift per position (14 instructions).
+#ifndef PG_ABLATE
+#define PG_ABLATE 0  // timing experiments of k_probe (tools/ab_ablate.sh); 0 = the product
+#endif
 #ifndef PG_RC_LDS
 #define PG_RC_LDS 1
 #endif
@@ -634,7 +637,11 @@ __global__ __launch_bounds__(64) void k_probe(const SubTable st, const uint64_t 
             m0[u] = m1[u] = 0;
             rcode[u] = 0;
         }
+#if PG_ABLATE == 3  // (timing experiment: keys, minimizers and runs only — no table access)
+        for (uint32_t r0 = 0; r0 < maxruns && line[0] == 0xDEADBEEFu; r0 += MAXRUN) {
+#else
         for (uint32_t r0 = 0; r0 < maxruns; r0 += MAXRUN) {  // one trip unless a batch has > MAXRUN lines
+#endif
             uint32_t nl[NB];
 #pragma unroll
             for (int u = 0; u < NB; ++u) {
@@ -655,7 +662,11 @@ __global__ __launch_bounds__(64) void k_probe(const SubTable st, const uint64_t 
 #pragma unroll
                 for (int it = 0; it < STAGE_ITERS; ++it) {
                     const uint32_t ls = min((uint32_t)(it * (64 / SLOTS) + lane / SLOTS), last);
+#if PG_ABLATE == 1  // (timing experiment, wrong rows: every fetch a cache hit — the lines of one 64 KB window)
+                    const uint32_t ln = nl[u] ? (lines_w[u][ls] & 511u) : 0u;
+#else
                     const uint32_t ln = nl[u] ? lines_w[u][ls] : 0u;
+#endif
                     v[u][it] = *reinterpret_cast<const uint4 *>(st.buckets + (((uint64_t)ln * BUCKET_BYTES) | ((lane % SLOTS) * 16u)));
                 }
             }
@@ -669,7 +680,14 @@ __global__ __launch_bounds__(64) void k_probe(const SubTable st, const uint64_t 
             __syncthreads();
 #pragma unroll
             for (int u = 0; u < NB; ++u)
+#if PG_ABLATE == 5  // (timing experiment: lines fetched and staged, no slot scan: every lane "hits" with one LDS word)
+                if (act[u] && rid[u] - r0 < nl[u]) {
+                    rcode[u] = 1;
+                    m0[u] = m1[u] = reinterpret_cast<const uint32_t *>(buf[u] + (rid[u] - r0) * LDS_LINE_U4)[2];
+                } else if (false)
+#else
                 if (act[u] && rid[u] - r0 < nl[u])
+#endif
                 {
                     if constexpr (WIDE) {
                         rcode[u] = scan_keys16_lds(buf[u] + (rid[u] - r0) * LDS_LINE_U4, key[u], m1[u]);
@@ -719,7 +737,12 @@ __global__ __launch_bounds__(64) void k_probe(const SubTable st, const uint64_t 
                         }
                     }
                 } else {
-                    if (inrange[u]) store_row<ROWMODE>(tile_rows + (ROWMODE == 1 ? (uint32_t)pl[u] : (uint32_t)pl[u] * nbytes), m0[u], m1[u], rc);
+#if PG_ABLATE == 2  // (timing experiment: no row store unless a value no mask has turns up)
+                    if (inrange[u] && m0[u] == 0xDEADBEEFu)
+#else
+                    if (inrange[u])
+#endif
+                        store_row<ROWMODE>(tile_rows + (ROWMODE == 1 ? (uint32_t)pl[u] : (uint32_t)pl[u] * nbytes), m0[u], m1[u], rc);
                 }
             }
         }
