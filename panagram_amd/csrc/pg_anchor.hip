@@ -85,6 +85,13 @@ __device__ __forceinline__ int scan_line_lds(const uint4 *line, uint64_t key, ui
         const unsigned long long b0 = e[1] | e[3] | e[5] | e[7], b1 = e[2] | e[3] | e[6] | e[7], b2 = e[4] | e[5] | e[6] | e[7];
         const unsigned long long any = b0 | b1 | b2 | e[0];
         const bool hit = __builtin_amdgcn_inverse_ballot_w64(any);
+#if PG_ABLATE == 6  // (timing experiment: keys read and compared, the hit slot's mask word NOT read)
+        if (hit) m0 = (uint32_t)b0 | 1u;
+        return hit ? 1 : (kk[SLOTS - 1] == EMPTY_KEY ? 0 : -1);
+#elif PG_ABLATE == 7  // (timing experiment: keys read, one compare instead of eight)
+        m0 = (uint32_t)(kk[0] ^ kk[1] ^ kk[2] ^ kk[3] ^ kk[4] ^ kk[5] ^ kk[6] ^ kk[7]) | 1u;
+        return (kk[0] ^ kk[3]) == key ? -1 : 1;
+#endif
         if (hit) {
             const uint32_t off = (__builtin_amdgcn_inverse_ballot_w64(b0) ? 16u : 0u) | (__builtin_amdgcn_inverse_ballot_w64(b1) ? 32u : 0u) |
                                  (__builtin_amdgcn_inverse_ballot_w64(b2) ? 64u : 0u);
