@@ -167,7 +167,8 @@ int pg_table_ngenomes(const pg_table *tbl);
 /* tuning knob with no reference counterpart: the table places a k-mer by its minimizer
  * (smallest canonical m-mer); m is picked from k, the key count and the genome length
  * (at creation from expected_keys; again from the length of the first sequence set inserted into the
- * empty table, and at pg_table_rehash).  set_minimizer pins m for
+ * empty table, and at pg_table_rehash; the environment variable PG_TABLE_WMAX=3..8 caps the window k-m+1 the
+ * library chooses — 4 suits genomes dominated by one young high-copy repeat family).  set_minimizer pins m for
  * an EMPTY table: 0 = hash the k-mer itself, else k >= 20 and 3 <= k-m+1 <= 8. */
 int pg_table_minimizer(const pg_table *tbl);
 int pg_table_set_minimizer(pg_table *tbl, int m);

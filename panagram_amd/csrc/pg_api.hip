@@ -437,6 +437,8 @@ extern "C" int pg_table_bytes_for(int k, int ngenomes, uint64_t expected_keys, u
     return PG_OK;
 }
 
+static uint32_t window_cap();  // (PG_TABLE_WMAX, below)
+
 extern "C" int pg_table_create(pg_ctx *ctx, int k, int ngenomes, uint64_t expected_keys, pg_table **out) {
     if (!ctx || !out) return fail(PG_E_INVALID, "pg_table_create: NULL argument");
     if (k < 1 || k > 32) return fail(PG_E_INVALID, "k=%d unsupported (1..32)", k);
@@ -450,7 +452,7 @@ extern "C" int pg_table_create(pg_ctx *ctx, int k, int ngenomes, uint64_t expect
     t->k = k;
     t->ngenomes = ngenomes;
     t->ndbs = ndbs;
-    t->m = minimizer_length((uint32_t)k, expected_keys);
+    t->m = minimizer_length((uint32_t)k, expected_keys, 0, window_cap());
     t->expected = expected_keys;
     t->d_counters = nullptr;
     hipError_t e = hipMalloc(reinterpret_cast<void **>(&t->d_counters), 2 * sizeof(unsigned long long));
@@ -544,12 +546,25 @@ extern "C" int pg_table_set_minimizer(pg_table *t, int m) {
 // The first sequence set that goes into an EMPTY table tells what the expected key count cannot: the non-redundant
 // length of the pangenome (distinct loci; a locus of a many-genome pangenome holds a key per variant).  The minimizer
 // length is settled again from it (minimizer_length, pg_device.h) — free while no key has a home line yet.
+// PG_TABLE_WMAX=3..8 caps the minimizer window the library chooses (default 8).  The wide window wins 10-25 % on
+// mostly unique sequence and loses on content dominated by one young high-copy repeat family, whose minimizer groups it
+// makes 1.8 x larger (tools/repeat_stress.py, 27 genomes, 2000 x 3 kb copies at 3 %: 26 % of the genome 56 vs 64 G
+// k-mers/s at w = 4, 10 % of it 71 vs 76); pg_table_set_minimizer pins m for one table.
+static uint32_t window_cap() {
+    static const uint32_t cap = [] {
+        const char *e = getenv("PG_TABLE_WMAX");
+        const int v = (e && *e) ? atoi(e) : (int)MZ_WMAX;
+        return (uint32_t)std::min<int>((int)MZ_WMAX, std::max<int>((int)MZ_WMIN, v));
+    }();
+    return cap;
+}
+
 static void settle_minimizer(pg_table *t, uint64_t positions) {
     if (t->m_pinned || t->first_len || positions == 0) return;
     for (auto &s : t->subs)
         if (s.count) return;
     t->first_len = positions;
-    t->m = minimizer_length((uint32_t)t->k, t->expected, positions);
+    t->m = minimizer_length((uint32_t)t->k, t->expected, positions, window_cap());
     for (auto &s : t->subs) s.d.m = t->m;
 }
 
@@ -1044,7 +1059,7 @@ extern "C" int pg_table_rehash(pg_table *t, double keys_per_bucket) {
     if (!t->m_pinned) {  // the key count is known now: settle the minimizer length for it
         uint64_t most = 0;
         for (auto &s : t->subs) most = std::max<uint64_t>(most, s.count);
-        t->m = minimizer_length((uint32_t)t->k, most, t->max_len);
+        t->m = minimizer_length((uint32_t)t->k, most, t->max_len, window_cap());
     }
     // Line width: 128-byte lines of 8 slots.  256-byte lines of 16 slots (PG_TABLE_SLOTS=16, a tuning
     // knob) keep a many-variant locus in ONE place at the price of two requests per line; measured,

@@ -104,7 +104,8 @@ struct TableDesc {
 // (the second term: a first sequence set much shorter than the genomes that follow must not talk m down).
 // m-mers longer than 16 bases use 64-bit arithmetic.
 constexpr uint32_t MZ_WMIN = 3, MZ_WMAX = 8;
-__host__ __device__ __forceinline__ uint32_t minimizer_length(uint32_t k, uint64_t expected_keys, uint64_t first_len = 0) {
+__host__ __device__ __forceinline__ uint32_t minimizer_length(uint32_t k, uint64_t expected_keys, uint64_t first_len = 0,
+                                                              uint32_t wmax = MZ_WMAX) {
     if (k < 20 || k > 32) return 0;
     uint32_t m_need = 16;  // unknown cardinality: good up to ~1e9 keys
     if (expected_keys) {
@@ -116,7 +117,7 @@ __host__ __device__ __forceinline__ uint32_t minimizer_length(uint32_t k, uint64
         while (m_len < 27 && (double)(1ull << (2 * m_len)) < 7.5 * (double)first_len) ++m_len;
         m_need = m_need >= m_len + 2 ? m_need - 2 : m_len;
     }
-    uint32_t m = k - (MZ_WMAX - 1);
+    uint32_t m = k - (wmax - 1);  // (wmax: PG_TABLE_WMAX caps the window, pg_api.hip — repeat-rich genomes)
     if (m < m_need) m = m_need;
     if (k - m + 1 == 5) ++m;
     if (m > k - (MZ_WMIN - 1)) m = k - (MZ_WMIN - 1);

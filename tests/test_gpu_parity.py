@@ -264,6 +264,21 @@ def test_minimizer_settles_on_the_first_sequence_set(ctx):
     tbl.close()
 
 
+def test_window_cap_environment_variable():
+    """PG_TABLE_WMAX caps the minimizer window the library chooses (read once per process: checked in a child)."""
+    import subprocess
+    import sys
+    code = ("from panagram_amd import engine\n"
+            "c = engine.Context(0)\n"
+            "print(engine.PanTable(c, 21, 27).minimizer, engine.PanTable(c, 31, 27).minimizer)\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for cap, want in (("4", "18 28"), ("6", "16 26"), ("", "16 24")):  # (no key count yet: m >= 16)
+        env = dict(os.environ, PG_TABLE_WMAX=cap) if cap else {k: v for k, v in os.environ.items() if k != "PG_TABLE_WMAX"}
+        out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        assert out.stdout.split("\n")[-2].strip() == want, (cap, out.stdout)
+
+
 def test_three_subtables_n130(ctx):
     """N = 130 -> 5 bitvec groups -> 3 sub-tables (64 + 64 + 2 genomes), 17-byte rows"""
     from panagram_amd import engine
