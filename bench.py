@@ -41,6 +41,9 @@ CLOCK_HZ = 2.4e9       # max shader clock, MI355X_MICROARCH.md
 VALU_CYCLES = 4.0      # issue cycles of a wave64 VALU instruction of k_probe's mix (tools/valu_rate.hip: 4.2-4.6 measured)
 
 
+LEG_TIMEOUT_S = 240  # watchdog of the further legs when there is more than one rank (they take seconds)
+
+
 def synth_genomes_device(ngenomes, contig_lens, d, seed, device):
     """SURVEY §8d generator (i.i.d. base genome; genome g>0 = per-base substitution at rate d,
     new base != old), drawn with torch on the GPU so that no PCIe traffic is involved.
@@ -644,6 +647,21 @@ def main():
     # carries the ONE complete line at the end)
     if rank == 0:
         print("[bench] timed region done, before the further legs: " + json.dumps(out), file=sys.stderr, flush=True)
+    # With more than one rank the further leg has a collective in it, and a rank that dies or stalls there would leave
+    # the others waiting inside RCCL for ever — and the measured line unprinted.  A watchdog per rank: if the leg has not
+    # come back after LEG_TIMEOUT_S, rank 0 prints the line as it stands (the leg marked as timed out) and every rank
+    # leaves with exit code 0.
+    watchdog = None
+    if world > 1:
+        def give_up():
+            if rank == 0:
+                out["config"].setdefault("genome_sharded_leg", {"error": f"no result after {LEG_TIMEOUT_S} s (watchdog): the measured line stands"})
+                print(json.dumps(out), flush=True)
+            print(f"[bench] rank {rank}: further leg timed out, leaving", file=sys.stderr, flush=True)
+            os._exit(0)
+        watchdog = threading.Timer(LEG_TIMEOUT_S, give_up)
+        watchdog.daemon = True
+        watchdog.start()
     if not args.no_sharded_leg and (world > 1 or default_shape):
         # the one mode with a data-path collective (BASELINE.json configs[4]); with one rank: the pipeline's own cost
         try:
@@ -655,10 +673,16 @@ def main():
             out["config"]["other_shapes"] = [north_star_leg(ctx, dev, args)]
         except Exception as e:
             out["config"]["other_shapes"] = [{"error": f"{type(e).__name__}: {e}"}]
+    if watchdog is not None:
+        watchdog.cancel()
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
+        bye = threading.Timer(60.0, lambda: os._exit(0))  # (the line is out: a stuck teardown must not turn into a failure)
+        bye.daemon = True
+        bye.start()
         dist.destroy_process_group()
+        bye.cancel()
 
 
 if __name__ == "__main__":
