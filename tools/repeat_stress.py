@@ -55,3 +55,5 @@ print(f"anchor {L/dt/1e9:.2f} G k-mers/s ({dt*1e3:.1f} ms), m = {tbl.minimizer}"
 rows = res.download(0)[0]
 assert (rows[:, 0] & 1).all(), "anchor genome must contain all its k-mers"
 print("own-bit check ok; rows with both bits:", int(((rows[:, 0] & 3) == 3).sum()))
+tbl.rehash(3.0)  # (the spill fraction is counted at a re-hash: keys outside their minimizer's home line / keys)
+print(f"after a re-hash to 3 keys per line: spill fraction {tbl.spill()[0]:.3f}, m = {tbl.minimizer}")
