@@ -712,8 +712,13 @@ __global__ __launch_bounds__(64) void k_probe(const SubTable st, const uint64_t 
             const bool ovf = act[u] && rcode[u] < 0;
             const unsigned long long omask = __ballot(ovf);
             if (omask) {
-                const uint32_t step = step_of_group(grp[u], st.nbuckets);
-                const uint32_t nx = next_line(line[u], step, st.nbuckets);
+                uint32_t step, nx;
+                if constexpr (GROUP_CHAIN == 1) {  // (tuning build: the group owns its home line only — level 1 is the key's own sequence)
+                    key_sequence(key[u], st.nbuckets, nx, step);
+                } else {
+                    step = step_of_group(grp[u], st.nbuckets);
+                    nx = next_line(line[u], step, st.nbuckets);
+                }
                 const uint32_t slot = qn + lanes_le_count(omask, ovf) - 1;
                 if (ovf) {
                     if (slot < (uint32_t)PROBE_QCAP) {

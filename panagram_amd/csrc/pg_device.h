@@ -168,7 +168,7 @@ __device__ __forceinline__ uint32_t next_line(uint32_t line, uint32_t step, uint
 #define PG_GROUP_CHAIN 4
 #endif
 constexpr uint32_t GROUP_CHAIN = PG_GROUP_CHAIN;
-static_assert(GROUP_CHAIN >= 2, "k_probe queues the NEXT line of the group's sequence for overflow level 1");
+static_assert(GROUP_CHAIN >= 1, "a group owns at least its home line");
 __device__ __forceinline__ void key_sequence(uint64_t key, uint64_t nlines, uint32_t &home, uint32_t &step) {
     const uint32_t g2 = fmix32(group_of_key(key) ^ 0x7feb352du);
     home = home_of_group(g2, nlines);
