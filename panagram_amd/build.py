@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpanagram_hip.so")
 SOURCES = ["pg_kernels.hip", "pg_anchor.hip", "pg_deflate.hip", "pg_api.hip", "pg_bgzf.cpp"]
-HEADERS = ["pg_device.h", "pg_kernels.h", os.path.join("..", "..", "include", "panagram_hip.h")]
+HEADERS = ["pg_device.h", "pg_kernels.h", "pg_guard.h", os.path.join("..", "..", "include", "panagram_hip.h")]
 
 
 def _stale() -> bool:

@@ -3,6 +3,7 @@
 // compute fallback lives here: without a GPU pg_ctx_create fails.
 #include "../../include/panagram_hip.h"
 #include "pg_kernels.h"
+#include "pg_guard.h"
 
 #include <algorithm>
 #include <atomic>
@@ -186,6 +187,7 @@ static int use_device(const pg_ctx *c) {
 // context
 // ---------------------------------------------------------------------------
 extern "C" int pg_ctx_create(int device_id, pg_ctx **out) {
+    PG_API_BEGIN
     if (!out) return fail(PG_E_INVALID, "pg_ctx_create: out is NULL");
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
@@ -220,6 +222,7 @@ extern "C" int pg_ctx_create(int device_id, pg_ctx **out) {
     }
     *out = c;
     return PG_OK;
+    PG_API_END
 }
 
 static void df_free_buffers(pg_ctx::DfSet &d);
@@ -278,6 +281,7 @@ static void row_free(pg_ctx *c, uint8_t *p, uint64_t cap) {
 }
 
 extern "C" int pg_ctx_mem_info(pg_ctx *c, uint64_t *free_bytes, uint64_t *total_bytes) {
+    PG_API_BEGIN
     if (!c) return fail(PG_E_INVALID, "ctx is NULL");
     if (int r = use_device(c)) return r;
     size_t f = 0, t = 0;
@@ -289,25 +293,31 @@ extern "C" int pg_ctx_mem_info(pg_ctx *c, uint64_t *free_bytes, uint64_t *total_
     if (free_bytes) *free_bytes = f;
     if (total_bytes) *total_bytes = t;
     return PG_OK;
+    PG_API_END
 }
 
 extern "C" int pg_ctx_trim(pg_ctx *c) {
+    PG_API_BEGIN
     if (!c) return fail(PG_E_INVALID, "ctx is NULL");
     if (int r = use_device(c)) return r;
     row_cache_trim(c);
     return PG_OK;
+    PG_API_END
 }
 
 extern "C" int pg_ctx_destroy(pg_ctx *c) {
+    PG_API_BEGIN
     if (!c || c->dead) return PG_OK;
     c->dead = true;
     if (c->refs == 0) ctx_free(c);
     return PG_OK;
+    PG_API_END
 }
 
 // plain device buffers for a caller that has no other allocator at hand (the genome-sharded pipeline's exchange
 // buffers in a single-process run; with several ranks torch owns them, because the collective takes tensors)
 extern "C" int pg_device_alloc(pg_ctx *c, uint64_t bytes, void **out) {
+    PG_API_BEGIN
     if (!c || !out) return fail(PG_E_INVALID, "pg_device_alloc: NULL argument");
     if (int r = use_device(c)) return r;
     void *p = nullptr;
@@ -319,34 +329,43 @@ extern "C" int pg_device_alloc(pg_ctx *c, uint64_t bytes, void **out) {
     }
     *out = p;
     return PG_OK;
+    PG_API_END
 }
 extern "C" int pg_device_memset(pg_ctx *c, void *p, int value, uint64_t bytes) {
+    PG_API_BEGIN
     if (!c || (!p && bytes)) return fail(PG_E_INVALID, "pg_device_memset: NULL argument");
     if (int r = use_device(c)) return r;
     if (bytes) HIP_TRY(hipMemsetAsync(p, value, bytes, c->stream));
     return PG_OK;
+    PG_API_END
 }
 extern "C" int pg_device_free(pg_ctx *c, void *p) {
+    PG_API_BEGIN
     if (!c) return fail(PG_E_INVALID, "ctx is NULL");
     if (!p) return PG_OK;
     if (int r = use_device(c)) return r;
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipFree(p));
     return PG_OK;
+    PG_API_END
 }
 
 extern "C" int pg_ctx_set_stream(pg_ctx *c, void *s, int use_own) {
+    PG_API_BEGIN
     if (!c) return fail(PG_E_INVALID, "ctx is NULL");
     c->stream = use_own ? c->own_stream : reinterpret_cast<hipStream_t>(s);
     return PG_OK;
+    PG_API_END
 }
 
 extern "C" int pg_ctx_synchronize(pg_ctx *c) {
+    PG_API_BEGIN
     if (!c) return fail(PG_E_INVALID, "ctx is NULL");
     if (int r = use_device(c)) return r;
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipStreamSynchronize(c->aux_stream));
     return PG_OK;
+    PG_API_END
 }
 
 // ---------------------------------------------------------------------------
@@ -428,6 +447,7 @@ static TableGeom geom_for(int ngenomes) {
 }
 
 extern "C" int pg_table_bytes_for(int k, int ngenomes, uint64_t expected_keys, uint64_t *bytes) {
+    PG_API_BEGIN
     if (!bytes) return fail(PG_E_INVALID, "pg_table_bytes_for: NULL argument");
     if (k < 1 || k > 32 || ngenomes < 1) return fail(PG_E_INVALID, "pg_table_bytes_for: bad k / ngenomes");
     const TableGeom g = geom_for(ngenomes);
@@ -435,11 +455,13 @@ extern "C" int pg_table_bytes_for(int k, int ngenomes, uint64_t expected_keys, u
     const uint64_t nb = std::max<uint64_t>((uint64_t)((double)std::max<uint64_t>(expected_keys, 1ull << 18) / (TARGET_LOAD * g.slots)) + 1, 64);
     *bytes = g.layout == LAYOUT_SPLIT ? nb * g.slots * (8ull + 4ull * g.W) : nb * 16ull * g.slots;
     return PG_OK;
+    PG_API_END
 }
 
 static uint32_t window_cap();  // (PG_TABLE_WMAX, below)
 
 extern "C" int pg_table_create(pg_ctx *ctx, int k, int ngenomes, uint64_t expected_keys, pg_table **out) {
+    PG_API_BEGIN
     if (!ctx || !out) return fail(PG_E_INVALID, "pg_table_create: NULL argument");
     if (k < 1 || k > 32) return fail(PG_E_INVALID, "k=%d unsupported (1..32)", k);
     if (ngenomes < 1) return fail(PG_E_INVALID, "ngenomes must be >= 1");
@@ -482,6 +504,7 @@ extern "C" int pg_table_create(pg_ctx *ctx, int k, int ngenomes, uint64_t expect
     }
     *out = t;
     return PG_OK;
+    PG_API_END
 }
 
 static void table_free(pg_table *t) {
@@ -500,15 +523,18 @@ static void table_release(pg_table *t) {
 }
 
 extern "C" int pg_table_destroy(pg_table *t) {
+    PG_API_BEGIN
     if (!t || t->dead) return PG_OK;
     t->dead = true;
     if (t->refs == 0) table_free(t);
     return PG_OK;
+    PG_API_END
 }
 
 // every line EMPTY again, the allocation kept: the genome-sharded mode builds one block table after the other in the
 // same memory (freeing and re-allocating tens of GB costs about 40 ms per GB on this stack)
 extern "C" int pg_table_clear(pg_table *t) {
+    PG_API_BEGIN
     if (!t) return fail(PG_E_INVALID, "table is NULL");
     if (t->refs > 0) {
         // (results of this table only hold geometry and their own buffers: they stay valid, their rows are stale)
@@ -523,6 +549,7 @@ extern "C" int pg_table_clear(pg_table *t) {
     t->spill = 0;
     t->first_len = t->max_len = 0;
     return PG_OK;
+    PG_API_END
 }
 
 extern "C" int pg_table_k(const pg_table *t) { return t ? t->k : 0; }
@@ -530,6 +557,7 @@ extern "C" int pg_table_ngenomes(const pg_table *t) { return t ? t->ngenomes : 0
 extern "C" int pg_table_minimizer(const pg_table *t) { return t ? (int)t->m : 0; }
 
 extern "C" int pg_table_set_minimizer(pg_table *t, int m) {
+    PG_API_BEGIN
     if (!t) return fail(PG_E_INVALID, "table is NULL");
     const int w = m ? t->k - m + 1 : 0;
     if (m && (t->k < 20 || w < (int)MZ_WMIN || w > (int)MZ_WMAX))
@@ -541,6 +569,7 @@ extern "C" int pg_table_set_minimizer(pg_table *t, int m) {
     t->m_pinned = true;
     for (auto &s : t->subs) s.d.m = (uint32_t)m;
     return PG_OK;
+    PG_API_END
 }
 
 // The first sequence set that goes into an EMPTY table tells what the expected key count cannot: the non-redundant
@@ -682,6 +711,7 @@ static int enqueue_insert(pg_table *t, const SubTable &d, int w, uint32_t bits, 
 }
 
 extern "C" int pg_table_insert_seqset(pg_table *t, int g, const pg_seqset *sq) {
+    PG_API_BEGIN
     if (!t || !sq) return fail(PG_E_INVALID, "pg_table_insert_seqset: NULL argument");
     if (g < 0 || g >= t->ngenomes) return fail(PG_E_INVALID, "genome index %d out of range (0..%d)", g, t->ngenomes - 1);
     if (t->ctx != sq->ctx) return fail(PG_E_INVALID, "table and seqset belong to different contexts");
@@ -708,6 +738,7 @@ extern "C" int pg_table_insert_seqset(pg_table *t, int g, const pg_seqset *sq) {
         if (int r = grow_after_overflow(t, si, total)) return r;
     }
     return fail(PG_E_CAPACITY, "k-mer table keeps overflowing");
+    PG_API_END
 }
 
 // Bits only: genome g's bit goes into the keys of `sq`'s k-mers that the table ALREADY holds; no key is added.  A table
@@ -715,6 +746,7 @@ extern "C" int pg_table_insert_seqset(pg_table *t, int g, const pg_seqset *sq) {
 // makes exactly as the table of all genomes does — a position's k-mer is one of the anchors' own — at a fraction of its
 // size.  (Tables of 256-byte lines, PG_TABLE_SLOTS=16 / PG_INSERT_PER_THREAD, have no such kernel: they insert.)
 extern "C" int pg_table_update_seqset(pg_table *t, int g, const pg_seqset *sq) {
+    PG_API_BEGIN
     if (!t || !sq) return fail(PG_E_INVALID, "pg_table_update_seqset: NULL argument");
     if (g < 0 || g >= t->ngenomes) return fail(PG_E_INVALID, "genome index %d out of range (0..%d)", g, t->ngenomes - 1);
     if (t->ctx != sq->ctx) return fail(PG_E_INVALID, "table and seqset belong to different contexts");
@@ -729,11 +761,13 @@ extern "C" int pg_table_update_seqset(pg_table *t, int g, const pg_seqset *sq) {
     const int er = enqueue_insert(t, t->subs[0].d, w, bits, 2 /* update only */, sq, t->d_counters);
     unsigned long long cnt[2] = {0, 0};
     return er ? er : read_counters(t, cnt);  // (synchronises)
+    PG_API_END
 }
 
 // kmc -ci<min_count> (workflow/Snakefile:88-89: -ci2 for FASTQ samples): occurrences are counted in
 // a private table first; the keys seen at least min_count times then enter the pan table.
 extern "C" int pg_table_insert_seqset_min(pg_table *t, int g, const pg_seqset *sq, uint32_t min_count) {
+    PG_API_BEGIN
     if (min_count <= 1) return pg_table_insert_seqset(t, g, sq);
     if (!t || !sq) return fail(PG_E_INVALID, "pg_table_insert_seqset_min: NULL argument");
     if (g < 0 || g >= t->ngenomes) return fail(PG_E_INVALID, "genome index %d out of range (0..%d)", g, t->ngenomes - 1);
@@ -787,6 +821,7 @@ extern "C" int pg_table_insert_seqset_min(pg_table *t, int g, const pg_seqset *s
         if (rc || !redo) return rc;
     }
     return fail(PG_E_CAPACITY, "k-mer counting table keeps overflowing");
+    PG_API_END
 }
 
 static int insert_keys_dev(pg_table *t, int db_idx, const uint64_t *d_keys, const uint32_t *d_vals, uint64_t n) {
@@ -807,6 +842,7 @@ static int insert_keys_dev(pg_table *t, int db_idx, const uint64_t *d_keys, cons
 
 extern "C" int pg_table_insert_keys(pg_table *t, int db_idx, const uint64_t *keys, const uint32_t *counters,
                                     uint64_t n) {
+    PG_API_BEGIN
     if (!t || (n && (!keys || !counters))) return fail(PG_E_INVALID, "pg_table_insert_keys: NULL argument");
     if (db_idx < 0 || db_idx >= t->ndbs) return fail(PG_E_INVALID, "db index %d out of range (0..%d)", db_idx, t->ndbs - 1);
     if (n == 0) return PG_OK;
@@ -829,6 +865,7 @@ extern "C" int pg_table_insert_keys(pg_table *t, int db_idx, const uint64_t *key
     hipFree(dk);
     hipFree(dv);
     return r;
+    PG_API_END
 }
 
 // ---------------------------------------------------------------------------
@@ -901,6 +938,7 @@ static int parse_kmc_pre(const uint8_t *pre, size_t pre_len, KmcHeader *H) {
 
 extern "C" int pg_table_load_kmc(pg_table *t, int db_idx, const void *pre_, size_t pre_len, const void *suf_,
                                  size_t suf_len) {
+    PG_API_BEGIN
     if (!t || !pre_ || !suf_) return fail(PG_E_INVALID, "pg_table_load_kmc: NULL argument");
     if (db_idx < 0 || db_idx >= t->ndbs) return fail(PG_E_INVALID, "db index %d out of range (0..%d)", db_idx, t->ndbs - 1);
     const uint8_t *pre = static_cast<const uint8_t *>(pre_);
@@ -911,7 +949,9 @@ extern "C" int pg_table_load_kmc(pg_table *t, int db_idx, const void *pre_, size
         return fail(PG_E_FORMAT, "kmc_suf: missing KMCS markers");
     if ((int)H.k != t->k) return fail(PG_E_FORMAT, "database k=%u but table k=%d", H.k, t->k);
     const uint32_t sb = (H.k - H.lut_p) / 4, rec = sb + H.csz;
-    if (rec && 8 + H.total * rec > suf_len)
+    // (a division, not 8 + total * rec: the product wraps for a corrupt total_kmers, the check would pass and the
+    // chunk loop would read far past the mapping; checked before anything is allocated for `total` records)
+    if (rec ? H.total > (suf_len - 8) / rec : H.total > H.nlut)
         return fail(PG_E_FORMAT, "kmc_suf: truncated (%llu records of %u bytes expected)", (unsigned long long)H.total, rec);
     // the LUT must be monotone from 0 to total: it is what maps a record number to its prefix
     std::vector<uint64_t> lut(H.nlut);
@@ -1005,23 +1045,29 @@ extern "C" int pg_table_load_kmc(pg_table *t, int db_idx, const void *pre_, size
     }
     if (d_lut) hipFree(d_lut);
     return rc;
+    PG_API_END
 }
 
 // (kept under its round-1 name: the KMC1 layout was the only one read then)
 extern "C" int pg_table_load_kmc1(pg_table *t, int db_idx, const void *pre, size_t pre_len, const void *suf, size_t suf_len) {
+    PG_API_BEGIN
     return pg_table_load_kmc(t, db_idx, pre, pre_len, suf, suf_len);
+    PG_API_END
 }
 
 // k of a KMC database from its .kmc_pre image (either layout): what a caller needs before it can create the table
 extern "C" int pg_kmc_kmer_length(const void *pre, size_t pre_len, uint32_t *k) {
+    PG_API_BEGIN
     if (!pre || !k) return fail(PG_E_INVALID, "pg_kmc_kmer_length: NULL argument");
     KmcHeader H;
     if (int r = parse_kmc_pre(static_cast<const uint8_t *>(pre), pre_len, &H)) return r;
     *k = H.k;
     return PG_OK;
+    PG_API_END
 }
 
 extern "C" int pg_table_stats(pg_table *t, uint64_t *nkeys, uint64_t *nslots, uint64_t *nbuckets, uint64_t *bytes) {
+    PG_API_BEGIN
     if (!t) return fail(PG_E_INVALID, "table is NULL");
     uint64_t a = 0, b = 0, c = 0;
     for (auto &s : t->subs) {
@@ -1038,6 +1084,7 @@ extern "C" int pg_table_stats(pg_table *t, uint64_t *nkeys, uint64_t *nslots, ui
         *bytes = by;
     }
     return PG_OK;
+    PG_API_END
 }
 
 // keys of sub-table si that do not sit in their group's home line
@@ -1052,6 +1099,7 @@ static int count_spill(pg_table *t, int si, uint64_t *out) {
 }
 
 extern "C" int pg_table_rehash(pg_table *t, double keys_per_bucket) {
+    PG_API_BEGIN
     if (!t) return fail(PG_E_INVALID, "table is NULL");
     if (!(keys_per_bucket > 0.05 && keys_per_bucket <= 8.0)) return fail(PG_E_INVALID, "keys_per_bucket must be in (0.05, 8]");
     if (int r = use_device(t->ctx)) return r;
@@ -1080,16 +1128,20 @@ extern "C" int pg_table_rehash(pg_table *t, double keys_per_bucket) {
     }
     t->spill = keys ? (double)spilled / (double)keys : 0.0;
     return PG_OK;
+    PG_API_END
 }
 
 extern "C" int pg_table_spill(const pg_table *t, double *fraction, uint32_t *slots) {
+    PG_API_BEGIN
     if (!t) return fail(PG_E_INVALID, "table is NULL");
     if (fraction) *fraction = t->spill;
     if (slots) *slots = t->subs.empty() ? 0 : t->subs[0].d.slots;
     return PG_OK;
+    PG_API_END
 }
 
 extern "C" int pg_table_export(pg_table *t, int db_idx, uint64_t *keys, uint32_t *counters, uint64_t cap, uint64_t *n) {
+    PG_API_BEGIN
     if (!t || !n) return fail(PG_E_INVALID, "pg_table_export: NULL argument");
     if (db_idx < 0 || db_idx >= t->ndbs) return fail(PG_E_INVALID, "db index %d out of range", db_idx);
     if (int r = use_device(t->ctx)) return r;
@@ -1125,6 +1177,7 @@ extern "C" int pg_table_export(pg_table *t, int db_idx, uint64_t *keys, uint32_t
     if (dv) hipFree(dv);
     *n = cnt[0];
     return rc;
+    PG_API_END
 }
 
 // ---------------------------------------------------------------------------
@@ -1137,6 +1190,7 @@ struct pg_sketch {
 };
 
 extern "C" int pg_sketch_create(pg_ctx *ctx, int k, pg_sketch **out) {
+    PG_API_BEGIN
     if (!ctx || !out) return fail(PG_E_INVALID, "pg_sketch_create: NULL argument");
     if (k < 1 || k > 32) return fail(PG_E_INVALID, "k=%d unsupported (1..32)", k);
     if (int r = use_device(ctx)) return r;
@@ -1151,9 +1205,11 @@ extern "C" int pg_sketch_create(pg_ctx *ctx, int k, pg_sketch **out) {
     ++ctx->refs;
     *out = sk;
     return PG_OK;
+    PG_API_END
 }
 
 extern "C" int pg_sketch_destroy(pg_sketch *sk) {
+    PG_API_BEGIN
     if (!sk) return PG_OK;
     hipSetDevice(sk->ctx->device);
     hipStreamSynchronize(sk->ctx->stream);
@@ -1162,9 +1218,11 @@ extern "C" int pg_sketch_destroy(pg_sketch *sk) {
     delete sk;
     ctx_release(c);
     return PG_OK;
+    PG_API_END
 }
 
 extern "C" int pg_sketch_add_seqset(pg_sketch *sk, const pg_seqset *sq) {
+    PG_API_BEGIN
     if (!sk || !sq) return fail(PG_E_INVALID, "pg_sketch_add_seqset: NULL argument");
     if (sk->ctx != sq->ctx) return fail(PG_E_INVALID, "sketch and seqset belong to different contexts");
     if (int r = use_device(sk->ctx)) return r;
@@ -1175,9 +1233,11 @@ extern "C" int pg_sketch_add_seqset(pg_sketch *sk, const pg_seqset *sq) {
                               sd.len - sk->k + 1, sk->d_regs));
     }
     return PG_OK;
+    PG_API_END
 }
 
 extern "C" int pg_sketch_registers(pg_sketch *sk, uint8_t *out) {
+    PG_API_BEGIN
     if (!sk || !out) return fail(PG_E_INVALID, "pg_sketch_registers: NULL argument");
     if (int r = use_device(sk->ctx)) return r;
     std::vector<uint32_t> regs((size_t)1 << SKETCH_BITS);
@@ -1185,11 +1245,13 @@ extern "C" int pg_sketch_registers(pg_sketch *sk, uint8_t *out) {
     HIP_TRY(hipStreamSynchronize(sk->ctx->stream));
     for (size_t i = 0; i < regs.size(); ++i) out[i] = (uint8_t)regs[i];
     return PG_OK;
+    PG_API_END
 }
 
 // HyperLogLog (Flajolet et al. 2007) with the small-range correction; 64-bit hashes need no
 // large-range one.  Standard error 1.04 / sqrt(2^16) = 0.4 %.
 extern "C" int pg_sketch_estimate_registers(const uint8_t *regs, uint64_t *distinct) {
+    PG_API_BEGIN
     if (!regs || !distinct) return fail(PG_E_INVALID, "pg_sketch_estimate_registers: NULL argument");
     const size_t n = (size_t)1 << SKETCH_BITS;
     const double m = (double)n;
@@ -1203,26 +1265,32 @@ extern "C" int pg_sketch_estimate_registers(const uint8_t *regs, uint64_t *disti
     if (est <= 2.5 * m && zeros) est = m * std::log(m / (double)zeros);
     *distinct = (uint64_t)(est + 0.5);
     return PG_OK;
+    PG_API_END
 }
 
 extern "C" int pg_sketch_estimate(pg_sketch *sk, uint64_t *distinct) {
+    PG_API_BEGIN
     if (!sk || !distinct) return fail(PG_E_INVALID, "pg_sketch_estimate: NULL argument");
     std::vector<uint8_t> regs((size_t)1 << SKETCH_BITS);
     if (int r = pg_sketch_registers(sk, regs.data())) return r;
     return pg_sketch_estimate_registers(regs.data(), distinct);
+    PG_API_END
 }
 
 extern "C" int pg_sketch_reset(pg_sketch *sk) {
+    PG_API_BEGIN
     if (!sk) return fail(PG_E_INVALID, "pg_sketch_reset: NULL argument");
     if (int r = use_device(sk->ctx)) return r;
     HIP_TRY(hipMemsetAsync(sk->d_regs, 0, sizeof(uint32_t) << SKETCH_BITS, sk->ctx->stream));
     return PG_OK;
+    PG_API_END
 }
 
 // ---------------------------------------------------------------------------
 // seqset
 // ---------------------------------------------------------------------------
 extern "C" int pg_seqset_create(pg_ctx *ctx, uint32_t ncontigs, const uint64_t *lens, pg_seqset **out) {
+    PG_API_BEGIN
     if (!ctx || !out || (ncontigs && !lens)) return fail(PG_E_INVALID, "pg_seqset_create: NULL argument");
     if (int r = use_device(ctx)) return r;
     pg_seqset *s = new pg_seqset();
@@ -1265,6 +1333,7 @@ extern "C" int pg_seqset_create(pg_ctx *ctx, uint32_t ncontigs, const uint64_t *
     }
     *out = s;
     return PG_OK;
+    PG_API_END
 }
 
 static void seqset_free(pg_seqset *s) {
@@ -1284,13 +1353,16 @@ static void seqset_release(pg_seqset *s) {
 }
 
 extern "C" int pg_seqset_destroy(pg_seqset *s) {
+    PG_API_BEGIN
     if (!s || s->dead) return PG_OK;
     s->dead = true;
     if (s->refs == 0) seqset_free(s);
     return PG_OK;
+    PG_API_END
 }
 
 extern "C" int pg_seqset_load_dev(pg_seqset *s, uint32_t idx, const void *d_ascii, uint64_t len) {
+    PG_API_BEGIN
     if (!s || (len && !d_ascii)) return fail(PG_E_INVALID, "pg_seqset_load_dev: NULL argument");
     if (idx >= s->n) return fail(PG_E_INVALID, "contig %u out of range (0..%u)", idx, s->n ? s->n - 1 : 0);
     const SeqDesc &d = s->desc[idx];
@@ -1300,9 +1372,11 @@ extern "C" int pg_seqset_load_dev(pg_seqset *s, uint32_t idx, const void *d_asci
     HIP_TRY(launch_pack(s->ctx->stream, d_ascii, len, s->d_seqw + d.seq_off, s->d_nmw + d.seq_off,
                         (len + 31) / 32, s->d_has_n + idx));
     return PG_OK;
+    PG_API_END
 }
 
 extern "C" int pg_seqset_load_host(pg_seqset *s, uint32_t idx, const char *ascii, uint64_t len) {
+    PG_API_BEGIN
     if (!s || (len && !ascii)) return fail(PG_E_INVALID, "pg_seqset_load_host: NULL argument");
     if (idx >= s->n) return fail(PG_E_INVALID, "contig %u out of range", idx);
     if (int r = use_device(s->ctx)) return r;
@@ -1319,6 +1393,7 @@ extern "C" int pg_seqset_load_host(pg_seqset *s, uint32_t idx, const char *ascii
     if (int r = pg_seqset_load_dev(s, idx, s->d_stage, len)) return r;
     HIP_TRY(hipStreamSynchronize(s->ctx->stream));  // staging buffer is reused by the next call
     return PG_OK;
+    PG_API_END
 }
 
 // ---------------------------------------------------------------------------
@@ -1328,6 +1403,7 @@ extern "C" int pg_seqset_load_host(pg_seqset *s, uint32_t idx, const char *ascii
 static inline bool host_is_ws(unsigned char c) { return c == ' ' || (c >= 9 && c <= 13); }
 
 extern "C" int pg_seqset_from_fasta(pg_ctx *ctx, const void *text_, uint64_t nbytes, pg_seqset **out) {
+    PG_API_BEGIN
     if (!ctx || !out || (nbytes && !text_)) return fail(PG_E_INVALID, "pg_seqset_from_fasta: NULL argument");
     if (int r = use_device(ctx)) return r;
     const unsigned char *text = static_cast<const unsigned char *>(text_);
@@ -1438,6 +1514,7 @@ extern "C" int pg_seqset_from_fasta(pg_ctx *ctx, const void *text_, uint64_t nby
     }
     *out = s;
     return PG_OK;
+    PG_API_END
 }
 
 // one seqset holding contigs [first[i], first[i] + count[i]) of sets[i], in order (device-to-device copy of the packed
@@ -1482,26 +1559,33 @@ static int seqset_concat(pg_ctx *ctx, const pg_seqset *const *sets, const uint32
 }
 
 extern "C" int pg_seqset_concat(pg_ctx *ctx, const pg_seqset *const *sets, uint32_t nsets, pg_seqset **out) {
+    PG_API_BEGIN
     return seqset_concat(ctx, sets, nullptr, nullptr, nsets, out);
+    PG_API_END
 }
 
 extern "C" int pg_seqset_concat_ranges(pg_ctx *ctx, const pg_seqset *const *sets, const uint32_t *first_contig,
                                        const uint32_t *ncontigs, uint32_t nsets, pg_seqset **out) {
+    PG_API_BEGIN
     if (nsets && (!first_contig || !ncontigs)) return fail(PG_E_INVALID, "pg_seqset_concat_ranges: NULL argument");
     return seqset_concat(ctx, sets, first_contig, ncontigs, nsets, out);
+    PG_API_END
 }
 
 extern "C" uint32_t pg_seqset_ncontigs(const pg_seqset *s) { return s ? s->n : 0; }
 
 extern "C" int pg_seqset_contig(const pg_seqset *s, uint32_t idx, const char **name, uint64_t *len) {
+    PG_API_BEGIN
     if (!s) return fail(PG_E_INVALID, "seqset is NULL");
     if (idx >= s->n) return fail(PG_E_INVALID, "contig %u out of range", idx);
     if (name) *name = idx < s->names.size() ? s->names[idx].c_str() : "";
     if (len) *len = s->desc[idx].len;
     return PG_OK;
+    PG_API_END
 }
 
 extern "C" int pg_seqset_unpack(const pg_seqset *s, uint32_t idx, char *out) {
+    PG_API_BEGIN
     if (!s || !out) return fail(PG_E_INVALID, "pg_seqset_unpack: NULL argument");
     if (idx >= s->n) return fail(PG_E_INVALID, "contig %u out of range", idx);
     if (int r = use_device(s->ctx)) return r;
@@ -1517,6 +1601,7 @@ extern "C" int pg_seqset_unpack(const pg_seqset *s, uint32_t idx, char *out) {
     for (uint64_t i = 0; i < d.len; ++i)
         out[i] = ((nm[i >> 5] >> (i & 31)) & 1u) ? 'N' : "ACGT"[(w[i >> 5] >> (2 * (i & 31))) & 3u];
     return PG_OK;
+    PG_API_END
 }
 
 extern "C" uint64_t pg_seqset_total_kmers(const pg_seqset *s, int k) {
@@ -1640,22 +1725,27 @@ static int result_create(pg_ctx *ctx, pg_table *t, int k, uint32_t N, const pg_s
 }
 
 extern "C" int pg_result_create(pg_table *t, const pg_seqset *sq, uint32_t flags, pg_result **out) {
+    PG_API_BEGIN
     if (!t || !sq || !out) return fail(PG_E_INVALID, "pg_result_create: NULL argument");
     return result_create(t->ctx, t, t->k, (uint32_t)t->ngenomes, sq, flags, ResultGeom(), out);
+    PG_API_END
 }
 
 extern "C" int pg_result_create_ex(pg_table *t, const pg_seqset *sq, uint32_t flags, uint32_t lowres_step,
                                    uint64_t max_bin_len, uint32_t min_bin_count, pg_result **out) {
+    PG_API_BEGIN
     if (!t || !sq || !out) return fail(PG_E_INVALID, "pg_result_create_ex: NULL argument");
     ResultGeom g;
     g.lowres_step = lowres_step;
     g.max_bin_len = max_bin_len;
     g.min_bin_count = min_bin_count;
     return result_create(t->ctx, t, t->k, (uint32_t)t->ngenomes, sq, flags, g, out);
+    PG_API_END
 }
 
 extern "C" int pg_result_create_rows(pg_ctx *ctx, int k, int ngenomes, const pg_seqset *sq, uint32_t flags,
                                      uint32_t lowres_step, uint64_t max_bin_len, uint32_t min_bin_count, pg_result **out) {
+    PG_API_BEGIN
     if (!ctx || !sq || !out) return fail(PG_E_INVALID, "pg_result_create_rows: NULL argument");
     if (k < 1 || k > 32) return fail(PG_E_INVALID, "k=%d unsupported (1..32)", k);
     if (ngenomes < 1) return fail(PG_E_INVALID, "ngenomes must be >= 1");
@@ -1664,9 +1754,11 @@ extern "C" int pg_result_create_rows(pg_ctx *ctx, int k, int ngenomes, const pg_
     g.max_bin_len = max_bin_len;
     g.min_bin_count = min_bin_count;
     return result_create(ctx, nullptr, k, (uint32_t)ngenomes, sq, flags | PG_ANCHOR_ROWS_ONLY, g, out);
+    PG_API_END
 }
 
 extern "C" int pg_result_destroy(pg_result *r) {
+    PG_API_BEGIN
     if (!r) return PG_OK;
     hipSetDevice(r->ctx->device);
     hipStreamSynchronize(r->ctx->stream);
@@ -1690,6 +1782,7 @@ extern "C" int pg_result_destroy(pg_result *r) {
     else ctx_release(c);
     seqset_release(sq);
     return PG_OK;
+    PG_API_END
 }
 
 // statistics kernels of a result, on stream `st`
@@ -1778,21 +1871,27 @@ static int coschedule(pg_result *r, const uint32_t *contig_group, uint32_t piece
 }
 
 extern "C" int pg_result_coschedule(pg_result *r, const uint32_t *contig_group, uint32_t piece_tiles) {
+    PG_API_BEGIN
     if (!r) return fail(PG_E_INVALID, "result is NULL");
     return coschedule(r, contig_group, piece_tiles, nullptr, 0);
+    PG_API_END
 }
 
 extern "C" int pg_result_coschedule_classes(pg_result *r, const uint32_t *contig_group, const uint32_t *contig_class,
                                             uint32_t piece_tiles) {
+    PG_API_BEGIN
     if (!r) return fail(PG_E_INVALID, "result is NULL");
     if (contig_group && !contig_class) return fail(PG_E_INVALID, "pg_result_coschedule_classes: contig_class is NULL");
     return coschedule(r, contig_group, piece_tiles, nullptr, 0, contig_class);
+    PG_API_END
 }
 
 extern "C" int pg_result_coschedule_ranges(pg_result *r, const uint32_t *contig_group, uint32_t piece_tiles,
                                            const uint32_t *range_first_contig, uint32_t nranges) {
+    PG_API_BEGIN
     if (!r) return fail(PG_E_INVALID, "result is NULL");
     return coschedule(r, contig_group, piece_tiles, range_first_contig, nranges);
+    PG_API_END
 }
 
 static int enqueue_epilogue(pg_result *r, hipStream_t st) {
@@ -1906,37 +2005,46 @@ static int anchor_run(pg_result *r, uint32_t tile_base, uint32_t ntiles, bool wh
 }
 
 extern "C" int pg_anchor_run(pg_result *r) {
+    PG_API_BEGIN
     if (!r) return fail(PG_E_INVALID, "result is NULL");
     if (r->flags & PG_ANCHOR_COLUMNS_ONLY) return fail(PG_E_INVALID, "a PG_ANCHOR_COLUMNS_ONLY result has no rows: use pg_anchor_run_columns_range");
     return anchor_run(r, 0, r->ntiles, true);
+    PG_API_END
 }
 
 extern "C" int pg_anchor_run_range(pg_result *r, uint32_t first_contig, uint32_t ncontigs) {
+    PG_API_BEGIN
     if (!r) return fail(PG_E_INVALID, "result is NULL");
     if (r->flags & PG_ANCHOR_COLUMNS_ONLY) return fail(PG_E_INVALID, "a PG_ANCHOR_COLUMNS_ONLY result has no rows: use pg_anchor_run_columns_range");
     if (!(r->flags & PG_ANCHOR_ROWS_ONLY)) return fail(PG_E_INVALID, "pg_anchor_run_range needs a PG_ANCHOR_ROWS_ONLY result");
     uint32_t t0, nt;
     if (int e = contig_tiles(r, first_contig, ncontigs, &t0, &nt)) return e;
     return anchor_run(r, t0, nt, false);
+    PG_API_END
 }
 
 extern "C" int pg_result_columns_direct(const pg_result *r, uint32_t width) {
+    PG_API_BEGIN
     if (!r || !r->tbl) return 0;
     const pg_table *t = r->tbl;
     return t->subs.size() == 1 && t->subs[0].d.layout == LAYOUT_SLOTS && t->subs[0].d.W == 1 && t->subs[0].d.slots == 8 &&
            t->ngenomes <= 8 && width <= 8 && (int)width >= t->ngenomes;
+    PG_API_END
 }
 
 extern "C" int pg_anchor_run_columns_range(pg_result *r, uint32_t first_contig, uint32_t ncontigs, uint32_t width, void *d_dst) {
+    PG_API_BEGIN
     if (!r || !d_dst) return fail(PG_E_INVALID, "pg_anchor_run_columns_range: NULL argument");
     if (!pg_result_columns_direct(r, width))
         return fail(PG_E_INVALID, "pg_anchor_run_columns_range: needs a table of up to 8 genomes (8-slot lines) and width in ngenomes..8");
     uint32_t t0, nt;
     if (int e = contig_tiles(r, first_contig, ncontigs, &t0, &nt)) return e;
     return anchor_run(r, t0, nt, false, width, d_dst);
+    PG_API_END
 }
 
 extern "C" int pg_result_timing(pg_result *r, float *probe_ms, float *epilogue_ms) {
+    PG_API_BEGIN
     if (!r) return fail(PG_E_INVALID, "result is NULL");
     if (!r->ev_ok) return fail(PG_E_INVALID, "pg_anchor_run has not been called on this result");
     if (int e = use_device(r->ctx)) return e;
@@ -1947,9 +2055,11 @@ extern "C" int pg_result_timing(pg_result *r, float *probe_ms, float *epilogue_m
     if (probe_ms) *probe_ms = a;
     if (epilogue_ms) *epilogue_ms = b;
     return PG_OK;
+    PG_API_END
 }
 
 extern "C" int pg_result_timing_reset(pg_result *r) {
+    PG_API_BEGIN
     if (!r) return fail(PG_E_INVALID, "result is NULL");
     // the latest set stays alive (r->ev[] and the writers' stream waits refer to it) but no longer counts
     while (r->ev_hist.size() > 1) {
@@ -1960,9 +2070,11 @@ extern "C" int pg_result_timing_reset(pg_result *r) {
     r->probe_ms_sum = r->epi_ms_sum = 0;
     r->probe_runs = r->epi_runs = 0;
     return PG_OK;
+    PG_API_END
 }
 
 extern "C" int pg_result_timing_mean(pg_result *r, double *probe_ms, double *epilogue_ms, uint32_t *nruns) {
+    PG_API_BEGIN
     if (!r) return fail(PG_E_INVALID, "result is NULL");
     if (int e = use_device(r->ctx)) return e;
     // sums of the sets that left the ring + the sets still in it (waits for the last of them)
@@ -1980,6 +2092,7 @@ extern "C" int pg_result_timing_mean(pg_result *r, double *probe_ms, double *epi
     r->probe_runs = pn0;
     r->epi_runs = en0;
     return rc;
+    PG_API_END
 }
 
 // ---------------------------------------------------------------------------
@@ -1997,6 +2110,7 @@ extern "C" uint64_t pg_result_columns_bytes_range(const pg_result *r, uint32_t w
 
 extern "C" int pg_result_extract_columns_range(pg_result *r, uint32_t g0, uint32_t width, uint32_t first_contig,
                                                uint32_t ncontigs, void *d_dst) {
+    PG_API_BEGIN
     if (!r || !d_dst) return fail(PG_E_INVALID, "pg_result_extract_columns: NULL argument");
     if (!r->ev_ok && !r->rows_valid) return fail(PG_E_INVALID, "the result holds no rows yet");
     uint32_t t0, nt;
@@ -2004,16 +2118,20 @@ extern "C" int pg_result_extract_columns_range(pg_result *r, uint32_t g0, uint32
     if (int e = use_device(r->ctx)) return e;
     HIP_TRY(launch_cols_extract(r->ctx->stream, r->N, r->d_ad, r->d_tile_contig, t0, nt, r->d_out1, g0, width, d_dst));
     return PG_OK;
+    PG_API_END
 }
 
 extern "C" int pg_result_extract_columns(pg_result *r, uint32_t g0, uint32_t width, void *d_dst) {
+    PG_API_BEGIN
     if (!r) return fail(PG_E_INVALID, "pg_result_extract_columns: NULL argument");
     return pg_result_extract_columns_range(r, g0, width, 0, (uint32_t)r->ad.size(), d_dst);
+    PG_API_END
 }
 
 extern "C" int pg_result_merge_columns_range(pg_result *r, const void *d_src, uint32_t part0, uint32_t nparts, uint32_t per,
                                              uint32_t first_contig, uint32_t ncontigs, int accumulate,
                                              uint64_t part_stride_bytes) {
+    PG_API_BEGIN
     if (!r || !d_src) return fail(PG_E_INVALID, "pg_result_merge_columns: NULL argument");
     if (per == 0 || nparts == 0) return fail(PG_E_INVALID, "pg_result_merge_columns: empty partition");
     uint32_t t0, nt;
@@ -2027,14 +2145,18 @@ extern "C" int pg_result_merge_columns_range(pg_result *r, const void *d_src, ui
                               part_stride_bytes / 8, per, accumulate ? 1u : 0u));
     r->rows_valid = true;
     return PG_OK;
+    PG_API_END
 }
 
 extern "C" int pg_result_merge_columns(pg_result *r, const void *d_src, uint32_t nparts, uint32_t per) {
+    PG_API_BEGIN
     if (!r) return fail(PG_E_INVALID, "pg_result_merge_columns: NULL argument");
     return pg_result_merge_columns_range(r, d_src, 0, nparts, per, 0, (uint32_t)r->ad.size(), 0, 0);
+    PG_API_END
 }
 
 extern "C" int pg_rows_epilogue(pg_result *r) {
+    PG_API_BEGIN
     if (!r) return fail(PG_E_INVALID, "result is NULL");
     if (int e = use_device(r->ctx)) return e;
     if (int e = join_result(r)) return e;
@@ -2050,6 +2172,7 @@ extern "C" int pg_rows_epilogue(pg_result *r) {
     r->ev_epi = true;
     r->ev_hist.back().epi = true;
     return PG_OK;
+    PG_API_END
 }
 
 // ---------------------------------------------------------------------------
@@ -2252,12 +2375,15 @@ static int write_bgzf_gpu(pg_result *r, const uint8_t *src, const std::vector<st
 // ---------------------------------------------------------------------------
 extern "C" int pg_result_write_bgzf(pg_result *r, int step, const char *gz_path, const char *gzi_path, int level,
                                     int nthreads) {
+    PG_API_BEGIN
     if (!r) return fail(PG_E_INVALID, "pg_result_write_bgzf: NULL argument");
     return pg_result_write_bgzf_range(r, step, 0, (uint32_t)r->ad.size(), gz_path, gzi_path, level, nthreads);
+    PG_API_END
 }
 
 extern "C" int pg_result_write_bgzf_range(pg_result *r, int step, uint32_t first_contig, uint32_t ncontigs,
                                           const char *gz_path, const char *gzi_path, int level, int nthreads) {
+    PG_API_BEGIN
     if (!r || !gz_path) return fail(PG_E_INVALID, "pg_result_write_bgzf: NULL argument");
     if ((uint64_t)first_contig + ncontigs > r->ad.size())
         return fail(PG_E_INVALID, "contigs %u..%u out of range", first_contig, first_contig + ncontigs);
@@ -2341,6 +2467,7 @@ extern "C" int pg_result_write_bgzf_range(pg_result *r, int step, uint32_t first
     }
     if (cs) hipStreamDestroy(cs);
     return rc ? rc : rc2;
+    PG_API_END
 }
 
 // ---------------------------------------------------------------------------
@@ -2348,6 +2475,7 @@ extern "C" int pg_result_write_bgzf_range(pg_result *r, int step, uint32_t first
 // ---------------------------------------------------------------------------
 extern "C" int pg_result_window_stats(pg_result *r, uint32_t idx, int step, uint32_t nwin, const uint64_t *starts,
                                       const uint64_t *ends, uint64_t *hist, uint64_t *colsums) {
+    PG_API_BEGIN
     if (!r || (nwin && (!starts || !ends || !hist))) return fail(PG_E_INVALID, "pg_result_window_stats: NULL argument");
     if (idx >= r->ad.size()) return fail(PG_E_INVALID, "contig %u out of range", idx);
     if (step != 1 && step != 100 && (uint32_t)step != r->lowres_step)
@@ -2383,10 +2511,12 @@ extern "C" int pg_result_window_stats(pg_result *r, uint32_t idx, int step, uint
     if (d_se) hipFree(d_se);
     if (d_out) hipFree(d_out);
     return rc;
+    PG_API_END
 }
 
 extern "C" int pg_result_contig_info(const pg_result *r, uint32_t idx, uint64_t *nkmers, uint64_t *nrows100,
                                      uint32_t *nbins, uint32_t *binlen) {
+    PG_API_BEGIN
     if (!r) return fail(PG_E_INVALID, "result is NULL");
     if (idx >= r->ad.size()) return fail(PG_E_INVALID, "contig %u out of range", idx);
     if (nkmers) *nkmers = r->ad[idx].nkmers;
@@ -2394,9 +2524,11 @@ extern "C" int pg_result_contig_info(const pg_result *r, uint32_t idx, uint64_t 
     if (nbins) *nbins = r->ad[idx].nbins;
     if (binlen) *binlen = r->ad[idx].binlen;
     return PG_OK;
+    PG_API_END
 }
 
 extern "C" int pg_result_download(pg_result *r, uint32_t idx, uint8_t *bitmap1, uint8_t *bitmap100, uint32_t *bins) {
+    PG_API_BEGIN
     if (!r) return fail(PG_E_INVALID, "result is NULL");
     if (idx >= r->ad.size()) return fail(PG_E_INVALID, "contig %u out of range", idx);
     if (int e = use_device(r->ctx)) return e;
@@ -2412,9 +2544,11 @@ extern "C" int pg_result_download(pg_result *r, uint32_t idx, uint8_t *bitmap1, 
         HIP_TRY(hipMemcpyAsync(bins, r->d_bins + a.bin_off * (N + 1), (uint64_t)a.nbins * (N + 1) * 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     return PG_OK;
+    PG_API_END
 }
 
 extern "C" int pg_result_colsums(pg_result *r, uint64_t *colsums) {
+    PG_API_BEGIN
     if (!r || !colsums) return fail(PG_E_INVALID, "pg_result_colsums: NULL argument");
     if (!(r->flags & PG_ANCHOR_COLSUMS)) return fail(PG_E_INVALID, "result was created without PG_ANCHOR_COLSUMS");
     if (int e = use_device(r->ctx)) return e;
@@ -2430,9 +2564,11 @@ extern "C" int pg_result_colsums(pg_result *r, uint64_t *colsums) {
     for (size_t c = 0; c < nc; ++c)
         for (size_t g = 0; g < N; ++g) colsums[g] += all[c * N + g];
     return PG_OK;
+    PG_API_END
 }
 
 extern "C" int pg_result_contig_colsums(pg_result *r, uint32_t idx, uint32_t ncontigs, uint64_t *colsums) {
+    PG_API_BEGIN
     if (!r || !colsums) return fail(PG_E_INVALID, "pg_result_contig_colsums: NULL argument");
     if (!(r->flags & PG_ANCHOR_COLSUMS)) return fail(PG_E_INVALID, "result was created without PG_ANCHOR_COLSUMS");
     if ((uint64_t)idx + ncontigs > r->ad.size()) return fail(PG_E_INVALID, "contigs %u..%u out of range", idx, idx + ncontigs);
@@ -2444,19 +2580,23 @@ extern "C" int pg_result_contig_colsums(pg_result *r, uint32_t idx, uint32_t nco
     HIP_TRY(hipMemcpyAsync(colsums, r->d_colsums + (size_t)idx * N, (size_t)ncontigs * N * 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     return PG_OK;
+    PG_API_END
 }
 
 extern "C" int pg_result_device_ptrs(pg_result *r, void **d1, uint64_t *b1, void **d100, uint64_t *b100) {
+    PG_API_BEGIN
     if (!r) return fail(PG_E_INVALID, "result is NULL");
     if (d1) *d1 = r->d_out1;
     if (b1) *b1 = r->out1_bytes;
     if (d100) *d100 = r->d_out100;
     if (b100) *b100 = r->out100_bytes;
     return PG_OK;
+    PG_API_END
 }
 
 extern "C" int pg_anchor_contig(pg_table *t, const char *ascii, uint64_t len, uint8_t *bitmap1, uint8_t *bitmap100,
                                 uint32_t *bins, uint64_t *colsums, uint64_t *nkmers) {
+    PG_API_BEGIN
     if (!t || (len && !ascii)) return fail(PG_E_INVALID, "pg_anchor_contig: NULL argument");
     if (nkmers) *nkmers = len >= (uint64_t)t->k ? len - t->k + 1 : 0;
     if (colsums) memset(colsums, 0, (size_t)t->ngenomes * 8);
@@ -2472,9 +2612,11 @@ extern "C" int pg_anchor_contig(pg_table *t, const char *ascii, uint64_t len, ui
     pg_result_destroy(res);
     pg_seqset_destroy(sq);
     return rc;
+    PG_API_END
 }
 
 extern "C" int pg_counters_for_read(pg_table *t, int db_idx, const char *ascii, uint64_t len, uint32_t *out) {
+    PG_API_BEGIN
     if (!t || (len && !ascii)) return fail(PG_E_INVALID, "pg_counters_for_read: NULL argument");
     if (db_idx < 0 || db_idx >= t->ndbs) return fail(PG_E_INVALID, "db index %d out of range (0..%d)", db_idx, t->ndbs - 1);
     if (len < (uint64_t)t->k) return PG_OK;
@@ -2496,4 +2638,5 @@ extern "C" int pg_counters_for_read(pg_table *t, int db_idx, const char *ascii, 
     if (d_out) hipFree(d_out);
     pg_seqset_destroy(sq);
     return rc;
+    PG_API_END
 }

@@ -19,13 +19,15 @@
 #include <condition_variable>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
 
+#include "pg_guard.h"
+
 extern "C" const char *pg_last_error(void);
-int pg_set_error(int code, const char *msg);  // pg_api.hip: one thread-local error slot for the library
 
 namespace {
 constexpr size_t BLOCK = 65280;         // htslib BGZF_BLOCK_SIZE
@@ -363,9 +365,20 @@ struct Pool {
             clen[i] = deflate_block(d, stored, row ? &rd : nullptr, row, data + off, n, cbuf + i * MAX_CBLOCK);
         }
     }
-    void loop() {
-        Deflater d(level), stored(0);
-        RowDeflater rd;
+    // A worker never lets an exception out of its thread function (that would be std::terminate under the
+    // interpreter): a failure — an allocation inside the encoders, say — marks the pool `failed`, the worker keeps
+    // taking part in the job hand-shake, and pg_bgzf_write reports PG_E_IO.
+    std::atomic<bool> failed{false};
+    void loop() noexcept {
+        std::unique_ptr<Deflater> d, stored;
+        std::unique_ptr<RowDeflater> rd;
+        try {
+            d.reset(new Deflater(level));
+            stored.reset(new Deflater(0));
+            rd.reset(new RowDeflater());
+        } catch (...) {
+            failed.store(true);
+        }
         uint64_t seen = 0;
         std::unique_lock<std::mutex> lk(mu);
         for (;;) {
@@ -373,22 +386,35 @@ struct Pool {
             if (quit) return;
             seen = gen;
             lk.unlock();
-            work(d, stored, rd);
+            if (!failed.load()) {
+                try {
+                    work(*d, *stored, *rd);
+                } catch (...) {
+                    failed.store(true);
+                }
+            }
             lk.lock();
             if (--running == 0) cv_done.notify_all();
         }
     }
     Pool(int nthreads, int lvl, unsigned row_) : level(lvl), row(row_) {
-        for (int t = 0; t < nthreads; ++t) th.emplace_back([this] { loop(); });
+        try {
+            for (int t = 0; t < nthreads; ++t) th.emplace_back([this] { loop(); });
+        } catch (...) {  // (thread creation refused: the ones already running must be joined before the vector dies)
+            stop();
+            throw;
+        }
     }
-    ~Pool() {
+    void stop() noexcept {
         {
             std::lock_guard<std::mutex> lk(mu);
             quit = true;
         }
         cv_job.notify_all();
         for (auto &t : th) t.join();
+        th.clear();
     }
+    ~Pool() { stop(); }
     void run(const unsigned char *d, size_t n, size_t blocks, unsigned char *out, size_t *lens) {
         std::unique_lock<std::mutex> lk(mu);
         data = d;
@@ -427,8 +453,10 @@ static int flush_blocks(pg_bgzf *w, const unsigned char *data, size_t nbytes) {
     if (nblk == 0) return PG_OK;
     if (w->cbuf.size() < nblk * MAX_CBLOCK) w->cbuf.resize(nblk * MAX_CBLOCK);
     w->clen.assign(nblk, 0);
-    if (w->pool && nblk > 1) w->pool->run(data, nbytes, nblk, w->cbuf.data(), w->clen.data());
-    else {
+    if (w->pool && nblk > 1) {
+        w->pool->run(data, nbytes, nblk, w->cbuf.data(), w->clen.data());
+        if (w->pool->failed.load()) return bfail(PG_E_IO, "a BGZF worker thread failed (out of memory?)");
+    } else {
         Deflater d(w->level), stored(0);
         RowDeflater rd;
         for (size_t i = 0; i < nblk; ++i)
@@ -448,11 +476,19 @@ static int flush_blocks(pg_bgzf *w, const unsigned char *data, size_t nbytes) {
 }
 
 extern "C" int pg_bgzf_open(const char *path, int level, int nthreads, pg_bgzf **out) {
+    PG_API_BEGIN
     if (!path || !out) return bfail(PG_E_INVALID, "pg_bgzf_open: NULL argument");
     FILE *f = fopen(path, "wb");
     if (!f) return bfail(PG_E_IO, std::string("cannot open ") + path + " for writing");
-    pg_bgzf *w = new pg_bgzf();
+    pg_bgzf *w = nullptr;
+    try {
+        w = new pg_bgzf();
+    } catch (...) {
+        fclose(f);
+        throw;  // (PG_API_END turns it into an error code)
+    }
     w->f = f;
+    w->pool = nullptr;
     const int lv = level < 0 ? -1 : (level & 0xff);
     w->level = ((lv < 0 || lv > 9) ? 6 : lv) | (level > 0 ? (level & PG_BGZF_RLE) : 0);
     w->row = level > 0 ? (unsigned)((level >> 16) & 0xff) : 0;
@@ -460,12 +496,20 @@ extern "C" int pg_bgzf_open(const char *path, int level, int nthreads, pg_bgzf *
     w->cpos = w->upos = 0;
     w->batch_blocks = 256;  // 16 MiB of input per parallel batch whatever the thread count
     w->failed = false;
-    w->pool = w->nthreads > 1 ? new Pool(w->nthreads, w->level, w->row) : nullptr;
+    try {
+        if (w->nthreads > 1) w->pool = new Pool(w->nthreads, w->level, w->row);
+    } catch (...) {
+        fclose(f);
+        delete w;
+        throw;
+    }
     *out = w;
     return PG_OK;
+    PG_API_END
 }
 
 extern "C" int pg_bgzf_write(pg_bgzf *w, const void *data_, size_t len) {
+    PG_API_BEGIN
     if (!w || (len && !data_)) return bfail(PG_E_INVALID, "pg_bgzf_write: NULL argument");
     if (w->failed) return bfail(PG_E_IO, "BGZF writer is in a failed state");
     const unsigned char *data = static_cast<const unsigned char *>(data_);
@@ -496,9 +540,11 @@ extern "C" int pg_bgzf_write(pg_bgzf *w, const void *data_, size_t len) {
     }
     if (len) w->pending.insert(w->pending.end(), data, data + len);
     return PG_OK;
+    PG_API_END
 }
 
 extern "C" int pg_bgzf_close(pg_bgzf *w, const char *gzi_path) {
+    PG_API_BEGIN
     if (!w) return PG_OK;
     int rc = PG_OK;
     if (!w->failed && !w->pending.empty()) rc = flush_blocks(w, w->pending.data(), w->pending.size());
@@ -521,4 +567,5 @@ extern "C" int pg_bgzf_close(pg_bgzf *w, const char *gzi_path) {
     delete w->pool;
     delete w;
     return rc;
+    PG_API_END
 }

@@ -76,3 +76,66 @@ def test_bgzf_writer_roundtrip(tmp_path):
     for coff in ent[:, 0]:
         assert raw[int(coff):int(coff) + 4] == b"\x1f\x8b\x08\x04"  # a BGZF block starts there
     assert raw[-28:] == bytes([0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0])
+
+
+def test_every_entry_point_sits_behind_the_exception_firewall():
+    """no C++ exception crosses the ABI.  Every extern "C" int function of the host translation units
+    whose body is more than a one-line expression opens with PG_API_BEGIN (pg_guard.h) and closes with PG_API_END."""
+    for name in ("pg_api.hip", "pg_bgzf.cpp"):
+        lines = open(os.path.join(ROOT, "panagram_amd", "csrc", name)).read().split("\n")
+        n = 0
+        for i, line in enumerate(lines):
+            if not line.startswith('extern "C" int pg_') or line.rstrip().endswith(("}", ";")):
+                continue
+            j = i
+            while not lines[j].rstrip().endswith("{"):
+                j += 1
+            end = lines.index("}", j)
+            assert lines[j + 1].strip() == "PG_API_BEGIN", f"{name}:{i + 1} {line[:60]} is not guarded"
+            assert lines[end - 1].strip() == "PG_API_END", f"{name}:{i + 1} {line[:60]}: guard not closed"
+            n += 1
+        assert n >= 3
+
+
+_FIREWALL_CHILD = r"""
+import ctypes, os, resource, sys
+sys.path.insert(0, %(root)r)
+from panagram_amd import _lib
+lib = _lib.load()
+path = os.path.join(%(tmp)r, "f.gz")
+# (a) host allocation failure inside an entry point: with the address space capped, the compressed-block buffer of a
+#     256 MiB write cannot be allocated -> std::bad_alloc inside pg_bgzf_write
+w = ctypes.c_void_p()
+assert lib.pg_bgzf_open(path.encode(), 1, 1, ctypes.byref(w)) == 0
+data = bytes(256 << 20)
+soft, hard = resource.getrlimit(resource.RLIMIT_AS)
+import re
+vm = int(re.search(r"VmSize:\s+(\d+) kB", open("/proc/self/status").read()).group(1)) << 10
+resource.setrlimit(resource.RLIMIT_AS, (vm + (64 << 20), hard))
+rc = lib.pg_bgzf_write(w, data, len(data))
+print("write rc", rc, lib.pg_last_error().decode())
+# (b) thread creation refused (each worker wants an 8 MiB stack): std::system_error inside pg_bgzf_open's pool
+w2 = ctypes.c_void_p()
+rc2 = lib.pg_bgzf_open((path + "2").encode(), 1, 512, ctypes.byref(w2))
+print("open rc", rc2, lib.pg_last_error().decode())
+resource.setrlimit(resource.RLIMIT_AS, (soft, hard))
+print("alive")
+"""
+
+
+def test_host_allocation_failure_is_an_error_code_not_an_abort(tmp_path):
+    """A std::bad_alloc / std::system_error raised inside the library comes back as a negative return code with a
+    message in pg_last_error() — the interpreter survives (run in a child: the address-space limit is process-wide)."""
+    import subprocess
+    import sys
+    from panagram_amd import build
+    build.build(verbose=False)
+    code = _FIREWALL_CHILD % {"root": ROOT, "tmp": str(tmp_path)}
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    out = p.stdout
+    assert p.returncode == 0, (p.returncode, out, p.stderr[-2000:])
+    assert "alive" in out
+    m = re.search(r"write rc (-?\d+) (.*)", out)
+    assert m and int(m.group(1)) == -4 and "memory" in m.group(2), out  # PG_E_CAPACITY
+    m = re.search(r"open rc (-?\d+) (.*)", out)
+    assert m and int(m.group(1)) < 0 and m.group(2), out

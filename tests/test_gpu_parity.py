@@ -901,3 +901,29 @@ def test_kmc_import_streams_in_chunks(ctx, tmp_path):
     order = np.argsort(gk)
     assert np.array_equal(gk[order], keys) and np.array_equal(gm[order], masks)
     tbl.close()
+
+
+def test_corrupt_kmc_total_is_a_format_error_not_a_crash(ctx):
+    """A total_kmers whose product with the record size wraps 64 bits (a corrupt .kmc_pre) must come back as
+    PG_E_FORMAT before anything is allocated or read — not pass the truncation check and read past the mapping."""
+    from panagram_amd import engine
+    fx = H.load_case(H.kmc2_cases()[0])
+    ref = H.load_case(str(fx["ref_case"]))
+    n, k = int(ref["ngenomes"]), int(ref["k"])
+    pre = bytearray(fx["db0_pre"].tobytes())
+    suf = fx["db0_suf"].tobytes()
+    hoff = int.from_bytes(pre[-8:-4], "little")
+    h = len(pre) - 8 - hoff
+    sb = (k - int.from_bytes(pre[h + 12:h + 16], "little")) // 4
+    rec = sb + int.from_bytes(pre[h + 8:h + 12], "little")
+    total_at = h + 16 + 4 + 8  # KMC2: signature_len, min_count, max_count, then total_kmers
+    real = int.from_bytes(pre[total_at:total_at + 8], "little")
+    assert 8 + real * rec <= len(suf)  # (the field really is where this test patches it)
+    wrapped = ((1 << 64) + len(suf) - 8) // rec - 1  # 8 + wrapped * rec wraps to a value below len(suf)
+    assert (8 + wrapped * rec) % (1 << 64) <= len(suf) and wrapped > real
+    pre[total_at:total_at + 8] = wrapped.to_bytes(8, "little")
+    tbl = engine.PanTable(ctx, k, n)
+    with pytest.raises(engine.PanagramHipError) as ei:
+        tbl.load_kmc(0, bytes(pre), suf)
+    assert "truncated" in str(ei.value)
+    tbl.close()
