@@ -329,6 +329,24 @@ class Index:
         return [self.kmc_prefix(f"bitvec{i}") for i in range(self.kmc_bitvec_count)]
 
     @property
+    def opdef_filenames(self):
+        return [self.kmc_prefix(f"opdef{i}.txt") for i in range(self.kmc_bitvec_count)]
+
+    def write_opdefs(self):
+        """The `kmc_tools complex` operation files of the reference workflow (index.py:407-426, rule `opdefs`
+        workflow/Snakefile:71-79): per 32-sample group, its samples' one-hot databases as inputs and
+        ``bitvec{i} = s0 + s1 + ... -ocsum`` as output.  The GPU table build needs none of this; the files are written
+        next to the exported ``bitvec{i}`` databases (``--export_kmc``) for a user who keeps `kmc_tools` in the loop."""
+        names = [str(n) for n in self.samples.index]
+        os.makedirs(self.get_subdir("kmc"), exist_ok=True)
+        for i, fname in enumerate(self.opdef_filenames):
+            group = names[32 * i:32 * (i + 1)]
+            text = ["INPUT:"] + [f"{n} = {self.kmc_prefix(n, 'onehot')}" for n in group]
+            text += ["OUTPUT:", f"{self.kmc_prefix(f'bitvec{i}')} = " + " + ".join(group), "-ocsum"]
+            with open(fname, "w") as f:
+                f.write("\n".join(text) + "\n")
+
+    @property
     def steps(self):
         return (1, self.lowres_step)
 
@@ -499,6 +517,7 @@ class Index:
                 for i, p in enumerate(self.bitvec_prefixes):
                     keys, vals = tbl.export(i)
                     write_kmc1(p, keys, vals, self.k)
+                self.write_opdefs()
         self._table = tbl
         return tbl
 

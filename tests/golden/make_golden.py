@@ -151,6 +151,50 @@ def make_kmc2_case(name, ref_case, lut, sig_len=7, nbins=13, guard=False):
         shutil.rmtree(root)
 
 
+def pin_product_kmc1_writer(name, cases):
+    """The PRODUCT's KMC1 writer (panagram_amd.index.write_kmc1, behind `panagram_amd index --export_kmc`) pinned by
+    the reference's own reader (CKMCFile::OpenForRA, cpp/anchor.cpp:26-31): the databases of existing fixtures are
+    written with it — once with the prefix length the fixture was made with, once with the writer's own choice —
+    `run_anchor` is run over them and must reproduce the fixture's golden outputs.  Only then are the sha256 of the
+    files it wrote committed: tests/test_host_logic.py checks the writer still produces exactly those bytes."""
+    from panagram_amd import index as pidx
+    out = dict(cases=np.array(cases))
+    for ref_case, lut in cases:
+        fx = np.load(os.path.join(HERE, ref_case + ".npz"))
+        n, k = int(fx["ngenomes"]), int(fx["k"])
+        for tag, p in (("lut", int(lut)), ("auto", None)):
+            root = tempfile.mkdtemp(prefix="golden_pw_")
+            try:
+                os.makedirs(os.path.join(root, "kmc"))
+                for i in range((n + 31) // 32):
+                    pre = os.path.join(root, "kmc", f"bitvec{i}")
+                    pidx.write_kmc1(pre, fx[f"db{i}_keys"], fx[f"db{i}_masks"], k, lut_prefix_len=p)
+                    for ext in ("kmc_pre", "kmc_suf"):
+                        with open(pre + "." + ext, "rb") as f:
+                            out[f"{ref_case}_{tag}_db{i}_{ext}_sha"] = hashlib.sha256(f.read()).hexdigest()
+                args = [RUN_ANCHOR, str(n), root]
+                for g in fx["anchors"]:
+                    os.makedirs(os.path.join(root, "anchor", f"g{g}"))
+                    fa = os.path.join(root, f"g{g}.fa")
+                    with open(fa, "wb") as f:
+                        f.write(fx[f"fasta_{g}"].tobytes())
+                    args += [f"g{g}", fa]
+                subprocess.run(args, check=True, stdout=subprocess.DEVNULL, env=dict(os.environ, OMP_NUM_THREADS="1"))
+                for g in fx["anchors"]:
+                    adir = os.path.join(root, "anchor", f"g{g}")
+                    for step in (1, 100):
+                        with gzip.open(os.path.join(adir, f"bitmap.{step}.gz"), "rb") as f:
+                            assert f.read() == fx[f"a{g}_bitmap{step}"].tobytes(), \
+                                f"{ref_case}/{tag}: the reference reads the product's KMC1 files differently"
+                    for t in ("bitsum.bins.tsv", "chrs.tsv"):
+                        with open(os.path.join(adir, t), "rb") as f:
+                            assert f.read() == fx[f"a{g}_{t}"].tobytes(), (ref_case, tag, t)
+            finally:
+                shutil.rmtree(root)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print("wrote", name, "(reference binary's outputs over the product-written KMC1 files == the golden outputs)")
+
+
 def make_case_if(name, *a, **kw):
     if not ONLY or name in ONLY:
         make_case(name, *a, **kw)
@@ -186,6 +230,9 @@ def main():
         make_kmc2_case("kmc2_n9_k21", "n9_k21", lut=5, sig_len=7, nbins=13)
     if not ONLY or "kmc2_n40_k31" in ONLY:
         make_kmc2_case("kmc2_n40_k31", "n40_k31", lut=7, sig_len=9, nbins=64, guard=True)
+    # the product's own KMC1 writer, read by the reference binary (two row widths, one and two databases)
+    if not ONLY or "kmc1_writer_pins" in ONLY:
+        pin_product_kmc1_writer("kmc1_writer_pins", [("n9_k21", 5), ("n40_k31", 7), ("n3_k32", 8), ("n5_k9", 5)])
     # >= 100 bins of 200000: exercises binlen=200000 + tail bin + multi-block .gzi
     make_case_if("big_n3_k21", 3, 21, [20300000, 150000], 0.01, 4321, [1], wrap=(80,), messy=False,
               store_payload=False, lut=9)

@@ -11,7 +11,7 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def _anchor_fixtures():
-    return [f for f in glob.glob(os.path.join(GOLDEN, "*.npz")) if not os.path.basename(f).startswith("kmc2_")]
+    return [f for f in glob.glob(os.path.join(GOLDEN, "*.npz")) if not os.path.basename(f).startswith(("kmc2_", "kmc1_"))]
 
 
 def payload_cases():

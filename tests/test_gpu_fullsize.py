@@ -138,15 +138,19 @@ def test_more_than_2_32_positions_in_one_result(ctx):
 
 def _fullsize_pangenome_properties(ctx, G, contig_lens, k, d, seed, picks, sample_n=2_000_000):
     """A BASELINE config at FULL size, every genome anchored in one co-scheduled result (the bench's mode):
-    size-independent properties over all of it + the CPU oracle on the first ``sample_n`` positions of the ``picks``
-    genomes, its k-mer DB built by brute force with torch (bench.sample_db_by_brute_force: no HIP kernel involved)."""
+    size-independent properties over all of it + the CPU oracle on the first ``sample_n`` positions of the first contig
+    and the last ``sample_n / 2`` of the last contig of the ``picks`` genomes, its k-mer DB built by brute force with torch (bench.sample_db_by_brute_force: no HIP kernel involved)."""
     import bench
     from oracle import coracle
     from panagram_amd import engine
     dev = torch.device("cuda", 0)
     pg = bench.Pangenome(ctx, dev, G, contig_lens, d, seed, k, keep_ascii=True)
     C = len(contig_lens)
-    samples = [pg.ascii[g][0][:sample_n] for g in picks]
+    # two stretches per picked genome: the head of its first contig and the TAIL of its last one (the last tiles of a
+    # late contig: the end of the co-schedule, a partial last tile, the last bin)
+    tail_n = sample_n // 2
+    where = [(g, 0, 0) for g in picks] + [(g, C - 1, contig_lens[C - 1] - tail_n) for g in picks]
+    samples = [pg.ascii[g][ci][s0:s0 + (sample_n if ci == 0 else tail_n)] for g, ci, s0 in where]
     dbs = bench.sample_db_by_brute_force(pg.ascii, samples, k, G)
     samples_host = [s.cpu().numpy() for s in samples]
     pg.ascii = None
@@ -174,11 +178,12 @@ def _fullsize_pangenome_properties(ctx, G, contig_lens, k, d, seed, picks, sampl
     assert total_bits == int(ccs.sum())
     # rows of the sampled genomes: bitmap.100 == bitmap.1[::100]; first sample_n rows == the CPU oracle's
     odbs = [coracle.OracleDB.from_arrays(kk, mm, k) for kk, mm in dbs]
-    for g, s in zip(picks, samples_host):
-        rows, rows100, _, _ = res.download(g * C)
-        assert rows.shape == (nk[0], nb) and np.array_equal(rows100, rows[::100])
+    for (g, ci, s0), s in zip(where, samples_host):
+        rows, rows100, _, _ = res.download(g * C + ci)
+        assert rows.shape == (nk[ci], nb) and np.array_equal(rows100, rows[::100])
         want = coracle.write_bits(odbs, G, s, k)[0]
-        assert np.array_equal(rows[:len(want)], want), f"genome {g}: GPU rows differ from the CPU oracle's"
+        assert s0 + len(want) == nk[ci] or ci == 0
+        assert np.array_equal(rows[s0:s0 + len(want)], want), f"genome {g}, contig {ci} from {s0}: GPU rows differ from the CPU oracle's"
         del rows, rows100
     for o in odbs:
         o.close()

@@ -46,6 +46,40 @@ def test_write_kmc1_readable_by_oracle_reader(tmp_path):
         assert db["k"] == 31 and np.array_equal(db["keys"], keys) and np.array_equal(db["counters"], masks)
 
 
+def test_write_kmc1_is_the_writer_the_reference_binary_accepted(tmp_path):
+    """tests/golden/make_golden.py::pin_product_kmc1_writer fed files written by THIS writer to the reference's
+    prebuilt cpp/run_anchor (KMC's own reader, cpp/anchor.cpp:26-31) and got the golden outputs back; it committed the
+    sha256 of those files.  The writer must still produce exactly those bytes — with the fixture's prefix length and
+    with its own choice — whatever order the keys arrive in (the GPU export is unsorted)."""
+    pins = H.load_case("kmc1_writer_pins")
+    rng = np.random.default_rng(1)
+    for ref_case, lut in pins["cases"]:
+        fx = H.load_case(str(ref_case))
+        k = int(fx["k"])
+        for tag, p in (("lut", int(lut)), ("auto", None)):
+            for i, (keys, masks) in enumerate(H.case_dbs(fx)):
+                perm = rng.permutation(len(keys))
+                pre = str(tmp_path / f"{ref_case}_{tag}_bitvec{i}")
+                pidx.write_kmc1(pre, keys[perm], masks[perm], k, lut_prefix_len=p)
+                for ext in ("kmc_pre", "kmc_suf"):
+                    got = H.sha(open(pre + "." + ext, "rb").read())
+                    assert got == str(pins[f"{ref_case}_{tag}_db{i}_{ext}_sha"]), (ref_case, tag, i, ext)
+
+
+def test_product_kmc1_writer_equals_the_fixture_writer(tmp_path):
+    """Byte equality of the two KMC1 writers in the tree: the golden anchor fixtures were produced from files of
+    oracle.pyoracle.write_kmc1; the product's writer emits the same bytes for the same prefix length."""
+    for name, lut in (("n9_k21", 5), ("n40_k31", 7), ("n33_k16", 4), ("n64_k31", 7)):
+        fx = H.load_case(name)
+        k = int(fx["k"])
+        for i, (keys, masks) in enumerate(H.case_dbs(fx)):
+            a, b = str(tmp_path / f"{name}_o{i}"), str(tmp_path / f"{name}_p{i}")
+            po.write_kmc1(a, keys, masks, k, lut_prefix_len=lut)
+            pidx.write_kmc1(b, keys, masks, k, lut_prefix_len=lut)
+            for ext in (".kmc_pre", ".kmc_suf"):
+                assert open(a + ext, "rb").read() == open(b + ext, "rb").read(), (name, i, ext)
+
+
 def _samples(tmp_path, n=3):
     rows = ["name\tfasta"]
     for g in range(n):
@@ -77,6 +111,22 @@ def test_index_config_and_samples_schema(tmp_path):
         bad = tmp_path / "bad.tsv"
         bad.write_text("name\tfasta\nbad name!\t/x.fa\n")
         pidx.Index(str(bad), prefix=str(tmp_path / "o2"))
+
+
+def test_opdef_files_follow_the_reference_text(tmp_path):
+    """kmc_tools `complex` operation files (index.py:407-426): INPUT one line per sample of the 32-sample group
+    (`name = <root>/kmc/<name>.onehot`), OUTPUT `<root>/kmc/bitvec{i} = s0 + s1 + ...`, then `-ocsum`."""
+    s = _samples(tmp_path, n=35)
+    out = tmp_path / "idx"
+    idx = pidx.Index(str(s), prefix=str(out), k=21, prepare=True)
+    idx.write_opdefs()
+    kmc = os.path.join(str(out), "kmc")
+    assert idx.opdef_filenames == [os.path.join(kmc, "opdef0.txt"), os.path.join(kmc, "opdef1.txt")]
+    names = [f"s{g}" for g in range(35)]
+    for i, grp in enumerate((names[:32], names[32:])):
+        exp = "INPUT:\n" + "".join(f"{n} = {kmc}/{n}.onehot\n" for n in grp)
+        exp += f"OUTPUT:\n{kmc}/bitvec{i} = {grp[0]}" + "".join(f" + {n}" for n in grp[1:]) + "\n-ocsum\n"
+        assert open(idx.opdef_filenames[i]).read() == exp
 
 
 def test_bgzf_read_side_matches_reference_addressing(tmp_path):
