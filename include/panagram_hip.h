@@ -201,6 +201,12 @@ int pg_seqset_concat(pg_ctx *ctx, const pg_seqset *const *sets, uint32_t nsets, 
  * that one launch covers the homologous pieces of every anchor */
 int pg_seqset_concat_ranges(pg_ctx *ctx, const pg_seqset *const *sets, const uint32_t *first_contig,
                             const uint32_t *ncontigs, uint32_t nsets, pg_seqset **out);
+/* a seqset of n PIECES of src's contigs: piece i = bases [start[i], start[i] + len[i]) of contig contig[i] (packed planes
+ * copied device to device; start[i] must be a multiple of 32).  The contig-sharded multi-GPU mode cuts long chromosomes
+ * into pieces with a k-1 base overlap, so that a piece's k-mer positions are rows [start, start + len - k + 1) of the
+ * whole contig's bitmap (cpp/anchor.cpp:127 cuts its chunks the same way); record ids become "<id>:<start>" */
+int pg_seqset_slice(pg_ctx *ctx, const pg_seqset *src, uint32_t n, const uint32_t *contig, const uint64_t *start,
+                    const uint64_t *len, pg_seqset **out);
 uint32_t pg_seqset_ncontigs(const pg_seqset *s);
 /* record id ("" unless parsed from FASTA; owned by the seqset) and length in bases of contig idx */
 int pg_seqset_contig(const pg_seqset *s, uint32_t idx, const char **name, uint64_t *len);

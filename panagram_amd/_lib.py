@@ -92,6 +92,7 @@ PROTOTYPES = {
     "pg_result_coschedule_ranges": (C.c_int, [_vp, _vp, C.c_uint32, _vp, C.c_uint32]),
     "pg_result_coschedule_classes": (C.c_int, [_vp, _vp, _vp, C.c_uint32]),
     "pg_seqset_concat_ranges": (C.c_int, [_vp, _vp, _vp, _vp, C.c_uint32, _vpp]),
+    "pg_seqset_slice": (C.c_int, [_vp, _vp, C.c_uint32, _vp, _vp, _vp, _vpp]),
     "pg_rows_epilogue": (C.c_int, [_vp]),
     "pg_result_timing": (C.c_int, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "pg_result_contig_info": (C.c_int, [_vp, C.c_uint32, _u64p, _u64p, _u32p, _u32p]),

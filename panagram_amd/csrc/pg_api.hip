@@ -1572,6 +1572,46 @@ extern "C" int pg_seqset_concat_ranges(pg_ctx *ctx, const pg_seqset *const *sets
     PG_API_END
 }
 
+extern "C" int pg_seqset_slice(pg_ctx *ctx, const pg_seqset *src, uint32_t n, const uint32_t *contig, const uint64_t *start,
+                               const uint64_t *len, pg_seqset **out) {
+    PG_API_BEGIN
+    if (!ctx || !src || !out || (n && (!contig || !start || !len))) return fail(PG_E_INVALID, "pg_seqset_slice: NULL argument");
+    if (src->ctx != ctx) return fail(PG_E_INVALID, "pg_seqset_slice: the seqset belongs to another context");
+    for (uint32_t i = 0; i < n; ++i) {
+        if (contig[i] >= src->n) return fail(PG_E_INVALID, "pg_seqset_slice: contig %u out of range (0..%u)", contig[i], src->n ? src->n - 1 : 0);
+        if (start[i] & 31u) return fail(PG_E_INVALID, "pg_seqset_slice: piece %u starts at base %llu — starts must be multiples of 32", i, (unsigned long long)start[i]);
+        if (start[i] > src->desc[contig[i]].len || len[i] > src->desc[contig[i]].len - start[i])
+            return fail(PG_E_INVALID, "pg_seqset_slice: piece %u (%llu + %llu) exceeds contig %u of %llu bases", i, (unsigned long long)start[i],
+                        (unsigned long long)len[i], contig[i], (unsigned long long)src->desc[contig[i]].len);
+    }
+    pg_seqset *s = nullptr;
+    if (int r = pg_seqset_create(ctx, n, len, &s)) return r;
+    hipStream_t st = ctx->stream;
+    hipError_t e = hipSuccess;
+    for (uint32_t i = 0; i < n && e == hipSuccess; ++i) {
+        const SeqDesc &from = src->desc[contig[i]];
+        const uint64_t w0 = start[i] >> 5, nw = (len[i] + 31) >> 5;  // (whole words: the piece starts on a word boundary)
+        if (nw) {
+            e = hipMemcpyAsync(s->d_seqw + s->desc[i].seq_off, src->d_seqw + from.seq_off + w0, nw * 8, hipMemcpyDeviceToDevice, st);
+            if (e == hipSuccess)
+                e = hipMemcpyAsync(s->d_nmw + s->desc[i].seq_off, src->d_nmw + from.seq_off + w0, nw * 4, hipMemcpyDeviceToDevice, st);
+        }
+        // (the contig's "holds a byte outside ACGT" flag is inherited: a piece without one only reads a zero plane)
+        if (e == hipSuccess) e = hipMemcpyAsync(s->d_has_n + i, src->d_has_n + contig[i], 4, hipMemcpyDeviceToDevice, st);
+        std::string nm = contig[i] < src->names.size() ? src->names[contig[i]] : std::string();
+        s->names.push_back(nm + ":" + std::to_string((unsigned long long)start[i]));
+    }
+    if (e == hipSuccess) e = launch_seq_tailmask(st, s->d_desc, n, s->d_seqw, s->d_nmw);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) {
+        pg_seqset_destroy(s);
+        return fail(PG_E_HIP, "pg_seqset_slice: %s", hipGetErrorString(e));
+    }
+    *out = s;
+    return PG_OK;
+    PG_API_END
+}
+
 extern "C" uint32_t pg_seqset_ncontigs(const pg_seqset *s) { return s ? s->n : 0; }
 
 extern "C" int pg_seqset_contig(const pg_seqset *s, uint32_t idx, const char **name, uint64_t *len) {

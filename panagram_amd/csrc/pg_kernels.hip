@@ -448,6 +448,24 @@ hipError_t launch_table_init(hipStream_t st, const SubTable &t) {
     return e;
 }
 
+// contigs cut out of longer ones (pg_seqset_slice) were copied word by word: the bases behind a contig's last one are
+// cleared from its last word — every packed contig ends in zero bits, as k_pack leaves it
+__global__ void k_seq_tailmask(const SeqDesc *__restrict__ sd, uint32_t n, uint64_t *__restrict__ seqw, uint32_t *__restrict__ nmw) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    const SeqDesc d = sd[c];
+    const uint32_t rem = (uint32_t)(d.len & 31u);
+    if (!rem) return;
+    const uint64_t w = d.seq_off + (d.len >> 5);
+    seqw[w] &= (1ull << (2 * rem)) - 1ull;
+    nmw[w] &= (1u << rem) - 1u;
+}
+hipError_t launch_seq_tailmask(hipStream_t st, const SeqDesc *sd, uint32_t n, uint64_t *seqw, uint32_t *nmw) {
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(k_seq_tailmask, dim3((n + 255) / 256), dim3(256), 0, st, sd, n, seqw, nmw);
+    return hipGetLastError();
+}
+
 hipError_t launch_pack(hipStream_t st, const void *d_ascii, uint64_t len, uint64_t *seqw, uint32_t *nmw,
                        uint64_t nwords, uint32_t *has_n) {
     if (nwords == 0) return hipSuccess;

@@ -98,76 +98,338 @@ def concat_bgzf(parts: Sequence[Tuple[str, str]], out_gz: str, out_gzi: str) -> 
     os.replace(out_gzi + ".tmp", out_gzi)
 
 
-def run_index_sharded(index, rank: int, world: int, barrier: Callable[[], None]) -> None:
-    """The fine-grained contig-sharded mode: ``(genome, contig)`` units dealt to the ranks longest-first,
-    the table replicated.  Every rank calls this.  Phase 1: a rank anchors ALL its units in one co-scheduled launch
-    (its contigs of every genome side by side, like ``Index.run()``'s batches) and leaves, per unit, finished BGZF
-    fragments — compressed on the GPU straight out of HBM (``pg_result_write_bgzf_range``) — plus the unit's bins and
-    column sums.  One barrier.  Phase 2: the owner of a genome concatenates its contigs' fragments in FASTA order
-    (``concat_bgzf``) and writes the tables.  No data-path collective; the decompressed outputs do not depend on the
-    GPU count (the BGZF block boundaries follow the fragments)."""
+# A piece: k-mer positions [start, start + npos) of contig ``ci`` of genome ``name`` (a whole contig: start 0, npos = its
+# k-mer count), in homology class ``cls``, piece number ``j`` of that class
+Piece = Tuple[str, int, int, int, int, int]  # (name, ci, start, npos, cls, j)
+
+
+MIN_PIECE = int(os.environ.get("PG_MIN_PIECE", str(1 << 20)))  # k-mer positions: no contig is cut into shorter pieces
+
+
+def piece_alignment(lowres_step: int) -> int:
+    """Piece starts are multiples of this: whole strides of the low-resolution bitmap (a piece's every lowres_step-th
+    row is the contig's) and whole 32-base words of the packed sequence (``pg_seqset_slice``).  Bins need no alignment:
+    a piece's statistics are taken over the contig's bin windows clipped to it, and bins that two pieces share are
+    added up when the genome is assembled."""
+    return int(np.lcm(int(lowres_step), 32))
+
+
+def plan_class_pieces(contigs: Sequence[Tuple[str, int, int, int]], world: int, lowres_step: int = 100,
+                      pieces_per_rank: Optional[int] = None, min_piece: Optional[int] = None) -> List[List[Piece]]:
+    """``_plan_class_pieces`` at the granularity (4 to 8 class pieces per rank, unless ``pieces_per_rank`` pins it) whose
+    fullest rank is lightest; ties go to the coarser plan."""
+    if pieces_per_rank is not None or world <= 1:
+        return _plan_class_pieces(contigs, world, lowres_step, pieces_per_rank or 4, min_piece)
+    best, best_load = None, None
+    for ppr in range(4, 9):
+        plan = _plan_class_pieces(contigs, world, lowres_step, ppr, min_piece)
+        load = max(sum(p[3] for p in sh) for sh in plan)
+        if best is None or load < best_load:
+            best, best_load = plan, load
+    return best
+
+
+def _plan_class_pieces(contigs: Sequence[Tuple[str, int, int, int]], world: int, lowres_step: int,
+                       pieces_per_rank: int, min_piece: Optional[int]) -> List[List[Piece]]:
+    """The contig-sharded partition that keeps the co-scheduling gain: the unit of work is a PIECE OF A
+    HOMOLOGY CLASS — the same stretch (by relative position) of the homologous contigs of EVERY anchor genome — so that
+    a rank's one co-scheduled launch still finds the lines its genomes share in L2.  ``contigs`` = ``(genome, contig
+    index, k-mer count, class)``.  A class is cut into about ``size / (total / (world * pieces_per_rank))`` pieces,
+    its contigs at the same relative places rounded to ``piece_alignment``, none shorter than ``min_piece`` positions;
+    the class pieces are dealt to the ranks longest-first.  Deterministic: every process computes the same plan."""
+    world = max(1, int(world))
+    align = piece_alignment(lowres_step)
+    min_piece = max(align, MIN_PIECE if min_piece is None else int(min_piece))
+    by_class: Dict[int, List[Tuple[str, int, int]]] = {}
+    for name, ci, nk, cls in contigs:
+        by_class.setdefault(int(cls), []).append((name, int(ci), int(nk)))
+    total = sum(nk for _, _, nk, _ in contigs)
+    target = max(1, total // (world * max(1, pieces_per_rank)))
+    units: List[Tuple[int, int, int, List[Piece]]] = []  # (weight, class, j, pieces)
+    for cls in sorted(by_class):
+        members = by_class[cls]
+        size = sum(nk for _, _, nk in members)
+        npieces = 1
+        if world > 1:
+            npieces = max(1, min(int(round(size / target)), min(nk for _, _, nk in members) // min_piece))
+        for j in range(npieces):
+            pieces = []
+            for name, ci, nk in members:
+                b0 = 0 if j == 0 else align * int(round(j * nk / (npieces * align)))
+                b1 = nk if j == npieces - 1 else align * int(round((j + 1) * nk / (npieces * align)))
+                if b1 > b0:
+                    pieces.append((name, ci, b0, b1 - b0, cls, j))
+            if pieces:
+                units.append((sum(p[3] for p in pieces), cls, j, pieces))
+    order = sorted(units, key=lambda u: (-u[0], u[1], u[2]))
+    loads = [0] * world
+    shards: List[List[Tuple[int, int, List[Piece]]]] = [[] for _ in range(world)]
+    for w, cls, j, pieces in order:
+        r = min(range(world), key=lambda i: (loads[i], i))
+        shards[r].append((cls, j, pieces))
+        loads[r] += w
+    out: List[List[Piece]] = []
+    for sh in shards:
+        sh.sort(key=lambda u: (u[0], u[1]))
+        out.append([p for _, _, pieces in sh for p in pieces])
+    return out
+
+
+def _plan_signature(index, world: int, plan_digest: str) -> str:
+    """what a fragment left in ``.parts`` must carry to be taken for this run's: the parameters, the inputs (path, size,
+    modification time) and the plan.  Outputs are a function of exactly these, so a fragment of an earlier, aborted run
+    with the same signature holds the same bytes this run would write."""
+    import hashlib
+    h = hashlib.sha1()
+    h.update(repr((index.k, world, tuple(index.steps), sorted(index.result_geometry.items()), index.ngenomes,
+                   index.bgzf_level, plan_digest)).encode())
+    for name, g in index.genomes.items():
+        if isinstance(g.fasta, str) and os.path.exists(g.fasta):
+            st = os.stat(g.fasta)
+            h.update(repr((name, g.fasta, st.st_size, st.st_mtime_ns)).encode())
+        else:
+            h.update(repr((name, None)).encode())
+    return h.hexdigest()
+
+
+def _claim(path: str) -> bool:
+    """exclusive creation of ``path`` (who assembles a genome); a claim left by a process of this host that no longer
+    exists is taken over"""
+    import socket
+    me = f"{socket.gethostname()} {os.getpid()}"
+    for _ in range(2):
+        try:
+            fd = os.open(path, os.O_CREAT | os.O_EXCL | os.O_WRONLY)
+            os.write(fd, me.encode())
+            os.close(fd)
+            return True
+        except FileExistsError:
+            try:
+                host, pid = open(path).read().split()
+                if host != socket.gethostname():
+                    return False
+                os.kill(int(pid), 0)
+                return False  # alive: it is assembling
+            except (ProcessLookupError, ValueError):
+                try:
+                    os.remove(path)
+                except FileNotFoundError:
+                    pass
+            except (FileNotFoundError, PermissionError):
+                return False
+    return False
+
+
+def run_index_sharded(index, rank: int, world: int, barrier: Optional[Callable[[], None]] = None,
+                      pieces_per_rank: Optional[int] = None) -> None:
+    """The contig-sharded multi-GPU mode (what ``Index.run()`` does with more than one rank when the table
+    fits a GPU).  Every rank calls this.
+
+    Work is dealt as pieces of homology classes (``plan_class_pieces``): a rank anchors, for its pieces, the
+    homologous stretch of EVERY anchor genome in one co-scheduled launch per batch — the same launch shape as the
+    single-GPU path, so the genomes still share their table lines in L2.  Its table holds the k-mers of its own pieces
+    only (built from them; every sample then only sets its bits, ``pg_table_update_seqset``): 1 / world of the
+    pangenome's keys per GPU, the same rows.  Per piece it leaves finished BGZF fragments — compressed on the GPU
+    straight out of HBM — plus the piece's bins, column sums and gene histograms, the marker file written last.
+    No data-path collective and no rendezvous: whoever finds a genome's pieces complete (the rank that finishes last,
+    at the latest) assembles that genome — fragments concatenated in order (``concat_bgzf``), bin rows appended,
+    sums added — under an exclusive claim.  ``barrier`` (torch.distributed's, when a process group exists) is only
+    used to make the last scan see every rank's markers whatever the file system.  The decompressed outputs do not
+    depend on the GPU count (BGZF block boundaries follow the fragments)."""
+    import hashlib
     from concurrent.futures import ThreadPoolExecutor
     from . import index as pidx
     engine = pidx.engine
     k = index.k
     ctx = index.context
-    units: List[Unit] = []
-    seqs = {}
-    for name in index.anchor_genomes:
-        seqs[name] = index.seqset_for(name)
-        units += [(name, ci, max(0, int(ln) - k + 1)) for ci, ln in enumerate(seqs[name].lens)]
-    for name in index.anchor_genomes:  # a stale .parts of an aborted run must not leak into this one
-        if index.anchor_genomes.index(name) % world == rank:
-            shutil.rmtree(_parts_dir(index.genomes[name]), ignore_errors=True)
-    barrier()
-    mine = plan_shards(units, world)[rank]
+    geo = index.result_geometry
+    anchors = list(index.anchor_genomes)
+    gid = {n: i for i, n in enumerate(anchors)}
+    seqs = {name: index.seqset_for(name) for name in anchors}
+    classes = engine.homology_classes([seqs[n].names for n in anchors])
+    contigs, c = [], 0
+    for name in anchors:
+        for ci, ln in enumerate(seqs[name].lens):
+            contigs.append((name, ci, max(0, int(ln) - k + 1), int(classes[c])))
+            c += 1
+    ppr = (int(os.environ["PG_PIECES_PER_RANK"]) if "PG_PIECES_PER_RANK" in os.environ else None) if pieces_per_rank is None else pieces_per_rank
+    plan = plan_class_pieces(contigs, world, geo["lowres_step"], ppr)
+    sig = _plan_signature(index, world, hashlib.sha1(repr(plan).encode()).hexdigest())
+    nk_of = {(name, ci): nk for name, ci, nk, _ in contigs}
+    pieces_of: Dict[str, List[Piece]] = {n: [] for n in anchors}
+    for sh in plan:
+        for p in sh:
+            pieces_of[p[0]].append(p)
+    for n in anchors:
+        pieces_of[n].sort(key=lambda p: (p[1], p[2]))
+
+    def contig_binlen(nk: int) -> int:  # cpp/anchor.cpp:114-118 / index.py:1169-1172 (result_create applies the same rule)
+        bl = geo["max_bin_len"]
+        if nk // bl < geo["min_bin_count"]:
+            bl = nk // geo["min_bin_count"]
+        return max(1, bl)
+
+    def base(p: Piece) -> str:
+        return os.path.join(_parts_dir(index.genomes[p[0]]), f"{p[1]}.{p[2]}")
+
+    mine = plan[rank] if rank < len(plan) else []
     if mine:
-        table = index.build_table()  # replicated: every rank builds (or loads) the whole table
-        parts = [(seqs[name], ci, 1) for name, ci, _ in mine]
-        merged = engine.SeqSet.concat_ranges(ctx, parts)
-        res = engine.AnchorResult(table, merged, colsums=True, **index.result_geometry)
-        gid = {n: i for i, n in enumerate(index.anchor_genomes)}
-        if len({u[0] for u in mine}) > 1:
-            res.coschedule(np.array([gid[u[0]] for u in mine], np.uint32))
-        res.run()
-        ccs = res.contig_colsums().astype(np.int64)
+        for p in mine:  # (what this rank is about to write again must not count as done meanwhile)
+            try:
+                os.remove(base(p) + ".npz")
+            except FileNotFoundError:
+                pass
+        # this rank's pieces of every genome, cut out of the packed sequences in HBM (k - 1 bases of overlap)
+        order = sorted(mine, key=lambda p: (p[4], p[5], gid[p[0]]))
+        own = {n: [p for p in order if p[0] == n] for n in anchors}
+        cut = {n: seqs[n].slice([(p[1], p[2], p[3] + k - 1) for p in ps]) for n, ps in own.items() if ps}
+        table = index.build_table(insert_sets=cut)
+        nb = (index.ngenomes + 7) // 8
+        genes = {n: index.genomes[n].load_genes() if index.genomes[n].annotated else None for n in cut}
 
-        def write_unit(i, name, ci):
-            g = index.genomes[name]
+        # batches of class pieces whose rows fit next to the table (the same bound as Index.run()'s batches)
+        free = ctx.mem_info()[0]
+        batch_bytes = int(min(index.batch_bytes, max(1 << 30, (free - (6 << 30)) / 2.3)))
+        batches, cur, cur_bytes = [], [], 0
+        for key in sorted({(p[4], p[5]) for p in order}):
+            grp = [p for p in order if (p[4], p[5]) == key]
+            b = sum(p[3] for p in grp) * nb
+            if cur and cur_bytes + b > batch_bytes:
+                batches.append(cur)
+                cur, cur_bytes = [], 0
+            cur += grp
+            cur_bytes += b
+        if cur:
+            batches.append(cur)
+        payload = sum(p[3] for p in order) * nb
+
+        def write_piece(res, i, p):
+            g = index.genomes[p[0]]
             os.makedirs(_parts_dir(g), exist_ok=True)
-            base = os.path.join(_parts_dir(g), str(ci))
             for s_ in index.steps:
-                res.write_bgzf(s_, f"{base}.{s_}.gz", f"{base}.{s_}.gzi", level=index.bgzf_level, threads=2, first_contig=i, ncontigs=1)
+                res.write_bgzf(s_, f"{base(p)}.{s_}.gz", f"{base(p)}.{s_}.gzi", level=index.bgzf_level, threads=2, first_contig=i, ncontigs=1)
             _, _, bins, info = res.download(i, want_bitmap1=False, want_bitmap100=False)
-            np.savez(base + ".tmp.npz", bins=bins, colsums=ccs[i], nkmers=info["nkmers"], nbins=info["nbins"],
-                     binlen=info["binlen"], nrows100=info["nrows100"])
-            os.replace(base + ".tmp.npz", base + ".npz")  # written last: the unit's completion marker
+            assert info["nkmers"] == p[3]
+            nk, bl = nk_of[(p[0], p[1])], contig_binlen(nk_of[(p[0], p[1])])
+            bin0 = p[2] // bl
+            if p[3] != nk:
+                # a piece of a longer contig: the statistics over the CONTIG's bins (cpp/anchor.cpp:114-120,179-189)
+                # clipped to the piece — a bin that two pieces share is added up when the genome is assembled
+                edges = np.arange(bin0, (p[2] + p[3] - 1) // bl + 2, dtype=np.int64) * bl
+                lo, hi = np.maximum(edges[:-1], p[2]) - p[2], np.minimum(edges[1:], p[2] + p[3]) - p[2]
+                h, _ = res.window_stats(i, lo, hi, step=1, colsums=False)
+                bins = h.astype(np.int64)
+            ghist = np.zeros(index.ngenomes + 1, np.int64)
+            gt = genes.get(p[0])
+            if gt is not None:  # the piece's share of its chromosome's gene occupancy (index.py:1055-1064): genes clipped to it
+                size = nk_of[(p[0], p[1])]
+                sel = gt[gt["chr"] == seqs[p[0]].names[p[1]]]
+                st, en = sel["start"].to_numpy(np.int64), sel["end"].to_numpy(np.int64)
+                ok = (en > st) & (st >= 0) & (en <= size)
+                a, b = np.maximum(st[ok], p[2]) - p[2], np.minimum(en[ok], p[2] + p[3]) - p[2]
+                hit = b > a
+                if hit.any():
+                    h, _ = res.window_stats(i, a[hit], b[hit], step=1, colsums=False)
+                    ghist = h.sum(axis=0).astype(np.int64)
+            np.savez(base(p) + ".tmp.npz", bins=bins, colsums=res.contig_colsums(i, 1)[0].astype(np.int64), nkmers=info["nkmers"],
+                     bin0=bin0, nrows100=info["nrows100"], gene_hist=ghist, sig=sig)
+            os.replace(base(p) + ".tmp.npz", base(p) + ".npz")  # written last: the piece's completion marker
 
-        with ThreadPoolExecutor(max_workers=index.writer_jobs(int(merged.lens.sum()) * ((index.ngenomes + 7) // 8))) as pool:
-            for f in [pool.submit(write_unit, i, name, ci) for i, (name, ci, _) in enumerate(mine)]:
-                f.result()
-        res.close()
-        merged.close()
-    barrier()
-    # phase 2: the owner of a genome assembles its files in FASTA order
-    for gi, name in enumerate(index.anchor_genomes):
-        if gi % world != rank:
-            continue
+        with ThreadPoolExecutor(max_workers=index.writer_jobs(payload)) as pool:
+            previous = None
+            for batch in batches:
+                # the batch's pieces side by side, genome after genome; co-scheduled by (class, piece)
+                per_genome = [[p for p in batch if p[0] == n] for n in anchors]
+                parts, layout = [], []
+                for n, ps in zip(anchors, per_genome):
+                    if ps:
+                        first = own[n].index(ps[0])
+                        assert own[n][first:first + len(ps)] == ps
+                        parts.append((cut[n], first, len(ps)))
+                        layout += ps
+                merged = engine.SeqSet.concat_ranges(ctx, parts)
+                res = engine.AnchorResult(table, merged, colsums=True, **geo)
+                if len({p[0] for p in layout}) > 1:
+                    cls_ids = {key: i for i, key in enumerate(sorted({(p[4], p[5]) for p in layout}))}
+                    res.coschedule(np.array([gid[p[0]] for p in layout], np.uint32),
+                                   contig_class=np.array([cls_ids[(p[4], p[5])] for p in layout], np.uint32))
+                res.run()
+                futs = [pool.submit(write_piece, res, i, p) for i, p in enumerate(layout)]
+                if previous is not None:  # at most two batches of rows resident
+                    _finish(*previous)
+                previous = (res, merged, futs)
+            if previous is not None:
+                _finish(*previous)
+        for ss in cut.values():
+            ss.close()
+
+    def try_assemble(name: str) -> bool:
         g = index.genomes[name]
+        ps = pieces_of[name]
+        pdir = _parts_dir(g)
+        if not os.path.isdir(pdir) and ps:
+            return os.path.exists(g.chrs_fname)  # assembled (and cleaned up) by another rank
+        metas = []
+        for p in ps:
+            try:
+                z = np.load(base(p) + ".npz")
+                if str(z["sig"]) != sig:
+                    return False
+                metas.append(z)
+            except (FileNotFoundError, OSError, KeyError, ValueError):
+                return False
+        os.makedirs(pdir, exist_ok=True)
+        if not _claim(os.path.join(pdir, "assemble.lock")):
+            return False
         g.ensure_log()
         os.makedirs(g.prefix, exist_ok=True)
         names = list(seqs[name].names)
-        metas = [np.load(os.path.join(_parts_dir(g), f"{ci}.npz")) for ci in range(len(names))]
         for s_ in index.steps:
-            concat_bgzf([(os.path.join(_parts_dir(g), f"{ci}.{s_}.gz"), os.path.join(_parts_dir(g), f"{ci}.{s_}.gzi"))
-                         for ci in range(len(names))], g.bitmap_gz_fname(s_), g.bitmap_gzi_fname(s_))
-        bins_infos = [(z["bins"], dict(nkmers=int(z["nkmers"]), nbins=int(z["nbins"]), binlen=int(z["binlen"]),
-                                       nrows100=int(z["nrows100"]))) for z in metas]
-        cs = np.sum([z["colsums"] for z in metas], axis=0) if metas else np.zeros(index.ngenomes, np.int64)
-        g._write_tables(names, bins_infos, cs)
+            concat_bgzf([(f"{base(p)}.{s_}.gz", f"{base(p)}.{s_}.gzi") for p in ps], g.bitmap_gz_fname(s_), g.bitmap_gzi_fname(s_))
+        bins_infos, gene_sum = [], {}
+        cs = np.zeros(index.ngenomes, np.int64)
+        for ci in range(len(names)):
+            zs = [z for p, z in zip(ps, metas) if p[1] == ci]
+            nk = nk_of[(name, ci)]
+            bl = contig_binlen(nk)
+            bins = np.zeros(((nk + bl - 1) // bl, index.ngenomes + 1), np.int64)
+            assert sum(int(z["nkmers"]) for z in zs) == nk
+            for z in zs:
+                b0 = int(z["bin0"])
+                bins[b0:b0 + len(z["bins"])] += z["bins"].astype(np.int64)
+                cs += z["colsums"]
+                gene_sum[names[ci]] = gene_sum.get(names[ci], 0) + z["gene_hist"]
+            bins_infos.append((bins, dict(nkmers=nk, nbins=len(bins), binlen=bl, nrows100=sum(int(z["nrows100"]) for z in zs))))
+        gene_hists = None
+        if g.annotated:
+            gene_hists = {}
+            for chrom, grp in g.load_genes().groupby("chr", sort=True):
+                if chrom in names:
+                    size = nk_of[(name, names.index(chrom))]
+                    st, en = grp["start"].to_numpy(np.int64), grp["end"].to_numpy(np.int64)
+                    for s_, e_ in zip(st[~((en > st) & (st >= 0) & (en <= size))], en[~((en > st) & (st >= 0) & (en <= size))]):
+                        g.log.warning(f"Skipping gene at {chrom}:{s_}-{e_}, coordinates out-of-bounds")
+                gene_hists[chrom] = (len(grp), np.asarray(gene_sum.get(chrom, np.zeros(index.ngenomes + 1, np.int64)), np.int64))
+        g._write_tables(names, bins_infos, cs, gene_hists)
         g.close_log()
-        shutil.rmtree(_parts_dir(g))
-    barrier()
+        shutil.rmtree(pdir)
+        return True
+
+    todo = [n for n in anchors]
+    for phase in range(2):
+        todo = [n for n in todo if not try_assemble(n)]
+        if barrier is None or phase == 1:
+            break
+        barrier()  # every rank's markers are out: whatever is still unassembled is complete now
+
+
+def _finish(res, merged, futs):
+    try:
+        for f in futs:
+            f.result()
+    finally:
+        res.close()
+        merged.close()
 
 
 # ---------------------------------------------------------------------------

@@ -242,6 +242,25 @@ class SeqSet(_Owner):
                    if parts else np.zeros(0, np.uint64))
         return ss
 
+    def slice(self, pieces: Sequence[Tuple[int, int, int]]) -> "SeqSet":
+        """A seqset of pieces ``(contig, start base, bases)`` of this one's contigs (starts: multiples of 32), packed
+        planes copied on the device: the contig-sharded multi-GPU mode's chunks of long chromosomes.  A piece that
+        carries ``k - 1`` bases of overlap holds exactly the k-mer positions ``[start, start + bases - k + 1)`` of its
+        contig (cpp/anchor.cpp:127 cuts its chunks the same way)."""
+        ss = SeqSet.__new__(SeqSet)
+        ss.ctx, ss._lib = self.ctx, self._lib
+        n = len(pieces)
+        contig = np.array([p[0] for p in pieces], np.uint32)
+        start = np.array([p[1] for p in pieces], np.uint64)
+        lens = np.array([p[2] for p in pieces], np.uint64)
+        h = C.c_void_p()
+        check(self._lib.pg_seqset_slice(self.ctx._h, self._h, n, _ptr(contig), _ptr(start), _ptr(lens), C.byref(h)))
+        ss._h = h
+        self.ctx._adopt(ss)
+        ss.names = [f"{self.names[c]}:{s0}" for c, s0, _ in pieces]
+        ss.lens = lens
+        return ss
+
     def load_host(self, idx: int, seq) -> None:
         v = _bytes_view(seq)
         check(self._lib.pg_seqset_load_host(self._h, idx, _ptr(v), len(v)))
@@ -453,13 +472,31 @@ class PanTable(_Owner):
 
 def homology_classes(name_lists: Sequence[Sequence[str]]) -> np.ndarray:
     """``contig_class`` for ``AnchorResult.coschedule`` from the genomes' record ids: contigs with the same id (the same
-    chromosome name in different FASTAs) form one class, classes numbered in order of first appearance; a genome whose
-    ids match nobody else's keeps its own contig order (class = position)."""
-    seen, out = {}, []
-    for names in name_lists:
+    chromosome name in different FASTAs) form one class, classes numbered in order of first appearance.  A genome
+    fewer than half of whose ids occur in another genome — assemblies usually carry per-assembly accessions (CM0xxxx.1,
+    another chr naming) — is paired BY POSITION instead: its i-th contig joins the class of the first genome's i-th
+    contig (chromosome-level assemblies of one species list their chromosomes in the same order), so that the
+    co-schedule still interleaves the genomes instead of running them one after the other.  Within an id-matched
+    genome a contig whose id nobody shares (an extra scaffold) is a class of its own."""
+    from collections import Counter
+    occ = Counter(nm for names in name_lists for nm in set(names) if nm)
+    by_id = [len(name_lists) > 1 and len(names) > 0 and 2 * sum(1 for nm in names if nm and occ[nm] > 1) >= len(names)
+             for names in name_lists]
+    seen, out, first = {}, [], None  # first: classes of the first genome's contigs, by position
+    for g, names in enumerate(name_lists):
+        mine = []
         for i, nm in enumerate(names):
-            key = nm if nm else ("", i)
-            out.append(seen.setdefault(key, len(seen)))
+            if by_id[g]:
+                key = ("id", nm) if (nm and occ[nm] > 1) else ("own", g, i)
+            elif first is not None and i < len(first):
+                mine.append(first[i])
+                continue
+            else:
+                key = ("own", g, i)
+            mine.append(seen.setdefault(key, len(seen)))
+        if first is None:
+            first = mine
+        out += mine
     return np.asarray(out, np.uint32)
 
 

@@ -250,6 +250,7 @@ class Index:
         self._load_samples()
         self._ctx = None
         self._table = None
+        self._table_scope = "all"
         self._seqsets: Dict[str, engine.SeqSet] = {}
 
     def _reopen_prepared(self):
@@ -466,6 +467,10 @@ class Index:
         every process."""
         if not (self.filtered_table and not self.export_kmc and all(i[3] <= 1 for i in inputs)):
             return self._expected_keys(inputs)
+        if self.world > 1 and os.environ.get("PG_PARTITION", "pieces") != "genomes":
+            # pieces of homology classes: a rank's table is built from its 1 / world of the anchored sequence
+            # (+30 %: the pieces are only balanced to a piece, and k-mers of repeats occur in several ranks' shares)
+            return int(self._expected_keys([i for i in inputs if i[0] in self.anchor_genomes]) * 1.3 / self.world) + 1024
         writer = self.writer_of_anchor() if self.world > 1 else {a: 0 for a in self.anchor_genomes}
         worst = 0
         for r in range(max(1, self.world)):
@@ -473,12 +478,21 @@ class Index:
             worst = max(worst, self._expected_keys(mine) if mine else 0)
         return worst or self._expected_keys(inputs)
 
-    def build_table(self, keep: Optional[Sequence[str]] = None) -> engine.PanTable:
-        """``keep``: the genomes whose packed sequences stay resident for the anchor step (default: all anchors)"""
+    def build_table(self, keep: Optional[Sequence[str]] = None, insert_sets: Optional[Dict[str, "engine.SeqSet"]] = None) -> engine.PanTable:
+        """``keep``: the genomes whose packed sequences stay resident for the anchor step (default: all anchors) — and,
+        in the filtered build, the genomes whose k-mers the table is built from.  ``insert_sets`` (the contig-sharded
+        multi-GPU mode): ``{genome: SeqSet}`` of the PIECES this process anchors — the table is built from those pieces,
+        every sample then only sets its bits."""
         keep = set(self.anchor_genomes if keep is None else keep)
         if self._table is not None:
+            # a filtered table answers only for what it was built from: anything else would silently read as absent
+            scope = self._table_scope
+            if scope != "all" and (insert_sets is not None or scope == "pieces" or not keep <= scope):
+                raise RuntimeError("the cached table was built for " + ("this process's pieces" if scope == "pieces" else f"the anchors {sorted(scope)}") +
+                                   " only; close() the index before building a table for other anchors")
             return self._table
         have = all(os.path.exists(p + ".kmc_pre") and os.path.exists(p + ".kmc_suf") for p in self.bitvec_prefixes)
+        scope = "all"
         if self.kmc.use_existing and have:
             tbl = engine.PanTable(self.context, self.k, self.ngenomes)
             for i, p in enumerate(self.bitvec_prefixes):
@@ -490,35 +504,56 @@ class Index:
             # table (and settles its minimizer length) once: no re-hash while it grows, no second
             # copy of the table in HBM.  Anchors keep their sequences for the anchor step.
             inputs = self.load_inputs()
-            # The anchor step only ever asks for k-mers of the genomes THIS process anchors (``keep``): the table is
-            # built from those and the other samples only set their bits in it (pg_table_update_seqset) — the rows are
-            # the ones the table of all genomes gives, the table is as small as the anchors' own k-mer set (a rank of a
-            # multi-GPU run, or a pangenome in which only some genomes are anchors).  Not when the merged databases
-            # are to be exported, nor with read-set samples (their -ci2 count tables merge through the inserting path).
+            # The anchor step only ever asks for k-mers of the sequence THIS process anchors (``keep`` genomes, or the
+            # pieces in ``insert_sets``): the table is built from that and the other samples only set their bits in it
+            # (pg_table_update_seqset) — the rows are the ones the table of all genomes gives, the table is as small as
+            # the anchored sequence's own k-mer set (a rank of a multi-GPU run, or a pangenome in which only some genomes
+            # are anchors).  Not when the merged databases are to be exported, nor with read-set samples (their -ci2
+            # count tables merge through the inserting path).
             first = [i for i in inputs if i[0] in keep]
             rest = [i for i in inputs if i[0] not in keep]
-            filtered = (self.filtered_table and not self.export_kmc and first and rest and all(i[3] <= 1 for i in inputs))
-            expected = self._expected_keys(first if filtered else inputs)
-            tbl = engine.PanTable(self.context, self.k, self.ngenomes, expected_keys=expected)
-            for name, g, ss, min_count, _ in (first + rest if filtered else inputs):
-                if filtered and name not in keep:
+            can_filter = self.filtered_table and not self.export_kmc and all(i[3] <= 1 for i in inputs)
+            if insert_sets is not None and can_filter:
+                sketch = engine.KmerSketch(self.context, self.k)
+                for ss in insert_sets.values():
+                    sketch.add(ss)
+                est = sketch.estimate()
+                sketch.close()
+                expected = est + est // 32 + 1024
+                tbl = engine.PanTable(self.context, self.k, self.ngenomes, expected_keys=expected)
+                for name, ss in insert_sets.items():
+                    tbl.insert_seqset(self.genomes[name].id, ss)
+                for name, g, ss, _, _ in inputs:
                     tbl.update_seqset(g.id, ss)
-                else:
-                    tbl.insert_seqset(g.id, ss, min_count=min_count)
-                if min_count > 1:
-                    ss.close()
-                elif name not in keep:
-                    self.drop_seqset(name)
+                    if name not in keep:
+                        self.drop_seqset(name)
+                scope, filtered = "pieces", True
+            else:
+                filtered = bool(can_filter and first and rest)
+                expected = self._expected_keys(first if filtered else inputs)
+                tbl = engine.PanTable(self.context, self.k, self.ngenomes, expected_keys=expected)
+                for name, g, ss, min_count, _ in (first + rest if filtered else inputs):
+                    if filtered and name not in keep:
+                        tbl.update_seqset(g.id, ss)
+                    else:
+                        tbl.insert_seqset(g.id, ss, min_count=min_count)
+                    if min_count > 1:
+                        ss.close()
+                    elif name not in keep:
+                        self.drop_seqset(name)
+                if filtered:
+                    scope = frozenset(i[0] for i in first)
             self._inputs = None
             logger.info("k-mer table built on GPU (sketch: %d distinct k-mers%s): %s", expected,
-                        f" of the {len(first)} genomes anchored here" if filtered else "", tbl.stats())
+                        (" of this process's pieces" if scope == "pieces" else f" of the {len(first)} genomes anchored here") if filtered else "",
+                        tbl.stats())
             if self.export_kmc:
                 os.makedirs(self.get_subdir("kmc"), exist_ok=True)
                 for i, p in enumerate(self.bitvec_prefixes):
                     keys, vals = tbl.export(i)
                     write_kmc1(p, keys, vals, self.k)
                 self.write_opdefs()
-        self._table = tbl
+        self._table, self._table_scope = tbl, scope
         return tbl
 
     def seqset_for(self, name: str) -> engine.SeqSet:
@@ -555,7 +590,7 @@ class Index:
         if self.shard == "genome" and self.genome_blocks > 0:
             return "genome", min(N, self.genome_blocks)
         inputs = self.load_inputs()
-        free, _total = self.context.mem_info()
+        free = self._agreed_free_memory()
         nb = (N + 7) // 8
         longest = max([int(i[2].lens.sum()) for i in inputs if i[0] in self.anchor_genomes] or [0])
         # next to the table: two batches of rows (one being written, one being anchored), at least one anchor each
@@ -592,10 +627,20 @@ class Index:
         from concurrent.futures import ThreadPoolExecutor
         os.makedirs(self.get_subdir("logs"), exist_ok=True)
         mode, nblocks = self.plan_sharding()
+        self._check_plan_agreed((mode, nblocks))
         if mode == "genome":
             from .distributed import run_genome_sharded
             logger.info("genome-sharded mode: %d genome blocks over %d GPU(s)", nblocks, self.world)
             run_genome_sharded(self, nblocks)
+            self.close()
+            return
+        if self.world > 1 and os.environ.get("PG_PARTITION", "pieces") != "genomes":
+            # several GPUs, a table that fits one: pieces of homology classes are dealt to the ranks, so that every
+            # rank's launch still co-schedules ALL anchor genomes (distributed.run_index_sharded); dealing whole
+            # genomes to ranks (PG_PARTITION=genomes, below) leaves a rank's launch without co-scheduling partners —
+            # and GPUs idle when there are fewer anchors than GPUs
+            from .distributed import run_index_sharded
+            run_index_sharded(self, self.rank, self.world, self._barrier())
             self.close()
             return
         mine = self.my_anchor_genomes()
@@ -633,6 +678,45 @@ class Index:
             if previous is not None:
                 self._finish_batch(*previous)
         self.close()
+
+    @staticmethod
+    def _dist():
+        """torch.distributed when this process is part of an initialised process group, else None (torch is not
+        imported for a single process)"""
+        import sys
+        td = sys.modules.get("torch.distributed")
+        return td if td is not None and td.is_available() and td.is_initialized() else None
+
+    def _barrier(self):
+        d = self._dist()
+        return d.barrier if d is not None and self.world > 1 else None
+
+    def _agreed_free_memory(self) -> int:
+        """HBM this process may plan with — THE SAME NUMBER ON EVERY RANK, since ranks that decide differently (one
+        replicated, one genome-sharded; or different block counts) would meet in mismatched collectives: the minimum of
+        the ranks' free memory when a process group exists, else (several ranks without one) the device's total minus
+        a fixed allowance for other tenants, else this device's free memory."""
+        free, total = self.context.mem_info()
+        if self.world <= 1:
+            return free
+        d = self._dist()
+        if d is None:
+            return total - (8 << 30)
+        import torch
+        dev = self.context.torch_device() if d.get_backend() == "nccl" else torch.device("cpu")
+        t = torch.tensor([free], dtype=torch.int64, device=dev)
+        d.all_reduce(t, op=d.ReduceOp.MIN)
+        return int(t.item())
+
+    def _check_plan_agreed(self, plan) -> None:
+        """every rank must have reached the same (mode, nblocks) before any of them enters a collective"""
+        d = self._dist()
+        if d is None or self.world <= 1:
+            return
+        got = [None] * self.world
+        d.all_gather_object(got, (plan[0], int(plan[1])))
+        if any(g != got[0] for g in got):
+            raise RuntimeError(f"the ranks planned different sharding modes {got}: pin one with PG_SHARD / PG_GENOME_BLOCKS")
 
     @staticmethod
     def writer_jobs(payload_bytes: int) -> int:

@@ -103,6 +103,10 @@ class SeqSet:
     def concat_ranges(cls, ctx, parts):
         return cls(ctx, [n for s, f, c in parts for n in s.names[f:f + c]], [q for s, f, c in parts for q in s.seqs[f:f + c]])
 
+    def slice(self, pieces):
+        assert all(s0 % 32 == 0 and s0 + n <= len(self.seqs[c]) for c, s0, n in pieces)
+        return SeqSet(self.ctx, [f"{self.names[c]}:{s0}" for c, s0, _ in pieces], [self.seqs[c][s0:s0 + n] for c, s0, n in pieces])
+
     def total_kmers(self, k):
         return int(sum(max(0, len(s) - k + 1) for s in self.seqs))
 

@@ -219,3 +219,123 @@ def test_single_process_passes_and_mode_choice(tmp_path, monkeypatch):
     assert mode == "genome" and 2 <= nblocks <= 8
     idx.run()
     _check_tree(idx_dir, fx)
+
+
+# ---------------------------------------------------------------------------
+# the contig-sharded multi-GPU partition: pieces of homology classes
+# ---------------------------------------------------------------------------
+def test_plan_class_pieces_covers_balances_and_aligns():
+    from panagram_amd.distributed import piece_alignment, plan_class_pieces
+    # 8 genomes x 5 chromosomes of 20 Mb (config 2's shape), class = chromosome
+    contigs = [(f"g{g}", c, 20_000_000 - 20 - 1000 * g, c) for g in range(8) for c in range(5)]
+    align = piece_alignment(100)
+    assert align == 800
+    for world in (1, 2, 3, 8):
+        plan = plan_class_pieces(contigs, world)
+        assert len(plan) == world and plan == plan_class_pieces(list(contigs), world)
+        pieces = [p for sh in plan for p in sh]
+        for name, ci, nk, _ in contigs:  # every contig is covered exactly once, in aligned pieces
+            mine = sorted(p for p in pieces if p[0] == name and p[1] == ci)
+            assert mine[0][2] == 0 and sum(p[3] for p in mine) == nk
+            for a, b in zip(mine, mine[1:]):
+                assert a[2] + a[3] == b[2] and b[2] % align == 0
+        loads = [sum(p[3] for p in sh) for sh in plan]
+        assert max(loads) <= 1.05 * sum(loads) / world  # 5 chromosomes on 8 ranks still balance
+        for sh in plan:  # a rank holds the SAME pieces of every genome: its launch co-schedules all of them
+            keys = {(p[4], p[5]) for p in sh}
+            for key in keys:
+                assert {p[0] for p in sh if (p[4], p[5]) == key} == {f"g{g}" for g in range(8)}
+    # no piece below the minimum length; a class with a short contig is cut less often (or not at all)
+    mixed = [("a", 0, 30_000_000, 0), ("b", 0, 1_500_000, 0), ("a", 1, 40_000_000, 1), ("b", 1, 41_000_000, 1)]
+    plan = plan_class_pieces(mixed, 4)
+    assert sum(1 for sh in plan for p in sh if p[4] == 0) == 2 and sum(1 for sh in plan for p in sh if p[4] == 1) > 2
+    assert min(p[3] for sh in plan for p in sh) >= 1 << 20
+
+
+def _piece_pangenome(tmp_path):
+    """3 genomes x (40 kb, 24 kb, 700 b, 15 b) with SNPs, an N run and lower case; the third genome names its records
+    differently (paired by position); a GFF with genes that straddle piece boundaries on the first genome"""
+    rng = np.random.default_rng(77)
+    gen = po.synth_genomes(3, [40000, 24000, 700, 15], 0.02, 5)
+    rows = ["name\tfasta\tgff"]
+    for g, contigs in enumerate(gen):
+        seqs = [po.codes_to_ascii(c) for c in contigs]
+        if g == 1:
+            seqs[0] = seqs[0][:15990] + b"N" * 30 + seqs[0][16020:20000] + seqs[0][20000:20400].lower() + seqs[0][20400:]
+        names = [f"chr{ci + 1}" if g < 2 else f"CM00{ci}.1" for ci in range(len(seqs))]
+        fa = tmp_path / f"g{g}.fa"
+        fa.write_bytes(po.fasta_text(names, seqs, (80, 70, 61)[g]))
+        gff = ""
+        if g == 0:
+            gff = str(tmp_path / "g0.gff")
+            with open(gff, "w") as f:
+                for st, en in ((100, 900), (15500, 16500), (19000, 21000), (31990, 32010), (39000, 39980), (39000, 50000)):
+                    f.write(f"chr1\tx\tgene\t{st}\t{en}\t.\t+\t.\tID=g{st}\n")
+                f.write("chr2\tx\tgene\t50\t23000\t.\t+\t.\tID=h\n")
+        rows.append(f"g{g}\t{fa}\t{gff}")
+    s = tmp_path / "samples.tsv"
+    s.write_text("\n".join(rows) + "\n")
+    return s
+
+
+def _pieces_worker(rank, world, port, idx_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from panagram_amd import index as pidx
+        from tests import fake_engine
+        pidx.engine = fake_engine
+        idx = pidx.Index(idx_dir, mode="w")
+        assert (idx.rank, idx.world) == (rank, world) and idx.plan_sharding() == ("replicated", 1)
+        idx.run()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_index_run_deals_pieces_of_homology_classes(world, tmp_path, monkeypatch):
+    """Index.run() with several ranks and a table that fits: chromosomes are cut into aligned pieces, every rank
+    anchors ITS pieces of EVERY genome (co-scheduled), fragments are assembled by whoever finds a genome complete.
+    Decompressed bitmaps, bins, chrs, paircounts and gene histograms equal the one-rank run's."""
+    import pandas as pd
+    from panagram_amd import distributed as pdist
+    from panagram_amd import index as pidx
+    from tests import fake_engine
+    s = _piece_pangenome(tmp_path)
+    geo = dict(k=21, lowres_step=50, max_bin_kbp=3, min_bin_count=5)
+    monkeypatch.setattr(pidx, "engine", fake_engine)
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    monkeypatch.setenv("RANK", "0")
+    pidx.Index(str(s), prefix=str(tmp_path / "one"), **geo).run()
+    pidx.Index(str(s), prefix=str(tmp_path / "many"), prepare=True, **geo)
+    # the plan really cuts the long chromosomes and gives every rank pieces of every genome
+    idx = pidx.Index(str(tmp_path / "many"), mode="w")
+    seqs = {n: idx.seqset_for(n) for n in idx.anchor_genomes}
+    cls = fake_engine.homology_classes([seqs[n].names for n in idx.anchor_genomes])
+    contigs, c = [], 0
+    for n in idx.anchor_genomes:
+        for ci, ln in enumerate(seqs[n].lens):
+            contigs.append((n, ci, max(0, int(ln) - 20), int(cls[c])))
+            c += 1
+    monkeypatch.setenv("PG_MIN_PIECE", "3000")  # (read by the workers at import: pieces of a few thousand positions)
+    plan = pdist.plan_class_pieces(contigs, world, 50, min_piece=3000)
+    assert all({p[0] for p in sh} == set(idx.anchor_genomes) for sh in plan)
+    assert max(p[5] for sh in plan for p in sh) >= 1 and all(p[2] % 800 == 0 for sh in plan for p in sh)
+    assert any(p[2] % 3000 for sh in plan for p in sh)  # pieces that do NOT start on a bin boundary
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_pieces_worker, args=(world, port, str(tmp_path / "many")), nprocs=world, join=True)
+    for g in range(3):
+        a, b = tmp_path / "one" / "anchor" / f"g{g}", tmp_path / "many" / "anchor" / f"g{g}"
+        for step in (1, 50):
+            assert gzip.open(a / f"bitmap.{step}.gz", "rb").read() == gzip.open(b / f"bitmap.{step}.gz", "rb").read()
+            blocks = pidx.load_bgz_blocks(str(b / f"bitmap.{step}.gzi"))
+            raw = gzip.open(b / f"bitmap.{step}.gz", "rb").read()
+            for start in (0, 3999, 4000, len(raw) - 7):  # the .gzi of the concatenated fragments addresses the payload
+                assert pidx.bgzf_read(str(b / f"bitmap.{step}.gz"), blocks, start, 7) == raw[start:start + 7]
+        for t in ("bitsum.bins.tsv", "chrs.tsv", "total_paircounts.csv"):
+            assert (a / t).read_bytes() == (b / t).read_bytes(), (g, t)
+        assert not (b / ".parts").exists()
+    assert (tmp_path / "one" / "anchor" / "g0" / "bitsum.genes.tsv").read_bytes() == \
+        (tmp_path / "many" / "anchor" / "g0" / "bitsum.genes.tsv").read_bytes()
+    genes = pd.read_table(tmp_path / "many" / "anchor" / "g0" / "bitsum.genes.tsv", index_col="chr")
+    assert genes.loc["chr1"].sum() > 0

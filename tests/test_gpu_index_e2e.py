@@ -439,12 +439,37 @@ def test_gpu_bgzf_multi_batch(ctx, tmp_path):
         x.close()
 
 
-@pytest.mark.parametrize("name,world", [("n9_k21", 2), ("n40_k31", 3)])
-def test_index_run_on_several_ranks_writes_the_same_tree(name, world, tmp_path):
-    """Multi-GPU Index.run (one process per GPU; here the ranks run one after the other on the one
-    GPU of the box): anchor genomes are dealt to the ranks, the table is replicated, and the tree of
-    files is byte-identical to the single-rank run — it does not depend on the GPU count."""
+def _same_index_payload(one, many, steps=(1, 100)):
+    """two index trees hold the same index: decompressed bitmaps and every table byte for byte (the compressed
+    bytes and the .gzi follow the BGZF block boundaries, which may differ), the .gzi addressing its own payload"""
     from panagram_amd import index as pidx
+    for dirpath, _, files in os.walk(one):
+        if os.path.basename(dirpath) == "logs":
+            continue
+        for f in files:
+            a = os.path.join(dirpath, f)
+            b = os.path.join(many, os.path.relpath(a, one))
+            if f.endswith(".gzi"):
+                continue
+            if f.endswith(".gz"):
+                raw = gzip.open(b, "rb").read()
+                assert gzip.open(a, "rb").read() == raw, f
+                blocks = pidx.load_bgz_blocks(b + "i")
+                for start in (0, len(raw) // 3, max(0, len(raw) - 5)):
+                    assert pidx.bgzf_read(b, blocks, start, 5) == raw[start:start + 5]
+            else:
+                assert open(a, "rb").read() == open(b, "rb").read(), f
+    assert not [d for d, _, _ in os.walk(many) if os.path.basename(d) == ".parts"]
+
+
+@pytest.mark.parametrize("name,world,partition", [("n9_k21", 2, "pieces"), ("n40_k31", 3, "pieces"), ("n9_k21", 2, "genomes")])
+def test_index_run_on_several_ranks_writes_the_same_tree(name, world, partition, tmp_path, monkeypatch):
+    """Multi-GPU Index.run (one process per GPU; here the ranks run one after the other on the one GPU of the box).
+    Default partition: pieces of homology classes — every rank anchors its share of EVERY genome, whoever completes a
+    genome assembles it (the last rank at the latest).  PG_PARTITION=genomes: whole anchor genomes dealt to the ranks.
+    Either way the index is the single-rank one — it does not depend on the GPU count."""
+    from panagram_amd import index as pidx
+    monkeypatch.setenv("PG_PARTITION", partition)
     fx = H.load_case(name)
     k = int(fx["k"])
     anchors = [f"g{g}" for g in fx["anchors"]]
@@ -458,19 +483,79 @@ def test_index_run_on_several_ranks_writes_the_same_tree(name, world, tmp_path):
         mine = idx.my_anchor_genomes()
         seen += mine
         idx.run()
-        for nm in mine:  # a rank leaves exactly its genomes' directories complete
-            assert (many / "anchor" / nm / "total_paircounts.csv").exists()
+        if partition == "genomes":
+            for nm in mine:  # a rank leaves exactly its genomes' directories complete
+                assert (many / "anchor" / nm / "total_paircounts.csv").exists()
+        elif rank < world - 1:  # nothing is complete before the last rank has anchored its pieces
+            assert not any((many / "anchor" / nm / "chrs.tsv").exists() for nm in anchors)
     assert sorted(seen) == sorted(anchors) and len(seen) == len(anchors)
-    if len(anchors) >= world:
-        assert all(pidx.Index(str(s), prefix=str(many), k=k, anchor_genomes=anchors, rank=r, world=world).my_anchor_genomes()
-                   for r in range(world))
-    for dirpath, _, files in os.walk(one):
-        if os.path.basename(dirpath) == "logs":
-            continue
-        for f in files:
-            a = os.path.join(dirpath, f)
-            b = os.path.join(many, os.path.relpath(a, one))
-            assert open(a, "rb").read() == open(b, "rb").read(), f
+    if partition == "genomes":
+        for dirpath, _, files in os.walk(one):
+            if os.path.basename(dirpath) == "logs":
+                continue
+            for f in files:
+                a = os.path.join(dirpath, f)
+                b = os.path.join(many, os.path.relpath(a, one))
+                assert open(a, "rb").read() == open(b, "rb").read(), f
+    else:
+        _same_index_payload(str(one), str(many))
+
+
+def test_seqset_slice_and_pieces_equal_whole_contigs(ctx):
+    """pg_seqset_slice: pieces of packed contigs (starts on 32-base words) unpack to the contig's bases; anchored with
+    k - 1 bases of overlap they give exactly the contig's rows — N runs and lower case across the cuts included."""
+    from panagram_amd import engine
+    rng = np.random.default_rng(9)
+    k, n = 21, 5
+    gen = po.synth_genomes(n, [9000, 2100], 0.02, 31)
+    genomes = [[po.codes_to_ascii(c) for c in g] for g in gen]
+    a = bytearray(genomes[2][0])
+    a[3190:3215] = b"N" * 25          # an N run across the cut at 3200
+    a[6380:6420] = bytes(a[6380:6420]).lower()
+    genomes[2][0] = bytes(a)
+    tbl = engine.PanTable(ctx, k, n)
+    for g in range(n):
+        ss = engine.SeqSet.from_host(ctx, genomes[g])
+        tbl.insert_seqset(g, ss)
+        ss.close()
+    whole = engine.SeqSet.from_host(ctx, genomes[2])
+    cuts = [(0, 0, 3200 + k - 1), (0, 3200, 3200 + k - 1), (0, 6400, 9000 - 6400), (1, 0, 2100), (1, 2080, 20), (0, 8992, 8)]
+    pieces = whole.slice(cuts)
+    assert list(pieces.lens) == [c[2] for c in cuts]
+    want = [whole.unpack(0), whole.unpack(1)]
+    for i, (ci, s0, ln) in enumerate(cuts):
+        assert pieces.unpack(i) == want[ci][s0:s0 + ln]
+    r0 = engine.AnchorResult(tbl, whole, colsums=True)
+    r0.run()
+    r1 = engine.AnchorResult(tbl, pieces, colsums=True)
+    r1.run()
+    rows = r0.download(0)[0]
+    got = np.concatenate([r1.download(i)[0] for i in range(3)])
+    assert np.array_equal(got, rows)
+    assert np.array_equal(r1.download(3)[0], r0.download(1)[0])
+    assert r1.download(4)[0].shape[0] == 0 and r1.download(5)[0].shape[0] == 0  # pieces shorter than k: no rows
+    with pytest.raises(engine.PanagramHipError):
+        whole.slice([(0, 100, 50)])  # not on a 32-base word
+    with pytest.raises(engine.PanagramHipError):
+        whole.slice([(0, 8992, 100)])  # past the end
+    for x in (r0, r1, pieces, whole, tbl):
+        x.close()
+
+
+def test_index_run_pieces_cut_chromosomes_on_the_gpu(tmp_path, monkeypatch):
+    """The default multi-rank partition on the real engine with chromosomes long enough to be cut (small minimum piece):
+    3 ranks one after the other; pieces that start inside a bin, genes across cuts, a genome with other record ids."""
+    from panagram_amd import distributed as pdist
+    from panagram_amd import index as pidx
+    from tests.test_distributed_cpu import _piece_pangenome
+    s = _piece_pangenome(tmp_path)
+    geo = dict(k=21, lowres_step=50, max_bin_kbp=3, min_bin_count=5)
+    pidx.Index(str(s), prefix=str(tmp_path / "one"), **geo).run()
+    monkeypatch.setattr(pdist, "MIN_PIECE", 3000)
+    for rank in range(3):
+        pidx.Index(str(s), prefix=str(tmp_path / "many"), rank=rank, world=3, **geo).run()
+    _same_index_payload(str(tmp_path / "one"), str(tmp_path / "many"), steps=(1, 50))
+    assert (tmp_path / "many" / "anchor" / "g0" / "bitsum.genes.tsv").exists()
 
 
 @pytest.mark.parametrize("n", [3, 12, 20, 27, 33, 50, 64, 96, 130, 300])

@@ -129,6 +129,26 @@ def test_opdef_files_follow_the_reference_text(tmp_path):
         assert open(idx.opdef_filenames[i]).read() == exp
 
 
+def test_homology_classes_pair_by_id_or_by_position():
+    """Contigs are co-scheduled by record id when assemblies share ids, and BY POSITION when a genome's ids match
+    nobody's (per-assembly accessions): the schedule must interleave such genomes too, not run them one after the
+    other (a class per contig)."""
+    from panagram_amd import engine
+    hc = engine.homology_classes
+    # shared ids, one genome in another order
+    assert list(hc([["chr1", "chr2", "chr3"], ["chr2", "chr1", "chr3"]])) == [0, 1, 2, 1, 0, 2]
+    # disjoint id sets everywhere: class = position; a longer genome's extra contig is alone
+    got = list(hc([["CM1", "CM2", "CM3"], ["XX1", "XX2", "XX3", "scaf"], ["YY1", "YY2"]]))
+    assert got == [0, 1, 2, 0, 1, 2, 3, 0, 1]
+    # two genomes share ids, a third has accessions of its own -> it joins the first genome's classes by position;
+    # a private scaffold of an id-matched genome stays alone
+    got = list(hc([["chr1", "chr2"], ["chr1", "chr2", "scafA"], ["A1", "A2", "A3"]]))
+    assert got[:4] == [0, 1, 0, 1] and got[4] not in (0, 1) and got[5:7] == [0, 1] and got[7] not in (0, 1, got[4])
+    # no ids at all (sequences loaded from memory)
+    assert list(hc([["", ""], ["", ""]])) == [0, 1, 0, 1]
+    assert list(hc([["a", "b"]])) == [0, 1]
+
+
 def test_bgzf_read_side_matches_reference_addressing(tmp_path):
     """load_bgz_blocks + virtual-offset style random access (index.py:793-845) over our writer."""
     from panagram_amd import engine
@@ -336,5 +356,5 @@ def test_homology_classes_from_record_ids():
     from panagram_amd.engine import homology_classes
     c = homology_classes([["chr1", "chr2", "chrM"], ["chr2", "chr1", "scaf9"], ["", ""], ["chrM"]])
     assert list(c[:3]) == [0, 1, 2] and list(c[3:6]) == [1, 0, 3]
-    assert c[6] != c[7] and len({int(c[6]), int(c[7])} & {0, 1, 2, 3}) == 0  # unnamed contigs stay on their own
+    assert list(c[6:8]) == [0, 1]  # a genome without ids is paired by position (the first genome's classes)
     assert c[8] == 2
