@@ -148,9 +148,17 @@ class Pangenome:
     """synthetic pangenome resident in HBM: packed sequences of this rank's contig group, the table of ALL groups"""
 
     def __init__(self, ctx, dev, G, contig_lens, d, seed, k, groups=1, my_group=0, keep_ascii=True, minimizer=-1,
-                 rehash_kpb=None, block=None):
+                 rehash_kpb=None, block=None, pieces_of=None):
+        """``pieces_of=(rank, world)`` (strong scaling): the pangenome is the SAME whatever the GPU count; this rank
+        anchors its pieces of homology classes (panagram_amd.distributed.plan_class_pieces — the partition
+        Index.run() uses with several ranks) against a table built from those pieces, every genome then only setting
+        its bits in it."""
         from panagram_amd import engine
         self.G, self.k, self.contig_lens = G, k, list(contig_lens)
+        self.pieces = None
+        if pieces_of is not None:
+            self._init_pieces(ctx, dev, d, seed, pieces_of, minimizer)
+            return
         L = sum(contig_lens)
         novel = 1.0 - (1.0 - d) ** k
         g_lo, g_hi = (0, G) if block is None else block  # genome block of the table (genome-sharded mode)
@@ -196,6 +204,58 @@ class Pangenome:
         self.stats = self.table.stats()
         self.pos_per_genome = [self.seqsets[g].total_kmers(k) for g in range(G)]
 
+    def _init_pieces(self, ctx, dev, d, seed, pieces_of, minimizer):
+        from panagram_amd import distributed as pdist
+        from panagram_amd import engine
+        rank, world = pieces_of
+        G, k, contig_lens = self.G, self.k, self.contig_lens
+        C = len(contig_lens)
+        genomes = synth_genomes_device(G, contig_lens, d, seed, dev)
+        torch.cuda.synchronize()
+        full = []
+        for g in range(G):
+            ss = engine.SeqSet(ctx, contig_lens)
+            for c, t in enumerate(genomes[g]):
+                ss.load_dev(c, t.data_ptr(), t.numel())
+            full.append(ss)
+        ctx.synchronize()
+        del genomes
+        torch.cuda.empty_cache()
+        contigs = [(g, c, contig_lens[c] - k + 1, c) for g in range(G) for c in range(C)]  # class = chromosome number
+        plan = pdist.plan_class_pieces(contigs, world)
+        mine = sorted(plan[rank], key=lambda p: (p[4], p[5], p[0]))
+        t0 = time.perf_counter()
+        # this rank's pieces, cut out of the packed genomes in HBM with k - 1 bases of overlap
+        self.pieces = [[p for p in mine if p[0] == g] for g in range(G)]
+        self.seqsets = [full[g].slice([(p[1], p[2], p[3] + k - 1) for p in self.pieces[g]]) for g in range(G)]
+        sketch = engine.KmerSketch(ctx, k)
+        for ss in self.seqsets:
+            sketch.add(ss)
+        est = sketch.estimate()
+        sketch.close()
+        self.table = engine.PanTable(ctx, k, G, expected_keys=est + est // 32 + 1024)
+        if minimizer >= 0:
+            self.table.set_minimizer(minimizer)
+        ctx.synchronize()
+        tb = time.perf_counter()
+        for g in range(G):
+            self.table.insert_seqset(g, self.seqsets[g])
+        if world > 1:
+            for g in range(G):
+                self.table.update_seqset(g, full[g])
+        ctx.synchronize()
+        self.build_s = time.perf_counter() - tb
+        self.filtered = world > 1
+        for ss in full:
+            ss.close()
+        self.ascii = None
+        self.setup_s = time.perf_counter() - t0
+        self.stats = self.table.stats()
+        self.pos_per_genome = [self.seqsets[g].total_kmers(k) for g in range(G)]
+        self.total_positions = sum(n for _, _, n, _ in contigs)  # of the whole pangenome, all ranks together
+        self.plan_loads = [sum(p[3] for p in sh) for sh in plan]
+        self.plan_class_pieces = len({(p[4], p[5]) for sh in plan for p in sh})
+
     def close(self):
         for ss in self.seqsets or []:
             ss.close()
@@ -237,7 +297,12 @@ def make_results(ctx, pg, colsums, per_genome, piece_tiles):
         return [engine.AnchorResult(pg.table, pg.seqsets[g], colsums=colsums) for g in range(pg.G)], None
     merged = engine.SeqSet.concat(ctx, pg.seqsets)
     r = engine.AnchorResult(pg.table, merged, colsums=colsums)
-    r.coschedule(np.repeat(np.arange(pg.G), len(pg.contig_lens)), piece_tiles)
+    if pg.pieces is not None:  # a rank's pieces of homology classes: co-scheduled by (class, piece), as run_index_sharded does
+        ids = {key: i for i, key in enumerate(sorted({(p[4], p[5]) for ps in pg.pieces for p in ps}))}
+        r.coschedule(np.concatenate([np.full(len(ps), g, np.uint32) for g, ps in enumerate(pg.pieces)]), piece_tiles,
+                     contig_class=np.array([ids[(p[4], p[5])] for ps in pg.pieces for p in ps], np.uint32))
+    else:
+        r.coschedule(np.repeat(np.arange(pg.G), len(pg.contig_lens)), piece_tiles)
     return [r], merged
 
 
@@ -256,46 +321,50 @@ def load_counters(pos_per_launch, k, G):
 
 
 def roofline_block(pos_per_launch, avg_launch_s, avg_epi_s, G, value_per_gpu, counters, nruns):
-    """The dominant kernel (k_probe) against the two ceilings that can bind it.
-    contract (SURVEY §8d): algorithmic bytes = one 64-byte bucket fetch per table probe + sequence + row;
-    the design needs far fewer bytes (minimizer-keyed lines serve runs of positions, co-scheduled genomes share
-    them in L2), so that figure can exceed the peak and is NOT the bound; what binds is instruction issue:
-    frac = VALU wave-instructions x issue cycles / (SIMDs x clock x launch time)."""
+    """The dominant kernel (k_probe) against the HBM roofline (8 TB/s, MI355X_MICROARCH.md).
+
+    ``achieved`` = ALGORITHMIC bytes per launch / the launch's mean duration, the algorithmic bytes being the design's
+    useful-payload floor SURVEY §8d defines: B_min = 0.25 (2-bit base) + 12 P (one 8-byte key + one 4-byte mask word per
+    table probed; P = 1: ONE table and one probe per position whatever the genome count) + 1.01 nbytes (the bitmap.1
+    row + 1/100 bitmap.100 row) bytes per position.  ``frac`` = achieved / peak <= 1 by construction, recomputable
+    from DESIGN.md §4 + profiles/.  ``traffic`` = HBM bytes per launch by the PMC counters of the committed rocprofv3
+    passes of this same command (profiles/traffic.json: FETCH_SIZE doubled per the guide's gfx950 correction, +
+    WRITE_SIZE), quoted only for the workload they were collected on; traffic / algorithmic = re-read overhead.
+    Secondary, named for what they are: ``contract_*`` = SURVEY §8d's 64-byte-bucket-per-probe figure (the kernel
+    does not move those bytes — minimizer-keyed lines serve runs of positions, co-scheduled genomes share them in L2 — so
+    it exceeds 1 and is no bound); ``valu_issue_*`` = the instruction-issue ceiling at the architectural 2 cycles per
+    wave64 VALU instruction and at the 4 cycles measured for this kernel's instruction mix (tools/valu_rate.hip)."""
     nbytes = (G + 7) // 8
-    P = (G + 63) // 64  # table probes per position in this design (one wide-mask sub-table per 64 genomes)
-    B = 0.25 + 64.0 * P + 1.01 * nbytes
-    contract_bytes = pos_per_launch * B
+    P = 1
+    B_min = 0.25 + 12.0 * P + 1.01 * nbytes
+    algorithmic = pos_per_launch * B_min
+    B_contract = 0.25 + 64.0 * ((G + 63) // 64) + 1.01 * nbytes
     out = {
-        "kernel": "k_probe",
-        "avg_launch_ms": avg_launch_s * 1e3, "launches_averaged": nruns,
-        "epilogue_kernel_ms": avg_epi_s * 1e3,
-        "algorithmic_bytes_per_position": B, "algorithmic_bytes_per_launch": contract_bytes,
-        "contract_hbm_GBps": contract_bytes / avg_launch_s / 1e9,
-        "contract_hbm_frac": contract_bytes / avg_launch_s / HBM_PEAK,
-        "contract_whole_run_frac": value_per_gpu * B / HBM_PEAK,
-        "traffic": None, "hbm_counter_frac": None, "valu_frac": None,
+        "bound": "hbm", "kernel": "k_probe",
+        "achieved": algorithmic / avg_launch_s / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+        "frac": algorithmic / avg_launch_s / HBM_PEAK,
+        "traffic": None,
+        "avg_launch_ms": avg_launch_s * 1e3, "launches_averaged": nruns, "epilogue_kernel_ms": avg_epi_s * 1e3,
+        "algorithmic_bytes_per_position": B_min, "algorithmic_bytes_per_launch": algorithmic,
+        "table_probes_per_position": P,
+        "hbm_counter_frac": None, "traffic_over_algorithmic": None,
+        "contract_bytes_per_position": B_contract, "contract_hbm_frac": pos_per_launch * B_contract / avg_launch_s / HBM_PEAK,
+        "valu_issue_frac_2cycle": None, "valu_issue_frac_4cycle": None,
     }
     if counters is not None:
         if counters.get("hbm_bytes_per_launch"):
-            traffic = counters["hbm_bytes_per_launch"]
-            out["traffic"] = traffic
-            out["hbm_counter_frac"] = traffic / avg_launch_s / HBM_PEAK
+            out["traffic"] = counters["hbm_bytes_per_launch"]
+            out["hbm_counter_frac"] = out["traffic"] / avg_launch_s / HBM_PEAK
+            out["traffic_over_algorithmic"] = out["traffic"] / algorithmic
         if counters.get("SQ_INSTS_VALU"):
             out["valu_wave_instructions_per_launch"] = counters["SQ_INSTS_VALU"]
             out["valu_wave_instructions_per_position"] = counters["SQ_INSTS_VALU"] / pos_per_launch
-            out["valu_frac"] = counters["SQ_INSTS_VALU"] * VALU_CYCLES / (SIMDS * CLOCK_HZ * avg_launch_s)
-    if out["valu_frac"] is not None and out["valu_frac"] >= (out["hbm_counter_frac"] or 0):
-        out.update(bound="valu", achieved=out["valu_wave_instructions_per_launch"] * VALU_CYCLES / avg_launch_s / 1e12,
-                   peak=SIMDS * CLOCK_HZ / 1e12, unit="T issue-cycles/s", frac=out["valu_frac"])
-    elif out["hbm_counter_frac"] is not None:
-        out.update(bound="hbm", achieved=out["traffic"] / avg_launch_s / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s",
-                   frac=out["hbm_counter_frac"])
-    else:  # no committed counter pass for this workload: no fraction is claimed (contract_* above is not a bound)
-        out.update(bound="unmeasured (no committed --pmc pass for this workload)", achieved=None, peak=None, unit=None, frac=None)
-    out["note"] = ("frac is the binding ceiling: VALU issue (SQ_INSTS_VALU of the committed rocprofv3 --pmc pass x 4 issue "
-                   "cycles / (1024 SIMDs x 2.4 GHz x launch time)) or counter-measured HBM bytes / 8 TB/s; contract_* price one "
-                   "64-byte table fetch per position (SURVEY 8d) — the kernel moves far fewer bytes (traffic), so that "
-                   "figure is not a bound (DESIGN.md section 4)")
+            out["valu_issue_frac_2cycle"] = counters["SQ_INSTS_VALU"] * 2.0 / (SIMDS * CLOCK_HZ * avg_launch_s)
+            out["valu_issue_frac_4cycle"] = counters["SQ_INSTS_VALU"] * VALU_CYCLES / (SIMDS * CLOCK_HZ * avg_launch_s)
+        out["counters_from"] = counters.get("profiled_on", "profiles/traffic.json (committed rocprofv3 --pmc passes of this command)")
+    out["note"] = ("frac = algorithmic bytes (B_min of SURVEY 8d x positions per launch) / mean k_probe launch time / 8 TB/s; traffic = "
+                   "PMC-measured HBM bytes of the same launch (null for workloads without a committed --pmc pass); the kernel is "
+                   "not HBM-bound — valu_issue_frac_* say how close instruction issue is to its ceiling (DESIGN.md section 4)")
     return out
 
 
@@ -356,6 +425,186 @@ def north_star_leg(ctx, dev, args):
     return out
 
 
+def write_fasta_from_device(path, names, contigs, width=80):
+    """FASTA text of ASCII tensors in HBM: the line breaks are put in on the GPU, the host only writes the bytes"""
+    with open(path, "wb") as f:
+        for nm, t in zip(names, contigs):
+            f.write(b">" + nm.encode() + b"\n")
+            n = t.numel()
+            full = (n // width) * width
+            if full:
+                body = torch.empty((n // width, width + 1), dtype=torch.uint8, device=t.device)
+                body[:, :width] = t[:full].view(-1, width)
+                body[:, width] = 10
+                f.write(body.cpu().numpy().tobytes())
+            if n > full:
+                f.write(t[full:].cpu().numpy().tobytes() + b"\n")
+
+
+def e2e_leg(dev, args, G, contig_lens, k):
+    """anchor END TO END — FASTA files on disk -> (table) -> every anchor's BGZF / .gzi / TSV files on disk
+    through the product's `panagram index` entry, Index.run() (the reference times the whole rule,
+    workflow/Snakefile:43-44).  Outside the timed region of `value`; the table build (FASTA read + GPU parse + sketch +
+    inserts) is timed on its own.  Checked: every anchor's files exist and its own column of total_paircounts.csv
+    counts every one of its positions."""
+    import shutil
+    import tempfile
+    import pandas as pd
+    from panagram_amd import index as pidx
+    root = tempfile.mkdtemp(prefix="pg_bench_e2e_")
+    try:
+        genomes = synth_genomes_device(G, contig_lens, args.d, args.seed, dev)
+        rows, nbytes_in = ["name\tfasta"], 0
+        t0 = time.perf_counter()
+        for g in range(G):
+            fa = os.path.join(root, f"g{g}.fa")
+            write_fasta_from_device(fa, [f"chr{c + 1}" for c in range(len(contig_lens))], genomes[g])
+            nbytes_in += os.path.getsize(fa)
+            rows.append(f"g{g}\t{fa}")
+        del genomes
+        torch.cuda.empty_cache()
+        with open(os.path.join(root, "samples.tsv"), "w") as f:
+            f.write("\n".join(rows) + "\n")
+        write_s = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        idx = pidx.Index(os.path.join(root, "samples.tsv"), prefix=os.path.join(root, "idx"), k=k)
+        idx.run()
+        t2 = time.perf_counter()
+        t1 = t0 + idx.timings.get("load_inputs_s", 0.0) + idx.timings.get("table_build_s", 0.0)
+        npos = G * sum(L - k + 1 for L in contig_lens)
+        out_bytes = 0
+        for g in range(G):
+            adir = os.path.join(root, "idx", "anchor", f"g{g}")
+            for fn in ("bitmap.1.gz", "bitmap.1.gzi", "bitmap.100.gz", "bitmap.100.gzi", "bitsum.bins.tsv", "chrs.tsv", "total_paircounts.csv"):
+                out_bytes += os.path.getsize(os.path.join(adir, fn))
+            tp = pd.read_csv(os.path.join(adir, "total_paircounts.csv"), index_col="name")
+            assert int(tp.loc[f"g{g}", "count"]) == npos // G, "an anchor's own column must count every one of its positions"
+        return {
+            "what": "Index.run(): FASTA files on disk -> k-mer table on the GPU -> every genome anchored -> bitmap.{1,100}.gz/.gzi, "
+                    "bitsum.bins.tsv, chrs.tsv, total_paircounts.csv on disk (GPU BGZF); table build included in seconds",
+            "seconds": t2 - t0, "value": npos / (t2 - t0), "unit": "k-mers/s", "positions": npos,
+            "read_parse_sketch_s": idx.timings.get("load_inputs_s"), "table_insert_s": idx.timings.get("table_build_s"),
+            "table_build_s": t1 - t0, "anchor_and_write_s": t2 - t1, "anchor_and_write_value": npos / (t2 - t1),
+            "fasta_bytes_in": nbytes_in, "index_bytes_out": out_bytes, "bitmap_payload_bytes": npos * ((G + 7) // 8) * 101 // 100,
+            "fasta_files_written_in_s": write_s, "tmp_dir_fs": root.rsplit("/", 1)[0],
+        }
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+
+
+def _revcomp_ascii(t):
+    lut = torch.zeros(256, dtype=torch.uint8, device=t.device)
+    for a, b in zip(b"ACGT", b"TGCA"):
+        lut[a] = b
+    return lut[t.flip(0).long()]
+
+
+def robustness_legs(ctx, dev, args, k):
+    """The headline is measured on collinear genomes that differ by SNPs; here, at 8 x 50 Mb and outside the timed
+    region, the same co-scheduled launch on inputs that are less kind: (a) every derived genome carries inversions and
+    lists its chromosomes in an order of its own (scheduled by homology class, as Index.run() pairs contigs by record
+    id); (b) a tenth of every genome is one young repeat family (thousands of 3-kb copies at 3 % divergence: huge
+    minimizer groups).  Each with its one-launch-per-genome value beside it.  Invariant checked: an anchor holds all of
+    its own k-mers."""
+    from panagram_amd import engine
+    G, C, L = 8, 5, 10_000_000
+    out = {}
+
+    def measure(genomes, classes, label, what):
+        seqsets = []
+        for g in range(G):
+            ss = engine.SeqSet(ctx, [int(t.numel()) for t in genomes[g]])
+            for c, t in enumerate(genomes[g]):
+                ss.load_dev(c, t.data_ptr(), t.numel())
+            seqsets.append(ss)
+        ctx.synchronize()
+        tbl = engine.PanTable(ctx, k, G, expected_keys=int(sum(t.numel() for t in genomes[0]) * (1 + (G - 1) * 0.25)))
+        tb = time.perf_counter()
+        for g in range(G):
+            tbl.insert_seqset(g, seqsets[g])
+        ctx.synchronize()
+        build_s = time.perf_counter() - tb
+        npos = sum(ss.total_kmers(k) for ss in seqsets)
+        merged = engine.SeqSet.concat(ctx, seqsets)
+        res = engine.AnchorResult(tbl, merged, colsums=True)
+        res.coschedule(np.repeat(np.arange(G), [len(g) for g in genomes]), contig_class=np.asarray(classes, np.uint32))
+        res.run()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            res.run()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 3
+        cs = res.contig_colsums(0, len(genomes[0])).sum(axis=0)
+        assert int(cs[0]) == seqsets[0].total_kmers(k), "anchor genome 0 must contain every one of its k-mers"
+        res.close()
+        merged.close()
+        singles = [engine.AnchorResult(tbl, ss, colsums=True) for ss in seqsets]
+        for r in singles:
+            r.run()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            for r in singles:
+                r.run()
+        torch.cuda.synchronize()
+        dt1 = (time.perf_counter() - t0) / 3
+        out[label] = {"what": what, "value": npos / dt, "per_genome_launches_value": npos / dt1, "unit": "k-mers/s",
+                      "positions_per_step": npos, "table_keys": tbl.stats()["nkeys"], "table_build_s": build_s}
+        for r in singles:
+            r.close()
+        for ss in seqsets:
+            ss.close()
+        tbl.close()
+        ctx.trim()
+        torch.cuda.empty_cache()
+
+    # (a) inversions + every derived genome's chromosomes in an order of its own
+    base = synth_genomes_device(G, [L] * C, args.d, args.seed + 101, dev)
+    rng = np.random.default_rng(args.seed + 5)
+    genomes, classes = [base[0]], list(range(C))
+    for g in range(1, G):
+        contigs = []
+        for t in base[g]:
+            t = t.clone()
+            for _ in range(3):
+                ln = int(rng.integers(200_000, 2_000_000))
+                s0 = int(rng.integers(0, L - ln))
+                t[s0:s0 + ln] = _revcomp_ascii(t[s0:s0 + ln])
+            contigs.append(t)
+        order = rng.permutation(C)
+        genomes.append([contigs[i] for i in order])
+        classes += [int(i) for i in order]
+    del base
+    measure(genomes, classes, "inversions_and_shuffled_contig_order",
+            "8 x 50 Mb, 1 % SNPs, 3 inversions of 0.2-2 Mb per chromosome, every derived genome listing its chromosomes in its own order")
+    del genomes
+    torch.cuda.empty_cache()
+    # (b) one tenth of the genome is a young repeat family
+    elem_n, copies = 3000, (C * L // 10) // 3500
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(args.seed + 77)
+    acgt = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+    elem = torch.randint(0, 4, (elem_n,), dtype=torch.uint8, device=dev, generator=gen)
+    uniq = synth_genomes_device(G, [L * 9 // 10] * C, args.d, args.seed + 202, dev)
+    genomes = []
+    for g in range(G):
+        contigs = []
+        per = copies // C
+        for c in range(C):
+            e = elem.repeat(per, 1)
+            mut = torch.rand(e.shape, device=dev, generator=gen) < 0.03
+            e = torch.where(mut, (e + torch.randint(1, 4, e.shape, dtype=torch.uint8, device=dev, generator=gen)) & 3, e)
+            spacer = torch.randint(0, 4, (per, 500), dtype=torch.uint8, device=dev, generator=gen)
+            fam = acgt[torch.cat([e, spacer], dim=1).reshape(-1).long()]
+            contigs.append(torch.cat([uniq[g][c], fam]))
+        genomes.append(contigs)
+    del uniq
+    measure(genomes, list(range(C)) * G, "repeat_family_10pct",
+            f"8 x 50 Mb, 90 % unique sequence at 1 % SNPs + 10 % one repeat family ({copies} copies of a 3-kb element at 3 % divergence per genome)")
+    return out
+
+
 def sharded_leg(ctx, dev, args, rank, world, dist, steps, warmup, nblocks=None):
     """The genome-sharded pipeline (panagram_amd.distributed.ShardedAnchoring — what Index.run() uses when the
     table exceeds one GPU) on the configs[1] pangenome: rank r holds the table of genome block r only, every rank
@@ -407,12 +656,36 @@ def sharded_leg(ctx, dev, args, rank, world, dist, steps, warmup, nblocks=None):
     return out
 
 
+def spawn_ranks(n):
+    """Re-run this command as ``n`` ranks of one node under torch.distributed.run (one process per GPU, RCCL over
+    xGMI), rendezvous on 127.0.0.1 at a free port; the ranks' output passes through.  Returns the exit code."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n and os.environ.get("PG_BENCH_ONE_DEVICE", "") in ("", "0"):
+        print(f"bench.py --gpus {n}: only {have} GPU(s) visible on this node", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("[bench] " + " ".join(cmd), file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--mode", choices=["contig-sharded", "genome-sharded"], default="contig-sharded")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="contig-sharded mode with N > 1 GPUs.  weak (default): the configs[1] pangenome made N x longer, "
+                         "each rank its own 5 contigs of every genome.  strong: the SAME pangenome whatever N (e.g. "
+                         "--genomes 27 --genome-mb 135 = BASELINE configs[2], '1 vs 8 GPUs'), cut into pieces of homology "
+                         "classes and dealt to the ranks exactly as Index.run() does (distributed.plan_class_pieces)")
     ap.add_argument("--blocks", type=int, default=0, help="genome blocks of the genome-sharded mode (default: one per GPU)")
     ap.add_argument("--genomes", type=int, default=8)
     ap.add_argument("--genome-mb", type=float, default=100.0)
@@ -436,6 +709,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-shapes", action="store_true", help="skip the north-star-shape leg (64 x 200 Mb, k=21)")
     ap.add_argument("--no-sharded-leg", action="store_true", help="skip the genome-sharded pipeline leg")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the files-to-files leg (Index.run() on FASTA files of this shape)")
+    ap.add_argument("--no-robustness", action="store_true", help="skip the robustness legs (inversions + shuffled contig order; repeat family)")
     ap.add_argument("--cpu-sample-mb", type=float, default=20.0, help="bases per thread of the CPU baseline leg (about 12 s of CPU work)")
     ap.add_argument("--emulate-rank", type=str, default="", metavar="R/N",
                     help="one process plays rank R of an N-rank contig-sharded run (no collective): the N x longer "
@@ -443,11 +718,17 @@ def main():
                          "set-up on a one-GPU box; the reported value is this rank's alone")
     args = ap.parse_args()
 
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback)")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` on its own: become N ranks (one process per GPU) instead of silently measuring one
+        sys.exit(spawn_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        sys.exit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback)")
+    if world != max(1, args.gpus) and rank == 0:
+        print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: the line reports the {world} rank(s) that actually run",
+              file=sys.stderr, flush=True)
     # (test knobs, for checking the N > 1 code path on a ONE-GPU box: all ranks on device 0 and a gloo process group —
     # RCCL refuses two ranks on one device.  The numbers of such a run mean nothing.)
     one_device = os.environ.get("PG_BENCH_ONE_DEVICE", "") not in ("", "0")
@@ -457,6 +738,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
+    ranks_observed = 1
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -464,6 +746,16 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+        # the rank count the collective library actually sees (one all-reduce of ones), and that no two ranks share a GPU
+        ones = torch.ones(1, device=dev if backend == "nccl" else "cpu", dtype=torch.int64)
+        dist.all_reduce(ones)
+        ranks_observed = int(ones.item())
+        gpus = [None] * world
+        dist.all_gather_object(gpus, (os.uname().nodename, str(getattr(torch.cuda.get_device_properties(local), "uuid", local))))
+        if ranks_observed != world:
+            sys.exit(f"bench.py: {ranks_observed} ranks answered the all-reduce, WORLD_SIZE says {world}")
+        if len(set(gpus)) != world and not one_device:
+            sys.exit(f"bench.py: {world} ranks on {len(set(gpus))} distinct GPU(s) — one process per GPU is the contract")
 
     from panagram_amd import engine
     ctx = engine.Context(local)
@@ -493,8 +785,12 @@ def main():
 
     # ---- k-mer set construction on the GPU (replaces kmc + kmc_tools; timed separately) ----
     keep_ascii = rank == 0 and world == 1 and not args.no_cpu_baseline
-    pg = Pangenome(ctx, dev, G, contig_lens, args.d, args.seed, k, groups=groups, my_group=my_group, keep_ascii=keep_ascii,
-                   minimizer=args.minimizer, rehash_kpb=None if (args.no_rehash or groups > 1 or args.keys_per_bucket <= 0) else args.keys_per_bucket)
+    strong = args.scaling == "strong" and (world > 1 or bool(args.emulate_rank))
+    if strong:
+        pg = Pangenome(ctx, dev, G, contig_lens, args.d, args.seed, k, minimizer=args.minimizer, pieces_of=(my_group, groups))
+    else:
+        pg = Pangenome(ctx, dev, G, contig_lens, args.d, args.seed, k, groups=groups, my_group=my_group, keep_ascii=keep_ascii,
+                       minimizer=args.minimizer, rehash_kpb=None if (args.no_rehash or groups > 1 or args.keys_per_bucket <= 0) else args.keys_per_bucket)
     st = pg.stats
     pg_rehashed = not (args.no_rehash or groups > 1 or args.keys_per_bucket <= 0)
     pos_per_step = sum(pg.pos_per_genome)
@@ -524,10 +820,17 @@ def main():
 
     # ---- invariants at full size (cheap): anchor g contains all of its own k-mers ----
     if not args.no_colsums:
-        cs = results[0].colsums() if args.per_genome_launches else results[0].contig_colsums(0, C).sum(axis=0)
+        nc0 = len(pg.pieces[0]) if pg.pieces is not None else C
+        cs = results[0].colsums() if args.per_genome_launches else results[0].contig_colsums(0, nc0).sum(axis=0)
         assert int(cs[0]) == pg.pos_per_genome[0], "anchor genome 0 must contain every one of its k-mers"
 
-    value = world * pos_per_step * args.steps / elapsed
+    if strong and world > 1:  # every rank a different share of ONE pangenome: the units all ranks processed
+        tot = torch.tensor([pos_per_step], device=dev if backend == "nccl" else "cpu", dtype=torch.int64)
+        dist.all_reduce(tot)
+        assert int(tot.item()) == pg.total_positions, "the ranks' pieces must cover the pangenome exactly once"
+        value = pg.total_positions * args.steps / elapsed
+    else:
+        value = world * pos_per_step * args.steps / elapsed
     counters = load_counters(pos_per_launch, k, G) if not args.per_genome_launches else None
     if counters is not None and groups > 1:
         # a rank of a multi-GPU run launches the profiled kernel over as many positions, against an N x larger table:
@@ -538,12 +841,19 @@ def main():
                        (64, 200, 31): "BASELINE.json configs[3] at full size, all 64 genomes anchored",
                        (8, 3000, 21): "the shape of BASELINE.json configs[4] on ONE GPU, at a divergence whose table fits"
                        }.get(shape, "not a BASELINE.json config")
-    if groups > 1 and world == 1:
+    if groups > 1 and world == 1 and not strong:
         tbl_txt = ("the table of the k-mers of this rank's contigs (the rest of the pangenome only sets bits in it)"
                    if pg.filtered else "table of all of it")
         workload = (f"EMULATED rank {my_group} of {groups}: {G} synthetic {args.genome_mb * groups:g} Mb genomes, {tbl_txt}, "
                     f"this rank's {C} contigs of every genome anchored")
         parallelism = f"one GPU playing rank {my_group} of a contig-sharded x{groups} run"
+    elif strong:
+        workload = (("" if world > 1 else f"EMULATED rank {my_group} of {groups} (this rank's value alone): ") + f"{G} synthetic {args.genome_mb:g} Mb genomes ({C} contigs each), k={k}, d={args.d} ({baseline_config}): ONE "
+                    f"pangenome whatever the GPU count, cut into {pg.plan_class_pieces} pieces of homology classes dealt to "
+                    f"{groups} rank(s) (distributed.plan_class_pieces, what Index.run() does); a rank anchors its pieces of "
+                    f"every genome in one co-scheduled launch against a table built from those pieces")
+        parallelism = (f"contig-sharded x{groups}, strong scaling: planned positions per rank {pg.plan_loads}, "
+                       "no data-path collective")
     elif world == 1:
         workload = (f"{G} synthetic {args.genome_mb:g} Mb genomes ({C} contigs each), k={k}, d={args.d}, all {G} genomes "
                     f"anchored per step, table resident in one GPU's HBM ({baseline_config})")
@@ -564,10 +874,11 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if strong else "weak",
         "vs_baseline": None,
         "dtype": "u64",
         "data": "synthetic",
+        "ranks_observed": ranks_observed,
         "config": {
             "workload": workload,
             "positions_per_step_per_gpu": pos_per_step,
@@ -605,7 +916,8 @@ def main():
             s2 = pgl["k_probe_ms_per_launch"] / 1e3
             pgl["hbm_counter_frac"] = c2["hbm_bytes_per_launch"] / s2 / HBM_PEAK
             if c2.get("SQ_INSTS_VALU"):
-                pgl["valu_frac"] = c2["SQ_INSTS_VALU"] * VALU_CYCLES / (SIMDS * CLOCK_HZ * s2)
+                pgl["valu_issue_frac_4cycle"] = c2["SQ_INSTS_VALU"] * VALU_CYCLES / (SIMDS * CLOCK_HZ * s2)
+                pgl["valu_issue_frac_2cycle"] = c2["SQ_INSTS_VALU"] * 2.0 / (SIMDS * CLOCK_HZ * s2)
             pgl["traffic"] = c2["hbm_bytes_per_launch"]
         out["config"]["per_genome_launches"] = pgl
         out["config"]["per_genome_launches_value"] = pgl["value"]
@@ -668,6 +980,17 @@ def main():
             out["config"]["genome_sharded_leg"] = sharded_leg(ctx, dev, args, rank, world, dist, 3, 1, args.blocks)
         except Exception as e:  # a failed extra leg must not take the measured line with it
             out["config"]["genome_sharded_leg"] = {"error": f"{type(e).__name__}: {e}"}
+    if world == 1 and default_shape and not args.no_e2e:
+        try:
+            out["e2e"] = e2e_leg(dev, args, G, contig_lens, k)
+        except Exception as e:
+            out["e2e"] = {"error": f"{type(e).__name__}: {e}"}
+    if world == 1 and default_shape and not args.no_robustness:
+        try:
+            out["robustness"] = robustness_legs(ctx, dev, args, k)
+            out["robustness"]["per_genome_launches_value_on_the_headline_workload"] = out["config"].get("per_genome_launches_value")
+        except Exception as e:
+            out["robustness"] = {"error": f"{type(e).__name__}: {e}"}
     if world == 1 and default_shape and not args.no_other_shapes:
         try:
             out["config"]["other_shapes"] = [north_star_leg(ctx, dev, args)]

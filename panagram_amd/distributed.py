@@ -369,18 +369,34 @@ def run_index_sharded(index, rank: int, world: int, barrier: Optional[Callable[[
         pdir = _parts_dir(g)
         if not os.path.isdir(pdir) and ps:
             return os.path.exists(g.chrs_fname)  # assembled (and cleaned up) by another rank
-        metas = []
-        for p in ps:
-            try:
-                z = np.load(base(p) + ".npz")
-                if str(z["sig"]) != sig:
-                    return False
-                metas.append(z)
-            except (FileNotFoundError, OSError, KeyError, ValueError):
-                return False
-        os.makedirs(pdir, exist_ok=True)
-        if not _claim(os.path.join(pdir, "assemble.lock")):
+        def load_markers():
+            out = []
+            for p in ps:
+                try:
+                    with np.load(base(p) + ".npz") as z:
+                        if str(z["sig"]) != sig:
+                            return None
+                        out.append({f: z[f] for f in z.files})
+                except (FileNotFoundError, OSError, KeyError, ValueError):
+                    return None
+            return out
+
+        if load_markers() is None:
             return False
+        os.makedirs(pdir, exist_ok=True)
+        lock = os.path.join(pdir, "assemble.lock")
+        if not _claim(lock):
+            return False
+        # (whoever assembled meanwhile removed the markers BEFORE giving up its claim: seeing them all under our own
+        # claim means the genome is ours to assemble)
+        metas = load_markers()
+        if metas is None:
+            os.remove(lock)
+            try:
+                os.rmdir(pdir)
+            except OSError:
+                pass
+            return os.path.exists(g.chrs_fname)
         g.ensure_log()
         os.makedirs(g.prefix, exist_ok=True)
         names = list(seqs[name].names)
@@ -412,7 +428,12 @@ def run_index_sharded(index, rank: int, world: int, barrier: Optional[Callable[[
                 gene_hists[chrom] = (len(grp), np.asarray(gene_sum.get(chrom, np.zeros(index.ngenomes + 1, np.int64)), np.int64))
         g._write_tables(names, bins_infos, cs, gene_hists)
         g.close_log()
-        shutil.rmtree(pdir)
+        for p in ps:  # markers first: from here on nobody takes the genome for complete-and-unassembled
+            os.remove(base(p) + ".npz")
+        for f in os.listdir(pdir):
+            if f != "assemble.lock":
+                os.remove(os.path.join(pdir, f))
+        shutil.rmtree(pdir)  # (the claim goes last)
         return True
 
     todo = [n for n in anchors]

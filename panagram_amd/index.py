@@ -251,6 +251,7 @@ class Index:
         self._ctx = None
         self._table = None
         self._table_scope = "all"
+        self.timings: Dict[str, float] = {}  # seconds spent in load_inputs / build_table (host wall clock), for reports
         self._seqsets: Dict[str, engine.SeqSet] = {}
 
     def _reopen_prepared(self):
@@ -418,7 +419,9 @@ class Index:
         the whole pangenome, or one block of genomes — can be estimated before a table is allocated."""
         if getattr(self, "_inputs", None) is not None:
             return self._inputs
+        import time
         from concurrent.futures import ThreadPoolExecutor
+        t_start = time.perf_counter()
         inputs = []
         sketch = engine.KmerSketch(self.context, self.k)
         # the FASTA files are read a few ahead by host threads while the GPU parses and sketches
@@ -450,6 +453,7 @@ class Index:
         sketch.close()
         self.context.trim()  # (the FASTA text buffer the parser kept for the next file)
         self._inputs = inputs
+        self.timings["load_inputs_s"] = self.timings.get("load_inputs_s", 0.0) + time.perf_counter() - t_start
         return inputs
 
     @staticmethod
@@ -493,6 +497,8 @@ class Index:
             return self._table
         have = all(os.path.exists(p + ".kmc_pre") and os.path.exists(p + ".kmc_suf") for p in self.bitvec_prefixes)
         scope = "all"
+        import time
+        t_start, t_inputs_before = time.perf_counter(), self.timings.get("load_inputs_s", 0.0)
         if self.kmc.use_existing and have:
             tbl = engine.PanTable(self.context, self.k, self.ngenomes)
             for i, p in enumerate(self.bitvec_prefixes):
@@ -553,6 +559,9 @@ class Index:
                     keys, vals = tbl.export(i)
                     write_kmc1(p, keys, vals, self.k)
                 self.write_opdefs()
+        self.context.synchronize()
+        # (the inserts alone: reading, parsing and sketching the inputs is load_inputs_s, also when it ran in here)
+        self.timings["table_build_s"] = time.perf_counter() - t_start - (self.timings.get("load_inputs_s", 0.0) - t_inputs_before)
         self._table, self._table_scope = tbl, scope
         return tbl
 

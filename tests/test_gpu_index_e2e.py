@@ -486,8 +486,6 @@ def test_index_run_on_several_ranks_writes_the_same_tree(name, world, partition,
         if partition == "genomes":
             for nm in mine:  # a rank leaves exactly its genomes' directories complete
                 assert (many / "anchor" / nm / "total_paircounts.csv").exists()
-        elif rank < world - 1:  # nothing is complete before the last rank has anchored its pieces
-            assert not any((many / "anchor" / nm / "chrs.tsv").exists() for nm in anchors)
     assert sorted(seen) == sorted(anchors) and len(seen) == len(anchors)
     if partition == "genomes":
         for dirpath, _, files in os.walk(one):
@@ -764,3 +762,37 @@ def test_contig_sharded_fragments_on_the_gpu(name, tmp_path):
         nk = len(seq) - k + 1
         assert np.array_equal(ridx.query_bitmap(f"g{g}", nm, 5, nk - 3).to_numpy(), bits[off + 5: off + nk - 3])
         off += nk
+
+
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_gpus_2_spawns_two_ranks_with_disjoint_work(scaling):
+    """`python bench.py --gpus 2` with WORLD_SIZE unset must become two ranks by itself (torch.distributed.run) and say
+    so on its line: n_gpus == 2 == ranks_observed.  On a one-GPU box both ranks share the device and talk over gloo
+    (PG_BENCH_ONE_DEVICE / PG_BENCH_BACKEND: the numbers mean nothing, the code path is the 2-GPU one).  Weak: each rank
+    its own contigs of a 2x longer pangenome.  Strong: ONE pangenome cut into pieces of homology classes whose planned
+    positions add up to it exactly — the ranks' shares are disjoint and cover it."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PG_BENCH_ONE_DEVICE="1", PG_BENCH_BACKEND="gloo")
+    for v in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(v, None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--genomes", "4",
+           "--genome-mb", "10", "--scaling", scaling, "--no-sharded-leg", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_observed"] == 2 and d["scaling"] == scaling
+    k, L, G = 21, 10_000_000, 4
+    per_contig = L // 5 - k + 1
+    if scaling == "weak":
+        assert d["config"]["positions_per_step_per_gpu"] == G * 5 * per_contig
+        assert abs(d["value"] - 2 * G * 5 * per_contig * d["steps"] / (d["ms_per_step"] * 1e-3 * d["steps"])) < 1e-3 * d["value"]
+    else:
+        total = G * 5 * per_contig
+        assert abs(d["value"] - total / (d["ms_per_step"] * 1e-3)) < 1e-3 * d["value"]
+        loads = [int(x) for x in d["config"]["parallelism"].split("[")[1].split("]")[0].split(",")]
+        assert len(loads) == 2 and sum(loads) == total and max(loads) <= 1.1 * total / 2
