@@ -775,7 +775,7 @@ def test_bench_gpus_2_spawns_two_ranks_with_disjoint_work(scaling):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, PG_BENCH_ONE_DEVICE="1", PG_BENCH_BACKEND="gloo")
+    env = dict(os.environ, PG_BENCH_ONE_DEVICE="1", PG_BENCH_BACKEND="gloo", PG_MIN_PIECE="100000")  # (2-Mb contigs are cut)
     for v in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(v, None)
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--genomes", "4",
