@@ -1226,12 +1226,36 @@ __device__ __forceinline__ void flush_hist(uint32_t N, uint32_t *hist, uint32_t 
 // MODE 0: one-byte rows (N <= 8), 1: rows of 2..8 bytes (N <= 64); wider rows go through
 // k_epilogue_chunks below.  One instantiation per mode so that each carries only its own accumulators
 // in registers.
+// The tiles a statistics workgroup takes: a contiguous range, cut in units of `gt` tiles (the group paths' granule).
+// ranges == NULL: the launch covers tiles [0, ntiles), split evenly over the grid.  Otherwise (a CHUNK of a run whose
+// probe launches are interleaved with their statistics passes, pg_api.hip: anchor_run): the launch covers the tile ranges
+// ranges[0 .. gridDim.x / wpr) — what one slice of the co-schedule touches of every genome — with wpr workgroups each.
+struct EpiRange {
+    uint32_t begin, end;
+};
+__device__ __forceinline__ EpiRange epi_range(uint32_t gt, uint32_t ntiles, const uint2 *ranges, uint32_t wpr) {
+    uint32_t lo = 0, hi = ntiles, j = blockIdx.x, n = gridDim.x;
+    if (ranges) {
+        const uint2 rg = ranges[blockIdx.x / wpr];
+        lo = rg.x;
+        hi = rg.y;
+        j = blockIdx.x % wpr;
+        n = wpr;
+    }
+    const uint32_t ngroups = (hi - lo + gt - 1) / gt;
+    EpiRange e;
+    e.begin = lo + gt * (uint32_t)((uint64_t)ngroups * j / n);
+    e.end = min(hi, lo + gt * (uint32_t)((uint64_t)ngroups * (j + 1) / n));
+    return e;
+}
+
 template <int MODE, int NBT>  // NBT = bytes per row (1..8): one instantiation, and one register allocation, per width
 __global__ __launch_bounds__(EPI_THREADS) void k_epilogue(uint32_t N, const AnchorDesc *__restrict__ ad,
                                                           const uint32_t *__restrict__ tile_contig, uint32_t ntiles,
                                                           const uint8_t *__restrict__ out1, uint8_t *__restrict__ out100,
                                                           uint32_t *__restrict__ bins,
-                                                          unsigned long long *__restrict__ colsums, uint32_t flags) {
+                                                          unsigned long long *__restrict__ colsums, uint32_t flags,
+                                                          const uint2 *__restrict__ ranges, uint32_t wpr) {
     extern __shared__ uint4 smem[];
     constexpr int PT = 4;  // rows per thread and tile: EPI_THREADS = PROBE_TILE / 4 threads per workgroup
     constexpr bool WIDE = MODE == 1;
@@ -1249,9 +1273,8 @@ __global__ __launch_bounds__(EPI_THREADS) void k_epilogue(uint32_t N, const Anch
     const bool want100 = (flags & 2u) == 0;  // bit 1: the low-resolution rows are taken by k_lowres (step != 100)
     // contiguous tile ranges, cut in units of the group paths' 4 tiles (16 rows per thread; one-byte rows: 8 tiles, 32 rows)
     constexpr uint32_t GT = MODE == 0 ? 8u : 4u;
-    const uint32_t ngroups = (ntiles + GT - 1) / GT;
-    const uint32_t t_begin = GT * (uint32_t)((uint64_t)ngroups * blockIdx.x / gridDim.x);
-    const uint32_t t_end = min(ntiles, GT * (uint32_t)((uint64_t)ngroups * (blockIdx.x + 1) / gridDim.x));
+    const EpiRange er = epi_range(GT, ntiles, ranges, wpr);
+    const uint32_t t_begin = er.begin, t_end = er.end;
     uint64_t cur_row0 = ~0ull;  // bins row the accumulators currently stand for
     uint32_t cur_c = ~0u;
     AnchorDesc a;
@@ -1839,7 +1862,8 @@ __global__ __launch_bounds__(EPI_THREADS) void k_epilogue_chunks(uint32_t N, con
                                                                  const uint32_t *__restrict__ tile_contig, uint32_t ntiles,
                                                                  const uint8_t *__restrict__ out1, uint8_t *__restrict__ out100,
                                                                  uint32_t *__restrict__ bins,
-                                                                 unsigned long long *__restrict__ colsums, uint32_t flags) {
+                                                                 unsigned long long *__restrict__ colsums, uint32_t flags,
+                                                                 const uint2 *__restrict__ ranges, uint32_t wpr) {
     extern __shared__ uint4 smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t nbytes = (N + 7) / 8, C = C_T ? (uint32_t)C_T : (nbytes + 15) / 16;
@@ -1866,9 +1890,8 @@ __global__ __launch_bounds__(EPI_THREADS) void k_epilogue_chunks(uint32_t N, con
     __syncthreads();
     const bool want_cs = (flags & 1u) != 0;
     const bool want100 = (flags & 2u) == 0;
-    const uint32_t ngroups = (ntiles + 3) / 4;
-    const uint32_t t_begin = 4u * (uint32_t)((uint64_t)ngroups * blockIdx.x / gridDim.x);
-    const uint32_t t_end = min(ntiles, 4u * (uint32_t)((uint64_t)ngroups * (blockIdx.x + 1) / gridDim.x));
+    const EpiRange er = epi_range(4u, ntiles, ranges, wpr);
+    const uint32_t t_begin = er.begin, t_end = er.end;
     uint64_t cur_row0 = ~0ull;
     uint32_t cur_c = ~0u;
     AnchorDesc a;
@@ -2390,8 +2413,11 @@ hipError_t launch_anchor(hipStream_t s, const TableDesc &T, const uint64_t *seqw
 
 hipError_t launch_rows_epilogue(hipStream_t st, uint32_t ngenomes, const AnchorDesc *ad, const uint32_t *tile_contig,
                                 uint32_t ntiles, const uint8_t *out1, uint8_t *out100, uint32_t *bins,
-                                unsigned long long *colsums, uint32_t flags) {
-    if (ntiles == 0) return hipSuccess;
+                                unsigned long long *colsums, uint32_t flags, const uint2 *d_ranges, uint32_t nranges,
+                                uint32_t range_tiles) {
+    // d_ranges: the launch covers these nranges tile ranges (range_tiles tiles in all) instead of [0, ntiles)
+    if (ntiles == 0 || (d_ranges && (nranges == 0 || range_tiles == 0))) return hipSuccess;
+    const uint32_t work_tiles = d_ranges ? range_tiles : ntiles;
     const uint32_t maxb = epi_maxb_for(ngenomes);
     flags = (flags & 0xFFFF00FFu) | (maxb << 8);
     size_t lds = (((maxb * (ngenomes + 1) + 3) & ~3u) + ((ngenomes + 3) & ~3u)) * 4 + 16;
@@ -2401,9 +2427,15 @@ hipError_t launch_rows_epilogue(hipStream_t st, uint32_t ngenomes, const AnchorD
     // long ranges (PG_EPI_MIN_TILES tiles) keep the pass light beside a concurrent k_probe; but never
     // fewer than ~1024 workgroups (4 per CU) as long as each still gets 16 tiles, or small inputs
     // turn latency-bound
-    uint32_t grid = (ntiles + PG_EPI_MIN_TILES - 1) / PG_EPI_MIN_TILES;
-    grid = std::max(grid, std::min(1024u, ntiles / 16u));
+    uint32_t grid = (work_tiles + PG_EPI_MIN_TILES - 1) / PG_EPI_MIN_TILES;
+    grid = std::max(grid, std::min(1024u, work_tiles / 16u));
     grid = grid < 1 ? 1 : (grid > maxg ? maxg : grid);
+    uint32_t wpr = 0;
+    auto per_range = [&]() {  // (ranges: the same number of workgroups for each, the grid a multiple of the range count)
+        if (!d_ranges) return;
+        wpr = std::max(1u, grid / nranges);
+        grid = wpr * nranges;
+    };
     // persistent workgroups: no more of them than the device holds at once (a second, partly filled round of
     // workgroups would leave CUs idle at the end: 8192 waves over 5120 slots cost the one-byte kernel 20 %)
     auto fit = [&](const void *kern, size_t lds_bytes) {
@@ -2435,8 +2467,9 @@ hipError_t launch_rows_epilogue(hipStream_t st, uint32_t ngenomes, const AnchorD
             default: break;
         }
         fit(reinterpret_cast<const void *>(kern), lds);
+        per_range();
         hipLaunchKernelGGL(kern, dim3(grid), dim3(EPI_THREADS), lds, st, ngenomes, ad, tile_contig, ntiles, out1, out100, bins,
-                           colsums, flags);
+                           colsums, flags, d_ranges, wpr);
     }
     else {  // chunk-parallel: one launch, every row read once
         const uint32_t C = (nbytes + 15) / 16;
@@ -2452,8 +2485,9 @@ hipError_t launch_rows_epilogue(hipStream_t st, uint32_t ngenomes, const AnchorD
             default: break;
         }
         fit(reinterpret_cast<const void *>(kern), lds_c);
+        per_range();
         hipLaunchKernelGGL(kern, dim3(grid), dim3(EPI_THREADS), lds_c, st, ngenomes, ad, tile_contig, ntiles, out1, out100, bins,
-                           colsums, flags);
+                           colsums, flags, d_ranges, wpr);
     }
     return hipGetLastError();
 }

@@ -167,6 +167,16 @@ struct pg_result {
         bool probe, epi;  // which of the two intervals (e[0]..e[1] probe, e[2]..e[3] statistics) were recorded
     };
     std::vector<EvSet> ev_hist, ev_free;
+    // A whole run goes out as a few CHUNKS of its launch order (slices of the co-schedule), the statistics pass of chunk c
+    // on the side stream beside the probe of chunk c+1: the pass reads rows at HBM speed while the probe is busy
+    // issuing instructions (run_chunks).  A chunk: schedule slice [s0, s1) and the tile ranges it touches.
+    struct Chunk {
+        uint32_t s0, s1, r0, nr, tiles;
+    };
+    std::vector<Chunk> chunks;
+    uint2 *d_ranges = nullptr;
+    bool chunks_ready = false;
+    std::vector<hipEvent_t> chunk_ev;
     size_t hist_skip = 0;  // leading sets of ev_hist from before the last pg_result_timing_reset
     double probe_ms_sum = 0, epi_ms_sum = 0;
     uint32_t probe_runs = 0, epi_runs = 0;
@@ -1810,6 +1820,8 @@ extern "C" int pg_result_destroy(pg_result *r) {
     hipFree(r->d_bins);
     hipFree(r->d_colsums);
     if (r->d_sched) hipFree(r->d_sched);
+    if (r->d_ranges) hipFree(r->d_ranges);
+    for (auto e : r->chunk_ev) hipEventDestroy(e);
     for (auto *v : {&r->ev_hist, &r->ev_free})
         for (auto &s : *v)
             for (auto &e : s.e)
@@ -1833,16 +1845,79 @@ extern "C" int pg_result_destroy(pg_result *r) {
 // tiles, every genome traversed at the same relative pace) lets the later genomes find the lines in
 // L2 / Infinity Cache.  Only the launch order changes — results are identical for any schedule.
 // ---------------------------------------------------------------------------
+// The chunks of a whole run (pg_result::Chunk): the launch order — `sched`, or tile order when NULL — is cut into
+// slices of at least 32768 tiles (four rounds of waves on the device: shorter probe launches
+// lose more in their tails than the overlap wins); per slice the tiles it touches, as sorted disjoint ranges — a slice
+// of the co-schedule covers one stretch of every genome.  A slice that touches more than 512 ranges (thousands of short
+// contigs) is not worth a launch of its own: the run then stays one probe launch and one statistics pass.
+static int build_chunks(pg_result *r, const uint32_t *sched) {
+    r->chunks.clear();
+    r->chunks_ready = true;
+    if (r->d_ranges) {
+        hipFree(r->d_ranges);
+        r->d_ranges = nullptr;
+    }
+    // Default: only runs of at least 4 M tiles with 8-byte rows go out in (16) chunks — measured
+    // (profiles/r3_ab_chunked_overlap.txt): 64 x 200 Mb, 8-byte rows 105.4 -> 100.8 ms per step; everywhere else the probe
+    // slows down by about what the pass takes when the two run side by side (8 x 100 Mb 4.86 -> 5.2 ms at any chunk
+    // count, 64 x 20 Mb 8.93 -> 8.93), i.e. the statistics pass cannot be hidden behind the probe.  PG_RUN_CHUNKS pins
+    // the count (1: never).
+    const char *env = getenv("PG_RUN_CHUNKS");
+    const uint32_t nbytes = (r->N + 7) / 8;
+    uint32_t K = env ? (uint32_t)atoi(env) : ((nbytes == 8 && r->ntiles >= (4u << 20)) ? 16u : 1u);
+    K = std::min(K, r->ntiles / 32768u);
+    if (K < 2) return PG_OK;
+    std::vector<uint2> ranges;
+    for (uint32_t c = 0; c < K; ++c) {
+        pg_result::Chunk ch;
+        ch.s0 = (uint32_t)((uint64_t)r->ntiles * c / K);
+        ch.s1 = (uint32_t)((uint64_t)r->ntiles * (c + 1) / K);
+        ch.r0 = (uint32_t)ranges.size();
+        ch.tiles = ch.s1 - ch.s0;
+        if (!sched) {
+            ranges.push_back(make_uint2(ch.s0, ch.s1));
+        } else {
+            std::vector<uint2> runs;  // maximal runs of consecutive tiles in the slice (a piece of a genome each)
+            for (uint32_t i = ch.s0; i < ch.s1; ++i) {
+                if (!runs.empty() && runs.back().y == sched[i]) ++runs.back().y;
+                else runs.push_back(make_uint2(sched[i], sched[i] + 1));
+            }
+            std::sort(runs.begin(), runs.end(), [](const uint2 &a, const uint2 &b) { return a.x < b.x; });
+            for (const uint2 &u : runs) {
+                if (ranges.size() > ch.r0 && ranges.back().y == u.x) ranges.back().y = u.y;
+                else ranges.push_back(u);
+            }
+        }
+        ch.nr = (uint32_t)ranges.size() - ch.r0;
+        if (ch.nr > 512) {
+            r->chunks.clear();
+            return PG_OK;
+        }
+        r->chunks.push_back(ch);
+    }
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&r->d_ranges), ranges.size() * sizeof(uint2)));
+    HIP_TRY(hipMemcpy(r->d_ranges, ranges.data(), ranges.size() * sizeof(uint2), hipMemcpyHostToDevice));
+    while (r->chunk_ev.size() < r->chunks.size()) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        r->chunk_ev.push_back(e);
+    }
+    return PG_OK;
+}
+
 static int coschedule(pg_result *r, const uint32_t *contig_group, uint32_t piece_tiles, const uint32_t *range_first,
                       uint32_t nranges, const uint32_t *contig_class = nullptr) {
     if (int e = use_device(r->ctx)) return e;
     hipStream_t st = r->ctx->stream;
     HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipStreamSynchronize(r->ctx->aux_stream));
     if (r->d_sched) {
         hipFree(r->d_sched);
         r->d_sched = nullptr;
     }
     r->sched_bounds.clear();
+    r->chunks.clear();
+    r->chunks_ready = false;  // (launch order again until a schedule is set below: chunks are cut at the next run)
     if (!contig_group || r->ntiles == 0) return PG_OK;  // NULL: back to launch order
     if (piece_tiles == 0) piece_tiles = 64;
     const size_t nc = r->ad.size();
@@ -1907,6 +1982,7 @@ static int coschedule(pg_result *r, const uint32_t *contig_group, uint32_t piece
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&r->d_sched), (size_t)r->ntiles * 4));
     HIP_TRY(hipMemcpyAsync(r->d_sched, sched.data(), (size_t)r->ntiles * 4, hipMemcpyHostToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));
+    if (!(r->flags & PG_ANCHOR_ROWS_ONLY)) return build_chunks(r, sched.data());
     return PG_OK;
 }
 
@@ -2015,6 +2091,39 @@ static bool sched_covers(const pg_result *r, uint32_t t0, uint32_t nt) {
     return std::binary_search(b.begin(), b.end(), t0) && std::binary_search(b.begin(), b.end(), t0 + nt);
 }
 
+// A whole run in chunks: probe(chunk c) on the main stream, the statistics of chunk c on the side stream behind it —
+// i.e. beside probe(chunk c + 1).  The two kernels want different things of the machine (k_probe: instruction issue and
+// random L2 lines; the statistics pass: streaming HBM reads), and the pass's rows are the ones just written.  Timing:
+// e[0]..e[1] spans the probe launches (back to back on their stream: the sum of their durations), e[2]..e[3] the
+// statistics side from its first kernel's start to its last one's end.
+static int run_chunks(pg_result *r, const TableDesc &T) {
+    hipStream_t st = r->ctx->stream, aux = r->ctx->aux_stream;
+    const uint32_t N = r->N;
+    const uint32_t kflags = (r->flags & PG_ANCHOR_COLSUMS) | (r->lowres_step == 100 ? 0u : 2u);
+    HIP_TRY(hipEventRecord(r->ev[0], st));
+    for (size_t c = 0; c < r->chunks.size(); ++c) {
+        const pg_result::Chunk &ch = r->chunks[c];
+        HIP_TRY(launch_anchor(st, T, r->seqs->d_seqw, r->seqs->d_nmw, r->seqs->d_has_n, r->seqs->d_desc, r->d_ad, r->d_tile_contig,
+                              r->d_sched, ch.s0, ch.s1 - ch.s0, r->d_out1, r->out1_bytes, 0));
+        HIP_TRY(hipEventRecord(r->chunk_ev[c], st));
+        HIP_TRY(hipStreamWaitEvent(aux, r->chunk_ev[c], 0));
+        if (c == 0) {
+            HIP_TRY(hipEventRecord(r->ev[2], aux));
+            HIP_TRY(hipMemsetAsync(r->d_bins, 0, std::max<uint64_t>(1, r->total_bins) * (N + 1) * 4, aux));
+            HIP_TRY(hipMemsetAsync(r->d_colsums, 0, std::max<size_t>(1, r->ad.size()) * N * 8, aux));
+        }
+        HIP_TRY(launch_rows_epilogue(aux, N, r->d_ad, r->d_tile_contig, r->ntiles, r->d_out1, r->d_out100, r->d_bins, r->d_colsums,
+                                     kflags, r->d_ranges + ch.r0, ch.nr, ch.tiles));
+    }
+    HIP_TRY(hipEventRecord(r->ev[1], st));
+    if (r->lowres_step != 100)
+        HIP_TRY(launch_lowres(aux, N, r->d_ad, r->d_tile_contig, r->ntiles, r->d_out1, r->d_out100, r->lowres_step));
+    HIP_TRY(hipEventRecord(r->ev[3], aux));
+    r->ev_ok = r->ev_epi = true;
+    r->ev_hist.back().epi = true;
+    return PG_OK;
+}
+
 static int anchor_run(pg_result *r, uint32_t tile_base, uint32_t ntiles, bool whole, uint32_t columns_width = 0,
                       void *d_columns = nullptr) {
     pg_table *t = r->tbl;
@@ -2024,6 +2133,11 @@ static int anchor_run(pg_result *r, uint32_t tile_base, uint32_t ntiles, bool wh
     if (int e = join_result(r)) return e;  // a previous run's statistics still read the rows we overwrite
     if (int e = next_events(r, true)) return e;
     TableDesc T = make_desc(t);
+    if (whole && !columns_width && !(r->flags & PG_ANCHOR_ROWS_ONLY)) {
+        if (!r->chunks_ready)
+            if (int e = build_chunks(r, nullptr)) return e;
+        if (r->chunks.size() > 1) return run_chunks(r, T);
+    }
     HIP_TRY(hipEventRecord(r->ev[0], st));
     HIP_TRY(launch_anchor(st, T, r->seqs->d_seqw, r->seqs->d_nmw, r->seqs->d_has_n, r->seqs->d_desc, r->d_ad,
                           r->d_tile_contig, sched_covers(r, tile_base, ntiles) ? r->d_sched : nullptr, tile_base, ntiles,

@@ -123,6 +123,7 @@ hipError_t launch_window_stats(hipStream_t st, uint32_t ngenomes, const uint8_t 
                                unsigned long long *cs);
 hipError_t launch_rows_epilogue(hipStream_t st, uint32_t ngenomes, const AnchorDesc *ad, const uint32_t *tile_contig,
                                 uint32_t ntiles, const uint8_t *out1, uint8_t *out100, uint32_t *bins,
-                                unsigned long long *colsums, uint32_t flags);
+                                unsigned long long *colsums, uint32_t flags, const uint2 *d_ranges = nullptr,
+                                uint32_t nranges = 0, uint32_t range_tiles = 0);
 
 }  // namespace pg
