@@ -672,12 +672,26 @@ class ShardedAnchoring:
         self.geometry = geometry or {}
         self.dist = None
         self.collective = self.world > 1 or always_gather
+        # how the blocks' bit columns travel: "rccl" — all_gather_into_tensor of device buffers on the default process
+        # group (RCCL over xGMI) — or "host" (SURVEY §8e's fallback without a GPU collective): every rank copies its
+        # columns to pinned host memory, the hosts all-gather them over a gloo group, the gathered blocks go back to
+        # the GPU and are merged as usual.  1 bit per genome and position: the detour costs PCIe time, not correctness.
+        self.exchange = os.environ.get("PG_SHARD_EXCHANGE", "rccl").lower()
+        if self.exchange not in ("rccl", "host"):
+            raise ValueError(f"PG_SHARD_EXCHANGE must be 'rccl' or 'host', got {self.exchange!r}")
+        self.host_group = None
         if self.collective:
             import torch.distributed as dist
             if not dist.is_initialized():
-                raise RuntimeError("genome-sharded mode on several ranks needs torch.distributed initialised "
-                                   "(python -m torch.distributed.run ... -m panagram_amd index ...)")
+                raise RuntimeError("genome-sharded mode on several ranks needs torch.distributed initialised, e.g.\n"
+                                   "  python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 "
+                                   "--master-port 29500 -m panagram_amd index samples.tsv -o out")
             self.dist = dist
+            if dist.get_world_size(group) != self.world or dist.get_rank(group) != self.rank:
+                raise RuntimeError(f"process group says rank {dist.get_rank(group)} of {dist.get_world_size(group)}, the index "
+                                   f"was opened as rank {self.rank} of {self.world} (RANK / WORLD_SIZE)")
+            if self.exchange == "host" and dist.get_backend(group) != "gloo":
+                self.host_group = dist.new_group(backend="gloo")  # (collective call: every rank is here)
         tile = engine.tile_positions()
         names = list(seqs)
         chunks = {a: contig_chunks(seqs[a].lens, k) for a in names}
@@ -711,6 +725,11 @@ class ShardedAnchoring:
             self.pipe = _Pipe(ctx, dev)
             for b_ in self.send:
                 b_._stream = getattr(self.pipe, "main", None)
+            self._host = None
+            if self.exchange == "host" and dev.type == "cuda":
+                self._host = (torch.empty(max(biggest, 8), dtype=torch.uint8).pin_memory(),
+                              torch.empty(max(biggest, 8) * self.world, dtype=torch.uint8).pin_memory())
+            self._first_contact(torch, dev)
         else:  # one process: its own block is all there is — merged straight out of the send buffer; no torch
             self.send = [engine.DeviceBuffer(ctx, biggest) for _ in range(2)]
             self.recv = self.send
@@ -718,6 +737,75 @@ class ShardedAnchoring:
         self.full: Dict[str, object] = {}  # writer side: anchor -> rows container (kept across passes)
         self._part, self._part_table = None, None  # the narrow result, kept while the table stays the same
         self.bytes_received = 0
+
+    def _first_contact(self, torch, dev) -> None:
+        """One tiny all-gather before any work is queued, with a deadline: a collective that cannot complete (ranks on
+        one GPU, a dead xGMI link, a rank that never arrived) is reported here, with what to try next, instead of as a
+        hang in the middle of the first pass.  Also checks that every rank answers with its own number."""
+        import threading
+        timeout = float(os.environ.get("PG_COLLECTIVE_TIMEOUT_S", "180"))
+        if dev.type == "cuda" and self.exchange == "rccl" and self.world > 1:
+            seen = [None] * self.world
+            self.dist.all_gather_object(seen, (os.uname().nodename, str(getattr(torch.cuda.get_device_properties(dev), "uuid", dev.index))),
+                                        group=self.group)
+            if len(set(seen)) != self.world:
+                raise RuntimeError(f"{self.world} ranks on {len(set(seen))} distinct GPU(s): RCCL needs one process per GPU "
+                                   "(LOCAL_RANK picks the device); PG_SHARD_EXCHANGE=host runs the exchange through the hosts instead")
+            n = torch.cuda.device_count()
+            blocked = [(dev.index, j) for j in range(n) if j != dev.index and not torch.cuda.can_device_access_peer(dev.index, j)]
+            if blocked:
+                logger_info("no peer access from GPU %d to %s: RCCL will not use xGMI there", dev.index, [j for _, j in blocked])
+        box = {}
+
+        def probe():
+            try:
+                got = self._gather(torch.full((8,), self.rank, dtype=torch.uint8, device=dev), dev)
+                if dev.type == "cuda":
+                    torch.cuda.synchronize(dev)
+                box["got"] = got.cpu().view(self.world, 8)[:, 0].tolist()
+            except Exception as e:  # noqa: BLE001 — reported below
+                box["err"] = e
+        t = threading.Thread(target=probe, daemon=True)
+        t.start()
+        t.join(timeout)
+        how = "RCCL all_gather_into_tensor" if self.exchange == "rccl" else "host all-gather (gloo)"
+        if t.is_alive():
+            raise RuntimeError(f"the first {how} of {self.world} ranks did not complete within {timeout:.0f} s "
+                               "(PG_COLLECTIVE_TIMEOUT_S).  Check that every rank was started (WORLD_SIZE), one per GPU; "
+                               + ("PG_SHARD_EXCHANGE=host takes the exchange off RCCL/xGMI." if self.exchange == "rccl" else ""))
+        if "err" in box:
+            raise RuntimeError(f"the first {how} failed: {box['err']}"
+                               + ("; PG_SHARD_EXCHANGE=host takes the exchange off RCCL/xGMI" if self.exchange == "rccl" else "")) from box["err"]
+        if box["got"] != list(range(self.world)):
+            raise RuntimeError(f"the first {how} returned blocks from ranks {box['got']}, expected 0..{self.world - 1}")
+
+    def _gather(self, mine, dev):
+        """all-gather of equal-sized uint8 blocks ``mine`` -> the concatenation, block i from rank i (the one exchange
+        step of the mode), by the configured route"""
+        import torch
+        out = torch.empty(mine.numel() * self.world, dtype=torch.uint8, device=mine.device)
+        self._gather_into(out, mine)
+        return out
+
+    def _gather_into(self, out_t, in_t) -> None:
+        if self.exchange == "rccl" or in_t.device.type != "cuda":
+            self.dist.all_gather_into_tensor(out_t, in_t, group=self.group if self.host_group is None else self.host_group)
+            return
+        import torch
+        n = in_t.numel()
+        if self._host is None or self._host[0].numel() < n:
+            self._host = (torch.empty(n, dtype=torch.uint8).pin_memory(), torch.empty(n * self.world, dtype=torch.uint8).pin_memory())
+        hs, hr = self._host[0][:n], self._host[1][:n * self.world]
+        hs.copy_(in_t, non_blocking=True)
+        torch.cuda.current_stream(in_t.device).synchronize()
+        self.dist.all_gather_into_tensor(hr, hs, group=self.host_group if self.host_group is not None else self.group)
+        out_t.copy_(hr, non_blocking=True)
+
+    def release(self, a: str) -> None:
+        """the writer is done with anchor ``a`` (files written): its full-width rows go back to the context"""
+        r = self.full.pop(a, None)
+        if r is not None:
+            r.close()
 
     def container(self, a: str):
         if a not in self.full:
@@ -774,7 +862,7 @@ class ShardedAnchoring:
             ready = pipe.mark_main()
             if self.collective:
                 out_t, in_t = self.recv[slot].t[:nbytes * self.world], self.send[slot].t[:nbytes]
-                ev = pipe.on_comm(ready, lambda o=out_t, t=in_t: self.dist.all_gather_into_tensor(o, t, group=self.group))
+                ev = pipe.on_comm(ready, lambda o=out_t, t=in_t: self._gather_into(o, t))
                 self.bytes_received += nbytes * (self.world - 1)
             else:
                 ev = ready
@@ -843,6 +931,15 @@ def run_genome_sharded(index, nblocks: int, group=None, exchange_stats: Optional
     tbl_mem = None
     if my_blocks:
         tbl_mem = engine.PanTable(ctx, k, per, expected_keys=max(index._expected_keys(blk) for blk in blocks.values()))
+    in_flight = 2 * index.writer_jobs(payload)  # anchors whose full-width rows wait for their writer: bounded
+
+    def finished(a, res):
+        joins.append((a, _finish_anchor(index, a, res, pool)))
+        while len(joins) > in_flight:  # the oldest writer first: its rows go back to the context before more pile up
+            a0, j0 = joins.pop(0)
+            j0()
+            sh.release(a0)
+
     try:
         for p in range(passes):
             b = p * world + rank
@@ -855,15 +952,16 @@ def run_genome_sharded(index, nblocks: int, group=None, exchange_stats: Optional
                 for name, g, ss, min_count, _ in blocks[b]:
                     tbl.insert_seqset(g.id - g_lo, ss, min_count=min_count)
                 logger_info("pass %d: table of genomes %d..%d: %s", p, g_lo, g_hi - 1, tbl.stats())
-            done = (lambda a, res: joins.append(_finish_anchor(index, a, res, pool))) if p == passes - 1 else None
+            done = finished if p == passes - 1 else None
             sh.run_pass(tbl, p * world, min(world, nblocks - p * world), passes > 1, done)
             if tbl is not None:
                 ctx.synchronize()  # (the pass's probes are done before the table is emptied for the next block)
         for a in anchors:  # an anchor FASTA without a record: nothing was exchanged, its (empty) files are still due
             if a not in sh.last_group and writer[a] == rank:
-                joins.append(_finish_anchor(index, a, sh.container(a), pool))
-        for j in joins:
+                joins.append((a, _finish_anchor(index, a, sh.container(a), pool)))
+        for a, j in joins:
             j()
+            sh.release(a)  # (its full-width rows: next to the block table the largest allocation of the mode)
     finally:
         pool.shutdown(wait=True)
         sh.close()

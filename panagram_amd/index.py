@@ -615,9 +615,13 @@ class Index:
             for b0 in range(0, N, per):
                 blk = [by_id[g] for g in range(b0, min(N, b0 + per)) if g in by_id]
                 worst = max(worst, engine.PanTable.bytes_for(self.k, min(per, N - b0), self._expected_keys(blk)))
-            # a block's table sits next to the anchors' rows of ITS genomes only (ceil(per/8) bytes) and the
-            # writers' full rows of one anchor
-            if worst <= free - self.HBM_RESERVE - 2 * longest * nb or nblocks >= N:
+            # a block's table sits next to the anchors' rows of ITS genomes only (ceil(per/8) bytes) and the full-width
+            # rows this rank holds as a writer: with several passes those of ALL its anchors (they gather bits pass by
+            # pass), with one pass those whose writer jobs are still in flight (run_genome_sharded bounds them)
+            mine = -(-len(self.anchor_genomes) // max(1, self.world))
+            passes = -(-((N + per - 1) // per) // max(1, self.world))
+            resident = (mine if passes > 1 else min(mine, 2 * self.writer_jobs(longest * nb * mine) + 1)) * longest * nb
+            if worst <= free - self.HBM_RESERVE - max(2 * longest * nb, resident) or nblocks >= N:
                 return "genome", (N + per - 1) // per
             nblocks += max(1, self.world)
 

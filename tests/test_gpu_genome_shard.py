@@ -230,10 +230,14 @@ def test_range_probe_extract_merge_equals_whole(ctx):
         x.close()
 
 
-def test_sharded_pipeline_through_rccl_on_one_rank(ctx):
+@pytest.mark.parametrize("exchange", ["rccl", "host"])
+def test_sharded_pipeline_through_rccl_on_one_rank(ctx, exchange, monkeypatch):
     """The pipeline's collective path on the one GPU of the test box: a process group of size 1 over "nccl"
-    (= RCCL), all_gather_into_tensor issued on the side stream for every chunk group, merged rows == golden."""
+    (= RCCL), all_gather_into_tensor issued on the side stream for every chunk group, merged rows == golden.
+    exchange = "host" (PG_SHARD_EXCHANGE): the fallback without a GPU collective — columns to pinned host memory, an
+    all-gather over a gloo group made next to the nccl one, back to the GPU, merged as usual."""
     import os
+    monkeypatch.setenv("PG_SHARD_EXCHANGE", exchange)
     import torch.distributed as dist
     from panagram_amd import distributed as pdist
     from panagram_amd import engine
@@ -338,15 +342,21 @@ def _two_rank_worker(rank, world, port, samples, out, k, anchors, shard, nblocks
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("exchange", ["rccl", "host"])
 @pytest.mark.parametrize("name,shard,nblocks,chunk", [("n8_k21", "genome", 2, 1500), ("n8_k21", "genome", 8, 1 << 27),
                                                       ("n9_k21", "genome", 4, 700), ("n9_k21", "replicated", 0, 1 << 27)])
-def test_two_processes_on_one_gpu(name, shard, nblocks, chunk, tmp_path):
+def test_two_processes_on_one_gpu(name, shard, nblocks, chunk, exchange, tmp_path, monkeypatch):
     """("n8_k21", genome, 2): one pass, each rank one block of 4 genomes; (…, 8): four passes of one-genome blocks
     (config 5's layout; columns straight from the probe); ("n9_k21", 4): blocks of 3, 3, 3 on two ranks — the second
     pass has an idle rank; replicated: pieces of homology classes dealt to the two ranks (both anchor every genome's
     share, co-scheduled), fragments assembled by whoever finds a genome complete, no collective."""
     import torch.multiprocessing as mp
     import os
+    if exchange == "host" and shard == "replicated":
+        pytest.skip("no exchange step in the contig-sharded mode")
+    # ("host": the two ranks' columns go GPU -> pinned host -> gloo all-gather -> GPU, PG_SHARD_EXCHANGE's fallback route;
+    # "rccl" here hands the CUDA tensors to the gloo group of this one-GPU set-up, see above)
+    monkeypatch.setenv("PG_SHARD_EXCHANGE", exchange)
     fx = H.load_case(name)
     s = _write_case(tmp_path, fx)
     out = tmp_path / "idx"
