@@ -744,7 +744,7 @@ class ShardedAnchoring:
         hang in the middle of the first pass.  Also checks that every rank answers with its own number."""
         import threading
         timeout = float(os.environ.get("PG_COLLECTIVE_TIMEOUT_S", "180"))
-        if dev.type == "cuda" and self.exchange == "rccl" and self.world > 1:
+        if dev.type == "cuda" and self.exchange == "rccl" and self.world > 1 and self.dist.get_backend(self.group) == "nccl":
             seen = [None] * self.world
             self.dist.all_gather_object(seen, (os.uname().nodename, str(getattr(torch.cuda.get_device_properties(dev), "uuid", dev.index))),
                                         group=self.group)
