@@ -378,9 +378,15 @@ __device__ __forceinline__ uint32_t sliding_min(uint32_t x) {
     return m;
 }
 #undef PG_DPPMIN
-// inclusive count of set bits of `mask` at lanes <= this lane
-__device__ __forceinline__ uint32_t lanes_le_count(unsigned long long mask, bool own) {
-    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u)) + (own ? 1u : 0u);
+// base + (set bits of `mask` at lanes <= this lane) - 1: for a lane whose own bit is set, its index among the set lanes
+// (a queue slot, counted from the wave-uniform `base`); for any lane, the number of the last set lane at or below it (a
+// run id, when the set lanes are the runs' first lanes).  Two VALU instructions: the shift of the mask by one lane —
+// which turns mbcnt's "below this lane" into "at or below" — and the constant are scalar work, and the constant rides in
+// on mbcnt's own addend.
+__device__ __forceinline__ uint32_t lanes_le_index(unsigned long long mask, uint32_t base) {
+    const unsigned long long m1 = mask >> 1;
+    const uint32_t c = base + (uint32_t)(mask & 1ull) - 1u;
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, c));
 }
 
 // ROWMODE 3 — the genome-sharded mode's narrow tables (a block of up to 8 genomes): the probe emits the block's
@@ -446,8 +452,8 @@ __device__ __forceinline__ void drain_queue(const SubTable &st, uint32_t qn, con
             const uint64_t key = canonical_from_xb(X, revcomp_window(rw, X, pl, k, kmask), k);
             const uint32_t prev_line = lane_up1(line);
             const bool leader = act && (lane == 0 || line != prev_line);
-            const unsigned long long lmask = __ballot(leader);
-            const uint32_t rid = lanes_le_count(lmask, leader) - 1;
+            const unsigned long long lmask = __builtin_amdgcn_ballot_w64(leader);
+            const uint32_t rid = lanes_le_index(lmask, 0u);
             const uint32_t nruns = (uint32_t)__popcll(lmask);
             uint32_t m0 = 0, m1 = 0;
             int rcode = 0;
@@ -487,9 +493,9 @@ __device__ __forceinline__ void drain_queue(const SubTable &st, uint32_t qn, con
                     if (act && (m0 | m1)) store_row<ROWMODE>(tile_rows + (uint64_t)pl * nbytes, m0, m1, rc);
                 }
             }
-            const unsigned long long kmask2 = __ballot(again);
+            const unsigned long long kmask2 = __builtin_amdgcn_ballot_w64(again);
             if (again) {  // in-place compaction: slot <= e, and this batch's reads are already done
-                const uint32_t slot = kept + lanes_le_count(kmask2, true) - 1;
+                const uint32_t slot = lanes_le_index(kmask2, kept);
                 uint32_t nl2 = line, ns2 = step;
                 // (staged levels end before the group's chain does: no switch to the key's own sequence
                 // here, and none of its hashing on this path)
@@ -577,6 +583,7 @@ __global__ __launch_bounds__(64) void k_probe(const SubTable st, const uint64_t 
     for (uint32_t b0 = 0; b0 < npos; b0 += NB * STRIDE) {
         int32_t pl[NB];
         bool inrange[NB], act[NB], leader[NB];
+        unsigned long long amask[NB];
         uint64_t key[NB];
         uint32_t grp[NB], line[NB], rid[NB], nruns[NB], m0[NB], m1[NB];
         int rcode[NB];
@@ -585,13 +592,20 @@ __global__ __launch_bounds__(64) void k_probe(const SubTable st, const uint64_t 
         for (int u = 0; u < NB; ++u) {
             const uint32_t b = b0 + u * STRIDE;
             pl[u] = (int32_t)(b + lane) - HALO;
-            inrange[u] = pl[u] >= (int32_t)b && pl[u] < (int32_t)npos;
+            // (pl >= b exactly for the lanes behind the halo: a constant lane mask; a ballot straight off the compare
+            // stays a scalar mask, one of a bool that was AND-ed together first is rebuilt through 0 / 1)
+            const unsigned long long rmask = __builtin_amdgcn_ballot_w64(pl[u] < (int32_t)npos) & ~((1ull << HALO) - 1ull);
+            inrange[u] = __builtin_amdgcn_inverse_ballot_w64(rmask);
             const uint32_t pq = (uint32_t)max(pl[u], 0);
             const uint64_t X = extract_bases32(reinterpret_cast<const uint32_t *>(sw), pq) & kmask;
             const uint64_t B = revcomp_window(rw, X, pq, k, kmask);
             key[u] = canonical_from_xb(X, B, k);
-            act[u] = inrange[u];
-            if (hasn) act[u] = act[u] && (extract_nmask(nw, pq, k) == 0);
+            // (the active lanes as a scalar lane mask from the start: a bool that meets itself again behind the
+            // wave-uniform `hasn` branch is materialised as 0 / 1 and compared back into a mask by the compiler)
+            unsigned long long am = rmask;
+            if (hasn) am &= __builtin_amdgcn_ballot_w64(extract_nmask(nw, pq, k) == 0);
+            amask[u] = am;
+            act[u] = __builtin_amdgcn_inverse_ballot_w64(am);
             if (W_C) {
                 // m-mer number b+lane is the LAST m-mer of this lane's own k-mer (the first lanes of a
                 // tile, which have no k-mer, take theirs out of the tile's first k-mer): forward strand
@@ -635,10 +649,11 @@ __global__ __launch_bounds__(64) void k_probe(const SubTable st, const uint64_t 
         uint32_t maxruns = 0;
 #pragma unroll
         for (int u = 0; u < NB; ++u) {
-            const bool prev_act = lane > 0 && lane_up1(act[u] ? 1u : 0u) != 0;
-            leader[u] = act[u] && (!prev_act || line[u] != prev_line[u]);
-            const unsigned long long lmask = __ballot(leader[u]);
-            rid[u] = lanes_le_count(lmask, leader[u]) - 1;  // run id of an active lane
+            // (lane masks on the scalar unit: a run starts at an active lane whose predecessor is inactive or on another
+            // line; lane 0 has no predecessor — the shift leaves its bit clear)
+            const unsigned long long lmask = amask[u] & (~(amask[u] << 1) | __builtin_amdgcn_ballot_w64(line[u] != prev_line[u]));
+            leader[u] = __builtin_amdgcn_inverse_ballot_w64(lmask);
+            rid[u] = lanes_le_index(lmask, 0u);  // run id of an active lane
             nruns[u] = (uint32_t)__popcll(lmask);
             maxruns = max(maxruns, nruns[u]);
             m0[u] = m1[u] = 0;
@@ -672,7 +687,8 @@ __global__ __launch_bounds__(64) void k_probe(const SubTable st, const uint64_t 
 #if PG_ABLATE == 1  // (timing experiment, wrong rows: every fetch a cache hit — the lines of one 64 KB window)
                     const uint32_t ln = nl[u] ? (lines_w[u][ls] & 511u) : 0u;
 #else
-                    const uint32_t ln = nl[u] ? lines_w[u][ls] : 0u;
+                    // (one batch per iteration: the loop only runs while the batch has lines left, nl >= 1)
+                    const uint32_t ln = (NB > 1 && !nl[u]) ? 0u : lines_w[u][ls];
 #endif
                     v[u][it] = *reinterpret_cast<const uint4 *>(st.buckets + (((uint64_t)ln * BUCKET_BYTES) | ((lane % SLOTS) * 16u)));
                 }
@@ -709,8 +725,10 @@ __global__ __launch_bounds__(64) void k_probe(const SubTable st, const uint64_t 
         // ---- overflow: absent from a full line -> queue entry for the next line of its sequence ----
 #pragma unroll
         for (int u = 0; u < NB; ++u) {
-            const bool ovf = act[u] && rcode[u] < 0;
-            const unsigned long long omask = __ballot(ovf);
+            // (sicmp = the compare as a lane mask, predicate 40 = signed less-than: a ballot of `rcode < 0` is sunk into the
+            // blocks rcode comes from and its bool rebuilt here through 0 / 1)
+            const unsigned long long omask = amask[u] & __builtin_amdgcn_sicmp(rcode[u], 0, 40);
+            const bool ovf = __builtin_amdgcn_inverse_ballot_w64(omask);
             if (omask) {
                 uint32_t step, nx;
                 if constexpr (GROUP_CHAIN == 1) {  // (tuning build: the group owns its home line only — level 1 is the key's own sequence)
@@ -719,7 +737,7 @@ __global__ __launch_bounds__(64) void k_probe(const SubTable st, const uint64_t 
                     step = step_of_group(grp[u], st.nbuckets);
                     nx = next_line(line[u], step, st.nbuckets);
                 }
-                const uint32_t slot = qn + lanes_le_count(omask, ovf) - 1;
+                const uint32_t slot = lanes_le_index(omask, qn);
                 if (ovf) {
                     if (slot < (uint32_t)PROBE_QCAP) {
                         q_line[slot] = nx;
@@ -923,7 +941,7 @@ __device__ __forceinline__ int wave_insert_batch(const SubTable &st, bool valid,
             won = cur == EMPTY_KEY;
             content = won ? key : cur;
         }
-        const unsigned long long lmask = __ballot(leader);
+        const unsigned long long lmask = __builtin_amdgcn_ballot_w64(leader);
         if (__ballot(want)) {
             const unsigned long long below = lmask & ((2ull << lane) - 1ull);
             const int mine = below ? 63 - __builtin_clzll(below) : lane;  // the leader this lane follows
@@ -1036,10 +1054,10 @@ __global__ __launch_bounds__(64) void k_insert_tile(const SubTable st, int w, ui
         }
         const uint32_t line = home_of_group(grp, st.nbuckets);
         const uint32_t prev_line = lane_up1(line);
-        const bool prev_act = lane > 0 && lane_up1(act ? 1u : 0u) != 0;
-        const bool leader = act && (!prev_act || line != prev_line);
-        const unsigned long long lmask = __ballot(leader);
-        const uint32_t rid = lanes_le_count(lmask, leader) - 1;
+        const unsigned long long amask = __builtin_amdgcn_ballot_w64(act);  // (run starts by lane-mask arithmetic on the scalar unit, as in k_probe)
+        const unsigned long long lmask = amask & (~(amask << 1) | __builtin_amdgcn_ballot_w64(line != prev_line));
+        const bool leader = __builtin_amdgcn_inverse_ballot_w64(lmask);
+        const uint32_t rid = lanes_le_index(lmask, 0u);
         const uint32_t nruns = (uint32_t)__popcll(lmask);
         bool found = false, full = true;  // full: the staged home line had no empty slot (or was not reached)
         for (uint32_t r0 = 0; r0 < nruns; r0 += PROBE_MAXRUN) {
@@ -1114,11 +1132,11 @@ __global__ __launch_bounds__(64) void k_insert_tile(const SubTable st, int w, ui
         // absent from the snapshot of its line (or the line was not reached): queue for the claiming insert
         // (update-only: a key missing from a home line that is not full is not in the table — lines fill front to back)
         const bool todo = act && !found && (!update_only || full);
-        const unsigned long long tmask = __ballot(todo);
+        const unsigned long long tmask = __builtin_amdgcn_ballot_w64(todo);
         if (tmask) {
             if (qn + 64 > (uint32_t)INSERT_QCAP) drain();
             if (todo) {
-                const uint32_t slot = qn + lanes_le_count(tmask, true) - 1;
+                const uint32_t slot = lanes_le_index(tmask, qn);
                 q_grp[slot] = grp;
                 q_pl[slot] = (uint16_t)pl;
             }
