@@ -421,6 +421,8 @@ __device__ __forceinline__ void drain_queue(const SubTable &st, uint32_t qn, con
     constexpr int LDS_LINE_U4 = SLOTS + 1;
     constexpr int BUCKET_BYTES = 16 * SLOTS;
     constexpr int STAGE_ITERS = (MAXRUN * SLOTS + 63) / 64;
+    const uint8_t *chunk_base = st.buckets + (uint32_t)(lane % SLOTS) * 16u;
+    const uint32_t lbytes = st.slots * (WIDE ? 8u : 16u);  // (= BUCKET_BYTES, as a run-time scalar: see k_probe)
     for (int level = 1; qn > 0; ++level) {
         __syncthreads();
         if (level > LEVELS) {
@@ -457,16 +459,20 @@ __device__ __forceinline__ void drain_queue(const SubTable &st, uint32_t qn, con
             const uint32_t nruns = (uint32_t)__popcll(lmask);
             uint32_t m0 = 0, m1 = 0;
             int rcode = 0;
+            // (staging as in k_probe's main batches: the entries behind the last run repeat the first run's line, every lane
+            // reads its entries at fixed places, one multiply-add per address)
+            const uint32_t padline = lmask ? (uint32_t)__builtin_amdgcn_readlane((int)line, __builtin_ctzll(lmask)) : 0u;
             for (uint32_t r0 = 0; r0 < nruns; r0 += MAXRUN) {
                 const uint32_t nl = min((uint32_t)MAXRUN, nruns - r0);
+                if (lane < MAXRUN) lines_w[lane] = padline;
                 if (leader && rid - r0 < nl) lines_w[rid - r0] = line;
                 __syncthreads();
                 uint4 v[STAGE_ITERS];
+                uint32_t ln[STAGE_ITERS];
 #pragma unroll
-                for (int u = 0; u < STAGE_ITERS; ++u) {
-                    const uint32_t ls = min((uint32_t)(u * (64 / SLOTS) + lane / SLOTS), nl - 1u);
-                    v[u] = *reinterpret_cast<const uint4 *>(st.buckets + (((uint64_t)lines_w[ls] * BUCKET_BYTES) | ((lane % SLOTS) * 16u)));
-                }
+                for (int u = 0; u < STAGE_ITERS; ++u) ln[u] = lines_w[u * (64 / SLOTS) + lane / SLOTS];
+#pragma unroll
+                for (int u = 0; u < STAGE_ITERS; ++u) v[u] = *reinterpret_cast<const uint4 *>(chunk_base + (uint64_t)ln[u] * lbytes);
 #pragma unroll
                 for (int u = 0; u < STAGE_ITERS; ++u) {
                     const uint32_t idx = u * 64 + lane;
@@ -580,12 +586,19 @@ __global__ __launch_bounds__(64) void k_probe(const SubTable st, const uint64_t 
     // NB independent 64-lane batches are carried through every stage together, so that the
     // LDS shuffles and the staged table fetches of one batch overlap those of the other(s)
     constexpr int NB = PROBE_NB;
-    for (uint32_t b0 = 0; b0 < npos; b0 += NB * STRIDE) {
+    const uint8_t *chunk_base = st.buckets + (uint32_t)(lane % SLOTS) * 16u;  // this lane's 16-byte chunk of line 0
+    const uint32_t lbytes = st.slots * (WIDE ? 8u : 16u);                      // bytes per line (= BUCKET_BYTES), as a run-time scalar
+    // One batch (NB of them side by side).  FIRST: the tile's first batch, whose leading HALO lanes stand before the
+    // tile's first k-mer (pl < 0: they take their m-mers out of that k-mer, at their own offsets); in every later batch
+    // a lane's m-mer sits at the one fixed offset and its position needs no clamp — the body is instantiated twice so
+    // that those later batches carry neither.
+    auto batch = [&](auto first_tag, const uint32_t b0) __attribute__((always_inline)) {
+        constexpr bool FIRST = decltype(first_tag)::value;
         int32_t pl[NB];
         bool inrange[NB], act[NB], leader[NB];
         unsigned long long amask[NB];
         uint64_t key[NB];
-        uint32_t grp[NB], line[NB], rid[NB], nruns[NB], m0[NB], m1[NB];
+        uint32_t grp[NB], line[NB], rid[NB], nruns[NB], m0[NB], m1[NB], padline[NB];
         int rcode[NB];
         // ---- keys: lane = position b + lane - HALO; it also owns m-mer number b + lane ----
 #pragma unroll
@@ -596,7 +609,7 @@ __global__ __launch_bounds__(64) void k_probe(const SubTable st, const uint64_t 
             // stays a scalar mask, one of a bool that was AND-ed together first is rebuilt through 0 / 1)
             const unsigned long long rmask = __builtin_amdgcn_ballot_w64(pl[u] < (int32_t)npos) & ~((1ull << HALO) - 1ull);
             inrange[u] = __builtin_amdgcn_inverse_ballot_w64(rmask);
-            const uint32_t pq = (uint32_t)max(pl[u], 0);
+            const uint32_t pq = FIRST ? (uint32_t)max(pl[u], 0) : (uint32_t)pl[u];
             const uint64_t X = extract_bases32(reinterpret_cast<const uint32_t *>(sw), pq) & kmask;
             const uint64_t B = revcomp_window(rw, X, pq, k, kmask);
             key[u] = canonical_from_xb(X, B, k);
@@ -610,7 +623,7 @@ __global__ __launch_bounds__(64) void k_probe(const SubTable st, const uint64_t 
                 // m-mer number b+lane is the LAST m-mer of this lane's own k-mer (the first lanes of a
                 // tile, which have no k-mer, take theirs out of the tile's first k-mer): forward strand
                 // from X, reverse complement from B — no second pass over the sequence words
-                const uint32_t off = (uint32_t)(pl[u] + HALO) - pq;  // m-mer's offset inside the k-mer, 0..HALO
+                const uint32_t off = FIRST ? (uint32_t)(pl[u] + HALO) - pq : (uint32_t)HALO;  // m-mer's offset inside the k-mer, 0..HALO
                 if constexpr (!M64) {  // m-mers of up to 32 bits: one funnel shift each, no 64-bit arithmetic
                     const uint32_t mm32 = (uint32_t)mm64;
                     const uint32_t fa = __builtin_amdgcn_alignbit((uint32_t)(X >> 32), (uint32_t)X, 2 * off) & mm32;
@@ -658,6 +671,7 @@ __global__ __launch_bounds__(64) void k_probe(const SubTable st, const uint64_t 
             maxruns = max(maxruns, nruns[u]);
             m0[u] = m1[u] = 0;
             rcode[u] = 0;
+            padline[u] = lmask ? (uint32_t)__builtin_amdgcn_readlane((int)line[u], __builtin_ctzll(lmask)) : 0u;  // (wave-uniform)
         }
 #if PG_ABLATE == 3  // (timing experiment: keys, minimizers and runs only — no table access)
         for (uint32_t r0 = 0; r0 < maxruns && line[0] == 0xDEADBEEFu; r0 += MAXRUN) {
@@ -668,30 +682,33 @@ __global__ __launch_bounds__(64) void k_probe(const SubTable st, const uint64_t 
 #pragma unroll
             for (int u = 0; u < NB; ++u) {
                 nl[u] = nruns[u] > r0 ? min((uint32_t)MAXRUN, nruns[u] - r0) : 0u;
+                // the step's line numbers, one per run; the entries behind the last run repeat the first run's line (the
+                // same address again inside one load: no second fetch), so that the staging lanes below read theirs at
+                // fixed places — no clamp of the entry's number, one LDS instruction for all of a lane's entries
+                if (lane < MAXRUN) lines_w[u][lane] = padline[u];
                 if (leader[u] && rid[u] - r0 < nl[u]) lines_w[u][rid[u] - r0] = line[u];
             }
             __syncthreads();
-            // stage: nl lines = nl*SLOTS chunks of 16 bytes, coalesced, all loads of the step in flight.
-            // Loads AND LDS writes are unconditional (chunks past the last line re-copy its last
-            // chunk into unused buffer lines): any predicate here makes the compiler sink each load
+            // stage: MAXRUN lines = MAXRUN*SLOTS chunks of 16 bytes, coalesced, all loads of the step in flight.
+            // Loads AND LDS writes are unconditional: any predicate here makes the compiler sink each load
             // into its own branch and wait for it there
-            // (a lane always fetches chunk lane % SLOTS of a line — an invariant offset OR-ed into line << 7 — and
-            // only the line's number is clamped: three address instructions per load)
+            // (a lane always fetches chunk lane % SLOTS of a line: its address = the lane's own base + line x line bytes,
+            // one multiply-add — the line bytes come from the table's descriptor, a scalar the compiler cannot turn into
+            // a 64-bit shift and a 64-bit add)
             uint4 v[NB][STAGE_ITERS];
 #pragma unroll
             for (int u = 0; u < NB; ++u) {
-                const uint32_t last = max(nl[u], 1u) - 1u;
+                uint32_t ln[STAGE_ITERS];
 #pragma unroll
                 for (int it = 0; it < STAGE_ITERS; ++it) {
-                    const uint32_t ls = min((uint32_t)(it * (64 / SLOTS) + lane / SLOTS), last);
+                    ln[it] = lines_w[u][it * (64 / SLOTS) + lane / SLOTS];
 #if PG_ABLATE == 1  // (timing experiment, wrong rows: every fetch a cache hit — the lines of one 64 KB window)
-                    const uint32_t ln = nl[u] ? (lines_w[u][ls] & 511u) : 0u;
-#else
-                    // (one batch per iteration: the loop only runs while the batch has lines left, nl >= 1)
-                    const uint32_t ln = (NB > 1 && !nl[u]) ? 0u : lines_w[u][ls];
+                    ln[it] &= 511u;
 #endif
-                    v[u][it] = *reinterpret_cast<const uint4 *>(st.buckets + (((uint64_t)ln * BUCKET_BYTES) | ((lane % SLOTS) * 16u)));
                 }
+#pragma unroll
+                for (int it = 0; it < STAGE_ITERS; ++it)
+                    v[u][it] = *reinterpret_cast<const uint4 *>(chunk_base + (uint64_t)ln[it] * lbytes);
             }
 #pragma unroll
             for (int u = 0; u < NB; ++u)
@@ -776,7 +793,9 @@ __global__ __launch_bounds__(64) void k_probe(const SubTable st, const uint64_t 
                 }
             }
         }
-    }
+    };
+    batch(std::true_type{}, 0u);
+    for (uint32_t b0 = NB * STRIDE; b0 < npos; b0 += NB * STRIDE) batch(std::false_type{}, b0);
 
     constexpr int LEVELS = (W_C >= 6 && !TWO && !WIDE && PROBE_STAGED_LEVELS > 1) ? 1 : PROBE_STAGED_LEVELS;  // (W_C >= 6: the wide-window tables of up to 16 genomes)
     drain_queue<TWO, ROWMODE, SLOTS, MAXRUN, WIDE, LEVELS>(st, qn, sw, rw, q_line, q_step, q_pl, lines_w[0], buf[0], tile_rows, nbytes, rc, lane);
