@@ -54,6 +54,9 @@ constexpr int PROBE_SEQW = ((PROBE_TILE + 31) / 32 + 6 + 3) & ~3;  // staged 32-
 #ifndef PG_RC_LDS
 #define PG_RC_LDS 1
 #endif
+#ifndef PG_PROBE_PIPE
+#define PG_PROBE_PIPE 1  // the front end of batch i + 1 ahead of the table look-up of batch i (k_probe)
+#endif
 constexpr uint32_t PROBE_SEQ_BASES = 32u * PROBE_SEQW;
 __device__ __forceinline__ uint64_t revcomp_window(const uint64_t *rw, uint64_t X, uint32_t p, int k, uint64_t kmask) {
 #if PG_RC_LDS
@@ -520,8 +523,12 @@ __device__ __forceinline__ void drain_queue(const SubTable &st, uint32_t qn, con
 
 // M64: m-mers longer than 16 bases.  WIDE: split layout (SLOTS = 8 then counts the 16-byte chunks of a key line: the
 // staging geometry is the same, a line holds 16 bare keys; m0 / m1 carry the hit's line and slot + 1)
+// (probe_pipelined: the instantiations that run the skewed batch order, see the end of the kernel; they are held to the 64
+// registers of 8 waves per SIMD — the only spill that costs them sits around the queue-full call, a cold path)
+template <int W_C, bool TWO, int ROWMODE, int SLOTS, bool WIDE>
+constexpr bool probe_pipelined = PG_PROBE_PIPE && ROWMODE == 1 && !TWO && !WIDE && SLOTS == 8 && W_C != 6;
 template <int W_C, bool TWO, int ROWMODE, int SLOTS, bool M64, bool WIDE = false>
-__global__ __launch_bounds__(64) void k_probe(const SubTable st, const uint64_t *__restrict__ seqw,
+__global__ __launch_bounds__(64, (probe_pipelined<W_C, TWO, ROWMODE, SLOTS, WIDE> ? 8 : 1)) void k_probe(const SubTable st, const uint64_t *__restrict__ seqw,
                                               const uint32_t *__restrict__ nmw, const uint32_t *__restrict__ has_n,
                                               const SeqDesc *__restrict__ sd, const AnchorDesc *__restrict__ ad,
                                               const uint32_t *__restrict__ tile_contig,
@@ -539,8 +546,8 @@ __global__ __launch_bounds__(64) void k_probe(const SubTable st, const uint64_t 
     // on 64 x 20 Mb, 92.0 -> 89.7 on 64 x 200 Mb; everywhere else 24 costs 8-10 %: LDS, occupancy; tools/ab_maxrun.sh)
     constexpr int MAXRUN = W_C == 6 ? (PROBE_MAXRUN * 3) / 2 : PROBE_MAXRUN;
     constexpr int STAGE_ITERS = (MAXRUN * SLOTS + 63) / 64;  // 16-byte loads per lane per staging step
-    __shared__ uint32_t lines_w[PROBE_NB][MAXRUN];
-    __shared__ uint4 buf[PROBE_NB][((STAGE_ITERS * 64 + SLOTS - 1) / SLOTS) * LDS_LINE_U4];  // room for every staged chunk slot
+    __shared__ uint32_t lines_w[1][MAXRUN];
+    __shared__ uint4 buf[1][((STAGE_ITERS * 64 + SLOTS - 1) / SLOTS) * LDS_LINE_U4];  // room for every staged chunk slot
     __shared__ uint32_t q_line[PROBE_QCAP];  // overflow queue of the tile (position order): next line to try,
     __shared__ uint32_t q_step[PROBE_QCAP];  // step of the entry's sequence
     __shared__ uint16_t q_pl[PROBE_QCAP];    // and position within the tile (the key is re-derived from sw)
@@ -583,219 +590,224 @@ __global__ __launch_bounds__(64) void k_probe(const SubTable st, const uint64_t 
     uint8_t *tile_rows = ROWMODE == 3 ? reinterpret_cast<uint8_t *>(cols) : out1 + a.out_off + (uint64_t)tile_start * nbytes;
     uint32_t qn = 0;  // wave-uniform: overflow entries of this tile so far
 
-    // NB independent 64-lane batches are carried through every stage together, so that the
-    // LDS shuffles and the staged table fetches of one batch overlap those of the other(s)
-    constexpr int NB = PROBE_NB;
     const uint8_t *chunk_base = st.buckets + (uint32_t)(lane % SLOTS) * 16u;  // this lane's 16-byte chunk of line 0
     const uint32_t lbytes = st.slots * (WIDE ? 8u : 16u);                      // bytes per line (= BUCKET_BYTES), as a run-time scalar
-    // One batch (NB of them side by side).  FIRST: the tile's first batch, whose leading HALO lanes stand before the
-    // tile's first k-mer (pl < 0: they take their m-mers out of that k-mer, at their own offsets); in every later batch
-    // a lane's m-mer sits at the one fixed offset and its position needs no clamp — the body is instantiated twice so
-    // that those later batches carry neither.
-    auto batch = [&](auto first_tag, const uint32_t b0) __attribute__((always_inline)) {
+
+    // A batch in three parts, so that the front end of batch i + 1 can run while the table lines of batch i are on
+    // their way (PG_PROBE_PIPE): the fetch is the longest wait of a batch — a couple of thousand cycles behind a busy
+    // texture-address unit and a TLB that misses on a quarter of these random lines — and the next batch's keys,
+    // minimizers and runs need nothing from it.
+    struct Front {  // what the front end of a batch leaves behind: no table access so far
+        uint64_t key;
+        uint32_t grp, line, rid, nruns, padline;
+        unsigned long long rmask, amask, lmask;  // lanes with a position / active (no N in the window) / first of a run
+    };
+    // ---- keys: lane = position b0 + lane - HALO; it also owns m-mer number b0 + lane ----
+    // FIRST: the tile's first batch, whose leading HALO lanes stand before the tile's first k-mer (pl < 0: they take
+    // their m-mers out of that k-mer, at their own offsets); in every later batch a lane's m-mer sits at the one fixed
+    // offset and its position needs no clamp — instantiated twice so that the later batches carry neither.
+    auto front = [&](auto first_tag, const uint32_t b0) __attribute__((always_inline)) {
         constexpr bool FIRST = decltype(first_tag)::value;
-        int32_t pl[NB];
-        bool inrange[NB], act[NB], leader[NB];
-        unsigned long long amask[NB];
-        uint64_t key[NB];
-        uint32_t grp[NB], line[NB], rid[NB], nruns[NB], m0[NB], m1[NB], padline[NB];
-        int rcode[NB];
-        // ---- keys: lane = position b + lane - HALO; it also owns m-mer number b + lane ----
-#pragma unroll
-        for (int u = 0; u < NB; ++u) {
-            const uint32_t b = b0 + u * STRIDE;
-            pl[u] = (int32_t)(b + lane) - HALO;
-            // (pl >= b exactly for the lanes behind the halo: a constant lane mask; a ballot straight off the compare
-            // stays a scalar mask, one of a bool that was AND-ed together first is rebuilt through 0 / 1)
-            const unsigned long long rmask = __builtin_amdgcn_ballot_w64(pl[u] < (int32_t)npos) & ~((1ull << HALO) - 1ull);
-            inrange[u] = __builtin_amdgcn_inverse_ballot_w64(rmask);
-            const uint32_t pq = FIRST ? (uint32_t)max(pl[u], 0) : (uint32_t)pl[u];
-            const uint64_t X = extract_bases32(reinterpret_cast<const uint32_t *>(sw), pq) & kmask;
-            const uint64_t B = revcomp_window(rw, X, pq, k, kmask);
-            key[u] = canonical_from_xb(X, B, k);
-            // (the active lanes as a scalar lane mask from the start: a bool that meets itself again behind the
-            // wave-uniform `hasn` branch is materialised as 0 / 1 and compared back into a mask by the compiler)
-            unsigned long long am = rmask;
-            if (hasn) am &= __builtin_amdgcn_ballot_w64(extract_nmask(nw, pq, k) == 0);
-            amask[u] = am;
-            act[u] = __builtin_amdgcn_inverse_ballot_w64(am);
-            if (W_C) {
-                // m-mer number b+lane is the LAST m-mer of this lane's own k-mer (the first lanes of a
-                // tile, which have no k-mer, take theirs out of the tile's first k-mer): forward strand
-                // from X, reverse complement from B — no second pass over the sequence words
-                const uint32_t off = FIRST ? (uint32_t)(pl[u] + HALO) - pq : (uint32_t)HALO;  // m-mer's offset inside the k-mer, 0..HALO
-                if constexpr (!M64) {  // m-mers of up to 32 bits: one funnel shift each, no 64-bit arithmetic
-                    const uint32_t mm32 = (uint32_t)mm64;
-                    const uint32_t fa = __builtin_amdgcn_alignbit((uint32_t)(X >> 32), (uint32_t)X, 2 * off) & mm32;
-                    const uint32_t fr = __builtin_amdgcn_alignbit((uint32_t)(B >> 32), (uint32_t)B, 2 * (HALO - off)) & mm32;
-                    grp[u] = mz_order(min(fa, fr));  // (= mmer_rank: its fold of the high half is the identity here)
-                } else {
-                    const uint64_t fa = (X >> (2 * off)) & mm64;
-                    const uint64_t fr = (B >> (2 * (HALO - off))) & mm64;
-                    grp[u] = mmer_rank(fa < fr ? fa : fr);
-                }
-            } else {
-                grp[u] = group_of_key(key[u]);
-            }
-        }
-#ifdef PG_DUMMY_VALU
-        {   // (experiment: PG_DUMMY_VALU extra full-rate-class VALU instructions per batch, nothing else changed)
-            uint32_t dm = grp[0];
-#pragma unroll
-            for (int i = 0; i < PG_DUMMY_VALU; ++i) asm volatile("v_alignbit_b32 %0, %0, %1, 3" : "+v"(dm) : "v"((uint32_t)lane));
-            if (dm == 0x12345u && lane == 77) out1[0] = 1;
-        }
-#endif
+        Front f;
+        const int32_t pl = (int32_t)(b0 + lane) - HALO;
+        // (pl >= b0 exactly for the lanes behind the halo: a constant lane mask; a ballot straight off the compare stays
+        // a scalar mask, one of a bool that was AND-ed together first is rebuilt through 0 / 1)
+        f.rmask = __builtin_amdgcn_ballot_w64(pl < (int32_t)npos) & ~((1ull << HALO) - 1ull);
+        const uint32_t pq = FIRST ? (uint32_t)max(pl, 0) : (uint32_t)pl;
+        const uint64_t X = extract_bases32(reinterpret_cast<const uint32_t *>(sw), pq) & kmask;
+        const uint64_t B = revcomp_window(rw, X, pq, k, kmask);
+        f.key = canonical_from_xb(X, B, k);
+        f.amask = f.rmask;
+        if (hasn) f.amask &= __builtin_amdgcn_ballot_w64(extract_nmask(nw, pq, k) == 0);
         if (W_C) {
+            // m-mer number b0+lane is the LAST m-mer of this lane's own k-mer (the first lanes of a tile, which have no
+            // k-mer, take theirs out of the tile's first k-mer): forward strand from X, reverse complement from B — no
+            // second pass over the sequence words
+            const uint32_t off = FIRST ? (uint32_t)(pl + HALO) - pq : (uint32_t)HALO;  // m-mer's offset inside the k-mer, 0..HALO
+            if constexpr (!M64) {  // m-mers of up to 32 bits: one funnel shift each, no 64-bit arithmetic
+                const uint32_t mm32 = (uint32_t)mm64;
+                const uint32_t fa = __builtin_amdgcn_alignbit((uint32_t)(X >> 32), (uint32_t)X, 2 * off) & mm32;
+                const uint32_t fr = __builtin_amdgcn_alignbit((uint32_t)(B >> 32), (uint32_t)B, 2 * (HALO - off)) & mm32;
+                f.grp = mz_order(min(fa, fr));  // (= mmer_rank: its fold of the high half is the identity here)
+            } else {
+                const uint64_t fa = (X >> (2 * off)) & mm64;
+                const uint64_t fr = (B >> (2 * (HALO - off))) & mm64;
+                f.grp = mmer_rank(fa < fr ? fa : fr);
+            }
+#ifdef PG_DUMMY_VALU
+            {   // (experiment: PG_DUMMY_VALU extra VALU instructions per batch, nothing else changed)
+                uint32_t dm = f.grp;
+#pragma unroll
+                for (int i = 0; i < PG_DUMMY_VALU; ++i) asm volatile("v_alignbit_b32 %0, %0, %1, 3" : "+v"(dm) : "v"((uint32_t)lane));
+                if (dm == 0x12345u && lane == 77) out1[0] = 1;
+            }
+#endif
             // sliding minimum over lanes [lane-W_C+1, lane]: m <- min(own rank, m of the lane below), W_C-1 times
             // (the first lanes of the wave see shorter windows: they are halo lanes, never active)
-#pragma unroll
-            for (int u = 0; u < NB; ++u) grp[u] = sliding_min<W_C ? W_C : 1>(grp[u]);
+            f.grp = sliding_min<W_C ? W_C : 1>(f.grp);
+        } else {
+            f.grp = group_of_key(f.key);
         }
-        // ---- runs of equal home line among the active lanes ----
-        uint32_t prev_line[NB];
-#pragma unroll
-        for (int u = 0; u < NB; ++u) {
-            line[u] = home_of_group(grp[u], st.nbuckets);
-            prev_line[u] = lane_up1(line[u]);
-        }
-        uint32_t maxruns = 0;
-#pragma unroll
-        for (int u = 0; u < NB; ++u) {
-            // (lane masks on the scalar unit: a run starts at an active lane whose predecessor is inactive or on another
-            // line; lane 0 has no predecessor — the shift leaves its bit clear)
-            const unsigned long long lmask = amask[u] & (~(amask[u] << 1) | __builtin_amdgcn_ballot_w64(line[u] != prev_line[u]));
-            leader[u] = __builtin_amdgcn_inverse_ballot_w64(lmask);
-            rid[u] = lanes_le_index(lmask, 0u);  // run id of an active lane
-            nruns[u] = (uint32_t)__popcll(lmask);
-            maxruns = max(maxruns, nruns[u]);
-            m0[u] = m1[u] = 0;
-            rcode[u] = 0;
-            padline[u] = lmask ? (uint32_t)__builtin_amdgcn_readlane((int)line[u], __builtin_ctzll(lmask)) : 0u;  // (wave-uniform)
-        }
+        // ---- runs of equal home line among the active lanes (lane masks on the scalar unit: a run starts at an active
+        // lane whose predecessor is inactive or on another line; lane 0 has no predecessor — the shift leaves its bit clear)
+        f.line = home_of_group(f.grp, st.nbuckets);
+        const uint32_t prev_line = lane_up1(f.line);
+        f.lmask = f.amask & (~(f.amask << 1) | __builtin_amdgcn_ballot_w64(f.line != prev_line));
+        f.rid = lanes_le_index(f.lmask, 0u);  // run id of an active lane
+        f.nruns = (uint32_t)__popcll(f.lmask);
+        f.padline = f.lmask ? (uint32_t)__builtin_amdgcn_readlane((int)f.line, __builtin_ctzll(f.lmask)) : 0u;  // (wave-uniform)
 #if PG_ABLATE == 3  // (timing experiment: keys, minimizers and runs only — no table access)
-        for (uint32_t r0 = 0; r0 < maxruns && line[0] == 0xDEADBEEFu; r0 += MAXRUN) {
-#else
-        for (uint32_t r0 = 0; r0 < maxruns; r0 += MAXRUN) {  // one trip unless a batch has > MAXRUN lines
+        if (f.line != 0xDEADBEEFu) f.nruns = 0;
 #endif
-            uint32_t nl[NB];
+        return f;
+    };
+    // ---- the fetch of a staging step: runs r0 .. r0 + MAXRUN - 1 of the batch, MAXRUN lines = MAXRUN * SLOTS chunks of 16
+    // bytes, coalesced, all loads of the step in flight.  The step's line numbers go through lines_w, one per run; the
+    // entries behind the last run repeat the first run's line (the same address again inside one load: no second
+    // fetch), so that a lane reads its entries at fixed places — no clamp of the entry's number, one LDS instruction for
+    // all of a lane's entries.  Loads are unconditional: any predicate makes the compiler sink each load into its own
+    // branch and wait for it there.  A lane always fetches chunk lane % SLOTS of a line: its address = the lane's own
+    // base + line x line bytes, one multiply-add (the line bytes come from the table's descriptor, a scalar the
+    // compiler cannot turn into a 64-bit shift and a 64-bit add).
+    struct Lines {  // the step's 16-byte chunks on their way into this lane's registers
+        uint4 v[STAGE_ITERS];
+    };
+    auto issue = [&](const Front &f, const uint32_t r0) __attribute__((always_inline)) {
+        Lines L;
+        const uint32_t nl = min((uint32_t)MAXRUN, f.nruns - r0);  // (0 for a batch without runs: r0 is 0 then)
+        const bool leader = __builtin_amdgcn_inverse_ballot_w64(f.lmask);
+        if (lane < MAXRUN) lines_w[0][lane] = f.padline;
+        if (leader && f.rid - r0 < nl) lines_w[0][f.rid - r0] = f.line;
+        __syncthreads();
+        uint32_t ln[STAGE_ITERS];
 #pragma unroll
-            for (int u = 0; u < NB; ++u) {
-                nl[u] = nruns[u] > r0 ? min((uint32_t)MAXRUN, nruns[u] - r0) : 0u;
-                // the step's line numbers, one per run; the entries behind the last run repeat the first run's line (the
-                // same address again inside one load: no second fetch), so that the staging lanes below read theirs at
-                // fixed places — no clamp of the entry's number, one LDS instruction for all of a lane's entries
-                if (lane < MAXRUN) lines_w[u][lane] = padline[u];
-                if (leader[u] && rid[u] - r0 < nl[u]) lines_w[u][rid[u] - r0] = line[u];
-            }
-            __syncthreads();
-            // stage: MAXRUN lines = MAXRUN*SLOTS chunks of 16 bytes, coalesced, all loads of the step in flight.
-            // Loads AND LDS writes are unconditional: any predicate here makes the compiler sink each load
-            // into its own branch and wait for it there
-            // (a lane always fetches chunk lane % SLOTS of a line: its address = the lane's own base + line x line bytes,
-            // one multiply-add — the line bytes come from the table's descriptor, a scalar the compiler cannot turn into
-            // a 64-bit shift and a 64-bit add)
-            uint4 v[NB][STAGE_ITERS];
-#pragma unroll
-            for (int u = 0; u < NB; ++u) {
-                uint32_t ln[STAGE_ITERS];
-#pragma unroll
-                for (int it = 0; it < STAGE_ITERS; ++it) {
-                    ln[it] = lines_w[u][it * (64 / SLOTS) + lane / SLOTS];
+        for (int it = 0; it < STAGE_ITERS; ++it) {
+            ln[it] = lines_w[0][it * (64 / SLOTS) + lane / SLOTS];
 #if PG_ABLATE == 1  // (timing experiment, wrong rows: every fetch a cache hit — the lines of one 64 KB window)
-                    ln[it] &= 511u;
+            ln[it] &= 511u;
 #endif
-                }
-#pragma unroll
-                for (int it = 0; it < STAGE_ITERS; ++it)
-                    v[u][it] = *reinterpret_cast<const uint4 *>(chunk_base + (uint64_t)ln[it] * lbytes);
-            }
-#pragma unroll
-            for (int u = 0; u < NB; ++u)
-#pragma unroll
-                for (int it = 0; it < STAGE_ITERS; ++it) {
-                    const uint32_t idx = it * 64 + lane;
-                    buf[u][(idx / SLOTS) * LDS_LINE_U4 + (idx % SLOTS)] = v[u][it];
-                }
-            __syncthreads();
-#pragma unroll
-            for (int u = 0; u < NB; ++u)
-#if PG_ABLATE == 5  // (timing experiment: lines fetched and staged, no slot scan: every lane "hits" with one LDS word)
-                if (act[u] && rid[u] - r0 < nl[u]) {
-                    rcode[u] = 1;
-                    m0[u] = m1[u] = reinterpret_cast<const uint32_t *>(buf[u] + (rid[u] - r0) * LDS_LINE_U4)[2];
-                } else if (false)
-#else
-                if (act[u] && rid[u] - r0 < nl[u])
-#endif
-                {
-                    if constexpr (WIDE) {
-                        rcode[u] = scan_keys16_lds(buf[u] + (rid[u] - r0) * LDS_LINE_U4, key[u], m1[u]);
-                        m0[u] = line[u];
-                    } else {
-                        rcode[u] = scan_line_lds<TWO, SLOTS>(buf[u] + (rid[u] - r0) * LDS_LINE_U4, key[u], m0[u], m1[u]);
-                    }
-                }
-            __syncthreads();
         }
-
-        // ---- overflow: absent from a full line -> queue entry for the next line of its sequence ----
 #pragma unroll
-        for (int u = 0; u < NB; ++u) {
-            // (sicmp = the compare as a lane mask, predicate 40 = signed less-than: a ballot of `rcode < 0` is sunk into the
-            // blocks rcode comes from and its bool rebuilt here through 0 / 1)
-            const unsigned long long omask = amask[u] & __builtin_amdgcn_sicmp(rcode[u], 0, 40);
-            const bool ovf = __builtin_amdgcn_inverse_ballot_w64(omask);
-            if (omask) {
-                uint32_t step, nx;
-                if constexpr (GROUP_CHAIN == 1) {  // (tuning build: the group owns its home line only — level 1 is the key's own sequence)
-                    key_sequence(key[u], st.nbuckets, nx, step);
-                } else {
-                    step = step_of_group(grp[u], st.nbuckets);
-                    nx = next_line(line[u], step, st.nbuckets);
-                }
-                const uint32_t slot = lanes_le_index(omask, qn);
-                if (ovf) {
-                    if (slot < (uint32_t)PROBE_QCAP) {
-                        q_line[slot] = nx;
-                        q_step[slot] = step;
-                        q_pl[slot] = (uint16_t)pl[u];
-                    } else {
-                        const uint2 mm2 = WIDE ? lane_chase_wide_cold(st.buckets, st.nbuckets, key[u], 1u, nx, step)
-                                               : lane_chase_cold<TWO, SLOTS>(st.buckets, st.nbuckets, key[u], 1u, nx, step);  // queue full
-                        m0[u] = mm2.x;
-                        m1[u] = mm2.y;
-                    }
-                }
-                qn = min(qn + (uint32_t)__popcll(omask), (uint32_t)PROBE_QCAP);
+        for (int it = 0; it < STAGE_ITERS; ++it) L.v[it] = *reinterpret_cast<const uint4 *>(chunk_base + (uint64_t)ln[it] * lbytes);
+        return L;
+    };
+    // ---- the rest of the batch: its lines into LDS, every lane scans its own; overflow entries; the rows ----
+    auto back = [&](const Front &f, const Lines &L, const uint32_t b0) __attribute__((always_inline)) {
+        const bool act = __builtin_amdgcn_inverse_ballot_w64(f.amask), inrange = __builtin_amdgcn_inverse_ballot_w64(f.rmask);
+        const int32_t pl = (int32_t)(b0 + lane) - HALO;
+        uint32_t m0 = 0, m1 = 0;
+        int rcode = 0;
+        // a staging step's chunks into LDS (wave-uniform placement: chunk idx of the step -> line idx / SLOTS, slot
+        // idx % SLOTS), then every lane of the step's runs scans its own line
+        auto stage_scan = [&](const Lines &S, const uint32_t r0) __attribute__((always_inline)) {
+            const uint32_t nl = min((uint32_t)MAXRUN, f.nruns - r0);
+#pragma unroll
+            for (int it = 0; it < STAGE_ITERS; ++it) {
+                const uint32_t idx = it * 64 + lane;
+                buf[0][(idx / SLOTS) * LDS_LINE_U4 + (idx % SLOTS)] = S.v[it];
             }
-            // (32-bit offset from the tile's uniform base: one store with a scalar base address)
-            if constexpr (WIDE) {
-                if (inrange[u]) store_row_wide(st.masks, st.W, nbytes, tile_rows + (uint64_t)(uint32_t)pl[u] * nbytes, m0[u], m1[u]);
-            } else {
-                if constexpr (ROWMODE == 3) {
-                    const uint32_t b = b0 + u * STRIDE;
-                    const uint32_t w0 = b >> 6, sh = b & 63u;
-                    for (uint32_t j = 0; j < rc.col0; ++j) {  // (uniform) one ballot per genome of the block
-                        const unsigned long long shifted = __ballot(inrange[u] && ((m0[u] >> j) & 1u)) >> HALO;  // bit i = position b + i
-                        if (lane == 0 && shifted) {
-                            cols[w0 * COLS_G + j] |= shifted << sh;
-                            if (sh && (shifted >> (64u - sh))) cols[(w0 + 1) * COLS_G + j] |= shifted >> (64u - sh);
-                        }
-                    }
-                } else {
-#if PG_ABLATE == 2  // (timing experiment: no row store unless a value no mask has turns up)
-                    if (inrange[u] && m0[u] == 0xDEADBEEFu)
+            __syncthreads();
+#if PG_ABLATE == 5  // (timing experiment: lines fetched and staged, no slot scan: every lane "hits" with one LDS word)
+            if (act && f.rid - r0 < nl) {
+                rcode = 1;
+                m0 = m1 = reinterpret_cast<const uint32_t *>(buf[0] + (f.rid - r0) * LDS_LINE_U4)[2];
+            }
 #else
-                    if (inrange[u])
-#endif
-                        store_row<ROWMODE>(tile_rows + (ROWMODE == 1 ? (uint32_t)pl[u] : (uint32_t)pl[u] * nbytes), m0[u], m1[u], rc);
+            if (act && f.rid - r0 < nl) {
+                if constexpr (WIDE) {
+                    rcode = scan_keys16_lds(buf[0] + (f.rid - r0) * LDS_LINE_U4, f.key, m1);
+                    m0 = f.line;
+                } else {
+                    rcode = scan_line_lds<TWO, SLOTS>(buf[0] + (f.rid - r0) * LDS_LINE_U4, f.key, m0, m1);
                 }
             }
+#endif
+            __syncthreads();
+        };
+        if (f.nruns) stage_scan(L, 0u);
+        for (uint32_t r0 = MAXRUN; r0 < f.nruns; r0 += MAXRUN) stage_scan(issue(f, r0), r0);  // (a batch with more than MAXRUN lines: rare)
+        // ---- overflow: absent from a full line -> queue entry for the next line of its sequence ----
+        // (sicmp = the compare as a lane mask, predicate 40 = signed less-than: a ballot of `rcode < 0` is sunk into the
+        // blocks rcode comes from and its bool rebuilt here through 0 / 1)
+        const unsigned long long omask = f.amask & __builtin_amdgcn_sicmp(rcode, 0, 40);
+        const bool ovf = __builtin_amdgcn_inverse_ballot_w64(omask);
+        if (omask) {
+            uint32_t step, nx;
+            if constexpr (GROUP_CHAIN == 1) {  // (tuning build: the group owns its home line only — level 1 is the key's own sequence)
+                key_sequence(f.key, st.nbuckets, nx, step);
+            } else {
+                step = step_of_group(f.grp, st.nbuckets);
+                nx = next_line(f.line, step, st.nbuckets);
+            }
+            const uint32_t slot = lanes_le_index(omask, qn);
+            if (ovf) {
+                if (slot < (uint32_t)PROBE_QCAP) {
+                    q_line[slot] = nx;
+                    q_step[slot] = step;
+                    q_pl[slot] = (uint16_t)pl;
+                } else {
+                    const uint2 mm2 = WIDE ? lane_chase_wide_cold(st.buckets, st.nbuckets, f.key, 1u, nx, step)
+                                           : lane_chase_cold<TWO, SLOTS>(st.buckets, st.nbuckets, f.key, 1u, nx, step);  // queue full
+                    m0 = mm2.x;
+                    m1 = mm2.y;
+                }
+            }
+            qn = min(qn + (uint32_t)__popcll(omask), (uint32_t)PROBE_QCAP);
+        }
+        // (32-bit offset from the tile's uniform base: one store with a scalar base address)
+        if constexpr (WIDE) {
+            if (inrange) store_row_wide(st.masks, st.W, nbytes, tile_rows + (uint64_t)(uint32_t)pl * nbytes, m0, m1);
+        } else if constexpr (ROWMODE == 3) {
+            const uint32_t w0 = b0 >> 6, sh = b0 & 63u;
+            for (uint32_t j = 0; j < rc.col0; ++j) {  // (uniform) one ballot per genome of the block
+                const unsigned long long shifted = __ballot(inrange && ((m0 >> j) & 1u)) >> HALO;  // bit i = position b0 + i
+                if (lane == 0 && shifted) {
+                    cols[w0 * COLS_G + j] |= shifted << sh;
+                    if (sh && (shifted >> (64u - sh))) cols[(w0 + 1) * COLS_G + j] |= shifted >> (64u - sh);
+                }
+            }
+        } else {
+#if PG_ABLATE == 2  // (timing experiment: no row store unless a value no mask has turns up)
+            if (inrange && m0 == 0xDEADBEEFu)
+#else
+            if (inrange)
+#endif
+                store_row<ROWMODE>(tile_rows + (ROWMODE == 1 ? (uint32_t)pl : (uint32_t)pl * nbytes), m0, m1, rc);
         }
     };
-    batch(std::true_type{}, 0u);
-    for (uint32_t b0 = NB * STRIDE; b0 < npos; b0 += NB * STRIDE) batch(std::false_type{}, b0);
+    // The skewed order — front end of batch i + 1 between the fetch of batch i and its use — keeps the fetched chunks
+    // and two batches' keys in registers at once: it pays where that still fits 64 registers (8 waves per SIMD: this
+    // kernel's speed goes with its occupancy — 7 waves cost 7 %, 5 waves 28 %), i.e. for the one-byte rows of up to 8
+    // genomes (configs[1]: 4.31 -> 4.17 ms); the wider instantiations spill there and keep the plain order.
+    constexpr bool PIPE = probe_pipelined<W_C, TWO, ROWMODE, SLOTS, WIDE>;
+    if constexpr (PIPE) {
+        Lines L;
+#pragma unroll
+        for (int it = 0; it < STAGE_ITERS; ++it) L.v[it] = make_uint4(0, 0, 0, 0);
+        Front cur = front(std::true_type{}, 0u);
+        if (cur.nruns) L = issue(cur, 0u);
+        for (uint32_t b0 = 0; b0 < npos; b0 += STRIDE) {
+            const bool more = b0 + STRIDE < npos;  // (wave-uniform)
+            Front nxt = cur;
+            __builtin_amdgcn_sched_barrier(0);  // (the parts stay apart: interleaved by the scheduler they keep both batches' temporaries alive)
+            if (more) nxt = front(std::false_type{}, b0 + STRIDE);  // while the lines of `cur` are on their way
+            __builtin_amdgcn_sched_barrier(0);
+            back(cur, L, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) {
+                cur = nxt;
+                if (cur.nruns) L = issue(cur, 0u);
+            }
+        }
+    } else {
+        auto whole = [&](auto first_tag, const uint32_t b0) __attribute__((always_inline)) {
+            const Front f = front(first_tag, b0);
+            const Lines L = issue(f, 0u);  // (also for a batch without runs — a stretch of N: line 0 is fetched and ignored)
+            back(f, L, b0);
+        };
+        whole(std::true_type{}, 0u);
+        for (uint32_t b0 = STRIDE; b0 < npos; b0 += STRIDE) whole(std::false_type{}, b0);
+    }
 
     constexpr int LEVELS = (W_C >= 6 && !TWO && !WIDE && PROBE_STAGED_LEVELS > 1) ? 1 : PROBE_STAGED_LEVELS;  // (W_C >= 6: the wide-window tables of up to 16 genomes)
     drain_queue<TWO, ROWMODE, SLOTS, MAXRUN, WIDE, LEVELS>(st, qn, sw, rw, q_line, q_step, q_pl, lines_w[0], buf[0], tile_rows, nbytes, rc, lane);

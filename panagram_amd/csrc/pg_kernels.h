@@ -16,10 +16,6 @@ constexpr int PROBE_MAXRUN = PG_PROBE_MAXRUN;  // table lines staged in LDS per 
 #define PG_PROBE_STAGED_LEVELS 2
 #endif
 constexpr int PROBE_STAGED_LEVELS = PG_PROBE_STAGED_LEVELS;  // LDS-staged overflow levels; beyond: lanes chase inline
-#ifndef PG_PROBE_NB
-#define PG_PROBE_NB 1
-#endif
-constexpr int PROBE_NB = PG_PROBE_NB;          // independent 64-lane batches in flight per wave iteration
 #ifndef PG_PROBE_QCAP
 #define PG_PROBE_QCAP (PG_PROBE_TILE * 3 / 8)
 #endif
