@@ -412,6 +412,8 @@ def north_star_leg(ctx, dev, args):
         "value": pos * steps / dt, "unit": "k-mers/s", "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * dt / steps,
         "positions_per_step": pos, "k_probe_ms": p_ms, "k_epilogue_ms": e_ms, "launches_averaged": nruns,
         "table_keys": pg.stats["nkeys"], "table_bytes": pg.stats["bytes"], "table_build_s": pg.build_s,
+        "launch_note": "a run of this size goes out in 16 chunks, the statistics pass of a chunk beside the next chunk's probe "
+                       "(DESIGN.md 7.2): k_probe_ms / k_epilogue_ms are the two streams' spans, not a sum",
         "rows_equal_gpu": ok,
         "rows_check": f"first {sample_n} positions of genomes {picks}: CPU oracle rows (k-mer DB of the sample built by "
                       f"brute force with torch in {db_s:.1f} s, {sum(len(kk) for kk, _ in dbs)} keys) == GPU rows of the timed result",

@@ -1865,7 +1865,8 @@ static int build_chunks(pg_result *r, const uint32_t *sched) {
     const char *env = getenv("PG_RUN_CHUNKS");
     const uint32_t nbytes = (r->N + 7) / 8;
     uint32_t K = env ? (uint32_t)atoi(env) : ((nbytes == 8 && r->ntiles >= (4u << 20)) ? 16u : 1u);
-    K = std::min(K, r->ntiles / 32768u);
+    const char *mt = getenv("PG_CHUNK_MIN_TILES");  // (tests: chunks of a few tiles)
+    K = std::min(K, r->ntiles / std::max(1u, mt ? (uint32_t)atoi(mt) : 32768u));
     if (K < 2) return PG_OK;
     std::vector<uint2> ranges;
     for (uint32_t c = 0; c < K; ++c) {

@@ -927,3 +927,54 @@ def test_corrupt_kmc_total_is_a_format_error_not_a_crash(ctx):
         tbl.load_kmc(0, bytes(pre), suf)
     assert "truncated" in str(ei.value)
     tbl.close()
+
+
+@pytest.mark.parametrize("n,k,chunks", [(7, 21, 3), (27, 21, 5), (64, 31, 4), (70, 21, 6)])
+def test_a_run_in_chunks_equals_the_run_in_one_launch(ctx, n, k, chunks, monkeypatch):
+    """pg_anchor_run as several probe launches (slices of the co-schedule) with the statistics pass of every slice on
+    the side stream over the tile ranges the slice touches (PG_RUN_CHUNKS; the default for huge 8-byte-row runs): rows,
+    bitmap.100, bins and column sums are those of the single launch + single pass — every row width class, schedules
+    by group and by class, and in plain tile order."""
+    from panagram_amd import engine
+    lens = [30000, 9000, 2600, 700]
+    gen = po.synth_genomes(n, lens, 0.02, 2000 + n)
+    genomes = [[po.codes_to_ascii(c) for c in g] for g in gen]
+    tbl = engine.PanTable(ctx, k, n)
+    sets = []
+    for g in range(n):
+        ss = engine.SeqSet.from_host(ctx, genomes[g])
+        tbl.insert_seqset(g, ss)
+        sets.append(ss)
+    anchors = [0, 1, n - 1]
+    merged = engine.SeqSet.concat(ctx, [sets[g] for g in anchors])
+    groups = np.repeat(np.arange(len(anchors)), len(lens))
+    ncontigs = len(groups)
+
+    def outputs(schedule):
+        res = engine.AnchorResult(tbl, merged, colsums=True)
+        if schedule == "groups":
+            res.coschedule(groups, 2)
+        elif schedule == "classes":
+            res.coschedule(groups, 3, contig_class=np.tile(np.arange(len(lens))[::-1], len(anchors)))
+        res.run()
+        res.run()  # (a second run over the same result: the side stream's previous pass is joined first)
+        out = [res.download(ci)[:3] for ci in range(ncontigs)], res.contig_colsums().copy()
+        res.close()
+        return out
+
+    monkeypatch.setenv("PG_RUN_CHUNKS", "1")
+    want = {s_: outputs(s_) for s_ in ("groups", "classes", "order")}
+    monkeypatch.setenv("PG_RUN_CHUNKS", str(chunks))
+    monkeypatch.setenv("PG_CHUNK_MIN_TILES", "4")
+    for s_ in ("groups", "classes", "order"):
+        got = outputs(s_)
+        for ci in range(ncontigs):
+            for x, y in zip(got[0][ci], want[s_][0][ci]):
+                assert np.array_equal(x, y), (s_, ci)
+        assert np.array_equal(got[1], want[s_][1]), s_
+    o = po.anchor_contig(po.build_bitvec_dbs(genomes, k), genomes[1][0], k, n)
+    assert np.array_equal(want["groups"][0][len(lens)][0], o[0])
+    merged.close()
+    for ss in sets:
+        ss.close()
+    tbl.close()
