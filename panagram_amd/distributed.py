@@ -192,32 +192,26 @@ def _plan_signature(index, world: int, plan_digest: str) -> str:
     return h.hexdigest()
 
 
-def _claim(path: str) -> bool:
-    """exclusive creation of ``path`` (who assembles a genome); a claim left by a process of this host that no longer
-    exists is taken over"""
-    import socket
-    me = f"{socket.gethostname()} {os.getpid()}"
-    for _ in range(2):
-        try:
-            fd = os.open(path, os.O_CREAT | os.O_EXCL | os.O_WRONLY)
-            os.write(fd, me.encode())
-            os.close(fd)
-            return True
-        except FileExistsError:
-            try:
-                host, pid = open(path).read().split()
-                if host != socket.gethostname():
-                    return False
-                os.kill(int(pid), 0)
-                return False  # alive: it is assembling
-            except (ProcessLookupError, ValueError):
-                try:
-                    os.remove(path)
-                except FileNotFoundError:
-                    pass
-            except (FileNotFoundError, PermissionError):
-                return False
-    return False
+def _claim(path: str) -> Optional[int]:
+    """Who assembles a genome: an exclusive advisory lock (``flock``) on ``path``, created if need be.  Returns the open
+    descriptor — the claim is held for as long as it stays open, and the kernel drops it with the process, so a rank that
+    died leaves no claim behind — or None: another rank holds it, or the directory is gone (the genome was assembled
+    and cleaned up meanwhile).  (A claim file created with O_EXCL and filled afterwards could be read empty by a second
+    rank, taken for a dead process's, removed and claimed again: two ranks assembling one genome at once, seen on the
+    GPU box under torchrun.)  A lock on a name that was removed since it was opened excludes nobody: it is refused."""
+    import fcntl
+    try:
+        fd = os.open(path, os.O_CREAT | os.O_RDWR, 0o644)
+    except FileNotFoundError:
+        return None
+    try:
+        fcntl.flock(fd, fcntl.LOCK_EX | fcntl.LOCK_NB)
+        if os.fstat(fd).st_ino == os.stat(path).st_ino:  # (only a holder of the claim removes the name: it stays ours)
+            return fd
+    except OSError:
+        pass
+    os.close(fd)
+    return None
 
 
 def run_index_sharded(index, rank: int, world: int, barrier: Optional[Callable[[], None]] = None,
@@ -385,8 +379,15 @@ def run_index_sharded(index, rank: int, world: int, barrier: Optional[Callable[[
             return False
         os.makedirs(pdir, exist_ok=True)
         lock = os.path.join(pdir, "assemble.lock")
-        if not _claim(lock):
+        claim = _claim(lock)
+        if claim is None:
             return False
+        try:
+            return assemble_under_claim(name, g, ps, pdir, lock, load_markers)
+        finally:
+            os.close(claim)
+
+    def assemble_under_claim(name, g, ps, pdir, lock, load_markers) -> bool:
         # (whoever assembled meanwhile removed the markers BEFORE giving up its claim: seeing them all under our own
         # claim means the genome is ours to assemble)
         metas = load_markers()
@@ -432,8 +433,11 @@ def run_index_sharded(index, rank: int, world: int, barrier: Optional[Callable[[
             os.remove(base(p) + ".npz")
         for f in os.listdir(pdir):
             if f != "assemble.lock":
-                os.remove(os.path.join(pdir, f))
-        shutil.rmtree(pdir)  # (the claim goes last)
+                try:
+                    os.remove(os.path.join(pdir, f))
+                except FileNotFoundError:  # (another rank's claim attempt, written aside and gone again)
+                    pass
+        shutil.rmtree(pdir, ignore_errors=True)  # (the claim goes last; a rank that finds the directory again finds no marker)
         return True
 
     todo = [n for n in anchors]

@@ -639,6 +639,34 @@ class Index:
             return
         from concurrent.futures import ThreadPoolExecutor
         os.makedirs(self.get_subdir("logs"), exist_ok=True)
+        own_group = self._ensure_process_group()
+        try:
+            self._run_planned(ThreadPoolExecutor)
+        finally:
+            if own_group:
+                self._dist().destroy_process_group()
+
+    def _ensure_process_group(self) -> bool:
+        """Under a launcher that set up a rendezvous (torchrun: MASTER_ADDR / MASTER_PORT, RANK, WORLD_SIZE) a run with
+        several ranks joins the process group itself — backend "nccl" (= RCCL over xGMI), this rank's GPU — so that the
+        ranks can agree on the plan and, in the genome-sharded mode, exchange their bit columns.  Returns whether this
+        call created the group (the caller then destroys it).  Without a rendezvous in the environment (ranks run by
+        hand, one after the other: the tests) nothing is initialised — the contig-sharded mode needs no group."""
+        if self.world <= 1 or "MASTER_ADDR" not in os.environ or int(os.environ.get("WORLD_SIZE", "1")) != self.world:
+            return False
+        import torch
+        import torch.distributed as dist
+        if dist.is_initialized():
+            return False
+        backend = os.environ.get("PG_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            torch.cuda.set_device(self.device)
+            dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=torch.device("cuda", self.device))
+        else:
+            dist.init_process_group(backend, rank=self.rank, world_size=self.world)
+        return True
+
+    def _run_planned(self, ThreadPoolExecutor):
         mode, nblocks = self.plan_sharding()
         self._check_plan_agreed((mode, nblocks))
         if mode == "genome":

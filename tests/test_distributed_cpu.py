@@ -339,3 +339,46 @@ def test_index_run_deals_pieces_of_homology_classes(world, tmp_path, monkeypatch
         (tmp_path / "many" / "anchor" / "g0" / "bitsum.genes.tsv").read_bytes()
     genes = pd.read_table(tmp_path / "many" / "anchor" / "g0" / "bitsum.genes.tsv", index_col="chr")
     assert genes.loc["chr1"].sum() > 0
+
+
+def _claim_racer(path, rounds, start, done, q):
+    from panagram_amd.distributed import _claim
+    wins = []
+    for r in range(rounds):
+        start.wait()
+        fd = _claim(f"{path}.{r}")
+        wins.append(fd is not None)
+        done.wait()  # the winner holds its claim until every racer has had its go
+        if fd is not None:
+            os.close(fd)
+    q.put(wins)
+
+
+@pytest.mark.parametrize("stale", [False, True])
+def test_the_assembly_claim_has_one_winner(stale, tmp_path):
+    """Eight processes go for the same claim at the same moment, 400 times over: exactly one gets each.  (A claim created
+    empty and filled afterwards let a second rank read it in between and take it for a dead process's: two ranks
+    assembled one genome at once — seen on the GPU box under torchrun.)  ``stale``: every claim file is already there,
+    left by a process that no longer exists; still one winner."""
+    import multiprocessing as mp
+    from panagram_amd.distributed import _claim
+    ctx = mp.get_context("fork")
+    n, rounds = 8, 400
+    path = str(tmp_path / "assemble.lock")
+    if stale:
+        for r in range(rounds):
+            with open(f"{path}.{r}", "w") as f:
+                f.write("left behind")
+    start, done, q = ctx.Barrier(n), ctx.Barrier(n), ctx.Queue()
+    procs = [ctx.Process(target=_claim_racer, args=(path, rounds, start, done, q)) for _ in range(n)]
+    for p in procs:
+        p.start()
+    wins = np.array([q.get(timeout=120) for _ in procs])
+    for p in procs:
+        p.join(30)
+    assert (wins.sum(axis=0) == 1).all(), np.flatnonzero(wins.sum(axis=0) != 1)
+    fd = _claim(path + ".0")  # released with the descriptor
+    assert fd is not None and _claim(path + ".0") is None
+    os.remove(path + ".0")
+    os.close(fd)
+    assert _claim(str(tmp_path / "gone" / "assemble.lock")) is None  # (the genome's .parts directory cleaned up)

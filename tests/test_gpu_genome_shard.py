@@ -364,3 +364,30 @@ def test_two_processes_on_one_gpu(name, shard, nblocks, chunk, exchange, tmp_pat
     mp.spawn(_two_rank_worker, args=(2, port, str(s), str(out), int(fx["k"]), [f"g{g}" for g in fx["anchors"]], shard, nblocks, chunk),
              nprocs=2, join=True)
     _check_tree(out, fx, gzi_like_reference=shard != "replicated")
+
+
+@pytest.mark.parametrize("shard,nblocks", [(None, 0), ("genome", 2)])
+def test_cli_under_torchrun_joins_the_group_itself(shard, nblocks, tmp_path):
+    """`python -m torch.distributed.run --nproc-per-node 2 -m panagram_amd index …`: nobody initialises torch.distributed
+    for the CLI, so Index.run() joins the launcher's rendezvous itself (index._ensure_process_group) — without that the
+    genome-sharded mode has no group to exchange columns over and the ranks cannot check that they agree on the plan.
+    (gloo instead of RCCL and --device 0 for both ranks: this box has one GPU.)"""
+    import os
+    import subprocess
+    import sys
+    fx = H.load_case("n8_k21")
+    s = _write_case(tmp_path, fx)
+    out = tmp_path / "idx"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PG_DIST_BACKEND="gloo", PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    for v in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "PG_SHARD", "PG_GENOME_BLOCKS"):
+        env.pop(v, None)
+    if shard:
+        env.update(PG_SHARD=shard, PG_GENOME_BLOCKS=str(nblocks))
+    port = 29700 + (os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), "-m", "panagram_amd", "index", str(s), "-o", str(out), "-k", str(int(fx["k"])),
+           "--device", "0", "--anchor_genomes", *[f"g{g}" for g in fx["anchors"]]]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert p.returncode == 0, "\n".join(ln for ln in p.stderr.splitlines() if "Traceback" in ln or "Error" in ln or ln.startswith("  File"))[-4000:]
+    _check_tree(out, fx, gzi_like_reference=shard == "genome")
