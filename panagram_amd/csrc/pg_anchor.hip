@@ -326,6 +326,14 @@ __device__ __forceinline__ void store_row(uint8_t *row, uint32_t m0, uint32_t m1
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
     if (ROWMODE == 1) {
         row[0] = (uint8_t)m0;
+    } else if (ROWMODE == 4) {  // four-byte rows (25..32 genomes): one aligned dword
+        *reinterpret_cast<uint32_t *>(row) = m0;
+    } else if (ROWMODE == 5) {  // two-byte rows (9..16 genomes)
+        *reinterpret_cast<uint16_t *>(row) = (uint16_t)m0;
+    } else if (ROWMODE == 6) {  // three-byte rows (17..24 genomes): two stores at byte alignment
+        struct __attribute__((packed)) U16 { uint16_t v; };
+        reinterpret_cast<U16 *>(row)->v = (uint16_t)m0;
+        row[2] = (uint8_t)(m0 >> 16);
     } else if (ROWMODE == 2 || rc.words == 4) {  // (rc.words == 4: both words at an 8-byte aligned column: one store)
         u32x2 q = {m0, m1};
         uint8_t *p = row + (ROWMODE == 2 ? 0u : rc.col0);
@@ -526,7 +534,7 @@ __device__ __forceinline__ void drain_queue(const SubTable &st, uint32_t qn, con
 // (probe_pipelined: the instantiations that run the skewed batch order, see the end of the kernel; they are held to the 64
 // registers of 8 waves per SIMD — the only spill that costs them sits around the queue-full call, a cold path)
 template <int W_C, bool TWO, int ROWMODE, int SLOTS, bool WIDE>
-constexpr bool probe_pipelined = PG_PROBE_PIPE && ROWMODE == 1 && !TWO && !WIDE && SLOTS == 8 && W_C != 6;
+constexpr bool probe_pipelined = PG_PROBE_PIPE && (ROWMODE == 1 || ROWMODE >= 4) && !TWO && !WIDE && SLOTS == 8 && W_C != 6;
 // The scalar registers count too: a SIMD's 800 SGPRs admit floor(800 / (ceil(sgpr / 16) * 16 + 16)) waves — 8 up to 80, 7 up to
 // 96, 6 up to 112 (MI355X_MICROARCH.md) — whatever the compiler's own occupancy figure says.  Left alone the generic-row and
 // split-layout instantiations took 92 and 105 (their lane masks live on the scalar unit): 7 and 6 waves.  Held to 80, a dozen
@@ -772,12 +780,33 @@ __attribute__((amdgpu_num_sgpr(80))) void k_probe(const SubTable st, const uint6
                 }
             }
         } else {
+            if constexpr (ROWMODE == 6) {
+                // Three-byte rows as ALIGNED dwords: a u16 and a u8 per lane at odd addresses cost the launch a third
+                // of its time (20 x 40 Mb: 6.7 ps per position against 5.1 with the four-byte rows of 27 genomes).
+                // The batch's rows are 3 x 58 consecutive bytes; the aligned dword that starts inside a lane's row
+                // holds the row's last 3 - j bytes and the next lane's first j + 1 (j = 0..2 by the row's address
+                // mod 4; a row that starts at byte 1 of a dword starts none) — the next lane's mask comes over one DPP
+                // shift, and ~43 lanes write whole dwords.  The lane without a successor in the batch (lane 63, or the
+                // tile's last position) and the batch's first position, whose leading bytes no lane of this batch
+                // covers, write their own three bytes as before; stores that overlap write equal bytes.
+                const uint32_t nxt = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m0, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+                const uint32_t o4 = (uint32_t)reinterpret_cast<uintptr_t>(tile_rows) & 3u;  // (a tile starts at a multiple of 512 rows)
+                const uint32_t j = ((uint32_t)pl - o4) & 3u;
+                const uint32_t lo = (nxt << 24) | (m0 & 0xFFFFFFu);
+                const uint32_t dw = __builtin_amdgcn_alignbit(nxt >> 8, lo, 8u * j);
+                const unsigned long long nextin = f.rmask >> 1;
+                const unsigned long long dmask = f.rmask & nextin & __builtin_amdgcn_ballot_w64(j != 3u);
+                const unsigned long long fmask = f.rmask & ((1ull << HALO) | ~nextin);
+                uint8_t *row = tile_rows + (uint32_t)pl * 3u;
+                if (__builtin_amdgcn_inverse_ballot_w64(dmask)) *reinterpret_cast<uint32_t *>(row + j) = dw;
+                if (__builtin_amdgcn_inverse_ballot_w64(fmask)) store_row<ROWMODE>(row, m0, m1, rc);
+            } else
 #if PG_ABLATE == 2  // (timing experiment: no row store unless a value no mask has turns up)
             if (inrange && m0 == 0xDEADBEEFu)
 #else
             if (inrange)
 #endif
-                store_row<ROWMODE>(tile_rows + (ROWMODE == 1 ? (uint32_t)pl : (uint32_t)pl * nbytes), m0, m1, rc);
+                store_row<ROWMODE>(tile_rows + (ROWMODE == 1 ? (uint32_t)pl : ROWMODE == 4 ? (uint32_t)pl * 4u : ROWMODE == 5 ? (uint32_t)pl * 2u : ROWMODE == 6 ? (uint32_t)pl * 3u : (uint32_t)pl * nbytes), m0, m1, rc);
         }
     };
     // The skewed order — front end of batch i + 1 between the fetch of batch i and its use — keeps the fetched chunks
@@ -2399,6 +2428,9 @@ static hipError_t probe_w(hipStream_t s, uint32_t ntiles, const SubTable &st, co
     }
     if (rowmode == 3) return probe_t<W_C, false, 3, 8>(PG_A);
     if (rowmode == 1) return probe_t<W_C, false, 1, 8>(PG_A);
+    if (rowmode == 4) return probe_t<W_C, false, 4, 8>(PG_A);
+    if (rowmode == 5) return probe_t<W_C, false, 5, 8>(PG_A);
+    if (rowmode == 6) return probe_t<W_C, false, 6, 8>(PG_A);
     return probe_t<W_C, false, 0, 8>(PG_A);
 #undef PG_A
 }
@@ -2406,6 +2438,9 @@ static hipError_t probe_w(hipStream_t s, uint32_t ntiles, const SubTable &st, co
 static int row_mode(uint32_t nbytes, const RowCols &rc) {
     if (nbytes == 1) return 1;
     if (nbytes == 8 && rc.col0 == 0 && rc.nb0 == 4 && rc.nb1 == 4) return 2;
+    if (nbytes == 4 && rc.col0 == 0 && rc.nb0 == 4 && rc.nb1 == 0) return 4;
+    if (nbytes == 2 && rc.col0 == 0 && rc.nb1 == 0) return 5;
+    if (nbytes == 3 && rc.col0 == 0 && rc.nb1 == 0) return 6;
     return 0;
 }
 
