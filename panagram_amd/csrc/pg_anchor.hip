@@ -267,7 +267,13 @@ __device__ __forceinline__ void copy_words_tail(const uint32_t *src, uint8_t *ds
         for (int i = 0; i < NS; ++i) o.w[i] = v.w[i];
         *reinterpret_cast<WordsN<NS> *>(dst) = o;
     }
-    for (uint32_t bb = 0; bb < tail; ++bb) dst[4 * NS + bb] = (uint8_t)(v.w[NS] >> (8 * bb));
+    if (NS > 0 && tail > 1) {  // (wave-uniform) the last 4 bytes of the row as one dword that overlaps the words before it — equal
+                               // bytes — instead of 2 or 3 single bytes (15-byte rows: 13.6 ps per position, 12- and 16-byte rows 9.5-9.8)
+        struct __attribute__((packed)) U32 { uint32_t v; };
+        reinterpret_cast<U32 *>(dst + 4 * NS + tail - 4)->v = __builtin_amdgcn_alignbit(v.w[NS], v.w[NS > 0 ? NS - 1 : 0], 8u * tail);
+    } else {
+        for (uint32_t bb = 0; bb < tail; ++bb) dst[4 * NS + bb] = (uint8_t)(v.w[NS] >> (8 * bb));
+    }
 }
 __device__ __forceinline__ void store_row_wide(const uint8_t *masks, uint32_t W, uint32_t nbytes, uint8_t *row, uint32_t hline,
                                                uint32_t slot1) {

@@ -306,7 +306,7 @@ def test_three_subtables_n130(ctx):
     tbl.close()
 
 
-@pytest.mark.parametrize("n", [12, 20, 27, 32, 44, 52, 96])
+@pytest.mark.parametrize("n", [12, 20, 27, 32, 44, 52, 80, 88, 96, 120])  # (80 / 88 / 120: 10-, 11- and 15-byte rows, whose tail is a dword overlapping the words before it)
 def test_rows_of_whole_words(ctx, n):
     """4- and 12-byte rows (N = 25..32, 89..96) leave the probe kernel as aligned 32-bit stores and go
     through the carry-save column sums: compare everything with the oracle"""
