@@ -1510,6 +1510,32 @@ __global__ __launch_bounds__(EPI_THREADS) void k_epilogue(uint32_t N, const Anch
         __syncthreads();
     };
 
+    // The group path of the 2..8-byte rows adds ONE to an LDS counter per row, and the lanes of a wave mostly ask for the
+    // same few counters (the popcount classes near N): the LDS works a wave's atomic off one lane per cycle and address —
+    // 0.9-1.0 ps per row whatever the row width, twice what 2-byte rows need otherwise.  While the groups lie inside one
+    // or two long bins (any contig of more than 200 kb) the window is therefore used as EPI_REPL copies of those two bin
+    // rows, lane l adding to copy l % EPI_REPL (copy c at c * repl_stride, an odd stride: the copies of one class sit in
+    // different banks); `unreplicate` folds the copies into the window's ordinary form — rows 0 and 1 — before anything
+    // else reads or flushes it.  `repl` is block-uniform.
+    constexpr uint32_t EPI_REPL = 8;  // (16 copies: no further gain, profiles/r3_ab_stats_hist_copies.txt)
+    const uint32_t repl_stride = (2u * (N + 1u)) | 1u;  // (EPI_REPL * repl_stride <= MAXB * (N + 1): MAXB >= 47 for N <= 64)
+    bool repl = false;
+    auto unreplicate = [&]() {
+        if constexpr (MODE != 1) return;
+        if (!repl) return;
+        __syncthreads();
+        for (uint32_t i = tid; i < 2u * (N + 1u); i += EPI_THREADS) {
+            uint32_t v = hist[i];
+#pragma unroll
+            for (uint32_t cpy = 1; cpy < EPI_REPL; ++cpy) {
+                v += hist[cpy * repl_stride + i];
+                hist[cpy * repl_stride + i] = 0;
+            }
+            hist[i] = v;
+        }
+        __syncthreads();
+        repl = false;
+    };
     uint4 gq_next = make_uint4(0, 0, 0, 0), gq_next2 = make_uint4(0, 0, 0, 0);  // group path: prefetched rows of the next group
     bool gq_valid = false;
     for (uint32_t tile = t_begin; tile < t_end; ++tile) {
@@ -1682,13 +1708,28 @@ __global__ __launch_bounds__(EPI_THREADS) void k_epilogue(uint32_t N, const Anch
                                 (nbg == 1u || (a.binlen >= 16u && nbg <= MAXB));
             if (grp_ok) {
                 const uint64_t row0g = a.bin_off + ts / a.binlen;
-                if (cur_row0 == ~0ull || row0g < cur_row0 || row0g + nbg > cur_row0 + MAXB) {
-                    if (cur_row0 != ~0ull) {
-                        __syncthreads();
-                        flush_hist(N, hist, bins, cur_row0, tid, MAXB);
-                        __syncthreads();
+                const bool want_repl = nbg <= 2u;  // (block-uniform)
+                if (want_repl) {
+                    if (!(repl && row0g >= cur_row0 && row0g + nbg <= cur_row0 + 2u)) {
+                        if (cur_row0 != ~0ull) {
+                            unreplicate();
+                            __syncthreads();
+                            flush_hist(N, hist, bins, cur_row0, tid, MAXB);
+                            __syncthreads();
+                        }
+                        cur_row0 = row0g;
+                        repl = true;
                     }
-                    cur_row0 = row0g;
+                } else {
+                    unreplicate();
+                    if (cur_row0 == ~0ull || row0g < cur_row0 || row0g + nbg > cur_row0 + MAXB) {
+                        if (cur_row0 != ~0ull) {
+                            __syncthreads();
+                            flush_hist(N, hist, bins, cur_row0, tid, MAXB);
+                            __syncthreads();
+                        }
+                        cur_row0 = row0g;
+                    }
                 }
                 // this thread's 16 rows: bin of the first one (relative to the group's first bin) and rows until the boundary
                 uint32_t rel0 = 0, jb = 16;
@@ -1697,7 +1738,7 @@ __global__ __launch_bounds__(EPI_THREADS) void k_epilogue(uint32_t N, const Anch
                     rel0 = bl >= span ? (d0 >= bl ? 1u : 0u) : __umulhi(d0, 0xFFFFFFFFu / bl + 1u);  // (d0 < 2^16)
                     jb = min(16u, (rel0 + 1u) * bl - d0);
                 }
-                uint32_t *hrow = hist + ((uint32_t)(row0g - cur_row0) + rel0) * (N + 1);
+                uint32_t *hrow = hist + ((uint32_t)(row0g - cur_row0) + rel0) * (N + 1) + (want_repl ? ((uint32_t)lane % EPI_REPL) * repl_stride : 0u);
                 const uint8_t *gt = out1 + a.out_off + ((uint64_t)ts + 16u * tid) * nbytes;
                 auto rows16 = [&](auto nbc) {
                     constexpr int NB = decltype(nbc)::value;
@@ -1746,6 +1787,7 @@ __global__ __launch_bounds__(EPI_THREADS) void k_epilogue(uint32_t N, const Anch
                 continue;
             }
         }
+        unreplicate();  // (the per-tile paths read the window in its ordinary form)
         const uint32_t tile_start = (tile - a.tile0) * PROBE_TILE;
         const uint32_t npos = min((uint32_t)PROBE_TILE, a.nkmers - tile_start);
         const uint32_t binlen = a.binlen, bin0 = tile_start / binlen, bin0_start = bin0 * binlen;
@@ -1927,6 +1969,7 @@ __global__ __launch_bounds__(EPI_THREADS) void k_epilogue(uint32_t N, const Anch
         }
     }
     if (want_cs && cur_c != ~0u) flush_colsums(cur_c);
+    unreplicate();
     reduce_hist();
     __syncthreads();
     if (cur_row0 != ~0ull) flush_hist(N, hist, bins, cur_row0, tid, MAXB);
