@@ -1,6 +1,6 @@
 #!/bin/bash
 cd ${GRAFT_REPO_ROOT:-/root/repo}
-for A in "--genomes 8 --genome-mb 200" "--genomes 8 --genome-mb 400" "--genomes 16 --genome-mb 200" "--genomes 27 --genome-mb 160"; do
+for A in "" "--genomes 27 --genome-mb 40" "--genomes 64 --genome-mb 20" "--genomes 128 --genome-mb 10" "--genomes 8 --genome-mb 700"; do
   timeout 600 python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-compare --no-other-shapes --no-sharded-leg --no-e2e --no-robustness $A 2>gpurun_out/ab.err | python -c "
 import sys,json
 d=json.loads(sys.stdin.read()); r=d['roofline']; n=d['config']['positions_per_step_per_gpu']
