@@ -436,10 +436,9 @@ __device__ __forceinline__ void drain_queue(const SubTable &st, uint32_t qn, con
     // kernel run 32 waves per CU instead of 26
     const int k = (int)st.k;
     constexpr int LDS_LINE_U4 = SLOTS + 1;
-    constexpr int BUCKET_BYTES = 16 * SLOTS;
     constexpr int STAGE_ITERS = (MAXRUN * SLOTS + 63) / 64;
     const uint8_t *chunk_base = st.buckets + (uint32_t)(lane % SLOTS) * 16u;
-    const uint32_t lbytes = st.slots * (WIDE ? 8u : 16u);  // (= BUCKET_BYTES, as a run-time scalar: see k_probe)
+    const uint32_t lbytes = st.slots * (WIDE ? 8u : 16u);  // (= 16 * SLOTS, as a run-time scalar: see k_probe)
     for (int level = 1; qn > 0; ++level) {
         __syncthreads();
         if (level > LEVELS) {
@@ -559,7 +558,6 @@ __attribute__((amdgpu_num_sgpr(80))) void k_probe(const SubTable st, const uint6
     // A staged line occupies 16*SLOTS + 16 bytes of LDS: the pad keeps the lanes' ds_read_b128 of
     // "their" lines off a common bank group (a power-of-two stride would be a 32-way conflict)
     constexpr int LDS_LINE_U4 = SLOTS + 1;
-    constexpr int BUCKET_BYTES = 16 * SLOTS;
     // lines staged per step: 16 take the ~13 distinct lines a batch meets at w = 7 / 8 in ONE step; at w = 6 (what k=21
     // gets on 150-570 Mb genomes) a batch meets ~17 and paid a second step for the last few — 24 there (9.01 -> 8.66 ms
     // on 64 x 20 Mb, 92.0 -> 89.7 on 64 x 200 Mb; everywhere else 24 costs 8-10 %: LDS, occupancy; tools/ab_maxrun.sh)
@@ -610,7 +608,7 @@ __attribute__((amdgpu_num_sgpr(80))) void k_probe(const SubTable st, const uint6
     uint32_t qn = 0;  // wave-uniform: overflow entries of this tile so far
 
     const uint8_t *chunk_base = st.buckets + (uint32_t)(lane % SLOTS) * 16u;  // this lane's 16-byte chunk of line 0
-    const uint32_t lbytes = st.slots * (WIDE ? 8u : 16u);                      // bytes per line (= BUCKET_BYTES), as a run-time scalar
+    const uint32_t lbytes = st.slots * (WIDE ? 8u : 16u);                      // bytes per line (= 16 * SLOTS), as a run-time scalar
 
     // A batch in three parts, so that the front end of batch i + 1 can run while the table lines of batch i are on
     // their way (PG_PROBE_PIPE): the fetch is the longest wait of a batch — a couple of thousand cycles behind a busy
