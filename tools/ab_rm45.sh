@@ -1,8 +1,8 @@
 #!/bin/bash
 cd ${GRAFT_REPO_ROOT:-/root/repo}
-for A in "" "--genomes 27 --genome-mb 40" "--genomes 64 --genome-mb 20" "--genomes 128 --genome-mb 10" "--genomes 8 --genome-mb 700"; do
+for A in "--d 0.01" "--d 0.05" "--d 0.1" "--genomes 27 --genome-mb 40 --d 0.05"; do
   timeout 600 python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-compare --no-other-shapes --no-sharded-leg --no-e2e --no-robustness $A 2>gpurun_out/ab.err | python -c "
 import sys,json
-d=json.loads(sys.stdin.read()); r=d['roofline']; n=d['config']['positions_per_step_per_gpu']
-print('[$1] [$A]', round(d['value']/1e9,1), 'step', round(d['ms_per_step'],3), 'probe', round(r['avg_launch_ms'],3), 'stats', round(r['epilogue_kernel_ms'],3), 'probe ps/pos', round(r['avg_launch_ms']*1e9/n,2))"
+d=json.loads(sys.stdin.read()); r=d['roofline']; n=d['config']['positions_per_step_per_gpu']; c=d['config']
+print('[$1] [$A]', round(d['value']/1e9,1), 'step', round(d['ms_per_step'],3), 'probe', round(r['avg_launch_ms'],3), 'probe ps/pos', round(r['avg_launch_ms']*1e9/n,2), 'build s', round(c['table_build_s'],3))"
 done
