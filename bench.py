@@ -994,7 +994,7 @@ def main():
             out["config"]["genome_sharded_leg"] = sharded_leg(ctx, dev, args, rank, world, dist, 3, 1, args.blocks)
         except Exception as e:  # a failed extra leg must not take the measured line with it
             out["config"]["genome_sharded_leg"] = {"error": f"{type(e).__name__}: {e}"}
-    if world == 1 and default_shape and not args.no_e2e:
+    if world == 1 and (default_shape or os.environ.get("PG_BENCH_E2E_ANY")) and not args.no_e2e:  # (PG_BENCH_E2E_ANY: experiments on other shapes)
         try:
             out["e2e"] = e2e_leg(dev, args, G, contig_lens, k)
         except Exception as e:
