@@ -2346,10 +2346,15 @@ __global__ __launch_bounds__(256) void k_cols_merge_b1(uint32_t N, const AnchorD
     *row = make_uint2(lo, hi);  // (bits of positions past nkmers are zero in the blocks: the padding stays zero)
 }
 
+// Wider rows.  A lane owns one position; the wave one slot of 64.  The row bytes are read a 32-bit word at a time (one
+// access per 32 genomes: the first version read a byte per genome in a loop that waited for each load in turn — 20 ps
+// per row at 32 genomes per block, ten times the probe), a ballot per genome turns the word's bit into the slot's u64,
+// kept by lane j and stored coalesced.
 __global__ __launch_bounds__(256) void k_cols_extract(uint32_t N, const AnchorDesc *__restrict__ ad,
                                                       const uint32_t *__restrict__ tile_contig, uint32_t tile_base,
                                                       uint32_t ntiles, const uint8_t *__restrict__ out1, uint32_t g0,
                                                       uint32_t width, unsigned long long *__restrict__ dst) {
+    struct __attribute__((packed)) U32 { uint32_t v; };
     const int lane = threadIdx.x & 63;
     const uint64_t slot = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);  // relative to the range's first tile
     if (slot >= (uint64_t)ntiles * 8) return;  // wave-uniform
@@ -2359,22 +2364,33 @@ __global__ __launch_bounds__(256) void k_cols_extract(uint32_t N, const AnchorDe
     const uint32_t p = (tile - a.tile0) * PROBE_TILE + sub * 64 + lane;
     const bool active = p < a.nkmers;
     const uint8_t *row = out1 + a.out_off + (uint64_t)p * nbytes;
+    const uint32_t gend = min(N, g0 + width);
     for (uint32_t j0 = 0; j0 < width; j0 += 64) {
         unsigned long long mine = 0;
-        const uint32_t jn = min(64u, width - j0);
-        for (uint32_t j = 0; j < jn; ++j) {
-            const uint32_t g = g0 + j0 + j;
-            const bool bit = active && g < N && ((row[g >> 3] >> (g & 7)) & 1u);
-            const unsigned long long m = __ballot(bit);
-            if ((uint32_t)lane == j) mine = m;
+        const uint32_t ga = g0 + j0, gz = min(gend, ga + 64u);  // genomes of this group of (up to) 64 columns
+        for (uint32_t wd = ga >> 5; 32u * wd < gz; ++wd) {
+            uint32_t v = 0;
+            if (active) {  // (the word may reach past the row's last byte: byte loads there)
+                if (4u * wd + 4u <= nbytes) v = reinterpret_cast<const U32 *>(row + 4u * wd)->v;
+                else
+                    for (uint32_t bb = 0; 4u * wd + bb < nbytes; ++bb) v |= (uint32_t)row[4u * wd + bb] << (8u * bb);
+            }
+            const uint32_t b_lo = max(ga, 32u * wd) - 32u * wd, b_hi = min(gz, 32u * wd + 32u) - 32u * wd;
+            for (uint32_t b = b_lo; b < b_hi; ++b) {
+                const unsigned long long m = __ballot((v >> b) & 1u);
+                if ((uint32_t)lane == 32u * wd + b - ga) mine = m;
+            }
         }
-        if ((uint32_t)lane < jn) dst[slot * width + j0 + lane] = mine;
+        if ((uint32_t)lane < min(64u, width - j0)) dst[slot * width + j0 + lane] = mine;  // (columns past N stay zero)
     }
 }
 
 // src = nparts blocks of part_words u64 each (block i = genomes (part0 + i) * per ...); the bits of those genomes are
 // set in the rows from the blocks.  accumulate == 0: the rows are written whole (bits of genomes outside the
 // blocks become 0); != 0: the blocks' bits are OR-ed into what the rows hold (genome blocks arriving pass by pass).
+// The u64 of a genome and slot is the same for the whole wave: lane l FETCHES the one of genome 32 d + l (one coalesced
+// access per 32 genomes) and the wave reads them lane by lane — as wave-uniform loads inside the genome loop every one
+// of them was waited for in turn (0.4-0.7 ms per call at 64 genomes).
 __global__ __launch_bounds__(256) void k_cols_merge(uint32_t N, const AnchorDesc *__restrict__ ad,
                                                     const uint32_t *__restrict__ tile_contig, uint32_t tile_base,
                                                     uint32_t ntiles, uint8_t *__restrict__ out1,
@@ -2391,18 +2407,25 @@ __global__ __launch_bounds__(256) void k_cols_merge(uint32_t N, const AnchorDesc
     const uint32_t gfirst = part0 * per, gend = min(N, (part0 + nparts) * per);  // genomes the blocks cover
     for (uint32_t d = 0; d < ndbs; ++d) {
         if (accumulate && (32 * d + 32 <= gfirst || 32 * d >= gend)) continue;  // (uniform) word untouched by these blocks
+        const uint32_t gl = 32u * d + ((uint32_t)lane & 31u);
+        unsigned long long mine = 0;
+        if (lane < 32 && gl >= gfirst && gl < gend) mine = src[(uint64_t)(gl / per - part0) * part_words + slot * per + gl % per];
         uint32_t w = 0;
-        const uint32_t nb = min(32u, N - 32 * d);
-        for (uint32_t b = 0; b < nb; ++b) {
-            const uint32_t g = 32 * d + b;
-            if (g < gfirst || g >= gend) continue;
-            const uint32_t part = g / per - part0, j = g % per;
-            const unsigned long long word = src[(uint64_t)part * part_words + slot * per + j];  // wave-uniform
-            w |= (uint32_t)((word >> lane) & 1ull) << b;
+        // bits of this word that the blocks cover (none: the word is written as zeros)
+        const bool any = 32u * d < gend && 32u * d + 32u > gfirst;
+        const uint32_t b_lo = any ? max(gfirst, 32u * d) - 32u * d : 0u, b_hi = any ? min(gend, 32u * d + 32u) - 32u * d : 0u;
+        for (uint32_t b = b_lo; b < b_hi; ++b) {  // (uniform)
+            const unsigned long long word = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mine >> 32), (int)b) << 32) |
+                                            (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mine, (int)b);
+            w |= (__builtin_amdgcn_inverse_ballot_w64(word) ? 1u : 0u) << b;
         }
         if (p < a.nkmers) {
             const uint32_t n = min(4u, nbytes - 4 * d);
-            if (accumulate) {
+            if (n == 4 && (nbytes & 3u) == 0) {  // (uniform) whole words of rows that start on word boundaries: one access, not four
+                uint32_t *rw = reinterpret_cast<uint32_t *>(row + 4 * d);
+                if (!accumulate) *rw = w;
+                else if (w) *rw |= w;
+            } else if (accumulate) {
                 for (uint32_t bb = 0; bb < n; ++bb) {
                     const uint8_t add = (uint8_t)(w >> (8 * bb));
                     if (add) row[4 * d + bb] |= add;

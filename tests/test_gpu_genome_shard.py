@@ -207,12 +207,14 @@ def test_range_probe_extract_merge_equals_whole(ctx):
         assert np.array_equal(piece.download(ci, want_bitmap100=False)[0], whole.download(ci, want_bitmap100=False)[0])
     per = 4
     allc = torch.zeros(whole.columns_bytes(per), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
     whole.extract_columns(4, per, allc.data_ptr())
     full = engine.AnchorResult.rows_container(ctx, k, n, ss, colsums=True)
     off = 0
     for c0, nc in [(0, 1), (1, 2), (3, 1)]:
         nb_ = piece.columns_bytes_range(per, c0, nc)
         buf = torch.zeros(nb_, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()  # (torch fills it on its own stream)
         piece.extract_columns_range(4, per, c0, nc, buf.data_ptr())
         ctx.synchronize()
         assert torch.equal(buf, allc[off:off + nb_])
@@ -391,3 +393,53 @@ def test_cli_under_torchrun_joins_the_group_itself(shard, nblocks, tmp_path):
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
     assert p.returncode == 0, "\n".join(ln for ln in p.stderr.splitlines() if "Traceback" in ln or "Error" in ln or ln.startswith("  File"))[-4000:]
     _check_tree(out, fx, gzi_like_reference=shard == "genome")
+
+
+@pytest.mark.parametrize("n,per", [(40, 20), (64, 8), (64, 32), (70, 24), (100, 70), (130, 33)])
+def test_columns_of_wide_blocks_round_trip(ctx, n, per):
+    """The exchange format at more genomes than config 5's eight: bit columns of every genome block extracted from the
+    rows (blocks that straddle the rows' 32-bit words, blocks wider than 64 genomes) and merged back — written whole
+    (accumulate off: the words no block covers must come out zero; a loop bound that wrapped there hung the kernel) and
+    OR-ed in block by block — give the rows again, block by block and all together."""
+    from panagram_amd import engine
+    k = 21
+    gen = po.synth_genomes(n, [3000, 700, 1300], 0.05, 4200 + n)
+    genomes = [[po.codes_to_ascii(c) for c in g] for g in gen]
+    tbl = engine.PanTable(ctx, k, n)
+    for g in range(n):
+        ss_ = engine.SeqSet.from_host(ctx, genomes[g])
+        tbl.insert_seqset(g, ss_)
+        ss_.close()
+    ss = engine.SeqSet.from_host(ctx, genomes[n // 2])
+    whole = engine.AnchorResult(tbl, ss, colsums=True, rows_only=True)
+    whole.run()
+    ctx.synchronize()
+    rows = [whole.download(ci, want_bitmap100=False)[0] for ci in range(3)]
+    assert all(r.any() for r in rows)
+    nblocks = (n + per - 1) // per
+    nbytes = (n + 7) // 8
+    bufs = [torch.zeros(whole.columns_bytes(per), dtype=torch.uint8, device="cuda") for _ in range(nblocks)]
+    torch.cuda.synchronize()  # (torch fills them on ITS stream; the library works on the context's)
+    for b in range(nblocks):
+        whole.extract_columns(b * per, per, bufs[b].data_ptr())
+    ctx.synchronize()
+
+    def block_mask(b):
+        keep = np.zeros(nbytes * 8, np.uint8)
+        keep[b * per:min(n, (b + 1) * per)] = 1
+        return np.packbits(keep.reshape(-1, 8), axis=1, bitorder="little").reshape(-1)
+
+    one = engine.AnchorResult.rows_container(ctx, k, n, ss, colsums=True)
+    for b in range(nblocks):  # one block written whole: everything else zero
+        one.merge_columns_range(bufs[b].data_ptr(), b, 1, per, 0, 3, accumulate=False)
+        ctx.synchronize()
+        for ci in range(3):
+            assert np.array_equal(one.download(ci, want_bitmap100=False)[0], rows[ci] & block_mask(b)), (b, ci)
+    acc = engine.AnchorResult.rows_container(ctx, k, n, ss, colsums=True)
+    for b in reversed(range(nblocks)):  # all blocks OR-ed in, last first
+        acc.merge_columns_range(bufs[b].data_ptr(), b, 1, per, 0, 3, accumulate=True)
+    ctx.synchronize()
+    for ci in range(3):
+        assert np.array_equal(acc.download(ci, want_bitmap100=False)[0], rows[ci])
+    for x in (one, acc, whole, ss, tbl):
+        x.close()
