@@ -334,6 +334,13 @@ int pg_result_coschedule_ranges(pg_result *r, const uint32_t *contig_group, uint
 int pg_result_contig_colsums(pg_result *r, uint32_t idx, uint32_t ncontigs, uint64_t *colsums);
 int pg_result_download(pg_result *r, uint32_t idx, uint8_t *bitmap1, uint8_t *bitmap100,
                        uint32_t *bins);
+/* The small outputs of contigs first .. first+ncontigs-1 in ONE call (an assembly of 20 000 contigs paid 26 us per
+ * contig for pg_result_contig_info + pg_result_download): the geometry into four arrays of ncontigs entries each (any
+ * may be NULL) and, when bins != NULL, the contigs' bin rows back to back — bins_words must be the sum of
+ * nbins[i] * (ngenomes + 1) — in one device-to-host copy; synchronises.  What KMCdb::write_bits accumulates per chunk
+ * (cpp/anchor.cpp:179-189), per contig. */
+int pg_result_contigs_small(pg_result *r, uint32_t first, uint32_t ncontigs, uint64_t *nkmers, uint64_t *nrows100,
+                            uint32_t *nbins, uint32_t *binlen, uint32_t *bins, uint64_t bins_words);
 /* per-genome column sums over ALL contigs of the seqset (ngenomes u64); synchronises */
 int pg_result_colsums(pg_result *r, uint64_t *colsums);
 /* device pointers (for benchmarking / checksums without PCIe traffic) */
@@ -373,6 +380,13 @@ int pg_bgzf_open(const char *path, int level, int nthreads, pg_bgzf **out);
 int pg_bgzf_write(pg_bgzf *w, const void *data, size_t len);
 /* writes the EOF block, closes the file and, if gzi_path != NULL, the index */
 int pg_bgzf_close(pg_bgzf *w, const char *gzi_path);
+
+/* bitsum.bins.tsv as KMCdb::anchor_fasta / write_bits write it (cpp/anchor.cpp:57-69,184-189): the header line
+ * "chr\tstart\t0\t1...\tN", then for contig c (numbered from 0) and bin b the line
+ * "c\t(b * binlen[c])\tcount_0...\tcount_N"; bins = the contigs' rows back to back, ngenomes + 1 counts each.
+ * Host code, no GPU; the text of millions of bins is formatted here rather than row by row in the interpreter. */
+int pg_write_bins_tsv(const char *path, uint32_t ngenomes, uint32_t ncontigs, const uint32_t *nbins, const uint32_t *binlen,
+                      const uint32_t *bins);
 
 #ifdef __cplusplus
 }

@@ -105,6 +105,8 @@ PROTOTYPES = {
     "pg_result_write_bgzf": (C.c_int, [_vp, C.c_int, C.c_char_p, C.c_char_p, C.c_int, C.c_int]),
     "pg_result_write_bgzf_range": (C.c_int, [_vp, C.c_int, C.c_uint32, C.c_uint32, C.c_char_p, C.c_char_p, C.c_int, C.c_int]),
     "pg_result_download": (C.c_int, [_vp, C.c_uint32, _vp, _vp, _vp]),
+    "pg_result_contigs_small": (C.c_int, [_vp, C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp, _vp, C.c_uint64]),
+    "pg_write_bins_tsv": (C.c_int, [C.c_char_p, C.c_uint32, C.c_uint32, _vp, _vp, _vp]),
     "pg_result_colsums": (C.c_int, [_vp, _vp]),
     "pg_result_device_ptrs": (C.c_int, [_vp, _vpp, _u64p, _vpp, _u64p]),
     "pg_anchor_contig": (C.c_int, [_vp, _vp, C.c_uint64, _vp, _vp, _vp, _vp, _u64p]),

@@ -2682,6 +2682,34 @@ extern "C" int pg_result_contig_info(const pg_result *r, uint32_t idx, uint64_t 
     PG_API_END
 }
 
+extern "C" int pg_result_contigs_small(pg_result *r, uint32_t first, uint32_t ncontigs, uint64_t *nkmers, uint64_t *nrows100,
+                                       uint32_t *nbins, uint32_t *binlen, uint32_t *bins, uint64_t bins_words) {
+    PG_API_BEGIN
+    if (!r) return fail(PG_E_INVALID, "result is NULL");
+    if ((uint64_t)first + ncontigs > r->ad.size()) return fail(PG_E_INVALID, "contigs %u..%u out of range", first, first + ncontigs);
+    uint64_t rows = 0;
+    for (uint32_t i = 0; i < ncontigs; ++i) {
+        const AnchorDesc &a = r->ad[first + i];
+        if (nkmers) nkmers[i] = a.nkmers;
+        if (nrows100) nrows100[i] = r->nrows100[first + i];
+        if (nbins) nbins[i] = a.nbins;
+        if (binlen) binlen[i] = a.binlen;
+        rows += a.nbins;
+    }
+    if (!bins || ncontigs == 0) return PG_OK;
+    const uint64_t N1 = (uint64_t)r->N + 1;
+    if (bins_words != rows * N1) return fail(PG_E_INVALID, "pg_result_contigs_small: %llu words for %llu bin rows of %llu", (unsigned long long)bins_words, (unsigned long long)rows, (unsigned long long)N1);
+    if (rows == 0) return PG_OK;
+    if (int e = use_device(r->ctx)) return e;
+    if (int e = join_result(r)) return e;
+    hipStream_t st = r->ctx->stream;
+    // (the contigs' bin rows follow one another in the result's buffer)
+    HIP_TRY(hipMemcpyAsync(bins, r->d_bins + r->ad[first].bin_off * N1, rows * N1 * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return PG_OK;
+    PG_API_END
+}
+
 extern "C" int pg_result_download(pg_result *r, uint32_t idx, uint8_t *bitmap1, uint8_t *bitmap100, uint32_t *bins) {
     PG_API_BEGIN
     if (!r) return fail(PG_E_INVALID, "result is NULL");

@@ -674,6 +674,18 @@ class AnchorResult:
         check(self._lib.pg_result_download(self._h, idx, _ptr(rows), _ptr(rows100), _ptr(bins)))
         return rows, rows100, bins, info
 
+    def contigs_small(self, first: int = 0, ncontigs: Optional[int] = None) -> "SmallOutputs":
+        """geometry and bin histograms of contigs ``first .. first+ncontigs-1`` in two library calls (one device-to-host
+        copy) whatever their number — per-contig ``download`` calls cost a fragmented assembly 26 us per contig"""
+        n = len(self.seqs.lens) - first if ncontigs is None else ncontigs
+        nk, n100 = np.zeros(n, np.uint64), np.zeros(n, np.uint64)
+        nb, bl = np.zeros(n, np.uint32), np.zeros(n, np.uint32)
+        check(self._lib.pg_result_contigs_small(self._h, first, n, _ptr(nk), _ptr(n100), _ptr(nb), _ptr(bl), None, 0))
+        bins = np.zeros((int(nb.sum(dtype=np.uint64)), self.ngenomes + 1), np.uint32)
+        if bins.size:
+            check(self._lib.pg_result_contigs_small(self._h, first, n, None, None, None, None, _ptr(bins), bins.size))
+        return SmallOutputs(nk, n100, nb, bl, bins)
+
     def colsums(self) -> np.ndarray:
         cs = np.zeros(self.ngenomes, np.uint64)
         check(self._lib.pg_result_colsums(self._h, _ptr(cs)))
@@ -695,6 +707,32 @@ class AnchorResult:
             self.close()
         except Exception:
             pass
+
+
+class SmallOutputs:
+    """The small per-contig outputs of a run of contigs: geometry arrays and the contigs' bin rows back to back
+    (``bins[nbins_total, N + 1]``).  ``out[i]`` is the tuple ``AnchorResult.download(i, False, False)`` returns."""
+
+    def __init__(self, nkmers, nrows100, nbins, binlen, bins):
+        self.nkmers, self.nrows100, self.nbins, self.binlen, self.bins = nkmers, nrows100, nbins, binlen, bins
+        self.bin_off = np.concatenate([[0], np.cumsum(nbins, dtype=np.int64)])
+
+    def __len__(self):
+        return len(self.nkmers)
+
+    def info(self, i: int) -> dict:
+        return dict(nkmers=int(self.nkmers[i]), nrows100=int(self.nrows100[i]), nbins=int(self.nbins[i]), binlen=int(self.binlen[i]))
+
+    def __getitem__(self, i: int):
+        return None, None, self.bins[self.bin_off[i]:self.bin_off[i + 1]], self.info(i)
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
+
+    def write_bins_tsv(self, path: str, ngenomes: int) -> None:
+        """bitsum.bins.tsv of these contigs (numbered from 0), formatted by the library"""
+        check(_lib.load().pg_write_bins_tsv(os.fsencode(path), ngenomes, len(self), _ptr(np.ascontiguousarray(self.nbins, np.uint32)),
+                                            _ptr(np.ascontiguousarray(self.binlen, np.uint32)), _ptr(np.ascontiguousarray(self.bins, np.uint32))))
 
 
 class BgzfWriter:

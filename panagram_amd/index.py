@@ -1026,7 +1026,7 @@ class Genome:
         geometry, column sums, per-gene occupancy — as the tuple ``write_from_result`` takes; the bitmap rows
         stay in HBM."""
         self.ensure_log()
-        small = [res.download(ci, want_bitmap1=False, want_bitmap100=False) for ci in range(lo, hi)]
+        small = res.contigs_small(lo, hi - lo)  # (one call for all contigs; small[i] = what res.download(lo + i, False, False) gives)
         cs = res.contig_colsums(lo, hi - lo).astype(np.int64).sum(axis=0)
         gene_hists = self._tabulate_genes(res, names, small, lo) if self.annotated else None
         return (lo, hi, names, small, cs, gene_hists)
@@ -1068,7 +1068,7 @@ class Genome:
                            ncontigs=hi - lo)
             os.replace(gz + ".tmp", gz)
             os.replace(gzi + ".tmp", gzi)
-        self._write_tables(names, [(b, info) for _, _, b, info in small], cs, gene_hists)
+        self._write_tables(names, small if isinstance(small, engine.SmallOutputs) else [(b, info) for _, _, b, info in small], cs, gene_hists)
         self.close_log()
 
     def _bgzf_threads(self) -> int:
@@ -1076,17 +1076,30 @@ class Genome:
 
     def _write_tables(self, names, bins_infos, paircount_sums, gene_hists=None):
         N = self.ngenomes
-        bins_rows: List[str] = ["chr\tstart" + "".join(f"\t{i}" for i in range(N + 1)) + "\n"]
         chr_rows: List[Tuple[str, int, int, int]] = []
-        for ci, (chrom, (bins, info)) in enumerate(zip(names, bins_infos)):
-            starts = np.arange(info["nbins"], dtype=np.int64) * info["binlen"]
-            body = np.column_stack([np.full(info["nbins"], ci, np.int64), starts, bins.astype(np.int64)])
-            bins_rows.extend("\t".join(map(str, row)) + "\n" for row in body.tolist())
-            gene_count = gene_hists[chrom][0] if gene_hists and chrom in gene_hists else 0
-            chr_rows.append((chrom, ci, info["nkmers"], gene_count))
-            self.log.info(f"Anchored {chrom}")
-        with open(self.bins_fname, "w") as f:
-            f.writelines(bins_rows)
+        if isinstance(bins_infos, engine.SmallOutputs):
+            # the contigs' bins in one array: the text is formatted by the library (two million rows per anchor genome for
+            # an assembly of 20 000 contigs; row by row in the interpreter that was most of such a run)
+            bins_infos.write_bins_tsv(self.bins_fname, N)
+            for ci, chrom in enumerate(names):
+                gene_count = gene_hists[chrom][0] if gene_hists and chrom in gene_hists else 0
+                chr_rows.append((chrom, ci, int(bins_infos.nkmers[ci]), gene_count))
+            if len(names) <= 1000:
+                for chrom in names:
+                    self.log.info(f"Anchored {chrom}")
+            else:  # (a log line per contig of a fragmented assembly is a second of logging per genome)
+                self.log.info(f"Anchored {len(names)} contigs ({names[0]} ... {names[-1]})")
+        else:
+            bins_rows: List[str] = ["chr\tstart" + "".join(f"\t{i}" for i in range(N + 1)) + "\n"]
+            for ci, (chrom, (bins, info)) in enumerate(zip(names, bins_infos)):
+                starts = np.arange(info["nbins"], dtype=np.int64) * info["binlen"]
+                body = np.column_stack([np.full(info["nbins"], ci, np.int64), starts, bins.astype(np.int64)])
+                bins_rows.extend("\t".join(map(str, row)) + "\n" for row in body.tolist())
+                gene_count = gene_hists[chrom][0] if gene_hists and chrom in gene_hists else 0
+                chr_rows.append((chrom, ci, info["nkmers"], gene_count))
+                self.log.info(f"Anchored {chrom}")
+            with open(self.bins_fname, "w") as f:
+                f.writelines(bins_rows)
         if gene_hists is not None:  # bitsum.genes.tsv: one row per annotated chromosome (index.py:1079-1082)
             pd.DataFrame([h for _, h in gene_hists.values()], index=pd.Index(list(gene_hists), name="chr"),
                          columns=range(N + 1)).to_csv(self.chr_genes_fname, sep="\t")

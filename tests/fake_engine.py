@@ -17,7 +17,7 @@ from typing import List, Optional, Sequence
 import numpy as np
 
 from oracle import pyoracle as po
-from panagram_amd.engine import BgzfWriter  # the host BGZF writer is real (no GPU involved)  # noqa: F401
+from panagram_amd.engine import BgzfWriter, SmallOutputs  # the host BGZF writer and the bins' text writer are real (no GPU involved)  # noqa: F401
 
 HBM_FREE = 64 << 30        # what Context.mem_info reports; tests shrink it to force the genome-sharded mode
 BYTES_PER_KEY = 43         # PanTable.bytes_for: 16-byte slots at 0.375 load
@@ -260,6 +260,15 @@ class AnchorResult:
         for b in range(info["nbins"]):
             bins[b] = np.bincount(popc[b * info["binlen"]:(b + 1) * info["binlen"]], minlength=self.ngenomes + 1)
         return (rows if want_bitmap1 else None, rows[::self.lowres_step] if want_bitmap100 else None, bins, info)
+
+    def contigs_small(self, first=0, ncontigs=None):
+        n = len(self._nk) - first if ncontigs is None else ncontigs
+        items = [self.download(first + i, False, False) for i in range(n)]
+        infos = [it[3] for it in items]
+        bins = np.vstack([it[2] for it in items]) if items else np.zeros((0, self.ngenomes + 1), np.uint32)
+        return SmallOutputs(np.array([i["nkmers"] for i in infos], np.uint64), np.array([i["nrows100"] for i in infos], np.uint64),
+                            np.array([i["nbins"] for i in infos], np.uint32), np.array([i["binlen"] for i in infos], np.uint32),
+                            np.ascontiguousarray(bins, np.uint32))
 
     def contig_colsums(self, idx=0, ncontigs=None):
         n = len(self._nk) - idx if ncontigs is None else ncontigs

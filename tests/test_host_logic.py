@@ -358,3 +358,27 @@ def test_homology_classes_from_record_ids():
     assert list(c[:3]) == [0, 1, 2] and list(c[3:6]) == [1, 0, 3]
     assert list(c[6:8]) == [0, 1]  # a genome without ids is paired by position (the first genome's classes)
     assert c[8] == 2
+
+
+def test_native_bins_tsv_equals_the_row_by_row_text(tmp_path):
+    """bitsum.bins.tsv formatted by the library (pg_write_bins_tsv: host code, used whenever a genome's bins arrive as
+    one array) against the row-by-row text Genome._write_tables used to build — the reference's lines
+    (cpp/anchor.cpp:57-69,184-189: chr number, bin start, N + 1 counts), including empty contigs and 32-bit counts."""
+    from panagram_amd import engine
+    rng = np.random.default_rng(5)
+    N = 11
+    nbins = np.array([3, 0, 1, 100, 7], np.uint32)
+    binlen = np.array([200000, 1, 17, 53, 4000000], np.uint32)
+    bins = rng.integers(0, 2 ** 32, (int(nbins.sum()), N + 1), dtype=np.uint64).astype(np.uint32)
+    bins[0, :3] = (0, 4294967295, 10)
+    so = engine.SmallOutputs(np.zeros(5, np.uint64), np.zeros(5, np.uint64), nbins, binlen, bins)
+    p = tmp_path / "bitsum.bins.tsv"
+    so.write_bins_tsv(str(p), N)
+    want = ["chr\tstart" + "".join(f"\t{i}" for i in range(N + 1)) + "\n"]
+    for ci in range(5):
+        _, _, b, info = so[ci]
+        assert (info["nbins"], info["binlen"]) == (int(nbins[ci]), int(binlen[ci])) and len(b) == nbins[ci]
+        for r in range(info["nbins"]):
+            want.append("\t".join(map(str, [ci, r * info["binlen"]] + b[r].astype(np.int64).tolist())) + "\n")
+    assert p.read_text() == "".join(want)
+    assert len(so) == 5 and [x[3]["nbins"] for x in so] == nbins.tolist()
