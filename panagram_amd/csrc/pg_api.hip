@@ -1547,16 +1547,25 @@ static int seqset_concat(pg_ctx *ctx, const pg_seqset *const *sets, const uint32
     for (uint32_t i = 0; i < nsets && e == hipSuccess; ++i) {
         const pg_seqset *src = sets[i];
         const uint32_t f = first ? first[i] : 0, n = first ? count[i] : src->n;
-        for (uint32_t j = f; j < f + n && e == hipSuccess; ++j, ++c) {
-            const uint64_t nw = std::min(src->desc[j].nwords, s->desc[c].nwords);
-            e = hipMemcpyAsync(s->d_seqw + s->desc[c].seq_off, src->d_seqw + src->desc[j].seq_off, nw * 8,
-                               hipMemcpyDeviceToDevice, st);
-            if (e == hipSuccess)
-                e = hipMemcpyAsync(s->d_nmw + s->desc[c].seq_off, src->d_nmw + src->desc[j].seq_off, nw * 4,
-                                   hipMemcpyDeviceToDevice, st);
-            if (e == hipSuccess)
-                e = hipMemcpyAsync(s->d_has_n + c, src->d_has_n + j, 4, hipMemcpyDeviceToDevice, st);
-            s->names.push_back(j < src->names.size() ? src->names[j] : std::string());
+        // Consecutive contigs of a set sit in its buffers the way they will sit in the new one (both layouts follow from
+        // the lengths alone), so a run of them is ONE copy per plane — three copies per contig were 9 us each, 1.4 s for
+        // the 160 000 contigs of eight fragmented assemblies.  A run ends where the two layouts part (never, today).
+        for (uint32_t j = f; j < f + n && e == hipSuccess;) {
+            uint32_t m = 1;
+            while (j + m < f + n && src->desc[j + m].nwords == s->desc[c + m].nwords && src->desc[j + m - 1].nwords == s->desc[c + m - 1].nwords &&
+                   src->desc[j + m].seq_off - src->desc[j].seq_off == s->desc[c + m].seq_off - s->desc[c].seq_off)
+                ++m;
+            const uint64_t last = std::min(src->desc[j + m - 1].nwords, s->desc[c + m - 1].nwords);
+            const uint64_t nw = m == 1 ? last : src->desc[j + m - 1].seq_off - src->desc[j].seq_off + last;
+            if (nw) {
+                e = hipMemcpyAsync(s->d_seqw + s->desc[c].seq_off, src->d_seqw + src->desc[j].seq_off, nw * 8, hipMemcpyDeviceToDevice, st);
+                if (e == hipSuccess)
+                    e = hipMemcpyAsync(s->d_nmw + s->desc[c].seq_off, src->d_nmw + src->desc[j].seq_off, nw * 4, hipMemcpyDeviceToDevice, st);
+            }
+            if (e == hipSuccess) e = hipMemcpyAsync(s->d_has_n + c, src->d_has_n + j, 4ull * m, hipMemcpyDeviceToDevice, st);
+            for (uint32_t q = 0; q < m; ++q) s->names.push_back(j + q < src->names.size() ? src->names[j + q] : std::string());
+            j += m;
+            c += m;
         }
     }
     if (e == hipSuccess) e = hipStreamSynchronize(st);
