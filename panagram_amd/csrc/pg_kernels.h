@@ -58,6 +58,15 @@ hipError_t launch_text_pack(hipStream_t st, const uint8_t *d_text, const TextChu
                             const uint64_t *d_rec_chunk0, uint32_t nrec, uint32_t *d_counts, uint64_t *d_base,
                             uint64_t *d_rec_len, const SeqDesc *sd, uint64_t *seqw, uint32_t *nmw, uint32_t *has_n);
 hipError_t launch_seq_tailmask(hipStream_t st, const SeqDesc *sd, uint32_t n, uint64_t *seqw, uint32_t *nmw);
+// packed contigs gathered into another seqset's planes: job i copies nwords words of both planes and the contig's flag
+struct SeqCopy {
+    const uint64_t *src_seqw;
+    const uint32_t *src_nmw;
+    const uint32_t *src_has_n;  // (this contig's flag)
+    uint64_t src_off, dst_off, nwords;
+};
+hipError_t launch_seq_gather(hipStream_t st, const SeqCopy *jobs, uint32_t n, uint64_t max_words, uint64_t *seqw, uint32_t *nmw,
+                             uint32_t *has_n);
 hipError_t launch_pack(hipStream_t st, const void *d_ascii, uint64_t len, uint64_t *seqw, uint32_t *nmw,
                        uint64_t nwords, uint32_t *has_n);
 hipError_t launch_sketch(hipStream_t st, int k, const uint64_t *seqw, const uint32_t *nmw, const uint32_t *has_n,
