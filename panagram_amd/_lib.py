@@ -76,6 +76,7 @@ PROTOTYPES = {
     "pg_seqset_ncontigs": (C.c_uint32, [_vp]),
     "pg_seqset_unpack": (C.c_int, [_vp, C.c_uint32, _vp]),
     "pg_seqset_contig": (C.c_int, [_vp, C.c_uint32, C.POINTER(C.c_char_p), _u64p]),
+    "pg_seqset_describe": (C.c_int, [_vp, _vp, _vp, C.c_uint64, _u64p]),
     "pg_result_create": (C.c_int, [_vp, _vp, C.c_uint32, _vpp]),
     "pg_result_create_ex": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, _vpp]),
     "pg_result_create_rows": (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, _vpp]),

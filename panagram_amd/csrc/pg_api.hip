@@ -1236,12 +1236,23 @@ extern "C" int pg_sketch_add_seqset(pg_sketch *sk, const pg_seqset *sq) {
     if (!sk || !sq) return fail(PG_E_INVALID, "pg_sketch_add_seqset: NULL argument");
     if (sk->ctx != sq->ctx) return fail(PG_E_INVALID, "sketch and seqset belong to different contexts");
     if (int r = use_device(sk->ctx)) return r;
+    // one launch over all contigs (a launch per contig was 76 ms per genome of 20 000 contigs)
+    std::vector<uint2> jobs;
     for (uint32_t c = 0; c < sq->n; ++c) {
         const SeqDesc &sd = sq->desc[c];
         if (sd.len < (uint64_t)sk->k) continue;
-        HIP_TRY(launch_sketch(sk->ctx->stream, sk->k, sq->d_seqw + sd.seq_off, sq->d_nmw + sd.seq_off, sq->d_has_n + c,
-                              sd.len - sk->k + 1, sk->d_regs));
+        const uint64_t nk = sd.len - sk->k + 1;
+        for (uint64_t q = 0; q * SKETCH_JOB < nk; ++q) jobs.push_back(make_uint2(c, (uint32_t)q));
     }
+    if (jobs.empty()) return PG_OK;
+    hipStream_t st = sk->ctx->stream;
+    uint2 *d_jobs = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_jobs), jobs.size() * sizeof(uint2)));
+    hipError_t e = hipMemcpyAsync(d_jobs, jobs.data(), jobs.size() * sizeof(uint2), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = launch_sketch_set(st, sk->k, sq->d_desc, d_jobs, (uint32_t)jobs.size(), sq->d_seqw, sq->d_nmw, sq->d_has_n, sk->d_regs);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);  // (the job list is freed below)
+    hipFree(d_jobs);
+    if (e != hipSuccess) return fail(PG_E_HIP, "pg_sketch_add_seqset: %s", hipGetErrorString(e));
     return PG_OK;
     PG_API_END
 }
@@ -1643,6 +1654,30 @@ extern "C" int pg_seqset_contig(const pg_seqset *s, uint32_t idx, const char **n
     if (idx >= s->n) return fail(PG_E_INVALID, "contig %u out of range", idx);
     if (name) *name = idx < s->names.size() ? s->names[idx].c_str() : "";
     if (len) *len = s->desc[idx].len;
+    return PG_OK;
+    PG_API_END
+}
+
+extern "C" int pg_seqset_describe(const pg_seqset *s, uint64_t *lens, char *names, uint64_t names_cap, uint64_t *names_bytes) {
+    PG_API_BEGIN
+    if (!s) return fail(PG_E_INVALID, "seqset is NULL");
+    uint64_t need = 0;
+    for (uint32_t i = 0; i < s->n; ++i) {
+        if (lens) lens[i] = s->desc[i].len;
+        need += (i < s->names.size() ? s->names[i].size() : 0) + 1;
+    }
+    if (names_bytes) *names_bytes = need;
+    if (names) {
+        if (names_cap < need) return fail(PG_E_INVALID, "pg_seqset_describe: %llu bytes of names, room for %llu", (unsigned long long)need, (unsigned long long)names_cap);
+        char *p = names;
+        for (uint32_t i = 0; i < s->n; ++i) {
+            if (i < s->names.size()) {
+                memcpy(p, s->names[i].data(), s->names[i].size());
+                p += s->names[i].size();
+            }
+            *p++ = 0;
+        }
+    }
     return PG_OK;
     PG_API_END
 }

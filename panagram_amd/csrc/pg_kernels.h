@@ -71,6 +71,10 @@ hipError_t launch_pack(hipStream_t st, const void *d_ascii, uint64_t len, uint64
                        uint64_t nwords, uint32_t *has_n);
 hipError_t launch_sketch(hipStream_t st, int k, const uint64_t *seqw, const uint32_t *nmw, const uint32_t *has_n,
                          uint64_t nkmers, uint32_t *regs);
+// ... of all contigs of a seqset in one launch: jobs[j] = (contig, chunk number) — positions [chunk, chunk + 1) x SKETCH_JOB
+constexpr uint32_t SKETCH_JOB = 1u << 16;
+hipError_t launch_sketch_set(hipStream_t st, int k, const SeqDesc *sd, const uint2 *jobs, uint32_t njobs, const uint64_t *seqw,
+                             const uint32_t *nmw, const uint32_t *has_n, uint32_t *regs);
 hipError_t launch_insert_seq(hipStream_t st, const SubTable &t, int w, uint32_t bits, int k,
                              const uint64_t *seqw, const uint32_t *nmw, const uint32_t *has_n,
                              uint64_t nkmers, unsigned long long *counters, uint32_t max_probe, int count_mode = 0);

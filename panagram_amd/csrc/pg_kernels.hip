@@ -259,6 +259,27 @@ __global__ __launch_bounds__(256) void k_sketch(int k, const uint64_t *seqw, con
     }
 }
 
+// the same over a whole seqset in ONE launch: job j = positions [start, start + SKETCH_JOB) of contig c (a launch per
+// contig cost an assembly of 20 000 contigs 76 ms per genome)
+__global__ __launch_bounds__(256) void k_sketch_set(int k, const SeqDesc *__restrict__ sd, const uint2 *__restrict__ jobs,
+                                                    const uint64_t *seqw_all, const uint32_t *nmw_all, const uint32_t *has_n,
+                                                    uint32_t *regs) {
+    const uint2 job = jobs[blockIdx.x];
+    const SeqDesc d = sd[job.x];
+    const uint64_t nkmers = d.len - (uint64_t)k + 1, p0 = (uint64_t)job.y * SKETCH_JOB, p1 = min(nkmers, p0 + SKETCH_JOB);
+    const uint64_t *seqw = seqw_all + d.seq_off;
+    const uint32_t *nmw = nmw_all + d.seq_off;
+    const bool hasn = has_n[job.x] != 0;
+    for (uint64_t p = p0 + threadIdx.x; p < p1; p += 256) {
+        if (hasn && extract_nmask(nmw, p, k)) continue;
+        const uint64_t h = sketch_hash(canonical_from_le(extract_bases(seqw, p), k));
+        const uint32_t idx = (uint32_t)(h >> (64 - SKETCH_BITS));
+        const uint64_t rest = h << SKETCH_BITS;
+        const uint32_t rho = rest ? (uint32_t)__clzll((long long)rest) + 1u : (65u - SKETCH_BITS);
+        if (regs[idx] < rho) atomicMax(&regs[idx], rho);
+    }
+}
+
 __global__ __launch_bounds__(256) void k_insert_keys(SubTable st, int w, const uint64_t *keys,
                                                      const uint32_t *vals, uint64_t n,
                                                      unsigned long long *counters, uint32_t max_probe) {
@@ -516,6 +537,13 @@ hipError_t launch_sketch(hipStream_t st, int k, const uint64_t *seqw, const uint
                          uint64_t nkmers, uint32_t *regs) {
     if (nkmers == 0) return hipSuccess;
     hipLaunchKernelGGL(k_sketch, dim3(grid_for(nkmers, 256, 256 * 64)), dim3(256), 0, st, k, seqw, nmw, has_n, nkmers, regs);
+    return hipGetLastError();
+}
+
+hipError_t launch_sketch_set(hipStream_t st, int k, const SeqDesc *sd, const uint2 *jobs, uint32_t njobs, const uint64_t *seqw,
+                             const uint32_t *nmw, const uint32_t *has_n, uint32_t *regs) {
+    if (njobs == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_sketch_set, dim3(njobs), dim3(256), 0, st, k, sd, jobs, seqw, nmw, has_n, regs);
     return hipGetLastError();
 }
 

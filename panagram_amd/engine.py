@@ -200,12 +200,11 @@ class SeqSet(_Owner):
         ss._h = h
         ctx._adopt(ss)
         n = int(ss._lib.pg_seqset_ncontigs(h))
-        names, lens = [], np.zeros(n, np.uint64)
-        for i in range(n):
-            nm, ln = C.c_char_p(), C.c_uint64()
-            check(ss._lib.pg_seqset_contig(h, i, C.byref(nm), C.byref(ln)))
-            names.append((nm.value or b"").decode("latin-1"))
-            lens[i] = ln.value
+        lens, need = np.zeros(n, np.uint64), C.c_uint64()
+        check(ss._lib.pg_seqset_describe(h, _ptr(lens), None, 0, C.byref(need)))  # (all contigs in two calls, not one each)
+        buf = np.zeros(max(1, need.value), np.uint8)
+        check(ss._lib.pg_seqset_describe(h, None, _ptr(buf), buf.size, None))
+        names = buf[:need.value].tobytes().decode("latin-1").split("\0")[:n] if n else []
         ss.names, ss.lens = names, lens
         return ss
 
