@@ -146,12 +146,36 @@ def _plan_class_pieces(contigs: Sequence[Tuple[str, int, int, int]], world: int,
     total = sum(nk for _, _, nk, _ in contigs)
     target = max(1, total // (world * max(1, pieces_per_rank)))
     units: List[Tuple[int, int, int, List[Piece]]] = []  # (weight, class, j, pieces)
+    # Small classes are dealt in BUNDLES of consecutive classes (the first genome's contig order), a quarter of a rank's
+    # target share at most: a draft assembly of 20 000 contigs dealt contig by contig leaves every rank every other contig
+    # — 20 000 fragments, markers and bin tables per genome to write and to put together again (two ranks on 4 x 4 000
+    # contigs: 35 s against 0.4 s on one).  A rank's contigs of a bundle are neighbours in their genomes, so they leave
+    # as ONE fragment (run_index_sharded).
+    cap = max(min_piece, target // 4)
+    bundle: List[Piece] = []
+    bundle_w, bundle_cls = 0, 0
+
+    def close_bundle():
+        nonlocal bundle, bundle_w
+        if bundle:
+            units.append((bundle_w, bundle_cls, 0, bundle))
+        bundle, bundle_w = [], 0
+
     for cls in sorted(by_class):
         members = by_class[cls]
         size = sum(nk for _, _, nk in members)
         npieces = 1
         if world > 1:
             npieces = max(1, min(int(round(size / target)), min(nk for _, _, nk in members) // min_piece))
+        if world > 1 and npieces == 1 and size < cap:
+            if bundle and bundle_w + size > cap:
+                close_bundle()
+            if not bundle:
+                bundle_cls = cls
+            bundle += [(name, ci, 0, nk, cls, 0) for name, ci, nk in members if nk > 0]
+            bundle_w += size
+            continue
+        close_bundle()
         for j in range(npieces):
             pieces = []
             for name, ci, nk in members:
@@ -161,6 +185,7 @@ def _plan_class_pieces(contigs: Sequence[Tuple[str, int, int, int]], world: int,
                     pieces.append((name, ci, b0, b1 - b0, cls, j))
             if pieces:
                 units.append((sum(p[3] for p in pieces), cls, j, pieces))
+    close_bundle()
     order = sorted(units, key=lambda u: (-u[0], u[1], u[2]))
     loads = [0] * world
     shards: List[List[Tuple[int, int, List[Piece]]]] = [[] for _ in range(world)]
@@ -285,8 +310,9 @@ def run_index_sharded(index, rank: int, world: int, barrier: Optional[Callable[[
         free = ctx.mem_info()[0]
         batch_bytes = int(min(index.batch_bytes, max(1 << 30, (free - (6 << 30)) / 2.3)))
         batches, cur, cur_bytes = [], [], 0
-        for key in sorted({(p[4], p[5]) for p in order}):
-            grp = [p for p in order if (p[4], p[5]) == key]
+        import itertools
+        for _key, grp_it in itertools.groupby(order, key=lambda p: (p[4], p[5])):  # (order is sorted by (class, piece, genome))
+            grp = list(grp_it)
             b = sum(p[3] for p in grp) * nb
             if cur and cur_bytes + b > batch_bytes:
                 batches.append(cur)
@@ -297,15 +323,11 @@ def run_index_sharded(index, rank: int, world: int, barrier: Optional[Callable[[
             batches.append(cur)
         payload = sum(p[3] for p in order) * nb
 
-        def write_piece(res, i, p):
-            g = index.genomes[p[0]]
-            os.makedirs(_parts_dir(g), exist_ok=True)
-            for s_ in index.steps:
-                res.write_bgzf(s_, f"{base(p)}.{s_}.gz", f"{base(p)}.{s_}.gzi", level=index.bgzf_level, threads=2, first_contig=i, ncontigs=1)
-            _, _, bins, info = res.download(i, want_bitmap1=False, want_bitmap100=False)
-            assert info["nkmers"] == p[3]
+        def piece_stats(res, i, p):
+            """bins (over the CONTIG's bin windows, clipped to the piece), first bin and gene histogram of piece p = contig i of res"""
             nk, bl = nk_of[(p[0], p[1])], contig_binlen(nk_of[(p[0], p[1])])
             bin0 = p[2] // bl
+            bins = None
             if p[3] != nk:
                 # a piece of a longer contig: the statistics over the CONTIG's bins (cpp/anchor.cpp:114-120,179-189)
                 # clipped to the piece — a bin that two pieces share is added up when the genome is assembled
@@ -316,18 +338,53 @@ def run_index_sharded(index, rank: int, world: int, barrier: Optional[Callable[[
             ghist = np.zeros(index.ngenomes + 1, np.int64)
             gt = genes.get(p[0])
             if gt is not None:  # the piece's share of its chromosome's gene occupancy (index.py:1055-1064): genes clipped to it
-                size = nk_of[(p[0], p[1])]
                 sel = gt[gt["chr"] == seqs[p[0]].names[p[1]]]
                 st, en = sel["start"].to_numpy(np.int64), sel["end"].to_numpy(np.int64)
-                ok = (en > st) & (st >= 0) & (en <= size)
+                ok = (en > st) & (st >= 0) & (en <= nk)
                 a, b = np.maximum(st[ok], p[2]) - p[2], np.minimum(en[ok], p[2] + p[3]) - p[2]
                 hit = b > a
                 if hit.any():
                     h, _ = res.window_stats(i, a[hit], b[hit], step=1, colsums=False)
                     ghist = h.sum(axis=0).astype(np.int64)
-            np.savez(base(p) + ".tmp.npz", bins=bins, colsums=res.contig_colsums(i, 1)[0].astype(np.int64), nkmers=info["nkmers"],
-                     bin0=bin0, nrows100=info["nrows100"], gene_hist=ghist, sig=sig)
-            os.replace(base(p) + ".tmp.npz", base(p) + ".npz")  # written last: the piece's completion marker
+            return bins, bin0, ghist
+
+        def write_unit(res, i0, ps):
+            """One fragment for a run of this rank's pieces that follow one another in their genome's files — whole
+            neighbouring contigs (a bundle of small classes), or a single piece: the rows' BGZF fragments, then the
+            marker with the pieces' bins, sums and gene histograms."""
+            g = index.genomes[ps[0][0]]
+            os.makedirs(_parts_dir(g), exist_ok=True)
+            m = len(ps)
+            for s_ in index.steps:
+                res.write_bgzf(s_, f"{base(ps[0])}.{s_}.gz", f"{base(ps[0])}.{s_}.gzi", level=index.bgzf_level, threads=2, first_contig=i0, ncontigs=m)
+            small = res.contigs_small(i0, m)
+            assert [int(x) for x in small.nkmers] == [p[3] for p in ps]
+            bins_l, bin0_l, gh_l = [], [], []
+            for q, p in enumerate(ps):
+                b, b0, gh = piece_stats(res, i0 + q, p) if (m == 1 or genes.get(p[0]) is not None) else (None, 0, np.zeros(index.ngenomes + 1, np.int64))
+                bins_l.append(small[q][2] if b is None else b.astype(np.uint32))  # (counts of a contig's bin: 32 bits, as on the device)
+                bin0_l.append(b0)
+                gh_l.append(gh)
+            np.savez(base(ps[0]) + ".tmp.npz", ci=np.array([p[1] for p in ps], np.int64), start=np.array([p[2] for p in ps], np.int64),
+                     nkmers=np.asarray(small.nkmers, np.int64), nrows100=np.asarray(small.nrows100, np.int64),
+                     nbins=np.array([len(b) for b in bins_l], np.int64), bin0=np.array(bin0_l, np.int64),
+                     bins=np.vstack(bins_l).astype(np.uint32) if bins_l else np.zeros((0, index.ngenomes + 1), np.uint32),
+                     colsums=res.contig_colsums(i0, m).astype(np.int64).sum(axis=0), gene_hist=np.vstack(gh_l), sig=sig)
+            os.replace(base(ps[0]) + ".tmp.npz", base(ps[0]) + ".npz")  # written last: the unit's completion marker
+
+        def units_of(layout):
+            """runs of the batch's pieces that one fragment can hold: neighbours in the batch AND in their genome's files
+            (whole contigs ci, ci + 1, ...)"""
+            out, i = [], 0
+            while i < len(layout):
+                p, m = layout[i], 1
+                whole = lambda x: x[2] == 0 and x[3] == nk_of[(x[0], x[1])]  # noqa: E731
+                while (i + m < len(layout) and whole(layout[i + m - 1]) and whole(layout[i + m]) and layout[i + m][0] == p[0]
+                       and layout[i + m][1] == layout[i + m - 1][1] + 1):
+                    m += 1
+                out.append((i, layout[i:i + m]))
+                i += m
+            return out
 
         with ThreadPoolExecutor(max_workers=index.writer_jobs(payload)) as pool:
             previous = None
@@ -348,7 +405,7 @@ def run_index_sharded(index, rank: int, world: int, barrier: Optional[Callable[[
                     res.coschedule(np.array([gid[p[0]] for p in layout], np.uint32),
                                    contig_class=np.array([cls_ids[(p[4], p[5])] for p in layout], np.uint32))
                 res.run()
-                futs = [pool.submit(write_piece, res, i, p) for i, p in enumerate(layout)]
+                futs = [pool.submit(write_unit, res, i0, ps) for i0, ps in units_of(layout)]
                 if previous is not None:  # at most two batches of rows resident
                     _finish(*previous)
                 previous = (res, merged, futs)
@@ -363,19 +420,35 @@ def run_index_sharded(index, rank: int, world: int, barrier: Optional[Callable[[
         pdir = _parts_dir(g)
         if not os.path.isdir(pdir) and ps:
             return os.path.exists(g.chrs_fname)  # assembled (and cleaned up) by another rank
-        def load_markers():
-            out = []
-            for p in ps:
+        def load_markers(full=True):
+            """the markers in the genome's .parts directory that carry this run's signature, if together they cover every
+            piece of the genome exactly once: [(first piece's base path, marker fields)] in file order — else None.
+            ``full`` off: only the fields that say what a marker covers (the bins of a fragmented genome are megabytes)"""
+            want = {(p[1], p[2]): p for p in ps}
+            found, seen = [], set()
+            try:
+                files = sorted(f for f in os.listdir(pdir) if f.endswith(".npz") and not f.endswith(".tmp.npz"))
+            except OSError:
+                return None
+            for f in files:
                 try:
-                    with np.load(base(p) + ".npz") as z:
+                    with np.load(os.path.join(pdir, f)) as z:
                         if str(z["sig"]) != sig:
-                            return None
-                        out.append({f: z[f] for f in z.files})
+                            continue
+                        d = {x: z[x] for x in (z.files if full else ("ci", "start", "nkmers"))}
                 except (FileNotFoundError, OSError, KeyError, ValueError):
                     return None
-            return out
+                keys = list(zip(d["ci"].tolist(), d["start"].tolist()))
+                if any(k_ not in want or k_ in seen for k_ in keys) or any(int(n_) != want[k_][3] for k_, n_ in zip(keys, d["nkmers"])):
+                    return None
+                seen.update(keys)
+                found.append((os.path.join(pdir, f[:-4]), keys, d))
+            if len(seen) != len(want):
+                return None
+            found.sort(key=lambda u: u[1][0])
+            return found
 
-        if load_markers() is None:
+        if load_markers(full=False) is None:
             return False
         os.makedirs(pdir, exist_ok=True)
         lock = os.path.join(pdir, "assemble.lock")
@@ -402,21 +475,37 @@ def run_index_sharded(index, rank: int, world: int, barrier: Optional[Callable[[
         os.makedirs(g.prefix, exist_ok=True)
         names = list(seqs[name].names)
         for s_ in index.steps:
-            concat_bgzf([(f"{base(p)}.{s_}.gz", f"{base(p)}.{s_}.gzi") for p in ps], g.bitmap_gz_fname(s_), g.bitmap_gzi_fname(s_))
-        bins_infos, gene_sum = [], {}
+            concat_bgzf([(f"{b_}.{s_}.gz", f"{b_}.{s_}.gzi") for b_, _, _ in metas], g.bitmap_gz_fname(s_), g.bitmap_gzi_fname(s_))
+        # the genome's bins in one array (contig after contig), every unit's rows added at its place
+        N1 = index.ngenomes + 1
+        nks = np.array([nk_of[(name, ci)] for ci in range(len(names))], np.int64)
+        bls = np.array([contig_binlen(int(nk)) for nk in nks], np.int64)
+        nbins = (nks + bls - 1) // bls
+        bin_off = np.concatenate([[0], np.cumsum(nbins)])
+        bins_all = np.zeros((int(bin_off[-1]), N1), np.int64)
+        nrows100 = np.zeros(len(names), np.int64)
+        covered = np.zeros(len(names), np.int64)
+        gene_sum = {}
         cs = np.zeros(index.ngenomes, np.int64)
-        for ci in range(len(names)):
-            zs = [z for p, z in zip(ps, metas) if p[1] == ci]
-            nk = nk_of[(name, ci)]
-            bl = contig_binlen(nk)
-            bins = np.zeros(((nk + bl - 1) // bl, index.ngenomes + 1), np.int64)
-            assert sum(int(z["nkmers"]) for z in zs) == nk
-            for z in zs:
-                b0 = int(z["bin0"])
-                bins[b0:b0 + len(z["bins"])] += z["bins"].astype(np.int64)
-                cs += z["colsums"]
-                gene_sum[names[ci]] = gene_sum.get(names[ci], 0) + z["gene_hist"]
-            bins_infos.append((bins, dict(nkmers=nk, nbins=len(bins), binlen=bl, nrows100=sum(int(z["nrows100"]) for z in zs))))
+        for _, keys, z in metas:
+            cs += z["colsums"]
+            off = np.concatenate([[0], np.cumsum(z["nbins"])])
+            whole_run = len(keys) > 1  # (whole neighbouring contigs: the unit's rows are the genome's, one block)
+            if whole_run:
+                a = int(bin_off[keys[0][0]])
+                assert int(off[-1]) == int(bin_off[keys[-1][0] + 1]) - a
+                bins_all[a:a + int(off[-1])] += z["bins"]
+            for q, (ci, _st) in enumerate(keys):
+                if not whole_run:
+                    a = int(bin_off[ci]) + int(z["bin0"][q])
+                    bins_all[a:a + int(z["nbins"][q])] += z["bins"][int(off[q]):int(off[q + 1])]
+                nrows100[ci] += int(z["nrows100"][q])
+                covered[ci] += int(z["nkmers"][q])
+                if g.annotated:
+                    gene_sum[names[ci]] = gene_sum.get(names[ci], 0) + z["gene_hist"][q]
+        assert np.array_equal(covered, nks)
+        bins_infos = pidx.engine.SmallOutputs(nks.astype(np.uint64), nrows100.astype(np.uint64), nbins.astype(np.uint32), bls.astype(np.uint32),
+                                              bins_all.astype(np.uint32))
         gene_hists = None
         if g.annotated:
             gene_hists = {}
@@ -429,8 +518,8 @@ def run_index_sharded(index, rank: int, world: int, barrier: Optional[Callable[[
                 gene_hists[chrom] = (len(grp), np.asarray(gene_sum.get(chrom, np.zeros(index.ngenomes + 1, np.int64)), np.int64))
         g._write_tables(names, bins_infos, cs, gene_hists)
         g.close_log()
-        for p in ps:  # markers first: from here on nobody takes the genome for complete-and-unassembled
-            os.remove(base(p) + ".npz")
+        for b_, _, _ in metas:  # markers first: from here on nobody takes the genome for complete-and-unassembled
+            os.remove(b_ + ".npz")
         for f in os.listdir(pdir):
             if f != "assemble.lock":
                 try:
