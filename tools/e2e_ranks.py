@@ -8,7 +8,7 @@ import _synth as po
 from panagram_amd import index as pidx
 ap = argparse.ArgumentParser()
 ap.add_argument("--genomes", type=int, default=4); ap.add_argument("--mb", type=float, default=40.0)
-ap.add_argument("--contigs", type=int, default=5); ap.add_argument("--world", type=int, default=2); ap.add_argument("--profile", action="store_true", help="cProfile of the LAST rank of the multi-rank run (it assembles)")
+ap.add_argument("--contigs", type=int, default=5); ap.add_argument("--world", type=int, default=2); ap.add_argument("--shard", default=None); ap.add_argument("--blocks", type=int, default=0); ap.add_argument("--profile", action="store_true", help="cProfile of the LAST rank of the multi-rank run (it assembles)")
 a = ap.parse_args()
 L, G, C, k = int(a.mb * 1e6), a.genomes, a.contigs, 21
 gen = po.synth_genomes(G, [L // C] * C, 0.01, 1234)
@@ -24,8 +24,8 @@ with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, f"idx{world}")
         for r in range(world):
             t0 = time.perf_counter()
-            idx = pidx.Index(os.path.join(d, "samples.tsv"), prefix=out, k=k, rank=r, world=world)
-            if a.profile and world > 1 and r == world - 1:
+            idx = pidx.Index(os.path.join(d, "samples.tsv"), prefix=out, k=k, rank=r, world=world, **(dict(shard=a.shard, genome_blocks=a.blocks) if a.shard else {}))
+            if a.profile and r == world - 1 and (world > 1 or a.world == 1):
                 import cProfile, pstats
                 pr = cProfile.Profile(); pr.enable(); idx.run(); pr.disable()
                 pstats.Stats(pr).sort_stats("cumulative").print_stats(30)
