@@ -166,7 +166,11 @@ def _plan_class_pieces(contigs: Sequence[Tuple[str, int, int, int]], world: int,
         size = sum(nk for _, _, nk in members)
         npieces = 1
         if world > 1:
-            npieces = max(1, min(int(round(size / target)), min(nk for _, _, nk in members) // min_piece))
+            # the cut is decided by the class's LONG members: a short scaffold that an assembly pairs with a 200 Mb
+            # chromosome (accession-style names fall back to pairing by position) must not make the class one unit —
+            # one rank would anchor that chromosome of every genome, against a table larger than the planner priced.
+            # Members too short for that many pieces stay whole, in piece 0.
+            npieces = max(1, min(int(round(size / target)), max(nk for _, _, nk in members) // min_piece))
         if world > 1 and npieces == 1 and size < cap:
             if bundle and bundle_w + size > cap:
                 close_bundle()
@@ -179,8 +183,11 @@ def _plan_class_pieces(contigs: Sequence[Tuple[str, int, int, int]], world: int,
         for j in range(npieces):
             pieces = []
             for name, ci, nk in members:
-                b0 = 0 if j == 0 else align * int(round(j * nk / (npieces * align)))
-                b1 = nk if j == npieces - 1 else align * int(round((j + 1) * nk / (npieces * align)))
+                if nk < npieces * min_piece:  # a short member of a class of long ones: whole, with the class's first piece
+                    b0, b1 = (0, nk) if j == 0 else (0, 0)
+                else:
+                    b0 = 0 if j == 0 else align * int(round(j * nk / (npieces * align)))
+                    b1 = nk if j == npieces - 1 else align * int(round((j + 1) * nk / (npieces * align)))
                 if b1 > b0:
                     pieces.append((name, ci, b0, b1 - b0, cls, j))
             if pieces:
@@ -356,9 +363,16 @@ def run_index_sharded(index, rank: int, world: int, barrier: Optional[Callable[[
             os.makedirs(_parts_dir(g), exist_ok=True)
             m = len(ps)
             for s_ in index.steps:
-                res.write_bgzf(s_, f"{base(ps[0])}.{s_}.gz", f"{base(ps[0])}.{s_}.gzi", level=index.bgzf_level, threads=2, first_contig=i0, ncontigs=m)
+                # (under a temporary name first: a rank that resumes over an aborted run's fragments of the same signature
+                # rewrites bytes another rank may be reading — a reader sees the old file or the new one, never half of one)
+                gz_, gzi_ = f"{base(ps[0])}.{s_}.gz", f"{base(ps[0])}.{s_}.gzi"
+                res.write_bgzf(s_, gz_ + ".tmp", gzi_ + ".tmp", level=index.bgzf_level, threads=2, first_contig=i0, ncontigs=m)
+                os.replace(gz_ + ".tmp", gz_)
+                os.replace(gzi_ + ".tmp", gzi_)
             small = res.contigs_small(i0, m)
-            assert [int(x) for x in small.nkmers] == [p[3] for p in ps]
+            if [int(x) for x in small.nkmers] != [p[3] for p in ps]:
+                raise RuntimeError(f"{ps[0][0]}: the result's contigs {[int(x) for x in small.nkmers]} are not the plan's pieces "
+                                   f"{[p[3] for p in ps]} (contig {ps[0][1]} from {ps[0][2]})")
             bins_l, bin0_l, gh_l = [], [], []
             for q, p in enumerate(ps):
                 b, b0, gh = piece_stats(res, i0 + q, p) if (m == 1 or genes.get(p[0]) is not None) else (None, 0, np.zeros(index.ngenomes + 1, np.int64))
@@ -395,7 +409,8 @@ def run_index_sharded(index, rank: int, world: int, barrier: Optional[Callable[[
                 for n, ps in zip(anchors, per_genome):
                     if ps:
                         first = own[n].index(ps[0])
-                        assert own[n][first:first + len(ps)] == ps
+                        if own[n][first:first + len(ps)] != ps:
+                            raise RuntimeError(f"{n}: a batch's pieces are not a run of this rank's slices (piece {ps[0][1:4]})")
                         parts.append((cut[n], first, len(ps)))
                         layout += ps
                 merged = engine.SeqSet.concat_ranges(ctx, parts)
@@ -418,7 +433,15 @@ def run_index_sharded(index, rank: int, world: int, barrier: Optional[Callable[[
         g = index.genomes[name]
         ps = pieces_of[name]
         pdir = _parts_dir(g)
-        if not os.path.isdir(pdir) and ps:
+        if not ps:
+            # a genome without a single k-mer position (an empty FASTA, contigs all shorter than k) has no piece and so
+            # no marker anybody could find complete: ONE rank — by the genome's number, no claim needed — writes its
+            # (empty) bitmaps and tables, as the one-rank run does
+            if gid[name] % world == rank:
+                os.makedirs(pdir, exist_ok=True)
+                return assemble_under_claim(name, g, ps, pdir, None, lambda full=True: [])
+            return os.path.exists(g.chrs_fname)
+        if not os.path.isdir(pdir):
             return os.path.exists(g.chrs_fname)  # assembled (and cleaned up) by another rank
         def load_markers(full=True):
             """the markers in the genome's .parts directory that carry this run's signature, if together they cover every
@@ -465,7 +488,7 @@ def run_index_sharded(index, rank: int, world: int, barrier: Optional[Callable[[
         # claim means the genome is ours to assemble)
         metas = load_markers()
         if metas is None:
-            os.remove(lock)
+            _remove_quietly(lock)
             try:
                 os.rmdir(pdir)
             except OSError:
@@ -493,7 +516,9 @@ def run_index_sharded(index, rank: int, world: int, barrier: Optional[Callable[[
             whole_run = len(keys) > 1  # (whole neighbouring contigs: the unit's rows are the genome's, one block)
             if whole_run:
                 a = int(bin_off[keys[0][0]])
-                assert int(off[-1]) == int(bin_off[keys[-1][0] + 1]) - a
+                if int(off[-1]) != int(bin_off[keys[-1][0] + 1]) - a:
+                    raise RuntimeError(f"{name}: the fragment of contigs {keys[0][0]}..{keys[-1][0]} holds {int(off[-1])} bins, "
+                                       f"the genome's geometry {int(bin_off[keys[-1][0] + 1]) - a} (a marker of another geometry?)")
                 bins_all[a:a + int(off[-1])] += z["bins"]
             for q, (ci, _st) in enumerate(keys):
                 if not whole_run:
@@ -503,7 +528,9 @@ def run_index_sharded(index, rank: int, world: int, barrier: Optional[Callable[[
                 covered[ci] += int(z["nkmers"][q])
                 if g.annotated:
                     gene_sum[names[ci]] = gene_sum.get(names[ci], 0) + z["gene_hist"][q]
-        assert np.array_equal(covered, nks)
+        if not np.array_equal(covered, nks):
+            bad = int(np.flatnonzero(covered != nks)[0])
+            raise RuntimeError(f"{name}: the fragments cover {int(covered[bad])} of contig {bad}'s {int(nks[bad])} k-mer positions")
         bins_infos = pidx.engine.SmallOutputs(nks.astype(np.uint64), nrows100.astype(np.uint64), nbins.astype(np.uint32), bls.astype(np.uint32),
                                               bins_all.astype(np.uint32))
         gene_hists = None
@@ -518,16 +545,38 @@ def run_index_sharded(index, rank: int, world: int, barrier: Optional[Callable[[
                 gene_hists[chrom] = (len(grp), np.asarray(gene_sum.get(chrom, np.zeros(index.ngenomes + 1, np.int64)), np.int64))
         g._write_tables(names, bins_infos, cs, gene_hists)
         g.close_log()
-        for b_, _, _ in metas:  # markers first: from here on nobody takes the genome for complete-and-unassembled
-            os.remove(b_ + ".npz")
-        for f in os.listdir(pdir):
-            if f != "assemble.lock":
-                try:
-                    os.remove(os.path.join(pdir, f))
-                except FileNotFoundError:  # (another rank's claim attempt, written aside and gone again)
-                    pass
-        shutil.rmtree(pdir, ignore_errors=True)  # (the claim goes last; a rank that finds the directory again finds no marker)
+        # markers first: from here on nobody takes the genome for complete-and-unassembled.  (A marker may be gone already:
+        # its rank resumed over an aborted run's fragments and removed it to write that unit again — same bytes.)
+        for b_, _, _ in metas:
+            _remove_quietly(b_ + ".npz")
+        # then what this assembly consumed — and nothing else: a rank still rewriting a stale unit keeps its temporary
+        # files and its directory, and clears them itself once it is through (leftovers(), below)
+        for b_, _, _ in metas:
+            for s_ in index.steps:
+                _remove_quietly(f"{b_}.{s_}.gz")
+                _remove_quietly(f"{b_}.{s_}.gzi")
+        if lock is not None:
+            _remove_quietly(lock)  # (the claim goes last; a rank that finds the directory again finds no marker)
+        try:
+            os.rmdir(pdir)
+        except OSError:
+            pass
         return True
+
+    def leftovers(name: str) -> None:
+        """this rank's units of a genome that was assembled over an aborted run's fragments while this rank was still
+        writing them again: nobody will read them"""
+        pdir = _parts_dir(index.genomes[name])
+        if not os.path.isdir(pdir):
+            return
+        for p in mine:
+            if p[0] == name:
+                for suffix in [".npz", ".tmp.npz"] + [f".{s_}.{e}" for s_ in index.steps for e in ("gz", "gzi", "gz.tmp", "gzi.tmp")]:
+                    _remove_quietly(base(p) + suffix)
+        try:
+            os.rmdir(pdir)
+        except OSError:
+            pass
 
     todo = [n for n in anchors]
     for phase in range(2):
@@ -535,6 +584,25 @@ def run_index_sharded(index, rank: int, world: int, barrier: Optional[Callable[[
         if barrier is None or phase == 1:
             break
         barrier()  # every rank's markers are out: whatever is still unassembled is complete now
+    if barrier is not None:
+        # no rank leaves (and tears the process group down, or reads the outputs) while another is still concatenating a
+        # genome it holds the claim of; after this barrier every genome must be there
+        barrier()
+        missing = [n for n in anchors if not os.path.exists(index.genomes[n].chrs_fname)]
+        if missing:
+            raise RuntimeError(f"rank {rank}: no rank assembled {missing} (fragments incomplete or of another run: see "
+                               f"{[_parts_dir(index.genomes[n]) for n in missing]})")
+        for n in anchors:
+            leftovers(n)
+    # (without a rendezvous — ranks started on their own, possibly one after the other — a rank cannot tell "another rank
+    # will assemble this" from "nobody will": the rank that finishes last finds every genome complete and assembles it)
+
+
+def _remove_quietly(path: str) -> None:
+    try:
+        os.remove(path)
+    except FileNotFoundError:
+        pass
 
 
 def _finish(res, merged, futs):

@@ -245,11 +245,22 @@ def test_plan_class_pieces_covers_balances_and_aligns():
             keys = {(p[4], p[5]) for p in sh}
             for key in keys:
                 assert {p[0] for p in sh if (p[4], p[5]) == key} == {f"g{g}" for g in range(8)}
-    # no piece below the minimum length; a class with a short contig is cut less often (or not at all)
+    # no CUT piece below the minimum length; a short member of a class of long ones (a scaffold that position pairing put
+    # beside a chromosome) does not hold the class back: the long member is cut, the short one stays whole in piece 0
     mixed = [("a", 0, 30_000_000, 0), ("b", 0, 1_500_000, 0), ("a", 1, 40_000_000, 1), ("b", 1, 41_000_000, 1)]
     plan = plan_class_pieces(mixed, 4)
-    assert sum(1 for sh in plan for p in sh if p[4] == 0) == 2 and sum(1 for sh in plan for p in sh if p[4] == 1) > 2
+    c0 = sorted(p for sh in plan for p in sh if p[4] == 0)
+    assert [p for p in c0 if p[0] == "b"] == [("b", 0, 0, 1_500_000, 0, 0)]
+    a0 = [p for p in c0 if p[0] == "a"]
+    assert len(a0) > 2 and a0[0][2] == 0 and sum(p[3] for p in a0) == 30_000_000
+    assert all(x[2] + x[3] == y[2] and y[2] % align == 0 for x, y in zip(a0, a0[1:]))
+    assert sum(1 for sh in plan for p in sh if p[4] == 1) > 2
     assert min(p[3] for sh in plan for p in sh) >= 1 << 20
+    loads = [sum(p[3] for p in sh) for sh in plan]
+    assert max(loads) <= 1.2 * sum(loads) / 4  # (one unit of 31.5 M on one rank before: 1.12 of ALL the work / 4 ... 1.0 of it)
+    # a class whose members are ALL short stays one unit
+    assert len([p for sh in plan_class_pieces([("a", 0, 900_000, 0), ("b", 0, 800_000, 0), ("a", 1, 9_000_000, 1),
+                                                ("b", 1, 9_000_000, 1)], 2) for p in sh if p[4] == 0]) == 2
 
 
 def _piece_pangenome(tmp_path):
@@ -339,6 +350,106 @@ def test_index_run_deals_pieces_of_homology_classes(world, tmp_path, monkeypatch
         (tmp_path / "many" / "anchor" / "g0" / "bitsum.genes.tsv").read_bytes()
     genes = pd.read_table(tmp_path / "many" / "anchor" / "g0" / "bitsum.genes.tsv", index_col="chr")
     assert genes.loc["chr1"].sum() > 0
+
+
+def _small_pangenome(tmp_path, lens_by_genome, seed=5):
+    ncontigs = max(len(x) for x in lens_by_genome)
+    longest = [max(x[ci] for x in lens_by_genome if ci < len(x)) for ci in range(ncontigs)]
+    gen = po.synth_genomes(len(lens_by_genome), longest, 0.02, seed)
+    rows = ["name\tfasta"]
+    for g, lens in enumerate(lens_by_genome):
+        seqs = [po.codes_to_ascii(c)[:ln] for c, ln in zip(gen[g], lens)]
+        fa = tmp_path / f"g{g}.fa"
+        fa.write_bytes(po.fasta_text([f"chr{ci + 1}" for ci in range(len(seqs))], seqs, 70))
+        rows.append(f"g{g}\t{fa}")
+    s = tmp_path / "samples.tsv"
+    s.write_text("\n".join(rows) + "\n")
+    return s
+
+
+def _trees_equal(a_root, b_root, genomes, steps=(1, 50)):
+    for g in genomes:
+        a, b = a_root / "anchor" / g, b_root / "anchor" / g
+        for step in steps:
+            assert gzip.open(a / f"bitmap.{step}.gz", "rb").read() == gzip.open(b / f"bitmap.{step}.gz", "rb").read(), (g, step)
+            assert (b / f"bitmap.{step}.gzi").exists()
+        for t in ("bitsum.bins.tsv", "chrs.tsv", "total_paircounts.csv"):
+            assert (a / t).read_bytes() == (b / t).read_bytes(), (g, t)
+        assert not (b / ".parts").exists(), g
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_an_anchor_genome_without_kmer_positions_still_gets_its_files(world, tmp_path, monkeypatch):
+    """An anchor genome whose contigs are all shorter than k (or an empty FASTA) has no piece, so no rank's marker ever
+    completes it: one rank writes its (empty) bitmaps and tables, as the one-rank run does — it used to be left without
+    an output directory, silently."""
+    from panagram_amd import index as pidx
+    from tests import fake_engine
+    s = _small_pangenome(tmp_path, [[30000, 9000], [15], [30000, 9000, 12], [18, 7]])
+    geo = dict(k=21, lowres_step=50, max_bin_kbp=3, min_bin_count=5)
+    monkeypatch.setattr(pidx, "engine", fake_engine)
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    monkeypatch.setenv("RANK", "0")
+    pidx.Index(str(s), prefix=str(tmp_path / "one"), **geo).run()
+    pidx.Index(str(s), prefix=str(tmp_path / "many"), prepare=True, **geo)
+    monkeypatch.setenv("PG_MIN_PIECE", "3000")
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_pieces_worker, args=(world, port, str(tmp_path / "many")), nprocs=world, join=True)
+    _trees_equal(tmp_path / "one", tmp_path / "many", [f"g{g}" for g in range(4)])
+    assert gzip.open(tmp_path / "many" / "anchor" / "g1" / "bitmap.1.gz", "rb").read() == b""
+    # ... and with the ranks run by hand one after the other (no process group, no barrier)
+    pidx.Index(str(s), prefix=str(tmp_path / "byhand"), prepare=True, **geo)
+    from panagram_amd import distributed as pdist
+    monkeypatch.setattr(pdist, "MIN_PIECE", 3000)
+    monkeypatch.setenv("WORLD_SIZE", str(world))
+    for rank in range(world):
+        monkeypatch.setenv("RANK", str(rank))
+        pidx.Index(str(tmp_path / "byhand"), mode="w").run()
+    _trees_equal(tmp_path / "one", tmp_path / "byhand", [f"g{g}" for g in range(4)])
+
+
+def test_a_run_over_an_aborted_runs_fragments_writes_the_same_tree(tmp_path, monkeypatch):
+    """Rank 0 of a two-rank run dies after its pieces (fragments and markers of this run's signature stay behind); the
+    run is started again: the ranks write their units anew (under temporary names, renamed when complete), the genome is
+    assembled once, nothing is left in .parts — also when a marker vanishes under the assembler (its rank resuming)."""
+    from panagram_amd import distributed as pdist
+    from panagram_amd import index as pidx
+    from tests import fake_engine
+    s = _small_pangenome(tmp_path, [[30000, 9000], [30000, 9000], [29000, 9000]])
+    geo = dict(k=21, lowres_step=50, max_bin_kbp=3, min_bin_count=5)
+    monkeypatch.setattr(pidx, "engine", fake_engine)
+    monkeypatch.setattr(pdist, "MIN_PIECE", 3000)
+    monkeypatch.setenv("PG_MIN_PIECE", "3000")
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    monkeypatch.setenv("RANK", "0")
+    pidx.Index(str(s), prefix=str(tmp_path / "one"), **geo).run()
+    pidx.Index(str(s), prefix=str(tmp_path / "many"), prepare=True, **geo)
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    pidx.Index(str(tmp_path / "many"), mode="w").run()  # rank 0 alone: its units, nothing assembled
+    parts = tmp_path / "many" / "anchor" / "g0" / ".parts"
+    stale = sorted(f for f in os.listdir(parts) if f.endswith(".npz"))
+    assert stale and not (tmp_path / "many" / "anchor" / "g0" / "chrs.tsv").exists()
+    assert not [f for f in os.listdir(parts) if f.endswith(".tmp")]
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_pieces_worker, args=(2, port, str(tmp_path / "many")), nprocs=2, join=True)
+    _trees_equal(tmp_path / "one", tmp_path / "many", ["g0", "g1", "g2"])
+    # a marker that is gone when the assembler comes to remove it does not stop the assembly
+    pidx.Index(str(s), prefix=str(tmp_path / "again"), prepare=True, **geo)
+    for rank in (0, 1):
+        monkeypatch.setenv("RANK", str(rank))
+        if rank == 1:
+            real = pdist._remove_quietly
+            gone = []
+
+            def remove_twice(path, real=real, gone=gone):
+                if path.endswith(".npz") and not gone:
+                    os.remove(path)  # (what a resuming rank does to its stale marker under the assembler's feet)
+                    gone.append(path)
+                real(path)
+            monkeypatch.setattr(pdist, "_remove_quietly", remove_twice)
+        pidx.Index(str(tmp_path / "again"), mode="w").run()
+    assert gone
+    _trees_equal(tmp_path / "one", tmp_path / "again", ["g0", "g1", "g2"])
 
 
 def _claim_racer(path, rounds, start, done, q):
