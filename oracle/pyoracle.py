@@ -550,34 +550,35 @@ def window_stats(rows: np.ndarray, ngenomes: int, starts, ends) -> Tuple[np.ndar
 # include/panagram_hip.h: tile t (512 positions of one contig) owns 8 slots of `width` u64 words;
 # word (8 t + s) * width + j holds genome g0 + j at positions 64 s .. 64 s + 63 of the tile (bit l).
 # ---------------------------------------------------------------------------
-def extract_columns(contig_rows: Sequence[np.ndarray], ngenomes: int, g0: int, width: int) -> np.ndarray:
-    tiles = []
+def extract_columns(contig_rows: Sequence[np.ndarray], ngenomes: int, g0: int, width: int, tile: int = 512) -> np.ndarray:
+    """(``tile``: positions per tile of the engine whose blocks these are — pg_tile_positions(); a tile owns tile / 64 slots)"""
+    tiles, ns = [], tile // 64
     for rows in contig_rows:
         bits = np.unpackbits(rows, axis=1, bitorder="little")[:, :ngenomes]
-        nt = (len(rows) + 511) // 512
-        pad = np.zeros((nt * 512, width), np.uint8)
+        nt = (len(rows) + tile - 1) // tile
+        pad = np.zeros((nt * tile, width), np.uint8)
         hi = min(ngenomes, g0 + width)
         if hi > g0:
             pad[:len(rows), :hi - g0] = bits[:, g0:hi]
         # [tile, slot, lane, j] -> [tile, slot, j, lane] -> 64 lane bits -> one u64, little bit order
-        v = pad.reshape(nt, 8, 64, width).transpose(0, 1, 3, 2)
-        tiles.append(np.packbits(v, axis=3, bitorder="little").reshape(nt * 8 * width * 8))
+        v = pad.reshape(nt, ns, 64, width).transpose(0, 1, 3, 2)
+        tiles.append(np.packbits(v, axis=3, bitorder="little").reshape(nt * ns * width * 8))
     return np.concatenate(tiles) if tiles else np.zeros(0, np.uint8)
 
 
-def merge_columns(blocks: Sequence[np.ndarray], contig_nkmers: Sequence[int], ngenomes: int, per: int) -> List[np.ndarray]:
+def merge_columns(blocks: Sequence[np.ndarray], contig_nkmers: Sequence[int], ngenomes: int, per: int, tile: int = 512) -> List[np.ndarray]:
     nbytes = (ngenomes + 7) // 8
-    out, off = [], 0
+    out, off, ns = [], 0, tile // 64
     for nk in contig_nkmers:
-        nt = (nk + 511) // 512
-        bits = np.zeros((nt * 512, nbytes * 8), np.uint8)
+        nt = (nk + tile - 1) // tile
+        bits = np.zeros((nt * tile, nbytes * 8), np.uint8)
         for i, blk in enumerate(blocks):
-            words = blk[off * per:(off + nt * 64) * per]
-            v = np.unpackbits(words.reshape(nt, 8, per, 8), axis=3, bitorder="little")  # [tile, slot, j, lane]
-            v = v.transpose(0, 1, 3, 2).reshape(nt * 512, per)
+            words = blk[off * per:(off + nt * ns * 8) * per]
+            v = np.unpackbits(words.reshape(nt, ns, per, 8), axis=3, bitorder="little")  # [tile, slot, j, lane]
+            v = v.transpose(0, 1, 3, 2).reshape(nt * tile, per)
             hi = min(ngenomes, (i + 1) * per)
             if hi > i * per:
                 bits[:, i * per:hi] = v[:, :hi - i * per]
         out.append(np.packbits(bits[:nk], axis=1, bitorder="little"))
-        off += nt * 64
+        off += nt * ns * 8
     return out

@@ -55,9 +55,23 @@ constexpr int PROBE_SEQW = ((PROBE_TILE + 31) / 32 + 6 + 3) & ~3;  // staged 32-
 #define PG_RC_LDS 1
 #endif
 #ifndef PG_PROBE_PIPE
-#define PG_PROBE_PIPE 1  // the front end of batch i + 1 ahead of the table look-up of batch i (k_probe)
+#define PG_PROBE_PIPE 2  // 1: the front end of batch i + 1 ahead of the table look-up of batch i (k_probe); 2: and its fetch issued as soon as batch i's chunks are staged
 #endif
 constexpr uint32_t PROBE_SEQ_BASES = 32u * PROBE_SEQW;
+// -DPG_PHASE_TIMING: a measuring build (tools/phase_timing.py) — every wave of k_probe stamps s_memtime at its phase
+// boundaries and adds the phases' cycles to pg_phase_cycles at the end of its tile: where a wave's time goes, waits for
+// the other waves of its SIMD included.  Slots: 0 prologue, 1 front end, 2 wait for the lines, 3 staging, 4 issue of the
+// next fetch, 5 slot scan, 6 overflow entries + row store, 7 loop bookkeeping, 8 drain + tail, 9 waves.
+#ifdef PG_PHASE_TIMING
+__device__ unsigned long long pg_phase_cycles[1024 * 16];  // (1024 sets, by block number: ten same-address atomics per wave serialise the launch)
+#define PG_PH_DECL uint32_t ph_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; uint32_t ph_t = (uint32_t)__builtin_readcyclecounter();
+#define PG_PH(i) { const uint32_t ph_n = (uint32_t)__builtin_readcyclecounter(); ph_acc[i] += ph_n - ph_t; ph_t = ph_n; }
+#define PG_PH_FLUSH { if (threadIdx.x == 0) { for (int ph_i = 0; ph_i < 9; ++ph_i) atomicAdd(&pg_phase_cycles[(blockIdx.x & 1023u) * 16u + ph_i], (unsigned long long)ph_acc[ph_i]); atomicAdd(&pg_phase_cycles[(blockIdx.x & 1023u) * 16u + 9], 1ull); } }
+#else
+#define PG_PH_DECL
+#define PG_PH(i)
+#define PG_PH_FLUSH
+#endif
 __device__ __forceinline__ uint64_t revcomp_window(const uint64_t *rw, uint64_t X, uint32_t p, int k, uint64_t kmask) {
 #if PG_RC_LDS
     return extract_bases32(reinterpret_cast<const uint32_t *>(rw), PROBE_SEQ_BASES - p - (uint32_t)k) & kmask;
@@ -69,14 +83,42 @@ __device__ __forceinline__ uint64_t revcomp_window(const uint64_t *rw, uint64_t 
 // scan the 8 slots of a line staged in LDS.  Lines fill front to back without holes (an insert
 // claims the first EMPTY slot and slots never revert), so "full" == last slot used.
 // returns 1 = found, 0 = absent (line not full), -1 = absent from a full line
+#ifndef PG_LDS_SOA
+#define PG_LDS_SOA 1  // staged lines keep their keys and their mask words apart in LDS (stage_chunk / scan_line_lds)
+#endif
+// A table line {key, m0, m1} x SLOTS is staged into LDS as SLOTS keys followed by SLOTS mask pairs: the scan then takes its
+// keys in SLOTS / 2 ds_read_b128 — 4 LDS cycles per 16 bytes and lane — where one ds_read2_b64 per two slots of the
+// interleaved line took 8 (MI355X_MICROARCH.md, LDS table): 16 instead of 32 LDS cycles per batch for the 8 keys, the
+// largest single item of a batch's ~95.  The staging lane's 16-byte chunk leaves as two 8-byte stores (6 + 6 cycles
+// against 13 for the one ds_write_b128).
+__device__ __forceinline__ void stage_chunk(uint4 *line, uint32_t slot, int slots, const uint4 v) {
+#if PG_LDS_SOA
+    uint2 *const p = reinterpret_cast<uint2 *>(line);
+    p[slot] = make_uint2(v.x, v.y);
+    p[slots + slot] = make_uint2(v.z, v.w);
+#else
+    line[slot] = v;
+#endif
+}
 template <bool TWO, int SLOTS>
 __device__ __forceinline__ int scan_line_lds(const uint4 *line, uint64_t key, uint32_t &m0, uint32_t &m1) {
     // all SLOTS key reads are issued together (one LDS wait); one compare per slot into a scalar lane mask;
     // the scalar unit folds the masks into the three bits of the hit slot's number (at most one slot holds the
     // key), three v_cndmask turn them into the slot's byte offset, and only that slot's masks are read
     uint64_t kk[SLOTS];
+#if PG_LDS_SOA
+#pragma unroll
+    for (int j = 0; j < SLOTS / 2; ++j) {
+        const uint4 v = line[j];
+        kk[2 * j] = (uint64_t)v.x | ((uint64_t)v.y << 32);
+        kk[2 * j + 1] = (uint64_t)v.z | ((uint64_t)v.w << 32);
+    }
+    constexpr uint32_t SLOT_BYTES = 8u, MASK0 = 8u * SLOTS;  // a slot's masks: MASK0 + 8 * slot
+#else
 #pragma unroll
     for (int sl = 0; sl < SLOTS; ++sl) kk[sl] = *reinterpret_cast<const uint64_t *>(line + sl);
+    constexpr uint32_t SLOT_BYTES = 16u, MASK0 = 8u;
+#endif
     m0 = m1 = 0;
     if constexpr (SLOTS == 8) {
         // (ballot of a compare = v_cmp_eq_u64 with a scalar destination; inverse_ballot = the SGPR pair used as a
@@ -96,11 +138,15 @@ __device__ __forceinline__ int scan_line_lds(const uint4 *line, uint64_t key, ui
         return (kk[0] ^ kk[3]) == key ? -1 : 1;
 #endif
         if (hit) {
-            const uint32_t off = (__builtin_amdgcn_inverse_ballot_w64(b0) ? 16u : 0u) | (__builtin_amdgcn_inverse_ballot_w64(b1) ? 32u : 0u) |
-                                 (__builtin_amdgcn_inverse_ballot_w64(b2) ? 64u : 0u);
-            const uint2 mk = *reinterpret_cast<const uint2 *>(reinterpret_cast<const uint8_t *>(line) + off + 8);
-            m0 = mk.x;
-            if (TWO) m1 = mk.y;
+            const uint32_t off = (__builtin_amdgcn_inverse_ballot_w64(b0) ? SLOT_BYTES : 0u) | (__builtin_amdgcn_inverse_ballot_w64(b1) ? 2u * SLOT_BYTES : 0u) |
+                                 (__builtin_amdgcn_inverse_ballot_w64(b2) ? 4u * SLOT_BYTES : 0u);
+            if constexpr (TWO) {
+                const uint2 mk = *reinterpret_cast<const uint2 *>(reinterpret_cast<const uint8_t *>(line) + off + MASK0);
+                m0 = mk.x;
+                m1 = mk.y;
+            } else {
+                m0 = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(line) + off + MASK0);
+            }
         }
         return hit ? 1 : (kk[SLOTS - 1] == EMPTY_KEY ? 0 : -1);
     } else {
@@ -108,7 +154,7 @@ __device__ __forceinline__ int scan_line_lds(const uint4 *line, uint64_t key, ui
 #pragma unroll
         for (int sl = 0; sl < SLOTS; ++sl) hit = (kk[sl] == key) ? sl : hit;
         if (hit >= 0) {
-            const uint2 mk = *reinterpret_cast<const uint2 *>(reinterpret_cast<const uint8_t *>(line + hit) + 8);
+            const uint2 mk = *reinterpret_cast<const uint2 *>(reinterpret_cast<const uint8_t *>(line) + (uint32_t)hit * SLOT_BYTES + MASK0);
             m0 = mk.x;
             if (TWO) m1 = mk.y;
         }
@@ -214,21 +260,6 @@ __device__ __forceinline__ void lane_chase_wide(const SubTable &st, uint64_t key
         advance_line(key, level, st.nbuckets, b, step);
     }
 }
-__device__ __attribute__((noinline)) uint2 lane_chase_wide_cold(uint8_t *buckets, uint64_t nbuckets, uint64_t key, uint32_t level,
-                                                                uint32_t b, uint32_t step) {
-    SubTable t;
-    t.buckets = buckets;
-    t.masks = nullptr;
-    t.nbuckets = nbuckets;
-    t.W = 0;
-    t.word0 = 0;
-    t.k = t.m = 0;
-    t.slots = SPLIT_KEYS;
-    t.layout = LAYOUT_SPLIT;
-    uint32_t hl, s1;
-    lane_chase_wide(t, key, level, b, step, hl, s1);
-    return make_uint2(hl, s1);
-}
 
 // the row of a position: the W mask words of (line, slot1 - 1), or zeros (slot1 == 0); nbytes = ceil(N / 8).
 // Rows and mask blocks are contiguous, so the copy goes in the widest pieces the width allows — one dwordx4 / x3 /
@@ -299,26 +330,6 @@ __device__ __forceinline__ void store_row_wide(const uint8_t *masks, uint32_t W,
     }
 }
 
-// the same out of line, everything by value (nothing of the caller is forced into scratch): for call
-// sites on a hot path where the chase itself is rare — inlined, its hash set-up gets hoisted into the
-// common path
-template <bool TWO, int SLOTS>
-__device__ __attribute__((noinline)) uint2 lane_chase_cold(uint8_t *buckets, uint64_t nbuckets, uint64_t key,
-                                                           uint32_t level, uint32_t b, uint32_t step) {
-    SubTable t;
-    t.buckets = buckets;
-    t.nbuckets = nbuckets;
-    t.W = TWO ? 2 : 1;
-    t.word0 = 0;
-    t.k = t.m = 0;
-    t.slots = SLOTS;
-    t.layout = LAYOUT_SLOTS;
-    t.masks = nullptr;
-    uint32_t m0, m1;
-    lane_chase<TWO, SLOTS>(t, key, level, b, step, m0, m1);
-    return make_uint2(m0, m1);
-}
-
 // write the row bytes this sub-table owns: low nb0 bytes of m0 at column col0, low nb1 bytes of
 // m1 at col0+4 (cpp/anchor.cpp:139-164).  ROWMODE 1: one-byte rows; 2: 8-byte rows (N = 64);
 // 0: generic byte loop.
@@ -375,6 +386,15 @@ __device__ __forceinline__ void store_row(uint8_t *row, uint32_t m0, uint32_t m1
 __device__ __forceinline__ uint32_t lane_up1(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
 }
+// lanes whose value differs from that of the lane below, as a lane mask: an xor whose first source is the DPP shift (a fast
+// VOP2 instruction; gfx950 has no DPP form of the compares) and a compare with zero — a move, the shift and a compare
+// before.  Lane 0 has no lane below: its bit is arbitrary — callers OR the mask with one that has bit 0 set, or ignore
+// lane 0.  (s_nop 1: a DPP source written by the VALU instruction before needs two wait states.)
+__device__ __forceinline__ unsigned long long differs_from_lane_below(uint32_t v) {
+    uint32_t t;
+    asm("s_nop 1\n\tv_xor_b32_dpp %0, %1, %1 wave_shr:1 row_mask:0xf bank_mask:0xf" : "=&v"(t) : "v"(v));
+    return __builtin_amdgcn_ballot_w64(t != 0u);
+}
 // Sliding minimum over the last W lanes (lanes below W-1 see shorter windows): m <- min(own, m of the lane below),
 // W-1 times, each step ONE instruction — the DPP shift is the min's own source modifier; lane 0, which has no lane
 // below, is left alone and keeps its m.  6 instructions for W = 7 where shuffle-doubling took 6 moves + 3 min +
@@ -407,11 +427,13 @@ __device__ __forceinline__ uint32_t lanes_le_index(unsigned long long mask, uint
 }
 
 // ROWMODE 3 — the genome-sharded mode's narrow tables (a block of up to 8 genomes): the probe emits the block's
-// COMPACT BIT COLUMNS directly — per tile 8 x u64 per genome, bit l of word s = position 64 s + l — instead of one-byte
+// COMPACT BIT COLUMNS directly — per tile TILE_SLOTS x u64 per genome, bit l of word s = position 64 s + l — instead of one-byte
 // rows that k_cols_extract would read back: the tile's columns are assembled in LDS (one ballot per genome and batch,
 // shifted to the batch's place by the scalar unit; positions resolved by the overflow levels OR their bits in) and
 // written once, 64 bytes per genome and tile.
 constexpr int COLS_G = 8;  // genomes per block in columns mode
+constexpr uint32_t TILE_SLOTS = PROBE_TILE / 64;  // u64 column words per genome and tile (a slot = 64 positions)
+static_assert(PROBE_TILE % 512 == 0, "the column kernels take a tile in units of 512 positions");
 __device__ __forceinline__ void cols_or_position(unsigned long long *cols, uint32_t pl, uint32_t m0) {
     while (m0) {  // (rare path: a lane per resolved position, an LDS atomic per set bit)
         const uint32_t j = (uint32_t)__ffs((int)m0) - 1u;
@@ -492,7 +514,8 @@ __device__ __forceinline__ void drain_queue(const SubTable &st, uint32_t qn, con
 #pragma unroll
                 for (int u = 0; u < STAGE_ITERS; ++u) {
                     const uint32_t idx = u * 64 + lane;
-                    buf[(idx / SLOTS) * LDS_LINE_U4 + (idx % SLOTS)] = v[u];
+                    if constexpr (WIDE) buf[(idx / SLOTS) * LDS_LINE_U4 + (idx % SLOTS)] = v[u];  // (bare keys: as they are)
+                    else stage_chunk(buf + (idx / SLOTS) * LDS_LINE_U4, idx % SLOTS, SLOTS, v[u]);
                 }
                 __syncthreads();
                 if (act && rid - r0 < nl) {
@@ -538,8 +561,12 @@ __device__ __forceinline__ void drain_queue(const SubTable &st, uint32_t qn, con
 // staging geometry is the same, a line holds 16 bare keys; m0 / m1 carry the hit's line and slot + 1)
 // (probe_pipelined: the instantiations that run the skewed batch order, see the end of the kernel; they are held to the 64
 // registers of 8 waves per SIMD — the only spill that costs them sits around the queue-full call, a cold path)
+#ifndef PG_PIPE_MORE
+#define PG_PIPE_MORE 5  // which further instantiations run the skewed order: bit 0 two-word slots, 1 split layout, 2 the 6-m-mer window, 3 generic rows
+#endif
 template <int W_C, bool TWO, int ROWMODE, int SLOTS, bool WIDE>
-constexpr bool probe_pipelined = PG_PROBE_PIPE && (ROWMODE == 1 || ROWMODE >= 4) && !TWO && !WIDE && SLOTS == 8 && W_C != 6;
+constexpr bool probe_pipelined = PG_PROBE_PIPE && SLOTS == 8 && (ROWMODE != 3) && ((ROWMODE == 1 || ROWMODE >= 4) || (PG_PIPE_MORE & 8) || TWO || WIDE) &&
+                                 (!TWO || (PG_PIPE_MORE & 1)) && (!WIDE || (PG_PIPE_MORE & 2)) && (W_C != 6 || (PG_PIPE_MORE & 4));
 // The scalar registers count too: a SIMD's 800 SGPRs admit floor(800 / (ceil(sgpr / 16) * 16 + 16)) waves — 8 up to 80, 7 up to
 // 96, 6 up to 112 (MI355X_MICROARCH.md) — whatever the compiler's own occupancy figure says.  Left alone the generic-row and
 // split-layout instantiations took 92 and 105 (their lane masks live on the scalar unit): 7 and 6 waves.  Held to 80, a dozen
@@ -552,9 +579,6 @@ __attribute__((amdgpu_num_sgpr(80))) void k_probe(const SubTable st, const uint6
                                               const uint32_t *__restrict__ tile_contig,
                                               const uint32_t *__restrict__ sched, uint32_t tile_base,
                                               uint8_t *__restrict__ out1, uint32_t nbytes, const RowCols rc) {
-    __shared__ uint64_t sw[PROBE_SEQW];
-    __shared__ uint64_t rw[PROBE_SEQW + 1];
-    __shared__ uint32_t nw[PROBE_SEQW];
     // A staged line occupies 16*SLOTS + 16 bytes of LDS: the pad keeps the lanes' ds_read_b128 of
     // "their" lines off a common bank group (a power-of-two stride would be a 32-way conflict)
     constexpr int LDS_LINE_U4 = SLOTS + 1;
@@ -563,13 +587,32 @@ __attribute__((amdgpu_num_sgpr(80))) void k_probe(const SubTable st, const uint6
     // on 64 x 20 Mb, 92.0 -> 89.7 on 64 x 200 Mb; everywhere else 24 costs 8-10 %: LDS, occupancy; tools/ab_maxrun.sh)
     constexpr int MAXRUN = W_C == 6 ? (PROBE_MAXRUN * 3) / 2 : PROBE_MAXRUN;
     constexpr int STAGE_ITERS = (MAXRUN * SLOTS + 63) / 64;  // 16-byte loads per lane per staging step
-    __shared__ uint32_t lines_w[1][MAXRUN];
-    __shared__ uint4 buf[1][((STAGE_ITERS * 64 + SLOTS - 1) / SLOTS) * LDS_LINE_U4];  // room for every staged chunk slot
-    __shared__ uint32_t q_line[PROBE_QCAP];  // overflow queue of the tile (position order): next line to try,
-    __shared__ uint32_t q_step[PROBE_QCAP];  // step of the entry's sequence
-    __shared__ uint16_t q_pl[PROBE_QCAP];    // and position within the tile (the key is re-derived from sw)
+    // ONE block of LDS, carved up by hand, the tile's sequence words FIRST: the two-dword window reads of every batch
+    // (ds_read2_b32, whose offsets reach 1020 bytes) then address them with an immediate instead of an add per window
+    // (left to itself the compiler put the staging buffer first and the sequence words at 4.2-4.6 KB).
+    constexpr int BUF_U4 = ((STAGE_ITERS * 64 + SLOTS - 1) / SLOTS) * LDS_LINE_U4;  // room for every staged chunk slot
+    constexpr int OFF_RW = PROBE_SEQW * 8, OFF_NW = OFF_RW + (PROBE_SEQW + 1) * 8, OFF_LW = OFF_NW + PROBE_SEQW * 4;
+    // (the 6-m-mer window stages 24 lines per step: with the full queue its 5968 bytes round up to 6144 = 26 waves per CU,
+    // 6 per SIMD; 152 entries bring it to 5568 -> 5632 = 29 waves, 7 per SIMD)
+    constexpr int QCAP = (W_C == 6 && PROBE_QCAP > 152) ? 152 : PROBE_QCAP;
+    constexpr int OFF_BUF = (OFF_LW + MAXRUN * 4 + 15) & ~15, OFF_QL = OFF_BUF + BUF_U4 * 16, OFF_QS = OFF_QL + QCAP * 4;
+    constexpr int OFF_QP = OFF_QS + QCAP * 4, LDS_BYTES = OFF_QP + QCAP * 2;
+    static_assert(OFF_LW <= 1020 || PROBE_TILE > 1024, "the sequence words must stay within reach of ds_read2_b32's offsets");
+    __shared__ __attribute__((aligned(16))) uint8_t lds[LDS_BYTES];
+    uint64_t *const sw = reinterpret_cast<uint64_t *>(lds);
+    uint64_t *const rw = reinterpret_cast<uint64_t *>(lds + OFF_RW);
+    uint32_t *const nw = reinterpret_cast<uint32_t *>(lds + OFF_NW);
+    uint32_t(*const lines_w)[MAXRUN] = reinterpret_cast<uint32_t(*)[MAXRUN]>(lds + OFF_LW);
+    uint4(*const buf)[BUF_U4] = reinterpret_cast<uint4(*)[BUF_U4]>(lds + OFF_BUF);
+    uint32_t *const q_line = reinterpret_cast<uint32_t *>(lds + OFF_QL);  // overflow queue of the tile (position order): next line to try,
+    uint32_t *const q_step = reinterpret_cast<uint32_t *>(lds + OFF_QS);  // step of the entry's sequence
+    uint16_t *const q_pl = reinterpret_cast<uint16_t *>(lds + OFF_QP);    // and position within the tile (the key is re-derived from sw)
+    PG_PH_DECL
     const int lane = threadIdx.x;
     const int k = (int)st.k;
+    // (a minimizer table has 20 <= k <= 32, minimizer_length: the low word of the k-mer mask is all ones there, and the
+    // compiler drops its ANDs once it knows)
+    if constexpr (W_C != 0) __builtin_assume(k >= 20 && k <= 32);
     // tiles run in launch order unless the result carries a schedule (co-scheduled anchor genomes:
     // homologous regions of all genomes next to each other, so that table lines are shared in L2)
     // (tile_base: the launch covers a contig range of the result; a schedule is a permutation within such ranges)
@@ -599,9 +642,9 @@ __attribute__((amdgpu_num_sgpr(80))) void k_probe(const SubTable st, const uint6
     const uint64_t mm64 = (m >= 32) ? ~0ull : ((1ull << (2 * (m ? m : 1))) - 1);
     // (columns mode: `out1` is the block's column buffer, `nbytes` its width in genomes; the "rows" of the tile are
     // the LDS words the columns are assembled in)
-    __shared__ unsigned long long cols[ROWMODE == 3 ? 8 * COLS_G : 1];
+    __shared__ unsigned long long cols[ROWMODE == 3 ? TILE_SLOTS * COLS_G : 1];
     if constexpr (ROWMODE == 3) {
-        cols[lane] = 0;
+        for (uint32_t i = lane; i < TILE_SLOTS * COLS_G; i += 64) cols[i] = 0;
         __syncthreads();
     }
     uint8_t *tile_rows = ROWMODE == 3 ? reinterpret_cast<uint8_t *>(cols) : out1 + a.out_off + (uint64_t)tile_start * nbytes;
@@ -668,8 +711,7 @@ __attribute__((amdgpu_num_sgpr(80))) void k_probe(const SubTable st, const uint6
         // ---- runs of equal home line among the active lanes (lane masks on the scalar unit: a run starts at an active
         // lane whose predecessor is inactive or on another line; lane 0 has no predecessor — the shift leaves its bit clear)
         f.line = home_of_group(f.grp, st.nbuckets);
-        const uint32_t prev_line = lane_up1(f.line);
-        f.lmask = f.amask & (~(f.amask << 1) | __builtin_amdgcn_ballot_w64(f.line != prev_line));
+        f.lmask = f.amask & (~(f.amask << 1) | differs_from_lane_below(f.line));
         f.rid = lanes_le_index(f.lmask, 0u);  // run id of an active lane
         f.nruns = (uint32_t)__popcll(f.lmask);
         f.padline = f.lmask ? (uint32_t)__builtin_amdgcn_readlane((int)f.line, __builtin_ctzll(f.lmask)) : 0u;  // (wave-uniform)
@@ -709,21 +751,26 @@ __attribute__((amdgpu_num_sgpr(80))) void k_probe(const SubTable st, const uint6
         return L;
     };
     // ---- the rest of the batch: its lines into LDS, every lane scans its own; overflow entries; the rows ----
-    auto back = [&](const Front &f, const Lines &L, const uint32_t b0) __attribute__((always_inline)) {
+    auto back = [&](const Front &f, const Lines &L, const uint32_t b0, auto &&after_staging) __attribute__((always_inline)) {
         const bool act = __builtin_amdgcn_inverse_ballot_w64(f.amask), inrange = __builtin_amdgcn_inverse_ballot_w64(f.rmask);
         const int32_t pl = (int32_t)(b0 + lane) - HALO;
         uint32_t m0 = 0, m1 = 0;
         int rcode = 0;
         // a staging step's chunks into LDS (wave-uniform placement: chunk idx of the step -> line idx / SLOTS, slot
         // idx % SLOTS), then every lane of the step's runs scans its own line
-        auto stage_scan = [&](const Lines &S, const uint32_t r0) __attribute__((always_inline)) {
-            const uint32_t nl = min((uint32_t)MAXRUN, f.nruns - r0);
+        auto stage = [&](const Lines &S) __attribute__((always_inline)) {
+            // (chunk it * 64 + lane of the step: line it * (64 / SLOTS) + lane / SLOTS, slot lane % SLOTS — one address per
+            // lane, the iterations at constant offsets from it)
+            uint4 *const mine = buf[0] + ((uint32_t)lane / SLOTS) * LDS_LINE_U4;
 #pragma unroll
             for (int it = 0; it < STAGE_ITERS; ++it) {
-                const uint32_t idx = it * 64 + lane;
-                buf[0][(idx / SLOTS) * LDS_LINE_U4 + (idx % SLOTS)] = S.v[it];
+                if constexpr (WIDE) mine[it * (64 / SLOTS) * LDS_LINE_U4 + ((uint32_t)lane % SLOTS)] = S.v[it];  // (bare keys: as they are)
+                else stage_chunk(mine + it * (64 / SLOTS) * LDS_LINE_U4, (uint32_t)lane % SLOTS, SLOTS, S.v[it]);
             }
             __syncthreads();
+        };
+        auto scan = [&](const uint32_t r0) __attribute__((always_inline)) {
+            const uint32_t nl = min((uint32_t)MAXRUN, f.nruns - r0);
 #if PG_ABLATE == 5  // (timing experiment: lines fetched and staged, no slot scan: every lane "hits" with one LDS word)
             if (act && f.rid - r0 < nl) {
                 rcode = 1;
@@ -741,8 +788,25 @@ __attribute__((amdgpu_num_sgpr(80))) void k_probe(const SubTable st, const uint6
 #endif
             __syncthreads();
         };
-        if (f.nruns) stage_scan(L, 0u);
-        for (uint32_t r0 = MAXRUN; r0 < f.nruns; r0 += MAXRUN) stage_scan(issue(f, r0), r0);  // (a batch with more than MAXRUN lines: rare)
+        // The batch's lines are waited for HERE, on every path (a batch without runs has none in flight).  Left to the
+        // compiler, the wait sits inside the branch below, the chunks count as possibly still on their way where the
+        // paths meet, and the first instruction that re-uses one of their registers — an address of the NEXT fetch,
+        // issued right behind this batch's row store — gets a vmcnt(0) that waits for that store to be acknowledged.
+        PG_PH(1)
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), nothing else
+        PG_PH(2)
+        if (f.nruns) stage(L);
+        PG_PH(3)
+        after_staging();  // (the chunks' registers are free from here on: the skewed order starts the NEXT batch's fetch now)
+        PG_PH(4)
+        if (f.nruns) scan(0u);
+        PG_PH(5)
+        for (uint32_t r0 = MAXRUN; r0 < f.nruns; r0 += MAXRUN) {  // (a batch with more than MAXRUN lines: rare)
+            const Lines X = issue(f, r0);
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            stage(X);
+            scan(r0);
+        }
         // ---- overflow: absent from a full line -> queue entry for the next line of its sequence ----
         // (sicmp = the compare as a lane mask, predicate 40 = signed less-than: a ballot of `rcode < 0` is sunk into the
         // blocks rcode comes from and its bool rebuilt here through 0 / 1)
@@ -756,20 +820,14 @@ __attribute__((amdgpu_num_sgpr(80))) void k_probe(const SubTable st, const uint6
                 step = step_of_group(f.grp, st.nbuckets);
                 nx = next_line(f.line, step, st.nbuckets);
             }
+            // (the queue always has room for a whole batch: the batch loop leaves for an early drain before it could not)
             const uint32_t slot = lanes_le_index(omask, qn);
             if (ovf) {
-                if (slot < (uint32_t)PROBE_QCAP) {
-                    q_line[slot] = nx;
-                    q_step[slot] = step;
-                    q_pl[slot] = (uint16_t)pl;
-                } else {
-                    const uint2 mm2 = WIDE ? lane_chase_wide_cold(st.buckets, st.nbuckets, f.key, 1u, nx, step)
-                                           : lane_chase_cold<TWO, SLOTS>(st.buckets, st.nbuckets, f.key, 1u, nx, step);  // queue full
-                    m0 = mm2.x;
-                    m1 = mm2.y;
-                }
+                q_line[slot] = nx;
+                q_step[slot] = step;
+                q_pl[slot] = (uint16_t)pl;
             }
-            qn = min(qn + (uint32_t)__popcll(omask), (uint32_t)PROBE_QCAP);
+            qn += (uint32_t)__popcll(omask);
         }
         // (32-bit offset from the tile's uniform base: one store with a scalar base address)
         if constexpr (WIDE) {
@@ -812,49 +870,93 @@ __attribute__((amdgpu_num_sgpr(80))) void k_probe(const SubTable st, const uint6
 #endif
                 store_row<ROWMODE>(tile_rows + (ROWMODE == 1 ? (uint32_t)pl : ROWMODE == 4 ? (uint32_t)pl * 4u : ROWMODE == 5 ? (uint32_t)pl * 2u : ROWMODE == 6 ? (uint32_t)pl * 3u : (uint32_t)pl * nbytes), m0, m1, rc);
         }
+        PG_PH(6)
     };
     // The skewed order — front end of batch i + 1 between the fetch of batch i and its use — keeps the fetched chunks
     // and two batches' keys in registers at once: it pays where that still fits 64 registers (8 waves per SIMD: this
     // kernel's speed goes with its occupancy — 7 waves cost 7 %, 5 waves 28 %), i.e. for the one-byte rows of up to 8
     // genomes (configs[1]: 4.31 -> 4.17 ms); the wider instantiations spill there and keep the plain order.
     constexpr bool PIPE = probe_pipelined<W_C, TWO, ROWMODE, SLOTS, WIDE>;
+    constexpr int LEVELS = (W_C >= 6 && !TWO && !WIDE && PROBE_STAGED_LEVELS > 1) ? 1 : PROBE_STAGED_LEVELS;  // (W_C >= 6: the wide-window tables of up to 16 genomes)
+    // The batch loop runs until the tile is through OR the overflow queue could not take another full batch (tiles inside
+    // a repeat family: most of their keys sit outside their home lines): the queue is drained then and the loop goes on
+    // where it stopped.  So no batch ever meets a full queue — the lane-by-lane chase that served it was a function
+    // call inside the loop, whose clobbered registers the allocator answered with spills on the hot path.
+    static_assert(QCAP >= 128, "an early drain must leave room for a batch");
+    constexpr uint32_t QROOM = QCAP - 64;  // entries the queue may hold when a batch starts
+    // (The hot loop stands on its own: what it keeps in registers is dead when it ends.  The tail — a plain batch loop
+    // around the one drain — only ever runs batches for the tiles whose queue filled up.)
+    uint32_t b0 = 0;
     if constexpr (PIPE) {
+        // The skewed order — front end of batch i + 1 between the fetch of batch i and its use — keeps the fetched chunks
+        // and two batches' keys in registers at once: it pays where that still fits 64 registers (8 waves per SIMD: this
+        // kernel's speed goes with its occupancy — 7 waves cost 7 %, 5 waves 28 %)
         Lines L;
 #pragma unroll
         for (int it = 0; it < STAGE_ITERS; ++it) L.v[it] = make_uint4(0, 0, 0, 0);
+        PG_PH(0)
         Front cur = front(std::true_type{}, 0u);
         if (cur.nruns) L = issue(cur, 0u);
-        for (uint32_t b0 = 0; b0 < npos; b0 += STRIDE) {
+        for (;;) {
+            PG_PH(7)
             const bool more = b0 + STRIDE < npos;  // (wave-uniform)
             Front nxt = cur;
             __builtin_amdgcn_sched_barrier(0);  // (the parts stay apart: interleaved by the scheduler they keep both batches' temporaries alive)
             if (more) nxt = front(std::false_type{}, b0 + STRIDE);  // while the lines of `cur` are on their way
             __builtin_amdgcn_sched_barrier(0);
-            back(cur, L, b0);
+#if PG_PROBE_PIPE >= 2
+            // the next batch's fetch goes out as soon as this batch's chunks have left their registers for LDS: it is in
+            // flight during this batch's slot scan, row store and overflow entries AND the front end after next
+            back(cur, L, b0, [&]() __attribute__((always_inline)) {
+                if (more && nxt.nruns) L = issue(nxt, 0u);
+            });
             __builtin_amdgcn_sched_barrier(0);
-            if (more) {
-                cur = nxt;
-                if (cur.nruns) L = issue(cur, 0u);
-            }
+            b0 += STRIDE;
+            if (!more || qn > QROOM) break;  // (rare way out with a fetch in flight: nobody reads it; the tail starts the batch again)
+            cur = nxt;
+#else
+            back(cur, L, b0, [] {});
+            __builtin_amdgcn_sched_barrier(0);
+            b0 += STRIDE;
+            // (the room is checked AFTER a batch's look-up, which is what fills the queue: the front end of the next batch
+            // is thrown away on the rare way out — the tail starts it again)
+            if (!more || qn > QROOM) break;
+            cur = nxt;
+            if (cur.nruns) L = issue(cur, 0u);
+#endif
         }
     } else {
-        auto whole = [&](auto first_tag, const uint32_t b0) __attribute__((always_inline)) {
-            const Front f = front(first_tag, b0);
+        {
+            const Front f = front(std::true_type{}, 0u);
             const Lines L = issue(f, 0u);  // (also for a batch without runs — a stretch of N: line 0 is fetched and ignored)
-            back(f, L, b0);
-        };
-        whole(std::true_type{}, 0u);
-        for (uint32_t b0 = STRIDE; b0 < npos; b0 += STRIDE) whole(std::false_type{}, b0);
+            back(f, L, 0u, [] {});
+        }
+        for (b0 = STRIDE; b0 < npos && qn <= QROOM; b0 += STRIDE) {
+            const Front f = front(std::false_type{}, b0);
+            const Lines L = issue(f, 0u);
+            back(f, L, b0, [] {});
+        }
     }
-
-    constexpr int LEVELS = (W_C >= 6 && !TWO && !WIDE && PROBE_STAGED_LEVELS > 1) ? 1 : PROBE_STAGED_LEVELS;  // (W_C >= 6: the wide-window tables of up to 16 genomes)
-    drain_queue<TWO, ROWMODE, SLOTS, MAXRUN, WIDE, LEVELS>(st, qn, sw, rw, q_line, q_step, q_pl, lines_w[0], buf[0], tile_rows, nbytes, rc, lane);
+    PG_PH(7)
+    for (;;) {
+        drain_queue<TWO, ROWMODE, SLOTS, MAXRUN, WIDE, LEVELS>(st, qn, sw, rw, q_line, q_step, q_pl, lines_w[0], buf[0], tile_rows, nbytes, rc, lane);
+        qn = 0;
+        if (b0 >= npos) break;
+        __syncthreads();
+        for (; b0 < npos && qn <= QROOM; b0 += STRIDE) {
+            const Front f = front(std::false_type{}, b0);
+            const Lines L = issue(f, 0u);
+            back(f, L, b0, [] {});
+        }
+    }
+    PG_PH(8)
+    PG_PH_FLUSH
     if constexpr (ROWMODE == 3) {
-        // the tile's columns: 8 slots x `width` (= nbytes) genomes, slot-major — what k_cols_extract would have written
+        // the tile's columns: TILE_SLOTS slots x `width` (= nbytes) genomes, slot-major — what k_cols_extract would have written
         __syncthreads();
         const uint32_t width = nbytes, trel = tile - tile_base;
-        unsigned long long *dst = reinterpret_cast<unsigned long long *>(out1) + (uint64_t)trel * 8u * width;
-        if ((uint32_t)lane < 8u * width) dst[lane] = cols[((uint32_t)lane / width) * COLS_G + (uint32_t)lane % width];
+        unsigned long long *dst = reinterpret_cast<unsigned long long *>(out1) + (uint64_t)trel * TILE_SLOTS * width;
+        for (uint32_t i = lane; i < TILE_SLOTS * width; i += 64) dst[i] = cols[(i / width) * COLS_G + i % width];
     }
 }
 
@@ -2277,8 +2379,8 @@ __global__ __launch_bounds__(256) void k_window_stats(uint32_t N, const uint8_t 
 // the genomes it owns, so what crosses xGMI is a COMPACT block of bit columns — for every 64
 // positions, one u64 per owned genome (bit l = position l) — all-gathered over RCCL and merged back
 // into full rows: (n-1)/n row bytes received per position instead of the 2(n-1)/n of an all-reduce.
-// Layout: tile t (512 positions) owns 8 slots of `width` u64 words: word (8t + s) * width + j =
-// genome g0 + j at positions 64 s .. 64 s + 63 of the tile.
+// Layout: tile t (PROBE_TILE positions) owns TILE_SLOTS = PROBE_TILE / 64 slots of `width` u64 words: word
+// (TILE_SLOTS t + s) * width + j = genome g0 + j at positions 64 s .. 64 s + 63 of the tile.
 // ---------------------------------------------------------------------------
 // One-byte rows (a block of up to 8 genomes — config 5: ONE genome per GPU): a lane takes 8 consecutive positions
 // (one 8-byte load, the wave a whole tile) and gathers bit g of its 8 row bytes into one byte with a multiply;
@@ -2289,11 +2391,12 @@ __global__ __launch_bounds__(256) void k_cols_extract_b1(uint32_t N, const Ancho
                                                          uint32_t ntiles, const uint8_t *__restrict__ out1, uint32_t g0,
                                                          uint32_t width, uint8_t *__restrict__ dst) {
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t trel = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint32_t unit = blockIdx.x * 4 + (threadIdx.x >> 6);  // 512 positions of a tile: 8 of its slots
+    const uint32_t trel = unit / (TILE_SLOTS / 8), u8 = (unit % (TILE_SLOTS / 8)) * 8;
     if (trel >= ntiles) return;  // wave-uniform
     const uint32_t tile = tile_base + trel;
     const AnchorDesc a = ad[tile_contig[tile]];
-    const uint32_t p0 = (tile - a.tile0) * PROBE_TILE + 8 * lane;
+    const uint32_t p0 = (tile - a.tile0) * PROBE_TILE + 64 * u8 + 8 * lane;
     uint32_t lo = 0, hi = 0;
     if (p0 < a.nkmers) {  // (rows are padded to 16 bytes per contig: the 8-byte load stays inside)
         const uint2 v = *reinterpret_cast<const uint2 *>(out1 + a.out_off + p0);
@@ -2301,7 +2404,7 @@ __global__ __launch_bounds__(256) void k_cols_extract_b1(uint32_t N, const Ancho
         lo = valid >= 4 ? v.x : (v.x & ((1u << (8 * valid)) - 1u));
         hi = valid >= 8 ? v.y : (valid > 4 ? (v.y & ((1u << (8 * (valid - 4))) - 1u)) : 0u);
     }
-    uint8_t *o = dst + ((uint64_t)trel * 8 + (lane >> 3)) * width * 8 + (lane & 7);
+    uint8_t *o = dst + ((uint64_t)trel * TILE_SLOTS + u8 + (lane >> 3)) * width * 8 + (lane & 7);
     for (uint32_t j = 0; j < width; ++j) {
         const uint32_t g = g0 + j;
         uint32_t b = 0;
@@ -2321,14 +2424,15 @@ __global__ __launch_bounds__(256) void k_cols_merge_b1(uint32_t N, const AnchorD
                                                        const uint8_t *__restrict__ src, uint32_t part0, uint32_t nparts,
                                                        uint64_t part_bytes, uint32_t per, uint32_t accumulate) {
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t trel = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint32_t unit = blockIdx.x * 4 + (threadIdx.x >> 6);  // 512 positions of a tile: 8 of its slots
+    const uint32_t trel = unit / (TILE_SLOTS / 8), u8 = (unit % (TILE_SLOTS / 8)) * 8;
     if (trel >= ntiles) return;
     const uint32_t tile = tile_base + trel;
     const AnchorDesc a = ad[tile_contig[tile]];
-    const uint32_t p0 = (tile - a.tile0) * PROBE_TILE + 8 * lane;
+    const uint32_t p0 = (tile - a.tile0) * PROBE_TILE + 64 * u8 + 8 * lane;
     if (p0 >= a.nkmers) return;
     const uint32_t gfirst = part0 * per, gend = min(N, (part0 + nparts) * per);
-    const uint8_t *in = src + ((uint64_t)trel * 8 + (lane >> 3)) * per * 8 + (lane & 7);
+    const uint8_t *in = src + ((uint64_t)trel * TILE_SLOTS + u8 + (lane >> 3)) * per * 8 + (lane & 7);
     uint32_t lo = 0, hi = 0;
     for (uint32_t g = gfirst; g < gend; ++g) {
         const uint32_t part = g / per - part0, j = g % per;
@@ -2357,8 +2461,8 @@ __global__ __launch_bounds__(256) void k_cols_extract(uint32_t N, const AnchorDe
     struct __attribute__((packed)) U32 { uint32_t v; };
     const int lane = threadIdx.x & 63;
     const uint64_t slot = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);  // relative to the range's first tile
-    if (slot >= (uint64_t)ntiles * 8) return;  // wave-uniform
-    const uint32_t tile = tile_base + (uint32_t)(slot >> 3), sub = (uint32_t)(slot & 7);
+    if (slot >= (uint64_t)ntiles * TILE_SLOTS) return;  // wave-uniform
+    const uint32_t tile = tile_base + (uint32_t)(slot / TILE_SLOTS), sub = (uint32_t)(slot % TILE_SLOTS);
     const AnchorDesc a = ad[tile_contig[tile]];
     const uint32_t nbytes = (N + 7) / 8;
     const uint32_t p = (tile - a.tile0) * PROBE_TILE + sub * 64 + lane;
@@ -2398,8 +2502,8 @@ __global__ __launch_bounds__(256) void k_cols_merge(uint32_t N, const AnchorDesc
                                                     uint32_t nparts, uint64_t part_words, uint32_t per, uint32_t accumulate) {
     const int lane = threadIdx.x & 63;
     const uint64_t slot = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (slot >= (uint64_t)ntiles * 8) return;
-    const uint32_t tile = tile_base + (uint32_t)(slot >> 3), sub = (uint32_t)(slot & 7);
+    if (slot >= (uint64_t)ntiles * TILE_SLOTS) return;
+    const uint32_t tile = tile_base + (uint32_t)(slot / TILE_SLOTS), sub = (uint32_t)(slot % TILE_SLOTS);
     const AnchorDesc a = ad[tile_contig[tile]];
     const uint32_t nbytes = (N + 7) / 8, ndbs = (N + 31) / 32;
     const uint32_t p = (tile - a.tile0) * PROBE_TILE + sub * 64 + lane;
@@ -2664,10 +2768,10 @@ hipError_t launch_cols_extract(hipStream_t st, uint32_t ngenomes, const AnchorDe
                                uint32_t tile_base, uint32_t ntiles, const uint8_t *out1, uint32_t g0, uint32_t width, void *dst) {
     if (ntiles == 0 || width == 0) return hipSuccess;
     if (ngenomes <= 8 && g0 < 8)  // one-byte rows
-        hipLaunchKernelGGL(k_cols_extract_b1, dim3((ntiles + 3) / 4), dim3(256), 0, st, ngenomes, ad, tile_contig, tile_base,
+        hipLaunchKernelGGL(k_cols_extract_b1, dim3((unsigned)(((uint64_t)ntiles * (TILE_SLOTS / 8) + 3) / 4)), dim3(256), 0, st, ngenomes, ad, tile_contig, tile_base,
                            ntiles, out1, g0, width, static_cast<uint8_t *>(dst));
     else
-        hipLaunchKernelGGL(k_cols_extract, dim3((unsigned)(((uint64_t)ntiles * 8 + 3) / 4)), dim3(256), 0, st, ngenomes, ad,
+        hipLaunchKernelGGL(k_cols_extract, dim3((unsigned)(((uint64_t)ntiles * TILE_SLOTS + 3) / 4)), dim3(256), 0, st, ngenomes, ad,
                            tile_contig, tile_base, ntiles, out1, g0, width, static_cast<unsigned long long *>(dst));
     return hipGetLastError();
 }
@@ -2677,10 +2781,10 @@ hipError_t launch_cols_merge(hipStream_t st, uint32_t ngenomes, const AnchorDesc
                              uint32_t nparts, uint64_t part_words, uint32_t per, uint32_t accumulate) {
     if (ntiles == 0 || per == 0 || nparts == 0) return hipSuccess;
     if (ngenomes <= 8)  // one-byte rows
-        hipLaunchKernelGGL(k_cols_merge_b1, dim3((ntiles + 3) / 4), dim3(256), 0, st, ngenomes, ad, tile_contig, tile_base,
+        hipLaunchKernelGGL(k_cols_merge_b1, dim3((unsigned)(((uint64_t)ntiles * (TILE_SLOTS / 8) + 3) / 4)), dim3(256), 0, st, ngenomes, ad, tile_contig, tile_base,
                            ntiles, out1, static_cast<const uint8_t *>(src), part0, nparts, part_words * 8, per, accumulate);
     else
-        hipLaunchKernelGGL(k_cols_merge, dim3((unsigned)(((uint64_t)ntiles * 8 + 3) / 4)), dim3(256), 0, st, ngenomes, ad,
+        hipLaunchKernelGGL(k_cols_merge, dim3((unsigned)(((uint64_t)ntiles * TILE_SLOTS + 3) / 4)), dim3(256), 0, st, ngenomes, ad,
                            tile_contig, tile_base, ntiles, out1, static_cast<const unsigned long long *>(src), part0, nparts,
                            part_words, per, accumulate);
     return hipGetLastError();
@@ -2706,6 +2810,23 @@ static hipError_t insert_tiles_w(hipStream_t s, uint32_t ntiles, const SubTable 
     return hipGetLastError();
 }
 
+#ifdef PG_PHASE_TIMING
+}  // namespace pg
+extern "C" int pg_debug_phase_cycles(unsigned long long *out16, int reset) {
+    hipDeviceSynchronize();
+    static unsigned long long all[1024 * 16];
+    if (hipMemcpyFromSymbol(all, HIP_SYMBOL(pg::pg_phase_cycles), sizeof all) != hipSuccess) return -1;
+    for (int i = 0; i < 16; ++i) out16[i] = 0;
+    for (int b = 0; b < 1024; ++b)
+        for (int i = 0; i < 16; ++i) out16[i] += all[b * 16 + i];
+    if (reset) {
+        for (auto &x : all) x = 0;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(pg::pg_phase_cycles), all, sizeof all) != hipSuccess) return -1;
+    }
+    return 0;
+}
+namespace pg {
+#endif
 hipError_t preload_anchor_kernels() {
     hipFuncAttributes fa;
     return hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(k_insert_tile<7, false>));

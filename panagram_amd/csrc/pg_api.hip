@@ -2302,13 +2302,13 @@ extern "C" int pg_result_timing_mean(pg_result *r, double *probe_ms, double *epi
 // genome-sharded exchange: compact bit columns out of / back into the rows
 // ---------------------------------------------------------------------------
 extern "C" uint64_t pg_result_columns_bytes(const pg_result *r, uint32_t width) {
-    return r ? (uint64_t)r->ntiles * 64ull * width : 0;
+    return r ? (uint64_t)r->ntiles * (PROBE_TILE / 8) * width : 0;  // (PROBE_TILE / 64 u64 words per genome and tile)
 }
 
 extern "C" uint64_t pg_result_columns_bytes_range(const pg_result *r, uint32_t width, uint32_t first_contig, uint32_t ncontigs) {
     uint32_t t0, nt;
     if (!r || contig_tiles(r, first_contig, ncontigs, &t0, &nt)) return 0;
-    return (uint64_t)nt * 64ull * width;
+    return (uint64_t)nt * (PROBE_TILE / 8) * width;
 }
 
 extern "C" int pg_result_extract_columns_range(pg_result *r, uint32_t g0, uint32_t width, uint32_t first_contig,
@@ -2339,7 +2339,7 @@ extern "C" int pg_result_merge_columns_range(pg_result *r, const void *d_src, ui
     if (per == 0 || nparts == 0) return fail(PG_E_INVALID, "pg_result_merge_columns: empty partition");
     uint32_t t0, nt;
     if (int e = contig_tiles(r, first_contig, ncontigs, &t0, &nt)) return e;
-    const uint64_t own = (uint64_t)nt * 64ull * per;
+    const uint64_t own = (uint64_t)nt * (PROBE_TILE / 8) * per;
     if (part_stride_bytes == 0) part_stride_bytes = own;
     if (part_stride_bytes < own || part_stride_bytes % 8) return fail(PG_E_INVALID, "pg_result_merge_columns_range: bad block stride");
     if (int e = use_device(r->ctx)) return e;

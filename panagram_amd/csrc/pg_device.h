@@ -151,7 +151,9 @@ __device__ __forceinline__ uint32_t mix1(uint32_t g, uint32_t mul) {
     const uint32_t h = g * mul;
     return h ^ (h >> 15);
 }
-__device__ __forceinline__ uint32_t home_of_group(uint32_t g, uint64_t nlines) { return range32(mix1(g, 0x85ebca6bu), nlines); }
+// (home: no xor-shift behind the multiply — range32 reads the top bits of g * odd, which depend on every bit of g already, and
+// the shift only stirs the low 17: two VALU instructions per batch of k_probe / k_insert_tile for nothing)
+__device__ __forceinline__ uint32_t home_of_group(uint32_t g, uint64_t nlines) { return range32(g * 0x85ebca6bu, nlines); }
 __device__ __forceinline__ uint32_t step_of_group(uint32_t g, uint64_t nlines) {
     return 1u + range32(mix1(g ^ 0x5bd1e995u, 0xc2b2ae35u), nlines - 1);
 }

@@ -4,8 +4,13 @@
 
 namespace pg {
 
+// Positions per wave-tile.  1024 since round 4: a wave spends a twelfth of a 512-position tile's time before its first
+// batch (descriptor and sequence loads, one after the other) and a fifth in the overflow drain behind its last, both
+// per TILE — tools/phase_timing.py — and with twice the positions the drain's batches are twice as dense: configs[1]
+// 4.19 -> 4.01 ms, 27 x 160 Mb +6 %, the probe of 64 x 160 Mb -10 %.  2048 needs the queue cut to 128 entries to keep
+// 32 waves per CU in LDS, and loses more to early drains than it saves (profiles/r4_ab_tile.txt).
 #ifndef PG_PROBE_TILE
-#define PG_PROBE_TILE 512
+#define PG_PROBE_TILE 1024
 #endif
 #ifndef PG_PROBE_MAXRUN
 #define PG_PROBE_MAXRUN 16
@@ -17,7 +22,7 @@ constexpr int PROBE_MAXRUN = PG_PROBE_MAXRUN;  // table lines staged in LDS per 
 #endif
 constexpr int PROBE_STAGED_LEVELS = PG_PROBE_STAGED_LEVELS;  // LDS-staged overflow levels; beyond: lanes chase inline
 #ifndef PG_PROBE_QCAP
-#define PG_PROBE_QCAP (PG_PROBE_TILE * 3 / 8)
+#define PG_PROBE_QCAP 192  // (with the 1024-position tile's sequence words: 5104 bytes of LDS per wave, 32 waves per CU)
 #endif
 constexpr int PROBE_QCAP = PG_PROBE_QCAP;      // per-tile LDS overflow queue (beyond: resolved inline)
 

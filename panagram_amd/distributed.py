@@ -854,6 +854,7 @@ class ShardedAnchoring:
             if self.exchange == "host" and dist.get_backend(group) != "gloo":
                 self.host_group = dist.new_group(backend="gloo")  # (collective call: every rank is here)
         tile = engine.tile_positions()
+        self.col_bytes = tile // 8  # bytes of one genome's bit column per tile (a u64 per 64 positions)
         names = list(seqs)
         chunks = {a: contig_chunks(seqs[a].lens, k) for a in names}
         # groups[i] = [(anchor, first contig, count, tile offset inside the group)], the same on every rank
@@ -875,7 +876,7 @@ class ShardedAnchoring:
                            for a in names if chunks[a]}
         self.merged = engine.SeqSet.concat_ranges(ctx, parts) if parts else None
         self._contig_anchor = np.asarray(contig_anchor, np.uint32)
-        biggest = max(self.group_tiles or [0]) * 64 * per
+        biggest = max(self.group_tiles or [0]) * self.col_bytes * per
         if self.collective:  # torch owns the buffers (the collective takes tensors) and the two streams
             import torch
             dev = ctx.torch_device()
@@ -1000,17 +1001,17 @@ class ShardedAnchoring:
         def settle(pend):
             i, slot, ev = pend
             pipe.main_waits(ev)  # (also what frees send[slot] for the next extract into it)
-            stride = self.group_tiles[i] * 64 * per  # recv holds `world` blocks of this size, block j = genome block part0 + j
+            stride = self.group_tiles[i] * self.col_bytes * per  # recv holds `world` blocks of this size, block j = genome block part0 + j
             for a, c0, nc, toff in self.groups[i]:
                 if self.writer[a] != self.rank:
                     continue
-                self.container(a).merge_columns_range(self.recv[slot].data_ptr() + toff * 64 * per, part0, nparts, per,
+                self.container(a).merge_columns_range(self.recv[slot].data_ptr() + toff * self.col_bytes * per, part0, nparts, per,
                                                       c0, nc, accumulate=accumulate, part_stride_bytes=stride)
                 if on_anchor_complete is not None and self.last_group[a] == i:
                     on_anchor_complete(a, self.full[a])
 
         for i in range(len(self.groups)):
-            slot, nbytes = i & 1, self.group_tiles[i] * 64 * per
+            slot, nbytes = i & 1, self.group_tiles[i] * self.col_bytes * per
             m0 = self.group_first[i]
             cnt = (self.group_first[i + 1] if i + 1 < len(self.groups) else ncontigs) - m0
             if part is not None and self._direct:

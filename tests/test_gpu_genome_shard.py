@@ -59,7 +59,7 @@ def test_partial_tables_combine_equals_reference(ctx, name, world, mode):
         part0, off = [], 0
         for ci in range(len(seqs)):
             part0.append(res[0].download(ci)[0])
-        assert np.array_equal(allb[:nb_cols].cpu().numpy(), po.extract_columns(part0, n, 0, per))
+        assert np.array_equal(allb[:nb_cols].cpu().numpy(), po.extract_columns(part0, n, 0, per, tile=engine.tile_positions()))
         res[0].merge_columns(allb.data_ptr(), world, per)
         ctx.synchronize()
     torch.cuda.synchronize()
