@@ -61,12 +61,12 @@ constexpr uint32_t PROBE_SEQ_BASES = 32u * PROBE_SEQW;
 // -DPG_PHASE_TIMING: a measuring build (tools/phase_timing.py) — every wave of k_probe stamps s_memtime at its phase
 // boundaries and adds the phases' cycles to pg_phase_cycles at the end of its tile: where a wave's time goes, waits for
 // the other waves of its SIMD included.  Slots: 0 prologue, 1 front end, 2 wait for the lines, 3 staging, 4 issue of the
-// next fetch, 5 slot scan, 6 overflow entries + row store, 7 loop bookkeeping, 8 drain + tail, 9 waves.
+// next fetch, 5 slot scan, 6 row store, 7 loop bookkeeping, 8 drain + tail, 9 waves, 10 overflow entries.
 #ifdef PG_PHASE_TIMING
 __device__ unsigned long long pg_phase_cycles[1024 * 16];  // (1024 sets, by block number: ten same-address atomics per wave serialise the launch)
-#define PG_PH_DECL uint32_t ph_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; uint32_t ph_t = (uint32_t)__builtin_readcyclecounter();
+#define PG_PH_DECL uint32_t ph_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; uint32_t ph_t = (uint32_t)__builtin_readcyclecounter();
 #define PG_PH(i) { const uint32_t ph_n = (uint32_t)__builtin_readcyclecounter(); ph_acc[i] += ph_n - ph_t; ph_t = ph_n; }
-#define PG_PH_FLUSH { if (threadIdx.x == 0) { for (int ph_i = 0; ph_i < 9; ++ph_i) atomicAdd(&pg_phase_cycles[(blockIdx.x & 1023u) * 16u + ph_i], (unsigned long long)ph_acc[ph_i]); atomicAdd(&pg_phase_cycles[(blockIdx.x & 1023u) * 16u + 9], 1ull); } }
+#define PG_PH_FLUSH { if (threadIdx.x == 0) { for (int ph_i = 0; ph_i < 9; ++ph_i) atomicAdd(&pg_phase_cycles[(blockIdx.x & 1023u) * 16u + ph_i], (unsigned long long)ph_acc[ph_i]); atomicAdd(&pg_phase_cycles[(blockIdx.x & 1023u) * 16u + 9], 1ull); atomicAdd(&pg_phase_cycles[(blockIdx.x & 1023u) * 16u + 10], (unsigned long long)ph_acc[10]); } }
 #else
 #define PG_PH_DECL
 #define PG_PH(i)
@@ -829,6 +829,7 @@ __attribute__((amdgpu_num_sgpr(80))) void k_probe(const SubTable st, const uint6
             }
             qn += (uint32_t)__popcll(omask);
         }
+        PG_PH(10)
         // (32-bit offset from the tile's uniform base: one store with a scalar base address)
         if constexpr (WIDE) {
             if (inrange) store_row_wide(st.masks, st.W, nbytes, tile_rows + (uint64_t)(uint32_t)pl * nbytes, m0, m1);

@@ -10,8 +10,8 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-NAMES = ["prologue", "front end", "wait for lines", "staging", "issue next fetch", "slot scan", "overflow + row store",
-         "loop bookkeeping", "drain + tail", "waves"]
+NAMES = ["prologue", "front end", "wait for lines", "staging", "issue next fetch", "slot scan", "row store",
+         "loop bookkeeping", "drain + tail", "waves", "overflow entries"]
 
 
 def main():
@@ -33,9 +33,9 @@ def main():
     assert fn(out, 0) == 0
     v = list(out)
     waves = v[9]
-    tot = sum(v[:9])
+    tot = sum(v[:9]) + v[10]
     print(f"value {d['value'] / 1e9:.1f} G k-mers/s, k_probe {d['roofline']['avg_launch_ms']:.3f} ms; waves timed {waves}, {tot / waves:.0f} cycles per wave (tile)")
-    for n, c in zip(NAMES[:9], v[:9]):
+    for n, c in list(zip(NAMES[:9], v[:9])) + [(NAMES[10], v[10])]:
         print(f"  {n:22s} {c / waves:9.0f} cycles per tile  {100.0 * c / tot:5.1f} %")
 
 
