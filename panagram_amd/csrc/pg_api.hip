@@ -15,6 +15,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -1428,6 +1429,51 @@ extern "C" int pg_seqset_from_fasta(pg_ctx *ctx, const void *text_, uint64_t nby
     if (!ctx || !out || (nbytes && !text_)) return fail(PG_E_INVALID, "pg_seqset_from_fasta: NULL argument");
     if (int r = use_device(ctx)) return r;
     const unsigned char *text = static_cast<const unsigned char *>(text_);
+    // The text goes up while the host looks for the header lines: the copy out of pageable memory (the runtime stages it,
+    // ~10 GB/s) and the memchr pass over the same bytes each take 6-10 ms per 100 MB, one after the other they were most
+    // of what a genome's load costs.  The upload runs on a helper thread and a stream of its own; the text buffer comes out of the context's buffer cache (one per genome of a pangenome, all about the
+    // same size: freeing GBs is paid by the next big allocation).
+    const uint64_t tcap = (nbytes + 4095) / 4096 * 4096 + 4096;
+    uint8_t *d_text = nullptr;
+    uint64_t text_cap = 0;
+    hipError_t e_up = row_alloc(ctx, tcap, &d_text, &text_cap);
+    if (e_up != hipSuccess) return fail(PG_E_HIP, "FASTA packing failed: %s", hipGetErrorString(e_up));
+    struct Upload {  // (joined on every way out, also an exception's)
+        std::thread th;
+        ~Upload() {
+            if (th.joinable()) th.join();
+        }
+    } up;
+    struct TextGuard {  // (given back after the upload has been joined: declared after it would free it first)
+        pg_ctx *c;
+        uint8_t *p;
+        uint64_t cap;
+        Upload *u;
+        ~TextGuard() {
+            if (u->th.joinable()) u->th.join();
+            row_free(c, p, cap);
+        }
+    } text_guard{ctx, d_text, text_cap, &up};
+    auto upload = [&]() noexcept {
+        if (hipSetDevice(ctx->device) != hipSuccess) {
+            e_up = hipErrorInvalidDevice;
+            return;
+        }
+        // (a stream of its own: several genomes may be loading at once — Index.load_inputs parses in its reader threads —
+        // and the staging of a pageable copy is host work that runs in the calling thread)
+        hipStream_t us = nullptr;
+        e_up = hipStreamCreateWithFlags(&us, hipStreamNonBlocking);
+        if (e_up != hipSuccess) return;
+        e_up = hipMemsetAsync(d_text + nbytes, 0, tcap - nbytes, us);
+        if (e_up == hipSuccess && nbytes) e_up = hipMemcpyAsync(d_text, text, nbytes, hipMemcpyHostToDevice, us);
+        if (e_up == hipSuccess) e_up = hipStreamSynchronize(us);
+        (void)hipStreamDestroy(us);
+    };
+    try {
+        up.th = std::thread(upload);
+    } catch (const std::system_error &) {  // no thread to be had: the copy runs here, before the scan
+        upload();
+    }
     struct Rec {
         std::string name;
         uint64_t s, e;
@@ -1489,8 +1535,6 @@ extern "C" int pg_seqset_from_fasta(pg_ctx *ctx, const void *text_, uint64_t nby
     }
     hipStream_t st = ctx->stream;
     const uint64_t nch = chunks.size();
-    const uint64_t tcap = (nbytes + 4095) / 4096 * 4096 + 4096;
-    uint8_t *d_text = nullptr;
     TextChunk *d_chunks = nullptr;
     uint64_t *d_chunk0 = nullptr, *d_base = nullptr, *d_len = nullptr;
     uint32_t *d_counts = nullptr;
@@ -1500,16 +1544,13 @@ extern "C" int pg_seqset_from_fasta(pg_ctx *ctx, const void *text_, uint64_t nby
         if (e == hipSuccess) e = x;
         return e == hipSuccess;
     };
-    uint64_t text_cap = 0;  // (the text buffer comes out of the context's buffer cache: one per genome of a pangenome,
-                            // all about the same size, and freeing GBs is paid by the next big allocation)
-    if (ok(row_alloc(ctx, tcap, &d_text, &text_cap)) &&
-        ok(hipMalloc(reinterpret_cast<void **>(&d_chunks), std::max<uint64_t>(nch, 1) * sizeof(TextChunk))) &&
+    if (ok(hipMalloc(reinterpret_cast<void **>(&d_chunks), std::max<uint64_t>(nch, 1) * sizeof(TextChunk))) &&
         ok(hipMalloc(reinterpret_cast<void **>(&d_chunk0), (nrec + 1) * 8)) &&
         ok(hipMalloc(reinterpret_cast<void **>(&d_base), std::max<uint64_t>(nch, 1) * 8)) &&
         ok(hipMalloc(reinterpret_cast<void **>(&d_len), nrec * 8)) &&
         ok(hipMalloc(reinterpret_cast<void **>(&d_counts), std::max<uint64_t>(nch, 1) * 4))) {
-        ok(hipMemsetAsync(d_text + nbytes, 0, tcap - nbytes, st));
-        ok(hipMemcpyAsync(d_text, text, nbytes, hipMemcpyHostToDevice, st));
+        if (up.th.joinable()) up.th.join();  // (the text is up — the helper waited for its stream)
+        ok(e_up);
         if (nch) ok(hipMemcpyAsync(d_chunks, chunks.data(), nch * sizeof(TextChunk), hipMemcpyHostToDevice, st));
         ok(hipMemcpyAsync(d_chunk0, chunk0.data(), (nrec + 1) * 8, hipMemcpyHostToDevice, st));
         if (e == hipSuccess)
@@ -1523,7 +1564,6 @@ extern "C" int pg_seqset_from_fasta(pg_ctx *ctx, const void *text_, uint64_t nby
             ok(hipStreamSynchronize(st));
         }
     }
-    row_free(ctx, d_text, text_cap);
     hipFree(d_chunks);
     hipFree(d_chunk0);
     hipFree(d_base);

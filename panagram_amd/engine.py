@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
 import weakref
 from typing import List, Optional, Sequence, Tuple
 
@@ -44,6 +45,9 @@ def kmc_kmer_length(pre) -> int:
 COLUMNS_DIRECT = os.environ.get("PG_COLUMNS_DIRECT", "0") not in ("", "0")
 
 
+_ADOPT_LOCK = threading.Lock()
+
+
 def tile_positions() -> int:
     """k-mer positions per tile (launch unit; a bit-column block holds 64 bytes per tile and genome)"""
     return int(_lib.load().pg_tile_positions())
@@ -55,10 +59,11 @@ class _Owner:
     a dropped object graph in no particular order — can never free a table under a result."""
 
     def _adopt(self, child) -> None:
-        if not hasattr(self, "_children"):
-            self._children = []
-        self._children = [w for w in self._children if w() is not None]
-        self._children.append(weakref.ref(child))
+        with _ADOPT_LOCK:  # (sequence sets are parsed by several host threads at once: Index.load_inputs)
+            if not hasattr(self, "_children"):
+                self._children = []
+            self._children = [w for w in self._children if w() is not None]
+            self._children.append(weakref.ref(child))
 
     def _close_children(self) -> None:
         for w in getattr(self, "_children", []):
