@@ -415,6 +415,59 @@ __device__ __forceinline__ uint32_t sliding_min(uint32_t x) {
     return m;
 }
 #undef PG_DPPMIN
+// ---- batches without halo lanes (PG_PROBE_CARRY) -----------------------------------------------------------------
+// A position's minimizer is the minimum over the W m-mers of its k-mer: its own (the last one) and the W - 1 before it,
+// which the W - 1 lanes below own.  The first W - 1 lanes of a batch have too few lanes below them; round 1-4 made them
+// HALO lanes — they only supplied m-mers, and a batch brought 64 - (W - 1) new positions (57 of 64 lanes at W = 7).
+// Instead (van Herk's two halves of a window): the window of lane j < W - 1 = the last W - 1 - j m-mers before the batch
+// (a suffix minimum over them) and the first j + 1 of this one (what the sliding minimum yields for a lane with fewer
+// than W - 1 lanes below).  One ds_bpermute brings the W - 1 m-mer ranks before the NEXT batch's first position — they
+// sit in consecutive lanes of this one — down to lanes 0 .. W - 2 (the carry; the other lanes hold ~0 once it is
+// used); their suffix minima take three row-local DPP steps there (a window of eight, cut off where the ~0 begin),
+// interleaved with the next batch's own sliding minimum, which takes them in with one v_min: up to 64 new positions
+// per batch for about eight instructions.
+#ifndef PG_PROBE_CARRY
+#define PG_PROBE_CARRY 1
+#endif
+#ifndef PG_PROBE_CUT
+#define PG_PROBE_CUT 1
+#endif
+// r[l] = min(x[l .. min(l + 7, last lane of l's row of 16)])
+__device__ __forceinline__ uint32_t suffix_min8_row(uint32_t x) {
+    uint32_t r = x;
+    asm("s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_shl:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_shl:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_shl:4 row_mask:0xf bank_mask:0xf"
+        : "+v"(r));
+    return r;
+}
+// the sliding minimum of x AND, in place, the suffix minima of a second vector (the carry): two dependent chains
+// interleaved (a DPP source written by a VALU instruction needs two wait states: the other chain's step is one of them)
+// (the sliding step as min(m, m of the lane below) — a window of t + 1 from two windows of t — needs no third operand: the
+// vector itself can then be the register the suffix chain works in; an input operand equal to a read-write one may be
+// given the SAME register by the compiler, and was)
+#define PG_F "v_min_u32_dpp %0, %0, %0 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+#define PG_S(n) "v_min_u32_dpp %1, %1, %1 row_shl:" #n " row_mask:0xf bank_mask:0xf\n\t"
+#define PG_N0 "s_nop 0\n\t"
+#define PG_N1 "s_nop 1\n\t"
+template <int W>
+__device__ __forceinline__ uint32_t sliding_min_suffix(uint32_t x, uint32_t &suffix) {
+    uint32_t m = x, r = suffix;
+    static_assert(W >= 2 && W <= 8, "minimizer window");
+    if constexpr (W == 2) asm(PG_N1 PG_F PG_S(1) PG_N1 PG_S(2) PG_N1 PG_S(4) : "+v"(m), "+v"(r));
+    if constexpr (W == 3) asm(PG_N1 PG_F PG_S(1) PG_N0 PG_F PG_S(2) PG_N1 PG_S(4) : "+v"(m), "+v"(r));
+    if constexpr (W == 4) asm(PG_N1 PG_F PG_S(1) PG_N0 PG_F PG_S(2) PG_N0 PG_F PG_S(4) : "+v"(m), "+v"(r));
+    if constexpr (W == 5) asm(PG_N1 PG_F PG_S(1) PG_N0 PG_F PG_S(2) PG_N0 PG_F PG_S(4) PG_N0 PG_F : "+v"(m), "+v"(r));
+    if constexpr (W == 6) asm(PG_N1 PG_F PG_S(1) PG_N0 PG_F PG_S(2) PG_N0 PG_F PG_S(4) PG_N0 PG_F PG_N1 PG_F : "+v"(m), "+v"(r));
+    if constexpr (W == 7) asm(PG_N1 PG_F PG_S(1) PG_N0 PG_F PG_S(2) PG_N0 PG_F PG_S(4) PG_N0 PG_F PG_N1 PG_F PG_N1 PG_F : "+v"(m), "+v"(r));
+    if constexpr (W == 8) asm(PG_N1 PG_F PG_S(1) PG_N0 PG_F PG_S(2) PG_N0 PG_F PG_S(4) PG_N0 PG_F PG_N1 PG_F PG_N1 PG_F PG_N1 PG_F : "+v"(m), "+v"(r));
+    suffix = r;
+    return m;
+}
+#undef PG_F
+#undef PG_S
+#undef PG_N0
+#undef PG_N1
 // base + (set bits of `mask` at lanes <= this lane) - 1: for a lane whose own bit is set, its index among the set lanes
 // (a queue slot, counted from the wave-uniform `base`); for any lane, the number of the last set lane at or below it (a
 // run id, when the set lanes are the runs' first lanes).  Two VALU instructions: the shift of the mask by one lane —
@@ -636,8 +689,13 @@ __attribute__((amdgpu_num_sgpr(80))) void k_probe(const SubTable st, const uint6
     __syncthreads();  // single wave: compiles to a wave-level wait, not an s_barrier
 
     const uint64_t kmask = kmer_mask(k);
-    constexpr int HALO = W_C ? W_C - 1 : 0;  // lanes of a batch that only supply m-mers to their successors
-    constexpr int STRIDE = 64 - HALO;        // new positions per batch
+    constexpr int HALO = W_C ? W_C - 1 : 0;  // m-mers of a window that lanes below its own supply
+    constexpr bool CARRY = PG_PROBE_CARRY && W_C >= 2;  // the first lanes' missing m-mers carried over from the batch before (sliding_min_suffix)
+    // CUT: a batch ends in front of its (MAXRUN + 1)-th run — the next batch starts there — so that ONE staging step takes
+    // every batch: at w = 7 a quarter of the 58-position batches met more than 16 lines and paid a second, unhidden fetch
+    constexpr bool CUT = PG_PROBE_CUT != 0;
+    constexpr int LHALO = CARRY ? 0 : HALO;  // lanes of a batch that only supply m-mers to their successors
+    [[maybe_unused]] constexpr int STRIDE = 64 - LHALO;  // new positions per batch (at most: CUT)
     const uint32_t m = W_C ? (uint32_t)k - W_C + 1 : 0;
     const uint64_t mm64 = (m >= 32) ? ~0ull : ((1ull << (2 * (m ? m : 1))) - 1);
     // (columns mode: `out1` is the block's column buffer, `nbytes` its width in genomes; the "rows" of the tile are
@@ -660,30 +718,48 @@ __attribute__((amdgpu_num_sgpr(80))) void k_probe(const SubTable st, const uint6
     struct Front {  // what the front end of a batch leaves behind: no table access so far
         uint64_t key;
         uint32_t grp, line, rid, nruns, padline;
+        uint32_t adv;                            // positions the batch covers: the next one starts that many further on (wave-uniform)
         unsigned long long rmask, amask, lmask;  // lanes with a position / active (no N in the window) / first of a run
     };
-    // ---- keys: lane = position b0 + lane - HALO; it also owns m-mer number b0 + lane ----
+    // ---- the carry of a batch that starts at position b0 of the tile (the tile's first, or one the tail loop starts
+    // again): lane j < HALO gets the rank of m-mer b0 + j (the m-mers before m-mer b0 + HALO, lane 0's own); the other
+    // lanes' values are not used.  An m-mer straight from the staged sequence words: forward strand from sw, reverse
+    // complement from rw — the values front() cuts out of X and B.
+    auto carry_at = [&](const uint32_t b0) __attribute__((always_inline)) {
+        uint32_t y = ~0u;
+        if constexpr (CARRY) {
+            const uint32_t q = b0 + (uint32_t)min(lane, HALO - 1);  // m-mer number = its first base in the tile
+            const uint64_t fa = extract_bases32(reinterpret_cast<const uint32_t *>(sw), q) & mm64;
+            const uint64_t fr = extract_bases32(reinterpret_cast<const uint32_t *>(rw), PROBE_SEQ_BASES - q - m) & mm64;
+            const uint32_t h = M64 ? mmer_rank(fa < fr ? fa : fr) : mz_order(min((uint32_t)fa, (uint32_t)fr));
+            y = h;
+        }
+        return y;
+    };
+    uint32_t carry = ~0u;  // (CARRY) what the next front() takes in (lanes 0 .. HALO - 1): written by carry_at or by the front() before
+    // ---- keys: lane = position b0 + lane - LHALO; it also owns m-mer number b0 + lane + (HALO - LHALO) ----
     // FIRST: the tile's first batch, whose leading HALO lanes stand before the tile's first k-mer (pl < 0: they take
     // their m-mers out of that k-mer, at their own offsets); in every later batch a lane's m-mer sits at the one fixed
     // offset and its position needs no clamp — instantiated twice so that the later batches carry neither.
     auto front = [&](auto first_tag, const uint32_t b0) __attribute__((always_inline)) {
         constexpr bool FIRST = decltype(first_tag)::value;
         Front f;
-        const int32_t pl = (int32_t)(b0 + lane) - HALO;
+        const int32_t pl = (int32_t)(b0 + lane) - LHALO;
         // (pl >= b0 exactly for the lanes behind the halo: a constant lane mask; a ballot straight off the compare stays
         // a scalar mask, one of a bool that was AND-ed together first is rebuilt through 0 / 1)
-        f.rmask = __builtin_amdgcn_ballot_w64(pl < (int32_t)npos) & ~((1ull << HALO) - 1ull);
-        const uint32_t pq = FIRST ? (uint32_t)max(pl, 0) : (uint32_t)pl;
+        f.rmask = __builtin_amdgcn_ballot_w64(pl < (int32_t)npos) & ~((1ull << LHALO) - 1ull);
+        const uint32_t pq = (FIRST && LHALO) ? (uint32_t)max(pl, 0) : (uint32_t)pl;
         const uint64_t X = extract_bases32(reinterpret_cast<const uint32_t *>(sw), pq) & kmask;
         const uint64_t B = revcomp_window(rw, X, pq, k, kmask);
         f.key = canonical_from_xb(X, B, k);
         f.amask = f.rmask;
         if (hasn) f.amask &= __builtin_amdgcn_ballot_w64(extract_nmask(nw, pq, k) == 0);
+        [[maybe_unused]] uint32_t own = 0;
         if (W_C) {
             // m-mer number b0+lane is the LAST m-mer of this lane's own k-mer (the first lanes of a tile, which have no
             // k-mer, take theirs out of the tile's first k-mer): forward strand from X, reverse complement from B — no
             // second pass over the sequence words
-            const uint32_t off = FIRST ? (uint32_t)(pl + HALO) - pq : (uint32_t)HALO;  // m-mer's offset inside the k-mer, 0..HALO
+            const uint32_t off = (FIRST && LHALO) ? (uint32_t)(pl + HALO) - pq : (uint32_t)HALO;  // m-mer's offset inside the k-mer, 0..HALO
             if constexpr (!M64) {  // m-mers of up to 32 bits: one funnel shift each, no 64-bit arithmetic
                 const uint32_t mm32 = (uint32_t)mm64;
                 const uint32_t fa = __builtin_amdgcn_alignbit((uint32_t)(X >> 32), (uint32_t)X, 2 * off) & mm32;
@@ -704,7 +780,14 @@ __attribute__((amdgpu_num_sgpr(80))) void k_probe(const SubTable st, const uint6
 #endif
             // sliding minimum over lanes [lane-W_C+1, lane]: m <- min(own rank, m of the lane below), W_C-1 times
             // (the first lanes of the wave see shorter windows: they are halo lanes, never active)
-            f.grp = sliding_min<W_C ? W_C : 1>(f.grp);
+            if constexpr (CARRY) {
+                own = f.grp;  // (this lane's own m-mer rank: the next batch's carry is cut out of these below)
+                uint32_t suffix = __builtin_amdgcn_inverse_ballot_w64((1ull << HALO) - 1ull) ? carry : ~0u;
+                f.grp = sliding_min_suffix<W_C >= 2 ? W_C : 2>(f.grp, suffix);
+                f.grp = min(f.grp, suffix);
+            } else {
+                f.grp = sliding_min<W_C ? W_C : 1>(f.grp);
+            }
         } else {
             f.grp = group_of_key(f.key);
         }
@@ -713,6 +796,22 @@ __attribute__((amdgpu_num_sgpr(80))) void k_probe(const SubTable st, const uint6
         f.line = home_of_group(f.grp, st.nbuckets);
         f.lmask = f.amask & (~(f.amask << 1) | differs_from_lane_below(f.line));
         f.rid = lanes_le_index(f.lmask, 0u);  // run id of an active lane
+        uint32_t lanes_kept = 64u;
+        if constexpr (CUT) {
+            // the lanes of the first MAXRUN runs — a prefix of the wave: run ids do not fall from lane to lane; the lanes
+            // in front of the first run count -1 — stay; the others' positions are the next batch's
+            const unsigned long long keep = __builtin_amdgcn_sicmp((int32_t)f.rid, MAXRUN, 40 /* signed < */);
+            f.amask &= keep;
+            f.rmask &= keep;
+            f.lmask &= keep;
+            lanes_kept = (uint32_t)__popcll(keep);  // (>= MAXRUN + LHALO when anything is cut: the batch always advances)
+        }
+        f.adv = lanes_kept - LHALO;
+        if constexpr (CARRY) {
+            // the next batch's carry: the HALO m-mer ranks in front of its first position's own = lanes lanes_kept - HALO
+            // .. lanes_kept - 1 of this batch (not needed before the next front(): the LDS crossbar's latency is hidden)
+            carry = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((((uint32_t)lane + lanes_kept - HALO) & 63u) << 2), (int)own);
+        }
         f.nruns = (uint32_t)__popcll(f.lmask);
         f.padline = f.lmask ? (uint32_t)__builtin_amdgcn_readlane((int)f.line, __builtin_ctzll(f.lmask)) : 0u;  // (wave-uniform)
 #if PG_ABLATE == 3  // (timing experiment: keys, minimizers and runs only — no table access)
@@ -753,7 +852,7 @@ __attribute__((amdgpu_num_sgpr(80))) void k_probe(const SubTable st, const uint6
     // ---- the rest of the batch: its lines into LDS, every lane scans its own; overflow entries; the rows ----
     auto back = [&](const Front &f, const Lines &L, const uint32_t b0, auto &&after_staging) __attribute__((always_inline)) {
         const bool act = __builtin_amdgcn_inverse_ballot_w64(f.amask), inrange = __builtin_amdgcn_inverse_ballot_w64(f.rmask);
-        const int32_t pl = (int32_t)(b0 + lane) - HALO;
+        const int32_t pl = (int32_t)(b0 + lane) - LHALO;
         uint32_t m0 = 0, m1 = 0;
         int rcode = 0;
         // a staging step's chunks into LDS (wave-uniform placement: chunk idx of the step -> line idx / SLOTS, slot
@@ -801,7 +900,8 @@ __attribute__((amdgpu_num_sgpr(80))) void k_probe(const SubTable st, const uint6
         PG_PH(4)
         if (f.nruns) scan(0u);
         PG_PH(5)
-        for (uint32_t r0 = MAXRUN; r0 < f.nruns; r0 += MAXRUN) {  // (a batch with more than MAXRUN lines: rare)
+        if constexpr (!CUT)
+        for (uint32_t r0 = MAXRUN; r0 < f.nruns; r0 += MAXRUN) {  // (a batch with more than MAXRUN lines: a quarter of the batches at w = 7)
             const Lines X = issue(f, r0);
             __builtin_amdgcn_s_waitcnt(0x0F70);
             stage(X);
@@ -836,7 +936,7 @@ __attribute__((amdgpu_num_sgpr(80))) void k_probe(const SubTable st, const uint6
         } else if constexpr (ROWMODE == 3) {
             const uint32_t w0 = b0 >> 6, sh = b0 & 63u;
             for (uint32_t j = 0; j < rc.col0; ++j) {  // (uniform) one ballot per genome of the block
-                const unsigned long long shifted = __ballot(inrange && ((m0 >> j) & 1u)) >> HALO;  // bit i = position b0 + i
+                const unsigned long long shifted = __ballot(inrange && ((m0 >> j) & 1u)) >> LHALO;  // bit i = position b0 + i
                 if (lane == 0 && shifted) {
                     cols[w0 * COLS_G + j] |= shifted << sh;
                     if (sh && (shifted >> (64u - sh))) cols[(w0 + 1) * COLS_G + j] |= shifted >> (64u - sh);
@@ -859,7 +959,7 @@ __attribute__((amdgpu_num_sgpr(80))) void k_probe(const SubTable st, const uint6
                 const uint32_t dw = __builtin_amdgcn_alignbit(nxt >> 8, lo, 8u * j);
                 const unsigned long long nextin = f.rmask >> 1;
                 const unsigned long long dmask = f.rmask & nextin & __builtin_amdgcn_ballot_w64(j != 3u);
-                const unsigned long long fmask = f.rmask & ((1ull << HALO) | ~nextin);
+                const unsigned long long fmask = f.rmask & ((1ull << LHALO) | ~nextin);
                 uint8_t *row = tile_rows + (uint32_t)pl * 3u;
                 if (__builtin_amdgcn_inverse_ballot_w64(dmask)) *reinterpret_cast<uint32_t *>(row + j) = dw;
                 if (__builtin_amdgcn_inverse_ballot_w64(fmask)) store_row<ROWMODE>(row, m0, m1, rc);
@@ -896,14 +996,16 @@ __attribute__((amdgpu_num_sgpr(80))) void k_probe(const SubTable st, const uint6
 #pragma unroll
         for (int it = 0; it < STAGE_ITERS; ++it) L.v[it] = make_uint4(0, 0, 0, 0);
         PG_PH(0)
+        carry = carry_at(0u);
         Front cur = front(std::true_type{}, 0u);
         if (cur.nruns) L = issue(cur, 0u);
         for (;;) {
             PG_PH(7)
-            const bool more = b0 + STRIDE < npos;  // (wave-uniform)
+            const uint32_t b1 = b0 + cur.adv;
+            const bool more = b1 < npos;  // (wave-uniform)
             Front nxt = cur;
             __builtin_amdgcn_sched_barrier(0);  // (the parts stay apart: interleaved by the scheduler they keep both batches' temporaries alive)
-            if (more) nxt = front(std::false_type{}, b0 + STRIDE);  // while the lines of `cur` are on their way
+            if (more) nxt = front(std::false_type{}, b1);  // while the lines of `cur` are on their way
             __builtin_amdgcn_sched_barrier(0);
 #if PG_PROBE_PIPE >= 2
             // the next batch's fetch goes out as soon as this batch's chunks have left their registers for LDS: it is in
@@ -912,13 +1014,13 @@ __attribute__((amdgpu_num_sgpr(80))) void k_probe(const SubTable st, const uint6
                 if (more && nxt.nruns) L = issue(nxt, 0u);
             });
             __builtin_amdgcn_sched_barrier(0);
-            b0 += STRIDE;
+            b0 = b1;
             if (!more || qn > QROOM) break;  // (rare way out with a fetch in flight: nobody reads it; the tail starts the batch again)
             cur = nxt;
 #else
             back(cur, L, b0, [] {});
             __builtin_amdgcn_sched_barrier(0);
-            b0 += STRIDE;
+            b0 = b1;
             // (the room is checked AFTER a batch's look-up, which is what fills the queue: the front end of the next batch
             // is thrown away on the rare way out — the tail starts it again)
             if (!more || qn > QROOM) break;
@@ -928,14 +1030,17 @@ __attribute__((amdgpu_num_sgpr(80))) void k_probe(const SubTable st, const uint6
         }
     } else {
         {
+            carry = carry_at(0u);
             const Front f = front(std::true_type{}, 0u);
             const Lines L = issue(f, 0u);  // (also for a batch without runs — a stretch of N: line 0 is fetched and ignored)
             back(f, L, 0u, [] {});
+            b0 = f.adv;
         }
-        for (b0 = STRIDE; b0 < npos && qn <= QROOM; b0 += STRIDE) {
+        while (b0 < npos && qn <= QROOM) {
             const Front f = front(std::false_type{}, b0);
             const Lines L = issue(f, 0u);
             back(f, L, b0, [] {});
+            b0 += f.adv;
         }
     }
     PG_PH(7)
@@ -944,10 +1049,12 @@ __attribute__((amdgpu_num_sgpr(80))) void k_probe(const SubTable st, const uint6
         qn = 0;
         if (b0 >= npos) break;
         __syncthreads();
-        for (; b0 < npos && qn <= QROOM; b0 += STRIDE) {
+        carry = carry_at(b0);  // (the hot loop may have left with the front end of a batch it did not finish)
+        while (b0 < npos && qn <= QROOM) {
             const Front f = front(std::false_type{}, b0);
             const Lines L = issue(f, 0u);
             back(f, L, b0, [] {});
+            b0 += f.adv;
         }
     }
     PG_PH(8)
