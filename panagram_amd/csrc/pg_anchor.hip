@@ -635,10 +635,14 @@ __attribute__((amdgpu_num_sgpr(80))) void k_probe(const SubTable st, const uint6
     // A staged line occupies 16*SLOTS + 16 bytes of LDS: the pad keeps the lanes' ds_read_b128 of
     // "their" lines off a common bank group (a power-of-two stride would be a 32-way conflict)
     constexpr int LDS_LINE_U4 = SLOTS + 1;
-    // lines staged per step: 16 take the ~13 distinct lines a batch meets at w = 7 / 8 in ONE step; at w = 6 (what k=21
-    // gets on 150-570 Mb genomes) a batch meets ~17 and paid a second step for the last few — 24 there (9.01 -> 8.66 ms
-    // on 64 x 20 Mb, 92.0 -> 89.7 on 64 x 200 Mb; everywhere else 24 costs 8-10 %: LDS, occupancy; tools/ab_maxrun.sh)
-    constexpr int MAXRUN = W_C == 6 ? (PROBE_MAXRUN * 3) / 2 : PROBE_MAXRUN;
+    // lines staged per step: 16, whatever the window — a batch ends in front of its 17th run (CUT below).  (While a batch
+    // was a fixed 58 - 61 positions, the 6-m-mer window — what k=21 gets on 150-570 Mb genomes, ~17 lines per batch — staged
+    // 24 to avoid a second step; with batches cut at 16 runs the smaller LDS footprint wins: 8 x 200 Mb 8.0 -> 7.6 ms,
+    // 27 x 160 Mb 21.7 -> 20.3, 64 x 160 Mb 67.3 -> 65.7; profiles/r4b_ab_w6_maxrun.txt)
+#ifndef PG_MAXRUN_W6
+#define PG_MAXRUN_W6 PROBE_MAXRUN  // (24 until batches were cut at MAXRUN runs, see below: -DPG_MAXRUN_W6=24 with -DPG_PROBE_CUT=0)
+#endif
+    constexpr int MAXRUN = W_C == 6 ? PG_MAXRUN_W6 : PROBE_MAXRUN;
     constexpr int STAGE_ITERS = (MAXRUN * SLOTS + 63) / 64;  // 16-byte loads per lane per staging step
     // ONE block of LDS, carved up by hand, the tile's sequence words FIRST: the two-dword window reads of every batch
     // (ds_read2_b32, whose offsets reach 1020 bytes) then address them with an immediate instead of an add per window
@@ -647,7 +651,7 @@ __attribute__((amdgpu_num_sgpr(80))) void k_probe(const SubTable st, const uint6
     constexpr int OFF_RW = PROBE_SEQW * 8, OFF_NW = OFF_RW + (PROBE_SEQW + 1) * 8, OFF_LW = OFF_NW + PROBE_SEQW * 4;
     // (the 6-m-mer window stages 24 lines per step: with the full queue its 5968 bytes round up to 6144 = 26 waves per CU,
     // 6 per SIMD; 152 entries bring it to 5568 -> 5632 = 29 waves, 7 per SIMD)
-    constexpr int QCAP = (W_C == 6 && PROBE_QCAP > 152) ? 152 : PROBE_QCAP;
+    constexpr int QCAP = (W_C == 6 && MAXRUN > PROBE_MAXRUN && PROBE_QCAP > 152) ? 152 : PROBE_QCAP;
     constexpr int OFF_BUF = (OFF_LW + MAXRUN * 4 + 15) & ~15, OFF_QL = OFF_BUF + BUF_U4 * 16, OFF_QS = OFF_QL + QCAP * 4;
     constexpr int OFF_QP = OFF_QS + QCAP * 4, LDS_BYTES = OFF_QP + QCAP * 2;
     static_assert(OFF_LW <= 1020 || PROBE_TILE > 1024, "the sequence words must stay within reach of ds_read2_b32's offsets");
@@ -693,7 +697,9 @@ __attribute__((amdgpu_num_sgpr(80))) void k_probe(const SubTable st, const uint6
     constexpr bool CARRY = PG_PROBE_CARRY && W_C >= 2;  // the first lanes' missing m-mers carried over from the batch before (sliding_min_suffix)
     // CUT: a batch ends in front of its (MAXRUN + 1)-th run — the next batch starts there — so that ONE staging step takes
     // every batch: at w = 7 a quarter of the 58-position batches met more than 16 lines and paid a second, unhidden fetch
-    constexpr bool CUT = PG_PROBE_CUT != 0;
+    // (not in direct mode, k < 20: every position is a run of its own there, and a batch of 16 positions would run the front
+    // end four times where four staging steps share one)
+    constexpr bool CUT = PG_PROBE_CUT != 0 && W_C != 0;
     constexpr int LHALO = CARRY ? 0 : HALO;  // lanes of a batch that only supply m-mers to their successors
     [[maybe_unused]] constexpr int STRIDE = 64 - LHALO;  // new positions per batch (at most: CUT)
     const uint32_t m = W_C ? (uint32_t)k - W_C + 1 : 0;
@@ -1305,7 +1311,8 @@ __global__ __launch_bounds__(64) void k_insert_tile(const SubTable st, int w, ui
         __syncthreads();
     };
 
-    for (uint32_t b = 0; b < npos; b += STRIDE) {
+    uint32_t adv = STRIDE;  // positions the batch covers (k_probe's CUT: a batch ends in front of its (PROBE_MAXRUN + 1)-th run)
+    for (uint32_t b = 0; b < npos; b += adv) {
         const int32_t pl = (int32_t)(b + lane) - HALO;
         const bool inrange = pl >= (int32_t)b && pl < (int32_t)npos;
         const uint32_t pq = (uint32_t)max(pl, 0);
@@ -1333,10 +1340,17 @@ __global__ __launch_bounds__(64) void k_insert_tile(const SubTable st, int w, ui
         }
         const uint32_t line = home_of_group(grp, st.nbuckets);
         const uint32_t prev_line = lane_up1(line);
-        const unsigned long long amask = __builtin_amdgcn_ballot_w64(act);  // (run starts by lane-mask arithmetic on the scalar unit, as in k_probe)
-        const unsigned long long lmask = amask & (~(amask << 1) | __builtin_amdgcn_ballot_w64(line != prev_line));
-        const bool leader = __builtin_amdgcn_inverse_ballot_w64(lmask);
+        unsigned long long amask = __builtin_amdgcn_ballot_w64(act);  // (run starts by lane-mask arithmetic on the scalar unit, as in k_probe)
+        unsigned long long lmask = amask & (~(amask << 1) | __builtin_amdgcn_ballot_w64(line != prev_line));
         const uint32_t rid = lanes_le_index(lmask, 0u);
+        if constexpr (PG_PROBE_CUT && W_C != 0) {  // one staging step per batch: the lanes behind the PROBE_MAXRUN-th run are the next batch's
+            const unsigned long long keep = __builtin_amdgcn_sicmp((int32_t)rid, PROBE_MAXRUN, 40 /* signed < */);
+            amask &= keep;
+            lmask &= keep;
+            act = __builtin_amdgcn_inverse_ballot_w64(amask);
+            adv = (uint32_t)__popcll(keep) - HALO;
+        }
+        const bool leader = __builtin_amdgcn_inverse_ballot_w64(lmask);
         const uint32_t nruns = (uint32_t)__popcll(lmask);
         bool found = false, full = true;  // full: the staged home line had no empty slot (or was not reached)
         for (uint32_t r0 = 0; r0 < nruns; r0 += PROBE_MAXRUN) {

@@ -2187,6 +2187,7 @@ static bool sched_covers(const pg_result *r, uint32_t t0, uint32_t nt) {
 // statistics side from its first kernel's start to its last one's end.
 static int run_chunks(pg_result *r, const TableDesc &T) {
     hipStream_t st = r->ctx->stream, aux = r->ctx->aux_stream;
+    if (const char *e = getenv("PG_CHUNK_SAME_STREAM"); e && *e == '1') aux = st;  // (experiment: the statistics of a chunk right behind its probe, nothing side by side)
     const uint32_t N = r->N;
     const uint32_t kflags = (r->flags & PG_ANCHOR_COLSUMS) | (r->lowres_step == 100 ? 0u : 2u);
     HIP_TRY(hipEventRecord(r->ev[0], st));
