@@ -72,9 +72,10 @@ __device__ unsigned long long pg_phase_cycles[1024 * 16];  // (1024 sets, by blo
 #define PG_PH(i)
 #define PG_PH_FLUSH
 #endif
-__device__ __forceinline__ uint64_t revcomp_window(const uint64_t *rw, uint64_t X, uint32_t p, int k, uint64_t kmask) {
+// (rcb = PROBE_SEQ_BASES - k, handed in: written as PROBE_SEQ_BASES - p - k the compiler adds p and k per position first)
+__device__ __forceinline__ uint64_t revcomp_window(const uint64_t *rw, uint64_t X, uint32_t p, int k, uint64_t kmask, uint32_t rcb) {
 #if PG_RC_LDS
-    return extract_bases32(reinterpret_cast<const uint32_t *>(rw), PROBE_SEQ_BASES - p - (uint32_t)k) & kmask;
+    return extract_bases32(reinterpret_cast<const uint32_t *>(rw), rcb - p) & kmask;
 #else
     return revcomp_le(X, k);
 #endif
@@ -514,6 +515,7 @@ __device__ __forceinline__ void drain_queue(const SubTable &st, uint32_t qn, con
     constexpr int STAGE_ITERS = (MAXRUN * SLOTS + 63) / 64;
     const uint8_t *chunk_base = st.buckets + (uint32_t)(lane % SLOTS) * 16u;
     const uint32_t lbytes = st.slots * (WIDE ? 8u : 16u);  // (= 16 * SLOTS, as a run-time scalar: see k_probe)
+    static_assert(LEVELS >= 1, "k_probe's entries (home line, group) are turned into (next line, step) by level 1's staged batches");
     for (int level = 1; qn > 0; ++level) {
         __syncthreads();
         if (level > LEVELS) {
@@ -538,11 +540,15 @@ __device__ __forceinline__ void drain_queue(const SubTable &st, uint32_t qn, con
             const uint32_t e = i0 + lane;
             const bool act = e < qn;
             const uint32_t ec = act ? e : qn - 1;
-            const uint32_t line = q_line[ec], step = q_step[ec];
+            uint32_t line = q_line[ec], step = q_step[ec];
+            if (GROUP_CHAIN > 1 && level == 1) {  // (k_probe's entries: home line and group — see there)
+                step = step_of_group(step, st.nbuckets);
+                line = next_line(line, step, st.nbuckets);
+            }
             const uint32_t pl = q_pl[ec];
             const uint64_t kmask = kmer_mask(k);
             const uint64_t X = extract_bases32(reinterpret_cast<const uint32_t *>(sw), pl) & kmask;
-            const uint64_t key = canonical_from_xb(X, revcomp_window(rw, X, pl, k, kmask), k);
+            const uint64_t key = canonical_from_xb(X, revcomp_window(rw, X, pl, k, kmask, PROBE_SEQ_BASES - (uint32_t)k), k);
             const uint32_t prev_line = lane_up1(line);
             const bool leader = act && (lane == 0 || line != prev_line);
             const unsigned long long lmask = __builtin_amdgcn_ballot_w64(leader);
@@ -692,7 +698,10 @@ __attribute__((amdgpu_num_sgpr(80))) void k_probe(const SubTable st, const uint6
     if (lane == 0) rw[PROBE_SEQW] = 0;  // (a window's three dwords may reach one word past the end)
     __syncthreads();  // single wave: compiles to a wave-level wait, not an s_barrier
 
-    const uint64_t kmask = kmer_mask(k);
+    // (minimizer tables: k >= 20, the mask's low word is all ones — spelt out, the compiler drops the ANDs with it: two per
+    // position)
+    const uint64_t kmask = W_C ? (((uint64_t)(k == 32 ? ~0u : ((1u << (2 * k - 32)) - 1u)) << 32) | 0xFFFFFFFFull) : kmer_mask(k);
+    const uint32_t rcb = PROBE_SEQ_BASES - (uint32_t)k;
     constexpr int HALO = W_C ? W_C - 1 : 0;  // m-mers of a window that lanes below its own supply
     constexpr bool CARRY = PG_PROBE_CARRY && W_C >= 2;  // the first lanes' missing m-mers carried over from the batch before (sliding_min_suffix)
     // CUT: a batch ends in front of its (MAXRUN + 1)-th run — the next batch starts there — so that ONE staging step takes
@@ -756,8 +765,8 @@ __attribute__((amdgpu_num_sgpr(80))) void k_probe(const SubTable st, const uint6
         f.rmask = __builtin_amdgcn_ballot_w64(pl < (int32_t)npos) & ~((1ull << LHALO) - 1ull);
         const uint32_t pq = (FIRST && LHALO) ? (uint32_t)max(pl, 0) : (uint32_t)pl;
         const uint64_t X = extract_bases32(reinterpret_cast<const uint32_t *>(sw), pq) & kmask;
-        const uint64_t B = revcomp_window(rw, X, pq, k, kmask);
-        f.key = canonical_from_xb(X, B, k);
+        const uint64_t B = revcomp_window(rw, X, pq, k, kmask, rcb);
+        f.key = ~(X > B ? X : B) & kmask;  // (canonical_from_xb with this kernel's mask)
         f.amask = f.rmask;
         if (hasn) f.amask &= __builtin_amdgcn_ballot_w64(extract_nmask(nw, pq, k) == 0);
         [[maybe_unused]] uint32_t own = 0;
@@ -816,7 +825,8 @@ __attribute__((amdgpu_num_sgpr(80))) void k_probe(const SubTable st, const uint6
         if constexpr (CARRY) {
             // the next batch's carry: the HALO m-mer ranks in front of its first position's own = lanes lanes_kept - HALO
             // .. lanes_kept - 1 of this batch (not needed before the next front(): the LDS crossbar's latency is hidden)
-            carry = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((((uint32_t)lane + lanes_kept - HALO) & 63u) << 2), (int)own);
+            // (lanes 0 .. HALO - 1, the only ones whose result is used, read lanes below 64: no wrap to take care of)
+            carry = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((uint32_t)lane << 2) + ((lanes_kept - HALO) << 2)), (int)own);
         }
         f.nruns = (uint32_t)__popcll(f.lmask);
         f.padline = f.lmask ? (uint32_t)__builtin_amdgcn_readlane((int)f.line, __builtin_ctzll(f.lmask)) : 0u;  // (wave-uniform)
@@ -919,12 +929,15 @@ __attribute__((amdgpu_num_sgpr(80))) void k_probe(const SubTable st, const uint6
         const unsigned long long omask = f.amask & __builtin_amdgcn_sicmp(rcode, 0, 40);
         const bool ovf = __builtin_amdgcn_inverse_ballot_w64(omask);
         if (omask) {
+            // (the entry carries the home line and the GROUP: its step and next line — two multiplies and the wrap — are
+            // worked out by the drain's dense batches (drain_queue, level 1), not here for the few overflowing lanes of
+            // every batch: nine VALU instructions per batch)
             uint32_t step, nx;
             if constexpr (GROUP_CHAIN == 1) {  // (tuning build: the group owns its home line only — level 1 is the key's own sequence)
                 key_sequence(f.key, st.nbuckets, nx, step);
             } else {
-                step = step_of_group(f.grp, st.nbuckets);
-                nx = next_line(f.line, step, st.nbuckets);
+                step = f.grp;
+                nx = f.line;
             }
             // (the queue always has room for a whole batch: the batch loop leaves for an early drain before it could not)
             const uint32_t slot = lanes_le_index(omask, qn);
@@ -1286,7 +1299,8 @@ __global__ __launch_bounds__(64) void k_insert_tile(const SubTable st, int w, ui
     }
     if (lane == 0) rw[PROBE_SEQW] = 0;  // (a window's three dwords may reach one word past the end)
     __syncthreads();
-    const uint64_t kmask = kmer_mask(k);
+    const uint64_t kmask = W_C ? (((uint64_t)(k == 32 ? ~0u : ((1u << (2 * k - 32)) - 1u)) << 32) | 0xFFFFFFFFull) : kmer_mask(k);  // (as in k_probe)
+    const uint32_t rcb = PROBE_SEQ_BASES - (uint32_t)k;
     constexpr int HALO = W_C ? W_C - 1 : 0;
     constexpr int STRIDE = 64 - HALO;
     const uint32_t m = W_C ? (uint32_t)k - W_C + 1 : 0;
@@ -1317,8 +1331,8 @@ __global__ __launch_bounds__(64) void k_insert_tile(const SubTable st, int w, ui
         const bool inrange = pl >= (int32_t)b && pl < (int32_t)npos;
         const uint32_t pq = (uint32_t)max(pl, 0);
         const uint64_t X = extract_bases32(reinterpret_cast<const uint32_t *>(sw), pq) & kmask;
-        const uint64_t B = revcomp_window(rw, X, pq, k, kmask);
-        const uint64_t key = canonical_from_xb(X, B, k);
+        const uint64_t B = revcomp_window(rw, X, pq, k, kmask, rcb);
+        const uint64_t key = ~(X > B ? X : B) & kmask;
         bool act = inrange;
         if (hasn) act = act && (extract_nmask(nw, pq, k) == 0);
         uint32_t grp;

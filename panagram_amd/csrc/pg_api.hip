@@ -408,7 +408,8 @@ static int alloc_sub(pg_ctx *ctx, uint32_t W, uint32_t word0, uint32_t k, uint32
                      uint32_t layout, SubTable *out) {
     if (nbuckets < 64) nbuckets = 64;
     nbuckets = next_prime(nbuckets);
-    if (nbuckets > 0xFFFFFFFFull) return fail(PG_E_CAPACITY, "sub-table would exceed 2^32 lines (512 GB)");
+    // (next_line adds a line number and a step in 32 bits: both below nbuckets, so nbuckets <= 2^31 keeps the sum exact)
+    if (nbuckets > 0x80000000ull) return fail(PG_E_CAPACITY, "sub-table would exceed 2^31 lines (256 GB of key lines)");
     SubTable t;
     t.W = W;
     t.word0 = word0;

@@ -157,9 +157,11 @@ __device__ __forceinline__ uint32_t home_of_group(uint32_t g, uint64_t nlines) {
 __device__ __forceinline__ uint32_t step_of_group(uint32_t g, uint64_t nlines) {
     return 1u + range32(mix1(g ^ 0x5bd1e995u, 0xc2b2ae35u), nlines - 1);
 }
+// (line, step < nlines <= 2^31, alloc_sub: the sum is exact in 32 bits; n - nlines wraps to a huge number exactly when
+// n < nlines, so the smaller of the two is the answer — add, subtract, min instead of a 64-bit add, compare and select)
 __device__ __forceinline__ uint32_t next_line(uint32_t line, uint32_t step, uint64_t nlines) {
-    const uint64_t n = (uint64_t)line + step;
-    return (uint32_t)(n >= nlines ? n - nlines : n);
+    const uint32_t n = line + step;
+    return min(n, n - (uint32_t)nlines);
 }
 // A minimizer group owns only the first GROUP_CHAIN lines of its sequence.  A key that finds them
 // all full continues on a sequence of ITS OWN (double hashing on the key): repeat families put
