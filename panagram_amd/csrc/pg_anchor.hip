@@ -433,6 +433,9 @@ __device__ __forceinline__ uint32_t sliding_min(uint32_t x) {
 #ifndef PG_PROBE_CUT
 #define PG_PROBE_CUT 1
 #endif
+#ifndef PG_EARLY_LINES
+#define PG_EARLY_LINES 1  // the first staging step's line numbers pass through LDS at the end of the front end (k_probe: front)
+#endif
 // r[l] = min(x[l .. min(l + 7, last lane of l's row of 16)])
 __device__ __forceinline__ uint32_t suffix_min8_row(uint32_t x) {
     uint32_t r = x;
@@ -734,6 +737,7 @@ __attribute__((amdgpu_num_sgpr(80))) void k_probe(const SubTable st, const uint6
         uint64_t key;
         uint32_t grp, line, rid, nruns, padline;
         uint32_t adv;                            // positions the batch covers: the next one starts that many further on (wave-uniform)
+        uint32_t ln[PG_EARLY_LINES ? STAGE_ITERS : 1];  // the lines this lane fetches a chunk of in the first staging step
         unsigned long long rmask, amask, lmask;  // lanes with a position / active (no N in the window) / first of a run
     };
     // ---- the carry of a batch that starts at position b0 of the tile (the tile's first, or one the tail loop starts
@@ -833,6 +837,18 @@ __attribute__((amdgpu_num_sgpr(80))) void k_probe(const SubTable st, const uint6
 #if PG_ABLATE == 3  // (timing experiment: keys, minimizers and runs only — no table access)
         if (f.line != 0xDEADBEEFu) f.nruns = 0;
 #endif
+        if constexpr (PG_EARLY_LINES != 0) {
+            // The first staging step's line numbers go through lines_w HERE — one per run, padded with the first run's
+            // (see issue) — and every lane reads back the ones it will fetch a chunk of: two LDS round trips that used to
+            // stand between "the chunks of the batch before are staged" and this batch's fetch; the read is in flight
+            // while the caller does something else (the skewed order: the whole staging of the batch before).
+            const bool leader = __builtin_amdgcn_inverse_ballot_w64(f.lmask);
+            if (lane < MAXRUN) lines_w[0][lane] = f.padline;
+            if (leader && f.rid < (uint32_t)MAXRUN) lines_w[0][f.rid] = f.line;
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < STAGE_ITERS; ++it) f.ln[it] = lines_w[0][it * (64 / SLOTS) + lane / SLOTS];
+        }
         return f;
     };
     // ---- the fetch of a staging step: runs r0 .. r0 + MAXRUN - 1 of the batch, MAXRUN lines = MAXRUN * SLOTS chunks of 16
@@ -848,15 +864,18 @@ __attribute__((amdgpu_num_sgpr(80))) void k_probe(const SubTable st, const uint6
     };
     auto issue = [&](const Front &f, const uint32_t r0) __attribute__((always_inline)) {
         Lines L;
-        const uint32_t nl = min((uint32_t)MAXRUN, f.nruns - r0);  // (0 for a batch without runs: r0 is 0 then)
-        const bool leader = __builtin_amdgcn_inverse_ballot_w64(f.lmask);
-        if (lane < MAXRUN) lines_w[0][lane] = f.padline;
-        if (leader && f.rid - r0 < nl) lines_w[0][f.rid - r0] = f.line;
-        __syncthreads();
         uint32_t ln[STAGE_ITERS];
+        if (PG_EARLY_LINES == 0 || r0 != 0u) {
+            const uint32_t nl = min((uint32_t)MAXRUN, f.nruns - r0);  // (0 for a batch without runs: r0 is 0 then)
+            const bool leader = __builtin_amdgcn_inverse_ballot_w64(f.lmask);
+            if (lane < MAXRUN) lines_w[0][lane] = f.padline;
+            if (leader && f.rid - r0 < nl) lines_w[0][f.rid - r0] = f.line;
+            __syncthreads();
+        }
 #pragma unroll
         for (int it = 0; it < STAGE_ITERS; ++it) {
-            ln[it] = lines_w[0][it * (64 / SLOTS) + lane / SLOTS];
+            if (PG_EARLY_LINES == 0 || r0 != 0u) ln[it] = lines_w[0][it * (64 / SLOTS) + lane / SLOTS];
+            else ln[it] = f.ln[it];
 #if PG_ABLATE == 1  // (timing experiment, wrong rows: every fetch a cache hit — the lines of one 64 KB window)
             ln[it] &= 511u;
 #endif
