@@ -24,6 +24,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <math.h>
 
 namespace pg {
 
@@ -98,30 +99,56 @@ struct TableDesc {
 //    (7.8e8 keys, 4^15 = 8 L) 130 / 123 / 121; 64 x 200 Mb (2.4e9 keys, 4^15 = 5.4 L) 100 / 114 / 115;
 //    8 x 3 Gb (3.4e9 keys; m = 16 / 17 / 18) 120 / 134 / 140.  L is known to the library as the length of the FIRST
 //    sequence set inserted into an empty table (pg_table_insert_seqset settles m again then).
-// So m = max(k - 7, m_need), w = k-m+1 kept in 3..8, a window that would come out as 5 narrowed to 4, with
-//   m_need = ceil(log4(4 * keys))                                    while no sequence has been inserted,
-//   m_need = max(ceil(log4(7.5 * L)), ceil(log4(4 * keys)) - 2)      once L is known
-// (the second term: a first sequence set much shorter than the genomes that follow must not talk m down).
+// Round 4 (k_probe's batches end in front of their 17th run, no halo lanes: profiles/r4b_m_sweep.txt) moved the balance:
+// a batch now holds 16 runs whatever the window, so a narrow window means a short batch (w = 4: 40 positions of 64
+// lanes) and costs more than it did — w 8 -> 7 nothing, 7 -> 6 about 3.5 %, 6 -> 5 another 7 %, 5 -> 4 another 9 % —
+// while merged groups cost what they always did: with r = 4^m / L (L = the pangenome's non-redundant length) a launch
+// loses about 50 % / r (r = 1.5: a third; 5: 10 %; 10: 5 %; 40: 1 %).  Measured on the new kernel (k=21, G k-mers/s at
+// m = 15 / 16 / 17 / 18): 8 x 100 Mb 197 / 199 / 182 / -, 8 x 200 Mb 187 / 200 / - / 165, 8 x 300 Mb 174 / 199 / - / 166,
+// 27 x 135 Mb (config 3) 162 / 177, 27 x 160 Mb 162 / 187 / - / 152, 4 x 700 Mb 135 / 179 / 174 / 159, 8 x 30 Mb 180 / 174;
+// at 3 % divergence 8 x 100 Mb 153 / 165 / - / 142, 27 x 40 Mb 133 / 149 / - / 134; k=20 (w = 6 / 5 / 4 / 3) 193 / 185 / 166 /
+// 141; k=22 (w = 8 / 7 / 6 / 5) 192 / 206 / 197 / 184.  More variants per locus (divergence, genome count) act like a longer
+// pangenome, but less than in proportion: L_eff = L * sqrt(keys / (2.3 L)) (2.3 keys per locus is what 8 genomes at 1 % have;
+// 64 x 160 Mb, 12 keys per locus: 139 / 137 / 126 at m = 16 / 17 / 18), the factor held to 4 (an expected key count far above
+// what the first sequence set supports is an estimate gone wrong); 8 x 3 Gb: 153 / 169 / 156 at m = 16 / 17 / 18.
+// So: m = the candidate (window 3..wmax, m >= 15) with the smallest  window_cost(w) + 50 / r  [percent];
+//   L_eff = 1.5e8 while neither a key count nor a sequence is known (m = 16 for k = 21);
+//   once a key count is known m stays within two bases of ceil(log4(4 * keys)) from below (a first sequence set much
+//   shorter than the genomes that follow must not talk m down).
 // m-mers longer than 16 bases use 64-bit arithmetic.
 constexpr uint32_t MZ_WMIN = 3, MZ_WMAX = 8;
 __host__ __device__ __forceinline__ uint32_t minimizer_length(uint32_t k, uint64_t expected_keys, uint64_t first_len = 0,
                                                               uint32_t wmax = MZ_WMAX) {
     if (k < 20 || k > 32) return 0;
-    uint32_t m_need = 16;  // unknown cardinality: good up to ~1e9 keys
-    if (expected_keys) {
-        m_need = 15;
-        while (m_need < 27 && (1ull << (2 * m_need)) < 4 * expected_keys) ++m_need;
-    }
+    double leff = 1.5e8;
     if (first_len) {
-        uint32_t m_len = 15;
-        while (m_len < 27 && (double)(1ull << (2 * m_len)) < 7.5 * (double)first_len) ++m_len;
-        m_need = m_need >= m_len + 2 ? m_need - 2 : m_len;
+        leff = (double)first_len;
+        double v = (double)expected_keys / (2.3 * leff);  // variants per locus, in units of what 8 genomes at 1 % have
+        if (v > 1.0) leff *= sqrt(v < 16.0 ? v : 16.0);
+    } else if (expected_keys) {
+        leff = (double)expected_keys / 2.3;
     }
-    uint32_t m = k - (wmax - 1);  // (wmax: PG_TABLE_WMAX caps the window, pg_api.hip — repeat-rich genomes)
-    if (m < m_need) m = m_need;
-    if (k - m + 1 == 5) ++m;
-    if (m > k - (MZ_WMIN - 1)) m = k - (MZ_WMIN - 1);
-    return m;
+    uint32_t m_lo = 15;  // (k=21, 100 Mb genomes: m = 14 84 G k-mers/s against 100 at m = 15, round 1)
+    if (k - (wmax - 1) > m_lo) m_lo = k - (wmax - 1);  // (wmax: PG_TABLE_WMAX caps the window, pg_api.hip — repeat-rich genomes)
+    if (expected_keys) {
+        uint32_t mk = 15;
+        while (mk < 27 && (1ull << (2 * mk)) < 4 * expected_keys) ++mk;
+        if (mk - 2 > m_lo) m_lo = mk - 2;
+    }
+    const uint32_t m_hi = k - (MZ_WMIN - 1);
+    if (m_lo > m_hi) m_lo = m_hi;
+    const double wcost[9] = {0, 0, 0, 35.0, 19.5, 10.5, 3.5, 0.5, 0.0};  // percent, by window
+    uint32_t best = m_lo;
+    double best_cost = 1e30;
+    for (uint32_t m = m_lo; m <= m_hi; ++m) {
+        const double r = (m >= 31 ? 4.6e18 : (double)(1ull << (2 * m))) / leff;
+        const double c = wcost[k - m + 1] + 50.0 / r;
+        if (c < best_cost) {  // (ties: the wider window)
+            best_cost = c;
+            best = m;
+        }
+    }
+    return best;
 }
 
 // ---- hashing ------------------------------------------------------------------
