@@ -600,6 +600,14 @@ static uint32_t window_cap() {
     return cap;
 }
 
+extern "C" int pg_minimizer_length(int k, uint64_t expected_keys, uint64_t first_len, int wmax) {
+    PG_API_BEGIN
+    if (k < 1 || k > 32) return 0;
+    const uint32_t cap = wmax ? (uint32_t)std::min<int>((int)MZ_WMAX, std::max<int>((int)MZ_WMIN, wmax)) : window_cap();
+    return (int)minimizer_length((uint32_t)k, expected_keys, first_len, cap);
+    PG_API_END
+}
+
 static void settle_minimizer(pg_table *t, uint64_t positions) {
     if (t->m_pinned || t->first_len || positions == 0) return;
     for (auto &s : t->subs)

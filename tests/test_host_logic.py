@@ -382,3 +382,27 @@ def test_native_bins_tsv_equals_the_row_by_row_text(tmp_path):
             want.append("\t".join(map(str, [ci, r * info["binlen"]] + b[r].astype(np.int64).tolist())) + "\n")
     assert p.read_text() == "".join(want)
     assert len(so) == 5 and [x[3]["nbins"] for x in so] == nbins.tolist()
+
+
+def test_minimizer_length_rule():
+    """The minimizer length the library chooses (pg_minimizer_length: host arithmetic) at the shapes
+    it was measured on (profiles/r4b_m_sweep.txt): the window-cost / merged-groups balance, the floor of 15, the key
+    count's lower bound, the window cap, direct mode below k = 20."""
+    from panagram_amd import _lib
+    f = _lib.load().pg_minimizer_length
+    M = 1_000_000
+    for k, keys, first_len, wmax, want in [
+            (21, 0, 0, 8, 16), (31, 0, 0, 8, 24), (21, 0, 0, 4, 18), (31, 0, 0, 4, 28), (21, 0, 0, 6, 16), (31, 0, 0, 6, 26),
+            (21, 300 * M, 0, 8, 16), (21, 300 * M, 5900, 8, 15),            # a first sequence set far shorter than the estimate
+            (21, 232 * M, 100 * M, 8, 16), (21, 70 * M, 30 * M, 8, 15),     # 8 x 100 Mb / 8 x 30 Mb
+            (21, 783 * M, 135 * M, 8, 16), (21, 464 * M, 200 * M, 8, 16),   # config 3 / 8 x 200 Mb
+            (21, 1100 * M, 700 * M, 8, 16), (21, 3433 * M, 3000 * M, 8, 17),  # 4 x 700 Mb / 8 x 3 Gb
+            (21, 242 * M, 20 * M, 8, 15), (21, 2400 * M, 200 * M, 8, 16),   # 64 x 20 Mb / 64 x 200 Mb (the north-star shape)
+            (20, 232 * M, 100 * M, 8, 15), (22, 232 * M, 100 * M, 8, 16), (24, 232 * M, 100 * M, 8, 17),
+            (31, 1941 * M, 200 * M, 8, 24), (32, 1000, 1000, 8, 25), (19, 232 * M, 100 * M, 8, 0), (7, 0, 0, 8, 0)]:
+        assert f(k, keys, first_len, wmax) == want, (k, keys, first_len, wmax, f(k, keys, first_len, wmax), want)
+    for k in range(20, 33):  # whatever the sizes: a window of 3..8, m >= 15 where k allows it
+        for keys in (0, 10 ** 6, 10 ** 8, 10 ** 10):
+            for first_len in (0, 10 ** 4, 10 ** 8, 3 * 10 ** 9):
+                m = f(k, keys, first_len, 8)
+                assert 3 <= k - m + 1 <= 8 and m >= min(15, k - 2), (k, keys, first_len, m)
