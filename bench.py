@@ -717,7 +717,7 @@ def main():
                     help="keep the table as created from the expected key count (a re-hash holds the table twice in HBM)")
     ap.add_argument("--per-genome-launches", action="store_true",
                     help="one launch per anchor genome instead of one co-scheduled launch over all of them")
-    ap.add_argument("--piece-tiles", type=int, default=0, help="co-scheduling granularity in 512-position tiles (0: library default)")
+    ap.add_argument("--piece-tiles", type=int, default=0, help="co-scheduling granularity in tiles of 1024 positions (0: library default, 64 down to 8 by genome count)")
     ap.add_argument("--no-compare", action="store_true", help="skip the untimed one-launch-per-genome comparison run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-shapes", action="store_true", help="skip the north-star-shape leg (64 x 200 Mb, k=21)")

@@ -2017,7 +2017,11 @@ static int coschedule(pg_result *r, const uint32_t *contig_group, uint32_t piece
     r->chunks.clear();
     r->chunks_ready = false;  // (launch order again until a schedule is set below: chunks are cut at the next run)
     if (!contig_group || r->ntiles == 0) return PG_OK;  // NULL: back to launch order
-    if (piece_tiles == 0) piece_tiles = 64;
+    // Default piece: 64 tiles for up to 32 genomes; 512 / genomes beyond, never under 8.  With 64-tile pieces a locus of 64
+    // genomes spanned 4096 tiles of the launch order — half the waves the device holds at once — and the later genomes
+    // found fewer of its lines in L2: 64 x 40 Mb 14.5 -> 13.6 ms, 128 x 10 Mb 11.2 -> 10.8, 40 x 30 Mb 7.54 -> 7.37; 8 to 27
+    // genomes are best at 64 or indifferent (16 x 60 Mb: 4.35 ms at 64, 4.42 at 16, 4.47 at 8; profiles/r4b_piece_sweep.txt).
+    const bool auto_piece = piece_tiles == 0;
     const size_t nc = r->ad.size();
     // contig ranges scheduled independently of each other (default: one range = the whole result)
     std::vector<uint32_t> firsts;
@@ -2064,6 +2068,7 @@ static int coschedule(pg_result *r, const uint32_t *contig_group, uint32_t piece
             const uint32_t nt = (uint32_t)(((uint64_t)r->ad[c].nkmers + PROBE_TILE - 1) / PROBE_TILE);
             for (uint32_t i = 0; i < nt; ++i) tiles[contig_group[c]].push_back(r->ad[c].tile0 + i);
         }
+        if (auto_piece) piece_tiles = ngroups <= 32 ? 64u : std::max(8u, 512u / ngroups);
         std::vector<Piece> pieces;
         for (uint32_t g = 0; g < ngroups; ++g) {
             const size_t np = (tiles[g].size() + piece_tiles - 1) / piece_tiles;
