@@ -1593,8 +1593,23 @@ __device__ __forceinline__ EpiRange epi_range(uint32_t gt, uint32_t ntiles, cons
     return e;
 }
 
+// (one-byte rows: held to the registers of 7 waves per SIMD — 72 VGPRs and 20 bytes of scratch on a cold path instead of 79,
+// 96 SGPRs instead of 106: 6 -> 7 workgroups per CU, the pass 0.362 -> 0.353 ms on 8 x 10^8 rows, 0.616 -> 0.588 on
+// 1.6 x 10^9; 8 waves (64 VGPRs, 40 bytes of scratch) are slower, 0.392; profiles/r4b_ab_epilogue_waves.txt)
+#ifndef PG_EPI_WAVES0
+#define PG_EPI_WAVES0 7
+#endif
+// (rows of 2 to 5 bytes: 6 waves per SIMD instead of the 4-5 their 96-106 VGPRs allowed — 12 x 60 Mb 0.578 -> 0.509 ms,
+// 20 x 40 Mb 0.647 -> 0.57, 27 x 40 Mb and 40 x 30 Mb 2-6 %; 8-byte rows lose with it, 1.95 -> 2.1-2.3 ms, and stay as they were)
+#ifndef PG_EPI_WAVES1
+#define PG_EPI_WAVES1 6
+#endif
+#ifndef PG_EPI_SGPRS0
+#define PG_EPI_SGPRS0 96
+#endif
 template <int MODE, int NBT>  // NBT = bytes per row (1..8): one instantiation, and one register allocation, per width
-__global__ __launch_bounds__(EPI_THREADS) void k_epilogue(uint32_t N, const AnchorDesc *__restrict__ ad,
+__global__ __launch_bounds__(EPI_THREADS, (MODE == 0 ? PG_EPI_WAVES0 : NBT <= 5 ? PG_EPI_WAVES1 : 1))
+__attribute__((amdgpu_num_sgpr(PG_EPI_SGPRS0))) void k_epilogue(uint32_t N, const AnchorDesc *__restrict__ ad,
                                                           const uint32_t *__restrict__ tile_contig, uint32_t ntiles,
                                                           const uint8_t *__restrict__ out1, uint8_t *__restrict__ out100,
                                                           uint32_t *__restrict__ bins,
@@ -2244,6 +2259,8 @@ __global__ __launch_bounds__(EPI_THREADS) void k_epilogue(uint32_t N, const Anch
 //                       flush), byte-sliced accumulators, LDS atomics every 252 rows, per contig to global
 // EXACT: nbytes == 16 C (N a multiple of 128): aligned loads, no tail mask.
 // ---------------------------------------------------------------------------
+// (held to the registers of 5 or 6 waves per SIMD this kernel spills in its row loop: 65-128 genomes 2.7-5.5 -> 5.0-13.9 ms,
+// profiles/r4b_ab_epilogue_waves.txt; it runs 3-4 waves on 112-157 VGPRs)
 template <int C_T, bool EXACT>  // chunks per row known at compile time (1..4), or 0: any
 __global__ __launch_bounds__(EPI_THREADS) void k_epilogue_chunks(uint32_t N, const AnchorDesc *__restrict__ ad,
                                                                  const uint32_t *__restrict__ tile_contig, uint32_t ntiles,
