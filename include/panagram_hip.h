@@ -174,9 +174,9 @@ int pg_table_minimizer(const pg_table *tbl);
 int pg_table_set_minimizer(pg_table *tbl, int m);
 /* the minimizer length the library would choose (pure host arithmetic, no device needed): k, the expected key count
  * (0: unknown), the k-mer positions of the first sequence set (0: unknown), the widest window allowed (3..8; 0: the
- * PG_TABLE_WMAX / default cap).  What it encodes — window cost against merged minimizer groups — is measured in
+ * PG_TABLE_WMAX / default cap), the genome count (0: unknown; more than 64 = the split layout).  What it encodes — window cost against merged minimizer groups — is measured in
  * profiles/r4b_m_sweep.txt; no reference counterpart (KMC's own signature length is fixed at 9, kmc_file.h). */
-int pg_minimizer_length(int k, uint64_t expected_keys, uint64_t first_len, int wmax);
+int pg_minimizer_length(int k, uint64_t expected_keys, uint64_t first_len, int wmax, int ngenomes);
 
 /* ---- sequences: 2-bit packed contigs resident in HBM -------------------
  * Reference: the FASTA record strings handed to write_bits / _write_bitmap

@@ -66,7 +66,7 @@ PROTOTYPES = {
     "pg_table_ngenomes": (C.c_int, [_vp]),
     "pg_table_minimizer": (C.c_int, [_vp]),
     "pg_table_set_minimizer": (C.c_int, [_vp, C.c_int]),
-    "pg_minimizer_length": (C.c_int, [C.c_int, C.c_uint64, C.c_uint64, C.c_int]),
+    "pg_minimizer_length": (C.c_int, [C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_int]),
     "pg_seqset_create": (C.c_int, [_vp, C.c_uint32, _vp, _vpp]),
     "pg_seqset_destroy": (C.c_int, [_vp]),
     "pg_seqset_load_host": (C.c_int, [_vp, C.c_uint32, _vp, C.c_uint64]),

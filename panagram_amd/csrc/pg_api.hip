@@ -486,7 +486,7 @@ extern "C" int pg_table_create(pg_ctx *ctx, int k, int ngenomes, uint64_t expect
     t->k = k;
     t->ngenomes = ngenomes;
     t->ndbs = ndbs;
-    t->m = minimizer_length((uint32_t)k, expected_keys, 0, window_cap());
+    t->m = minimizer_length((uint32_t)k, expected_keys, 0, window_cap(), (uint32_t)ngenomes);
     t->expected = expected_keys;
     t->d_counters = nullptr;
     hipError_t e = hipMalloc(reinterpret_cast<void **>(&t->d_counters), 2 * sizeof(unsigned long long));
@@ -600,11 +600,11 @@ static uint32_t window_cap() {
     return cap;
 }
 
-extern "C" int pg_minimizer_length(int k, uint64_t expected_keys, uint64_t first_len, int wmax) {
+extern "C" int pg_minimizer_length(int k, uint64_t expected_keys, uint64_t first_len, int wmax, int ngenomes) {
     PG_API_BEGIN
     if (k < 1 || k > 32) return 0;
     const uint32_t cap = wmax ? (uint32_t)std::min<int>((int)MZ_WMAX, std::max<int>((int)MZ_WMIN, wmax)) : window_cap();
-    return (int)minimizer_length((uint32_t)k, expected_keys, first_len, cap);
+    return (int)minimizer_length((uint32_t)k, expected_keys, first_len, cap, (uint32_t)std::max(0, ngenomes));
     PG_API_END
 }
 
@@ -613,7 +613,7 @@ static void settle_minimizer(pg_table *t, uint64_t positions) {
     for (auto &s : t->subs)
         if (s.count) return;
     t->first_len = positions;
-    t->m = minimizer_length((uint32_t)t->k, t->expected, positions, window_cap());
+    t->m = minimizer_length((uint32_t)t->k, t->expected, positions, window_cap(), (uint32_t)t->ngenomes);
     for (auto &s : t->subs) s.d.m = t->m;
 }
 
@@ -1127,7 +1127,7 @@ extern "C" int pg_table_rehash(pg_table *t, double keys_per_bucket) {
     if (!t->m_pinned) {  // the key count is known now: settle the minimizer length for it
         uint64_t most = 0;
         for (auto &s : t->subs) most = std::max<uint64_t>(most, s.count);
-        t->m = minimizer_length((uint32_t)t->k, most, t->max_len, window_cap());
+        t->m = minimizer_length((uint32_t)t->k, most, t->max_len, window_cap(), (uint32_t)t->ngenomes);
     }
     // Line width: 128-byte lines of 8 slots.  256-byte lines of 16 slots (PG_TABLE_SLOTS=16, a tuning
     // knob) keep a many-variant locus in ONE place at the price of two requests per line; measured,

@@ -400,9 +400,11 @@ def test_minimizer_length_rule():
             (21, 242 * M, 20 * M, 8, 15), (21, 2400 * M, 200 * M, 8, 16),   # 64 x 20 Mb / 64 x 200 Mb (the north-star shape)
             (20, 232 * M, 100 * M, 8, 15), (22, 232 * M, 100 * M, 8, 16), (24, 232 * M, 100 * M, 8, 17),
             (31, 1941 * M, 200 * M, 8, 24), (32, 1000, 1000, 8, 25), (19, 232 * M, 100 * M, 8, 0), (7, 0, 0, 8, 0)]:
-        assert f(k, keys, first_len, wmax) == want, (k, keys, first_len, wmax, f(k, keys, first_len, wmax), want)
+        assert f(k, keys, first_len, wmax, 8) == want, (k, keys, first_len, wmax, f(k, keys, first_len, wmax, 8), want)
+    # more than 64 genomes (split layout: 16 keys per line): merged groups cost half as much
+    assert f(21, 1000 * M, 40 * M, 8, 128) == 15 and f(21, 1000 * M, 40 * M, 8, 64) == 16 and f(21, 300 * M, 10 * M, 8, 128) == 15
     for k in range(20, 33):  # whatever the sizes: a window of 3..8, m >= 15 where k allows it
         for keys in (0, 10 ** 6, 10 ** 8, 10 ** 10):
             for first_len in (0, 10 ** 4, 10 ** 8, 3 * 10 ** 9):
-                m = f(k, keys, first_len, 8)
+                m = f(k, keys, first_len, 8, 0)
                 assert 3 <= k - m + 1 <= 8 and m >= min(15, k - 2), (k, keys, first_len, m)
