@@ -430,6 +430,17 @@ __device__ __forceinline__ uint32_t sliding_min(uint32_t x) {
 #ifndef PG_PROBE_CARRY
 #define PG_PROBE_CARRY 1
 #endif
+// -DPG_PRIO=0xABCD: wave priorities (s_setprio) by phase of a batch, an experiment — A from the wait for the batch's lines on
+// (staging), B around the issue of the next fetch, C for slot scan / overflow entries / row store, D for the front end of
+// the batch after next; 0 = no s_setprio at all (the product; profiles/r4e_ab_setprio.txt)
+#ifndef PG_PRIO
+#define PG_PRIO 0
+#endif
+#if PG_PRIO
+#define PG_PRIO_AT(i) __builtin_amdgcn_s_setprio((PG_PRIO >> (4 * (4 - (i)))) & 3);
+#else
+#define PG_PRIO_AT(i)
+#endif
 #ifndef PG_PROBE_CUT
 #define PG_PROBE_CUT 1
 #endif
@@ -927,11 +938,14 @@ __attribute__((amdgpu_num_sgpr(80))) void k_probe(const SubTable st, const uint6
         // paths meet, and the first instruction that re-uses one of their registers — an address of the NEXT fetch,
         // issued right behind this batch's row store — gets a vmcnt(0) that waits for that store to be acknowledged.
         PG_PH(1)
+        PG_PRIO_AT(1)
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), nothing else
         PG_PH(2)
         if (f.nruns) stage(L);
         PG_PH(3)
+        PG_PRIO_AT(2)
         after_staging();  // (the chunks' registers are free from here on: the skewed order starts the NEXT batch's fetch now)
+        PG_PRIO_AT(3)
         PG_PH(4)
         if (f.nruns) scan(0u);
         PG_PH(5)
@@ -1010,6 +1024,7 @@ __attribute__((amdgpu_num_sgpr(80))) void k_probe(const SubTable st, const uint6
                 store_row<ROWMODE>(tile_rows + (ROWMODE == 1 ? (uint32_t)pl : ROWMODE == 4 ? (uint32_t)pl * 4u : ROWMODE == 5 ? (uint32_t)pl * 2u : ROWMODE == 6 ? (uint32_t)pl * 3u : (uint32_t)pl * nbytes), m0, m1, rc);
         }
         PG_PH(6)
+        PG_PRIO_AT(4)
     };
     // The skewed order — front end of batch i + 1 between the fetch of batch i and its use — keeps the fetched chunks
     // and two batches' keys in registers at once: it pays where that still fits 64 registers (8 waves per SIMD: this

@@ -8,6 +8,13 @@ submodule; used at ``panagram/index.py:849-860,934-935``), backed by the GPU tab
 
 Same names, argument meaning and (bool) return convention; one deliberate difference: an
 ill-formed database raises instead of silently answering zeros.
+
+What this seam costs: it keeps the reference's data flow — the sequence goes up as text and ONE
+u32 PER POSITION AND DATABASE comes back to the host (``GetCountersForRead``'s contract), i.e.
+4 bytes per position over PCIe around about a millisecond of kernels per 10^8 positions: 6-16 G
+k-mers/s by box against 200 G for ``Index.run()`` / ``run_anchor``, which keep the
+rows in HBM until they leave as BGZF blocks.  It exists for parity tests and for callers that
+cannot change; the fast path is the one INTEGRATION.md patches in.
 """
 from __future__ import annotations
 
