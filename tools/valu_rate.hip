@@ -13,6 +13,7 @@
         uint32_t r0 = seed + threadIdx.x, r1 = r0 * 3, r2 = r0 * 5, r3 = r0 * 7, r4 = r0 * 9,   \
                  r5 = r0 * 11, r6 = r0 * 13, r7 = r0 * 15;                                      \
         uint64_t mask = 0x5555555555555555ull ^ seed;                                            \
+        uint32_t x0 = r0 + 1, x1 = r0 + 2, x2 = r0 + 3, x3 = r0 + 4, x4 = r0 + 5, x5 = r0 + 6, x6 = r0 + 7, x7 = r0 + 8; \
         uint64_t q0 = r0, q1 = r1, q2 = r2, q3 = r3, q4 = r4, q5 = r5, q6 = r6, q7 = r7;        \
         for (int i = 0; i < iters; ++i) {                                                       \
             ASM1(0) ASM1(1) ASM1(2) ASM1(3) ASM1(4) ASM1(5) ASM1(6) ASM1(7)                     \
@@ -21,7 +22,7 @@
             ASM1(0) ASM1(1) ASM1(2) ASM1(3) ASM1(4) ASM1(5) ASM1(6) ASM1(7)                     \
         }                                                                                       \
         out[blockIdx.x * blockDim.x + threadIdx.x] = r0 ^ r1 ^ r2 ^ r3 ^ r4 ^ r5 ^ r6 ^ r7 ^     \
-            (uint32_t)(q0 ^ q1 ^ q2 ^ q3 ^ q4 ^ q5 ^ q6 ^ q7 ^ mask);                                   \
+            (uint32_t)(q0 ^ q1 ^ q2 ^ q3 ^ q4 ^ q5 ^ q6 ^ q7 ^ mask) ^ x0 ^ x1 ^ x2 ^ x3 ^ x4 ^ x5 ^ x6 ^ x7;                                   \
     }
 
 #define A_ADD(n) asm volatile("v_add_u32 %0, %0, %1" : "+v"(r##n) : "v"(seed));
@@ -46,6 +47,10 @@
 #define A_CMPCND(n) asm volatile("v_cmp_ne_u32 vcc, %0, %1\n s_nop 1\n v_cndmask_b32 %0, %0, %1, vcc" : "+v"(r##n) : "v"(seed) : "vcc");
 #define A_CMPCNDS(n) asm volatile("v_cmp_ne_u32 %1, %0, %2\n s_nop 1\n v_cndmask_b32_e64 %0, %0, %2, %1" : "+v"(r##n), "+s"(mask) : "v"(seed));
 #define A_CMP64CND(n) asm volatile("v_cmp_ne_u64 vcc, %1, %2\n s_nop 1\n v_cndmask_b32 %0, %0, %3, vcc" : "+v"(r##n) : "v"(q##n), "v"(q0), "v"(seed) : "vcc");
+#define A_CMPCND2(n) asm volatile("v_cmp_ne_u32 vcc, %0, %1\n s_nop 1\n v_cndmask_b32 %0, %0, %1, vcc\n v_cndmask_b32 %2, %2, %1, vcc" : "+v"(r##n), "+v"(seed) , "+v"(x##n): : "vcc");
+#define A_CMPCND2S(n) asm volatile("v_cmp_ne_u32 %1, %0, %2\n s_nop 1\n v_cndmask_b32_e64 %0, %0, %2, %1\n v_cndmask_b32_e64 %3, %3, %2, %1" : "+v"(r##n), "+s"(mask), "+v"(seed), "+v"(x##n));
+#define A_CND64VCC(n) asm volatile("v_cndmask_b32_e64 %0, %0, %1, vcc" : "+v"(r##n) : "v"(seed));
+#define A_CMP64CND2(n) asm volatile("v_cmp_gt_u64 vcc, %1, %2\n s_nop 1\n v_cndmask_b32 %0, %0, %3, vcc\n v_cndmask_b32 %4, %4, %3, vcc" : "+v"(r##n) : "v"(q##n), "v"(q0), "v"(seed), "v"(x##n) : "vcc");
 #define A_MAD64(n) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(q##n) : "v"(r##n), "v"(seed) : "vcc");
 #define A_MBCNT(n) asm volatile("v_mbcnt_lo_u32_b32 %0, %1, %0" : "+v"(r##n) : "v"(seed));
 #define A_MOV64(n) asm volatile("v_mov_b64 %0, %1" : "=v"(q##n) : "v"(q0));
@@ -76,6 +81,7 @@ KERNEL(k_mov64, A_MOV64) KERNEL(k_pkadd, A_PKADD) KERNEL(k_andor, A_AND_OR) KERN
 KERNEL(k_mindpp, A_MINDPP) KERNEL(k_mindpprow, A_MINDPPROW) KERNEL(k_cmp64s, A_CMP64S) KERNEL(k_cmp32s, A_CMP32S) KERNEL(k_not, A_NOT)
 KERNEL(k_lshl, A_LSHL) KERNEL(k_lshladd, A_LSHLADD) KERNEL(k_add3, A_ADD3) KERNEL(k_or3, A_OR3) KERNEL(k_and, A_AND) KERNEL(k_bfe, A_BFE)
 KERNEL(k_lshladd64, A_LSHLADD64) KERNEL(k_shl64, A_SHL64)
+KERNEL(k_cmpcnd2, A_CMPCND2) KERNEL(k_cmpcnd2s, A_CMPCND2S) KERNEL(k_cnd64vcc, A_CND64VCC) KERNEL(k_cmp64cnd2, A_CMP64CND2)
 KERNEL(k_bcnt, A_BCNT) KERNEL(k_cndm2, A_CNDM2) KERNEL(k_cndms, A_CNDMS) KERNEL(k_cmpcnd, A_CMPCND) KERNEL(k_cmpcnds, A_CMPCNDS) KERNEL(k_cmp64cnd, A_CMP64CND)
 
 template <typename K>
@@ -111,5 +117,7 @@ int main() {
     RUN(k_mov64) RUN(k_pkadd) RUN(k_andor) RUN(k_xad) RUN(k_perm) RUN(k_bcnt)
     RUN(k_mindpp) RUN(k_mindpprow) RUN(k_cmp64s) RUN(k_cmp32s) RUN(k_not) RUN(k_lshl) RUN(k_lshladd) RUN(k_add3) RUN(k_or3) RUN(k_and)
     RUN(k_bfe) RUN(k_lshladd64) RUN(k_shl64)
+    // (several instructions per asm statement: divide by their number)
+    RUN(k_cmpcnd2) RUN(k_cmpcnd2s) RUN(k_cnd64vcc) RUN(k_cmp64cnd2)
     return 0;
 }
