@@ -2270,14 +2270,19 @@ __attribute__((amdgpu_num_sgpr(PG_EPI_SGPRS0))) void k_epilogue(uint32_t N, cons
 // instructions per word, 2.8 wave-instructions per 16-byte row, issue-bound at 2.7 TB/s.)
 //   popcount of a row   4 v_bcnt per lane, C - 1 shuffles to the row's first lane, one LDS atomic
 //   bitmap.100          each lane copies its chunk of the 1-in-100 rows
-//   column sums         carry-save vertical counters per word (4 rows at a time, 12 rows per
-//                       flush), byte-sliced accumulators, LDS atomics every 252 rows, per contig to global
+//   column sums         carry-save vertical counters per word: eight bit planes behind a Harley-Seal
+//                       tree (4 rows at a time), LDS atomics every 240 rows, per contig to global
 // EXACT: nbytes == 16 C (N a multiple of 128): aligned loads, no tail mask.
 // ---------------------------------------------------------------------------
-// (held to the registers of 5 or 6 waves per SIMD this kernel spills in its row loop: 65-128 genomes 2.7-5.5 -> 5.0-13.9 ms,
-// profiles/r4b_ab_epilogue_waves.txt; it runs 3-4 waves on 112-157 VGPRs)
+// (it runs 3-4 waves per SIMD on 104-149 VGPRs; round 4's first attempt to hold it to 5 or 6: 65-128 genomes 2.7-5.5 -> 5.0-13.9 ms,
+// profiles/r4b_ab_epilogue_waves.txt)
 template <int C_T, bool EXACT>  // chunks per row known at compile time (1..4), or 0: any
-__global__ __launch_bounds__(EPI_THREADS) void k_epilogue_chunks(uint32_t N, const AnchorDesc *__restrict__ ad,
+// (held to the registers of 5 waves per SIMD — 96 — it still spills in the row loop: 65-128 genomes 2.67-5.23 -> 3.04-5.55 ms,
+// profiles/r4e_ab_stats_harley_seal.txt)
+#ifndef PG_EPI_WAVESC
+#define PG_EPI_WAVESC 1
+#endif
+__global__ __launch_bounds__(EPI_THREADS, PG_EPI_WAVESC) void k_epilogue_chunks(uint32_t N, const AnchorDesc *__restrict__ ad,
                                                                  const uint32_t *__restrict__ tile_contig, uint32_t ntiles,
                                                                  const uint8_t *__restrict__ out1, uint8_t *__restrict__ out100,
                                                                  uint32_t *__restrict__ bins,
@@ -2316,64 +2321,78 @@ __global__ __launch_bounds__(EPI_THREADS) void k_epilogue_chunks(uint32_t N, con
     AnchorDesc a;
     a.out_off = a.out100_off = a.bin_off = 0;
     a.nkmers = a.binlen = a.tile0 = a.nbins = 0;
-    uint32_t vp[4][4], bacc[4][8];
+    // Column sums: per lane and word EIGHT bit planes of vertical counters (bit g of plane p = bit p of the number of rows seen
+    // with genome g set: up to 255 rows between flushes) fed through a Harley-Seal carry-save tree — four rows enter the
+    // ones / twos planes per iteration (9 instructions), their carry of weight 4 is held back every other iteration and
+    // enters the fours plane together with the next one (3), likewise the eights (3 per 8 rows), and only every 16 rows a
+    // carry ripples through the four upper planes (8): 3.3 instructions per row and word.  (Rounds 2-4 kept four planes,
+    // emptied every 12 rows into byte-sliced accumulators — 64 instructions per word — and those every 252 rows into LDS:
+    // 8.3 per row and word, a third of this pass's instructions, and 48 registers where this takes 40.)
+    uint32_t vp[4][8], pf[4], pe[4];
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) vp[w][q] = 0;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) bacc[w][q] = 0;
+        for (int q = 0; q < 8; ++q) vp[w][q] = 0;
+        pf[w] = pe[w] = 0;
     }
-    uint32_t vrows = 0, brounds = 0;
-    auto vadd4 = [&](uint32_t (&p)[4], uint32_t r0, uint32_t r1, uint32_t r2, uint32_t r3) {
+    uint32_t vrows = 0;  // rows in the planes (block-uniform, a multiple of 4): the carries held back follow from it
+    // add a word of carries of weight 2^q0 to the planes q0 .. 7 (no carry leaves plane 7: fewer than 256 rows)
+    auto ripple = [&](uint32_t (&p)[8], uint32_t cw, int q0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (q >= q0) {
+                const uint32_t n = p[q] & cw;
+                p[q] ^= cw;
+                cw = n;
+            }
+    };
+    auto vadd4 = [&](int w, uint32_t r0, uint32_t r1, uint32_t r2, uint32_t r3, bool odd4, bool odd8) __attribute__((always_inline)) {
+        uint32_t (&p)[8] = vp[w];
         const uint32_t x = p[0];
-        const uint32_t t1 = x ^ r0, s1 = t1 ^ r1, ca = (t1 & r1) | (~t1 & x);
-        const uint32_t t2 = s1 ^ r2, s2 = t2 ^ r3, cb = (t2 & r3) | (~t2 & s1);
+        const uint32_t t1 = x ^ r0, s1 = t1 ^ r1, ca = (t1 & r1) | (~t1 & x);      // x + r0 + r1
+        const uint32_t t2 = s1 ^ r2, s2 = t2 ^ r3, cb = (t2 & r3) | (~t2 & s1);    // .. + r2 + r3
         p[0] = s2;
         const uint32_t y = p[1];
-        const uint32_t t3 = y ^ ca, cc = (t3 & cb) | (~t3 & y);
+        const uint32_t t3 = y ^ ca, cc = (t3 & cb) | (~t3 & y);                     // twos + ca + cb -> a carry of weight 4
         p[1] = t3 ^ cb;
-        const uint32_t c4 = p[2] & cc;
-        p[2] ^= cc;
-        p[3] ^= c4;
+        if (!odd4) {  // (block-uniform) held back: the next four rows' carry joins it
+            pf[w] = cc;
+            return;
+        }
+        const uint32_t z = p[2], t4 = z ^ pf[w], c8 = (t4 & cc) | (~t4 & z);       // fours + both carries -> weight 8
+        p[2] = t4 ^ cc;
+        if (!odd8) {
+            pe[w] = c8;
+            return;
+        }
+        const uint32_t u = p[3], t5 = u ^ pe[w], c16 = (t5 & c8) | (~t5 & u);      // eights + both carries -> weight 16
+        p[3] = t5 ^ c8;
+        ripple(p, c16, 4);
     };
-    auto bflush = [&]() __attribute__((always_inline)) {  // byte-sliced accumulators -> the workgroup's LDS counters of this lane's words
+    auto vflush = [&]() __attribute__((always_inline)) {  // planes -> the workgroup's LDS counters of this lane's words
+        const bool odd4 = (vrows & 4u) != 0, odd8 = (vrows & 8u) != 0;  // carries still held back (a flush between whole 16-row blocks)
 #pragma unroll
-        for (int w = 0; w < 4; ++w)  // (static register indices: a rolled loop would put bacc in scratch)
+        for (int w = 0; w < 4; ++w) {
+            if (odd4) ripple(vp[w], pf[w], 2);
+            if (odd8) ripple(vp[w], pe[w], 3);
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const uint32_t v = bacc[w][q];
+            for (int j = 0; j < 8; ++j) {  // bits j, 8 + j, 16 + j, 24 + j of the word: their four counts as the bytes of v
+                uint32_t v = 0;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v |= ((vp[w][q] >> j) & 0x01010101u) << q;
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
                     const uint32_t cnt = (v >> (8 * b)) & 255u;
-                    if (cnt) atomicAdd(&cs_mine[32 * w + 8 * b + q], cnt);
+                    if (cnt) atomicAdd(&cs_mine[32 * w + 8 * b + j], cnt);
                 }
             }
 #pragma unroll
-        for (int w = 0; w < 4; ++w)
-#pragma unroll
-            for (int q = 0; q < 8; ++q) bacc[w][q] = 0;
-        brounds = 0;
-    };
-    auto vflush = [&]() __attribute__((always_inline)) {
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint32_t M = 0x11111111u;
-                const uint32_t nib = ((vp[w][0] >> j) & M) | (((vp[w][1] >> j) & M) << 1) | (((vp[w][2] >> j) & M) << 2) |
-                                     (((vp[w][3] >> j) & M) << 3);
-                bacc[w][j] += nib & 0x0F0F0F0Fu;
-                bacc[w][4 + j] += (nib >> 4) & 0x0F0F0F0Fu;
-            }
-            vp[w][0] = vp[w][1] = vp[w][2] = vp[w][3] = 0;
+            for (int q = 0; q < 8; ++q) vp[w][q] = 0;
         }
         vrows = 0;
-        ++brounds;
     };
     auto flush_colsums = [&](uint32_t contig) __attribute__((always_inline)) {
         if (vrows) vflush();
-        if (brounds) bflush();
         __syncthreads();
         for (uint32_t i = tid; i < N; i += EPI_THREADS) {
             uint32_t v = 0;
@@ -2502,15 +2521,13 @@ __global__ __launch_bounds__(EPI_THREADS) void k_epilogue_chunks(uint32_t N, con
                 }
             }
             if (want_cs) {  // rows beyond npos are zero: adding them is harmless
-                vadd4(vp[0], v[0].x, v[1].x, v[2].x, v[3].x);
-                vadd4(vp[1], v[0].y, v[1].y, v[2].y, v[3].y);
-                vadd4(vp[2], v[0].z, v[1].z, v[2].z, v[3].z);
-                vadd4(vp[3], v[0].w, v[1].w, v[2].w, v[3].w);
+                const bool odd4 = (vrows & 4u) != 0, odd8 = (vrows & 8u) != 0;
+                vadd4(0, v[0].x, v[1].x, v[2].x, v[3].x, odd4, odd8);
+                vadd4(1, v[0].y, v[1].y, v[2].y, v[3].y, odd4, odd8);
+                vadd4(2, v[0].z, v[1].z, v[2].z, v[3].z, odd4, odd8);
+                vadd4(3, v[0].w, v[1].w, v[2].w, v[3].w, odd4, odd8);
                 vrows += 4;
-                if (vrows == 12) {  // (the 4 planes count to 15)
-                    vflush();
-                    if (brounds == 21) bflush();  // 21 x 12 rows: the byte counters are about to fill
-                }
+                if (vrows == 240) vflush();  // (the 8 planes count to 255)
             }
         }
 #pragma unroll
