@@ -2279,6 +2279,9 @@ __attribute__((amdgpu_num_sgpr(PG_EPI_SGPRS0))) void k_epilogue(uint32_t N, cons
 template <int C_T, bool EXACT>  // chunks per row known at compile time (1..4), or 0: any
 // (held to the registers of 5 waves per SIMD — 96 — it still spills in the row loop: 65-128 genomes 2.67-5.23 -> 3.04-5.55 ms,
 // profiles/r4e_ab_stats_harley_seal.txt)
+#ifndef PG_EPI_REPLC
+#define PG_EPI_REPLC 1  // k_epilogue_chunks: the histogram of a tile inside one or two long bins in 8 (4) copies
+#endif
 #ifndef PG_EPI_WAVESC
 #define PG_EPI_WAVESC 1
 #endif
@@ -2448,6 +2451,34 @@ __global__ __launch_bounds__(EPI_THREADS, PG_EPI_WAVESC) void k_epilogue_chunks(
     // per-tile state (block-uniform), set when an iteration starts a tile
     uint32_t tile_start = 0, npos = 0, binlen = 1, bin0 = 0, bin0_start = 0, binv = 0, rel_base = 0;
     bool big = false, windowed = false;
+    // One LDS counter per row and (bin, class): the lanes of a wave mostly ask for the same few — on a real pangenome most rows
+    // carry ALL genomes — and the LDS works lanes that add to one word off one after the other (SQ_LDS_BANK_CONFLICT was 94 %
+    // of this pass's LDS cycles, a wave waited for the LDS 28 % of its time; d = 0.0001: +15 % on the whole pass).  While the
+    // tiles lie inside one or two long bins (any contig of more than 100 tiles) the window is therefore used as repl_n COPIES of
+    // those two bin rows, row-lane l / C adding to copy (l / C) % repl_n (copy c at c * repl_stride, an odd stride: the copies
+    // of one class sit in different banks) — k_epilogue's scheme for rows of 2..8 bytes; `unreplicate` folds the copies into
+    // the window's ordinary form, rows 0 and 1, before anything else reads or flushes it.  `repl` is block-uniform.
+    // Measured (profiles/r4e_ab_stats_hist_copies_wide.txt): core-heavy rows (d = 0.0001) 65 genomes 2.95 -> 2.73 ms, 128 genomes
+    // 6.44 -> 5.29 (89.9 -> 98.8 G k-mers/s for the step); the bench's d = 0.01 +1 %.  Rows of two or three chunks (more than
+    // 128 genomes: only every second or third lane adds) LOSE 3-6 % with it at either divergence and keep the plain window.
+    const uint32_t repl_stride = (2u * (N + 1u)) | 1u;
+    const uint32_t repl_n = 8u * repl_stride <= MAXB * (N + 1u) ? 8u : 4u;  // (MAXB >= 16: four copies always fit)
+    const uint32_t repl_off = (((uint32_t)lane / C) % repl_n) * repl_stride;
+    bool repl = false;
+    auto unreplicate = [&]() __attribute__((always_inline)) {
+        if (!repl) return;
+        __syncthreads();
+        for (uint32_t i = tid; i < 2u * (N + 1u); i += EPI_THREADS) {
+            uint32_t hv = hist[i];
+            for (uint32_t cpy = 1; cpy < repl_n; ++cpy) {
+                hv += hist[cpy * repl_stride + i];
+                hist[cpy * repl_stride + i] = 0;
+            }
+            hist[i] = hv;
+        }
+        __syncthreads();
+        repl = false;
+    };
     for (uint32_t it = 0; it <= nit; ++it) {  // (one more round: the last contig's column sums, flushed at ONE site)
         const bool fin = it == nit;
         if (it + 1 < nit) issue(it + 1, vn);
@@ -2470,19 +2501,34 @@ __global__ __launch_bounds__(EPI_THREADS, PG_EPI_WAVESC) void k_epilogue_chunks(
             windowed = binlen >= MINBIN;
             const uint32_t last_rel = (tile_start + npos - 1 - bin0_start) / binlen;
             binv = big ? 0u : 0xFFFFFFFFu / binlen + 1u;
-            const bool fits = cur_row0 != ~0ull && (!windowed ? row0 == cur_row0 : (row0 >= cur_row0 && row0 + last_rel < cur_row0 + MAXB));
-            if (!fits) {
-                if (cur_row0 != ~0ull) {
-                    __syncthreads();
-                    flush_hist(N, hist, bins, cur_row0, tid, MAXB);
-                    __syncthreads();
+            if (PG_EPI_REPLC && big && C == 1u) {  // (block-uniform) the tile's one or two bins as copies
+                if (!(repl && row0 >= cur_row0 && row0 + last_rel < cur_row0 + 2u)) {
+                    if (cur_row0 != ~0ull) {
+                        const uint32_t held = repl ? 2u : MAXB;  // (as copies the window held two rows: nothing beyond them to look at)
+                        unreplicate();
+                        __syncthreads();
+                        flush_hist(N, hist, bins, cur_row0, tid, held);
+                        __syncthreads();
+                    }
+                    cur_row0 = row0;
+                    repl = true;
                 }
-                cur_row0 = row0;
+            } else {
+                unreplicate();
+                const bool fits = cur_row0 != ~0ull && (!windowed ? row0 == cur_row0 : (row0 >= cur_row0 && row0 + last_rel < cur_row0 + MAXB));
+                if (!fits) {
+                    if (cur_row0 != ~0ull) {
+                        __syncthreads();
+                        flush_hist(N, hist, bins, cur_row0, tid, MAXB);
+                        __syncthreads();
+                    }
+                    cur_row0 = row0;
+                }
             }
             rel_base = (uint32_t)(row0 - cur_row0);
         }
         if (r0 < npos) {  // (block-uniform)
-            uint32_t *hrow = hist + rel_base * (N + 1);
+            uint32_t *hrow = hist + rel_base * (N + 1) + (repl ? repl_off : 0u);
             const bool full = EXACT && C_T && (64 % (C_T ? C_T : 1) == 0) && r0 + iter_rows <= npos;  // (block-uniform) no row to mask
 #pragma unroll
             for (uint32_t j = 0; j < NJ; ++j) {
@@ -2533,6 +2579,7 @@ __global__ __launch_bounds__(EPI_THREADS, PG_EPI_WAVESC) void k_epilogue_chunks(
 #pragma unroll
         for (uint32_t j = 0; j < NJ; ++j) v[j] = vn[j];
     }
+    unreplicate();
     __syncthreads();
     if (cur_row0 != ~0ull) flush_hist(N, hist, bins, cur_row0, tid, MAXB);
 }

@@ -800,6 +800,48 @@ def test_one_byte_rows_long_contigs_against_oracle(ctx, n, k, lens):
     tbl.close()
 
 
+@pytest.mark.parametrize("n,k,lens", [(65, 21, [230_000, 9_000]), (128, 31, [150_000, 2_000]), (200, 21, [120_000]),
+                                      (257, 21, [110_000, 5_000])])
+def test_wide_rows_long_contigs_against_oracle(ctx, n, k, lens):
+    """more than 64 genomes on contigs whose bins are longer than a tile (nkmers / 100 = 1099 .. 2299 rows): the
+    chunk-parallel statistics pass then keeps the histogram of a tile's one or two bins in several LDS copies, folds them
+    when the window moves on (every second or third tile here) and goes back to the plain window on the short contig
+    behind.  One, two and three 16-byte chunks per row, exact and ragged.  Rows, bitmap.100, bins and per-contig column
+    sums against the oracle."""
+    from panagram_amd import engine
+    rng = np.random.default_rng(n * 1000 + k)
+    gen = po.synth_genomes(n, lens, 0.01, 57 + n)
+    genomes = [[bytearray(po.codes_to_ascii(c)) for c in g] for g in gen]
+    for g in (0, n // 2, n - 1):
+        for c in genomes[g]:
+            p, run = int(rng.integers(0, len(c) - 1500)), int(rng.integers(1, 1200))
+            c[p:p + run] = b"N" * run
+            q = int(rng.integers(0, len(c) - 500))
+            c[q:q + 400] = bytes(c[q:q + 400]).lower()
+    genomes = [[bytes(c) for c in g] for g in genomes]
+    dbs = po.build_bitvec_dbs(genomes, k)
+    tbl = engine.PanTable(ctx, k, n)
+    for g in range(n):
+        ss = engine.SeqSet.from_host(ctx, genomes[g])
+        tbl.insert_seqset(g, ss)
+        ss.close()
+    for g in {0, n - 1}:
+        ss = engine.SeqSet.from_host(ctx, genomes[g])
+        res = engine.AnchorResult(tbl, ss, colsums=True)
+        res.run()
+        ccs = res.contig_colsums().astype(np.int64)
+        for ci, seq in enumerate(genomes[g]):
+            rows, rows100, bins, info = res.download(ci)
+            o_rows, o_rows100, o_bins, _, o_cs = po.anchor_contig(dbs, seq, k, n)
+            assert np.array_equal(rows, o_rows)
+            assert np.array_equal(rows100, o_rows100)
+            assert np.array_equal(bins.astype(np.int64), o_bins), np.argwhere(bins.astype(np.int64) != o_bins)[:5]
+            assert np.array_equal(ccs[ci], o_cs)
+        res.close()
+        ss.close()
+    tbl.close()
+
+
 _FUZZ_N = [2, 8, 9, 16, 17, 24, 25, 32, 33, 40, 63, 64, 65, 72, 96, 97, 127, 128, 129, 160, 193, 256, 257, 300]
 
 
