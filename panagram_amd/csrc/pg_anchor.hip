@@ -1611,6 +1611,9 @@ __device__ __forceinline__ EpiRange epi_range(uint32_t gt, uint32_t ntiles, cons
 // (one-byte rows: held to the registers of 7 waves per SIMD — 72 VGPRs and 20 bytes of scratch on a cold path instead of 79,
 // 96 SGPRs instead of 106: 6 -> 7 workgroups per CU, the pass 0.362 -> 0.353 ms on 8 x 10^8 rows, 0.616 -> 0.588 on
 // 1.6 x 10^9; 8 waves (64 VGPRs, 40 bytes of scratch) are slower, 0.392; profiles/r4b_ab_epilogue_waves.txt)
+#ifndef PG_EPI_WAIT_HERE
+#define PG_EPI_WAIT_HERE 1  // k_epilogue, one-byte rows: see the group path's prefetch
+#endif
 #ifndef PG_EPI_WAVES0
 #define PG_EPI_WAVES0 7
 #endif
@@ -1878,6 +1881,13 @@ __attribute__((amdgpu_num_sgpr(PG_EPI_SGPRS0))) void k_epilogue(uint32_t N, cons
                 const uint4 z4 = make_uint4(0, 0, 0, 0);
                 const uint4 qa = gq_valid ? gq_next : (nv > 0u ? gg[0] : z4);
                 const uint4 qb = gq_valid ? gq_next2 : (nv > 16u ? gg[1] : z4);
+#if PG_EPI_WAIT_HERE
+                // This group's rows are waited for HERE, before the next group's loads go out.  Left to the compiler the wait sat
+                // at the rows' first use — BEHIND the prefetch — and, the paths above having merged, as vmcnt(0): it waited for
+                // the prefetch as well, so that a group's load latency and its arithmetic ran one after the other (0.35 ms for
+                // 8 x 10^8 rows where a kernel of the same geometry that only loads and counts takes 0.19).
+                __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), nothing else
+#endif
                 // prefetch the next group when this one is whole and a whole group follows right behind
                 const uint32_t tiles_here = (grows_n + PROBE_TILE - 1) / PROBE_TILE;
                 gq_valid = grows_n == span && rows_at(tile + 8, ts + span) == span && group_kind(ts + span, span) != 0;
