@@ -1611,6 +1611,9 @@ __device__ __forceinline__ EpiRange epi_range(uint32_t gt, uint32_t ntiles, cons
 // (one-byte rows: held to the registers of 7 waves per SIMD — 72 VGPRs and 20 bytes of scratch on a cold path instead of 79,
 // 96 SGPRs instead of 106: 6 -> 7 workgroups per CU, the pass 0.362 -> 0.353 ms on 8 x 10^8 rows, 0.616 -> 0.588 on
 // 1.6 x 10^9; 8 waves (64 VGPRs, 40 bytes of scratch) are slower, 0.392; profiles/r4b_ab_epilogue_waves.txt)
+#ifndef PG_EPI_STREAK
+#define PG_EPI_STREAK 1  // k_epilogue, one-byte rows: the bookkeeping of whole one-bin groups once per streak (see the tile loop)
+#endif
 #ifndef PG_EPI_WAIT_HERE
 #define PG_EPI_WAIT_HERE 1  // k_epilogue, one-byte rows: see the group path's prefetch
 #endif
@@ -1826,12 +1829,23 @@ __attribute__((amdgpu_num_sgpr(PG_EPI_SGPRS0))) void k_epilogue(uint32_t N, cons
     };
     uint4 gq_next = make_uint4(0, 0, 0, 0), gq_next2 = make_uint4(0, 0, 0, 0);  // group path: prefetched rows of the next group
     bool gq_valid = false;
+    // (one-byte rows) STREAK: whole one-bin groups known to follow the current one inside its bin, contig and tile range.  This
+    // pass is bound by its SCALAR instructions — a SIMD issues at most one per four cycles, and the block-uniform bookkeeping of
+    // a group (two tile_contig look-ups, six divisions by the bin length at 11 instructions each, the window checks) came to
+    // 330 of them against 195 vector instructions (100 dummy s_add per group: +0.07 ms on 8 x 10^8 rows, 100 dummy VALU: +0.04;
+    // profiles/r4e_stats_scalar_bound.txt).  Worked out ONCE when a group turns out whole and inside one bin; the groups of
+    // the streak then take nothing of that: same contig, same bin row, no window check, the next group's prefetch certain.
+    uint32_t streak = 0, nk_ba = 0, nk_bz = 0;
+    int nk_kind = 0;
     for (uint32_t tile = t_begin; tile < t_end; ++tile) {
-        const uint32_t c = tile_contig[tile];
-        if (c != cur_c) {  // block-uniform; consecutive tiles nearly always share their contig
-            if (want_cs && cur_c != ~0u) flush_colsums(cur_c);
-            a = ad[c];
-            cur_c = c;
+        uint32_t c = cur_c;
+        if (!(MODE == 0 && PG_EPI_STREAK && (streak || gq_valid))) {  // (a group the one before has announced lies in its contig)
+            c = tile_contig[tile];
+            if (c != cur_c) {  // block-uniform; consecutive tiles nearly always share their contig
+                if (want_cs && cur_c != ~0u) flush_colsums(cur_c);
+                a = ad[c];
+                cur_c = c;
+            }
         }
         // ---- group path (N <= 8): 8 full tiles of one contig inside one bin = 32 one-byte rows per thread in two
         // 16-byte loads, worked on BIT-SLICED: a three-stage butterfly between the 8 words regroups their 256 bits so
@@ -1854,26 +1868,46 @@ __attribute__((amdgpu_num_sgpr(PG_EPI_SGPRS0))) void k_epilogue(uint32_t N, cons
                 if (tl >= t_end || tile_contig[tl] != c || t0 >= a.nkmers) return 0u;
                 return min(min(span, a.nkmers - t0), (t_end - tl) * (uint32_t)PROBE_TILE);
             };
-            auto group_kind = [&](uint32_t t0, uint32_t rows) -> int {  // (block-uniform) 1: one bin, 2: several bins, 0: not a group
+            // (block-uniform) first and last bin of the rows [t0, t0 + rows) and the kind of group they make — 1: one bin, 2: several
+            // bins, 0: not a group
+            auto group_kind = [&](uint32_t t0, uint32_t rows, uint32_t &ba, uint32_t &bz) -> int {
                 if (rows == 0) return 0;
-                const uint32_t bl = a.binlen, ba = t0 / bl, bz = (t0 + rows - 1) / bl;
+                const uint32_t bl = a.binlen;
+                ba = t0 / bl;
+                bz = (t0 + rows - 1) / bl;
                 if (ba == bz) return 1;
                 return (bl >= 32u && bz - ba + 1u <= MAXB) ? 2 : 0;
             };
-            const uint32_t grows_n = rows_at(tile, ts);  // (>= 1: this tile has rows)
-            const int kind = group_kind(ts, grows_n);
+            const bool fast = PG_EPI_STREAK && streak != 0;  // (block-uniform) a group of a streak: whole, one bin, the bin of the group before
+            const bool known = PG_EPI_STREAK && !fast && gq_valid;  // the group before worked this one out (whole; nk_kind, nk_ba .. nk_bz) when it asked for its rows
+            uint32_t grows_n = span, ba = nk_ba, bz = nk_bz;
+            int kind = fast ? 1 : nk_kind;
+            if (fast) {
+                --streak;
+            } else if (!known) {
+                grows_n = rows_at(tile, ts);  // (>= 1: this tile has rows)
+                kind = group_kind(ts, grows_n, ba, bz);
+            }
             if (kind != 0) {
-                const uint64_t row0g = a.bin_off + ts / a.binlen;
-                const uint32_t nbg = (ts + grows_n - 1) / a.binlen - ts / a.binlen + 1u;  // bins of the group
-                const bool keep = cur_row0 != ~0ull && (kind == 1 ? row0g == cur_row0 : (row0g >= cur_row0 && row0g + nbg <= cur_row0 + MAXB));
-                if (!keep) {
-                    if (cur_row0 != ~0ull) {
-                        reduce_hist();
-                        __syncthreads();
-                        flush_hist(N, hist, bins, cur_row0, tid, MAXB);
-                        __syncthreads();
+                uint64_t row0g = cur_row0;
+                if (!fast) {
+                    row0g = a.bin_off + ba;
+                    const uint32_t nbg = bz - ba + 1u;  // bins of the group
+                    const bool keep = cur_row0 != ~0ull && (kind == 1 ? row0g == cur_row0 : (row0g >= cur_row0 && row0g + nbg <= cur_row0 + MAXB));
+                    if (!keep) {
+                        if (cur_row0 != ~0ull) {
+                            reduce_hist();
+                            __syncthreads();
+                            flush_hist(N, hist, bins, cur_row0, tid, MAXB);
+                            __syncthreads();
+                        }
+                        cur_row0 = row0g;
                     }
-                    cur_row0 = row0g;
+                    if (PG_EPI_STREAK && kind == 1 && grows_n == span) {
+                        // whole groups from ts on that end inside this bin, this contig and this workgroup's range (this one included)
+                        const uint64_t bin_end = min((uint64_t)(ba + 1u) * a.binlen, (uint64_t)a.nkmers);
+                        streak = min((uint32_t)(bin_end - ts) / span, (t_end - tile) / 8u) - 1u;
+                    }
                 }
                 const uint32_t nv = 32u * tid < grows_n ? min(32u, grows_n - 32u * tid) : 0u;  // this thread's valid rows
                 // (a 16-byte load that begins on a valid row ends inside the contig's 16-byte padded region)
@@ -1890,7 +1924,11 @@ __attribute__((amdgpu_num_sgpr(PG_EPI_SGPRS0))) void k_epilogue(uint32_t N, cons
 #endif
                 // prefetch the next group when this one is whole and a whole group follows right behind
                 const uint32_t tiles_here = (grows_n + PROBE_TILE - 1) / PROBE_TILE;
-                gq_valid = grows_n == span && rows_at(tile + 8, ts + span) == span && group_kind(ts + span, span) != 0;
+                gq_valid = streak != 0;
+                if (!gq_valid && grows_n == span && rows_at(tile + 8, ts + span) == span) {
+                    nk_kind = group_kind(ts + span, span, nk_ba, nk_bz);
+                    gq_valid = nk_kind != 0;
+                }
                 if (gq_valid) {
                     gq_next = gg[span / 16u];
                     gq_next2 = gg[span / 16u + 1];
@@ -1956,7 +1994,7 @@ __attribute__((amdgpu_num_sgpr(PG_EPI_SGPRS0))) void k_epilogue(uint32_t N, cons
                 } else {
                     // this thread's rows pos0 .. pos0 + nv - 1: bin of the first one (relative to the group's first bin) and
                     // rows until the next bin boundary
-                    const uint32_t bl = a.binlen, bin0s = (ts / bl) * bl, d0 = pos0 - bin0s;
+                    const uint32_t bl = a.binlen, bin0s = ba * bl, d0 = pos0 - bin0s;  // (ba = ts / bl)
                     const uint32_t rel0 = bl >= span ? (d0 >= bl ? 1u : 0u) : __umulhi(d0, 0xFFFFFFFFu / bl + 1u);  // (d0 < 2^16)
                     const uint32_t jb = min(nv, (rel0 + 1u) * bl - d0);  // valid rows of the first bin
                     const uint32_t mlo = rows_below(jb);
