@@ -163,6 +163,46 @@ __device__ __forceinline__ int scan_line_lds(const uint4 *line, uint64_t key, ui
     }
 }
 
+// The same scan WITHOUT control flow, for the batches whose every active lane has a staged line (k_probe's cut batches): all
+// 64 lanes read and compare — a lane without a k-mer whatever its clamped run number points at — the hit slot's mask
+// word is read by every lane (slot 0's where nothing matched) and selected by `any & amask`; the lanes whose key is absent
+// from a FULL line come back as a lane mask.  No exec-mask save / restore around the scan and around the hit path, no return
+// code rebuilt through 0 / 1 / -1 and compared again: 11 scalar instructions and three branches fewer per batch.  Measured:
+// within 0.5 % of the scan with its branches — what a dummy instruction costs in the FRONT END of a batch (profiles/
+// r4e_probe_dummy_salu.txt) an instruction saved behind the fetch does not give back; PG_SCAN_FLAT stays 0.
+template <bool TWO>
+__device__ __forceinline__ unsigned long long scan_line_lds_flat(const uint4 *line, uint64_t key, unsigned long long amask, uint32_t &m0,
+                                                                 uint32_t &m1) {
+    static_assert(PG_LDS_SOA == 1, "scan_line_lds_flat reads the split staged line");
+    constexpr int SLOTS = 8;
+    uint64_t kk[SLOTS];
+#pragma unroll
+    for (int j = 0; j < SLOTS / 2; ++j) {
+        const uint4 v = line[j];
+        kk[2 * j] = (uint64_t)v.x | ((uint64_t)v.y << 32);
+        kk[2 * j + 1] = (uint64_t)v.z | ((uint64_t)v.w << 32);
+    }
+    constexpr uint32_t SLOT_BYTES = 8u, MASK0 = 8u * SLOTS;
+    unsigned long long e[8];
+#pragma unroll
+    for (int sl = 0; sl < 8; ++sl) e[sl] = __builtin_amdgcn_ballot_w64(kk[sl] == key);
+    const unsigned long long b0 = e[1] | e[3] | e[5] | e[7], b1 = e[2] | e[3] | e[6] | e[7], b2 = e[4] | e[5] | e[6] | e[7];
+    const unsigned long long any = b0 | b1 | b2 | e[0];
+    const uint32_t off = (__builtin_amdgcn_inverse_ballot_w64(b0) ? SLOT_BYTES : 0u) | (__builtin_amdgcn_inverse_ballot_w64(b1) ? 2u * SLOT_BYTES : 0u) |
+                         (__builtin_amdgcn_inverse_ballot_w64(b2) ? 4u * SLOT_BYTES : 0u);
+    const bool hit = __builtin_amdgcn_inverse_ballot_w64(any & amask);
+    if constexpr (TWO) {
+        const uint2 mk = *reinterpret_cast<const uint2 *>(reinterpret_cast<const uint8_t *>(line) + off + MASK0);
+        m0 = hit ? mk.x : 0u;
+        m1 = hit ? mk.y : 0u;
+    } else {
+        const uint32_t mk = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(line) + off + MASK0);
+        m0 = hit ? mk : 0u;
+        m1 = 0;
+    }
+    return amask & ~any & __builtin_amdgcn_ballot_w64(kk[SLOTS - 1] != EMPTY_KEY);
+}
+
 // one line straight from global memory: the 8 slot loads are issued together (one latency)
 template <bool TWO, int SLOTS>
 __device__ __forceinline__ int scan_line_global(const SubTable &st, uint32_t b, uint64_t key, uint32_t &m0, uint32_t &m1) {
@@ -427,6 +467,12 @@ __device__ __forceinline__ uint32_t sliding_min(uint32_t x) {
 // used); their suffix minima take three row-local DPP steps there (a window of eight, cut off where the ~0 begin),
 // interleaved with the next batch's own sliding minimum, which takes them in with one v_min: up to 64 new positions
 // per batch for about eight instructions.
+#ifndef PG_SCAN_FLAT
+#define PG_SCAN_FLAT 0  // 1: k_probe's slot scan without control flow (scan_line_lds_flat) — 11 scalar instructions and three branches fewer per batch, parity green, and no faster: not the default (profiles/r4e_ab_probe_scalar_cuts.txt)
+#endif
+#ifndef PG_RUNLESS_TESTS
+#define PG_RUNLESS_TESTS 0  // 1: k_probe's batches without runs skip fetch, staging and scan (rounds 1-4; see back())
+#endif
 #ifndef PG_PROBE_CARRY
 #define PG_PROBE_CARRY 1
 #endif
@@ -492,6 +538,13 @@ __device__ __forceinline__ uint32_t lanes_le_index(unsigned long long mask, uint
     const unsigned long long m1 = mask >> 1;
     const uint32_t c = base + (uint32_t)(mask & 1ull) - 1u;
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, c));
+}
+
+// for a lane whose own bit of `mask` is set: base + its index among the set lanes = base + the set lanes BELOW it, which is
+// what mbcnt counts as it is — none of lanes_le_index's scalar shifts (a scalar instruction costs k_probe's launch what a
+// vector one does: profiles/r4e_probe_dummy_salu.txt)
+__device__ __forceinline__ uint32_t set_lane_index(unsigned long long mask, uint32_t base) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, base));
 }
 
 // ROWMODE 3 — the genome-sharded mode's narrow tables (a block of up to 8 genomes): the probe emits the block's
@@ -613,7 +666,7 @@ __device__ __forceinline__ void drain_queue(const SubTable &st, uint32_t qn, con
             }
             const unsigned long long kmask2 = __builtin_amdgcn_ballot_w64(again);
             if (again) {  // in-place compaction: slot <= e, and this batch's reads are already done
-                const uint32_t slot = lanes_le_index(kmask2, kept);
+                const uint32_t slot = set_lane_index(kmask2, kept);
                 uint32_t nl2 = line, ns2 = step;
                 // (staged levels end before the group's chain does: no switch to the key's own sequence
                 // here, and none of its hashing on this path)
@@ -914,7 +967,14 @@ __attribute__((amdgpu_num_sgpr(80))) void k_probe(const SubTable st, const uint6
             }
             __syncthreads();
         };
+        constexpr bool FLAT = PG_SCAN_FLAT && PG_ABLATE == 0 && CUT && !WIDE && SLOTS == 8;  // (CUT: an active lane's run is one of the step's)
+        unsigned long long ovf_flat = 0;
         auto scan = [&](const uint32_t r0) __attribute__((always_inline)) {
+            if constexpr (FLAT) {
+                ovf_flat = scan_line_lds_flat<TWO>(buf[0] + min(f.rid, (uint32_t)MAXRUN - 1u) * LDS_LINE_U4, f.key, f.amask, m0, m1);
+                __syncthreads();
+                return;
+            }
             const uint32_t nl = min((uint32_t)MAXRUN, f.nruns - r0);
 #if PG_ABLATE == 5  // (timing experiment: lines fetched and staged, no slot scan: every lane "hits" with one LDS word)
             if (act && f.rid - r0 < nl) {
@@ -941,13 +1001,15 @@ __attribute__((amdgpu_num_sgpr(80))) void k_probe(const SubTable st, const uint6
         PG_PRIO_AT(1)
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), nothing else
         PG_PH(2)
-        if (f.nruns) stage(L);
+        // (a batch without runs — a stretch of N — is not singled out: its lines_w hold line 0 throughout (padline), which is fetched,
+        // staged and scanned by no lane; three wave-uniform tests and their branches per batch were 10 scalar instructions)
+        if (PG_RUNLESS_TESTS == 0 || f.nruns) stage(L);
         PG_PH(3)
         PG_PRIO_AT(2)
         after_staging();  // (the chunks' registers are free from here on: the skewed order starts the NEXT batch's fetch now)
         PG_PRIO_AT(3)
         PG_PH(4)
-        if (f.nruns) scan(0u);
+        if (PG_RUNLESS_TESTS == 0 || f.nruns) scan(0u);
         PG_PH(5)
         if constexpr (!CUT)
         for (uint32_t r0 = MAXRUN; r0 < f.nruns; r0 += MAXRUN) {  // (a batch with more than MAXRUN lines: a quarter of the batches at w = 7)
@@ -959,7 +1021,7 @@ __attribute__((amdgpu_num_sgpr(80))) void k_probe(const SubTable st, const uint6
         // ---- overflow: absent from a full line -> queue entry for the next line of its sequence ----
         // (sicmp = the compare as a lane mask, predicate 40 = signed less-than: a ballot of `rcode < 0` is sunk into the
         // blocks rcode comes from and its bool rebuilt here through 0 / 1)
-        const unsigned long long omask = f.amask & __builtin_amdgcn_sicmp(rcode, 0, 40);
+        const unsigned long long omask = FLAT ? ovf_flat : (f.amask & __builtin_amdgcn_sicmp(rcode, 0, 40));
         const bool ovf = __builtin_amdgcn_inverse_ballot_w64(omask);
         if (omask) {
             // (the entry carries the home line and the GROUP: its step and next line — two multiplies and the wrap — are
@@ -973,7 +1035,7 @@ __attribute__((amdgpu_num_sgpr(80))) void k_probe(const SubTable st, const uint6
                 nx = f.line;
             }
             // (the queue always has room for a whole batch: the batch loop leaves for an early drain before it could not)
-            const uint32_t slot = lanes_le_index(omask, qn);
+            const uint32_t slot = set_lane_index(omask, qn);
             if (ovf) {
                 q_line[slot] = nx;
                 q_step[slot] = step;
@@ -1051,7 +1113,7 @@ __attribute__((amdgpu_num_sgpr(80))) void k_probe(const SubTable st, const uint6
         PG_PH(0)
         carry = carry_at(0u);
         Front cur = front(std::true_type{}, 0u);
-        if (cur.nruns) L = issue(cur, 0u);
+        if (PG_RUNLESS_TESTS == 0 || cur.nruns) L = issue(cur, 0u);
         for (;;) {
             PG_PH(7)
             const uint32_t b1 = b0 + cur.adv;
@@ -1064,7 +1126,7 @@ __attribute__((amdgpu_num_sgpr(80))) void k_probe(const SubTable st, const uint6
             // the next batch's fetch goes out as soon as this batch's chunks have left their registers for LDS: it is in
             // flight during this batch's slot scan, row store and overflow entries AND the front end after next
             back(cur, L, b0, [&]() __attribute__((always_inline)) {
-                if (more && nxt.nruns) L = issue(nxt, 0u);
+                if (more && (PG_RUNLESS_TESTS == 0 || nxt.nruns)) L = issue(nxt, 0u);
             });
             __builtin_amdgcn_sched_barrier(0);
             b0 = b1;
@@ -1078,7 +1140,7 @@ __attribute__((amdgpu_num_sgpr(80))) void k_probe(const SubTable st, const uint6
             // is thrown away on the rare way out — the tail starts it again)
             if (!more || qn > QROOM) break;
             cur = nxt;
-            if (cur.nruns) L = issue(cur, 0u);
+            if (PG_RUNLESS_TESTS == 0 || cur.nruns) L = issue(cur, 0u);
 #endif
         }
     } else {
