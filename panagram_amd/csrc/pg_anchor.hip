@@ -467,6 +467,9 @@ __device__ __forceinline__ uint32_t sliding_min(uint32_t x) {
 // used); their suffix minima take three row-local DPP steps there (a window of eight, cut off where the ~0 begin),
 // interleaved with the next batch's own sliding minimum, which takes them in with one v_min: up to 64 new positions
 // per batch for about eight instructions.
+#ifndef PG_RID_ADDC
+#define PG_RID_ADDC 1  // k_probe's front end: run ids by mbcnt + v_addc_co_u32 (run_ids), no test for a batch without runs
+#endif
 #ifndef PG_SCAN_FLAT
 #define PG_SCAN_FLAT 0  // 1: k_probe's slot scan without control flow (scan_line_lds_flat) — 11 scalar instructions and three branches fewer per batch, parity green, and no faster: not the default (profiles/r4e_ab_probe_scalar_cuts.txt)
 #endif
@@ -540,6 +543,20 @@ __device__ __forceinline__ uint32_t lanes_le_index(unsigned long long mask, uint
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, c));
 }
 
+// run ids: (set lanes of `lmask` at or below this lane) - 1 — lanes_le_index(lmask, 0) — with NO scalar instruction: mbcnt counts
+// the set lanes BELOW (its addend -1 is an inline constant), and a lane's own bit comes in as the carry of v_addc_co_u32,
+// whose carry-in operand is a lane mask in an SGPR pair
+__device__ __forceinline__ uint32_t run_ids(unsigned long long lmask) {
+#if PG_RID_ADDC
+    const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(lmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lmask, ~0u));
+    uint32_t rid;
+    unsigned long long carry_out;
+    asm("v_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(rid), "=s"(carry_out) : "v"(below), "s"(lmask));
+    return rid;
+#else
+    return lanes_le_index(lmask, 0u);
+#endif
+}
 // for a lane whose own bit of `mask` is set: base + its index among the set lanes = base + the set lanes BELOW it, which is
 // what mbcnt counts as it is — none of lanes_le_index's scalar shifts (a scalar instruction costs k_probe's launch what a
 // vector one does: profiles/r4e_probe_dummy_salu.txt)
@@ -878,7 +895,7 @@ __attribute__((amdgpu_num_sgpr(80))) void k_probe(const SubTable st, const uint6
         // lane whose predecessor is inactive or on another line; lane 0 has no predecessor — the shift leaves its bit clear)
         f.line = home_of_group(f.grp, st.nbuckets);
         f.lmask = f.amask & (~(f.amask << 1) | differs_from_lane_below(f.line));
-        f.rid = lanes_le_index(f.lmask, 0u);  // run id of an active lane
+        f.rid = run_ids(f.lmask);  // run id of an active lane
         uint32_t lanes_kept = 64u;
         if constexpr (CUT) {
             // the lanes of the first MAXRUN runs — a prefix of the wave: run ids do not fall from lane to lane; the lanes
@@ -897,7 +914,13 @@ __attribute__((amdgpu_num_sgpr(80))) void k_probe(const SubTable st, const uint6
             carry = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((uint32_t)lane << 2) + ((lanes_kept - HALO) << 2)), (int)own);
         }
         f.nruns = (uint32_t)__popcll(f.lmask);
+#if PG_RID_ADDC
+        // (a batch without runs: s_ff1 of an empty mask is -1, v_readlane takes it modulo 64 — lane 63's line, a line of the table
+        // like any other, fetched and scanned by no lane: no test for the empty mask)
+        f.padline = (uint32_t)__builtin_amdgcn_readlane((int)f.line, __builtin_ctzll(f.lmask) & 63);  // (wave-uniform)
+#else
         f.padline = f.lmask ? (uint32_t)__builtin_amdgcn_readlane((int)f.line, __builtin_ctzll(f.lmask)) : 0u;  // (wave-uniform)
+#endif
 #if PG_ABLATE == 3  // (timing experiment: keys, minimizers and runs only — no table access)
         if (f.line != 0xDEADBEEFu) f.nruns = 0;
 #endif
