@@ -759,7 +759,8 @@ def test_kmer_sketch_registers_equal_oracle(ctx, k):
 
 
 @pytest.mark.parametrize("n,k,lens", [(1, 21, [700_123]), (5, 21, [520_000, 9_000]), (8, 31, [900_077, 450_321]),
-                                      (8, 21, [50_020, 12_345, 7_000, 33_333]), (3, 21, [204_900, 6_700])])
+                                      (8, 21, [50_020, 12_345, 7_000, 33_333]), (3, 21, [204_900, 6_700]),
+                                      (2, 21, [3_400_000, 1_700_000, 250_000])])  # (bins of 34 k and 17 k rows: STREAKS of whole one-bin groups, k_epilogue)
 def test_one_byte_rows_long_contigs_against_oracle(ctx, n, k, lens):
     """contigs long enough for the bit-sliced statistics path of one-byte rows (32 rows per thread over 8 whole tiles)
     in both of its kinds — all 4096 rows inside one bin; several bins of 66..2049 rows each, a thread's rows split at
