@@ -1696,6 +1696,9 @@ __device__ __forceinline__ EpiRange epi_range(uint32_t gt, uint32_t ntiles, cons
 // (one-byte rows: held to the registers of 7 waves per SIMD — 72 VGPRs and 20 bytes of scratch on a cold path instead of 79,
 // 96 SGPRs instead of 106: 6 -> 7 workgroups per CU, the pass 0.362 -> 0.353 ms on 8 x 10^8 rows, 0.616 -> 0.588 on
 // 1.6 x 10^9; 8 waves (64 VGPRs, 40 bytes of scratch) are slower, 0.392; profiles/r4b_ab_epilogue_waves.txt)
+#ifndef PG_EPI_HS
+#define PG_EPI_HS 1  // k_epilogue, rows of 2..8 bytes: column sums through eight counter planes behind a Harley-Seal tree
+#endif
 #ifndef PG_EPI_STREAK
 #define PG_EPI_STREAK 1  // k_epilogue, one-byte rows: the bookkeeping of whole one-bin groups once per streak (see the tile loop)
 #endif
@@ -1766,6 +1769,90 @@ __attribute__((amdgpu_num_sgpr(PG_EPI_SGPRS0))) void k_epilogue(uint32_t N, cons
     //      accumulators: byte b of bacc[w][q] counts genome 32w + 8b + q (up to 252 rows);
     //  L3  a halving exchange over the wave (17 shuffles per word) leaves each total in one lane,
     //      which adds it to the workgroup's LDS counters.
+#if PG_EPI_HS
+    // (round 4: L1 and L2 as in k_epilogue_chunks — EIGHT bit planes per word behind a Harley-Seal carry-save tree: four rows
+    // enter the ones / twos planes per call (9 instructions), their carry of weight 4 is held back every other call and enters
+    // the fours plane with the next one (3), likewise the eights, and every 16 rows one carry ripples through the upper four
+    // planes (8): 3.3 instructions per row and word where four planes emptied every 12 rows into byte-sliced accumulators took
+    // 8.3 — a quarter of the 22 vector instructions per row that bound the pass for rows of 2 and 3 bytes
+    // (profiles/r4e_pmc_n12_n27.txt); the planes are emptied every 240 rows straight into L3's exchange)
+    uint32_t vp[2][8] = {{0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0}}, pf[2] = {0, 0}, pe[2] = {0, 0};
+    uint32_t vrows = 0;  // rows in the planes (block-uniform, a multiple of 4): the carries held back follow from it
+    constexpr uint32_t VROWS_FLUSH = 240;
+    auto ripple = [&](uint32_t (&p)[8], uint32_t cw, int q0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (q >= q0) {
+                const uint32_t n = p[q] & cw;
+                p[q] ^= cw;
+                cw = n;
+            }
+    };
+    auto vadd4 = [&](int ws, uint32_t r0, uint32_t r1, uint32_t r2, uint32_t r3) __attribute__((always_inline)) {
+        const bool odd4 = (vrows & 4u) != 0, odd8 = (vrows & 8u) != 0;  // (the caller advances vrows once all words of the four rows are in)
+        uint32_t (&p)[8] = vp[ws];
+        const uint32_t x = p[0];
+        const uint32_t t1 = x ^ r0, s1 = t1 ^ r1, ca = (t1 & r1) | (~t1 & x);      // x + r0 + r1
+        const uint32_t t2 = s1 ^ r2, s2 = t2 ^ r3, cb = (t2 & r3) | (~t2 & s1);    // .. + r2 + r3
+        p[0] = s2;
+        const uint32_t y = p[1];
+        const uint32_t t3 = y ^ ca, cc = (t3 & cb) | (~t3 & y);                     // twos + ca + cb -> a carry of weight 4
+        p[1] = t3 ^ cb;
+        if (!odd4) {
+            pf[ws] = cc;
+            return;
+        }
+        const uint32_t z = p[2], t4 = z ^ pf[ws], c8 = (t4 & cc) | (~t4 & z);      // fours + both carries -> weight 8
+        p[2] = t4 ^ cc;
+        if (!odd8) {
+            pe[ws] = c8;
+            return;
+        }
+        const uint32_t u = p[3], t5 = u ^ pe[ws], c16 = (t5 & c8) | (~t5 & u);     // eights + both carries -> weight 16
+        p[3] = t5 ^ c8;
+        ripple(p, c16, 4);
+    };
+    auto vflush = [&]() {  // L1 -> L3, wave-uniform call sites only
+        const bool odd4 = (vrows & 4u) != 0, odd8 = (vrows & 8u) != 0;  // carries still held back (a flush between whole 16-row blocks)
+        for (uint32_t ws = 0; ws < ndbs && ws < 2; ++ws) {
+            if (odd4) ripple(vp[ws], pf[ws], 2);
+            if (odd8) ripple(vp[ws], pe[ws], 3);
+            uint32_t R[16];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {  // byte b of v counts genome 32 ws + 8 b + q (up to 255 rows)
+                uint32_t v = 0;
+#pragma unroll
+                for (int pl = 0; pl < 8; ++pl) v |= ((vp[ws][pl] >> q) & 0x01010101u) << pl;
+                R[2 * q] = v & 0x00FF00FFu;
+                R[2 * q + 1] = (v >> 8) & 0x00FF00FFu;
+            }
+#pragma unroll
+            for (int pl = 0; pl < 8; ++pl) vp[ws][pl] = 0;
+#pragma unroll
+            for (int half = 8, bit = 32; half >= 1; half >>= 1, bit >>= 1) {
+                const bool up = (lane & bit) != 0;
+#pragma unroll
+                for (int i = 0; i < half; ++i) {
+                    const uint32_t send = up ? R[i] : R[i + half];
+                    const uint32_t keep = up ? R[i + half] : R[i];
+                    R[i] = keep + (uint32_t)__shfl_xor((int)send, bit);
+                }
+            }
+            R[0] += (uint32_t)__shfl_xor((int)R[0], 2);
+            R[0] += (uint32_t)__shfl_xor((int)R[0], 1);
+            if ((lane & 3) == 0) {  // this lane holds register (lane >> 2): q = idx / 2, odd idx = bytes 1 and 3
+                const uint32_t idx = (uint32_t)lane >> 2;
+                const uint32_t g0 = 32 * ws + (idx >> 1) + ((idx & 1) ? 8u : 0u);
+                if (g0 < Nw && (R[0] & 0xFFFFu)) atomicAdd(&cs[g0], R[0] & 0xFFFFu);
+                if (g0 + 16 < Nw && (R[0] >> 16)) atomicAdd(&cs[g0 + 16], R[0] >> 16);
+            }
+        }
+        vrows = 0;
+    };
+    [[maybe_unused]] uint32_t brounds = 0;
+    auto wave_colsums = [&]() {};
+#else
+    constexpr uint32_t VROWS_FLUSH = 12;
     uint32_t vp[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
     uint32_t bacc[2][8] = {{0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0}};
     uint32_t vrows = 0, brounds = 0;
@@ -1828,6 +1915,7 @@ __attribute__((amdgpu_num_sgpr(PG_EPI_SGPRS0))) void k_epilogue(uint32_t N, cons
         if (++brounds == 21) wave_colsums();  // 21 x 12 rows: the byte counters are about to fill
     };
 
+#endif
     auto spill = [&]() {  // the per-tile path's classes (7-bit fields of hacc) join the thresholds: thr[i] += rows of class > i
         uint32_t run = 0;
 #pragma unroll
@@ -2177,7 +2265,7 @@ __attribute__((amdgpu_num_sgpr(PG_EPI_SGPRS0))) void k_epilogue(uint32_t N, cons
                             vadd4(0, w0[0], w0[1], w0[2], w0[3]);
                             if (NB > 4) vadd4(1, w1[0], w1[1], w1[2], w1[3]);
                             vrows += PT;
-                            if (vrows == 12) vflush();
+                            if (vrows == VROWS_FLUSH) vflush();
                         }
                     }
                 };
@@ -2358,7 +2446,7 @@ __attribute__((amdgpu_num_sgpr(PG_EPI_SGPRS0))) void k_epilogue(uint32_t N, cons
                 vadd4(0, w0[0], w0[1], w0[2], w0[3]);
                 if (ndbs > 1) vadd4(1, w1[0], w1[1], w1[2], w1[3]);
                 vrows += PT;
-                if (vrows == 12) vflush();
+                if (vrows == VROWS_FLUSH) vflush();
             }
         } else {
             next_valid = false;
