@@ -159,7 +159,7 @@ class Pangenome:
     """synthetic pangenome resident in HBM: packed sequences of this rank's contig group, the table of ALL groups"""
 
     def __init__(self, ctx, dev, G, contig_lens, d, seed, k, groups=1, my_group=0, keep_ascii=True, minimizer=-1,
-                 rehash_kpb=None, block=None, pieces_of=None):
+                 rehash_kpb=None, block=None, pieces_of=None, coscheduled=0):
         """``pieces_of=(rank, world)`` (strong scaling): the pangenome is the SAME whatever the GPU count; this rank
         anchors its pieces of homology classes (panagram_amd.distributed.plan_class_pieces — the partition
         Index.run() uses with several ranks) against a table built from those pieces, every genome then only setting
@@ -167,6 +167,9 @@ class Pangenome:
         from panagram_amd import engine
         self.G, self.k, self.contig_lens = G, k, list(contig_lens)
         self.pieces = None
+        # (how the table will be probed decides its minimizer window with the key count, as Index.build_table tells it:
+        # the anchor genomes of a launch, 1 = one launch per genome)
+        self.coscheduled = coscheduled or G
         if pieces_of is not None:
             self._init_pieces(ctx, dev, d, seed, pieces_of, minimizer)
             return
@@ -178,7 +181,7 @@ class Pangenome:
         self.filtered = groups > 1 and os.environ.get("PG_FULL_TABLE", "") in ("", "0")
         est = int(L * (1 + max(0, g_hi - g_lo - 1) * novel) * 1.05) * (1 if self.filtered else groups)
         t0 = time.perf_counter()
-        self.table = engine.PanTable(ctx, k, g_hi - g_lo, expected_keys=est)
+        self.table = engine.PanTable(ctx, k, g_hi - g_lo, expected_keys=est, coscheduled=self.coscheduled)
         if minimizer >= 0:
             self.table.set_minimizer(minimizer)
         self.seqsets, self.ascii = None, None
@@ -244,7 +247,7 @@ class Pangenome:
             sketch.add(ss)
         est = sketch.estimate()
         sketch.close()
-        self.table = engine.PanTable(ctx, k, G, expected_keys=est + est // 32 + 1024)
+        self.table = engine.PanTable(ctx, k, G, expected_keys=est + est // 32 + 1024, coscheduled=self.coscheduled)
         if minimizer >= 0:
             self.table.set_minimizer(minimizer)
         ctx.synchronize()
@@ -317,14 +320,34 @@ def make_results(ctx, pg, colsums, per_genome, piece_tiles):
     return [r], merged
 
 
+KERNEL_SOURCES = ("pg_anchor.hip", "pg_device.h", "pg_kernels.h")  # what k_probe / k_epilogue are compiled from
+
+
+def kernel_sources_sha():
+    """sha256 over the kernel sources (first 16 hex digits): profiles/traffic.json records the one its --pmc passes ran on
+    (tools/make_traffic.py), so that counters of an older kernel cannot pass for the current one's"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "panagram_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def load_counters(pos_per_launch, k, G):
     """PMC counters cannot be read from inside this process: the figures come from the committed
     rocprofv3 --pmc passes of this same command (profiles/traffic.json, corrected as MI355X_MICROARCH.md
-    prescribes) and are only quoted when the workload is the one that was profiled"""
+    prescribes) and are only quoted when the workload is the one that was profiled.  The line says which file they came
+    from (its sha256) and whether the kernel sources are still the ones that were profiled."""
+    import hashlib
     try:
-        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-            tj = json.load(f)
+        path = os.path.join(ROOT, "profiles", "traffic.json")
+        with open(path, "rb") as f:
+            raw = f.read()
+        tj = json.loads(raw)
         if abs(tj["positions_per_launch"] - pos_per_launch) < 1 and k == 21 and G == 8:
+            tj["file_sha16"] = hashlib.sha256(raw).hexdigest()[:16]
+            tj["sources_match"] = tj.get("kernel_sources_sha16") == kernel_sources_sha()
             return tj
     except (OSError, KeyError, ValueError):
         pass
@@ -373,6 +396,10 @@ def roofline_block(pos_per_launch, avg_launch_s, avg_epi_s, G, value_per_gpu, co
             out["valu_issue_frac_2cycle"] = counters["SQ_INSTS_VALU"] * 2.0 / (SIMDS * CLOCK_HZ * avg_launch_s)
             out["valu_issue_frac_4cycle"] = counters["SQ_INSTS_VALU"] * VALU_CYCLES / (SIMDS * CLOCK_HZ * avg_launch_s)
         out["counters_from"] = counters.get("profiled_on", "profiles/traffic.json (committed rocprofv3 --pmc passes of this command)")
+        out["counters_round"] = counters.get("round")
+        out["counters_file_sha16"] = counters.get("file_sha16")
+        # false: the kernel sources changed after the --pmc passes — traffic and instruction counts are the OLD kernel's
+        out["counters_kernel_sources_match"] = counters.get("sources_match")
     out["note"] = ("frac = algorithmic bytes (B_min of SURVEY 8d x positions per launch) / mean k_probe launch time / 8 TB/s; traffic = "
                    "PMC-measured HBM bytes of the same launch (null for workloads without a committed --pmc pass); the kernel is "
                    "not HBM-bound — valu_issue_frac_* say how close instruction issue is to its ceiling (DESIGN.md section 4)")
@@ -435,6 +462,127 @@ def north_star_leg(ctx, dev, args):
         merged.close()
     pg.close()
     ctx.trim()
+    return out
+
+
+def config5_leg(ctx, dev, args, genome_mb=None, contigs=24, sample_n=1_000_000, chunk_positions=None):
+    """BASELINE.json configs[4] AS SPECIFIED — 8 synthetic 3 Gb genomes (24 contigs of 125 Mb each), k=21, d=0.05: 1.7e10
+    distinct k-mers, more than one GPU's 288 GB holds — on ONE GPU through the product's own pass mode
+    (panagram_amd.distributed.ShardedAnchoring, what Index.run() runs when plan_sharding says "genome"): genome_blocks = 8,
+    ONE genome per block; pass p builds the table of genome p in the same allocation (pg_table_clear), probes EVERY anchor
+    position of all 8 genomes against it in co-scheduled chunk groups, extracts the block's bit column and ORs it into the
+    anchors' full rows (accumulate).  With 8 GPUs the 8 passes run side by side, one per rank, and the columns travel by
+    all-gather (the same code, world = 8); here one GPU does the 8 ranks' work one after the other, without a collective.
+    The byte layout that must come out: cpp/anchor.cpp:139-164 (one byte per position, bit g = genome g).
+    Checked: every anchor's own column counts every one of its positions; the first ``sample_n`` rows of anchor 0 and the
+    LAST ``sample_n`` rows of anchor 5's last contig equal the CPU oracle's, whose k-mer DB for the samples is built by brute
+    force with torch (no HIP kernel involved in the expected rows).  Outside the timed region of ``value``."""
+    from panagram_amd import distributed as pdist
+    from panagram_amd import engine
+    G, k, d = 8, 21, 0.05
+    L = int((genome_mb if genome_mb is not None else float(os.environ.get("PG_BENCH_C5_MB", "3000"))) * 1e6)
+    contig_lens = [L // contigs] * contigs
+    t_leg = time.perf_counter()
+    genomes = synth_genomes_device(G, contig_lens, d, args.seed + 5, dev)
+    torch.cuda.synchronize()
+    synth_s = time.perf_counter() - t_leg
+    # ---- expected rows of two samples: head of anchor 0, tail of anchor 5 (brute-force DB, CPU oracle) ----
+    picks = [(0, 0, "head"), (5, contigs - 1, "tail")]
+    n = min(sample_n, contig_lens[0] - k + 1)
+    samples = [genomes[g][c][:n + k - 1] if where == "head" else genomes[g][c][-(n + k - 1):] for g, c, where in picks]
+    t0 = time.perf_counter()
+    dbs = sample_db_by_brute_force(genomes, samples, k, G)
+    db_s = time.perf_counter() - t0
+    samples_host = [x.cpu().numpy() for x in samples]
+    # ---- packed sequences (0.375 byte per base); the ASCII goes ----
+    seqsets = []
+    for g in range(G):
+        ss = engine.SeqSet(ctx, contig_lens)
+        for c, t in enumerate(genomes[g]):
+            ss.load_dev(c, t.data_ptr(), t.numel())
+        seqsets.append(ss)
+    ctx.synchronize()
+    del genomes, samples
+    torch.cuda.empty_cache()
+    names = [f"g{g}" for g in range(G)]
+    seqs = dict(zip(names, seqsets))
+    pos_per_genome = [ss.total_kmers(k) for ss in seqsets]
+    pos = sum(pos_per_genome)
+    # ---- ONE table allocation for all blocks, sized from the genomes' sketches (run_genome_sharded does the same) ----
+    sketch = engine.KmerSketch(ctx, k)
+    est = 0
+    for ss in seqsets:
+        sketch.reset()
+        sketch.add(ss)
+        est = max(est, sketch.estimate())
+    sketch.close()
+    old_chunk = pdist.CHUNK_POSITIONS
+    if chunk_positions:
+        pdist.CHUNK_POSITIONS = chunk_positions
+    try:
+        sh = pdist.ShardedAnchoring(engine, ctx, k, G, 1, 0, 1, seqs, {a: 0 for a in names}, None, None)
+    finally:
+        pdist.CHUNK_POSITIONS = old_chunk
+    tbl = engine.PanTable(ctx, k, 1, expected_keys=est + est // 32 + 1024, coscheduled=G)
+    passes, done = [], []
+    total_build = total_pass = 0.0
+    for p in range(G):
+        if p:
+            tbl.clear()
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        tbl.insert_seqset(0, seqsets[p])
+        ctx.synchronize()
+        build_s = time.perf_counter() - t0
+        stt = tbl.stats()
+        # (a measuring pass first, synchronised after every stage — probe / extract / merge — then the pass as the product
+        # runs it, timed as a whole; OR-ing a block's bits into the rows twice changes nothing)
+        ph = {}
+        sh.run_pass(tbl, p, 1, True, None, phase_s=ph)
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        sh.run_pass(tbl, p, 1, True, (lambda a, res: (res.rows_epilogue(), done.append(a))) if p == G - 1 else None)
+        ctx.synchronize()
+        pass_s = time.perf_counter() - t0
+        total_build += build_s
+        total_pass += pass_s
+        passes.append({"genome_block": p, "table_keys": stt["nkeys"], "table_bytes": stt["bytes"], "minimizer_length": tbl.minimizer,
+                       "table_build_s": build_s, "pass_ms": 1e3 * pass_s, "value": pos / pass_s,
+                       "probe_ms": 1e3 * ph.get("probe", 0.0), "extract_ms": 1e3 * ph.get("extract", 0.0), "merge_ms": 1e3 * ph.get("merge", 0.0)})
+    # ---- checks on the completed rows ----
+    own_ok = all(int(sh.full[a].colsums()[gi]) == pos_per_genome[gi] for gi, a in enumerate(names))
+
+    def gpu_rows(t, nrows):
+        g, c, where = picks[t]
+        rows = sh.full[names[g]].download(c, want_bitmap100=False)[0]
+        return rows[:nrows] if where == "head" else rows[-nrows:]
+    v, cdt, npos, ok = cpu_baseline(dbs, samples_host, k, G, gpu_rows)
+    out = {
+        "workload": f"BASELINE.json configs[4]: 8 synthetic {L / 1e6:g} Mb genomes ({contigs} contigs each), k=21, d=0.05, genome_blocks=8 "
+                    "(one genome per block), all 8 anchored, on ONE GPU as 8 passes through distributed.ShardedAnchoring "
+                    "(table of block p built in one re-used allocation, every anchor position probed, bit column extracted and "
+                    "OR-ed into the full rows); with 8 GPUs the passes run side by side and the columns are all-gathered",
+        "positions": pos, "genome_blocks": G, "chunk_groups_per_pass": len(sh.groups),
+        "value": pos / total_pass, "value_with_table_builds": pos / (total_pass + total_build), "unit": "k-mers/s",
+        "value_note": "the whole job on ONE GPU: all positions / the 8 passes' time (each pass probes every position against one "
+                      "genome's table: 8 GPUs' work); per_pass_value_mean is what one rank of an 8-GPU run sustains, the "
+                      "job's 8-GPU rate if the all-gather hides behind the next group's probe (DESIGN.md section 6)",
+        "per_pass_value_mean": float(np.mean([x["value"] for x in passes])),
+        "passes_s": total_pass, "table_builds_s": total_build, "passes": passes,
+        "union_keys_sum_over_blocks": int(sum(x["table_keys"] for x in passes)),
+        "anchors_hold_all_own_kmers": bool(own_ok), "anchors_completed": len(done),
+        "rows_equal_gpu": ok,
+        "rows_check": f"first {n} rows of genome 0 and last {n} rows of genome 5's last contig: CPU oracle rows (k-mer DB of the "
+                      f"samples built by brute force with torch in {db_s:.1f} s, {sum(len(kk) for kk, _ in dbs)} keys) == the rows "
+                      "the 8 passes assembled",
+        "synth_s": synth_s, "leg_s": time.perf_counter() - t_leg,
+    }
+    sh.close()
+    tbl.close()
+    for ss in seqsets:
+        ss.close()
+    ctx.trim()
+    torch.cuda.empty_cache()
     return out
 
 
@@ -523,7 +671,7 @@ def robustness_legs(ctx, dev, args, k):
     G, C, L = 8, 5, 10_000_000
     out = {}
 
-    def measure(genomes, classes, label, what):
+    def measure(genomes, classes, label, what, minimizer=-1, into=None):
         seqsets = []
         for g in range(G):
             ss = engine.SeqSet(ctx, [int(t.numel()) for t in genomes[g]])
@@ -531,7 +679,9 @@ def robustness_legs(ctx, dev, args, k):
                 ss.load_dev(c, t.data_ptr(), t.numel())
             seqsets.append(ss)
         ctx.synchronize()
-        tbl = engine.PanTable(ctx, k, G, expected_keys=int(sum(t.numel() for t in genomes[0]) * (1 + (G - 1) * 0.25)))
+        tbl = engine.PanTable(ctx, k, G, expected_keys=int(sum(t.numel() for t in genomes[0]) * (1 + (G - 1) * 0.25)), coscheduled=G)
+        if minimizer >= 0:
+            tbl.set_minimizer(minimizer)
         tb = time.perf_counter()
         for g in range(G):
             tbl.insert_seqset(g, seqsets[g])
@@ -549,7 +699,9 @@ def robustness_legs(ctx, dev, args, k):
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / 3
         cs = res.contig_colsums(0, len(genomes[0])).sum(axis=0)
-        assert int(cs[0]) == seqsets[0].total_kmers(k), "anchor genome 0 must contain every one of its k-mers"
+        # (an anchor holds every one of its k-mers; positions whose window holds an N have none)
+        own_min = seqsets[0].total_kmers(k) - sum(int((t == ord("N")).sum().item()) for t in genomes[0]) * k
+        assert own_min <= int(cs[0]) <= seqsets[0].total_kmers(k), "anchor genome 0 must contain every one of its k-mers"
         res.close()
         merged.close()
         singles = [engine.AnchorResult(tbl, ss, colsums=True) for ss in seqsets]
@@ -562,8 +714,10 @@ def robustness_legs(ctx, dev, args, k):
                 r.run()
         torch.cuda.synchronize()
         dt1 = (time.perf_counter() - t0) / 3
-        out[label] = {"what": what, "value": npos / dt, "per_genome_launches_value": npos / dt1, "unit": "k-mers/s",
-                      "positions_per_step": npos, "table_keys": tbl.stats()["nkeys"], "table_build_s": build_s}
+        (out if into is None else into)[label] = {
+            "what": what, "value": npos / dt, "per_genome_launches_value": npos / dt1, "unit": "k-mers/s",
+            "positions_per_step": npos, "table_keys": tbl.stats()["nkeys"], "table_build_s": build_s,
+            "minimizer_length": tbl.minimizer, "table_spill_fraction": tbl.measure_spill()}
         for r in singles:
             r.close()
         for ss in seqsets:
@@ -615,7 +769,96 @@ def robustness_legs(ctx, dev, args, k):
     del uniq
     measure(genomes, list(range(C)) * G, "repeat_family_10pct",
             f"8 x 50 Mb, 90 % unique sequence at 1 % SNPs + 10 % one repeat family ({copies} copies of a 3-kb element at 3 % divergence per genome)")
+    del genomes
+    torch.cuda.empty_cache()
+    # (c) a plant-like pangenome: half of every genome is transposable-element copies of many families and ages
+    genomes, what = plant_like_pangenome(dev, G, C, L, args.d, args.seed + 303)
+    leg = {}
+    measure(genomes, list(range(C)) * G, "library_choice", what, into=leg)
+    measure(genomes, list(range(C)) * G, "window_capped_at_4", "the same, minimizer window capped at 4 (what PG_TABLE_WMAX=4 chooses: m = k - 3)",
+            minimizer=k - 3, into=leg)
+    a, b = leg["library_choice"], leg["window_capped_at_4"]
+    out["plant_like_50pct_repeats"] = dict(a, window_capped_at_4={x: b[x] for x in ("value", "per_genome_launches_value", "minimizer_length",
+                                                                                    "table_keys", "table_spill_fraction", "table_build_s")})
     return out
+
+
+def plant_like_pangenome(dev, G, C, L, d, seed, families=30, repeat_share=0.5):
+    """What the reference is used on (README.md: plant pangenomes; panagram/introgressions/run_example.sh:8-22 simulates from
+    A. thaliana chr1): an ancestral genome of C chromosomes of L bases in which ``repeat_share`` of the sequence is copies of
+    ``families`` transposable-element families — element length 300 b .. 8 kb, copy number 10^2 .. 10^4, copies diverged from
+    their family's consensus by the family's AGE, 1 .. 20 % (log-uniform each; copy numbers scaled so that the share comes
+    out) — scattered between stretches of unique sequence, plus two 1-Mb tandem arrays of a 178-b satellite unit (copies 2 %
+    apart) and three assembly gaps of 500 N per chromosome.  The G genomes are that ancestor with substitutions at rate d
+    (genome 0: the ancestor) — the insertions are shared, as most are within a species — and gaps of their own.
+    Returns ([genome][chromosome] ASCII tensors, description)."""
+    rng = np.random.default_rng(seed)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed)
+    acgt = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+    total = C * L
+    sat_bases = 2 * 1_000_000
+    te_target = int(repeat_share * total) - sat_bases
+    lens = np.exp(rng.uniform(np.log(300), np.log(8000), families)).astype(np.int64)
+    copies = np.exp(rng.uniform(np.log(100), np.log(10000), families))
+    copies = np.maximum(100, copies * te_target / float((lens * copies).sum())).astype(np.int64)
+    ages = np.exp(rng.uniform(np.log(0.01), np.log(0.20), families))
+
+    def mutated(cons, n, rate):  # n copies of a consensus (codes 0..3), each base substituted with probability `rate`
+        e = cons.repeat(n, 1)
+        mut = torch.rand(e.shape, device=dev, generator=gen) < rate
+        return torch.where(mut, (e + torch.randint(1, 4, e.shape, dtype=torch.uint8, device=dev, generator=gen)) & 3, e)
+
+    pieces = []  # every element copy of every family, as rows of the families' matrices
+    for f in range(families):
+        cons = torch.randint(0, 4, (int(lens[f]),), dtype=torch.uint8, device=dev, generator=gen)
+        m = mutated(cons, int(copies[f]), float(ages[f]))
+        pieces += list(m.unbind(0))
+    order = rng.permutation(len(pieces))
+    te_bases = int((lens * copies).sum())
+    sats = []
+    for _ in range(2):
+        unit = torch.randint(0, 4, (178,), dtype=torch.uint8, device=dev, generator=gen)
+        sats.append(mutated(unit, 1_000_000 // 178, 0.02).reshape(-1))
+    # chromosome c takes every C-th element copy, each followed by a stretch of unique sequence; the satellites go into the
+    # middle of chromosomes 0 and 2
+    uniq_total = total - te_bases - sum(int(x.numel()) for x in sats)
+    base = []
+    for c in range(C):
+        mine = [pieces[i] for i in order[c::C]]
+        room = L - sum(int(x.numel()) for x in mine) - (int(sats[c // 2].numel()) if c in (0, 2) else 0)
+        room = max(room, len(mine))
+        cuts = np.sort(rng.integers(0, room, len(mine)))
+        gaps = np.diff(np.concatenate([[0], cuts, [room]]))  # unique stretches before / between / after the copies
+        u = torch.randint(0, 4, (int(room),), dtype=torch.uint8, device=dev, generator=gen)
+        parts, off = [], 0
+        for j, x in enumerate(mine):
+            parts.append(u[off:off + int(gaps[j])])
+            off += int(gaps[j])
+            parts.append(x)
+            if c in (0, 2) and j == len(mine) // 2:
+                parts.append(sats[c // 2])
+        parts.append(u[off:])
+        base.append(torch.cat(parts)[:L].contiguous())
+    del pieces, sats
+    genomes = []
+    for g in range(G):
+        contigs = []
+        for b in base:
+            t = b
+            if g:
+                mut = torch.rand(b.shape, device=dev, generator=gen) < d
+                t = torch.where(mut, (b + torch.randint(1, 4, b.shape, dtype=torch.uint8, device=dev, generator=gen)) & 3, b)
+            a = acgt[t.long()]
+            for p in rng.integers(1000, int(b.numel()) - 2000, 3).tolist():
+                a[p:p + 500] = ord("N")
+            contigs.append(a)
+        genomes.append(contigs)
+    what = (f"{G} x {C * L / 1e6:g} Mb, plant-like: {100 * (te_bases + 2e6) / total:.0f} % of every genome is repeats — {families} transposable-"
+            f"element families (elements of {int(lens.min())}-{int(lens.max())} b, {int(copies.min())}-{int(copies.max())} copies each, copies "
+            f"{100 * ages.min():.0f}-{100 * ages.max():.0f} % off their consensus, {len(order)} copies in all) scattered through unique sequence, two 1-Mb "
+            f"tandem arrays of a 178-b satellite, three 500-N gaps per chromosome; genomes = the ancestor + {100 * d:g} % SNPs")
+    return genomes, what
 
 
 def sharded_leg(ctx, dev, args, rank, world, dist, steps, warmup, nblocks=None):
@@ -724,6 +967,7 @@ def main():
     ap.add_argument("--no-sharded-leg", action="store_true", help="skip the genome-sharded pipeline leg")
     ap.add_argument("--no-e2e", action="store_true", help="skip the files-to-files leg (Index.run() on FASTA files of this shape)")
     ap.add_argument("--no-robustness", action="store_true", help="skip the robustness legs (inversions + shuffled contig order; repeat family)")
+    ap.add_argument("--no-config5", action="store_true", help="skip the BASELINE configs[4] leg (8 x 3 Gb, d=0.05, 8 genome blocks as passes on this GPU)")
     ap.add_argument("--cpu-sample-mb", type=float, default=20.0, help="bases per thread of the CPU baseline leg (about 12 s of CPU work)")
     ap.add_argument("--emulate-rank", type=str, default="", metavar="R/N",
                     help="one process plays rank R of an N-rank contig-sharded run (no collective): the N x longer "
@@ -849,7 +1093,8 @@ def main():
     if counters is not None and groups > 1:
         # a rank of a multi-GPU run launches the profiled kernel over as many positions, against an N x larger table:
         # the instruction count per position carries over, the HBM traffic of the one-GPU profile does not
-        counters = {"SQ_INSTS_VALU": counters.get("SQ_INSTS_VALU"), "profiled_on": "one GPU (profiles/traffic.json)"}
+        counters = {"SQ_INSTS_VALU": counters.get("SQ_INSTS_VALU"), "profiled_on": "one GPU (profiles/traffic.json)",
+                    "round": counters.get("round"), "file_sha16": counters.get("file_sha16"), "sources_match": counters.get("sources_match")}
     shape = (G, round(args.genome_mb), k)
     baseline_config = {(8, 100, 21): "BASELINE.json configs[1]", (27, 135, 21): "BASELINE.json configs[2] at full size",
                        (64, 200, 31): "BASELINE.json configs[3] at full size, all 64 genomes anchored",
@@ -887,6 +1132,7 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,
+        "timed_region_s": elapsed,  # (the launch gets 3-5 % faster once the clock has settled: DESIGN.md section 4)
         "higher_is_better": True,
         "scaling": "strong" if strong else "weak",
         "vs_baseline": None,
@@ -897,8 +1143,9 @@ def main():
             "workload": workload,
             "positions_per_step_per_gpu": pos_per_step,
             "table_keys": st["nkeys"], "table_bytes": st["bytes"], "keys_per_128B_line": round(st["nkeys"] / max(1, st["nbuckets"]), 3),
-            "table_rehashed": bool(pg_rehashed),
-            "table_build_s": pg.build_s, "table_spill_fraction": pg.table.spill()[0], "table_slots_per_line": pg.table.spill()[1],
+            "table_rehashed": bool(pg_rehashed), "minimizer_length": pg.table.minimizer,
+            "table_built_for_coscheduled_anchors": pg.coscheduled,
+            "table_build_s": pg.build_s, "table_spill_fraction": pg.table.measure_spill(), "table_slots_per_line": pg.table.spill()[1],
             "probes_per_position": (G + 63) // 64, "nbytes": (G + 7) // 8,
             "colsums": not args.no_colsums,
             "launches_per_step": len(results),
@@ -910,8 +1157,20 @@ def main():
     }
 
     if world == 1 and not args.per_genome_launches and not args.no_compare:
-        # for comparison only (outside the timed region): the same work as one launch per genome
-        alt, _ = make_results(ctx, pg, not args.no_colsums, True, 0)
+        # for comparison only (outside the timed region): the same work as one launch per genome — what a single-anchor
+        # Index.run(), the run_anchor CLI with one FASTA or unrelated sequences get — against the table the product builds
+        # for THAT mode (PanTable(coscheduled=1): how a table will be probed decides its minimizer window)
+        from panagram_amd import engine as _engine
+        pg1 = pg
+        if args.minimizer < 0 and not pg_rehashed:
+            t1 = _engine.PanTable(ctx, k, G, expected_keys=int(st["nkeys"] * 1.02) + 1024, coscheduled=1)
+            tb1 = time.perf_counter()
+            for g in range(G):
+                t1.insert_seqset(g, pg.seqsets[g])
+            ctx.synchronize()
+            pg1 = type("PerGenomeTable", (), dict(table=t1, seqsets=pg.seqsets, G=G, pieces=None, contig_lens=pg.contig_lens))()
+            pg1_build_s = time.perf_counter() - tb1
+        alt, _ = make_results(ctx, pg1, not args.no_colsums, True, 0)
 
         def alt_step():
             for r in alt:
@@ -924,7 +1183,9 @@ def main():
         dt = timed_steps(alt_step, 3, 0, 1, dev, None)
         tma = [r.timing_mean() for r in alt]
         pgl = {"value": pos_per_step * 3 / dt, "k_probe_ms_per_launch": float(np.mean([t[0] for t in tma])),
-               "positions_per_launch": pos_per_step / len(alt)}
+               "positions_per_launch": pos_per_step / len(alt), "minimizer_length": pg1.table.minimizer,
+               "table": ("its own: built for one launch per genome (PanTable(coscheduled=1)) in %.3f s" % pg1_build_s) if pg1 is not pg
+                        else "the timed region's"}
         if counters is not None and counters.get("per_genome_launches"):
             c2 = counters["per_genome_launches"]
             s2 = pgl["k_probe_ms_per_launch"] / 1e3
@@ -937,6 +1198,8 @@ def main():
         out["config"]["per_genome_launches_value"] = pgl["value"]
         for r in alt:
             r.close()
+        if pg1 is not pg:
+            pg1.table.close()
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         nthreads = min(G, engine.usable_cpus())
@@ -1010,6 +1273,11 @@ def main():
             out["config"]["other_shapes"] = [north_star_leg(ctx, dev, args)]
         except Exception as e:
             out["config"]["other_shapes"] = [{"error": f"{type(e).__name__}: {e}"}]
+    if world == 1 and default_shape and not args.no_config5:
+        try:
+            out["config"]["config5_leg"] = config5_leg(ctx, dev, args)
+        except Exception as e:
+            out["config"]["config5_leg"] = {"error": f"{type(e).__name__}: {e}"}
     if watchdog is not None:
         watchdog.cancel()
     if rank == 0:

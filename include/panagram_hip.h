@@ -51,7 +51,8 @@ const char *pg_last_error(void);
 /* library version string, e.g. "panagram_hip 0.2 gfx950" */
 const char *pg_version(void);
 /* k-mer positions per tile: the unit of a launch, of pg_result_coschedule's pieces and of the bit-column blocks
- * (64 bytes per tile and genome) */
+ * (pg_tile_positions() / 8 bytes per tile and genome — one u64 per 64 positions; 128 bytes with today's tiles of 1024.
+ * Size buffers with pg_result_columns_bytes / pg_result_columns_bytes_range, never with a constant) */
 uint32_t pg_tile_positions(void);
 
 /* ---- context ---------------------------------------------------------- */
@@ -157,6 +158,9 @@ int pg_sketch_destroy(pg_sketch *sk);
 int pg_table_rehash(pg_table *tbl, double keys_per_bucket);
 /* as of the last pg_table_rehash: fraction of keys outside their home line, slots per line */
 int pg_table_spill(const pg_table *tbl, double *fraction, uint32_t *slots);
+/* the same fraction measured NOW, on the table as it stands (one pass over its lines): a table built in place and never
+ * re-hashed — what Index.run() anchors against — has no "last re-hash".  Diagnostic; no reference counterpart. */
+int pg_table_measure_spill(pg_table *tbl, double *fraction);
 /* export group db_idx as (key, counter) pairs, unsorted; *n receives the count
  * (call with keys==NULL to query).  Lets the caller write a KMC1 database the
  * reference can open. */
@@ -177,6 +181,15 @@ int pg_table_set_minimizer(pg_table *tbl, int m);
  * PG_TABLE_WMAX / default cap), the genome count (0: unknown; more than 64 = the split layout).  What it encodes — window cost against merged minimizer groups — is measured in
  * profiles/r4b_m_sweep.txt; no reference counterpart (KMC's own signature length is fixed at 9, kmc_file.h). */
 int pg_minimizer_length(int k, uint64_t expected_keys, uint64_t first_len, int wmax, int ngenomes);
+/* How the table will be PROBED decides the window too: `coscheduled` = the number of anchor genomes one launch anchors side
+ * by side (pg_result_coschedule*; 0: not known, taken as several — what pg_minimizer_length assumes; 1: one genome per
+ * launch, no partner: a single-anchor `panagram index` (index.py:1012, one Snakemake job per anchor), `run_anchor` with one
+ * FASTA (cpp/anchor.cpp:217-223 with argc == 5), a py_kmc_api-style GetCountersForRead caller (index.py:934-935)).  Without a
+ * partner every table line comes from HBM and the launch's time follows the lines per position, which a wider window
+ * lowers (profiles/r5_m_sweep_pergenome.txt).  pg_table_set_coscheduled tells an EMPTY table (before
+ * the first insert / load); pg_minimizer_length_for is the rule itself. */
+int pg_table_set_coscheduled(pg_table *tbl, int anchors);
+int pg_minimizer_length_for(int k, uint64_t expected_keys, uint64_t first_len, int wmax, int ngenomes, int coscheduled);
 
 /* ---- sequences: 2-bit packed contigs resident in HBM -------------------
  * Reference: the FASTA record strings handed to write_bits / _write_bitmap

@@ -547,10 +547,12 @@ def window_stats(rows: np.ndarray, ngenomes: int, starts, ends) -> Tuple[np.ndar
 
 # ---------------------------------------------------------------------------
 # genome-sharded exchange: compact bit columns <-> rows.  Layout restated from
-# include/panagram_hip.h: tile t (512 positions of one contig) owns 8 slots of `width` u64 words;
-# word (8 t + s) * width + j holds genome g0 + j at positions 64 s .. 64 s + 63 of the tile (bit l).
+# include/panagram_hip.h: tile t (`tile` = pg_tile_positions() positions of one contig: 1024 today, 512 until round 4)
+# owns ns = tile / 64 slots of `width` u64 words; word (ns t + s) * width + j holds genome g0 + j at positions
+# 64 s .. 64 s + 63 of the tile (bit l).  `tile` has no default: a caller that guesses the engine's tile gets blocks of
+# another geometry without any error.
 # ---------------------------------------------------------------------------
-def extract_columns(contig_rows: Sequence[np.ndarray], ngenomes: int, g0: int, width: int, tile: int = 512) -> np.ndarray:
+def extract_columns(contig_rows: Sequence[np.ndarray], ngenomes: int, g0: int, width: int, *, tile: int) -> np.ndarray:
     """(``tile``: positions per tile of the engine whose blocks these are — pg_tile_positions(); a tile owns tile / 64 slots)"""
     tiles, ns = [], tile // 64
     for rows in contig_rows:
@@ -566,7 +568,7 @@ def extract_columns(contig_rows: Sequence[np.ndarray], ngenomes: int, g0: int, w
     return np.concatenate(tiles) if tiles else np.zeros(0, np.uint8)
 
 
-def merge_columns(blocks: Sequence[np.ndarray], contig_nkmers: Sequence[int], ngenomes: int, per: int, tile: int = 512) -> List[np.ndarray]:
+def merge_columns(blocks: Sequence[np.ndarray], contig_nkmers: Sequence[int], ngenomes: int, per: int, *, tile: int) -> List[np.ndarray]:
     nbytes = (ngenomes + 7) // 8
     out, off, ns = [], 0, tile // 64
     for nk in contig_nkmers:

@@ -53,6 +53,7 @@ PROTOTYPES = {
     "pg_table_stats": (C.c_int, [_vp, _u64p, _u64p, _u64p, _u64p]),
     "pg_table_rehash": (C.c_int, [_vp, C.c_double]),
     "pg_table_spill": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]),
+    "pg_table_measure_spill": (C.c_int, [_vp, C.POINTER(C.c_double)]),
     "pg_sketch_create": (C.c_int, [_vp, C.c_int, C.POINTER(_vp)]),
     "pg_sketch_add_seqset": (C.c_int, [_vp, _vp]),
     "pg_sketch_estimate": (C.c_int, [_vp, _u64p]),
@@ -67,6 +68,8 @@ PROTOTYPES = {
     "pg_table_minimizer": (C.c_int, [_vp]),
     "pg_table_set_minimizer": (C.c_int, [_vp, C.c_int]),
     "pg_minimizer_length": (C.c_int, [C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_int]),
+    "pg_minimizer_length_for": (C.c_int, [C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int]),
+    "pg_table_set_coscheduled": (C.c_int, [_vp, C.c_int]),
     "pg_seqset_create": (C.c_int, [_vp, C.c_uint32, _vp, _vpp]),
     "pg_seqset_destroy": (C.c_int, [_vp]),
     "pg_seqset_load_host": (C.c_int, [_vp, C.c_uint32, _vp, C.c_uint64]),

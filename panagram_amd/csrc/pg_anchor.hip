@@ -917,7 +917,11 @@ __attribute__((amdgpu_num_sgpr(80))) void k_probe(const SubTable st, const uint6
 #if PG_RID_ADDC
         // (a batch without runs: s_ff1 of an empty mask is -1, v_readlane takes it modulo 64 — lane 63's line, a line of the table
         // like any other, fetched and scanned by no lane: no test for the empty mask)
-        f.padline = (uint32_t)__builtin_amdgcn_readlane((int)f.line, __builtin_ctzll(f.lmask) & 63);  // (wave-uniform)
+        // (the instruction itself, not __builtin_ctzll: ctz of 0 is undefined to the COMPILER — it may fold anything — while
+        // s_ff1_i32_b64 is defined by the ISA to return -1; __ffsll - 1 is defined too and costs two scalar instructions more)
+        int first_run;
+        asm("s_ff1_i32_b64 %0, %1" : "=s"(first_run) : "s"(f.lmask));
+        f.padline = (uint32_t)__builtin_amdgcn_readlane((int)f.line, first_run & 63);  // (wave-uniform)
 #else
         f.padline = f.lmask ? (uint32_t)__builtin_amdgcn_readlane((int)f.line, __builtin_ctzll(f.lmask)) : 0u;  // (wave-uniform)
 #endif

@@ -97,6 +97,7 @@ struct pg_table {
     int k, ngenomes, ndbs;
     uint32_t m;  // minimizer length of every sub-table (0 = direct hashing)
     bool m_pinned = false;  // set by pg_table_set_minimizer: re-hashing keeps m
+    uint32_t cosched = 0;   // anchor genomes a probe launch will co-schedule (pg_table_set_coscheduled; 0: not told — several)
     uint64_t expected = 0;  // pg_table_create's expected_keys (0: unknown)
     uint64_t first_len = 0;  // k-mer positions of the first sequence set inserted into the empty table (settle_minimizer)
     uint64_t max_len = 0;    // ... of the longest one inserted so far (what a re-hash settles m from)
@@ -608,12 +609,37 @@ extern "C" int pg_minimizer_length(int k, uint64_t expected_keys, uint64_t first
     PG_API_END
 }
 
+extern "C" int pg_minimizer_length_for(int k, uint64_t expected_keys, uint64_t first_len, int wmax, int ngenomes, int coscheduled) {
+    PG_API_BEGIN
+    if (k < 1 || k > 32) return 0;
+    const uint32_t cap = wmax ? (uint32_t)std::min<int>((int)MZ_WMAX, std::max<int>((int)MZ_WMIN, wmax)) : window_cap();
+    return (int)minimizer_length((uint32_t)k, expected_keys, first_len, cap, (uint32_t)std::max(0, ngenomes), (uint32_t)std::max(0, coscheduled));
+    PG_API_END
+}
+
+// How the table will be probed (minimizer_length, pg_device.h): the number of anchor genomes one launch co-schedules.  Only
+// while the table is empty — the minimizer length decides every key's home line.
+extern "C" int pg_table_set_coscheduled(pg_table *t, int anchors) {
+    PG_API_BEGIN
+    if (!t) return fail(PG_E_INVALID, "table is NULL");
+    if (anchors < 0) return fail(PG_E_INVALID, "pg_table_set_coscheduled: %d anchors", anchors);
+    for (auto &s : t->subs)
+        if (s.count) return fail(PG_E_INVALID, "pg_table_set_coscheduled: the table already holds keys");
+    t->cosched = (uint32_t)anchors;
+    if (!t->m_pinned) {
+        t->m = minimizer_length((uint32_t)t->k, t->expected, t->first_len, window_cap(), (uint32_t)t->ngenomes, t->cosched);
+        for (auto &s : t->subs) s.d.m = t->m;
+    }
+    return PG_OK;
+    PG_API_END
+}
+
 static void settle_minimizer(pg_table *t, uint64_t positions) {
     if (t->m_pinned || t->first_len || positions == 0) return;
     for (auto &s : t->subs)
         if (s.count) return;
     t->first_len = positions;
-    t->m = minimizer_length((uint32_t)t->k, t->expected, positions, window_cap(), (uint32_t)t->ngenomes);
+    t->m = minimizer_length((uint32_t)t->k, t->expected, positions, window_cap(), (uint32_t)t->ngenomes, t->cosched);
     for (auto &s : t->subs) s.d.m = t->m;
 }
 
@@ -987,6 +1013,15 @@ extern "C" int pg_table_load_kmc(pg_table *t, int db_idx, const void *pre_, size
     if (int r = use_device(t->ctx)) return r;
     TABLE_WRITER(t);
     const int si = 0, w = db_idx;
+    {   // the first database into an EMPTY table: its record count is a key count the table was not created with — settle
+        // the minimizer length from it (and from how the table will be probed) while no key has a home line yet
+        bool empty = !t->m_pinned && !t->first_len;
+        for (auto &sh : t->subs) empty = empty && sh.count == 0;
+        if (empty && !t->expected) {
+            t->m = minimizer_length((uint32_t)t->k, H.total, 0, window_cap(), (uint32_t)t->ngenomes, t->cosched);
+            for (auto &sh : t->subs) sh.d.m = t->m;
+        }
+    }
     if (int r = ensure_room(t, si, H.total)) return r;
     hipStream_t st = t->ctx->stream;
     // chunks of whole records, about 256 MiB each, through two device buffers: the upload of chunk c+1 (pageable or
@@ -1127,7 +1162,7 @@ extern "C" int pg_table_rehash(pg_table *t, double keys_per_bucket) {
     if (!t->m_pinned) {  // the key count is known now: settle the minimizer length for it
         uint64_t most = 0;
         for (auto &s : t->subs) most = std::max<uint64_t>(most, s.count);
-        t->m = minimizer_length((uint32_t)t->k, most, t->max_len, window_cap(), (uint32_t)t->ngenomes);
+        t->m = minimizer_length((uint32_t)t->k, most, t->max_len, window_cap(), (uint32_t)t->ngenomes, t->cosched);
     }
     // Line width: 128-byte lines of 8 slots.  256-byte lines of 16 slots (PG_TABLE_SLOTS=16, a tuning
     // knob) keep a many-variant locus in ONE place at the price of two requests per line; measured,
@@ -1147,6 +1182,26 @@ extern "C" int pg_table_rehash(pg_table *t, double keys_per_bucket) {
         spilled += sp;
     }
     t->spill = keys ? (double)spilled / (double)keys : 0.0;
+    return PG_OK;
+    PG_API_END
+}
+
+// the same figure for the table AS IT STANDS (pg_table_spill answers as of the last re-hash: 0 for a table that was built in
+// place and never re-hashed — Index.run()'s, bench.py's): one pass over the table's lines (k_count_spill)
+extern "C" int pg_table_measure_spill(pg_table *t, double *fraction) {
+    PG_API_BEGIN
+    if (!t) return fail(PG_E_INVALID, "table is NULL");
+    if (int r = use_device(t->ctx)) return r;
+    TABLE_WRITER(t);
+    uint64_t keys = 0, spilled = 0;
+    for (size_t si = 0; si < t->subs.size(); ++si) {
+        uint64_t sp = 0;
+        if (int r = count_spill(t, (int)si, &sp)) return r;
+        keys += t->subs[si].count;
+        spilled += sp;
+    }
+    t->spill = keys ? (double)spilled / (double)keys : 0.0;
+    if (fraction) *fraction = t->spill;
     return PG_OK;
     PG_API_END
 }
@@ -1478,10 +1533,14 @@ extern "C" int pg_seqset_from_fasta(pg_ctx *ctx, const void *text_, uint64_t nby
         if (e_up == hipSuccess) e_up = hipStreamSynchronize(us);
         (void)hipStreamDestroy(us);
     };
-    try {
-        up.th = std::thread(upload);
-    } catch (const std::system_error &) {  // no thread to be had: the copy runs here, before the scan
-        upload();
+    if (nbytes < (1u << 20)) {
+        upload();  // (a small text: a thread and a stream per call cost more than the overlap brings)
+    } else {
+        try {
+            up.th = std::thread(upload);
+        } catch (const std::system_error &) {  // no thread to be had: the copy runs here, before the scan
+            upload();
+        }
     }
     struct Rec {
         std::string name;
@@ -1573,6 +1632,9 @@ extern "C" int pg_seqset_from_fasta(pg_ctx *ctx, const void *text_, uint64_t nby
             ok(hipStreamSynchronize(st));
         }
     }
+    // (an error may have come back with kernels still queued on st that read the text buffer — the upload ran on a stream of
+    // its own, nothing else orders them against the buffer's next user once it is back in the context's cache)
+    if (e != hipSuccess) (void)hipStreamSynchronize(st);
     hipFree(d_chunks);
     hipFree(d_chunk0);
     hipFree(d_base);

@@ -117,8 +117,15 @@ struct TableDesc {
 //   shorter than the genomes that follow must not talk m down).
 // m-mers longer than 16 bases use 64-bit arithmetic.
 constexpr uint32_t MZ_WMIN = 3, MZ_WMAX = 8;
+// `cosched`: how many anchor genomes a probe launch co-schedules against this table (0: not known — several, the product's
+// default; 1: the table will be probed one genome at a time — a single-anchor `panagram index`, the run_anchor CLI with one
+// FASTA, py_kmc_api-style GetCountersForRead callers, unrelated sequences).  Co-scheduled launches take most table lines
+// from L2 and are bound by instruction issue: the window's price is the shorter batch (the table above).  A launch WITHOUT a
+// partner fetches every line from HBM at the random-line rate of the memory system, and its time goes with the lines per
+// position, about 2 / (w + 1): the window's price is steeper there and the same rule picked the narrower window for both —
+// round 4 gained 1 % co-scheduled at configs[1] with m = 16 and lost 9 % per genome (125 -> 115 G k-mers/s).
 __host__ __device__ __forceinline__ uint32_t minimizer_length(uint32_t k, uint64_t expected_keys, uint64_t first_len = 0,
-                                                              uint32_t wmax = MZ_WMAX, uint32_t ngenomes = 0) {
+                                                              uint32_t wmax = MZ_WMAX, uint32_t ngenomes = 0, uint32_t cosched = 0) {
     if (k < 20 || k > 32) return 0;
     // (more than 64 genomes: the split layout's lines hold 16 keys, a merged group fits more often — half the penalty:
     // 128 x 40 Mb 83.6 / 80.7 / 76.6 G k-mers/s at m = 15 / 16 / 17, 128 x 10 Mb 74.5 / 72.6 / 69.0)
@@ -140,7 +147,9 @@ __host__ __device__ __forceinline__ uint32_t minimizer_length(uint32_t k, uint64
     }
     const uint32_t m_hi = k - (MZ_WMIN - 1);
     if (m_lo > m_hi) m_lo = m_hi;
-    const double wcost[9] = {0, 0, 0, 35.0, 19.5, 10.5, 3.5, 0.5, 0.0};  // percent, by window
+    const double wcost_co[9] = {0, 0, 0, 35.0, 19.5, 10.5, 3.5, 0.5, 0.0};   // percent, by window: co-scheduled launches
+    const double wcost_one[9] = {0, 0, 0, 62.0, 42.0, 26.0, 12.0, 2.0, 0.0};  // one launch per genome (profiles/r5_m_sweep_pergenome.txt)
+    const double *wcost = cosched == 1 ? wcost_one : wcost_co;
     uint32_t best = m_lo;
     double best_cost = 1e30;
     for (uint32_t m = m_lo; m <= m_hi; ++m) {

@@ -555,12 +555,22 @@ def run_index_sharded(index, rank: int, world: int, barrier: Optional[Callable[[
             for s_ in index.steps:
                 _remove_quietly(f"{b_}.{s_}.gz")
                 _remove_quietly(f"{b_}.{s_}.gzi")
+        # and what an aborted run of ANOTHER signature (other world size, plan or parameters: other base names) left here —
+        # nobody will ever read it, and it is GBs.  Under the claim, behind a complete assembly, every finished file of the
+        # directory is garbage: this run's units were all consumed above, and a rank that is rewriting a unit it took for
+        # stale works under *.tmp names until its rename (those, and only those, are left alone; it clears up behind itself).
+        _clear_stale_fragments(pdir)
         if lock is not None:
             _remove_quietly(lock)  # (the claim goes last; a rank that finds the directory again finds no marker)
         try:
             os.rmdir(pdir)
         except OSError:
-            pass
+            try:
+                left = sorted(os.listdir(pdir))
+            except OSError:
+                left = []
+            if left:
+                logger_info("%s: %d file(s) left in %s (another rank's temporary files: %s ...)", name, len(left), pdir, left[:3])
         return True
 
     def leftovers(name: str) -> None:
@@ -596,6 +606,25 @@ def run_index_sharded(index, rank: int, world: int, barrier: Optional[Callable[[
             leftovers(n)
     # (without a rendezvous — ranks started on their own, possibly one after the other — a rank cannot tell "another rank
     # will assemble this" from "nobody will": the rank that finishes last finds every genome complete and assembles it)
+
+
+def _clear_stale_fragments(pdir: str) -> int:
+    """Remove every finished fragment, index and marker of a genome's .parts directory — called under the assembly claim
+    once the genome's files are complete, when nothing in there can be needed again (see the call site).  Temporary files
+    (``*.tmp``, ``*.tmp.npz``: a live rank's unit in the making) and the claim file are not touched.  Returns the number
+    of files removed."""
+    n = 0
+    try:
+        files = os.listdir(pdir)
+    except OSError:
+        return 0
+    for f in files:
+        if f == "assemble.lock" or f.endswith(".tmp") or f.endswith(".tmp.npz"):
+            continue
+        if f.endswith((".npz", ".gz", ".gzi")):
+            _remove_quietly(os.path.join(pdir, f))
+            n += 1
+    return n
 
 
 def _remove_quietly(path: str) -> None:
@@ -992,33 +1021,57 @@ class ShardedAnchoring:
             self._part_table = table
         return self._part
 
-    def run_pass(self, table, part0: int, nparts: int, accumulate: bool, on_anchor_complete=None) -> None:
+    def run_pass(self, table, part0: int, nparts: int, accumulate: bool, on_anchor_complete=None, phase_s: Optional[dict] = None) -> None:
+        """``phase_s`` (measurement only: bench.py's config5_leg): a dict that receives the seconds this pass spends in
+        "probe", "extract" and "merge" — the context is synchronised after each stage, so the pass no longer overlaps
+        anything; never set by the product."""
+        import time
         pipe, per = self.pipe, self.per
         part = self._narrow(table) if (table is not None and self.merged is not None) else None
         ncontigs = len(self._contig_anchor)
         pending = None  # (group, slot, gather-done event) of the group whose gather is in flight
 
+        def now():
+            if phase_s is None:
+                return 0.0
+            self.ctx.synchronize()
+            return time.perf_counter()
+
+        def lap(name, t0):
+            if phase_s is None:
+                return t0
+            t1 = now()
+            phase_s[name] = phase_s.get(name, 0.0) + (t1 - t0)
+            return t1
+
         def settle(pend):
             i, slot, ev = pend
             pipe.main_waits(ev)  # (also what frees send[slot] for the next extract into it)
             stride = self.group_tiles[i] * self.col_bytes * per  # recv holds `world` blocks of this size, block j = genome block part0 + j
+            t0 = now()
             for a, c0, nc, toff in self.groups[i]:
                 if self.writer[a] != self.rank:
                     continue
                 self.container(a).merge_columns_range(self.recv[slot].data_ptr() + toff * self.col_bytes * per, part0, nparts, per,
                                                       c0, nc, accumulate=accumulate, part_stride_bytes=stride)
+                t0 = lap("merge", t0)
                 if on_anchor_complete is not None and self.last_group[a] == i:
                     on_anchor_complete(a, self.full[a])
+                    t0 = lap("statistics", t0)
 
         for i in range(len(self.groups)):
             slot, nbytes = i & 1, self.group_tiles[i] * self.col_bytes * per
             m0 = self.group_first[i]
             cnt = (self.group_first[i + 1] if i + 1 < len(self.groups) else ncontigs) - m0
+            t0 = now()
             if part is not None and self._direct:
                 part.run_columns_range(m0, cnt, per, self.send[slot].data_ptr())
+                lap("probe", t0)
             elif part is not None:
                 part.run_range(m0, cnt)
+                t0 = lap("probe", t0)
                 part.extract_columns_range(0, per, m0, cnt, self.send[slot].data_ptr())
+                lap("extract", t0)
             else:
                 self.send[slot].zero(nbytes)  # a rank without a block in this pass contributes zeros
             ready = pipe.mark_main()
@@ -1092,7 +1145,8 @@ def run_genome_sharded(index, nblocks: int, group=None, exchange_stats: Optional
     blocks = {b: [inputs[g] for g in range(b * per, min(N, (b + 1) * per)) if g in inputs] for b in my_blocks}
     tbl_mem = None
     if my_blocks:
-        tbl_mem = engine.PanTable(ctx, k, per, expected_keys=max(index._expected_keys(blk) for blk in blocks.values()))
+        tbl_mem = engine.PanTable(ctx, k, per, expected_keys=max(index._expected_keys(blk) for blk in blocks.values()),
+                                  coscheduled=max(1, len(anchors)))  # (a chunk group co-schedules every anchor's chunk)
     in_flight = 2 * index.writer_jobs(payload)  # anchors whose full-width rows wait for their writer: bounded
 
     def finished(a, res):

@@ -49,7 +49,8 @@ _ADOPT_LOCK = threading.Lock()
 
 
 def tile_positions() -> int:
-    """k-mer positions per tile (launch unit; a bit-column block holds 64 bytes per tile and genome)"""
+    """k-mer positions per tile (launch unit; a bit-column block holds tile_positions() // 8 bytes per tile and genome:
+    size buffers with AnchorResult.columns_bytes, never with a constant)"""
     return int(_lib.load().pg_tile_positions())
 
 
@@ -347,7 +348,10 @@ class KmerSketch:
 class PanTable(_Owner):
     """GPU-resident k-mer -> genome-mask table (replaces kmc/bitvec{i})."""
 
-    def __init__(self, ctx: Context, k: int, ngenomes: int, expected_keys: int = 0):
+    def __init__(self, ctx: Context, k: int, ngenomes: int, expected_keys: int = 0, coscheduled: int = 0):
+        """``coscheduled``: how many anchor genomes one probe launch will anchor side by side against this table (0: not
+        known = several; 1: one genome per launch, no co-scheduling partner) — it decides the minimizer window with the
+        key count (pg_table_set_coscheduled, include/panagram_hip.h)"""
         self.ctx = ctx
         self._lib = ctx._lib
         self.k, self.ngenomes = k, ngenomes
@@ -357,6 +361,12 @@ class PanTable(_Owner):
         check(self._lib.pg_table_create(ctx._h, k, ngenomes, expected_keys, C.byref(h)))
         self._h = h
         ctx._adopt(self)
+        if coscheduled:
+            self.set_coscheduled(coscheduled)
+
+    def set_coscheduled(self, anchors: int) -> None:
+        """tell an EMPTY table how it will be probed (see __init__)"""
+        check(self._lib.pg_table_set_coscheduled(self._h, int(anchors)))
 
     @staticmethod
     def bytes_for(k: int, ngenomes: int, expected_keys: int) -> int:
@@ -415,6 +425,12 @@ class PanTable(_Owner):
         f, n = C.c_double(), C.c_uint32()
         check(self._lib.pg_table_spill(self._h, C.byref(f), C.byref(n)))
         return f.value, n.value
+
+    def measure_spill(self) -> float:
+        """fraction of keys outside their minimizer's home line, measured now (one pass over the table)"""
+        f = C.c_double()
+        check(self._lib.pg_table_measure_spill(self._h, C.byref(f)))
+        return f.value
 
     @property
     def minimizer(self) -> int:

@@ -499,8 +499,11 @@ class Index:
         scope = "all"
         import time
         t_start, t_inputs_before = time.perf_counter(), self.timings.get("load_inputs_s", 0.0)
+        # how the table will be probed decides its minimizer window with the key count (pg_table_set_coscheduled): the anchor
+        # genomes of a batch share ONE co-scheduled launch; a single anchor has no partner
+        cosched = max(1, len(keep if insert_sets is None else insert_sets))
         if self.kmc.use_existing and have:
-            tbl = engine.PanTable(self.context, self.k, self.ngenomes)
+            tbl = engine.PanTable(self.context, self.k, self.ngenomes, coscheduled=cosched)
             for i, p in enumerate(self.bitvec_prefixes):
                 tbl.load_kmc_files(i, p)
             logger.info("KMC Database Loaded")
@@ -526,7 +529,7 @@ class Index:
                 est = sketch.estimate()
                 sketch.close()
                 expected = est + est // 32 + 1024
-                tbl = engine.PanTable(self.context, self.k, self.ngenomes, expected_keys=expected)
+                tbl = engine.PanTable(self.context, self.k, self.ngenomes, expected_keys=expected, coscheduled=cosched)
                 for name, ss in insert_sets.items():
                     tbl.insert_seqset(self.genomes[name].id, ss)
                 for name, g, ss, _, _ in inputs:
@@ -537,7 +540,7 @@ class Index:
             else:
                 filtered = bool(can_filter and first and rest)
                 expected = self._expected_keys(first if filtered else inputs)
-                tbl = engine.PanTable(self.context, self.k, self.ngenomes, expected_keys=expected)
+                tbl = engine.PanTable(self.context, self.k, self.ngenomes, expected_keys=expected, coscheduled=cosched)
                 for name, g, ss, min_count, _ in (first + rest if filtered else inputs):
                     if filtered and name not in keep:
                         tbl.update_seqset(g.id, ss)
@@ -638,6 +641,8 @@ class Index:
             print("Prepared. Run 'python -m panagram_amd index <dir>' to build the index")
             return
         from concurrent.futures import ThreadPoolExecutor
+        import time
+        self._run_t0, self._cpu_t0 = time.perf_counter(), time.process_time()
         os.makedirs(self.get_subdir("logs"), exist_ok=True)
         own_group = self._ensure_process_group()
         try:
@@ -894,6 +899,7 @@ class Genome:
         # one basicConfig — per genome; here many genomes share a process, each with a handler of its own
         self.log = logging.getLogger(f"{__name__}.genome.{name}")
         self._log_handler = None
+        self._bench_t0 = None  # when this genome's anchoring began (write_benchmark)
         if self.anchored and os.path.exists(self.chrs_fname):
             self.load_chrs()
 
@@ -997,8 +1003,46 @@ class Genome:
             self.log.setLevel(logging.INFO)
             self._log_handler = h
 
+    def write_benchmark(self) -> None:
+        """logs/anchor.<name>.benchmark.txt in the format of Snakemake's ``benchmark:`` directive — the reference's own timing
+        artefact for this step (panagram/workflow/Snakefile:43-44; cpp/Snakefile:43-44): one header line, one row, tab-separated
+        ``s  h:m:s  max_rss  max_vms  max_uss  max_pss  io_in  io_out  mean_load  cpu_time`` (seconds; MB; percent).  The
+        reference runs one process per anchor; here every anchor of a run shares one process per GPU, so ``s`` is the wall
+        time from the moment this genome's anchoring began (its log's "Anchoring Started": the launch it shares with the
+        other anchors of its batch) until its files were complete, and the memory / IO / CPU columns are the process's."""
+        import resource
+        import time
+        if not self.index.write_mode:
+            return
+        t0 = self._bench_t0 if self._bench_t0 is not None else getattr(self.index, "_run_t0", None)
+        if t0 is None:
+            return
+        secs = max(0.0, time.perf_counter() - t0)
+        cpu = max(0.0, time.process_time() - getattr(self.index, "_cpu_t0", 0.0))
+        rss = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024.0
+        vms = uss = pss = io_in = io_out = float("nan")
+        try:
+            import psutil
+            pr = psutil.Process()
+            mi = pr.memory_full_info()
+            vms, uss, pss = mi.vms / 2 ** 20, mi.uss / 2 ** 20, getattr(mi, "pss", float("nan")) / 2 ** 20
+            io = pr.io_counters()
+            io_in, io_out = io.read_chars / 2 ** 20, io.write_chars / 2 ** 20
+        except Exception:  # noqa: BLE001 — psutil missing or /proc restricted: the columns stay NaN, as Snakemake writes them then
+            pass
+        hms = f"{int(secs // 3600)}:{int(secs % 3600 // 60):02d}:{int(secs % 60):02d}"
+        os.makedirs(self.index.get_subdir("logs"), exist_ok=True)
+        path = os.path.join(self.index.get_subdir("logs"), f"anchor.{self.name}.benchmark.txt")
+        fields = [f"{secs:.4f}", hms] + [f"{x:.2f}" for x in (rss, vms, uss, pss, io_in, io_out, 100.0 * cpu / secs if secs > 0 else 0.0, cpu)]
+        with open(path + ".tmp", "w") as f:
+            f.write("s\th:m:s\tmax_rss\tmax_vms\tmax_uss\tmax_pss\tio_in\tio_out\tmean_load\tcpu_time\n" + "\t".join(fields) + "\n")
+        os.replace(path + ".tmp", path)
+
     def ensure_log(self):
         """logs/anchor.<name>.log.txt, unless a log has been set up already"""
+        if self._bench_t0 is None:
+            import time
+            self._bench_t0 = time.perf_counter()
         if self._log_handler is None and self.index.write_mode:
             os.makedirs(self.index.get_subdir("logs"), exist_ok=True)
             self.setup_log(os.path.join(self.index.get_subdir("logs"), f"anchor.{self.name}.log.txt"))
@@ -1109,6 +1153,7 @@ class Genome:
             os.path.join(self.prefix, "total_paircounts.csv"))
         chrs = pd.DataFrame(chr_rows, columns=["name", "id", "size", "gene_count"]).set_index("name")
         self.set_chrs(chrs)
+        self.write_benchmark()
         self.chrs.to_csv(self.chrs_fname, sep="\t")  # written last: it is the rule's completion marker
 
     def run_anchor(self, table: engine.PanTable, logfile: Optional[str] = None, bgzf_threads: Optional[int] = None):
@@ -1188,11 +1233,12 @@ def run_anchor_cli(argv: Sequence[str], device: int = 0) -> int:
     ctx = engine.Context(device)
     prefixes = [os.path.join(root, "kmc", f"bitvec{i}") for i in range(ndbs)]
     k = engine.kmc_kmer_length(np.memmap(prefixes[0] + ".kmc_pre", dtype=np.uint8, mode="r"))
-    tbl = engine.PanTable(ctx, k, ngenomes)
+    anchors = list(zip(pairs[0::2], pairs[1::2]))
+    # (how the table will be probed decides its minimizer window with the key count: one FASTA has no co-scheduling partner)
+    tbl = engine.PanTable(ctx, k, ngenomes, coscheduled=max(1, len(anchors)))
     for i, p in enumerate(prefixes):
         tbl.load_kmc_files(i, p)
     nb_row = (ngenomes + 7) // 8
-    anchors = list(zip(pairs[0::2], pairs[1::2]))
     bgzf_level = int(os.environ.get("PG_BGZF_LEVEL", "-2"))
 
     def write_anchor(res, name, lo, names):

@@ -61,7 +61,8 @@ class KMCFile:
             return False
         hoff = struct.unpack("<I", pre[-8:-4])[0]
         self._k = struct.unpack("<I", pre[len(pre) - 8 - hoff:len(pre) - 4 - hoff])[0]
-        self._tbl = engine.PanTable(_context(self._device), self._k, 32)
+        # (coscheduled=1: GetCountersForRead answers one sequence at a time — no co-scheduling partner)
+        self._tbl = engine.PanTable(_context(self._device), self._k, 32, coscheduled=1)
         self._tbl.load_kmc1(0, pre, suf)  # raises PanagramHipError on an ill-formed DB
         return True
 

@@ -60,11 +60,11 @@ def _worker(rank, world, port, root, name):
         for nk in nks:
             rows_part.append(part.reshape(-1, nb)[off:off + nk])
             off += nk
-        mine = po.extract_columns(rows_part, n, rank * per, per)
+        mine = po.extract_columns(rows_part, n, rank * per, per, tile=1024)
         allb = gather_columns(torch.from_numpy(mine)).numpy()
         blocks = np.split(allb, world)
         assert np.array_equal(blocks[rank], mine)
-        merged = po.merge_columns(blocks, nks, n, per)
+        merged = po.merge_columns(blocks, nks, n, per, tile=1024)
         assert np.array_equal(np.concatenate(merged).reshape(-1), full)
     finally:
         dist.destroy_process_group()
@@ -159,6 +159,11 @@ def _check_tree(idx_dir, fx):
         tp = pd.read_csv(os.path.join(adir, "total_paircounts.csv"), index_col="name")
         assert np.array_equal(tp["count"].to_numpy(), ora["colsums"])
         assert os.path.exists(os.path.join(idx_dir, "logs", f"anchor.g{g}.log.txt"))
+        # the reference's own timing artefact for the step (Snakemake's benchmark: file, workflow/Snakefile:43-44)
+        bench = open(os.path.join(idx_dir, "logs", f"anchor.g{g}.benchmark.txt")).read().split("\n")
+        assert bench[0].split("\t") == ["s", "h:m:s", "max_rss", "max_vms", "max_uss", "max_pss", "io_in", "io_out", "mean_load", "cpu_time"]
+        row = bench[1].split("\t")
+        assert len(row) == 10 and float(row[0]) >= 0 and row[1].count(":") == 2 and float(row[2]) > 0 and bench[2] == ""
 
 
 def _index_run_worker(rank, world, port, idx_dir, shard, nblocks, chunk):
@@ -186,6 +191,29 @@ def test_world2_index_run_genome_sharded(name, nblocks, tmp_path):
     idx_dir = _prepare_index(tmp_path, fx)
     port = 29500 + (os.getpid() % 2000)
     mp.spawn(_index_run_worker, args=(2, port, idx_dir, "genome", nblocks, 1500), nprocs=2, join=True)
+    _check_tree(idx_dir, fx)
+
+
+@pytest.mark.parametrize("shard,nblocks,chunk", [("genome", 8, 1500), ("replicated", 0, 1 << 27)])
+def test_world8_index_run_dress_rehearsal(shard, nblocks, chunk, tmp_path):
+    """EIGHT ranks (the node size BASELINE.json's multi-GPU configs name) through Index.run() itself over gloo, the
+    stand-in engine below it.  genome / 8 blocks on "n8_k21" is configs[4]'s layout exactly — ONE genome per rank, one
+    pass, every rank probing every anchor position against its one-genome table, 8 bit columns all-gathered per chunk
+    group (several groups per anchor) and merged on the anchors' writers; replicated = pieces of homology classes dealt to
+    8 ranks, fragments assembled without a rendezvous.  The tree equals the reference binary's golden outputs.  The
+    reference's only parallel axis is one OpenMP thread per anchor FASTA (cpp/anchor.cpp:217-223)."""
+    fx = H.load_case("n8_k21")
+    idx_dir = _prepare_index(tmp_path, fx)
+    port = 29500 + (os.getpid() % 2000)
+    env_before = os.environ.get("PG_MIN_PIECE")
+    os.environ["PG_MIN_PIECE"] = "500"  # (the fixture's contigs are a few kb: cut them all the same)
+    try:
+        mp.spawn(_index_run_worker, args=(8, port, idx_dir, shard, nblocks, chunk), nprocs=8, join=True)
+    finally:
+        if env_before is None:
+            os.environ.pop("PG_MIN_PIECE", None)
+        else:
+            os.environ["PG_MIN_PIECE"] = env_before
     _check_tree(idx_dir, fx)
 
 
@@ -303,7 +331,7 @@ def _pieces_worker(rank, world, port, idx_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_index_run_deals_pieces_of_homology_classes(world, tmp_path, monkeypatch):
     """Index.run() with several ranks and a table that fits: chromosomes are cut into aligned pieces, every rank
     anchors ITS pieces of EVERY genome (co-scheduled), fragments are assembled by whoever finds a genome complete.
@@ -430,6 +458,14 @@ def test_a_run_over_an_aborted_runs_fragments_writes_the_same_tree(tmp_path, mon
     stale = sorted(f for f in os.listdir(parts) if f.endswith(".npz"))
     assert stale and not (tmp_path / "many" / "anchor" / "g0" / "chrs.tsv").exists()
     assert not [f for f in os.listdir(parts) if f.endswith(".tmp")]
+    # ... and an aborted run of ANOTHER signature (three ranks: other pieces, other base names) left its units there too:
+    # nobody will read them; the assembly clears them away instead of leaving the directory behind with GBs in it
+    with np.load(parts / stale[0]) as z:
+        foreign = {x: z[x] for x in z.files}
+    foreign["sig"] = np.array("a run with three ranks")
+    np.savez(parts / "0.777.npz", **foreign)
+    for sfx in ("1.gz", "1.gzi", "50.gz", "50.gzi"):
+        (parts / f"0.777.{sfx}").write_bytes(b"left behind")
     port = 29500 + (os.getpid() % 2000)
     mp.spawn(_pieces_worker, args=(2, port, str(tmp_path / "many")), nprocs=2, join=True)
     _trees_equal(tmp_path / "one", tmp_path / "many", ["g0", "g1", "g2"])

@@ -368,6 +368,28 @@ def test_two_processes_on_one_gpu(name, shard, nblocks, chunk, exchange, tmp_pat
     _check_tree(out, fx, gzi_like_reference=shard != "replicated")
 
 
+@pytest.mark.parametrize("shard,nblocks,chunk", [("genome", 8, 1500), ("replicated", 0, 1 << 27)])
+def test_eight_processes_on_one_gpu(shard, nblocks, chunk, tmp_path, monkeypatch):
+    """An 8-rank dress rehearsal on the one device — the first contact with an 8-GPU node should not be the first time
+    anything runs at world = 8.  genome / 8 blocks on "n8_k21" is BASELINE.json configs[4]'s layout exactly: EIGHT real-engine
+    processes, one genome's table each, every rank probing every anchor position (several chunk groups per anchor), the 8
+    bit columns exchanged per group and merged on the anchors' writers, ONE pass.  RCCL refuses several ranks on one device,
+    so the exchange takes the product's host route (PG_SHARD_EXCHANGE=host: columns to pinned memory, all-gather over gloo,
+    back to the GPU) — what that route is for.  replicated: pieces of homology classes dealt to 8 ranks, fragments assembled
+    without a rendezvous.  Both trees equal the reference binary's golden outputs (cpp/anchor.cpp:139-164, 217-223)."""
+    import torch.multiprocessing as mp
+    import os
+    monkeypatch.setenv("PG_SHARD_EXCHANGE", "host")
+    monkeypatch.setenv("PG_MIN_PIECE", "500")  # (the fixture's contigs are a few kb: cut them all the same)
+    fx = H.load_case("n8_k21")
+    s = _write_case(tmp_path, fx)
+    out = tmp_path / "idx"
+    port = 29600 + (os.getpid() % 2000)
+    mp.spawn(_two_rank_worker, args=(8, port, str(s), str(out), int(fx["k"]), [f"g{g}" for g in fx["anchors"]], shard, nblocks, chunk),
+             nprocs=8, join=True)
+    _check_tree(out, fx, gzi_like_reference=shard != "replicated")
+
+
 @pytest.mark.parametrize("shard,nblocks", [(None, 0), ("genome", 2)])
 def test_cli_under_torchrun_joins_the_group_itself(shard, nblocks, tmp_path):
     """`python -m torch.distributed.run --nproc-per-node 2 -m panagram_amd index …`: nobody initialises torch.distributed
@@ -443,3 +465,44 @@ def test_columns_of_wide_blocks_round_trip(ctx, n, per):
         assert np.array_equal(acc.download(ci, want_bitmap100=False)[0], rows[ci])
     for x in (one, acc, whole, ss, tbl):
         x.close()
+
+
+def test_config5_as_specified_at_reduced_length_through_the_pass_mode(ctx):
+    """BASELINE.json configs[4]'s parameters — 8 genomes in 24 contigs each, k = 21, d = 0.05, genome_blocks = 8 (one genome
+    per block) — at a tenth of the length (8 x 300 Mb: 2.4 x 10^9 positions, 3 x 10^8 keys per block table), on one GPU
+    through the product's pass mode (distributed.ShardedAnchoring: the block tables built one after another in ONE
+    allocation, every anchor position probed against each, the block's bit column OR-ed into the full rows) — the
+    same function ``bench.py`` runs at full size as ``config5_leg``.  The rows' head (anchor 0) and tail (the end of
+    anchor 5's last contig) equal the CPU oracle's, whose k-mer DB is built by brute force with torch; every anchor
+    holds all of its own k-mers.  Byte layout: cpp/anchor.cpp:139-164."""
+    import types
+    import bench
+    dev = torch.device("cuda", 0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    try:
+        out = bench.config5_leg(ctx, dev, types.SimpleNamespace(seed=1234), genome_mb=300, contigs=24, sample_n=200_000)
+    finally:
+        ctx.set_stream(None)
+    assert out["rows_equal_gpu"] is True, out["rows_check"]
+    assert out["anchors_hold_all_own_kmers"] and out["anchors_completed"] == 8
+    assert out["genome_blocks"] == 8 and len(out["passes"]) == 8 and out["chunk_groups_per_pass"] >= 2
+    assert out["positions"] == 8 * 24 * (12_500_000 - 20)
+    # d = 0.05: a derived genome shares 0.95^21 = 34 % of its k-mers with the base genome — the blocks' tables are as large
+    # as each other, and their union (what ONE table would have to hold) is several times one block's
+    keys = [p["table_keys"] for p in out["passes"]]
+    assert min(keys) > 0.95 * max(keys) and 2.9e8 < max(keys) < 3.0e8
+
+
+def test_config5_pass_mode_with_many_chunk_groups(ctx):
+    """the same at 8 x 24 Mb with chunks of 2^20 positions: every anchor's contigs spread over 24 chunk groups (the
+    double-buffered extract / merge pipeline turns over many times), heads and tails again against the oracle"""
+    import types
+    import bench
+    dev = torch.device("cuda", 0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    try:
+        out = bench.config5_leg(ctx, dev, types.SimpleNamespace(seed=77), genome_mb=24, contigs=24, sample_n=100_000,
+                                chunk_positions=1 << 20)
+    finally:
+        ctx.set_stream(None)
+    assert out["rows_equal_gpu"] is True and out["anchors_hold_all_own_kmers"] and out["chunk_groups_per_pass"] == 24

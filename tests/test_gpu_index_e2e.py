@@ -796,3 +796,30 @@ def test_bench_gpus_2_spawns_two_ranks_with_disjoint_work(scaling):
         assert abs(d["value"] - total / (d["ms_per_step"] * 1e-3)) < 1e-3 * d["value"]
         loads = [int(x) for x in d["config"]["parallelism"].split("[")[1].split("]")[0].split(",")]
         assert len(loads) == 2 and sum(loads) == total and max(loads) <= 1.1 * total / 2
+
+
+def test_bench_gpus_8_dress_rehearsal_on_one_device():
+    """`python bench.py --gpus 8 --scaling strong` on a configs[2]-shaped pangenome (27 genomes x 5 chromosomes, a tenth of
+    the length) with all 8 ranks on the one device over gloo (PG_BENCH_ONE_DEVICE / PG_BENCH_BACKEND: the numbers mean
+    nothing, the code path is the 8-GPU one the driver will launch): eight ranks answer, their pieces of homology classes are
+    disjoint and cover the pangenome exactly, and the fullest rank carries at most 15 % more than the mean."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PG_BENCH_ONE_DEVICE="1", PG_BENCH_BACKEND="gloo", PG_MIN_PIECE="100000")  # (a tenth of the default 2^20)
+    for v in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(v, None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--genomes", "27",
+           "--genome-mb", "13.5", "--scaling", "strong", "--no-sharded-leg", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["ranks_observed"] == 8 and d["scaling"] == "strong"
+    total = 27 * 5 * (13_500_000 // 5 - 21 + 1)
+    loads = [int(x) for x in d["config"]["parallelism"].split("[")[1].split("]")[0].split(",")]
+    assert len(loads) == 8 and sum(loads) == total and min(loads) > 0
+    assert max(loads) <= 1.15 * total / 8, loads
+    assert abs(d["value"] - total / (d["ms_per_step"] * 1e-3)) < 1e-3 * d["value"]

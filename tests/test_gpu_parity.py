@@ -846,7 +846,7 @@ def test_wide_rows_long_contigs_against_oracle(ctx, n, k, lens):
 _FUZZ_N = [2, 8, 9, 16, 17, 24, 25, 32, 33, 40, 63, 64, 65, 72, 96, 97, 127, 128, 129, 160, 193, 256, 257, 300]
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("PG_FUZZ_SEEDS", "12"))))  # (more seeds: PG_FUZZ_SEEDS=200)
+@pytest.mark.parametrize("seed", range(int(os.environ.get("PG_FUZZ_SEEDS", "64"))))  # (more seeds: PG_FUZZ_SEEDS=600)
 def test_random_shapes_against_oracle(ctx, seed):
     """Randomised sweep over genome counts around every row-width boundary (1..38-byte rows, 1..5
     sub-tables), k, and contig lengths around the tile / bin / 1-in-100 boundaries, N runs included:
