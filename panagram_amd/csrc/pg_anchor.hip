@@ -2810,6 +2810,351 @@ __global__ __launch_bounds__(EPI_THREADS, PG_EPI_WAVESC) void k_epilogue_chunks(
 }
 
 // ---------------------------------------------------------------------------
+// Rows of 9..16 bytes (65..128 genomes): k_epilogue's scheme for 2..8-byte rows at THREE or FOUR words per row.
+// k_epilogue_chunks gives every row one lane and one (unaligned) 16-byte load whatever its width — ≈ 38 instructions per
+// row and lane, 4.1 ps per row at 9 bytes as at 16: the 65th genome paid for 128 (0.98 -> 2.68 ms for one more row byte).
+// Here a thread owns 16 consecutive rows of a group of four full tiles (4 x NBT aligned words per four rows, cut into
+// rows with static funnel shifts), the group's bookkeeping (bins, window, the 1-in-100 row) is paid once per 16 rows,
+// the histogram takes one LDS atomic per row (in 8 copies while the group lies inside one or two long bins), and the
+// column sums go through eight counter planes per word behind the Harley-Seal tree (3.3 instructions per row and word).
+// Tiles that form no group — a contig's last ones, contigs of a few tiles, bins shorter than 16 rows — take the same
+// four rows per thread one tile at a time.  Reference: the per-bin histogram and rows of cpp/anchor.cpp:150-189,
+// index.py:1169-1183; column sums: index.py:1051,1068-1074.
+// ---------------------------------------------------------------------------
+#ifndef PG_EPI_W
+#define PG_EPI_W 1  // 0: rows of 9..16 bytes through k_epilogue_chunks (rounds 2-4)
+#endif
+#ifndef PG_EPI_WAVESW12
+#define PG_EPI_WAVESW12 1  // waves per SIMD the instantiations of 9..12-byte rows are held to (1: the compiler's choice)
+#endif
+#ifndef PG_EPI_WAVESW16
+#define PG_EPI_WAVESW16 1  // ... of 13..16-byte rows
+#endif
+template <int NB>
+__device__ __forceinline__ void cut4_rows_w(const uint32_t (&raw)[NB], uint32_t (&w)[(NB + 3) / 4][4]) {
+    constexpr int NW = (NB + 3) / 4;
+    constexpr uint32_t last_keep = (NB % 4) ? ((1u << (8 * (NB % 4))) - 1u) : 0xFFFFFFFFu;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int off = j * NB, idx = off >> 2, sh = 8 * (off & 3);  // (constants once unrolled)
+#pragma unroll
+        for (int t = 0; t < NW; ++t) {
+            const uint32_t lo = raw[idx + t];  // (idx + NW - 1 <= NB - 1: the row ends inside the four rows' words)
+            const uint32_t hi = (idx + t + 1 < NB) ? raw[idx + t + 1] : 0u;
+            uint32_t v = sh ? __builtin_amdgcn_alignbit(hi, lo, (uint32_t)sh) : lo;
+            if (t == NW - 1) v &= last_keep;
+            w[t][j] = v;
+        }
+    }
+}
+// one row of NBT bytes copied to the low-resolution bitmap: one unaligned 16-byte read (it may reach into the rows that follow, or
+// into the 16 bytes of slack every row buffer carries), whole words and the tail's bytes written
+template <int NBT>
+__device__ __forceinline__ void copy_row_w(const uint8_t *pr, uint8_t *o) {
+    struct __attribute__((packed)) U32 { uint32_t v; };
+    struct __attribute__((packed)) U128 { uint32_t x, y, z, w; };
+    const U128 t = *reinterpret_cast<const U128 *>(pr);
+    const uint32_t xw[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+    for (int w = 0; w < NBT / 4; ++w) reinterpret_cast<U32 *>(o + 4 * w)->v = xw[w];
+#pragma unroll
+    for (int bb = 0; bb < NBT % 4; ++bb) o[4 * (NBT / 4) + bb] = (uint8_t)(xw[(NBT / 4) & 3] >> (8 * bb));
+}
+template <int NBT>
+__global__ __launch_bounds__(EPI_THREADS, (NBT <= 12 ? PG_EPI_WAVESW12 : PG_EPI_WAVESW16)) void k_epilogue_w(uint32_t N, const AnchorDesc *__restrict__ ad,
+                                                                          const uint32_t *__restrict__ tile_contig, uint32_t ntiles,
+                                                                          const uint8_t *__restrict__ out1, uint8_t *__restrict__ out100,
+                                                                          uint32_t *__restrict__ bins,
+                                                                          unsigned long long *__restrict__ colsums, uint32_t flags,
+                                                                          const uint2 *__restrict__ ranges, uint32_t wpr) {
+    static_assert(NBT >= 9 && NBT <= 16, "rows of 9..16 bytes");
+    extern __shared__ uint4 smem[];
+    constexpr int PT = 4;             // rows per thread and tile
+    constexpr int NW = (NBT + 3) / 4;  // words per row
+    constexpr uint32_t nbytes = NBT;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const uint32_t Nw = N;
+    uint32_t *hist = reinterpret_cast<uint32_t *>(smem);
+    const uint32_t MAXB = max(EPI_MAXB, (flags >> 8) & 0xFFu), MINBIN = epi_minbin(MAXB);
+    uint32_t *cs = hist + ((MAXB * (N + 1) + 3) & ~3u);
+    for (uint32_t i = tid; i < MAXB * (N + 1); i += EPI_THREADS) hist[i] = 0;
+    for (uint32_t i = tid; i < N; i += EPI_THREADS) cs[i] = 0;
+    __syncthreads();
+    const bool want_cs = (flags & 1u) != 0;
+    const bool want100 = (flags & 2u) == 0;
+    const EpiRange er = epi_range(4u, ntiles, ranges, wpr);
+    const uint32_t t_begin = er.begin, t_end = er.end;
+    uint64_t cur_row0 = ~0ull;
+    uint32_t cur_c = ~0u;
+    AnchorDesc a;
+    a.out_off = a.out100_off = a.bin_off = 0;
+    a.nkmers = a.binlen = a.tile0 = a.nbins = 0;
+    const uint32_t p0 = tid * PT;
+    // ---- column sums: eight counter planes per word behind a Harley-Seal tree (as k_epilogue, rows of 2..8 bytes) ----
+    uint32_t vp[NW][8], pf[NW], pe[NW];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) vp[w][q] = 0;
+        pf[w] = pe[w] = 0;
+    }
+    uint32_t vrows = 0;  // rows in the planes (block-uniform, a multiple of 4)
+    auto ripple = [&](uint32_t (&p)[8], uint32_t cw, int q0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (q >= q0) {
+                const uint32_t n = p[q] & cw;
+                p[q] ^= cw;
+                cw = n;
+            }
+    };
+    auto vadd4 = [&](uint32_t (&p)[8], uint32_t &pfw, uint32_t &pew, const uint32_t (&r)[4], bool odd4, bool odd8) __attribute__((always_inline)) {
+        const uint32_t x = p[0];
+        const uint32_t t1 = x ^ r[0], s1 = t1 ^ r[1], ca = (t1 & r[1]) | (~t1 & x);      // x + r0 + r1
+        const uint32_t t2 = s1 ^ r[2], s2 = t2 ^ r[3], cb = (t2 & r[3]) | (~t2 & s1);    // .. + r2 + r3
+        p[0] = s2;
+        const uint32_t y = p[1];
+        const uint32_t t3 = y ^ ca, cc = (t3 & cb) | (~t3 & y);                           // twos + ca + cb -> a carry of weight 4
+        p[1] = t3 ^ cb;
+        if (!odd4) {
+            pfw = cc;
+            return;
+        }
+        const uint32_t z = p[2], t4 = z ^ pfw, c8 = (t4 & cc) | (~t4 & z);               // fours + both carries -> weight 8
+        p[2] = t4 ^ cc;
+        if (!odd8) {
+            pew = c8;
+            return;
+        }
+        const uint32_t u = p[3], t5 = u ^ pew, c16 = (t5 & c8) | (~t5 & u);              // eights + both carries -> weight 16
+        p[3] = t5 ^ c8;
+        ripple(p, c16, 4);
+    };
+    auto vadd_rows = [&](const uint32_t (&w)[NW][4]) __attribute__((always_inline)) {  // four rows into the planes of every word
+        const bool odd4 = (vrows & 4u) != 0, odd8 = (vrows & 8u) != 0;
+#pragma unroll
+        for (int t = 0; t < NW; ++t) vadd4(vp[t], pf[t], pe[t], w[t], odd4, odd8);
+        vrows += PT;
+    };
+    auto vflush = [&]() __attribute__((always_inline)) {  // planes -> the workgroup's LDS counters: ONE (wave-uniform) call site, at the top of the tile loop
+        const bool odd4 = (vrows & 4u) != 0, odd8 = (vrows & 8u) != 0;
+#pragma unroll
+        for (int ws = 0; ws < NW; ++ws) {
+            if (odd4) ripple(vp[ws], pf[ws], 2);
+            if (odd8) ripple(vp[ws], pe[ws], 3);
+            uint32_t R[16];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {  // byte b of v counts genome 32 ws + 8 b + q (up to 255 rows)
+                uint32_t v = 0;
+#pragma unroll
+                for (int pl = 0; pl < 8; ++pl) v |= ((vp[ws][pl] >> q) & 0x01010101u) << pl;
+                R[2 * q] = v & 0x00FF00FFu;
+                R[2 * q + 1] = (v >> 8) & 0x00FF00FFu;
+            }
+#pragma unroll
+            for (int pl = 0; pl < 8; ++pl) vp[ws][pl] = 0;
+#pragma unroll
+            for (int half = 8, bit = 32; half >= 1; half >>= 1, bit >>= 1) {
+                const bool up = (lane & bit) != 0;
+#pragma unroll
+                for (int i = 0; i < half; ++i) {
+                    const uint32_t send = up ? R[i] : R[i + half];
+                    const uint32_t keep = up ? R[i + half] : R[i];
+                    R[i] = keep + (uint32_t)__shfl_xor((int)send, bit);
+                }
+            }
+            R[0] += (uint32_t)__shfl_xor((int)R[0], 2);
+            R[0] += (uint32_t)__shfl_xor((int)R[0], 1);
+            if ((lane & 3) == 0) {  // this lane holds register (lane >> 2): q = idx / 2, odd idx = bytes 1 and 3
+                const uint32_t idx = (uint32_t)lane >> 2;
+                const uint32_t g0 = 32 * ws + (idx >> 1) + ((idx & 1) ? 8u : 0u);
+                if (g0 < Nw && (R[0] & 0xFFFFu)) atomicAdd(&cs[g0], R[0] & 0xFFFFu);
+                if (g0 + 16 < Nw && (R[0] >> 16)) atomicAdd(&cs[g0 + 16], R[0] >> 16);
+            }
+        }
+        vrows = 0;
+    };
+    auto flush_colsums = [&](uint32_t contig) __attribute__((always_inline)) {  // (one call site)
+        __syncthreads();
+        for (uint32_t i = tid; i < N; i += EPI_THREADS) {
+            const uint32_t v = cs[i];
+            if (v) {
+                atomicAdd(&colsums[(uint64_t)contig * N + i], (unsigned long long)v);
+                cs[i] = 0;
+            }
+        }
+        __syncthreads();
+    };
+    // ---- the histogram window as EPI_REPL copies of two bin rows while the groups lie inside one or two long bins ----
+    constexpr uint32_t EPI_REPL = 8;
+    const uint32_t repl_stride = (2u * (N + 1u)) | 1u;  // (8 copies fit: MAXB >= 16 rows of N + 1)
+    bool repl = false;
+    auto unreplicate = [&]() __attribute__((always_inline)) {
+        if (!repl) return;
+        __syncthreads();
+        for (uint32_t i = tid; i < 2u * (N + 1u); i += EPI_THREADS) {
+            uint32_t v = hist[i];
+#pragma unroll
+            for (uint32_t cpy = 1; cpy < EPI_REPL; ++cpy) {
+                v += hist[cpy * repl_stride + i];
+                hist[cpy * repl_stride + i] = 0;
+            }
+            hist[i] = v;
+        }
+        __syncthreads();
+        repl = false;
+    };
+    auto popc_row = [&](const uint32_t (&w)[NW][4], int j) __attribute__((always_inline)) -> uint32_t {
+        uint32_t pc = (uint32_t)__popc(w[0][j]);
+#pragma unroll
+        for (int t = 1; t < NW; ++t) pc += (uint32_t)__popc(w[t][j]);
+        return min(pc, N);  // (junk bits beyond ngenomes count as class N)
+    };
+    for (uint32_t tile = t_begin; tile <= t_end; ++tile) {  // (one more round: the last contig's column sums leave at the one site)
+        const bool fin = tile >= t_end;
+        const uint32_t c = fin ? ~0u : tile_contig[tile];
+        // the planes count to 255 rows and a group brings 16: emptied here when they could not take another group, and when
+        // the range moves on to another contig (column sums are kept per contig)
+        if (want_cs && vrows && (vrows + 16u > 255u || c != cur_c)) vflush();
+        if (c != cur_c) {  // block-uniform
+            if (want_cs && cur_c != ~0u) flush_colsums(cur_c);
+            if (!fin) a = ad[c];
+            cur_c = c;
+        }
+        if (fin) break;
+        // ---- group path: 4 full tiles of one contig = 16 consecutive rows per thread ----
+        {
+            const uint32_t ts = (tile - a.tile0) * PROBE_TILE;
+            const uint32_t span = 4u * PROBE_TILE;
+            const uint32_t nbg = (ts + span - 1) / a.binlen - ts / a.binlen + 1u;  // bins of the group
+            const bool grp_ok = tile + 3 < t_end && tile_contig[tile + 3] == c && ts + span <= a.nkmers &&
+                                (nbg == 1u || (a.binlen >= 16u && nbg <= MAXB));
+            if (grp_ok) {
+                const uint64_t row0g = a.bin_off + ts / a.binlen;
+                const bool want_repl = nbg <= 2u;  // (block-uniform)
+                if (want_repl) {
+                    if (!(repl && row0g >= cur_row0 && row0g + nbg <= cur_row0 + 2u)) {
+                        if (cur_row0 != ~0ull) {
+                            unreplicate();
+                            __syncthreads();
+                            flush_hist(N, hist, bins, cur_row0, tid, MAXB);
+                            __syncthreads();
+                        }
+                        cur_row0 = row0g;
+                        repl = true;
+                    }
+                } else {
+                    unreplicate();
+                    if (cur_row0 == ~0ull || row0g < cur_row0 || row0g + nbg > cur_row0 + MAXB) {
+                        if (cur_row0 != ~0ull) {
+                            __syncthreads();
+                            flush_hist(N, hist, bins, cur_row0, tid, MAXB);
+                            __syncthreads();
+                        }
+                        cur_row0 = row0g;
+                    }
+                }
+                uint32_t rel0 = 0, jb = 16;  // bin of the thread's first row (relative to the group's first bin), rows until the boundary
+                if (nbg > 1u) {
+                    const uint32_t bl = a.binlen, d0 = ts + 16u * tid - (ts / bl) * bl;
+                    rel0 = bl >= span ? (d0 >= bl ? 1u : 0u) : __umulhi(d0, 0xFFFFFFFFu / bl + 1u);  // (d0 < 2^16)
+                    jb = min(16u, (rel0 + 1u) * bl - d0);
+                }
+                uint32_t *hrow = hist + ((uint32_t)(row0g - cur_row0) + rel0) * (N + 1) + (want_repl ? ((uint32_t)lane % EPI_REPL) * repl_stride : 0u);
+                const uint8_t *gt = out1 + a.out_off + ((uint64_t)ts + 16u * tid) * nbytes;
+                uint32_t raw[4][NBT];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {  // all 16 rows in flight
+#pragma unroll
+                    for (int i = 0; i < NBT; ++i) raw[q][i] = reinterpret_cast<const uint32_t *>(gt + q * 4 * NBT)[i];
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    uint32_t w[NW][4];
+                    cut4_rows_w<NBT>(raw[q], w);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) atomicAdd(&hrow[((uint32_t)(4 * q + j) >= jb ? N + 1 : 0u) + popc_row(w, j)], 1u);
+                    if (want_cs) vadd_rows(w);
+                }
+                // 1-in-100 rows: at most one multiple of 100 among 16 consecutive positions; its row is read again (a cache hit)
+                const uint32_t pos0 = ts + 16u * tid;
+                const uint32_t r100 = (pos0 + 99u) / 100u;
+                const uint32_t first = r100 * 100u - pos0;
+                if (want100 && first < 16u) copy_row_w<NBT>(gt + first * nbytes, out100 + a.out100_off + (uint64_t)r100 * nbytes);
+                tile += 3;
+                continue;
+            }
+        }
+        // ---- one tile: the thread's four rows ----
+        unreplicate();
+        const uint32_t tile_start = (tile - a.tile0) * PROBE_TILE;
+        const uint32_t npos = min((uint32_t)PROBE_TILE, a.nkmers - tile_start);
+        const uint32_t binlen = a.binlen, bin0 = tile_start / binlen, bin0_start = bin0 * binlen;
+        const uint64_t row0 = a.bin_off + bin0;
+        const bool big = binlen >= (uint32_t)PROBE_TILE;  // a tile spans at most 2 bins
+        const bool windowed = binlen >= MINBIN;           // ... at most MAXB bins
+        const uint32_t last_rel = (tile_start + npos - 1 - bin0_start) / binlen;
+        const uint32_t binv = big ? 0u : 0xFFFFFFFFu / binlen + 1u;
+        const bool fits = cur_row0 != ~0ull && (!windowed ? row0 == cur_row0 : (row0 >= cur_row0 && row0 + last_rel < cur_row0 + MAXB));
+        if (!fits) {
+            if (cur_row0 != ~0ull) {
+                __syncthreads();
+                flush_hist(N, hist, bins, cur_row0, tid, MAXB);
+                __syncthreads();
+            }
+            cur_row0 = row0;
+        }
+        const uint32_t rel_base = (uint32_t)(row0 - cur_row0);
+        const uint8_t *g = out1 + a.out_off + (uint64_t)tile_start * nbytes;
+        const uint32_t nact = p0 < npos ? min(4u, npos - p0) : 0u;
+        uint32_t w[NW][4];
+        if (npos == (uint32_t)PROBE_TILE) {  // (block-uniform) a full tile: NBT aligned words
+            uint32_t raw[NBT];
+#pragma unroll
+            for (int i = 0; i < NBT; ++i) raw[i] = reinterpret_cast<const uint32_t *>(g + (uint64_t)p0 * nbytes)[i];
+            cut4_rows_w<NBT>(raw, w);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int t = 0; t < NW; ++t) {
+                    uint32_t v = 0;
+                    if ((uint32_t)j < nact) {
+#pragma unroll
+                        for (int bb = 0; bb < (NBT - 4 * t < 4 ? NBT - 4 * t : 4); ++bb) v |= (uint32_t)g[(uint64_t)(p0 + j) * nbytes + 4 * t + bb] << (8 * bb);
+                    }
+                    w[t][j] = v;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t pos = tile_start + p0 + j;
+            const uint32_t pc = popc_row(w, j);
+            if (windowed) {
+                if ((uint32_t)j < nact) {
+                    const uint32_t dpos = pos - bin0_start;
+                    const uint32_t rel = big ? (dpos >= binlen ? 1u : 0u) : __umulhi(dpos, binv);
+                    atomicAdd(&hist[(rel_base + rel) * (N + 1) + pc], 1u);
+                }
+            } else {
+                hist_position((uint32_t)j < nact, pos, pc, N, binlen, bin0, bin0_start, rel_base, hist, bins, a.bin_off, lane, MAXB);
+            }
+        }
+        if (nact) {  // 1-in-100 rows: at most one of 4 consecutive positions is a multiple of 100
+            const uint32_t pos0 = tile_start + p0;
+            const uint32_t r100 = (pos0 + 99u) / 100u;
+            const uint32_t jsel = r100 * 100u - pos0;
+            if (want100 && jsel < nact) copy_row_w<NBT>(g + (uint64_t)(p0 + jsel) * nbytes, out100 + a.out100_off + (uint64_t)r100 * nbytes);
+        }
+        if (want_cs) vadd_rows(w);  // (rows beyond npos are zero — a partial tile's words are built that way: adding them is harmless)
+    }
+    unreplicate();
+    __syncthreads();
+    if (cur_row0 != ~0ull) flush_hist(N, hist, bins, cur_row0, tid, MAXB);
+}
+
+// ---------------------------------------------------------------------------
 // statistics of arbitrary row windows of a finished bitmap (genes, bins of any length): per window
 // the histogram of row popcounts and, optionally, the per-genome column sums.  Not on the hot
 // path: LDS atomics for the histogram, one ballot per genome bit and 64 rows for the columns.
@@ -3203,6 +3548,23 @@ hipError_t launch_rows_epilogue(hipStream_t st, uint32_t ngenomes, const AnchorD
             case 6: kern = k_epilogue<1, 6>; break;
             case 7: kern = k_epilogue<1, 7>; break;
             case 8: kern = k_epilogue<1, 8>; break;
+            default: break;
+        }
+        fit(reinterpret_cast<const void *>(kern), lds);
+        per_range();
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(EPI_THREADS), lds, st, ngenomes, ad, tile_contig, ntiles, out1, out100, bins,
+                           colsums, flags, d_ranges, wpr);
+    }
+    else if (PG_EPI_W && nbytes <= 16) {  // 65..128 genomes: 16 rows per thread, three or four words per row
+        auto kern = k_epilogue_w<16>;
+        switch (nbytes) {
+            case 9: kern = k_epilogue_w<9>; break;
+            case 10: kern = k_epilogue_w<10>; break;
+            case 11: kern = k_epilogue_w<11>; break;
+            case 12: kern = k_epilogue_w<12>; break;
+            case 13: kern = k_epilogue_w<13>; break;
+            case 14: kern = k_epilogue_w<14>; break;
+            case 15: kern = k_epilogue_w<15>; break;
             default: break;
         }
         fit(reinterpret_cast<const void *>(kern), lds);

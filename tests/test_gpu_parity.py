@@ -843,6 +843,48 @@ def test_wide_rows_long_contigs_against_oracle(ctx, n, k, lens):
     tbl.close()
 
 
+@pytest.mark.parametrize("n", [66, 73, 80, 81, 88, 90, 99, 105, 112, 113, 120, 126])
+def test_rows_of_9_to_16_bytes_against_oracle(ctx, n):
+    """65..128 genomes, every row width from 9 to 16 bytes (three and four words per row, ragged and whole): the statistics
+    pass k_epilogue_w reads 16 consecutive rows per thread as 4 x nbytes aligned words and cuts the rows out with static
+    funnel shifts.  Contigs whose groups of four tiles lie inside one or two long bins (the histogram in 8 LDS copies),
+    across several bins of a few hundred rows (the plain window), a contig of three tiles (no group: one tile at a time,
+    bins shorter than the window's minimum) and one whose last tile is partial.  Rows, bitmap.100, bins and per-contig column
+    sums against the oracle (cpp/anchor.cpp:150-189, index.py:1051,1169-1183)."""
+    from panagram_amd import engine
+    k = 21 if n % 2 else 31
+    lens = [262_000 + 17 * n, 41_000 + n, 3_000 + n]
+    rng = np.random.default_rng(n * 77 + k)
+    gen = po.synth_genomes(n, lens, 0.01, 911 + n)
+    genomes = [[bytearray(po.codes_to_ascii(c)) for c in g] for g in gen]
+    for g in (0, n - 1):
+        for c in genomes[g]:
+            p, run = int(rng.integers(0, len(c) - 1500)), int(rng.integers(1, 700))
+            c[p:p + run] = b"N" * run
+    genomes = [[bytes(c) for c in g] for g in genomes]
+    dbs = po.build_bitvec_dbs(genomes, k)
+    tbl = engine.PanTable(ctx, k, n)
+    for g in range(n):
+        ss = engine.SeqSet.from_host(ctx, genomes[g])
+        tbl.insert_seqset(g, ss)
+        ss.close()
+    g = 0 if n % 3 else n - 1
+    ss = engine.SeqSet.from_host(ctx, genomes[g])
+    res = engine.AnchorResult(tbl, ss, colsums=True)
+    res.run()
+    ccs = res.contig_colsums().astype(np.int64)
+    for ci, seq in enumerate(genomes[g]):
+        rows, rows100, bins, info = res.download(ci)
+        o_rows, o_rows100, o_bins, _, o_cs = po.anchor_contig(dbs, seq, k, n)
+        assert np.array_equal(rows, o_rows)
+        assert np.array_equal(rows100, o_rows100)
+        assert np.array_equal(bins.astype(np.int64), o_bins), np.argwhere(bins.astype(np.int64) != o_bins)[:5]
+        assert np.array_equal(ccs[ci], o_cs)
+    res.close()
+    ss.close()
+    tbl.close()
+
+
 _FUZZ_N = [2, 8, 9, 16, 17, 24, 25, 32, 33, 40, 63, 64, 65, 72, 96, 97, 127, 128, 129, 160, 193, 256, 257, 300]
 
 
