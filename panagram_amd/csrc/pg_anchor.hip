@@ -804,7 +804,11 @@ __attribute__((amdgpu_num_sgpr(80))) void k_probe(const SubTable st, const uint6
         for (uint32_t i = lane; i < TILE_SLOTS * COLS_G; i += 64) cols[i] = 0;
         __syncthreads();
     }
+#if PG_ABLATE == 9 || PG_ABLATE == 10  // (timing experiment, wrong rows: every tile writes into a window of 256 tiles' rows — the L2 takes the stores, HBM sees none)
+    uint8_t *tile_rows = out1 + (uint64_t)(blockIdx.x & 255u) * PROBE_TILE * nbytes;
+#else
     uint8_t *tile_rows = ROWMODE == 3 ? reinterpret_cast<uint8_t *>(cols) : out1 + a.out_off + (uint64_t)tile_start * nbytes;
+#endif
     uint32_t qn = 0;  // wave-uniform: overflow entries of this tile so far
 
     const uint8_t *chunk_base = st.buckets + (uint32_t)(lane % SLOTS) * 16u;  // this lane's 16-byte chunk of line 0
@@ -1073,7 +1077,15 @@ __attribute__((amdgpu_num_sgpr(80))) void k_probe(const SubTable st, const uint6
         PG_PH(10)
         // (32-bit offset from the tile's uniform base: one store with a scalar base address)
         if constexpr (WIDE) {
-            if (inrange) store_row_wide(st.masks, st.W, nbytes, tile_rows + (uint64_t)(uint32_t)pl * nbytes, m0, m1);
+#if PG_ABLATE == 2  // (timing experiment: no mask gather, no row store)
+            if (inrange && m0 == 0xDEADBEEFu && m1 == 77u)
+#elif PG_ABLATE == 8 || PG_ABLATE == 10  // (timing experiment, wrong rows: the row store without a DIVERGENT mask gather — every hit copies slot 0 of line 0's block)
+            if (m1) m0 = 0, m1 = 1;
+            if (inrange)
+#else
+            if (inrange)
+#endif
+                store_row_wide(st.masks, st.W, nbytes, tile_rows + (uint64_t)(uint32_t)pl * nbytes, m0, m1);
         } else if constexpr (ROWMODE == 3) {
             const uint32_t w0 = b0 >> 6, sh = b0 & 63u;
             for (uint32_t j = 0; j < rc.col0; ++j) {  // (uniform) one ballot per genome of the block
