@@ -2825,8 +2825,9 @@ __global__ __launch_bounds__(EPI_THREADS, PG_EPI_WAVESC) void k_epilogue_chunks(
 // Rows of 9..16 bytes (65..128 genomes): k_epilogue's scheme for 2..8-byte rows at THREE or FOUR words per row.
 // k_epilogue_chunks gives every row one lane and one (unaligned) 16-byte load whatever its width — ≈ 38 instructions per
 // row and lane, 4.1 ps per row at 9 bytes as at 16: the 65th genome paid for 128 (0.98 -> 2.68 ms for one more row byte).
-// Here a thread owns 16 consecutive rows of a group of four full tiles (4 x NBT aligned words per four rows, cut into
-// rows with static funnel shifts), the group's bookkeeping (bins, window, the 1-in-100 row) is paid once per 16 rows,
+// Here a thread owns RPT consecutive rows of a group of full tiles (NBT aligned words per four rows, cut into rows with
+// static funnel shifts; RPT = 8, a group = two tiles: 16 rows per thread as for the narrower widths cost a wave of occupancy
+// and 2-7 %, profiles/r5g_ab_stats_w_rows.txt), the group's bookkeeping (bins, window, the 1-in-100 row) is paid once per group,
 // the histogram takes one LDS atomic per row (in 8 copies while the group lies inside one or two long bins), and the
 // column sums go through eight counter planes per word behind the Harley-Seal tree (3.3 instructions per row and word).
 // Tiles that form no group — a contig's last ones, contigs of a few tiles, bins shorter than 16 rows — take the same
@@ -2836,11 +2837,17 @@ __global__ __launch_bounds__(EPI_THREADS, PG_EPI_WAVESC) void k_epilogue_chunks(
 #ifndef PG_EPI_W
 #define PG_EPI_W 1  // 0: rows of 9..16 bytes through k_epilogue_chunks (rounds 2-4)
 #endif
+#ifndef PG_EPI_W_GQ12
+#define PG_EPI_W_GQ12 2  // k_epilogue_w, rows of 9..12 bytes: tiles per group (4: 16 consecutive rows per thread, 2: 8)
+#endif
+#ifndef PG_EPI_W_GQ16
+#define PG_EPI_W_GQ16 2  // ... rows of 13..16 bytes
+#endif
 #ifndef PG_EPI_WAVESW12
 #define PG_EPI_WAVESW12 1  // waves per SIMD the instantiations of 9..12-byte rows are held to (1: the compiler's choice)
 #endif
 #ifndef PG_EPI_WAVESW16
-#define PG_EPI_WAVESW16 1  // ... of 13..16-byte rows
+#define PG_EPI_WAVESW16 4  // ... of 13..16-byte rows
 #endif
 template <int NB>
 __device__ __forceinline__ void cut4_rows_w(const uint32_t (&raw)[NB], uint32_t (&w)[(NB + 3) / 4][4]) {
@@ -2883,6 +2890,8 @@ __global__ __launch_bounds__(EPI_THREADS, (NBT <= 12 ? PG_EPI_WAVESW12 : PG_EPI_
     extern __shared__ uint4 smem[];
     constexpr int PT = 4;             // rows per thread and tile
     constexpr int NW = (NBT + 3) / 4;  // words per row
+    constexpr int GQ = (NBT <= 12 ? PG_EPI_W_GQ12 : PG_EPI_W_GQ16);  // tiles per group = blocks of four rows per thread and group
+    constexpr uint32_t RPT = 4u * GQ;   // consecutive rows of a group per thread
     constexpr uint32_t nbytes = NBT;
     const int tid = threadIdx.x, lane = tid & 63;
     const uint32_t Nw = N;
@@ -3027,7 +3036,7 @@ __global__ __launch_bounds__(EPI_THREADS, (NBT <= 12 ? PG_EPI_WAVESW12 : PG_EPI_
         const uint32_t c = fin ? ~0u : tile_contig[tile];
         // the planes count to 255 rows and a group brings 16: emptied here when they could not take another group, and when
         // the range moves on to another contig (column sums are kept per contig)
-        if (want_cs && vrows && (vrows + 16u > 255u || c != cur_c)) vflush();
+        if (want_cs && vrows && (vrows + RPT > 255u || c != cur_c)) vflush();
         if (c != cur_c) {  // block-uniform
             if (want_cs && cur_c != ~0u) flush_colsums(cur_c);
             if (!fin) a = ad[c];
@@ -3037,10 +3046,10 @@ __global__ __launch_bounds__(EPI_THREADS, (NBT <= 12 ? PG_EPI_WAVESW12 : PG_EPI_
         // ---- group path: 4 full tiles of one contig = 16 consecutive rows per thread ----
         {
             const uint32_t ts = (tile - a.tile0) * PROBE_TILE;
-            const uint32_t span = 4u * PROBE_TILE;
+            const uint32_t span = (uint32_t)GQ * PROBE_TILE;
             const uint32_t nbg = (ts + span - 1) / a.binlen - ts / a.binlen + 1u;  // bins of the group
-            const bool grp_ok = tile + 3 < t_end && tile_contig[tile + 3] == c && ts + span <= a.nkmers &&
-                                (nbg == 1u || (a.binlen >= 16u && nbg <= MAXB));
+            const bool grp_ok = tile + (GQ - 1) < t_end && tile_contig[tile + (GQ - 1)] == c && ts + span <= a.nkmers &&
+                                (nbg == 1u || (a.binlen >= RPT && nbg <= MAXB));
             if (grp_ok) {
                 const uint64_t row0g = a.bin_off + ts / a.binlen;
                 const bool want_repl = nbg <= 2u;  // (block-uniform)
@@ -3066,22 +3075,22 @@ __global__ __launch_bounds__(EPI_THREADS, (NBT <= 12 ? PG_EPI_WAVESW12 : PG_EPI_
                         cur_row0 = row0g;
                     }
                 }
-                uint32_t rel0 = 0, jb = 16;  // bin of the thread's first row (relative to the group's first bin), rows until the boundary
+                uint32_t rel0 = 0, jb = RPT;  // bin of the thread's first row (relative to the group's first bin), rows until the boundary
                 if (nbg > 1u) {
-                    const uint32_t bl = a.binlen, d0 = ts + 16u * tid - (ts / bl) * bl;
+                    const uint32_t bl = a.binlen, d0 = ts + RPT * tid - (ts / bl) * bl;
                     rel0 = bl >= span ? (d0 >= bl ? 1u : 0u) : __umulhi(d0, 0xFFFFFFFFu / bl + 1u);  // (d0 < 2^16)
-                    jb = min(16u, (rel0 + 1u) * bl - d0);
+                    jb = min(RPT, (rel0 + 1u) * bl - d0);
                 }
                 uint32_t *hrow = hist + ((uint32_t)(row0g - cur_row0) + rel0) * (N + 1) + (want_repl ? ((uint32_t)lane % EPI_REPL) * repl_stride : 0u);
-                const uint8_t *gt = out1 + a.out_off + ((uint64_t)ts + 16u * tid) * nbytes;
-                uint32_t raw[4][NBT];
+                const uint8_t *gt = out1 + a.out_off + ((uint64_t)ts + RPT * tid) * nbytes;
+                uint32_t raw[GQ][NBT];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {  // all 16 rows in flight
+                for (int q = 0; q < GQ; ++q) {  // all of the thread's rows in flight
 #pragma unroll
                     for (int i = 0; i < NBT; ++i) raw[q][i] = reinterpret_cast<const uint32_t *>(gt + q * 4 * NBT)[i];
                 }
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
+                for (int q = 0; q < GQ; ++q) {
                     uint32_t w[NW][4];
                     cut4_rows_w<NBT>(raw[q], w);
 #pragma unroll
@@ -3089,11 +3098,11 @@ __global__ __launch_bounds__(EPI_THREADS, (NBT <= 12 ? PG_EPI_WAVESW12 : PG_EPI_
                     if (want_cs) vadd_rows(w);
                 }
                 // 1-in-100 rows: at most one multiple of 100 among 16 consecutive positions; its row is read again (a cache hit)
-                const uint32_t pos0 = ts + 16u * tid;
+                const uint32_t pos0 = ts + RPT * tid;
                 const uint32_t r100 = (pos0 + 99u) / 100u;
                 const uint32_t first = r100 * 100u - pos0;
-                if (want100 && first < 16u) copy_row_w<NBT>(gt + first * nbytes, out100 + a.out100_off + (uint64_t)r100 * nbytes);
-                tile += 3;
+                if (want100 && first < RPT) copy_row_w<NBT>(gt + first * nbytes, out100 + a.out100_off + (uint64_t)r100 * nbytes);
+                tile += GQ - 1;
                 continue;
             }
         }

@@ -9,7 +9,7 @@
 #   bash tools/ab_libs.sh tools/lines.sh tagA tagB  the same over prebuilt library variants (build_variants/lib_<tag>.so)
 #
 # columns: [tag] [arguments] G k-mers/s | step ms | k_probe ms | statistics ms | probe ps per position | keys | table GB |
-#          keys per 128-byte line | table build s | roofline frac | m (the table's minimizer length)
+#          keys per 128-byte line | table build s | roofline frac | m (the table's minimizer length) | fraction of the keys outside their home line
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p gpurun_out
 TAG=${1:-}
@@ -27,6 +27,6 @@ d = json.loads(sys.stdin.read()); r = d['roofline']; c = d['config']; n = c['pos
 print('[$TAG] [' + ' '.join('''$A'''.split()) + ']', round(d['value'] / 1e9, 1), '| step', round(d['ms_per_step'], 3), '| probe', round(r['avg_launch_ms'], 3),
       '| stats', round(r['epilogue_kernel_ms'], 3), '| ps/pos', round(r['avg_launch_ms'] * 1e9 / (n / c['launches_per_step']), 2), '| keys', c['table_keys'],
       '| GB', round(c['table_bytes'] / 1e9, 1), '| keys/line', c['keys_per_128B_line'], '| build s', round(c['table_build_s'], 3),
-      '| frac', round(r['frac'], 3), '| m', c.get('minimizer_length'))" || tail -3 gpurun_out/lines.err
+      '| frac', round(r['frac'], 3), '| m', c.get('minimizer_length'), '| spill', round(c.get('table_spill_fraction') or 0, 3))" || tail -3 gpurun_out/lines.err
   done
 done
