@@ -968,6 +968,7 @@ def main():
     ap.add_argument("--no-e2e", action="store_true", help="skip the files-to-files leg (Index.run() on FASTA files of this shape)")
     ap.add_argument("--no-robustness", action="store_true", help="skip the robustness legs (inversions + shuffled contig order; repeat family)")
     ap.add_argument("--no-config5", action="store_true", help="skip the BASELINE configs[4] leg (8 x 3 Gb, d=0.05, 8 genome blocks as passes on this GPU)")
+    ap.add_argument("--settle-s", type=float, default=0.4, help="seconds of untimed steps before the warm-up steps (the shader clock settles; 0: none)")
     ap.add_argument("--cpu-sample-mb", type=float, default=20.0, help="bases per thread of the CPU baseline leg (about 12 s of CPU work)")
     ap.add_argument("--emulate-rank", type=str, default="", metavar="R/N",
                     help="one process plays rank R of an N-rank contig-sharded run (no collective): the N x longer "
@@ -1059,6 +1060,14 @@ def main():
             r.run()
     # per-launch kernel durations come from HIP events recorded by the library on the stream the
     # kernels run on, one event set per run: the mean over ALL timed steps' launches (pg_result_timing_mean)
+    # (untimed, before the W warm-up steps: the step repeated for --settle-s seconds, so that the timed region runs at the
+    # shader clock a long job has — the first tenths of a second after the table build run 3-5 % slower, profiles/r4c_clock.txt;
+    # reported as clock_settle_s)
+    t_settle = time.perf_counter()
+    while args.settle_s > 0 and time.perf_counter() - t_settle < args.settle_s:
+        for _ in range(8):
+            step()
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -1133,6 +1142,7 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,
         "timed_region_s": elapsed,  # (the launch gets 3-5 % faster once the clock has settled: DESIGN.md section 4)
+        "clock_settle_s": args.settle_s,  # untimed steps before the warm-up steps (see above)
         "higher_is_better": True,
         "scaling": "strong" if strong else "weak",
         "vs_baseline": None,

@@ -1014,7 +1014,7 @@ def test_corrupt_kmc_total_is_a_format_error_not_a_crash(ctx):
     tbl.close()
 
 
-@pytest.mark.parametrize("n,k,chunks", [(7, 21, 3), (27, 21, 5), (64, 31, 4), (70, 21, 6)])
+@pytest.mark.parametrize("n,k,chunks", [(7, 21, 3), (27, 21, 5), (64, 31, 4), (70, 21, 6), (100, 21, 4)])
 def test_a_run_in_chunks_equals_the_run_in_one_launch(ctx, n, k, chunks, monkeypatch):
     """pg_anchor_run as several probe launches (slices of the co-schedule) with the statistics pass of every slice on
     the side stream over the tile ranges the slice touches (PG_RUN_CHUNKS; the default for huge 8-byte-row runs): rows,
