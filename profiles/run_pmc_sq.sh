@@ -5,7 +5,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
-ARGS="--steps 2 --warmup 1 --no-cpu-baseline --no-e2e --no-robustness $@"
+ARGS="--steps 2 --warmup 1 --settle-s 0 --no-cpu-baseline --no-e2e --no-robustness --no-config5 $@"
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT/pmc_sq -o pmc -- python $R/bench.py $ARGS > $OUT/bench.json 2> $OUT/pmc_sq.err
 rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_WAIT_INST_LDS SQ_INSTS_FLAT --output-format csv -d $OUT/pmc_sq2 -o pmc -- python $R/bench.py $ARGS > /dev/null 2> $OUT/pmc_sq2.err
 python - <<PY

@@ -5,7 +5,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 OUT=$R/gpurun_out/pmck_$TAG
 rm -rf $OUT; mkdir -p $OUT
-ARGS="--steps 2 --warmup 1 --no-cpu-baseline --no-compare --no-other-shapes --no-sharded-leg $@"
+ARGS="--steps 2 --warmup 1 --settle-s 0 --no-cpu-baseline --no-compare --no-other-shapes --no-sharded-leg --no-e2e --no-robustness --no-config5 $@"
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU --output-format csv -d $OUT/a -o pmc -- python $R/bench.py $ARGS > $OUT/bench.json 2> $OUT/a.err
 rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_SMEM SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/b -o pmc -- python $R/bench.py $ARGS > /dev/null 2> $OUT/b.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/t -o trace -- python $R/bench.py $ARGS > /dev/null 2> $OUT/t.err
