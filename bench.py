@@ -1048,7 +1048,8 @@ def main():
         pg = Pangenome(ctx, dev, G, contig_lens, args.d, args.seed, k, minimizer=args.minimizer, pieces_of=(my_group, groups))
     else:
         pg = Pangenome(ctx, dev, G, contig_lens, args.d, args.seed, k, groups=groups, my_group=my_group, keep_ascii=keep_ascii,
-                       minimizer=args.minimizer, rehash_kpb=None if (args.no_rehash or groups > 1 or args.keys_per_bucket <= 0) else args.keys_per_bucket)
+                       minimizer=args.minimizer, rehash_kpb=None if (args.no_rehash or groups > 1 or args.keys_per_bucket <= 0) else args.keys_per_bucket,
+                       coscheduled=1 if args.per_genome_launches else 0)  # (the timed mode's table is built for the way it is probed)
     st = pg.stats
     pg_rehashed = not (args.no_rehash or groups > 1 or args.keys_per_bucket <= 0)
     pos_per_step = sum(pg.pos_per_genome)
