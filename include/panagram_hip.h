@@ -83,8 +83,9 @@ int pg_device_free(pg_ctx *ctx, void *ptr);
 /* ---- pan-kmer table: replaces the merged KMC "bitvec" databases --------
  * Reference: KMCdb::KMCdb opens root/kmc/bitvec{i} with CKMCFile::OpenForRA
  * (cpp/anchor.cpp:21-35); Genome._load_kmc (index.py:847-863).
- * One GPU-resident open-addressed table per pair of 32-genome groups: 128-byte lines of
- * 8 slots {u64 key, u32 mask, u32 mask}, home line = hash of the k-mer's minimizer;
+ * ONE GPU-resident open-addressed table whatever the genome count, in 128-byte lines: up to 64 genomes 8 slots
+ * {u64 key, u32 mask, u32 mask}; 65..96 genomes 6 bare keys followed by their 12-byte mask blocks (inline layout);
+ * more: 16 bare keys, the mask words in a second array (split layout).  Home line = hash of the k-mer's minimizer;
  * key = canonical k-mer (2k-bit integer, first base most significant), value = the group's u32
  * one-hot-OR mask(s).  k in 1..32.  One writer at a time: the calls that add keys (insert_*, load_kmc1,
  * rehash) serialise on a per-table lock; lookups (pg_anchor_run ...) must not overlap them. */

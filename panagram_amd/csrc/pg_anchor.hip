@@ -371,6 +371,88 @@ __device__ __forceinline__ void store_row_wide(const uint8_t *masks, uint32_t W,
     }
 }
 
+// ---- inline layout (65..128 genomes, round 5): a line = S bare keys (S = 6 at W = 3 mask words, 5 at W = 4) followed by the slots'
+// mask blocks; staged whole like a split-layout key line, but a hit's mask words come out of the SAME staged line ----
+// scan of a staged line: 1 = found, 0 = absent (line not full), -1 = absent from a full line; slot1 = slot + 1 (0: absent).
+// The hit's slot number stays on the vector unit (one compare + one select per key; from the last key down, so that the lowest
+// match stays — k_insert_tile's snapshots may show a claim that is about to be retired).  Words 5.. of the line that hold mask
+// bits (S = 5) are not compared.
+__device__ __forceinline__ int scan_keys_inl(const uint4 *line, uint64_t key, uint32_t S, uint32_t &slot1) {
+    uint64_t kk[6];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const uint4 v = line[c];
+        kk[2 * c] = (uint64_t)v.x | ((uint64_t)v.y << 32);
+        kk[2 * c + 1] = (uint64_t)v.z | ((uint64_t)v.w << 32);
+    }
+    const bool six = S >= 6u;  // (wave-uniform)
+    slot1 = (six && kk[5] == key) ? 6u : 0u;
+#pragma unroll
+    for (int sl = 4; sl >= 0; --sl) slot1 = (kk[sl] == key) ? (uint32_t)(sl + 1) : slot1;
+    const uint64_t last = six ? kk[5] : kk[4];
+    return slot1 ? 1 : (last == EMPTY_KEY ? 0 : -1);
+}
+// the W (3 or 4) mask words of slot `slot` out of a staged line: four words from byte 8 S + 4 W slot on (W = 3: the fourth is the
+// next slot's first word or the line's pad — rows of W = 3 tables are at most 12 bytes, it is never stored)
+__device__ __forceinline__ void masks_inl(const uint4 *line, uint32_t S, uint32_t W, uint32_t slot, uint32_t (&w)[4]) {
+    const WordsN<4> v = *reinterpret_cast<const WordsN<4> *>(reinterpret_cast<const uint8_t *>(line) + 8u * S + 4u * W * slot);
+    w[0] = v.w[0], w[1] = v.w[1], w[2] = v.w[2], w[3] = v.w[3];
+}
+// a row of 9..16 bytes out of registers (zeros for an absent key): the widest pieces the width allows, as store_row_wide
+template <int NS>
+__device__ __forceinline__ void store_words_tail(const uint32_t (&v)[4], uint8_t *dst, uint32_t tail) {
+    WordsN<NS> o;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) o.w[i] = v[i];
+    *reinterpret_cast<WordsN<NS> *>(dst) = o;
+    if (tail > 1) {  // (wave-uniform) the row's last 4 bytes as one dword that overlaps the words before it — equal bytes
+        struct __attribute__((packed)) U32 { uint32_t v; };
+        reinterpret_cast<U32 *>(dst + 4 * NS + tail - 4)->v = __builtin_amdgcn_alignbit(v[NS & 3], v[NS - 1], 8u * tail);
+    } else if (tail == 1) {
+        dst[4 * NS] = (uint8_t)v[NS & 3];
+    }
+}
+__device__ __forceinline__ void store_row_regs(uint8_t *row, uint32_t nbytes, const uint32_t (&w)[4]) {
+    if (nbytes == 16) {  // (wave-uniform) one store covers the row: non-temporal, as store_row_wide
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 q = {w[0], w[1], w[2], w[3]};
+        if (PG_NT_ROWS) __builtin_nontemporal_store(q, reinterpret_cast<u32x4 *>(row));
+        else *reinterpret_cast<u32x4 *>(row) = q;
+    } else if (nbytes >= 12) {
+        store_words_tail<3>(w, row, nbytes - 12u);
+    } else {
+        store_words_tail<2>(w, row, nbytes - 8u);
+    }
+}
+// follow a key's probe sequence through inline-layout lines in global memory (all six key words of a line in flight together)
+__device__ __forceinline__ void lane_chase_inl(const SubTable &st, uint64_t key, uint32_t level, uint32_t b, uint32_t step, uint32_t (&w)[4]) {
+    w[0] = w[1] = w[2] = w[3] = 0;
+    for (uint64_t n = 0; n < st.nbuckets + GROUP_CHAIN; ++n) {
+        const uint8_t *base = st.buckets + (uint64_t)b * 128u;
+        const uint4 *line = reinterpret_cast<const uint4 *>(base);
+        uint4 v[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v[c] = line[c];
+        const uint64_t kk[6] = {(uint64_t)v[0].x | ((uint64_t)v[0].y << 32), (uint64_t)v[0].z | ((uint64_t)v[0].w << 32),
+                                (uint64_t)v[1].x | ((uint64_t)v[1].y << 32), (uint64_t)v[1].z | ((uint64_t)v[1].w << 32),
+                                (uint64_t)v[2].x | ((uint64_t)v[2].y << 32), (uint64_t)v[2].z | ((uint64_t)v[2].w << 32)};
+        uint32_t found = 0;
+#pragma unroll
+        for (int sl = 5; sl >= 0; --sl)
+            if ((uint32_t)sl < st.slots && kk[sl] == key) found = (uint32_t)sl + 1u;
+        if (found) {
+            const uint32_t *mp = reinterpret_cast<const uint32_t *>(base + 8u * st.slots) + (found - 1u) * st.W;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)  // (static indices: the words stay in registers)
+                if ((uint32_t)i < st.W) w[i] = mp[i];
+            return;
+        }
+        if ((st.slots >= 6u ? kk[5] : kk[4]) == EMPTY_KEY) return;  // line not full: absent
+        level = min(level + 1, GROUP_CHAIN + 1);
+        advance_line(key, level, st.nbuckets, b, step);
+    }
+}
+
 // write the row bytes this sub-table owns: low nb0 bytes of m0 at column col0, low nb1 bytes of
 // m1 at col0+4 (cpp/anchor.cpp:139-164).  ROWMODE 1: one-byte rows; 2: 8-byte rows (N = 64);
 // 0: generic byte loop.
@@ -587,7 +669,7 @@ __device__ __forceinline__ void cols_or_position(unsigned long long *cols, uint3
 // by lane.  Two for many-genome tables (narrow windows, big groups: a third of the overflowing keys overflow again); ONE
 // for the wide-window tables of up to 16 genomes, where the second staged level costs more than the few lanes it saves
 // (+1.5 % at configs 1-2, tools/ab_one.sh; -1 % at 64 genomes).
-template <bool TWO, int ROWMODE, int SLOTS, int MAXRUN, bool WIDE, int LEVELS>
+template <bool TWO, int ROWMODE, int SLOTS, int MAXRUN, bool WIDE, int LEVELS, bool INL = false>
 __device__ __forceinline__ void drain_queue(const SubTable &st, uint32_t qn, const uint64_t *sw, const uint64_t *rw, uint32_t *q_line,
                                             uint32_t *q_step, uint16_t *q_pl, uint32_t *lines_w, uint4 *buf,
                                             uint8_t *tile_rows, uint32_t nbytes, const RowCols rc, int lane) {
@@ -598,7 +680,7 @@ __device__ __forceinline__ void drain_queue(const SubTable &st, uint32_t qn, con
     constexpr int LDS_LINE_U4 = SLOTS + 1;
     constexpr int STAGE_ITERS = (MAXRUN * SLOTS + 63) / 64;
     const uint8_t *chunk_base = st.buckets + (uint32_t)(lane % SLOTS) * 16u;
-    const uint32_t lbytes = st.slots * (WIDE ? 8u : 16u);  // (= 16 * SLOTS, as a run-time scalar: see k_probe)
+    const uint32_t lbytes = INL ? st.layout * 64u : st.slots * (WIDE ? 8u : 16u);  // (= 16 * SLOTS = 128, as a run-time scalar: see k_probe)
     static_assert(LEVELS >= 1, "k_probe's entries (home line, group) are turned into (next line, step) by level 1's staged batches");
     for (int level = 1; qn > 0; ++level) {
         __syncthreads();
@@ -608,7 +690,11 @@ __device__ __forceinline__ void drain_queue(const SubTable &st, uint32_t qn, con
             for (uint32_t e = lane; e < qn; e += 64) {
                 uint32_t m0, m1;
                 const uint64_t key = canonical_from_le(extract_bases(sw, q_pl[e]), k);
-                if constexpr (WIDE) {
+                if constexpr (WIDE && INL) {
+                    uint32_t rw4[4];
+                    lane_chase_inl(st, key, (uint32_t)level, q_line[e], q_step[e], rw4);
+                    if (rw4[0] | rw4[1] | rw4[2] | rw4[3]) store_row_regs(tile_rows + (uint64_t)q_pl[e] * nbytes, nbytes, rw4);
+                } else if constexpr (WIDE) {
                     lane_chase_wide(st, key, (uint32_t)level, q_line[e], q_step[e], m0, m1);
                     if (m1) store_row_wide(st.masks, st.W, nbytes, tile_rows + (uint64_t)q_pl[e] * nbytes, m0, m1);
                 } else {
@@ -639,6 +725,7 @@ __device__ __forceinline__ void drain_queue(const SubTable &st, uint32_t qn, con
             const uint32_t rid = lanes_le_index(lmask, 0u);
             const uint32_t nruns = (uint32_t)__popcll(lmask);
             uint32_t m0 = 0, m1 = 0;
+            [[maybe_unused]] uint32_t rw4[4] = {0, 0, 0, 0};  // (inline layout: the row's words)
             int rcode = 0;
             // (staging as in k_probe's main batches: the entries behind the last run repeat the first run's line, every lane
             // reads its entries at fixed places, one multiply-add per address)
@@ -662,7 +749,10 @@ __device__ __forceinline__ void drain_queue(const SubTable &st, uint32_t qn, con
                 }
                 __syncthreads();
                 if (act && rid - r0 < nl) {
-                    if constexpr (WIDE) {
+                    if constexpr (WIDE && INL) {
+                        rcode = scan_keys_inl(buf + (rid - r0) * LDS_LINE_U4, key, st.slots, m1);
+                        if (m1) masks_inl(buf + (rid - r0) * LDS_LINE_U4, st.slots, st.W, m1 - 1u, rw4);
+                    } else if constexpr (WIDE) {
                         rcode = scan_keys16_lds(buf + (rid - r0) * LDS_LINE_U4, key, m1);
                         m0 = line;
                     } else {
@@ -672,7 +762,9 @@ __device__ __forceinline__ void drain_queue(const SubTable &st, uint32_t qn, con
                 __syncthreads();
             }
             const bool again = act && rcode < 0;
-            if constexpr (WIDE) {
+            if constexpr (WIDE && INL) {
+                if (act && m1) store_row_regs(tile_rows + (uint64_t)pl * nbytes, nbytes, rw4);
+            } else if constexpr (WIDE) {
                 if (act && m1) store_row_wide(st.masks, st.W, nbytes, tile_rows + (uint64_t)pl * nbytes, m0, m1);
             } else {
                 if constexpr (ROWMODE == 3) {
@@ -704,18 +796,24 @@ __device__ __forceinline__ void drain_queue(const SubTable &st, uint32_t qn, con
 // staging geometry is the same, a line holds 16 bare keys; m0 / m1 carry the hit's line and slot + 1)
 // (probe_pipelined: the instantiations that run the skewed batch order, see the end of the kernel; they are held to the 64
 // registers of 8 waves per SIMD — the only spill that costs them sits around the queue-full call, a cold path)
+#ifndef PG_INL_WAVES8
+#define PG_INL_WAVES8 1  // the inline-layout probe held to the 64 registers of 8 waves per SIMD
+#endif
 #ifndef PG_PIPE_MORE
 #define PG_PIPE_MORE 5  // which further instantiations run the skewed order: bit 0 two-word slots, 1 split layout, 2 the 6-m-mer window, 3 generic rows
 #endif
-template <int W_C, bool TWO, int ROWMODE, int SLOTS, bool WIDE>
+#ifndef PG_INL_PIPE
+#define PG_INL_PIPE 0  // 1: the inline-layout probe in the skewed batch order too (it needs 43 registers in the plain order)
+#endif
+template <int W_C, bool TWO, int ROWMODE, int SLOTS, bool WIDE, bool INL = false>
 constexpr bool probe_pipelined = PG_PROBE_PIPE && SLOTS == 8 && (ROWMODE != 3) && ((ROWMODE == 1 || ROWMODE >= 4) || (PG_PIPE_MORE & 8) || TWO || WIDE) &&
-                                 (!TWO || (PG_PIPE_MORE & 1)) && (!WIDE || (PG_PIPE_MORE & 2)) && (W_C != 6 || (PG_PIPE_MORE & 4));
+                                 (!TWO || (PG_PIPE_MORE & 1)) && (!WIDE || (PG_PIPE_MORE & 2) || (INL && PG_INL_PIPE)) && (W_C != 6 || (PG_PIPE_MORE & 4));
 // The scalar registers count too: a SIMD's 800 SGPRs admit floor(800 / (ceil(sgpr / 16) * 16 + 16)) waves — 8 up to 80, 7 up to
 // 96, 6 up to 112 (MI355X_MICROARCH.md) — whatever the compiler's own occupancy figure says.  Left alone the generic-row and
 // split-layout instantiations took 92 and 105 (their lane masks live on the scalar unit): 7 and 6 waves.  Held to 80, a dozen
 // masks move to vector lanes and the ninth to 63rd genome gain 3-6 % (27 x 40 Mb 140 -> 148 G k-mers/s).
-template <int W_C, bool TWO, int ROWMODE, int SLOTS, bool M64, bool WIDE = false>
-__global__ __launch_bounds__(64, (probe_pipelined<W_C, TWO, ROWMODE, SLOTS, WIDE> ? 8 : 1))
+template <int W_C, bool TWO, int ROWMODE, int SLOTS, bool M64, bool WIDE = false, bool INL = false>
+__global__ __launch_bounds__(64, ((probe_pipelined<W_C, TWO, ROWMODE, SLOTS, WIDE, INL> || (INL && PG_INL_WAVES8)) ? 8 : 1))
 __attribute__((amdgpu_num_sgpr(80))) void k_probe(const SubTable st, const uint64_t *__restrict__ seqw,
                                               const uint32_t *__restrict__ nmw, const uint32_t *__restrict__ has_n,
                                               const SeqDesc *__restrict__ sd, const AnchorDesc *__restrict__ ad,
@@ -812,7 +910,7 @@ __attribute__((amdgpu_num_sgpr(80))) void k_probe(const SubTable st, const uint6
     uint32_t qn = 0;  // wave-uniform: overflow entries of this tile so far
 
     const uint8_t *chunk_base = st.buckets + (uint32_t)(lane % SLOTS) * 16u;  // this lane's 16-byte chunk of line 0
-    const uint32_t lbytes = st.slots * (WIDE ? 8u : 16u);                      // bytes per line (= 16 * SLOTS), as a run-time scalar
+    const uint32_t lbytes = INL ? st.layout * 64u : st.slots * (WIDE ? 8u : 16u);  // bytes per line (= 16 * SLOTS = 128), as a run-time scalar (inline layout: LAYOUT_INLINE * 64)
 
     // A batch in three parts, so that the front end of batch i + 1 can run while the table lines of batch i are on
     // their way (PG_PROBE_PIPE): the fetch is the longest wait of a batch — a couple of thousand cycles behind a busy
@@ -984,6 +1082,7 @@ __attribute__((amdgpu_num_sgpr(80))) void k_probe(const SubTable st, const uint6
         const bool act = __builtin_amdgcn_inverse_ballot_w64(f.amask), inrange = __builtin_amdgcn_inverse_ballot_w64(f.rmask);
         const int32_t pl = (int32_t)(b0 + lane) - LHALO;
         uint32_t m0 = 0, m1 = 0;
+        [[maybe_unused]] uint32_t rw4[4] = {0, 0, 0, 0};  // (inline layout: the row's words, zeros for an absent key)
         int rcode = 0;
         // a staging step's chunks into LDS (wave-uniform placement: chunk idx of the step -> line idx / SLOTS, slot
         // idx % SLOTS), then every lane of the step's runs scans its own line
@@ -1014,7 +1113,10 @@ __attribute__((amdgpu_num_sgpr(80))) void k_probe(const SubTable st, const uint6
             }
 #else
             if (act && f.rid - r0 < nl) {
-                if constexpr (WIDE) {
+                if constexpr (WIDE && INL) {
+                    rcode = scan_keys_inl(buf[0] + (f.rid - r0) * LDS_LINE_U4, f.key, st.slots, m1);
+                    if (m1) masks_inl(buf[0] + (f.rid - r0) * LDS_LINE_U4, st.slots, st.W, m1 - 1u, rw4);
+                } else if constexpr (WIDE) {
                     rcode = scan_keys16_lds(buf[0] + (f.rid - r0) * LDS_LINE_U4, f.key, m1);
                     m0 = f.line;
                 } else {
@@ -1076,7 +1178,9 @@ __attribute__((amdgpu_num_sgpr(80))) void k_probe(const SubTable st, const uint6
         }
         PG_PH(10)
         // (32-bit offset from the tile's uniform base: one store with a scalar base address)
-        if constexpr (WIDE) {
+        if constexpr (WIDE && INL) {
+            if (inrange) store_row_regs(tile_rows + (uint64_t)(uint32_t)pl * nbytes, nbytes, rw4);
+        } else if constexpr (WIDE) {
 #if PG_ABLATE == 2  // (timing experiment: no mask gather, no row store)
             if (inrange && m0 == 0xDEADBEEFu && m1 == 77u)
 #elif PG_ABLATE == 8 || PG_ABLATE == 10  // (timing experiment, wrong rows: the row store without a DIVERGENT mask gather — every hit copies slot 0 of line 0's block)
@@ -1131,7 +1235,7 @@ __attribute__((amdgpu_num_sgpr(80))) void k_probe(const SubTable st, const uint6
     // and two batches' keys in registers at once: it pays where that still fits 64 registers (8 waves per SIMD: this
     // kernel's speed goes with its occupancy — 7 waves cost 7 %, 5 waves 28 %), i.e. for the one-byte rows of up to 8
     // genomes (configs[1]: 4.31 -> 4.17 ms); the wider instantiations spill there and keep the plain order.
-    constexpr bool PIPE = probe_pipelined<W_C, TWO, ROWMODE, SLOTS, WIDE>;
+    constexpr bool PIPE = probe_pipelined<W_C, TWO, ROWMODE, SLOTS, WIDE, INL>;
     constexpr int LEVELS = (W_C >= 6 && !TWO && !WIDE && PROBE_STAGED_LEVELS > 1) ? 1 : PROBE_STAGED_LEVELS;  // (W_C >= 6: the wide-window tables of up to 16 genomes)
     // The batch loop runs until the tile is through OR the overflow queue could not take another full batch (tiles inside
     // a repeat family: most of their keys sit outside their home lines): the queue is drained then and the loop goes on
@@ -1199,7 +1303,7 @@ __attribute__((amdgpu_num_sgpr(80))) void k_probe(const SubTable st, const uint6
     }
     PG_PH(7)
     for (;;) {
-        drain_queue<TWO, ROWMODE, SLOTS, MAXRUN, WIDE, LEVELS>(st, qn, sw, rw, q_line, q_step, q_pl, lines_w[0], buf[0], tile_rows, nbytes, rc, lane);
+        drain_queue<TWO, ROWMODE, SLOTS, MAXRUN, WIDE, LEVELS, INL>(st, qn, sw, rw, q_line, q_step, q_pl, lines_w[0], buf[0], tile_rows, nbytes, rc, lane);
         qn = 0;
         if (b0 >= npos) break;
         __syncthreads();
@@ -1254,7 +1358,7 @@ constexpr int INSERT_QCAP = 256;
 template <bool COUNT, bool CLAIM = true>
 __device__ __forceinline__ int wave_insert_batch(const SubTable &st, bool valid, uint64_t key, uint32_t grp, int w, uint32_t bits,
                                                  uint32_t max_probe, int lane) {
-    const uint32_t kstride = st.layout == LAYOUT_SPLIT ? 8u : 16u, slots = st.slots;
+    const uint32_t kstride = key_stride(st), slots = st.slots;
     uint32_t b = home_of_group(grp, st.nbuckets), step = step_of_group(grp, st.nbuckets), probes = 0;
     int s = -1;  // slot to try next in line b; -1: the line has not been read yet; slots: the line is full
     bool done = !valid, fresh = false;  // fresh: the line has just been read, s is its first empty slot
@@ -1291,9 +1395,11 @@ __device__ __forceinline__ int wave_insert_batch(const SubTable &st, bool valid,
             for (uint32_t s0 = 0; s0 < slots; s0 += 8) {
                 uint64_t kk[8];
 #pragma unroll
-                for (int i = 0; i < 8; ++i)
+                for (int i = 0; i < 8; ++i) {
                     kk[i] = __hip_atomic_load(reinterpret_cast<unsigned long long *>(base + kstride * (s0 + i)), __ATOMIC_RELAXED,
                                               __HIP_MEMORY_SCOPE_AGENT);
+                    if (s0 + (uint32_t)i >= slots) kk[i] = TOMB_KEY;  // (inline layout: mask words behind the line's 5 or 6 keys — neither a key nor empty)
+                }
                 int h8 = -1, f8 = -1;
 #pragma unroll
                 for (int i = 7; i >= 0; --i) {
@@ -1522,7 +1628,15 @@ __global__ __launch_bounds__(64) void k_insert_tile(const SubTable st, int w, ui
                 const uint4 *ln = buf + (rid - r0) * LDS_LINE_U4;
                 uint32_t *mp = nullptr;
                 uint32_t cur = 0;
-                if (split) {
+                if (st.layout == LAYOUT_INLINE) {  // (uniform)
+                    uint32_t slot1;
+                    full = scan_keys_inl(ln, key, st.slots, slot1) < 0;
+                    if (slot1) {
+                        found = true;
+                        mp = mask_ptr(st, line, slot1 - 1u, (uint32_t)w);
+                        cur = *reinterpret_cast<const volatile uint32_t *>(mp);
+                    }
+                } else if (split) {
                     uint32_t slot1;
                     full = scan_keys16_lds<true>(ln, key, slot1) < 0;
                     if (slot1) {
@@ -3421,6 +3535,15 @@ static hipError_t probe_w(hipStream_t s, uint32_t ntiles, const SubTable &st, co
                           const uint32_t *has_n, const SeqDesc *sd, const AnchorDesc *ad, const uint32_t *tile_contig,
                           const uint32_t *sched, uint32_t tile_base, uint8_t *out1, uint32_t nbytes, const RowCols &rc, int rowmode) {
 #define PG_A s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, sched, tile_base, out1, nbytes, rc
+    if (st.layout == LAYOUT_INLINE) {  // 65..128 genomes: keys and their mask blocks in one line
+        if (W_C && st.m > 16)
+            hipLaunchKernelGGL((k_probe<W_C, false, 0, 8, true, true, true>), dim3(ntiles), dim3(64), 0, s, st, seqw, nmw, has_n, sd, ad,
+                               tile_contig, sched, tile_base, out1, nbytes, rc);
+        else
+            hipLaunchKernelGGL((k_probe<W_C, false, 0, 8, false, true, true>), dim3(ntiles), dim3(64), 0, s, st, seqw, nmw, has_n, sd, ad,
+                               tile_contig, sched, tile_base, out1, nbytes, rc);
+        return hipGetLastError();
+    }
     if (st.layout == LAYOUT_SPLIT) {  // more than 64 genomes: key lines + mask array
         if (W_C && st.m > 16)
             hipLaunchKernelGGL((k_probe<W_C, false, 0, 8, true, true>), dim3(ntiles), dim3(64), 0, s, st, seqw, nmw, has_n, sd, ad,

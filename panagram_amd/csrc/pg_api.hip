@@ -187,6 +187,9 @@ static constexpr size_t EV_RING = 128;
 
 static constexpr uint32_t MAX_PROBE = 512;  // lines an insert may walk before the table is grown
 static constexpr double GROW_AT = 0.55;     // grow when keys > GROW_AT * slots
+#ifndef PG_INLINE_LAYOUT
+#define PG_INLINE_LAYOUT 1
+#endif
 static constexpr double TARGET_LOAD = 0.375; // load right after growing (3 keys per 8-slot line)
 static constexpr double HARD_LOAD = 0.85;   // worst-case guard before a batch
 
@@ -453,9 +456,17 @@ static int alloc_sub(pg_ctx *ctx, uint32_t W, uint32_t word0, uint32_t k, uint32
 struct TableGeom {
     uint32_t W, slots, layout;
 };
+// 65..96 genomes (W = 3): the inline layout — 6 keys per 128-byte line with their mask blocks behind them (5 at W = 4: kept for experiments), no
+// dependent gather (PG_WIDE_LAYOUT=split: the split layout for them too, rounds 2-4; PG_WIDE_LAYOUT=inline: the default)
 static TableGeom geom_for(int ngenomes) {
     const uint32_t ndbs = (uint32_t)(ngenomes + 31) / 32;
     if (ndbs <= 2) return {ndbs, 8u, LAYOUT_SLOTS};
+    static const bool want_inline = [] {
+        const char *e = getenv("PG_WIDE_LAYOUT");
+        return !(e && strcmp(e, "split") == 0);
+    }();
+    // (W = 3 only: at W = 4 a line holds 5 keys and the split layout's 16 win — 128 x 10 Mb 10.0 ms against 10.75 at the inline layout's best m)
+    if (ndbs == 3 && want_inline && PG_INLINE_LAYOUT) return {ndbs, inline_slots(ndbs), LAYOUT_INLINE};
     return {ndbs, SPLIT_KEYS, LAYOUT_SPLIT};
 }
 
@@ -466,12 +477,12 @@ extern "C" int pg_table_bytes_for(int k, int ngenomes, uint64_t expected_keys, u
     const TableGeom g = geom_for(ngenomes);
     // (an estimate: one prime search less — the line count itself, not the next prime above it)
     const uint64_t nb = std::max<uint64_t>((uint64_t)((double)std::max<uint64_t>(expected_keys, 1ull << 18) / (TARGET_LOAD * g.slots)) + 1, 64);
-    *bytes = g.layout == LAYOUT_SPLIT ? nb * g.slots * (8ull + 4ull * g.W) : nb * 16ull * g.slots;
+    *bytes = g.layout == LAYOUT_SPLIT ? nb * g.slots * (8ull + 4ull * g.W) : g.layout == LAYOUT_INLINE ? nb * 128ull : nb * 16ull * g.slots;
     return PG_OK;
     PG_API_END
 }
 
-static uint32_t window_cap();  // (PG_TABLE_WMAX, below)
+static uint32_t window_cap(int ngenomes = 0);  // (PG_TABLE_WMAX, below)
 
 extern "C" int pg_table_create(pg_ctx *ctx, int k, int ngenomes, uint64_t expected_keys, pg_table **out) {
     PG_API_BEGIN
@@ -487,7 +498,7 @@ extern "C" int pg_table_create(pg_ctx *ctx, int k, int ngenomes, uint64_t expect
     t->k = k;
     t->ngenomes = ngenomes;
     t->ndbs = ndbs;
-    t->m = minimizer_length((uint32_t)k, expected_keys, 0, window_cap(), (uint32_t)ngenomes);
+    t->m = minimizer_length((uint32_t)k, expected_keys, 0, window_cap(ngenomes), (uint32_t)ngenomes);
     t->expected = expected_keys;
     t->d_counters = nullptr;
     hipError_t e = hipMalloc(reinterpret_cast<void **>(&t->d_counters), 2 * sizeof(unsigned long long));
@@ -592,19 +603,24 @@ extern "C" int pg_table_set_minimizer(pg_table *t, int m) {
 // mostly unique sequence and loses on content dominated by one young high-copy repeat family, whose minimizer groups it
 // makes 1.8 x larger (tools/repeat_stress.py, 27 genomes, 2000 x 3 kb copies at 3 %: 26 % of the genome 56 vs 64 G
 // k-mers/s at w = 4, 10 % of it 71 vs 76); pg_table_set_minimizer pins m for one table.
-static uint32_t window_cap() {
+// Tables in the inline layout (65..96 genomes: 6 keys per line) take a window of at most 6 m-mers: a minimizer group of w = 7 holds more
+// keys than a line and every second look-up of a variant k-mer overflows — k=21: 65 / 80 / 96 x 10 Mb 87 / 79 / 86 G k-mers/s at m = 15,
+// 103 / 98 / 106 at m = 16 (the split layout at its best m: 94 / 91 / 90); k=31, 96 genomes: 88 / 91 / 110 / 102 at w = 8 / 7 / 6 / 5
+// (profiles/r5i_inline_layout.txt).
+static uint32_t window_cap(int ngenomes) {
     static const uint32_t cap = [] {
         const char *e = getenv("PG_TABLE_WMAX");
         const int v = (e && *e) ? atoi(e) : (int)MZ_WMAX;
         return (uint32_t)std::min<int>((int)MZ_WMAX, std::max<int>((int)MZ_WMIN, v));
     }();
+    if (ngenomes > 0 && geom_for(ngenomes).layout == LAYOUT_INLINE) return std::min(cap, 6u);
     return cap;
 }
 
 extern "C" int pg_minimizer_length(int k, uint64_t expected_keys, uint64_t first_len, int wmax, int ngenomes) {
     PG_API_BEGIN
     if (k < 1 || k > 32) return 0;
-    const uint32_t cap = wmax ? (uint32_t)std::min<int>((int)MZ_WMAX, std::max<int>((int)MZ_WMIN, wmax)) : window_cap();
+    const uint32_t cap = wmax ? (uint32_t)std::min<int>((int)MZ_WMAX, std::max<int>((int)MZ_WMIN, wmax)) : window_cap(ngenomes);
     return (int)minimizer_length((uint32_t)k, expected_keys, first_len, cap, (uint32_t)std::max(0, ngenomes));
     PG_API_END
 }
@@ -612,7 +628,7 @@ extern "C" int pg_minimizer_length(int k, uint64_t expected_keys, uint64_t first
 extern "C" int pg_minimizer_length_for(int k, uint64_t expected_keys, uint64_t first_len, int wmax, int ngenomes, int coscheduled) {
     PG_API_BEGIN
     if (k < 1 || k > 32) return 0;
-    const uint32_t cap = wmax ? (uint32_t)std::min<int>((int)MZ_WMAX, std::max<int>((int)MZ_WMIN, wmax)) : window_cap();
+    const uint32_t cap = wmax ? (uint32_t)std::min<int>((int)MZ_WMAX, std::max<int>((int)MZ_WMIN, wmax)) : window_cap(ngenomes);
     return (int)minimizer_length((uint32_t)k, expected_keys, first_len, cap, (uint32_t)std::max(0, ngenomes), (uint32_t)std::max(0, coscheduled));
     PG_API_END
 }
@@ -627,7 +643,7 @@ extern "C" int pg_table_set_coscheduled(pg_table *t, int anchors) {
         if (s.count) return fail(PG_E_INVALID, "pg_table_set_coscheduled: the table already holds keys");
     t->cosched = (uint32_t)anchors;
     if (!t->m_pinned) {
-        t->m = minimizer_length((uint32_t)t->k, t->expected, t->first_len, window_cap(), (uint32_t)t->ngenomes, t->cosched);
+        t->m = minimizer_length((uint32_t)t->k, t->expected, t->first_len, window_cap(t->ngenomes), (uint32_t)t->ngenomes, t->cosched);
         for (auto &s : t->subs) s.d.m = t->m;
     }
     return PG_OK;
@@ -639,7 +655,7 @@ static void settle_minimizer(pg_table *t, uint64_t positions) {
     for (auto &s : t->subs)
         if (s.count) return;
     t->first_len = positions;
-    t->m = minimizer_length((uint32_t)t->k, t->expected, positions, window_cap(), (uint32_t)t->ngenomes, t->cosched);
+    t->m = minimizer_length((uint32_t)t->k, t->expected, positions, window_cap(t->ngenomes), (uint32_t)t->ngenomes, t->cosched);
     for (auto &s : t->subs) s.d.m = t->m;
 }
 
@@ -723,7 +739,7 @@ static int after_insert(pg_table *t, int si) {
 static int enqueue_insert(pg_table *t, const SubTable &d, int w, uint32_t bits, int count_mode, const pg_seqset *sq,
                           unsigned long long *counters) {
     hipStream_t st = t->ctx->stream;
-    const bool tiles_ok = d.layout == LAYOUT_SPLIT || d.slots == 8;
+    const bool tiles_ok = d.layout != LAYOUT_SLOTS || d.slots == 8;
     if (!tiles_ok || getenv("PG_INSERT_PER_THREAD")) {
         for (uint32_t c = 0; c < sq->n; ++c) {
             const SeqDesc &sd = sq->desc[c];
@@ -797,7 +813,7 @@ extern "C" int pg_table_update_seqset(pg_table *t, int g, const pg_seqset *sq) {
     if (g < 0 || g >= t->ngenomes) return fail(PG_E_INVALID, "genome index %d out of range (0..%d)", g, t->ngenomes - 1);
     if (t->ctx != sq->ctx) return fail(PG_E_INVALID, "table and seqset belong to different contexts");
     const SubTable &d0 = t->subs[0].d;
-    if (!(d0.layout == LAYOUT_SPLIT || d0.slots == 8) || getenv("PG_INSERT_PER_THREAD")) return pg_table_insert_seqset(t, g, sq);
+    if (!(d0.layout != LAYOUT_SLOTS || d0.slots == 8) || getenv("PG_INSERT_PER_THREAD")) return pg_table_insert_seqset(t, g, sq);
     if (int r = use_device(t->ctx)) return r;
     TABLE_WRITER(t);
     const int w = g / 32;
@@ -1018,7 +1034,7 @@ extern "C" int pg_table_load_kmc(pg_table *t, int db_idx, const void *pre_, size
         bool empty = !t->m_pinned && !t->first_len;
         for (auto &sh : t->subs) empty = empty && sh.count == 0;
         if (empty && !t->expected) {
-            t->m = minimizer_length((uint32_t)t->k, H.total, 0, window_cap(), (uint32_t)t->ngenomes, t->cosched);
+            t->m = minimizer_length((uint32_t)t->k, H.total, 0, window_cap(t->ngenomes), (uint32_t)t->ngenomes, t->cosched);
             for (auto &sh : t->subs) sh.d.m = t->m;
         }
     }
@@ -1162,7 +1178,7 @@ extern "C" int pg_table_rehash(pg_table *t, double keys_per_bucket) {
     if (!t->m_pinned) {  // the key count is known now: settle the minimizer length for it
         uint64_t most = 0;
         for (auto &s : t->subs) most = std::max<uint64_t>(most, s.count);
-        t->m = minimizer_length((uint32_t)t->k, most, t->max_len, window_cap(), (uint32_t)t->ngenomes, t->cosched);
+        t->m = minimizer_length((uint32_t)t->k, most, t->max_len, window_cap(t->ngenomes), (uint32_t)t->ngenomes, t->cosched);
     }
     // Line width: 128-byte lines of 8 slots.  256-byte lines of 16 slots (PG_TABLE_SLOTS=16, a tuning
     // knob) keep a many-variant locus in ONE place at the price of two requests per line; measured,
@@ -1173,7 +1189,7 @@ extern "C" int pg_table_rehash(pg_table *t, double keys_per_bucket) {
         if (atoi(e) == 16) slots = 16;
     uint64_t keys = 0, spilled = 0;
     for (size_t si = 0; si < t->subs.size(); ++si) {
-        if (t->subs[si].d.layout == LAYOUT_SPLIT) slots = SPLIT_KEYS;
+        if (t->subs[si].d.layout != LAYOUT_SLOTS) slots = t->subs[si].d.slots;  // (split and inline lines keep their geometry)
         const double kpb = std::min(keys_per_bucket * (slots / 8.0), 0.8 * slots);  // keys per line
         if (int r = regrow(t, (int)si, (uint64_t)((double)t->subs[si].count / kpb) + 1, slots)) return r;
         uint64_t sp = 0;

@@ -1,7 +1,8 @@
 // pg_device.h — device-side building blocks shared by the gfx950 kernels.
 //
-// Table layout (up to 64 genomes: one sub-table of W = 1 or 2 mask words per slot, described here; more genomes: ONE
-// table in the split layout — bare keys in the lines, all mask words of a slot in a second array — see SubTable):
+// Table layout (up to 64 genomes: one sub-table of W = 1 or 2 mask words per slot, described here; 65..96 genomes: ONE table in
+// the inline layout — 6 bare keys and their mask blocks in one line; more genomes: ONE table in the split layout — bare keys
+// in the lines, all mask words of a slot in a second array — see SubTable):
 //   line   = 128 bytes, 128-byte aligned: MI355X moves 128 B per random HBM access whatever
 //            the request size (tools/gather_bench.hip: 32/64/128-B random gathers all run at
 //            ~50 G requests/s), so a probe fetches — and uses — a whole line
@@ -54,18 +55,27 @@ struct SubTable {
     uint32_t layout;    // LAYOUT_SLOTS / LAYOUT_SPLIT
     uint8_t *masks;     // LAYOUT_SPLIT only
 };
-constexpr uint32_t LAYOUT_SLOTS = 0, LAYOUT_SPLIT = 1;
+constexpr uint32_t LAYOUT_SLOTS = 0, LAYOUT_SPLIT = 1, LAYOUT_INLINE = 2;
 constexpr uint32_t SPLIT_KEYS = 16;  // keys per line of the split layout
+//   LAYOUT_INLINE (65..128 genomes, round 5): a 128-byte line = S bare keys followed by the S slots' mask blocks of W words —
+//                S = 6 at W = 3 (48 + 72 bytes), S = 5 at W = 4 (40 + 80 bytes): ONE fetch brings a hit's mask words with its
+//                key, where the split layout's probe follows its key line with a dependent, divergent gather
+__host__ __device__ __forceinline__ uint32_t inline_slots(uint32_t W) { return 120u / (8u + 4u * W); }
 
-__host__ __device__ __forceinline__ uint32_t line_bytes(const SubTable &st) { return (st.layout == LAYOUT_SPLIT ? 8u : 16u) * st.slots; }
+__host__ __device__ __forceinline__ uint32_t line_bytes(const SubTable &st) {
+    return st.layout == LAYOUT_INLINE ? 128u : (st.layout == LAYOUT_SPLIT ? 8u : 16u) * st.slots;
+}
+// bytes from one key of a line to the next
+__host__ __device__ __forceinline__ uint32_t key_stride(const SubTable &st) { return st.layout == LAYOUT_SLOTS ? 16u : 8u; }
 __host__ __device__ __forceinline__ uint64_t table_bytes(const SubTable &st) {
     return st.nbuckets * line_bytes(st) + (st.layout == LAYOUT_SPLIT ? st.nbuckets * st.slots * 4ull * st.W : 0ull);
 }
 __device__ __forceinline__ unsigned long long *key_ptr(const SubTable &st, uint64_t line, uint32_t s) {
-    return reinterpret_cast<unsigned long long *>(st.buckets + line * line_bytes(st) + (st.layout == LAYOUT_SPLIT ? 8u : 16u) * s);
+    return reinterpret_cast<unsigned long long *>(st.buckets + line * line_bytes(st) + key_stride(st) * s);
 }
 __device__ __forceinline__ uint32_t *mask_ptr(const SubTable &st, uint64_t line, uint32_t s, uint32_t w) {
     if (st.layout == LAYOUT_SPLIT) return reinterpret_cast<uint32_t *>(st.masks) + (line * st.slots + s) * st.W + w;
+    if (st.layout == LAYOUT_INLINE) return reinterpret_cast<uint32_t *>(st.buckets + line * 128u + 8u * st.slots) + s * st.W + w;
     return reinterpret_cast<uint32_t *>(st.buckets + line * (16u * st.slots) + 16u * s + 8u) + w;
 }
 
@@ -367,15 +377,17 @@ __device__ __forceinline__ int lane_insert_grp(const SubTable &st, uint64_t key,
                                                uint32_t grp) {
     uint32_t b = home_of_group(grp, st.nbuckets);
     uint32_t step = step_of_group(grp, st.nbuckets);
-    const uint32_t kstride = st.layout == LAYOUT_SPLIT ? 8u : 16u;  // bytes from one key of a line to the next
+    const uint32_t kstride = key_stride(st);  // bytes from one key of a line to the next
     for (uint32_t probes = 0; probes < max_probe; ++probes) {
         uint8_t *base = st.buckets + (uint64_t)b * line_bytes(st);
         for (uint32_t s0 = 0; s0 < st.slots; s0 += 8) {  // 8 slots at a time: all key loads in flight together
             uint8_t *grp8 = base + kstride * s0;
             uint64_t kk[8];
 #pragma unroll
-            for (int s = 0; s < 8; ++s)  // (relaxed atomic loads: all eight in flight together; volatile ones are waited for one by one)
+            for (int s = 0; s < 8; ++s) {  // (relaxed atomic loads: all eight in flight together; volatile ones are waited for one by one)
                 kk[s] = __hip_atomic_load(reinterpret_cast<unsigned long long *>(grp8 + kstride * s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (s0 + s >= st.slots) kk[s] = TOMB_KEY;  // (inline layout: 5 or 6 keys, mask words behind them — neither a key nor empty)
+            }
             int hit = -1, free_s = -1;
 #pragma unroll
             for (int s = 7; s >= 0; --s) {
@@ -385,7 +397,7 @@ __device__ __forceinline__ int lane_insert_grp(const SubTable &st, uint64_t key,
             int claimed = 0;
             // slots before the first empty one hold other keys for good; from there on a slot may be
             // taken by a concurrent insert between our read and our CAS: walk on, one CAS per slot
-            for (int s = (hit >= 0 ? hit : free_s); hit < 0 && s >= 0 && s < 8; ++s) {
+            for (int s = (hit >= 0 ? hit : free_s); hit < 0 && s >= 0 && s < 8 && s0 + (uint32_t)s < st.slots; ++s) {
                 unsigned long long *kp = reinterpret_cast<unsigned long long *>(grp8 + kstride * s);
                 const unsigned long long cur = atomicCAS(kp, (unsigned long long)EMPTY_KEY, (unsigned long long)key);
                 if (cur == EMPTY_KEY) {

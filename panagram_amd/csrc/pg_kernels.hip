@@ -18,12 +18,20 @@ namespace pg {
 // ---------------------------------------------------------------------------
 // table init: every thread writes one 16-byte chunk of a bucket
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_table_init(uint4 *chunks, uint64_t nchunks, uint32_t split) {
+// mode 0: slots layout, 1: split layout's key lines, 2 + S: inline layout with S keys per 128-byte line
+__global__ __launch_bounds__(256) void k_table_init(uint4 *chunks, uint64_t nchunks, uint32_t mode) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (; i < nchunks; i += stride) {
-        // slots layout: {EMPTY key, mask0 = 0, mask1 = 0}; split layout: two EMPTY keys (the mask array is memset)
-        chunks[i] = split ? make_uint4(~0u, ~0u, ~0u, ~0u) : make_uint4(~0u, ~0u, 0u, 0u);
+        // slots layout: {EMPTY key, mask0 = 0, mask1 = 0}; split layout: two EMPTY keys (the mask array is memset);
+        // inline layout: the line's first S 8-byte words are EMPTY keys, the mask blocks behind them zero
+        if (mode >= 2) {
+            const uint32_t S = mode - 2u, k0 = 2u * (uint32_t)(i & 7u);  // this chunk's two 8-byte words of its line
+            const uint32_t a = k0 < S ? ~0u : 0u, b = k0 + 1u < S ? ~0u : 0u;
+            chunks[i] = make_uint4(a, a, b, b);
+        } else {
+            chunks[i] = mode ? make_uint4(~0u, ~0u, ~0u, ~0u) : make_uint4(~0u, ~0u, 0u, 0u);
+        }
     }
 }
 
@@ -462,7 +470,8 @@ static inline unsigned grid_for(uint64_t n, unsigned block, unsigned cap) {
 hipError_t launch_table_init(hipStream_t st, const SubTable &t) {
     const uint64_t nchunks = t.nbuckets * line_bytes(t) / 16;
     hipLaunchKernelGGL(k_table_init, dim3(grid_for(nchunks, 256, 256 * 32)), dim3(256), 0, st,
-                       reinterpret_cast<uint4 *>(t.buckets), nchunks, t.layout == LAYOUT_SPLIT ? 1u : 0u);
+                       reinterpret_cast<uint4 *>(t.buckets), nchunks,
+                       t.layout == LAYOUT_INLINE ? 2u + t.slots : t.layout == LAYOUT_SPLIT ? 1u : 0u);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess && t.layout == LAYOUT_SPLIT)
         e = hipMemsetAsync(t.masks, 0, t.nbuckets * t.slots * 4ull * t.W, st);

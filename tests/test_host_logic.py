@@ -403,6 +403,10 @@ def test_minimizer_length_rule():
         assert f(k, keys, first_len, wmax, 8) == want, (k, keys, first_len, wmax, f(k, keys, first_len, wmax, 8), want)
     # more than 64 genomes (split layout: 16 keys per line): merged groups cost half as much
     assert f(21, 1000 * M, 40 * M, 8, 128) == 15 and f(21, 1000 * M, 40 * M, 8, 64) == 16 and f(21, 300 * M, 10 * M, 8, 128) == 15
+    # 65..96 genomes (inline layout: 6 keys per line): the library's own cap (wmax = 0) holds the window to 6 m-mers — a group of
+    # w = 7 does not fit a line (profiles/r5i_inline_layout.txt); 97+ genomes keep the split layout and the wide window
+    assert f(21, 123 * M, 10 * M, 0, 65) == 16 and f(21, 172 * M, 10 * M, 0, 96) == 16 and f(31, 241 * M, 10 * M, 0, 96) == 26
+    assert f(21, 218 * M, 10 * M, 0, 128) == 15 and f(21, 123 * M, 10 * M, 0, 64) == 15
     for k in range(20, 33):  # whatever the sizes: a window of 3..8, m >= 15 where k allows it
         for keys in (0, 10 ** 6, 10 ** 8, 10 ** 10):
             for first_len in (0, 10 ** 4, 10 ** 8, 3 * 10 ** 9):
