@@ -465,6 +465,53 @@ def north_star_leg(ctx, dev, args):
     return out
 
 
+def wide_legs(ctx, dev, args, k=21):
+    """More than 64 genomes (rows of 9, 12 and 16 bytes): 65 / 96 / 128 synthetic 10 Mb genomes (2 contigs each), d = 0.01, all
+    anchored per step in one co-scheduled launch + one statistics pass — the inline table layout (65..96 genomes) and the split
+    layout (more) with k_epilogue_w; the first 200 000 rows of two anchors against the CPU oracle (k-mer DB of the samples by brute
+    force with torch).  Outside the timed region of ``value``.  The reference's multi-DB loop: cpp/anchor.cpp:138-165."""
+    out = []
+    for G in (65, 96, 128):
+        L, C = 10_000_000, 2
+        contig_lens = [L // C] * C
+        pg = Pangenome(ctx, dev, G, contig_lens, 0.01, args.seed + 2, k, keep_ascii=True)
+        sample_n = 200_000
+        picks = [0, G - 1]
+        samples = [pg.ascii[g][0][:sample_n] for g in picks]
+        dbs = sample_db_by_brute_force(pg.ascii, samples, k, G)
+        samples_host = [x.cpu().numpy() for x in samples]
+        pg.ascii = None
+        torch.cuda.empty_cache()
+        results, merged = make_results(ctx, pg, True, False, 0)
+        steps, warmup = 5, 2
+        for _ in range(warmup):
+            results[0].run()
+        torch.cuda.synchronize()
+        results[0].timing_reset()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            results[0].run()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        p_ms, e_ms, nruns = results[0].timing_mean()
+        pos = sum(pg.pos_per_genome)
+        v, cdt, npos, ok = cpu_baseline(dbs, samples_host, k, G,
+                                        lambda t, n: results[0].download(picks[t] * C, want_bitmap100=False)[0][:n])
+        st = pg.stats
+        out.append({"genomes": G, "genome_mb": L / 1e6, "nbytes": (G + 7) // 8, "value": pos * steps / dt, "unit": "k-mers/s",
+                    "ms_per_step": 1e3 * dt / steps, "k_probe_ms": p_ms, "statistics_ms": e_ms, "positions_per_step": pos,
+                    "table_keys": st["nkeys"], "table_bytes": st["bytes"], "table_keys_per_line_capacity": st["nslots"] // st["nbuckets"],
+                    "minimizer_length": pg.table.minimizer, "table_spill_fraction": pg.table.measure_spill(), "table_build_s": pg.build_s,
+                    "rows_equal_gpu": ok, "rows_check": f"first {sample_n} rows of genomes {picks} == CPU oracle rows"})
+        for r in results:
+            r.close()
+        if merged is not None:
+            merged.close()
+        pg.close()
+        ctx.trim()
+    return out
+
+
 def config5_leg(ctx, dev, args, genome_mb=None, contigs=24, sample_n=1_000_000, chunk_positions=None):
     """BASELINE.json configs[4] AS SPECIFIED — 8 synthetic 3 Gb genomes (24 contigs of 125 Mb each), k=21, d=0.05: 1.7e10
     distinct k-mers, more than one GPU's 288 GB holds — on ONE GPU through the product's own pass mode
@@ -1284,6 +1331,11 @@ def main():
             out["config"]["other_shapes"] = [north_star_leg(ctx, dev, args)]
         except Exception as e:
             out["config"]["other_shapes"] = [{"error": f"{type(e).__name__}: {e}"}]
+    if world == 1 and default_shape and not args.no_other_shapes:
+        try:
+            out["config"]["wide_shapes"] = wide_legs(ctx, dev, args)
+        except Exception as e:
+            out["config"]["wide_shapes"] = [{"error": f"{type(e).__name__}: {e}"}]
     if world == 1 and default_shape and not args.no_config5:
         try:
             out["config"]["config5_leg"] = config5_leg(ctx, dev, args)
