@@ -306,6 +306,72 @@ def test_three_subtables_n130(ctx):
     tbl.close()
 
 
+@pytest.mark.parametrize("n,k", [(70, 21), (96, 31), (65, 15)])
+def test_inline_layout_table_operations(ctx, n, k, tmp_path):
+    """65..96 genomes: the inline table layout (6 bare keys + their mask blocks per 128-byte line) through every operation that
+    touches a table — wave-cooperative build, export per 32-genome group, key-array import, re-hash to a dense table (long
+    chains, the overflow levels and the lane-by-lane chase), update-only insertion, GetCountersForRead look-ups, the KMC import
+    and a cleared table built again — against the oracle's databases and rows (cpp/anchor.cpp:138-165; index.py:934-945).
+    k = 15: direct mode (no minimizer)."""
+    from panagram_amd import engine
+    gen = po.synth_genomes(n, [9000, 2500], 0.02, 5151 + n)
+    genomes = [[po.codes_to_ascii(c) for c in g] for g in gen]
+    dbs = po.build_bitvec_dbs(genomes, k)
+    tbl = engine.PanTable(ctx, k, n)
+    sets = [engine.SeqSet.from_host(ctx, g) for g in genomes]
+    for g in range(n):
+        tbl.insert_seqset(g, sets[g])
+    st = tbl.stats()
+    assert st["nslots"] // st["nbuckets"] == 6, st  # the inline layout: six keys per line
+
+    def check_export(t):
+        for d, (fk, fm) in enumerate(dbs):
+            keys, vals = t.export(d)
+            o = np.argsort(keys)
+            assert np.array_equal(keys[o], fk) and np.array_equal(vals[o], fm), d
+
+    def check_rows(t, who):
+        for g in who:
+            for seq in genomes[g]:
+                rows, rows100, bins, cs = t.anchor_contig(seq)
+                o_rows, o_rows100, o_bins, _, o_cs = po.anchor_contig(dbs, seq, k, n)
+                assert np.array_equal(rows, o_rows) and np.array_equal(rows100, o_rows100)
+                assert np.array_equal(bins.astype(np.int64), o_bins) and np.array_equal(cs.astype(np.int64), o_cs)
+
+    check_export(tbl)
+    check_rows(tbl, (0, n - 1))
+    for d in range(len(dbs)):  # GetCountersForRead per 32-genome group (single-lane look-ups)
+        got = tbl.counters_for_read(d, genomes[1][0])
+        assert np.array_equal(got, po.counters_for_read(dbs[d], genomes[1][0], k)), d
+    tbl.rehash(4.5)  # 4.5 of 6 slots per line: most groups spill, chains of several lines
+    check_export(tbl)
+    check_rows(tbl, (n // 2,))
+    # a second table from key arrays (k_insert_keys), then a cleared table built again with update-only passes
+    t2 = engine.PanTable(ctx, k, n)
+    for d, (fk, fm) in enumerate(dbs):
+        t2.insert_keys(d, fk, fm)
+    check_export(t2)
+    check_rows(t2, (3,))
+    t2.clear()
+    t2.insert_seqset(0, sets[0])
+    for g in range(1, n):
+        t2.update_seqset(g, sets[g])  # bits for the keys genome 0 holds, no new keys
+    rows = t2.anchor_contig(genomes[0][0])[0]
+    assert np.array_equal(rows, po.anchor_contig(dbs, genomes[0][0], k, n)[0])  # an anchor only asks for its own k-mers
+    t2.close()
+    # KMC1 files of the groups (the writer's own prefix length), imported on the GPU (k_import_kmc)
+    t3 = engine.PanTable(ctx, k, n)
+    for d, (fk, fm) in enumerate(dbs):
+        pfx = str(tmp_path / f"bitvec{d}")
+        po.write_kmc1(pfx, fk, fm, k)
+        t3.load_kmc_files(d, pfx)
+    check_rows(t3, (n - 1,))
+    t3.close()
+    for ss in sets:
+        ss.close()
+    tbl.close()
+
+
 @pytest.mark.parametrize("n", [12, 20, 27, 32, 44, 52, 80, 88, 96, 120])  # (80 / 88 / 120: 10-, 11- and 15-byte rows, whose tail is a dword overlapping the words before it)
 def test_rows_of_whole_words(ctx, n):
     """4- and 12-byte rows (N = 25..32, 89..96) leave the probe kernel as aligned 32-bit stores and go
