@@ -424,6 +424,35 @@ __device__ __forceinline__ void store_row_regs(uint8_t *row, uint32_t nbytes, co
         store_words_tail<2>(w, row, nbytes - 8u);
     }
 }
+// A ragged row (9..11 or 13..15 bytes) as ONE store: the 12 or 16 bytes from the row's start on = the row and the first bytes of the
+// NEXT row, which the next lane holds (one DPP shift of its first word) — overlapping stores of one instruction write equal bytes.
+// A lane whose successor has no row in this batch writes zeros there: the next batch's own store, later in this wave's program
+// order, puts them right — so not for the tile's last batch (the bytes behind its last row are another wave's), and not for the
+// rows the overflow drain resolves (store_row_regs: exact).  Two stores per row at odd addresses cost the probe of 65 genomes
+// 8 % against the one store of 12-byte rows (7.6 against 7.0 ps per position).
+#ifndef PG_ROW_FUSE
+#define PG_ROW_FUSE 1
+#endif
+#ifndef PG_ROW_FUSE3
+#define PG_ROW_FUSE3 1  // three-byte rows as one unaligned dword per row (0: round 3's aligned-dword scheme)
+#endif
+#ifndef PG_ROW_FUSE8
+#define PG_ROW_FUSE8 1  // the same for rows of 5..7 bytes (one 8-byte store)
+#endif
+// nxt: the first row word of the lane above (0 where that lane has no row), taken by the caller with every lane active
+__device__ __forceinline__ void store_row_fused(uint8_t *row, uint32_t nbytes, const uint32_t (&w)[4], uint32_t nxt) {
+    const uint32_t t = nbytes & 3u;  // (wave-uniform, 1..3) bytes of the row's last word
+    const uint32_t keep = (1u << (8u * t)) - 1u;
+    if (nbytes > 12u) {
+        WordsN<4> o;
+        o.w[0] = w[0], o.w[1] = w[1], o.w[2] = w[2], o.w[3] = (w[3] & keep) | (nxt << (8u * t));
+        *reinterpret_cast<WordsN<4> *>(row) = o;
+    } else {
+        WordsN<3> o;
+        o.w[0] = w[0], o.w[1] = w[1], o.w[2] = (w[2] & keep) | (nxt << (8u * t));
+        *reinterpret_cast<WordsN<3> *>(row) = o;
+    }
+}
 // follow a key's probe sequence through inline-layout lines in global memory (all six key words of a line in flight together)
 __device__ __forceinline__ void lane_chase_inl(const SubTable &st, uint64_t key, uint32_t level, uint32_t b, uint32_t step, uint32_t (&w)[4]) {
     w[0] = w[1] = w[2] = w[3] = 0;
@@ -1179,7 +1208,15 @@ __attribute__((amdgpu_num_sgpr(80))) void k_probe(const SubTable st, const uint6
         PG_PH(10)
         // (32-bit offset from the tile's uniform base: one store with a scalar base address)
         if constexpr (WIDE && INL) {
-            if (inrange) store_row_regs(tile_rows + (uint64_t)(uint32_t)pl * nbytes, nbytes, rw4);
+            // (ragged rows: one store per row — not in the tile's last batch, see store_row_fused; positions without a row hold zeros)
+            const bool fuse = PG_ROW_FUSE && (nbytes & 3u) != 0u && b0 + (uint32_t)__popcll(f.rmask) < npos;  // (wave-uniform)
+            if (fuse) {
+                const uint32_t mine = inrange ? rw4[0] : 0u;
+                const uint32_t nxt = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0x130 /* wave_shl:1 */, 0xf, 0xf, true);  // (lane 63: 0)
+                if (inrange) store_row_fused(tile_rows + (uint64_t)(uint32_t)pl * nbytes, nbytes, rw4, nxt);
+            } else if (inrange) {
+                store_row_regs(tile_rows + (uint64_t)(uint32_t)pl * nbytes, nbytes, rw4);
+            }
         } else if constexpr (WIDE) {
 #if PG_ABLATE == 2  // (timing experiment: no mask gather, no row store)
             if (inrange && m0 == 0xDEADBEEFu && m1 == 77u)
@@ -1187,7 +1224,17 @@ __attribute__((amdgpu_num_sgpr(80))) void k_probe(const SubTable st, const uint6
             if (m1) m0 = 0, m1 = 1;
             if (inrange)
 #else
-            if (inrange)
+            // (rows of 13..15 bytes, W = 4: the hit's four mask words into registers and ONE 16-byte store per row, as the inline
+            // layout's ragged rows — store_row_fused; not in the tile's last batch)
+            if (PG_ROW_FUSE && st.W == 4u && (nbytes & 3u) != 0u && b0 + (uint32_t)__popcll(f.rmask) < npos) {  // (wave-uniform)
+                uint32_t v4[4] = {0, 0, 0, 0};
+                if (inrange && m1) {
+                    const WordsN<4> g = *reinterpret_cast<const WordsN<4> *>(reinterpret_cast<const uint32_t *>(st.masks) + ((uint64_t)m0 * SPLIT_KEYS + (m1 - 1u)) * 4u);
+                    v4[0] = g.w[0], v4[1] = g.w[1], v4[2] = g.w[2], v4[3] = g.w[3];
+                }
+                const uint32_t nxt = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v4[0], 0x130 /* wave_shl:1 */, 0xf, 0xf, true);  // (lanes without a row hold 0)
+                if (inrange) store_row_fused(tile_rows + (uint64_t)(uint32_t)pl * nbytes, nbytes, v4, nxt);
+            } else if (inrange)
 #endif
                 store_row_wide(st.masks, st.W, nbytes, tile_rows + (uint64_t)(uint32_t)pl * nbytes, m0, m1);
         } else if constexpr (ROWMODE == 3) {
@@ -1200,7 +1247,14 @@ __attribute__((amdgpu_num_sgpr(80))) void k_probe(const SubTable st, const uint6
                 }
             }
         } else {
-            if constexpr (ROWMODE == 6) {
+            if (PG_ROW_FUSE3 && ROWMODE == 6 && b0 + (uint32_t)__popcll(f.rmask) < npos) {  // (wave-uniform; ROWMODE a constant)
+                // (three-byte rows as ONE unaligned dword per row — the row and the next lane's first byte — as the
+                // 5..7-byte rows; not in the tile's last batch)
+                const uint32_t mine = inrange ? m0 : 0u;
+                const uint32_t nxt = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0x130 /* wave_shl:1 */, 0xf, 0xf, true);
+                struct __attribute__((packed)) U32 { uint32_t v; };
+                if (inrange) reinterpret_cast<U32 *>(tile_rows + (uint32_t)pl * 3u)->v = (m0 & 0xFFFFFFu) | (nxt << 24);
+            } else if constexpr (ROWMODE == 6) {
                 // Three-byte rows as ALIGNED dwords: a u16 and a u8 per lane at odd addresses cost the launch a third
                 // of its time (20 x 40 Mb: 6.7 ps per position against 5.1 with the four-byte rows of 27 genomes).
                 // The batch's rows are 3 x 58 consecutive bytes; the aligned dword that starts inside a lane's row
@@ -1224,7 +1278,19 @@ __attribute__((amdgpu_num_sgpr(80))) void k_probe(const SubTable st, const uint6
 #if PG_ABLATE == 2  // (timing experiment: no row store unless a value no mask has turns up)
             if (inrange && m0 == 0xDEADBEEFu)
 #else
-            if (inrange)
+            // (rows of 5..7 bytes, 33..56 genomes: ONE 8-byte store per row — the row and the first bytes of the next lane's, as
+            // store_row_fused does for the wider ragged rows; not in the tile's last batch)
+            if (PG_ROW_FUSE8 && ROWMODE == 0 && TWO && rc.words == 3u && nbytes >= 5u && b0 + (uint32_t)__popcll(f.rmask) < npos) {  // (wave-uniform)
+                const uint32_t mine = inrange ? m0 : 0u;
+                const uint32_t nxt = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0x130 /* wave_shl:1 */, 0xf, 0xf, true);
+                if (inrange) {
+                    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+                    struct __attribute__((packed, aligned(1))) U64 { u32x2 v; };
+                    const uint32_t t8 = 8u * (nbytes - 4u);  // bits of the row in its second word (8, 16 or 24)
+                    u32x2 q = {m0, (m1 & ((1u << t8) - 1u)) | (nxt << t8)};
+                    reinterpret_cast<U64 *>(tile_rows + (uint32_t)pl * nbytes)->v = q;
+                }
+            } else if (inrange)
 #endif
                 store_row<ROWMODE>(tile_rows + (ROWMODE == 1 ? (uint32_t)pl : ROWMODE == 4 ? (uint32_t)pl * 4u : ROWMODE == 5 ? (uint32_t)pl * 2u : ROWMODE == 6 ? (uint32_t)pl * 3u : (uint32_t)pl * nbytes), m0, m1, rc);
         }

@@ -461,12 +461,12 @@ struct TableGeom {
 static TableGeom geom_for(int ngenomes) {
     const uint32_t ndbs = (uint32_t)(ngenomes + 31) / 32;
     if (ndbs <= 2) return {ndbs, 8u, LAYOUT_SLOTS};
-    static const bool want_inline = [] {
+    static const int want_inline = [] {  // 0: never, 1: W = 3 (the default), 2: W = 4 too (experiments: PG_WIDE_LAYOUT=inline4)
         const char *e = getenv("PG_WIDE_LAYOUT");
-        return !(e && strcmp(e, "split") == 0);
+        return (e && strcmp(e, "split") == 0) ? 0 : (e && strcmp(e, "inline4") == 0) ? 2 : 1;
     }();
     // (W = 3 only: at W = 4 a line holds 5 keys and the split layout's 16 win — 128 x 10 Mb 10.0 ms against 10.75 at the inline layout's best m)
-    if (ndbs == 3 && want_inline && PG_INLINE_LAYOUT) return {ndbs, inline_slots(ndbs), LAYOUT_INLINE};
+    if ((ndbs == 3 || (ndbs == 4 && want_inline == 2)) && want_inline && PG_INLINE_LAYOUT) return {ndbs, inline_slots(ndbs), LAYOUT_INLINE};
     return {ndbs, SPLIT_KEYS, LAYOUT_SPLIT};
 }
 
