@@ -483,7 +483,7 @@ def wide_legs(ctx, dev, args, k=21):
         pg.ascii = None
         torch.cuda.empty_cache()
         results, merged = make_results(ctx, pg, True, False, 0)
-        steps, warmup = 5, 2
+        steps, warmup = 12, 6
         for _ in range(warmup):
             results[0].run()
         torch.cuda.synchronize()
