@@ -310,6 +310,9 @@ template <int NW>
 struct __attribute__((packed, aligned(4))) WordsN {
     uint32_t w[NW];
 };
+#ifndef PG_ROW12_NT
+#define PG_ROW12_NT 1  // 12-byte rows (89..96 genomes, inline layout) as one non-temporal store: 96 genomes 6.75 -> 6.12 ms (profiles/r5m_ab_row_fuse.txt)
+#endif
 #ifndef PG_NT_ROWS
 #define PG_NT_ROWS 1  // non-temporal stores for rows that ONE store instruction covers (8 and 16 bytes): see store_row
 #endif
@@ -401,6 +404,12 @@ __device__ __forceinline__ void masks_inl(const uint4 *line, uint32_t S, uint32_
 // a row of 9..16 bytes out of registers (zeros for an absent key): the widest pieces the width allows, as store_row_wide
 template <int NS>
 __device__ __forceinline__ void store_words_tail(const uint32_t (&v)[4], uint8_t *dst, uint32_t tail) {
+    if (PG_ROW12_NT && NS == 3 && tail == 0) {  // (wave-uniform) a 12-byte row is one store: non-temporal
+        typedef uint32_t u32x3 __attribute__((ext_vector_type(3), aligned(4)));
+        u32x3 q = {v[0], v[1], v[2]};
+        __builtin_nontemporal_store(q, reinterpret_cast<u32x3 *>(dst));
+        return;
+    }
     WordsN<NS> o;
 #pragma unroll
     for (int i = 0; i < NS; ++i) o.w[i] = v[i];
@@ -436,6 +445,9 @@ __device__ __forceinline__ void store_row_regs(uint8_t *row, uint32_t nbytes, co
 #ifndef PG_ROW_FUSE3
 #define PG_ROW_FUSE3 1  // three-byte rows as one unaligned dword per row (0: round 3's aligned-dword scheme)
 #endif
+#ifndef PG_ROW_FUSE_NT
+#define PG_ROW_FUSE_NT 1  // the one-store rows of 9..11 and 13..15 bytes written non-temporally (65 genomes 4.3-4.5 -> 3.98 ms, 72 x 30 Mb 14.7 -> 13.8; profiles/r5m_ab_row_fuse.txt)
+#endif
 #ifndef PG_ROW_FUSE8
 #define PG_ROW_FUSE8 1  // the same for rows of 5..7 bytes (one 8-byte store)
 #endif
@@ -443,14 +455,16 @@ __device__ __forceinline__ void store_row_regs(uint8_t *row, uint32_t nbytes, co
 __device__ __forceinline__ void store_row_fused(uint8_t *row, uint32_t nbytes, const uint32_t (&w)[4], uint32_t nxt) {
     const uint32_t t = nbytes & 3u;  // (wave-uniform, 1..3) bytes of the row's last word
     const uint32_t keep = (1u << (8u * t)) - 1u;
+    typedef uint32_t u32x4u __attribute__((ext_vector_type(4), aligned(1)));
+    typedef uint32_t u32x3u __attribute__((ext_vector_type(3), aligned(1)));
     if (nbytes > 12u) {
-        WordsN<4> o;
-        o.w[0] = w[0], o.w[1] = w[1], o.w[2] = w[2], o.w[3] = (w[3] & keep) | (nxt << (8u * t));
-        *reinterpret_cast<WordsN<4> *>(row) = o;
+        u32x4u q = {w[0], w[1], w[2], (w[3] & keep) | (nxt << (8u * t))};
+        if (PG_ROW_FUSE_NT) __builtin_nontemporal_store(q, reinterpret_cast<u32x4u *>(row));
+        else *reinterpret_cast<u32x4u *>(row) = q;
     } else {
-        WordsN<3> o;
-        o.w[0] = w[0], o.w[1] = w[1], o.w[2] = (w[2] & keep) | (nxt << (8u * t));
-        *reinterpret_cast<WordsN<3> *>(row) = o;
+        u32x3u q = {w[0], w[1], (w[2] & keep) | (nxt << (8u * t))};
+        if (PG_ROW_FUSE_NT) __builtin_nontemporal_store(q, reinterpret_cast<u32x3u *>(row));
+        else *reinterpret_cast<u32x3u *>(row) = q;
     }
 }
 // follow a key's probe sequence through inline-layout lines in global memory (all six key words of a line in flight together)
@@ -1284,11 +1298,10 @@ __attribute__((amdgpu_num_sgpr(80))) void k_probe(const SubTable st, const uint6
                 const uint32_t mine = inrange ? m0 : 0u;
                 const uint32_t nxt = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0x130 /* wave_shl:1 */, 0xf, 0xf, true);
                 if (inrange) {
-                    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-                    struct __attribute__((packed, aligned(1))) U64 { u32x2 v; };
+                    typedef uint32_t u32x2u __attribute__((ext_vector_type(2), aligned(1)));
                     const uint32_t t8 = 8u * (nbytes - 4u);  // bits of the row in its second word (8, 16 or 24)
-                    u32x2 q = {m0, (m1 & ((1u << t8) - 1u)) | (nxt << t8)};
-                    reinterpret_cast<U64 *>(tile_rows + (uint32_t)pl * nbytes)->v = q;
+                    u32x2u q = {m0, (m1 & ((1u << t8) - 1u)) | (nxt << t8)};
+                    *reinterpret_cast<u32x2u *>(tile_rows + (uint32_t)pl * nbytes) = q;  // (non-temporal: 56 genomes +3 %, 40 genomes mixed — plain)
                 }
             } else if (inrange)
 #endif
