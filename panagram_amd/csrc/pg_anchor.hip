@@ -313,6 +313,9 @@ struct __attribute__((packed, aligned(4))) WordsN {
 #ifndef PG_ROW12_NT
 #define PG_ROW12_NT 1  // 12-byte rows (89..96 genomes, inline layout) as one non-temporal store: 96 genomes 6.75 -> 6.12 ms (profiles/r5m_ab_row_fuse.txt)
 #endif
+#ifndef PG_ROW4_NT
+#define PG_ROW4_NT 0  // two- and four-byte rows non-temporal: 27 x 40 Mb 4.96 -> 5.59 ms, 16 x 50 Mb 3.35 -> 3.86 (profiles/r5m_ab_row_fuse.txt): not
+#endif
 #ifndef PG_NT_ROWS
 #define PG_NT_ROWS 1  // non-temporal stores for rows that ONE store instruction covers (8 and 16 bytes): see store_row
 #endif
@@ -510,9 +513,11 @@ __device__ __forceinline__ void store_row(uint8_t *row, uint32_t m0, uint32_t m1
     if (ROWMODE == 1) {
         row[0] = (uint8_t)m0;
     } else if (ROWMODE == 4) {  // four-byte rows (25..32 genomes): one aligned dword
-        *reinterpret_cast<uint32_t *>(row) = m0;
+        if (PG_ROW4_NT) __builtin_nontemporal_store(m0, reinterpret_cast<uint32_t *>(row));
+        else *reinterpret_cast<uint32_t *>(row) = m0;
     } else if (ROWMODE == 5) {  // two-byte rows (9..16 genomes)
-        *reinterpret_cast<uint16_t *>(row) = (uint16_t)m0;
+        if (PG_ROW4_NT) __builtin_nontemporal_store((uint16_t)m0, reinterpret_cast<uint16_t *>(row));
+        else *reinterpret_cast<uint16_t *>(row) = (uint16_t)m0;
     } else if (ROWMODE == 6) {  // three-byte rows (17..24 genomes): two stores at byte alignment
         struct __attribute__((packed)) U16 { uint16_t v; };
         reinterpret_cast<U16 *>(row)->v = (uint16_t)m0;
