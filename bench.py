@@ -466,13 +466,13 @@ def north_star_leg(ctx, dev, args):
 
 
 def wide_legs(ctx, dev, args, k=21):
-    """More than 64 genomes (rows of 9, 12 and 16 bytes): 65 / 96 / 128 synthetic 10 Mb genomes (2 contigs each), d = 0.01, all
+    """More than 64 genomes (rows of 9, 12 and 16 bytes): 65 / 96 / 128 synthetic 10 Mb genomes (5 contigs each), d = 0.01, all
     anchored per step in one co-scheduled launch + one statistics pass — the inline table layout (65..96 genomes) and the split
     layout (more) with k_epilogue_w; the first 200 000 rows of two anchors against the CPU oracle (k-mer DB of the samples by brute
     force with torch).  Outside the timed region of ``value``.  The reference's multi-DB loop: cpp/anchor.cpp:138-165."""
     out = []
     for G in (65, 96, 128):
-        L, C = 10_000_000, 2
+        L, C = 10_000_000, 5  # (the shape of tools/lines.sh's --genomes G --genome-mb 10: what profiles/r5* were measured on)
         contig_lens = [L // C] * C
         pg = Pangenome(ctx, dev, G, contig_lens, 0.01, args.seed + 2, k, keep_ascii=True)
         sample_n = 200_000
