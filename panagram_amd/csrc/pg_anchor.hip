@@ -3422,72 +3422,104 @@ __global__ __launch_bounds__(256) void k_window_stats(uint32_t N, const uint8_t 
 // Layout: tile t (PROBE_TILE positions) owns TILE_SLOTS = PROBE_TILE / 64 slots of `width` u64 words: word
 // (TILE_SLOTS t + s) * width + j = genome g0 + j at positions 64 s .. 64 s + 63 of the tile.
 // ---------------------------------------------------------------------------
-// One-byte rows (a block of up to 8 genomes — config 5: ONE genome per GPU): a lane takes 8 consecutive positions
-// (one 8-byte load, the wave a whole tile) and gathers bit g of its 8 row bytes into one byte with a multiply;
-// byte (lane % 8) of word (slot = lane / 8, genome j).  10 instructions per genome and 8 positions instead of a
-// ballot per genome and position.
+// One-byte rows (a block of up to 8 genomes — config 5: ONE genome per GPU): a lane takes 16 consecutive positions (one
+// aligned 16-byte load, the wave a whole tile) and gathers bit g of 8 row bytes into one byte with a multiply — two bytes per
+// genome and lane: bytes 2 (lane % 4), 2 (lane % 4) + 1 of word (slot = lane / 4, genome j), one 16-bit store.  A wave takes
+// COLS_TPW tiles, all of their loads in flight together.  (Rounds 2-4: a wave per 512 positions, 8 per lane — 4.7 x 10^7 waves
+// of one load and one byte store each for config 5's 2.4 x 10^10 positions: 15 ms per pass at 1.6 TB/s, the launch's waves,
+// not its bytes.)
+constexpr uint32_t COLS_TPW = 4;  // tiles per wave of the one-byte-row column kernels
+static_assert(PROBE_TILE == 1024, "k_cols_extract_b1 / k_cols_merge_b1: a wave's 64 lanes x 16 positions are one tile");
 __global__ __launch_bounds__(256) void k_cols_extract_b1(uint32_t N, const AnchorDesc *__restrict__ ad,
                                                          const uint32_t *__restrict__ tile_contig, uint32_t tile_base,
                                                          uint32_t ntiles, const uint8_t *__restrict__ out1, uint32_t g0,
                                                          uint32_t width, uint8_t *__restrict__ dst) {
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t unit = blockIdx.x * 4 + (threadIdx.x >> 6);  // 512 positions of a tile: 8 of its slots
-    const uint32_t trel = unit / (TILE_SLOTS / 8), u8 = (unit % (TILE_SLOTS / 8)) * 8;
-    if (trel >= ntiles) return;  // wave-uniform
-    const uint32_t tile = tile_base + trel;
-    const AnchorDesc a = ad[tile_contig[tile]];
-    const uint32_t p0 = (tile - a.tile0) * PROBE_TILE + 64 * u8 + 8 * lane;
-    uint32_t lo = 0, hi = 0;
-    if (p0 < a.nkmers) {  // (rows are padded to 16 bytes per contig: the 8-byte load stays inside)
-        const uint2 v = *reinterpret_cast<const uint2 *>(out1 + a.out_off + p0);
-        const uint32_t valid = min(8u, a.nkmers - p0);
-        lo = valid >= 4 ? v.x : (v.x & ((1u << (8 * valid)) - 1u));
-        hi = valid >= 8 ? v.y : (valid > 4 ? (v.y & ((1u << (8 * (valid - 4))) - 1u)) : 0u);
-    }
-    uint8_t *o = dst + ((uint64_t)trel * TILE_SLOTS + u8 + (lane >> 3)) * width * 8 + (lane & 7);
-    for (uint32_t j = 0; j < width; ++j) {
-        const uint32_t g = g0 + j;
-        uint32_t b = 0;
-        if (g < N) {  // bit g of rows 0..3 / 4..7 -> bits 0..3 / 4..7 (0x01020408: the four bits meet in bits 24..27)
-            const uint32_t a0 = ((lo >> g) & 0x01010101u) * 0x01020408u, a1 = ((hi >> g) & 0x01010101u) * 0x01020408u;
-            b = ((a0 >> 24) & 0xFu) | ((a1 >> 20) & 0xF0u);
+    const uint32_t t0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * COLS_TPW;
+    if (t0 >= ntiles) return;  // wave-uniform
+    uint4 v[COLS_TPW];
+    uint32_t valid[COLS_TPW];
+#pragma unroll
+    for (uint32_t k = 0; k < COLS_TPW; ++k) {
+        v[k] = make_uint4(0, 0, 0, 0);
+        valid[k] = 0;
+        if (t0 + k < ntiles) {  // (wave-uniform)
+            const uint32_t tile = tile_base + t0 + k;
+            const AnchorDesc a = ad[tile_contig[tile]];
+            const uint32_t p0 = (tile - a.tile0) * PROBE_TILE + 16 * lane;
+            if (p0 < a.nkmers) {  // (rows are padded to 16 bytes per contig: the aligned 16-byte load stays inside)
+                v[k] = *reinterpret_cast<const uint4 *>(out1 + a.out_off + p0);
+                valid[k] = min(16u, a.nkmers - p0);
+            }
         }
-        o[8 * j] = (uint8_t)b;
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < COLS_TPW; ++k) {
+        if (t0 + k >= ntiles) break;  // (wave-uniform)
+        uint32_t w[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+#pragma unroll
+        for (uint32_t i = 0; i < 4; ++i) {  // bytes of positions past the contig's end hold whatever follows: cleared
+            const uint32_t nv = valid[k] > 4 * i ? min(4u, valid[k] - 4 * i) : 0u;
+            w[i] &= nv >= 4 ? 0xFFFFFFFFu : (1u << (8 * nv)) - 1u;
+        }
+        uint8_t *o = dst + ((uint64_t)(t0 + k) * TILE_SLOTS + (lane >> 2)) * width * 8 + 2 * (lane & 3);
+        for (uint32_t j = 0; j < width; ++j) {
+            const uint32_t g = g0 + j;
+            uint32_t b = 0;
+            if (g < N) {  // bit g of rows 0..3 / 4..7 -> bits 0..3 / 4..7 (0x01020408: the four bits meet in bits 24..27)
+                const uint32_t a0 = ((w[0] >> g) & 0x01010101u) * 0x01020408u, a1 = ((w[1] >> g) & 0x01010101u) * 0x01020408u;
+                const uint32_t a2 = ((w[2] >> g) & 0x01010101u) * 0x01020408u, a3 = ((w[3] >> g) & 0x01010101u) * 0x01020408u;
+                b = ((a0 >> 24) & 0xFu) | ((a1 >> 20) & 0xF0u) | ((a2 >> 16) & 0xF00u) | ((a3 >> 12) & 0xF000u);
+            }
+            *reinterpret_cast<uint16_t *>(o + 8 * j) = (uint16_t)b;
+        }
     }
 }
 
-// the reverse for one-byte rows (N <= 8): a lane rebuilds the rows of 8 consecutive positions — byte (lane % 8) of
-// each genome's word spread over 8 row bytes — and stores (or ORs) them as one 8-byte word
+// the reverse for one-byte rows (N <= 8): a lane rebuilds the rows of 16 consecutive positions — its two bytes of each genome's
+// word spread over 16 row bytes — and stores (or ORs) them as one aligned 16-byte word; COLS_TPW tiles per wave, their loads
+// (the genomes' bytes and, when accumulating, the rows as they are) in flight together
 __global__ __launch_bounds__(256) void k_cols_merge_b1(uint32_t N, const AnchorDesc *__restrict__ ad,
                                                        const uint32_t *__restrict__ tile_contig, uint32_t tile_base,
                                                        uint32_t ntiles, uint8_t *__restrict__ out1,
                                                        const uint8_t *__restrict__ src, uint32_t part0, uint32_t nparts,
                                                        uint64_t part_bytes, uint32_t per, uint32_t accumulate) {
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t unit = blockIdx.x * 4 + (threadIdx.x >> 6);  // 512 positions of a tile: 8 of its slots
-    const uint32_t trel = unit / (TILE_SLOTS / 8), u8 = (unit % (TILE_SLOTS / 8)) * 8;
-    if (trel >= ntiles) return;
-    const uint32_t tile = tile_base + trel;
-    const AnchorDesc a = ad[tile_contig[tile]];
-    const uint32_t p0 = (tile - a.tile0) * PROBE_TILE + 64 * u8 + 8 * lane;
-    if (p0 >= a.nkmers) return;
+    const uint32_t t0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * COLS_TPW;
+    if (t0 >= ntiles) return;  // wave-uniform
     const uint32_t gfirst = part0 * per, gend = min(N, (part0 + nparts) * per);
-    const uint8_t *in = src + ((uint64_t)trel * TILE_SLOTS + u8 + (lane >> 3)) * per * 8 + (lane & 7);
-    uint32_t lo = 0, hi = 0;
-    for (uint32_t g = gfirst; g < gend; ++g) {
-        const uint32_t part = g / per - part0, j = g % per;
-        const uint32_t b = in[(uint64_t)part * part_bytes + 8 * j];
-        const uint32_t rep = b * 0x01010101u;  // bit i of b -> bit 0 of byte i
-        lo |= ((((rep & 0x08040201u) + 0x7F7F7F7Fu) >> 7) & 0x01010101u) << g;
-        hi |= ((((rep & 0x80402010u) + 0x7F7F7F7Fu) >> 7) & 0x01010101u) << g;
+    uint4 old[COLS_TPW];
+    uint4 *rowp[COLS_TPW];
+#pragma unroll
+    for (uint32_t k = 0; k < COLS_TPW; ++k) {
+        old[k] = make_uint4(0, 0, 0, 0);
+        rowp[k] = nullptr;
+        if (t0 + k < ntiles) {  // (wave-uniform)
+            const uint32_t tile = tile_base + t0 + k;
+            const AnchorDesc a = ad[tile_contig[tile]];
+            const uint32_t p0 = (tile - a.tile0) * PROBE_TILE + 16 * lane;
+            if (p0 < a.nkmers) {
+                rowp[k] = reinterpret_cast<uint4 *>(out1 + a.out_off + p0);
+                if (accumulate) old[k] = *rowp[k];
+            }
+        }
     }
-    uint2 *row = reinterpret_cast<uint2 *>(out1 + a.out_off + p0);
-    if (accumulate) {
-        const uint2 old = *row;
-        lo |= old.x;
-        hi |= old.y;
+#pragma unroll
+    for (uint32_t k = 0; k < COLS_TPW; ++k) {
+        if (t0 + k >= ntiles) break;  // (wave-uniform)
+        const uint8_t *in = src + ((uint64_t)(t0 + k) * TILE_SLOTS + (lane >> 2)) * per * 8 + 2 * (lane & 3);
+        uint32_t w[4] = {old[k].x, old[k].y, old[k].z, old[k].w};
+        for (uint32_t g = gfirst; g < gend; ++g) {
+            const uint32_t part = g / per - part0, j = g % per;
+            const uint32_t b2 = *reinterpret_cast<const uint16_t *>(in + (uint64_t)part * part_bytes + 8 * j);
+            const uint32_t r0 = (b2 & 0xFFu) * 0x01010101u, r1 = (b2 >> 8) * 0x01010101u;  // bit i of a byte -> bit 0 of byte i
+            w[0] |= ((((r0 & 0x08040201u) + 0x7F7F7F7Fu) >> 7) & 0x01010101u) << g;
+            w[1] |= ((((r0 & 0x80402010u) + 0x7F7F7F7Fu) >> 7) & 0x01010101u) << g;
+            w[2] |= ((((r1 & 0x08040201u) + 0x7F7F7F7Fu) >> 7) & 0x01010101u) << g;
+            w[3] |= ((((r1 & 0x80402010u) + 0x7F7F7F7Fu) >> 7) & 0x01010101u) << g;
+        }
+        if (rowp[k]) *rowp[k] = make_uint4(w[0], w[1], w[2], w[3]);  // (bits of positions past nkmers are zero in the blocks: the padding stays zero)
     }
-    *row = make_uint2(lo, hi);  // (bits of positions past nkmers are zero in the blocks: the padding stays zero)
 }
 
 // Wider rows.  A lane owns one position; the wave one slot of 64.  The row bytes are read a 32-bit word at a time (one
@@ -3834,7 +3866,7 @@ hipError_t launch_cols_extract(hipStream_t st, uint32_t ngenomes, const AnchorDe
                                uint32_t tile_base, uint32_t ntiles, const uint8_t *out1, uint32_t g0, uint32_t width, void *dst) {
     if (ntiles == 0 || width == 0) return hipSuccess;
     if (ngenomes <= 8 && g0 < 8)  // one-byte rows
-        hipLaunchKernelGGL(k_cols_extract_b1, dim3((unsigned)(((uint64_t)ntiles * (TILE_SLOTS / 8) + 3) / 4)), dim3(256), 0, st, ngenomes, ad, tile_contig, tile_base,
+        hipLaunchKernelGGL(k_cols_extract_b1, dim3((unsigned)(((uint64_t)ntiles + 4 * COLS_TPW - 1) / (4 * COLS_TPW))), dim3(256), 0, st, ngenomes, ad, tile_contig, tile_base,
                            ntiles, out1, g0, width, static_cast<uint8_t *>(dst));
     else
         hipLaunchKernelGGL(k_cols_extract, dim3((unsigned)(((uint64_t)ntiles * TILE_SLOTS + 3) / 4)), dim3(256), 0, st, ngenomes, ad,
@@ -3847,7 +3879,7 @@ hipError_t launch_cols_merge(hipStream_t st, uint32_t ngenomes, const AnchorDesc
                              uint32_t nparts, uint64_t part_words, uint32_t per, uint32_t accumulate) {
     if (ntiles == 0 || per == 0 || nparts == 0) return hipSuccess;
     if (ngenomes <= 8)  // one-byte rows
-        hipLaunchKernelGGL(k_cols_merge_b1, dim3((unsigned)(((uint64_t)ntiles * (TILE_SLOTS / 8) + 3) / 4)), dim3(256), 0, st, ngenomes, ad, tile_contig, tile_base,
+        hipLaunchKernelGGL(k_cols_merge_b1, dim3((unsigned)(((uint64_t)ntiles + 4 * COLS_TPW - 1) / (4 * COLS_TPW))), dim3(256), 0, st, ngenomes, ad, tile_contig, tile_base,
                            ntiles, out1, static_cast<const uint8_t *>(src), part0, nparts, part_words * 8, per, accumulate);
     else
         hipLaunchKernelGGL(k_cols_merge, dim3((unsigned)(((uint64_t)ntiles * TILE_SLOTS + 3) / 4)), dim3(256), 0, st, ngenomes, ad,
