@@ -320,7 +320,7 @@ def make_results(ctx, pg, colsums, per_genome, piece_tiles):
     return [r], merged
 
 
-KERNEL_SOURCES = ("pg_anchor.hip", "pg_device.h", "pg_kernels.h")  # what k_probe / k_epilogue are compiled from
+KERNEL_SOURCES = ("pg_anchor.hip", "pg_device.h", "pg_kernels.h", "pg_kernels.hip", "pg_api.hip")  # what k_probe / k_epilogue are compiled from, and what picks the table layout and window they run with (geom_for, k_table_init)
 
 
 def kernel_sources_sha():
@@ -354,7 +354,7 @@ def load_counters(pos_per_launch, k, G):
     return None
 
 
-def roofline_block(pos_per_launch, avg_launch_s, avg_epi_s, G, value_per_gpu, counters, nruns):
+def roofline_block(pos_per_launch, avg_launch_s, avg_epi_s, G, value_per_gpu, counters, nruns, bound="issue"):
     """The dominant kernel (k_probe) against the HBM roofline (8 TB/s, MI355X_MICROARCH.md).
 
     ``achieved`` = ALGORITHMIC bytes per launch / the launch's mean duration, the algorithmic bytes being the design's
@@ -374,7 +374,10 @@ def roofline_block(pos_per_launch, avg_launch_s, avg_epi_s, G, value_per_gpu, co
     algorithmic = pos_per_launch * B_min
     B_contract = 0.25 + 64.0 * ((G + 63) // 64) + 1.01 * nbytes
     out = {
-        "bound": "hbm", "kernel": "k_probe",
+        # what binds this launch: co-scheduled genomes take most table lines from L2 and the kernel runs into VALU instruction
+        # issue ("issue"); one launch per genome / diverged genomes run into HBM's random-line rate ("hbm").  achieved / peak /
+        # frac are priced against the HBM roofline either way (priced_against), as the contract asks.
+        "bound": bound, "priced_against": "hbm", "kernel": "k_probe",
         "achieved": algorithmic / avg_launch_s / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
         "frac": algorithmic / avg_launch_s / HBM_PEAK,
         "traffic": None,
@@ -463,6 +466,105 @@ def north_star_leg(ctx, dev, args):
     pg.close()
     ctx.trim()
     return out
+
+
+def baseline_config_leg(ctx, dev, args, label, G, contig_lens, k, d, seed, picks, sample_n, steps=3, warmup=1):
+    """One of BASELINE.json's wider configs at FULL size on one GPU, as the headline is measured: every genome anchored per
+    step in one co-scheduled result + its statistics, inputs and outputs in HBM.  Carries its own roofline block (B_min of
+    SURVEY 8d for its row width, the k_probe time from HIP events on the kernels' stream) and an oracle check: the first
+    ``sample_n`` rows of the first contig and the last ``sample_n / 2`` rows of the last contig of the ``picks`` genomes
+    against the CPU oracle (cpp/anchor.cpp:112-195 restated in oracle/anchor_oracle.c), its k-mer DB built by brute force
+    with torch.  Outside the timed region of ``value``."""
+    pg = Pangenome(ctx, dev, G, contig_lens, d, seed, k, keep_ascii=True)
+    C = len(contig_lens)
+    tail_n = sample_n // 2
+    where = [(g, 0, 0) for g in picks] + [(g, C - 1, contig_lens[C - 1] - tail_n) for g in picks]
+    samples = [pg.ascii[g][ci][s0:s0 + (sample_n if ci == 0 else tail_n)] for g, ci, s0 in where]
+    t0 = time.perf_counter()
+    dbs = sample_db_by_brute_force(pg.ascii, samples, k, G)
+    db_s = time.perf_counter() - t0
+    samples_host = [x.cpu().numpy() for x in samples]
+    pg.ascii = None
+    del samples
+    torch.cuda.empty_cache()
+    results, merged = make_results(ctx, pg, True, False, 0)
+    for _ in range(warmup):
+        results[0].run()
+    torch.cuda.synchronize()
+    results[0].timing_reset()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        results[0].run()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    p_ms, e_ms, nruns = results[0].timing_mean()
+    pos = sum(pg.pos_per_genome)
+    ccs = results[0].contig_colsums().astype(np.int64)
+    own_ok = all(int(ccs[g * C:(g + 1) * C, g].sum()) == pg.pos_per_genome[g] for g in range(G))
+
+    def gpu_rows(t, n):
+        g, ci, s0 = where[t]
+        rows = results[0].download(g * C + ci, want_bitmap100=False)[0]
+        return rows[s0:s0 + n]
+    v, cdt, npos, ok = cpu_baseline(dbs, samples_host, k, G, gpu_rows)
+    st = pg.stats
+    rf = roofline_block(pos, p_ms / 1e3, e_ms / 1e3, G, pos * steps / dt, None, nruns, bound="issue + hbm (see DESIGN.md section 4)")
+    out = {"config": label,
+           "workload": f"{G} synthetic {sum(contig_lens) / 1e6:g} Mb genomes ({C} contigs each), k={k}, d={d}, all {G} anchored per step, one GPU",
+           "value": pos * steps / dt, "unit": "k-mers/s", "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * dt / steps,
+           "positions_per_step": pos, "nbytes": (G + 7) // 8, "k_probe_ms": p_ms, "statistics_ms": e_ms, "launches_averaged": nruns,
+           "table_keys": st["nkeys"], "table_bytes": st["bytes"], "minimizer_length": pg.table.minimizer, "table_build_s": pg.build_s,
+           "row_bytes_per_step": pos * ((G + 7) // 8),
+           "roofline": {kk: rf[kk] for kk in ("bound", "priced_against", "kernel", "achieved", "peak", "unit", "frac", "avg_launch_ms",
+                                              "algorithmic_bytes_per_position", "algorithmic_bytes_per_launch")},
+           "anchors_hold_all_own_kmers": bool(own_ok), "rows_equal_gpu": ok,
+           "rows_check": f"genomes {list(picks)}: first {sample_n} rows of the first contig and last {tail_n} rows of the last contig == CPU "
+                         f"oracle rows (k-mer DB of the samples by brute force with torch in {db_s:.1f} s)"}
+    if nruns and e_ms > 0.5 * p_ms and (G + 7) // 8 >= 8:
+        out["launch_note"] = ("a run of this size goes out in chunks, the statistics of a chunk beside the next chunk's probe: k_probe_ms / "
+                              "statistics_ms are the two streams' spans, not a sum")
+    for r in results:
+        r.close()
+    if merged is not None:
+        merged.close()
+    pg.close()
+    ctx.trim()
+    torch.cuda.empty_cache()
+    return out
+
+
+def baseline_config_legs(ctx, dev, args):
+    """BASELINE.json configs[2] (27 Arabidopsis-scale ~135 Mb genomes, k=21) and configs[3] (64 synthetic 200 Mb genomes,
+    k=31) at full size on this GPU, each with its roofline block and oracle-checked head / tail rows; and configs[3] files ->
+    files through Index.run() (SURVEY 8d(ii) for the widest config: 102 GB of rows through k_row_deflate and to disk)."""
+    import shutil
+    import tempfile
+    legs = []
+    for label, G, lens, k, d, seed, picks, sn in (
+            ("BASELINE.json configs[2] at full size", 27, [27_000_000] * 5, 21, 0.01, args.seed + 3, (0, 19), 1_000_000),
+            ("BASELINE.json configs[3] at full size, all 64 genomes anchored", 64, [20_000_000] * 10, 31, 0.005, args.seed + 4, (0, 41), 500_000)):
+        try:
+            legs.append(baseline_config_leg(ctx, dev, args, label, G, lens, k, d, seed, picks, sn))
+        except Exception as e:  # noqa: BLE001 — a failed extra leg must not take the measured line with it
+            legs.append({"config": label, "error": f"{type(e).__name__}: {e}"})
+    e2e = None
+    if not args.no_e2e:
+        try:
+            free = shutil.disk_usage(tempfile.gettempdir()).free
+            if free < 80e9:
+                e2e = {"skipped": f"{free / 1e9:.0f} GB free under {tempfile.gettempdir()}: 13 GB of FASTA + the index need more"}
+            else:
+                a4 = argparse.Namespace(**vars(args))
+                a4.d, a4.seed = 0.005, args.seed + 4
+                e2e = e2e_leg(dev, a4, 64, [20_000_000] * 10, 31)
+                e2e["config"] = "BASELINE.json configs[3]: 64 x 200 Mb, k=31, files -> files"
+                e2e["payload_gb_per_s"] = e2e["bitmap_payload_bytes"] / e2e["anchor_and_write_s"] / 1e9
+                e2e["index_write_gb_per_s"] = e2e["index_bytes_out"] / e2e["anchor_and_write_s"] / 1e9
+        except Exception as e:  # noqa: BLE001
+            e2e = {"error": f"{type(e).__name__}: {e}"}
+        ctx.trim()
+        torch.cuda.empty_cache()
+    return legs, e2e
 
 
 def wide_legs(ctx, dev, args, k=21):
@@ -675,8 +777,10 @@ def e2e_leg(dev, args, G, contig_lens, k):
             f.write("\n".join(rows) + "\n")
         write_s = time.perf_counter() - t0
         t0 = time.perf_counter()
-        idx = pidx.Index(os.path.join(root, "samples.tsv"), prefix=os.path.join(root, "idx"), k=k)
-        idx.run()
+        import contextlib
+        with contextlib.redirect_stdout(sys.stderr):  # (the CLI's progress lines: stdout carries the ONE JSON line)
+            idx = pidx.Index(os.path.join(root, "samples.tsv"), prefix=os.path.join(root, "idx"), k=k)
+            idx.run()
         t2 = time.perf_counter()
         t1 = t0 + idx.timings.get("load_inputs_s", 0.0) + idx.timings.get("table_build_s", 0.0)
         npos = G * sum(L - k + 1 for L in contig_lens)
@@ -1014,6 +1118,7 @@ def main():
     ap.add_argument("--no-sharded-leg", action="store_true", help="skip the genome-sharded pipeline leg")
     ap.add_argument("--no-e2e", action="store_true", help="skip the files-to-files leg (Index.run() on FASTA files of this shape)")
     ap.add_argument("--no-robustness", action="store_true", help="skip the robustness legs (inversions + shuffled contig order; repeat family)")
+    ap.add_argument("--no-baseline-configs", action="store_true", help="skip the BASELINE configs[2] / configs[3] legs at full size (and configs[3] files -> files)")
     ap.add_argument("--no-config5", action="store_true", help="skip the BASELINE configs[4] leg (8 x 3 Gb, d=0.05, 8 genome blocks as passes on this GPU)")
     ap.add_argument("--settle-s", type=float, default=0.4, help="seconds of untimed steps before the warm-up steps (the shader clock settles; 0: none)")
     ap.add_argument("--cpu-sample-mb", type=float, default=20.0, help="bases per thread of the CPU baseline leg (about 12 s of CPU work)")
@@ -1211,7 +1316,8 @@ def main():
                         "one launch over all anchor genomes, tiles co-scheduled (homologous regions side by side)",
             "parallelism": parallelism,
         },
-        "roofline": roofline_block(pos_per_launch, avg_launch_s, avg_epi_s, G, value / world, counters, nruns),
+        "roofline": roofline_block(pos_per_launch, avg_launch_s, avg_epi_s, G, value / world, counters, nruns,
+                                   bound="hbm" if args.per_genome_launches else "issue"),
     }
 
     if world == 1 and not args.per_genome_launches and not args.no_compare:
@@ -1336,6 +1442,11 @@ def main():
             out["config"]["wide_shapes"] = wide_legs(ctx, dev, args)
         except Exception as e:
             out["config"]["wide_shapes"] = [{"error": f"{type(e).__name__}: {e}"}]
+    if world == 1 and default_shape and not args.no_other_shapes and not args.no_baseline_configs:
+        try:
+            out["config"]["baseline_configs"], out["e2e_config4"] = baseline_config_legs(ctx, dev, args)
+        except Exception as e:
+            out["config"]["baseline_configs"] = [{"error": f"{type(e).__name__}: {e}"}]
     if world == 1 and default_shape and not args.no_config5:
         try:
             out["config"]["config5_leg"] = config5_leg(ctx, dev, args)

@@ -2428,7 +2428,7 @@ __attribute__((amdgpu_num_sgpr(PG_EPI_SGPRS0))) void k_epilogue(uint32_t N, cons
                                 (nbg == 1u || (a.binlen >= 16u && nbg <= MAXB));
             if (grp_ok) {
                 const uint64_t row0g = a.bin_off + ts / a.binlen;
-                const bool want_repl = nbg <= 2u;  // (block-uniform)
+                const bool want_repl = nbg <= 2u && EPI_REPL * repl_stride <= MAXB * (N + 1u);  // (block-uniform; the copies must fit the window: the last one would run into `cs` otherwise)
                 if (want_repl) {
                     if (!(repl && row0g >= cur_row0 && row0g + nbg <= cur_row0 + 2u)) {
                         if (cur_row0 != ~0ull) {
@@ -3206,7 +3206,7 @@ __global__ __launch_bounds__(EPI_THREADS, (NBT <= 12 ? PG_EPI_WAVESW12 : PG_EPI_
     };
     // ---- the histogram window as EPI_REPL copies of two bin rows while the groups lie inside one or two long bins ----
     constexpr uint32_t EPI_REPL = 8;
-    const uint32_t repl_stride = (2u * (N + 1u)) | 1u;  // (8 copies fit: MAXB >= 16 rows of N + 1)
+    const uint32_t repl_stride = (2u * (N + 1u)) | 1u;  // (8 copies need 16 (N + 1) + 8 words: they fit from MAXB = 17 on — epi_maxb_for gives >= 23 for N <= 128; want_repl checks)
     bool repl = false;
     auto unreplicate = [&]() __attribute__((always_inline)) {
         if (!repl) return;
@@ -3241,7 +3241,7 @@ __global__ __launch_bounds__(EPI_THREADS, (NBT <= 12 ? PG_EPI_WAVESW12 : PG_EPI_
             cur_c = c;
         }
         if (fin) break;
-        // ---- group path: 4 full tiles of one contig = 16 consecutive rows per thread ----
+        // ---- group path: GQ full tiles of one contig = 4 GQ consecutive rows per thread (GQ = 2: 8 rows) ----
         {
             const uint32_t ts = (tile - a.tile0) * PROBE_TILE;
             const uint32_t span = (uint32_t)GQ * PROBE_TILE;
@@ -3250,7 +3250,7 @@ __global__ __launch_bounds__(EPI_THREADS, (NBT <= 12 ? PG_EPI_WAVESW12 : PG_EPI_
                                 (nbg == 1u || (a.binlen >= RPT && nbg <= MAXB));
             if (grp_ok) {
                 const uint64_t row0g = a.bin_off + ts / a.binlen;
-                const bool want_repl = nbg <= 2u;  // (block-uniform)
+                const bool want_repl = nbg <= 2u && EPI_REPL * repl_stride <= MAXB * (N + 1u);  // (block-uniform; the copies must fit the window: the last one would run into `cs` otherwise)
                 if (want_repl) {
                     if (!(repl && row0g >= cur_row0 && row0g + nbg <= cur_row0 + 2u)) {
                         if (cur_row0 != ~0ull) {

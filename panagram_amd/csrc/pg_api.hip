@@ -1216,8 +1216,8 @@ extern "C" int pg_table_measure_spill(pg_table *t, double *fraction) {
         keys += t->subs[si].count;
         spilled += sp;
     }
-    t->spill = keys ? (double)spilled / (double)keys : 0.0;
-    if (fraction) *fraction = t->spill;
+    // (returned only: pg_table_spill keeps answering "as of the last pg_table_rehash", its documented contract)
+    if (fraction) *fraction = keys ? (double)spilled / (double)keys : 0.0;
     return PG_OK;
     PG_API_END
 }

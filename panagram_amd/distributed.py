@@ -270,6 +270,10 @@ def run_index_sharded(index, rank: int, world: int, barrier: Optional[Callable[[
     ctx = index.context
     geo = index.result_geometry
     anchors = list(index.anchor_genomes)
+    # when this rank's anchoring began: what logs/anchor.<name>.benchmark.txt counts from for a genome assembled out of
+    # pieces (its log is only opened at assembly time; Genome.write_benchmark)
+    import time as _time
+    anchoring_t0 = _time.perf_counter()
     gid = {n: i for i, n in enumerate(anchors)}
     seqs = {name: index.seqset_for(name) for name in anchors}
     classes = engine.homology_classes([seqs[n].names for n in anchors])
@@ -494,7 +498,7 @@ def run_index_sharded(index, rank: int, world: int, barrier: Optional[Callable[[
             except OSError:
                 pass
             return os.path.exists(g.chrs_fname)
-        g.ensure_log()
+        g.ensure_log(started=anchoring_t0)
         os.makedirs(g.prefix, exist_ok=True)
         names = list(seqs[name].names)
         for s_ in index.steps:

@@ -1037,12 +1037,14 @@ class Genome:
         with open(path + ".tmp", "w") as f:
             f.write("s\th:m:s\tmax_rss\tmax_vms\tmax_uss\tmax_pss\tio_in\tio_out\tmean_load\tcpu_time\n" + "\t".join(fields) + "\n")
         os.replace(path + ".tmp", path)
+        self._bench_t0 = None  # a second run of the same object counts from its own start
 
-    def ensure_log(self):
-        """logs/anchor.<name>.log.txt, unless a log has been set up already"""
+    def ensure_log(self, started: Optional[float] = None):
+        """logs/anchor.<name>.log.txt, unless a log has been set up already.  ``started``: when this genome's anchoring
+        began, if that was before this call (a genome assembled from pieces: its launches ran long before its log opens)"""
         if self._bench_t0 is None:
             import time
-            self._bench_t0 = time.perf_counter()
+            self._bench_t0 = time.perf_counter() if started is None else started
         if self._log_handler is None and self.index.write_mode:
             os.makedirs(self.index.get_subdir("logs"), exist_ok=True)
             self.setup_log(os.path.join(self.index.get_subdir("logs"), f"anchor.{self.name}.log.txt"))

@@ -85,6 +85,13 @@ def test_config2_fullsize_properties(ctx):
     for s in seqsets:
         s.close()
     tbl.close()
+    del genomes
+    torch.cuda.empty_cache()
+    ctx.trim()
+    # the headline workload exactly as bench.py runs it (all 8 genomes in ONE co-scheduled result) against the CPU oracle:
+    # head of the first contig and tail of the last one of two genomes (cpp/anchor.cpp:112-195 restated in oracle/)
+    st2 = _fullsize_pangenome_properties(ctx, G, contig_lens, k, 0.01, 1234, picks=(0, 5))
+    assert 2.0e8 < st2["nkeys"] < 2.6e8
 
 
 @pytest.mark.parametrize("G,k", [(64, 31), (65, 31), (27, 21)])

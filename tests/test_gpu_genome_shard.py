@@ -390,6 +390,67 @@ def test_eight_processes_on_one_gpu(shard, nblocks, chunk, tmp_path, monkeypatch
     _check_tree(out, fx, gzi_like_reference=shard != "replicated")
 
 
+def _real_gpu_worker(rank, world, port, samples, out, k, anchors, shard, nblocks, chunk):
+    """rank r on GPU r, torch.distributed over RCCL ("nccl"): the product's multi-GPU set-up as a launcher gives it"""
+    import os
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    os.environ.pop("PG_DIST_BACKEND", None)
+    os.environ.pop("PG_SHARD_EXCHANGE", None)
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    try:
+        from panagram_amd import distributed as pdist
+        from panagram_amd import index as pidx
+        pdist.CHUNK_POSITIONS = chunk
+        idx = pidx.Index(samples, prefix=out, k=k, anchor_genomes=anchors, shard=shard, genome_blocks=nblocks, device=rank)
+        assert (idx.rank, idx.world) == (rank, world)
+        idx.run()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name,shard,nblocks,chunk", [("n9_k21", "replicated", 0, 1 << 27), ("n8_k21", "genome", 0, 1500),
+                                                      ("n8_k21", "genome", 8, 1 << 27)])
+def test_real_gpus_over_rccl_give_the_one_rank_tree(name, shard, nblocks, chunk, tmp_path, monkeypatch):
+    """SURVEY section 4's "1 vs N GPUs produce identical payload bytes", on REAL GPUs: Index.run() on min(8, device_count)
+    ranks, one process per GPU, torch.distributed backend "nccl" (= RCCL over xGMI) — the contig-sharded mode ("replicated":
+    pieces of homology classes dealt to the ranks, no collective; cpp/anchor.cpp:217-223 is the axis) and the genome-sharded
+    mode (one genome block per GPU, or 8 one-genome blocks as passes: the bit columns cross xGMI) — against the reference
+    binary's golden outputs AND against the tree one rank writes on its own.  Skipped on a one-GPU box (there the same
+    code runs with several processes on the one device over gloo: test_two/eight_processes_on_one_gpu)."""
+    import os
+    import torch.multiprocessing as mp
+    ngpu = torch.cuda.device_count()
+    if ngpu < 2:
+        pytest.skip("needs at least two GPUs (RCCL refuses several ranks on one device)")
+    world = min(8, ngpu)
+    monkeypatch.setenv("PG_MIN_PIECE", "500")  # (the fixture's contigs are a few kb: cut them all the same)
+    fx = H.load_case(name)
+    s = _write_case(tmp_path, fx)
+    anchors = [f"g{g}" for g in fx["anchors"]]
+    nb = nblocks if nblocks else world
+    out = tmp_path / "idx"
+    port = 29800 + (os.getpid() % 2000)
+    mp.spawn(_real_gpu_worker, args=(world, port, str(s), str(out), int(fx["k"]), anchors, shard, nb if shard == "genome" else 0, chunk),
+             nprocs=world, join=True)
+    _check_tree(out, fx, gzi_like_reference=shard != "replicated")
+    # ... and the decompressed payloads, TSVs and column sums equal what ONE rank writes
+    from panagram_amd import index as pidx
+    one = tmp_path / "idx1"
+    idx = pidx.Index(str(s), prefix=str(one), k=int(fx["k"]), anchor_genomes=anchors)
+    idx.run()
+    import gzip
+    for a in anchors:
+        for fn in ("bitmap.1.gz", "bitmap.100.gz"):
+            with gzip.open(out / "anchor" / a / fn) as f1, gzip.open(one / "anchor" / a / fn) as f2:
+                assert f1.read() == f2.read(), (a, fn)
+        for fn in ("bitsum.bins.tsv", "chrs.tsv", "total_paircounts.csv"):
+            assert (out / "anchor" / a / fn).read_bytes() == (one / "anchor" / a / fn).read_bytes(), (a, fn)
+
+
 @pytest.mark.parametrize("shard,nblocks", [(None, 0), ("genome", 2)])
 def test_cli_under_torchrun_joins_the_group_itself(shard, nblocks, tmp_path):
     """`python -m torch.distributed.run --nproc-per-node 2 -m panagram_amd index …`: nobody initialises torch.distributed

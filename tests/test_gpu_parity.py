@@ -951,6 +951,61 @@ def test_rows_of_9_to_16_bytes_against_oracle(ctx, n):
     tbl.close()
 
 
+@pytest.mark.parametrize("n", [20, 36, 44, 52, 68, 76, 84, 100, 108, 116])  # rows of 3 / 5, 6, 7 / 9, 10, 11 / 13, 14, 15 bytes
+def test_ragged_rows_keep_their_neighbours_first_bytes(ctx, n):
+    """k_probe writes a ragged row (3, 5..7, 9..11, 13..15 bytes) as ONE store of the next word size: the row plus the first
+    bytes of the NEXT position's row, which the next lane holds; the last lane of a batch has no successor in its batch and
+    writes ZEROS there, which the next batch's own store — a later instruction of the same wave — puts right (DESIGN.md
+    section 3, "ragged rows"; rows resolved by the overflow drain are stored exactly).  Directed at that invariant: every
+    genome a near copy of the ancestor, so that nearly EVERY row has all of its first bytes set (a zero left behind at a
+    batch boundary cannot hide), at every ragged width; half of the contig is one diverged repeat family, whose keys
+    overflow their home lines (queue entries in every batch, queue-full drains in the middle of tiles, rows rewritten by
+    the drain next to rows of the main batches).  Rows against the oracle (cpp/anchor.cpp:139-164)."""
+    from panagram_amd import engine
+    k = 21 if n % 8 else 31
+    rng = np.random.default_rng(5150 + n)
+    elem = rng.integers(0, 4, 500, dtype=np.uint8)
+    parts = [rng.integers(0, 4, 6000, dtype=np.uint8)]
+    for c in range(12):
+        e = elem.copy()
+        mut = rng.random(len(e)) < 0.05
+        e[mut] = (e[mut] + rng.integers(1, 4, int(mut.sum()), dtype=np.uint8)) % 4
+        parts += [e, rng.integers(0, 4, 25, dtype=np.uint8)]
+    anc = [np.concatenate(parts), rng.integers(0, 4, 2500 + n, dtype=np.uint8)]
+    genomes = []
+    for g in range(n):
+        cs = []
+        for a in anc:
+            c = a.copy()
+            if g:
+                mut = rng.random(len(c)) < 0.0015
+                c[mut] = (c[mut] + rng.integers(1, 4, int(mut.sum()), dtype=np.uint8)) % 4
+            cs.append(po.codes_to_ascii(c))
+        genomes.append(cs)
+    dbs = po.build_bitvec_dbs(genomes, k)
+    tbl = engine.PanTable(ctx, k, n)
+    for g in range(n):
+        ss = engine.SeqSet.from_host(ctx, genomes[g])
+        tbl.insert_seqset(g, ss)
+        ss.close()
+    for dense in (False, True):
+        if dense:
+            tbl.rehash(6.0)  # (denser lines: more keys outside their home line, more drain work)
+        for g in (0, n - 1):
+            ss = engine.SeqSet.from_host(ctx, genomes[g])
+            res = engine.AnchorResult(tbl, ss, colsums=True)
+            res.run()
+            for ci, seq in enumerate(genomes[g]):
+                rows = res.download(ci)[0]
+                o_rows = po.anchor_contig(dbs, seq, k, n)[0]
+                full = (o_rows[:, 0] == 0xFF).mean()
+                assert full > 0.5, full  # (the directed part: most rows do start with a set byte)
+                assert np.array_equal(rows, o_rows), (n, dense, g, ci, np.argwhere(rows != o_rows)[:4])
+            res.close()
+            ss.close()
+    tbl.close()
+
+
 _FUZZ_N = [2, 8, 9, 16, 17, 24, 25, 32, 33, 40, 63, 64, 65, 72, 96, 97, 127, 128, 129, 160, 193, 256, 257, 300]
 
 

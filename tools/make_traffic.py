@@ -17,8 +17,8 @@ hbm = lambda d: 2.0 * d["FETCH_SIZE"] * 1024 + d["WRITE_SIZE"] * 1024
 t = launch_ms(f"profiles/{tag}_summary.md")
 out = {
  "round": tag, "kernel": "k_probe",
- "kernel_sources_sha16": __import__("hashlib").sha256(b"".join(open("panagram_amd/csrc/" + f, "rb").read() for f in ("pg_anchor.hip", "pg_device.h", "pg_kernels.h"))).hexdigest()[:16],
- "kernel_sources_note": "sha256 of pg_anchor.hip + pg_device.h + pg_kernels.h when this file was made (right after the --pmc passes): bench.py reports whether the kernels it runs are still those",
+ "kernel_sources_sha16": __import__("hashlib").sha256(b"".join(open("panagram_amd/csrc/" + f, "rb").read() for f in ("pg_anchor.hip", "pg_device.h", "pg_kernels.h", "pg_kernels.hip", "pg_api.hip"))).hexdigest()[:16],
+ "kernel_sources_note": "sha256 of pg_anchor.hip + pg_device.h + pg_kernels.h + pg_kernels.hip + pg_api.hip (bench.KERNEL_SOURCES) when this file was made (right after the --pmc passes): bench.py reports whether the kernels it runs are still those",
  "workload": "bench.py default (8 x 100 Mb, k=21; the table as the library builds it, no re-hash), ONE co-scheduled launch over all 8 anchor genomes",
  "positions_per_launch": pos,
  "FETCH_SIZE_kb": c["FETCH_SIZE"], "WRITE_SIZE_kb": c["WRITE_SIZE"], "TCC_EA0_RDREQ": c["TCC_EA0_RDREQ_sum"], "TCC_HIT": c["TCC_HIT_sum"], "TCC_MISS": c["TCC_MISS_sum"],
