@@ -846,10 +846,18 @@ class ShardedAnchoring:
     sequences are laid out group by group in one merged seqset for this).  ``run_pass`` probes every group against
     ``table`` (None: this rank has no block in the pass and contributes zeros):
 
-        probe group i  ->  extract its bit columns  ->  all-gather on the side stream  ->  merge on the writers
+        probe group i  ->  extract its bit columns  ->  exchange on the side stream  ->  merge on the writers
                            probe group i+1 ...
 
-    and calls ``on_anchor_complete(name, rows_container)`` on the writer once an anchor's last chunk is merged."""
+    and calls ``on_anchor_complete(name, rows_container)`` on the writer once an anchor's last chunk is merged.
+
+    The exchange (round 6): only an anchor's WRITER merges its columns, so a rank sends each anchor's columns to that
+    writer alone — an all-to-all with split sizes (RCCL ``all_to_all_single``; batched ``isend`` / ``irecv`` where the
+    backend has no all-to-all: gloo) — instead of all-gathering every block's columns to every rank: a rank receives
+    (world - 1) / world of ITS OWN anchors' columns, 1 / world of what the all-gather delivered (config 5 on 8 GPUs: 2.6 GB
+    per GPU instead of 21 GB).  A group's members are laid out writer by writer for this, so that what goes to one rank is
+    one contiguous piece of the send buffer.  ``PG_SHARD_EXCHANGE=allgather`` keeps the all-gather (the north star's
+    wording; the same bytes on disk), ``host`` / ``host-allgather`` take either through pinned host memory and gloo."""
 
     # widest block whose columns the probe assembles itself (a ballot + two LDS words per genome and batch): one genome
     # per block — config 5's layout — where it also spares the narrow row buffer (one byte per anchor position: 24 GB
@@ -870,9 +878,12 @@ class ShardedAnchoring:
         # group (RCCL over xGMI) — or "host" (SURVEY §8e's fallback without a GPU collective): every rank copies its
         # columns to pinned host memory, the hosts all-gather them over a gloo group, the gathered blocks go back to
         # the GPU and are merged as usual.  1 bit per genome and position: the detour costs PCIe time, not correctness.
-        self.exchange = os.environ.get("PG_SHARD_EXCHANGE", "rccl").lower()
-        if self.exchange not in ("rccl", "host"):
-            raise ValueError(f"PG_SHARD_EXCHANGE must be 'rccl' or 'host', got {self.exchange!r}")
+        # (round 6) "rccl" and "host" send an anchor's columns to its writer only; "allgather" / "host-allgather": to every rank
+        mode = os.environ.get("PG_SHARD_EXCHANGE", "rccl").lower()
+        if mode not in ("rccl", "host", "allgather", "host-allgather"):
+            raise ValueError(f"PG_SHARD_EXCHANGE must be 'rccl', 'host', 'allgather' or 'host-allgather', got {mode!r}")
+        self.exchange = "host" if mode.startswith("host") else "rccl"
+        self.to_writers = not mode.endswith("allgather")
         self.host_group = None
         if self.collective:
             import torch.distributed as dist
@@ -891,30 +902,47 @@ class ShardedAnchoring:
         names = list(seqs)
         chunks = {a: contig_chunks(seqs[a].lens, k) for a in names}
         # groups[i] = [(anchor, first contig, count, tile offset inside the group)], the same on every rank
+        # (members writer by writer, a writer's anchors in their own order: what goes to one rank is ONE contiguous piece of
+        # the group's column buffer — dest_off / dest_tiles [i][w], in tiles)
         self.groups, parts, self.group_first, self.group_tiles = [], [], [], []
+        self.dest_off, self.dest_tiles = [], []
         contig_anchor = []
+        by_writer = sorted(range(len(names)), key=lambda ai: (int(writer.get(names[ai], 0)), ai))
         for i in range(max([len(c) for c in chunks.values()] or [0])):
             members, toff = [], 0
             self.group_first.append(len(contig_anchor))
-            for ai, a in enumerate(names):
+            doff, dtiles = [0] * self.world, [0] * self.world
+            for ai in by_writer:
+                a = names[ai]
                 if i < len(chunks[a]):
                     c0, nc = chunks[a][i]
+                    w = int(writer.get(a, 0))
+                    if not 0 <= w < self.world:
+                        raise ValueError(f"anchor {a!r} has writer rank {w}, the run has {self.world} rank(s)")
+                    if dtiles[w] == 0:
+                        doff[w] = toff
                     members.append((a, c0, nc, toff))
-                    toff += sum((max(0, int(ln) - k + 1) + tile - 1) // tile for ln in seqs[a].lens[c0:c0 + nc])
+                    nt = sum((max(0, int(ln) - k + 1) + tile - 1) // tile for ln in seqs[a].lens[c0:c0 + nc])
+                    toff += nt
+                    dtiles[w] += nt
                     parts.append((seqs[a], c0, nc))
                     contig_anchor += [ai] * nc
             self.groups.append(members)
             self.group_tiles.append(toff)
+            self.dest_off.append(doff)
+            self.dest_tiles.append(dtiles)
         self.last_group = {a: max(i for i, m in enumerate(self.groups) if any(x[0] == a for x in m))
                            for a in names if chunks[a]}
         self.merged = engine.SeqSet.concat_ranges(ctx, parts) if parts else None
         self._contig_anchor = np.asarray(contig_anchor, np.uint32)
         biggest = max(self.group_tiles or [0]) * self.col_bytes * per
+        # what this rank receives per group: `world` blocks of its OWN anchors' columns (to_writers), or of everybody's
+        own_biggest = max([d[self.rank] for d in self.dest_tiles] or [0]) * self.col_bytes * per if self.to_writers else biggest
         if self.collective:  # torch owns the buffers (the collective takes tensors) and the two streams
             import torch
             dev = ctx.torch_device()
             self.send = [_TorchBuffer(torch, biggest, dev) for _ in range(2)]
-            self.recv = [_TorchBuffer(torch, biggest * self.world, dev) for _ in range(2)]
+            self.recv = [_TorchBuffer(torch, own_biggest * self.world, dev) for _ in range(2)]
             if dev.type == "cuda":
                 torch.cuda.synchronize(dev)  # the buffers were zeroed on torch's stream; the kernels run on the pipe's
             self.pipe = _Pipe(ctx, dev)
@@ -923,7 +951,7 @@ class ShardedAnchoring:
             self._host = None
             if self.exchange == "host" and dev.type == "cuda":
                 self._host = (torch.empty(max(biggest, 8), dtype=torch.uint8).pin_memory(),
-                              torch.empty(max(biggest, 8) * self.world, dtype=torch.uint8).pin_memory())
+                              torch.empty(max(own_biggest, 8) * self.world, dtype=torch.uint8).pin_memory())
             self._first_contact(torch, dev)
         else:  # one process: its own block is all there is — merged straight out of the send buffer; no torch
             self.send = [engine.DeviceBuffer(ctx, biggest) for _ in range(2)]
@@ -963,7 +991,7 @@ class ShardedAnchoring:
         t = threading.Thread(target=probe, daemon=True)
         t.start()
         t.join(timeout)
-        how = "RCCL all_gather_into_tensor" if self.exchange == "rccl" else "host all-gather (gloo)"
+        how = "RCCL collective (all_gather_into_tensor)" if self.exchange == "rccl" else "host all-gather (gloo)"
         if t.is_alive():
             raise RuntimeError(f"the first {how} of {self.world} ranks did not complete within {timeout:.0f} s "
                                "(PG_COLLECTIVE_TIMEOUT_S).  Check that every rank was started (WORLD_SIZE), one per GPU; "
@@ -995,6 +1023,46 @@ class ShardedAnchoring:
         torch.cuda.current_stream(in_t.device).synchronize()
         self.dist.all_gather_into_tensor(hr, hs, group=self.host_group if self.host_group is not None else self.group)
         out_t.copy_(hr, non_blocking=True)
+
+    def _to_writers_into(self, out_t, in_t, send_off, send_len, own: int) -> None:
+        """The writer-only exchange of one chunk group: piece [send_off[w], send_off[w] + send_len[w]) of ``in_t`` — the columns
+        of the anchors rank w writes — goes to rank w; ``out_t`` receives ``world`` blocks of ``own`` bytes, block j = what rank
+        j (genome block part0 + j) computed for THIS rank's anchors.  RCCL: one all_to_all_single with split sizes; a backend
+        without all-to-all (gloo) or the host route: batched isend / irecv, the rank's own piece copied in place."""
+        dist, world, rank = self.dist, self.world, self.rank
+        group = self.group if self.host_group is None else self.host_group
+        on_gpu = in_t.device.type == "cuda"
+        backend = dist.get_backend(self.group)
+        if self.exchange == "rccl" and on_gpu and backend == "nccl":
+            # (the pieces are laid out writer by writer: input split w is exactly what rank w gets)
+            assert all(send_off[w] == sum(send_len[:w]) for w in range(world))
+            dist.all_to_all_single(out_t[:own * world], in_t[:sum(send_len)], output_split_sizes=[own] * world,
+                                   input_split_sizes=list(send_len), group=self.group)
+            return
+        import torch
+        src, dst = in_t, out_t
+        if on_gpu:  # through pinned host memory (the "host" route, or CUDA tensors over a gloo group)
+            n_in, n_out = int(in_t.numel()), own * world
+            if self._host is None or self._host[0].numel() < n_in or self._host[1].numel() < n_out:
+                self._host = (torch.empty(max(n_in, 8), dtype=torch.uint8).pin_memory(), torch.empty(max(n_out, 8), dtype=torch.uint8).pin_memory())
+            src, dst = self._host[0][:n_in], self._host[1][:max(n_out, 1)]
+            src.copy_(in_t, non_blocking=True)
+            torch.cuda.current_stream(in_t.device).synchronize()
+        ops = []
+        for j in range(world):
+            if j == rank:
+                continue
+            if send_len[j]:
+                ops.append(dist.P2POp(dist.isend, src[send_off[j]:send_off[j] + send_len[j]], j, group))
+            if own:
+                ops.append(dist.P2POp(dist.irecv, dst[j * own:(j + 1) * own], j, group))
+        if own:
+            dst[rank * own:(rank + 1) * own].copy_(src[send_off[rank]:send_off[rank] + own])
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        if on_gpu and own:
+            out_t[:own * world].copy_(dst[:own * world], non_blocking=True)
 
     def release(self, a: str) -> None:
         """the writer is done with anchor ``a`` (files written): its full-width rows go back to the context"""
@@ -1048,15 +1116,20 @@ class ShardedAnchoring:
             phase_s[name] = phase_s.get(name, 0.0) + (t1 - t0)
             return t1
 
+        to_writers = self.collective and self.to_writers
+
         def settle(pend):
             i, slot, ev = pend
             pipe.main_waits(ev)  # (also what frees send[slot] for the next extract into it)
-            stride = self.group_tiles[i] * self.col_bytes * per  # recv holds `world` blocks of this size, block j = genome block part0 + j
+            # recv holds `world` blocks, block j = genome block part0 + j: of the whole group's columns (all-gather / one
+            # process), or of this writer's anchors only, which start at tile dest_off[i][rank] of the group
+            stride = (self.dest_tiles[i][self.rank] if to_writers else self.group_tiles[i]) * self.col_bytes * per
+            t_first = self.dest_off[i][self.rank] if to_writers else 0
             t0 = now()
             for a, c0, nc, toff in self.groups[i]:
                 if self.writer[a] != self.rank:
                     continue
-                self.container(a).merge_columns_range(self.recv[slot].data_ptr() + toff * self.col_bytes * per, part0, nparts, per,
+                self.container(a).merge_columns_range(self.recv[slot].data_ptr() + (toff - t_first) * self.col_bytes * per, part0, nparts, per,
                                                       c0, nc, accumulate=accumulate, part_stride_bytes=stride)
                 t0 = lap("merge", t0)
                 if on_anchor_complete is not None and self.last_group[a] == i:
@@ -1079,7 +1152,14 @@ class ShardedAnchoring:
             else:
                 self.send[slot].zero(nbytes)  # a rank without a block in this pass contributes zeros
             ready = pipe.mark_main()
-            if self.collective:
+            if to_writers:
+                unit = self.col_bytes * per
+                own = self.dest_tiles[i][self.rank] * unit
+                soff, slen = [t * unit for t in self.dest_off[i]], [t * unit for t in self.dest_tiles[i]]
+                ev = pipe.on_comm(ready, lambda o=self.recv[slot].t, t=self.send[slot].t[:nbytes], so=soff, sl=slen, ow=own:
+                                  self._to_writers_into(o, t, so, sl, ow))
+                self.bytes_received += own * (self.world - 1)
+            elif self.collective:
                 out_t, in_t = self.recv[slot].t[:nbytes * self.world], self.send[slot].t[:nbytes]
                 ev = pipe.on_comm(ready, lambda o=out_t, t=in_t: self._gather_into(o, t))
                 self.bytes_received += nbytes * (self.world - 1)
@@ -1188,7 +1268,11 @@ def run_genome_sharded(index, nblocks: int, group=None, exchange_stats: Optional
         if tbl_mem is not None:
             tbl_mem.close()
     if exchange_stats is not None:
-        exchange_stats.update(bytes_received=sh.bytes_received, passes=passes, nblocks=nblocks, per=per, chunks=len(sh.groups))
+        unit = sh.col_bytes * per  # bytes of one block's columns per tile
+        exchange_stats.update(bytes_received=sh.bytes_received, passes=passes, nblocks=nblocks, per=per, chunks=len(sh.groups),
+                              to_writers=bool(sh.to_writers), exchange=sh.exchange,
+                              own_column_bytes_per_pass=sum(d[rank] for d in sh.dest_tiles) * unit,
+                              all_column_bytes_per_pass=sum(sh.group_tiles) * unit)
     if sh.dist is not None:
         sh.dist.barrier(group=group)
 

@@ -677,7 +677,8 @@ class Index:
         if mode == "genome":
             from .distributed import run_genome_sharded
             logger.info("genome-sharded mode: %d genome blocks over %d GPU(s)", nblocks, self.world)
-            run_genome_sharded(self, nblocks)
+            self.exchange_stats = {}  # what this rank's exchange moved (bytes_received, passes, chunks): distributed.run_genome_sharded
+            run_genome_sharded(self, nblocks, exchange_stats=self.exchange_stats)
             self.close()
             return
         if self.world > 1 and os.environ.get("PG_PARTITION", "pieces") != "genomes":

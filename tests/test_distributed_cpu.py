@@ -178,6 +178,10 @@ def _index_run_worker(rank, world, port, idx_dir, shard, nblocks, chunk):
         idx = pidx.Index(idx_dir, mode="w", shard=shard, genome_blocks=nblocks)
         assert (idx.rank, idx.world) == (rank, world)
         idx.run()
+        if getattr(idx, "exchange_stats", None):  # what the rank's exchange moved, for the tests that count bytes
+            import json
+            with open(os.path.join(idx_dir, f"exchange.rank{rank}.json"), "w") as f:
+                json.dump(idx.exchange_stats, f)
     finally:
         dist.destroy_process_group()
 
@@ -215,6 +219,40 @@ def test_world8_index_run_dress_rehearsal(shard, nblocks, chunk, tmp_path):
         else:
             os.environ["PG_MIN_PIECE"] = env_before
     _check_tree(idx_dir, fx)
+
+
+@pytest.mark.parametrize("world,nblocks,chunk", [(2, 2, 1500), (8, 8, 1500), (3, 5, 900)])
+def test_exchange_sends_columns_to_their_writer_only(world, nblocks, chunk, tmp_path, monkeypatch):
+    """The genome-sharded exchange (round 6): a rank's columns of an anchor go to that anchor's WRITER only (batched isend /
+    irecv here: gloo has no all-to-all; all_to_all_single on RCCL) — every rank receives (world - 1) x its OWN anchors'
+    columns per pass — where PG_SHARD_EXCHANGE=allgather delivers every anchor's columns to every rank: world x the bytes
+    over the run.  Both trees equal the reference binary's golden outputs; (3 ranks, 5 blocks): two passes, the second with an
+    idle rank, 8 anchors dealt 3 / 3 / 2."""
+    import json
+    fx = H.load_case("n8_k21")
+    monkeypatch.setenv("PG_MIN_PIECE", "500")
+    got = {}
+    for mode in ("rccl", "allgather"):
+        monkeypatch.setenv("PG_SHARD_EXCHANGE", mode)
+        sub = tmp_path / mode
+        sub.mkdir()
+        idx_dir = _prepare_index(sub, fx)
+        port = 29500 + (os.getpid() % 2000)
+        mp.spawn(_index_run_worker, args=(world, port, idx_dir, "genome", nblocks, chunk), nprocs=world, join=True)
+        _check_tree(idx_dir, fx)
+        got[mode] = [json.load(open(os.path.join(idx_dir, f"exchange.rank{r}.json"))) for r in range(world)]
+    w, g = got["rccl"], got["allgather"]
+    assert all(x["to_writers"] for x in w) and not any(x["to_writers"] for x in g)
+    passes = w[0]["passes"]
+    assert passes == (nblocks + world - 1) // world
+    total = w[0]["all_column_bytes_per_pass"]
+    assert total > 0 and all(x["all_column_bytes_per_pass"] == total for x in w + g)
+    assert sum(x["own_column_bytes_per_pass"] for x in w) == total  # every anchor has exactly one writer
+    for x in w:   # (world - 1) x the rank's own anchors' columns, every pass
+        assert x["bytes_received"] == (world - 1) * x["own_column_bytes_per_pass"] * passes
+    for x in g:   # the all-gather: (world - 1) x everybody's
+        assert x["bytes_received"] == (world - 1) * total * passes
+    assert sum(x["bytes_received"] for x in g) == world * sum(x["bytes_received"] for x in w)
 
 
 def test_world2_index_run_replicated(tmp_path):
