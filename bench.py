@@ -614,7 +614,7 @@ def wide_legs(ctx, dev, args, k=21):
     return out
 
 
-def config5_leg(ctx, dev, args, genome_mb=None, contigs=24, sample_n=1_000_000, chunk_positions=None):
+def config5_leg(ctx, dev, args, genome_mb=None, contigs=24, sample_n=1_000_000, chunk_positions=None, per=1, keys_per_line=None):
     """BASELINE.json configs[4] AS SPECIFIED — 8 synthetic 3 Gb genomes (24 contigs of 125 Mb each), k=21, d=0.05: 1.7e10
     distinct k-mers, more than one GPU's 288 GB holds — on ONE GPU through the product's own pass mode
     (panagram_amd.distributed.ShardedAnchoring, what Index.run() runs when plan_sharding says "genome"): genome_blocks = 8,
@@ -660,27 +660,44 @@ def config5_leg(ctx, dev, args, genome_mb=None, contigs=24, sample_n=1_000_000, 
     # ---- ONE table allocation for all blocks, sized from the genomes' sketches (run_genome_sharded does the same) ----
     sketch = engine.KmerSketch(ctx, k)
     est = 0
-    for ss in seqsets:
+    for b0 in range(0, G, per):  # distinct k-mers of the largest block (the union of its genomes' sketches)
         sketch.reset()
-        sketch.add(ss)
+        for ss in seqsets[b0:b0 + per]:
+            sketch.add(ss)
         est = max(est, sketch.estimate())
     sketch.close()
     old_chunk = pdist.CHUNK_POSITIONS
     if chunk_positions:
         pdist.CHUNK_POSITIONS = chunk_positions
     try:
-        sh = pdist.ShardedAnchoring(engine, ctx, k, G, 1, 0, 1, seqs, {a: 0 for a in names}, None, None)
+        sh = pdist.ShardedAnchoring(engine, ctx, k, G, per, 0, 1, seqs, {a: 0 for a in names}, None, None)
     finally:
         pdist.CHUNK_POSITIONS = old_chunk
-    tbl = engine.PanTable(ctx, k, 1, expected_keys=est + est // 32 + 1024, coscheduled=G)
+    # (``per`` genomes per block: the block's table holds the union of their k-mers — at d = 0.05 two genomes share a ninth of
+    # theirs — created at ``keys_per_line`` keys per 128-byte line so that it fits beside the rows: fewer, denser passes)
+    nblocks = (G + per - 1) // per
+    expect = est + est // 32 + 1024
+    if keys_per_line == "auto":
+        # as Index.plan_sharding sizes a block table: what is free next to the full rows (one byte per anchor position at 8
+        # genomes), the narrow result's rows and the library's reserve, at no fewer than the library's 3 keys per line
+        torch.cuda.synchronize()
+        free = torch.cuda.mem_get_info()[0]
+        room = free - (8 << 30) - pos * ((G + 7) // 8) - pos * ((per + 7) // 8)
+        keys_per_line = max(3.0, round(expect * 128.0 * 1.02 / max(room, 1) + 0.05, 1))
+        if keys_per_line > 6.2:
+            raise RuntimeError(f"blocks of {per} genomes do not fit this GPU at any usable density ({keys_per_line} keys per line)")
+        if keys_per_line <= 3.0:
+            keys_per_line = None
+    tbl = engine.PanTable(ctx, k, per, expected_keys=expect, coscheduled=G, **({"keys_per_line": float(keys_per_line)} if keys_per_line else {}))
     passes, done = [], []
     total_build = total_pass = 0.0
-    for p in range(G):
+    for p in range(nblocks):
         if p:
             tbl.clear()
         ctx.synchronize()
         t0 = time.perf_counter()
-        tbl.insert_seqset(0, seqsets[p])
+        for j, g in enumerate(range(p * per, min(G, (p + 1) * per))):
+            tbl.insert_seqset(j, seqsets[g])
         ctx.synchronize()
         build_s = time.perf_counter() - t0
         stt = tbl.stats()
@@ -690,7 +707,7 @@ def config5_leg(ctx, dev, args, genome_mb=None, contigs=24, sample_n=1_000_000, 
         sh.run_pass(tbl, p, 1, True, None, phase_s=ph)
         ctx.synchronize()
         t0 = time.perf_counter()
-        sh.run_pass(tbl, p, 1, True, (lambda a, res: (res.rows_epilogue(), done.append(a))) if p == G - 1 else None)
+        sh.run_pass(tbl, p, 1, True, (lambda a, res: (res.rows_epilogue(), done.append(a))) if p == nblocks - 1 else None)
         ctx.synchronize()
         pass_s = time.perf_counter() - t0
         total_build += build_s
@@ -707,15 +724,16 @@ def config5_leg(ctx, dev, args, genome_mb=None, contigs=24, sample_n=1_000_000, 
         return rows[:nrows] if where == "head" else rows[-nrows:]
     v, cdt, npos, ok = cpu_baseline(dbs, samples_host, k, G, gpu_rows)
     out = {
-        "workload": f"BASELINE.json configs[4]: 8 synthetic {L / 1e6:g} Mb genomes ({contigs} contigs each), k=21, d=0.05, genome_blocks=8 "
-                    "(one genome per block), all 8 anchored, on ONE GPU as 8 passes through distributed.ShardedAnchoring "
-                    "(table of block p built in one re-used allocation, every anchor position probed, bit column extracted and "
-                    "OR-ed into the full rows); with 8 GPUs the passes run side by side and the columns are all-gathered",
-        "positions": pos, "genome_blocks": G, "chunk_groups_per_pass": len(sh.groups),
+        "workload": f"BASELINE.json configs[4]: 8 synthetic {L / 1e6:g} Mb genomes ({contigs} contigs each), k=21, d=0.05, genome_blocks={nblocks} "
+                    f"({per} genome(s) per block), all 8 anchored, on ONE GPU as {nblocks} passes through distributed.ShardedAnchoring "
+                    "(table of block p built in one re-used allocation, every anchor position probed, the block's bit columns extracted and "
+                    "OR-ed into the full rows); with 8 GPUs one-genome blocks run side by side in ONE pass and each anchor's columns go to its writer",
+        "positions": pos, "genome_blocks": nblocks, "genomes_per_block": per, "table_keys_per_line_at_creation": keys_per_line or 3,
+        "chunk_groups_per_pass": len(sh.groups),
         "value": pos / total_pass, "value_with_table_builds": pos / (total_pass + total_build), "unit": "k-mers/s",
-        "value_note": "the whole job on ONE GPU: all positions / the 8 passes' time (each pass probes every position against one "
-                      "genome's table: 8 GPUs' work); per_pass_value_mean is what one rank of an 8-GPU run sustains, the "
-                      "job's 8-GPU rate if the all-gather hides behind the next group's probe (DESIGN.md section 6)",
+        "value_note": "the whole job on ONE GPU: all positions / the passes' time (each pass probes every position against one "
+                      "block's table); with one genome per block per_pass_value_mean is what one rank of an 8-GPU run sustains, the "
+                      "job's 8-GPU rate if the exchange hides behind the next group's probe (DESIGN.md section 6)",
         "per_pass_value_mean": float(np.mean([x["value"] for x in passes])),
         "passes_s": total_pass, "table_builds_s": total_build, "passes": passes,
         "union_keys_sum_over_blocks": int(sum(x["table_keys"] for x in passes)),
@@ -723,7 +741,7 @@ def config5_leg(ctx, dev, args, genome_mb=None, contigs=24, sample_n=1_000_000, 
         "rows_equal_gpu": ok,
         "rows_check": f"first {n} rows of genome 0 and last {n} rows of genome 5's last contig: CPU oracle rows (k-mer DB of the "
                       f"samples built by brute force with torch in {db_s:.1f} s, {sum(len(kk) for kk, _ in dbs)} keys) == the rows "
-                      "the 8 passes assembled",
+                      f"the {nblocks} passes assembled",
         "synth_s": synth_s, "leg_s": time.perf_counter() - t_leg,
     }
     sh.close()
@@ -1452,6 +1470,12 @@ def main():
             out["config"]["config5_leg"] = config5_leg(ctx, dev, args)
         except Exception as e:
             out["config"]["config5_leg"] = {"error": f"{type(e).__name__}: {e}"}
+        ctx.trim()
+        torch.cuda.empty_cache()
+        try:  # what Index.plan_sharding chooses on one GPU since round 6: two genomes per block in a denser table, half the passes
+            out["config"]["config5_leg_two_genome_blocks"] = config5_leg(ctx, dev, args, per=2, keys_per_line="auto")
+        except Exception as e:
+            out["config"]["config5_leg_two_genome_blocks"] = {"error": f"{type(e).__name__}: {e}"}
     if watchdog is not None:
         watchdog.cancel()
     if rank == 0:

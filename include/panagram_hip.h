@@ -90,6 +90,15 @@ int pg_device_free(pg_ctx *ctx, void *ptr);
  * one-hot-OR mask(s).  k in 1..32.  One writer at a time: the calls that add keys (insert_*, load_kmc1,
  * rehash) serialise on a per-table lock; lookups (pg_anchor_run ...) must not overlap them. */
 int pg_table_create(pg_ctx *ctx, int k, int ngenomes, uint64_t expected_keys, pg_table **out);
+/* the same with the table's density chosen by the caller: keys_per_line (1 .. 6.4) keys per 128-byte line of 8 slots instead
+ * of the library's 3, for a known expected_keys (> 0) and up to 64 genomes.  What it is for: the genome-sharded mode's block
+ * tables (BASELINE configs[4]) — a denser table holds the union of TWO genomes' k-mers in one GPU's HBM, the
+ * job takes half the passes over the anchors' positions, and a pass against 3.4-4.5 keys per line is 5-25 % slower, not 100 %
+ * (profiles/r6g_config5_blocks.txt).  The table is not grown back to 3 keys per line while it fills.  The reference has one
+ * density: KMC's sorted suffix arrays (call site cpp/anchor.cpp:28-31). */
+int pg_table_create_dense(pg_ctx *ctx, int k, int ngenomes, uint64_t expected_keys, double keys_per_line, pg_table **out);
+/* device bytes pg_table_create_dense would allocate (host only; the planner's arithmetic) */
+int pg_table_bytes_for_dense(int k, int ngenomes, uint64_t expected_keys, double keys_per_line, uint64_t *bytes);
 /* device bytes pg_table_create would allocate for that many keys (host only): lets the caller decide between one
  * replicated table and the genome-sharded mode before allocating anything */
 int pg_table_bytes_for(int k, int ngenomes, uint64_t expected_keys, uint64_t *bytes);
@@ -283,6 +292,15 @@ int pg_result_timing(pg_result *r, float *probe_ms, float *epilogue_ms);
  * is waited for between runs): what a benchmark quotes as its average launch.  nruns = probe launches counted. */
 int pg_result_timing_reset(pg_result *r);
 int pg_result_timing_mean(pg_result *r, double *probe_ms, double *epilogue_ms, uint32_t *nruns);
+/* Fused statistics (round 6, an opt-in experiment: PG_FUSE_STATS=1 in the environment): a pg_anchor_run over rows of 2..8
+ * bytes ends every tile INSIDE k_probe with the tile's popcount histogram, column sums and 1-in-100 rows — what
+ * cpp/anchor.cpp:156-183 does in its scatter loop — read back from the rows while the cache still holds them; a small kernel
+ * adds the tiles' counters up (k_tile_reduce) and the statistics pass (k_epilogue*) only visits contigs whose bins are
+ * shorter than a tile.  The outputs are the same bytes either way (tests/test_gpu_parity.py); the default stays the pass over
+ * every row, which is faster.  *n = whole runs of this result that took the fused path so far (0: none did —
+ * not asked for, one-byte rows, rows wider than 8 bytes, several sub-tables, no contig with long enough bins, no memory for the
+ * tiles' counters: 2-6 % of the rows).  No reference counterpart: a diagnostic for tests and bench.py. */
+int pg_result_fused_runs(const pg_result *r, uint32_t *n);
 /* Genome-sharded exchange (union of tables > one GPU's HBM): rank i owns genomes
  * [i*per, (i+1)*per) and its PG_ANCHOR_ROWS_ONLY rows hold only their bits.  extract writes the
  * compact block of bit columns of genomes [g0, g0+width) — pg_result_columns_bytes(width) bytes,

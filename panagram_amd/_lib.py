@@ -41,6 +41,8 @@ PROTOTYPES = {
     "pg_device_memset": (C.c_int, [_vp, _vp, C.c_int, C.c_uint64]),
     "pg_device_free": (C.c_int, [_vp, _vp]),
     "pg_table_create": (C.c_int, [_vp, C.c_int, C.c_int, C.c_uint64, _vpp]),
+    "pg_table_create_dense": (C.c_int, [_vp, C.c_int, C.c_int, C.c_uint64, C.c_double, _vpp]),
+    "pg_table_bytes_for_dense": (C.c_int, [C.c_int, C.c_int, C.c_uint64, C.c_double, _u64p]),
     "pg_table_destroy": (C.c_int, [_vp]),
     "pg_table_clear": (C.c_int, [_vp]),
     "pg_table_insert_seqset": (C.c_int, [_vp, C.c_int, _vp]),
@@ -91,6 +93,7 @@ PROTOTYPES = {
     "pg_anchor_run_columns_range": (C.c_int, [_vp, C.c_uint32, C.c_uint32, C.c_uint32, _vp]),
     "pg_result_timing_reset": (C.c_int, [_vp]),
     "pg_result_timing_mean": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double), _u32p]),
+    "pg_result_fused_runs": (C.c_int, [_vp, _u32p]),
     "pg_result_columns_bytes_range": (C.c_uint64, [_vp, C.c_uint32, C.c_uint32, C.c_uint32]),
     "pg_result_extract_columns_range": (C.c_int, [_vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _vp]),
     "pg_result_merge_columns_range": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_uint64]),

@@ -840,6 +840,236 @@ __device__ __forceinline__ void drain_queue(const SubTable &st, uint32_t qn, con
     }
 }
 
+// ---------------------------------------------------------------------------
+// Fused statistics (round 6; FuseArgs in pg_kernels.h): the END of a tile inside k_probe.  The statistics pass read every row
+// again from HBM — a quarter of the step at 65-128 genomes, 102 GB at BASELINE configs[3] — although each wave has just
+// written its tile's rows (at most 16 KB): here the wave reads them back while they are still in the L2 / Infinity Cache and
+// leaves the tile's counters, 0.4-5 % of the row bytes, for k_tile_reduce to add up.  Nothing of this touches the batch loop:
+// no register, no LDS byte and no instruction of it (the tile's descriptors are loaded again at the end, so that the loop
+// keeps no more values alive than the unfused kernel's).  Extra VALU work at the tile's end is cheap where it matters: 48
+// extra instructions per batch cost the probe of 65 / 128 genomes 0.6 %, of 27 / 64 genomes 9 % (profiles/r6b_elasticity.txt).
+//   rows        16 per lane (row j * 64 + lane of the tile, j = 0..15), each ONE load of ceil(nbytes / 4) dwords at its byte
+//               offset (gfx950 takes unaligned dword accesses), L1 bypassed (sc1: the L2 is where the wave's stores are)
+//   histogram   popcount -> (bin of the row relative to the tile's first, popcount): one LDS add of 1 << 16 * (index & 1) to a
+//               packed pair of u16 counters, four copies by lane & 3 (a tile has 1024 rows: no field overflows)
+//   column sums sixteen rows per word through a Harley-Seal carry-save tree (15 adders: 45 instructions) into five bit
+//               planes, transposed to byte counters and summed over the lanes by a halving exchange (k_epilogue's vflush)
+//   bitmap.100  the tile's rows at multiples of 100 (eleven at most), copied byte by byte by the first lanes
+// The reference does all of this in its scatter loop (cpp/anchor.cpp:156-183); the column sums are index.py:1051's.
+// ---------------------------------------------------------------------------
+#ifndef PG_FUSE_LOAD_SC1
+#define PG_FUSE_LOAD_SC1 1  // 0: the row read-back with the default cache policy (experiment)
+#endif
+// NW (1..4) dwords from byte `off` of the tile's rows (any byte alignment: gfx950 takes unaligned dword accesses), as agent-scope
+// loads of 8 and 4 bytes — sc1: served by the L2, where the wave's stores are, whatever the L1 holds — with the tile's base
+// address in a scalar register pair.  (A buffer descriptor would do the same in one instruction for three or four words, but its
+// four scalar registers do not survive in the wide instantiations, which are held to 80: the compiler then keeps it in vector
+// registers and wraps every load in a readfirstlane loop.)
+typedef const __attribute__((address_space(1))) uint8_t *GlobalBytes;  // (a pointer the compiler knows to be global memory: global_load with a scalar base, not flat_load)
+template <int NW>
+__device__ __forceinline__ void fuse_load_row(GlobalBytes base, uint32_t off, uint32_t (&w)[NW]) {
+    GlobalBytes p = base + off;
+#if PG_FUSE_LOAD_SC1
+#pragma unroll
+    for (int i = 0; i + 1 < NW; i += 2) {
+        const unsigned long long v = __hip_atomic_load(reinterpret_cast<const __attribute__((address_space(1))) unsigned long long *>(p + 4 * i), __ATOMIC_RELAXED,
+                                                       __HIP_MEMORY_SCOPE_AGENT);
+        w[i] = (uint32_t)v, w[i + 1] = (uint32_t)(v >> 32);
+    }
+    if constexpr (NW & 1)
+        w[NW - 1] = __hip_atomic_load(reinterpret_cast<const __attribute__((address_space(1))) uint32_t *>(p + 4 * (NW - 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+    const WordsN<NW> v = *reinterpret_cast<const __attribute__((address_space(1))) WordsN<NW> *>(p);
+#pragma unroll
+    for (int i = 0; i < NW; ++i) w[i] = v.w[i];
+#endif
+}
+// the five bit planes of one row word (bit c of plane i = bit i of the number of the lane's 16 rows that hold column c) -> the
+// tile's 32 column counters of that word, two u16 per output word: entry e (0..15) = columns e and e + 16
+__device__ __forceinline__ void fuse_flush_word(const uint32_t (&pl)[5], uint32_t *out16, int lane) {
+    uint32_t R[16];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {  // byte b of v counts column 8 b + q (16 at most)
+        uint32_t v = 0;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) v |= ((pl[i] >> q) & 0x01010101u) << i;
+        R[2 * q] = v & 0x00FF00FFu;
+        R[2 * q + 1] = (v >> 8) & 0x00FF00FFu;
+    }
+    // 16 registers x 64 lanes -> one register per group of four lanes: a lane pair exchanges halves of its register file four times
+    // (literal bounds: with the halving written as a loop the compiler indexes R dynamically — a chain of 16 selects per access)
+#define PG_XCHG(HALF, BIT)                                                  \
+    {                                                                       \
+        const bool up = (lane & BIT) != 0;                                  \
+        _Pragma("unroll") for (int i = 0; i < HALF; ++i) {                  \
+            const uint32_t send = up ? R[i] : R[i + HALF];                  \
+            const uint32_t keep = up ? R[i + HALF] : R[i];                  \
+            R[i] = keep + (uint32_t)__shfl_xor((int)send, BIT);             \
+        }                                                                   \
+    }
+    PG_XCHG(8, 32)
+    PG_XCHG(4, 16)
+    PG_XCHG(2, 8)
+    PG_XCHG(1, 4)
+#undef PG_XCHG
+    R[0] += (uint32_t)__shfl_xor((int)R[0], 2);
+    R[0] += (uint32_t)__shfl_xor((int)R[0], 1);
+    if ((lane & 3) == 0) {  // this lane holds register lane >> 2 = 2 q + odd: columns q + 8 odd (low half) and + 16 (high half)
+        const uint32_t idx = (uint32_t)lane >> 2;
+        out16[(idx >> 1) + ((idx & 1u) ? 8u : 0u)] = R[0];
+    }
+}
+// One pass over the tile's rows for NWP (1 or 2) of their words, from byte `woff` of the row on: the lane's 16 rows in four
+// groups of four (two groups' loads in flight), their popcounts added to `pcs` (one byte per row, four rows per register: a row
+// of three or four words takes two passes — the registers of ONE pass of two words are what fits beside the 64 of eight waves per
+// SIMD) and, in the row's LAST pass, counted into the histogram; the words' column sums through the carry-save tree and out.
+template <int NWP, bool LASTPASS>
+__device__ __forceinline__ void tile_statistics_pass(uint32_t *Hc, GlobalBytes rs, uint32_t npos, uint32_t nbytes, uint32_t woff,
+                                                     uint32_t keep_last, uint32_t split, uint32_t N, uint32_t (&pcs)[4], uint32_t *cs_out, int lane) {
+    const uint32_t N1 = N + 1u;
+    uint32_t ones[NWP], twos[NWP], fours[NWP], eights[NWP], sixteens[NWP], hold4[NWP], hold8[NWP];
+#pragma unroll
+    for (int w = 0; w < NWP; ++w) ones[w] = twos[w] = fours[w] = eights[w] = sixteens[w] = hold4[w] = hold8[w] = 0;
+    uint32_t nx[4][NWP];
+    auto request = [&](int g, uint32_t (&dst)[4][NWP]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t r = (uint32_t)(4 * g + i) * 64u + (uint32_t)lane;
+            fuse_load_row<NWP>(rs, min(r, npos - 1u) * nbytes + woff, dst[i]);  // (rows behind the tile's last: that one again, masked out below)
+        }
+    };
+    request(0, nx);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        uint32_t rw[4][NWP];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int w = 0; w < NWP; ++w) rw[i][w] = nx[i][w];
+        if (g < 3) request(g + 1, nx);
+        uint32_t pc4 = pcs[g];  // the four rows' popcounts so far, a byte each
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t r = (uint32_t)(4 * g + i) * 64u + (uint32_t)lane;
+            // (validity and the bin as arithmetic, not as lane masks: sixteen rows' masks alive at once are 32 scalar registers the
+            // wide instantiations do not have)
+            const uint32_t vmask = (uint32_t)((int32_t)(r - npos) >> 31);  // all ones for a row of the tile (r < npos <= 1024)
+            if (LASTPASS) rw[i][NWP - 1] &= keep_last;  // (the row's last word holds bytes of the next row)
+            uint32_t pc = 0;
+#pragma unroll
+            for (int w = 0; w < NWP; ++w) {
+                rw[i][w] &= vmask;
+                pc += (uint32_t)__popc(rw[i][w]);
+            }
+            if (LASTPASS) {
+                pc = min(pc + ((pc4 >> (8 * i)) & 0xFFu), N);  // (junk bits beyond ngenomes: the reference indexes out of bounds there; our rows have none)
+                const uint32_t idx = pc + (N1 & (uint32_t)((int32_t)(split - 1u - r) >> 31));  // + N + 1 for a row of the tile's second bin (r >= split)
+                atomicAdd(&Hc[idx], vmask & 1u);
+            } else {
+                pc4 += pc << (8 * i);  // (at most 64 per pass)
+            }
+        }
+        if (!LASTPASS) pcs[g] = pc4;
+#pragma unroll
+        for (int w = 0; w < NWP; ++w) {  // four rows into the planes: three carry-save adders, the carries of weight 4 and 8 held back in turn
+            uint32_t u = ones[w] ^ rw[0][w];
+            const uint32_t c2a = (ones[w] & rw[0][w]) | (u & rw[1][w]);
+            ones[w] = u ^ rw[1][w];
+            u = ones[w] ^ rw[2][w];
+            const uint32_t c2b = (ones[w] & rw[2][w]) | (u & rw[3][w]);
+            ones[w] = u ^ rw[3][w];
+            u = twos[w] ^ c2a;
+            const uint32_t c4 = (twos[w] & c2a) | (u & c2b);
+            twos[w] = u ^ c2b;
+            if ((g & 1) == 0) {
+                hold4[w] = c4;
+            } else {
+                u = fours[w] ^ hold4[w];
+                const uint32_t c8 = (fours[w] & hold4[w]) | (u & c4);
+                fours[w] = u ^ c4;
+                if (g == 1) {
+                    hold8[w] = c8;
+                } else {
+                    u = eights[w] ^ hold8[w];
+                    sixteens[w] = (eights[w] & hold8[w]) | (u & c8);
+                    eights[w] = u ^ c8;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int w = 0; w < NWP; ++w) {
+        const uint32_t pl[5] = {ones[w], twos[w], fours[w], eights[w], sixteens[w]};
+        fuse_flush_word(pl, cs_out + 16 * w, lane);
+    }
+}
+
+template <int NW>
+__device__ __forceinline__ void tile_statistics(uint32_t *H, const uint8_t *tile_rows, uint32_t npos, uint32_t nbytes, const AnchorDesc &a,
+                                                uint32_t tile_start, uint32_t tile, const FuseArgs &fo, int lane) {
+    const uint32_t N = fo.ngenomes, N1 = N + 1u, hw = fo.hw;
+    const uint32_t nh = 2u * N1;  // histogram counters of a tile: (bin 0 / 1) x (popcount 0..N), four copies of them in LDS
+#ifdef PG_PHASE_TIMING  // (slots 11..15 of the phase counters: wait for the stores, zero + 1-in-100 request, rows (first pass), rows (second pass) + 1-in-100 stores, histogram out)
+    uint32_t tph[5] = {0, 0, 0, 0, 0}, tph_t = (uint32_t)__builtin_readcyclecounter();
+#define PG_TPH(i) { const uint32_t n_ = (uint32_t)__builtin_readcyclecounter(); tph[i] += n_ - tph_t; tph_t = n_; }
+#else
+#define PG_TPH(i)
+#endif
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): every row store of this wave has been acknowledged by the L2
+    __syncthreads();                     // (the probe's LDS buffers are dead from here on)
+    PG_TPH(0)
+    // (the base through readfirstlane: the tile's address is wave-uniform, but the compiler cannot see it)
+    const uint64_t base = reinterpret_cast<uint64_t>(tile_rows);
+    GlobalBytes rs = reinterpret_cast<GlobalBytes>(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(base >> 32)) << 32) |
+                                                   (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base));
+    // bitmap.100: rows whose position in the contig is a multiple of 100 (cpp/anchor.cpp:169-177), eleven at most: requested now,
+    // stored behind the rows' passes (a round trip to the L2 that nothing waits for)
+    const uint32_t r100 = (100u - tile_start % 100u) % 100u + 100u * (uint32_t)lane;
+    const bool want100 = fo.out100 != nullptr && r100 < npos;
+    uint32_t w100[NW];
+    fuse_load_row<NW>(rs, min(r100, npos - 1u) * nbytes, w100);
+    for (uint32_t i = lane; i < 4u * nh; i += 64) H[i] = 0;
+    // rows [0, split) of the tile lie in its first bin, the others in the next one (bins are at least a tile long)
+    const uint64_t bin_end = ((uint64_t)(tile_start / a.binlen) + 1u) * a.binlen;
+    const uint32_t split = (uint32_t)min((uint64_t)npos, bin_end - tile_start);
+    const uint32_t keep = (nbytes & 3u) ? ((1u << (8u * (nbytes & 3u))) - 1u) : ~0u;  // bytes of the row in its last word
+    uint32_t *const Hc = H + ((uint32_t)lane & 3u) * nh;
+    uint32_t *cs_out = fo.tile_cs + (uint64_t)tile * fo.csw;
+    uint32_t pcs[4] = {0, 0, 0, 0};
+    __syncthreads();
+    PG_TPH(1)
+    if constexpr (NW <= 2) {
+        tile_statistics_pass<NW, true>(Hc, rs, npos, nbytes, 0u, keep, split, N, pcs, cs_out, lane);
+        PG_TPH(2)
+    } else {
+        tile_statistics_pass<2, false>(Hc, rs, npos, nbytes, 0u, ~0u, split, N, pcs, cs_out, lane);
+        PG_TPH(2)
+        tile_statistics_pass<NW - 2, true>(Hc, rs, npos, nbytes, 8u, keep, split, N, pcs, cs_out + 32, lane);
+    }
+    if (want100) {
+        uint8_t *dst = fo.out100 + a.out100_off + (uint64_t)((tile_start + r100) / 100u) * nbytes;
+#pragma unroll
+        for (int i = 0; i < NW; ++i)
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                if ((uint32_t)(4 * i + b) < nbytes) dst[4 * i + b] = (uint8_t)(w100[i] >> (8 * b));
+    }
+    __syncthreads();
+    PG_TPH(3)
+    uint32_t *th = fo.tile_hist + (uint64_t)tile * hw;
+    for (uint32_t i = lane; i < hw; i += 64) {  // two counters per word (a tile has 1024 rows: a u16 holds any count)
+        const uint32_t lo = H[2u * i] + H[nh + 2u * i] + H[2u * nh + 2u * i] + H[3u * nh + 2u * i];
+        const uint32_t hi = H[2u * i + 1u] + H[nh + 2u * i + 1u] + H[2u * nh + 2u * i + 1u] + H[3u * nh + 2u * i + 1u];
+        th[i] = lo | (hi << 16);
+    }
+    PG_TPH(4)
+#ifdef PG_PHASE_TIMING
+    if (lane == 0)
+        for (int i = 0; i < 5; ++i) atomicAdd(&pg_phase_cycles[(blockIdx.x & 1023u) * 16u + 11 + i], (unsigned long long)tph[i]);
+#endif
+#undef PG_TPH
+}
+
 // M64: m-mers longer than 16 bases.  WIDE: split layout (SLOTS = 8 then counts the 16-byte chunks of a key line: the
 // staging geometry is the same, a line holds 16 bare keys; m0 / m1 carry the hit's line and slot + 1)
 // (probe_pipelined: the instantiations that run the skewed batch order, see the end of the kernel; they are held to the 64
@@ -860,14 +1090,15 @@ constexpr bool probe_pipelined = PG_PROBE_PIPE && SLOTS == 8 && (ROWMODE != 3) &
 // 96, 6 up to 112 (MI355X_MICROARCH.md) — whatever the compiler's own occupancy figure says.  Left alone the generic-row and
 // split-layout instantiations took 92 and 105 (their lane masks live on the scalar unit): 7 and 6 waves.  Held to 80, a dozen
 // masks move to vector lanes and the ninth to 63rd genome gain 3-6 % (27 x 40 Mb 140 -> 148 G k-mers/s).
-template <int W_C, bool TWO, int ROWMODE, int SLOTS, bool M64, bool WIDE = false, bool INL = false>
-__global__ __launch_bounds__(64, ((probe_pipelined<W_C, TWO, ROWMODE, SLOTS, WIDE, INL> || (INL && PG_INL_WAVES8)) ? 8 : 1))
+// FUSE: the tile ends with its statistics (tile_statistics above; `fo` says where they go)
+template <int W_C, bool TWO, int ROWMODE, int SLOTS, bool M64, bool WIDE = false, bool INL = false, bool FUSE = false>
+__global__ __launch_bounds__(64, ((probe_pipelined<W_C, TWO, ROWMODE, SLOTS, WIDE, INL> || (INL && PG_INL_WAVES8) || FUSE) ? 8 : 1))
 __attribute__((amdgpu_num_sgpr(80))) void k_probe(const SubTable st, const uint64_t *__restrict__ seqw,
                                               const uint32_t *__restrict__ nmw, const uint32_t *__restrict__ has_n,
                                               const SeqDesc *__restrict__ sd, const AnchorDesc *__restrict__ ad,
                                               const uint32_t *__restrict__ tile_contig,
                                               const uint32_t *__restrict__ sched, uint32_t tile_base,
-                                              uint8_t *__restrict__ out1, uint32_t nbytes, const RowCols rc) {
+                                              uint8_t *__restrict__ out1, uint32_t nbytes, const RowCols rc, const FuseArgs fo) {
     // A staged line occupies 16*SLOTS + 16 bytes of LDS: the pad keeps the lanes' ds_read_b128 of
     // "their" lines off a common bank group (a power-of-two stride would be a 32-way conflict)
     constexpr int LDS_LINE_U4 = SLOTS + 1;
@@ -1401,6 +1632,28 @@ __attribute__((amdgpu_num_sgpr(80))) void k_probe(const SubTable st, const uint6
     }
     PG_PH(8)
     PG_PH_FLUSH
+    if constexpr (FUSE) {
+        static_assert(ROWMODE != 1 && ROWMODE != 3 && LDS_BYTES >= 4 * 4 * 2 * 129, "fused statistics: rows of 2..16 bytes; four copies of 2 x 129 histogram counters in LDS");
+        // Everything about the tile is looked up AGAIN (through pointers the compiler cannot identify with the ones the kernel
+        // began with): kept alive across the batch loop these values would cost it scalar registers it does not have.
+        const AnchorDesc *ad2 = ad;
+        const uint32_t *tc2 = tile_contig, *sched2 = sched;
+        asm volatile("" : "+s"(ad2), "+s"(tc2), "+s"(sched2));
+        const uint32_t tile2 = sched2 ? sched2[blockIdx.x + tile_base] : blockIdx.x + tile_base;
+        const AnchorDesc a2 = ad2[tc2[tile2]];
+        if (a2.binlen >= (uint32_t)PROBE_TILE) {  // (wave-uniform) contigs with shorter bins are the statistics pass's (launched over their tiles only)
+            const uint32_t ts2 = (tile2 - a2.tile0) * PROBE_TILE;
+            const uint32_t np2 = min((uint32_t)PROBE_TILE, a2.nkmers - ts2);
+            const uint8_t *rows2 = out1 + a2.out_off + (uint64_t)ts2 * nbytes;
+            uint32_t *H = reinterpret_cast<uint32_t *>(lds);
+            if constexpr (WIDE) {
+                if (nbytes <= 12u) tile_statistics<3>(H, rows2, np2, nbytes, a2, ts2, tile2, fo, lane);
+                else tile_statistics<4>(H, rows2, np2, nbytes, a2, ts2, tile2, fo, lane);
+            } else {
+                tile_statistics<TWO ? 2 : 1>(H, rows2, np2, nbytes, a2, ts2, tile2, fo, lane);
+            }
+        }
+    }
     if constexpr (ROWMODE == 3) {
         // the tile's columns: TILE_SLOTS slots x `width` (= nbytes) genomes, slot-major — what k_cols_extract would have written
         __syncthreads();
@@ -3636,37 +3889,64 @@ __global__ __launch_bounds__(64) void k_lowres(uint32_t N, const AnchorDesc *__r
 template <int W_C, bool TWO, int ROWMODE, int SLOTS>
 static hipError_t probe_t(hipStream_t s, uint32_t ntiles, const SubTable &st, const uint64_t *seqw, const uint32_t *nmw,
                           const uint32_t *has_n, const SeqDesc *sd, const AnchorDesc *ad, const uint32_t *tile_contig,
-                          const uint32_t *sched, uint32_t tile_base, uint8_t *out1, uint32_t nbytes, const RowCols &rc) {
-    if (W_C && st.m > 16)
+                          const uint32_t *sched, uint32_t tile_base, uint8_t *out1, uint32_t nbytes, const RowCols &rc, const FuseArgs *fuse) {
+    const bool m64 = W_C && st.m > 16;
+    if constexpr (SLOTS == 8 && ROWMODE != 1 && ROWMODE != 3) {  // (the fused instantiations: rows of 2..8 bytes, 8-slot lines)
+        if (fuse) {
+            if (m64)
+                hipLaunchKernelGGL((k_probe<W_C, TWO, ROWMODE, SLOTS, true, false, false, true>), dim3(ntiles), dim3(64), 0, s, st, seqw, nmw, has_n, sd, ad,
+                                   tile_contig, sched, tile_base, out1, nbytes, rc, *fuse);
+            else
+                hipLaunchKernelGGL((k_probe<W_C, TWO, ROWMODE, SLOTS, false, false, false, true>), dim3(ntiles), dim3(64), 0, s, st, seqw, nmw, has_n, sd, ad,
+                                   tile_contig, sched, tile_base, out1, nbytes, rc, *fuse);
+            return hipGetLastError();
+        }
+    }
+    if (fuse) return hipErrorInvalidValue;  // (launch_anchor only asks for what is instantiated)
+    const FuseArgs none = {nullptr, nullptr, nullptr, 0, 0, 0};
+    if (m64)
         hipLaunchKernelGGL((k_probe<W_C, TWO, ROWMODE, SLOTS, true>), dim3(ntiles), dim3(64), 0, s, st, seqw, nmw, has_n, sd, ad,
-                           tile_contig, sched, tile_base, out1, nbytes, rc);
+                           tile_contig, sched, tile_base, out1, nbytes, rc, none);
     else
         hipLaunchKernelGGL((k_probe<W_C, TWO, ROWMODE, SLOTS, false>), dim3(ntiles), dim3(64), 0, s, st, seqw, nmw, has_n, sd, ad,
-                           tile_contig, sched, tile_base, out1, nbytes, rc);
+                           tile_contig, sched, tile_base, out1, nbytes, rc, none);
     return hipGetLastError();
 }
 
 template <int W_C>
 static hipError_t probe_w(hipStream_t s, uint32_t ntiles, const SubTable &st, const uint64_t *seqw, const uint32_t *nmw,
                           const uint32_t *has_n, const SeqDesc *sd, const AnchorDesc *ad, const uint32_t *tile_contig,
-                          const uint32_t *sched, uint32_t tile_base, uint8_t *out1, uint32_t nbytes, const RowCols &rc, int rowmode) {
-#define PG_A s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, sched, tile_base, out1, nbytes, rc
-    if (st.layout == LAYOUT_INLINE) {  // 65..128 genomes: keys and their mask blocks in one line
-        if (W_C && st.m > 16)
-            hipLaunchKernelGGL((k_probe<W_C, false, 0, 8, true, true, true>), dim3(ntiles), dim3(64), 0, s, st, seqw, nmw, has_n, sd, ad,
-                               tile_contig, sched, tile_base, out1, nbytes, rc);
-        else
-            hipLaunchKernelGGL((k_probe<W_C, false, 0, 8, false, true, true>), dim3(ntiles), dim3(64), 0, s, st, seqw, nmw, has_n, sd, ad,
-                               tile_contig, sched, tile_base, out1, nbytes, rc);
-        return hipGetLastError();
-    }
-    if (st.layout == LAYOUT_SPLIT) {  // more than 64 genomes: key lines + mask array
-        if (W_C && st.m > 16)
-            hipLaunchKernelGGL((k_probe<W_C, false, 0, 8, true, true>), dim3(ntiles), dim3(64), 0, s, st, seqw, nmw, has_n, sd, ad,
-                               tile_contig, sched, tile_base, out1, nbytes, rc);
-        else
-            hipLaunchKernelGGL((k_probe<W_C, false, 0, 8, false, true>), dim3(ntiles), dim3(64), 0, s, st, seqw, nmw, has_n, sd, ad,
-                               tile_contig, sched, tile_base, out1, nbytes, rc);
+                          const uint32_t *sched, uint32_t tile_base, uint8_t *out1, uint32_t nbytes, const RowCols &rc, int rowmode,
+                          const FuseArgs *fuse = nullptr) {
+#define PG_A s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, sched, tile_base, out1, nbytes, rc, fuse
+#define PG_K s, st, seqw, nmw, has_n, sd, ad, tile_contig, sched, tile_base, out1, nbytes, rc
+    const FuseArgs none = {nullptr, nullptr, nullptr, 0, 0, 0};
+    const bool m64 = W_C && st.m > 16;
+    if (st.layout == LAYOUT_INLINE || st.layout == LAYOUT_SPLIT) {
+        // more than 64 genomes: keys and their mask blocks in one line (inline, 65..96 genomes), or key lines + mask array (split)
+        const bool inl = st.layout == LAYOUT_INLINE;
+        if (fuse && (nbytes > 16u || !PG_FUSE_WIDE)) return hipErrorInvalidValue;
+        if (inl) {
+            if (fuse) {
+#if PG_FUSE_WIDE
+                if (m64) hipLaunchKernelGGL((k_probe<W_C, false, 0, 8, true, true, true, true>), dim3(ntiles), dim3(64), 0, PG_K, *fuse);
+                else hipLaunchKernelGGL((k_probe<W_C, false, 0, 8, false, true, true, true>), dim3(ntiles), dim3(64), 0, PG_K, *fuse);
+#endif
+            } else {
+                if (m64) hipLaunchKernelGGL((k_probe<W_C, false, 0, 8, true, true, true>), dim3(ntiles), dim3(64), 0, PG_K, none);
+                else hipLaunchKernelGGL((k_probe<W_C, false, 0, 8, false, true, true>), dim3(ntiles), dim3(64), 0, PG_K, none);
+            }
+        } else {
+            if (fuse) {
+#if PG_FUSE_WIDE
+                if (m64) hipLaunchKernelGGL((k_probe<W_C, false, 0, 8, true, true, false, true>), dim3(ntiles), dim3(64), 0, PG_K, *fuse);
+                else hipLaunchKernelGGL((k_probe<W_C, false, 0, 8, false, true, false, true>), dim3(ntiles), dim3(64), 0, PG_K, *fuse);
+#endif
+            } else {
+                if (m64) hipLaunchKernelGGL((k_probe<W_C, false, 0, 8, true, true>), dim3(ntiles), dim3(64), 0, PG_K, none);
+                else hipLaunchKernelGGL((k_probe<W_C, false, 0, 8, false, true>), dim3(ntiles), dim3(64), 0, PG_K, none);
+            }
+        }
         return hipGetLastError();
     }
     if (st.slots == 16) {
@@ -3688,6 +3968,7 @@ static hipError_t probe_w(hipStream_t s, uint32_t ntiles, const SubTable &st, co
     if (rowmode == 6) return probe_t<W_C, false, 6, 8>(PG_A);
     return probe_t<W_C, false, 0, 8>(PG_A);
 #undef PG_A
+#undef PG_K
 }
 
 static int row_mode(uint32_t nbytes, const RowCols &rc) {
@@ -3704,11 +3985,15 @@ static int row_mode(uint32_t nbytes, const RowCols &rc) {
 hipError_t launch_anchor(hipStream_t s, const TableDesc &T, const uint64_t *seqw, const uint32_t *nmw,
                          const uint32_t *has_n, const SeqDesc *sd, const AnchorDesc *ad, const uint32_t *tile_contig,
                          const uint32_t *sched, uint32_t tile_base, uint32_t ntiles, uint8_t *out1, uint64_t out1_bytes,
-                         uint32_t columns_width) {
+                         uint32_t columns_width, const FuseArgs *fuse) {
     if (ntiles == 0) return hipSuccess;
     const uint32_t nbytes = (T.ngenomes + 7) / 8;
     hipError_t e = hipSuccess;
     (void)out1_bytes;
+    // fused statistics: one sub-table writes whole rows of 2..16 bytes, 8-slot / inline / split lines (pg_api.hip asks only then)
+    if (fuse && (columns_width || T.nsub != 1 || !fuse_rows_ok(nbytes) || fuse->ngenomes != T.ngenomes ||
+                 (T.sub[0].layout == LAYOUT_SLOTS && T.sub[0].slots != 8)))
+        return hipErrorInvalidValue;
     if (columns_width) {
         const SubTable &st = T.sub[0];
         if (T.nsub != 1 || st.layout != LAYOUT_SLOTS || st.W != 1 || st.slots != 8 || T.ngenomes > (uint32_t)COLS_G ||
@@ -3741,13 +4026,13 @@ hipError_t launch_anchor(hipStream_t s, const TableDesc &T, const uint64_t *seqw
         const int rm = (T.nsub == 1) ? row_mode(nbytes, rc) : 0;
         const uint32_t w = st.m ? st.k - st.m + 1 : 0;
         switch (w) {  // the kernel's compile-time window must be the one the table was built with
-            case 0: e = probe_w<0>(s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, sched, tile_base, out1, nbytes, rc, rm); break;
-            case 3: e = probe_w<3>(s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, sched, tile_base, out1, nbytes, rc, rm); break;
-            case 4: e = probe_w<4>(s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, sched, tile_base, out1, nbytes, rc, rm); break;
-            case 5: e = probe_w<5>(s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, sched, tile_base, out1, nbytes, rc, rm); break;
-            case 6: e = probe_w<6>(s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, sched, tile_base, out1, nbytes, rc, rm); break;
-            case 7: e = probe_w<7>(s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, sched, tile_base, out1, nbytes, rc, rm); break;
-            case 8: e = probe_w<8>(s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, sched, tile_base, out1, nbytes, rc, rm); break;
+            case 0: e = probe_w<0>(s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, sched, tile_base, out1, nbytes, rc, rm, fuse); break;
+            case 3: e = probe_w<3>(s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, sched, tile_base, out1, nbytes, rc, rm, fuse); break;
+            case 4: e = probe_w<4>(s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, sched, tile_base, out1, nbytes, rc, rm, fuse); break;
+            case 5: e = probe_w<5>(s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, sched, tile_base, out1, nbytes, rc, rm, fuse); break;
+            case 6: e = probe_w<6>(s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, sched, tile_base, out1, nbytes, rc, rm, fuse); break;
+            case 7: e = probe_w<7>(s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, sched, tile_base, out1, nbytes, rc, rm, fuse); break;
+            case 8: e = probe_w<8>(s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, sched, tile_base, out1, nbytes, rc, rm, fuse); break;
             default: return hipErrorInvalidValue;
         }
         if (e != hipSuccess) return e;
@@ -3850,6 +4135,78 @@ hipError_t launch_rows_epilogue(hipStream_t st, uint32_t ngenomes, const AnchorD
         hipLaunchKernelGGL(kern, dim3(grid), dim3(EPI_THREADS), lds_c, st, ngenomes, ad, tile_contig, ntiles, out1, out100, bins,
                            colsums, flags, d_ranges, wpr);
     }
+    return hipGetLastError();
+}
+
+// The tiles' counters of a fused launch (FuseArgs) into the bins and the per-contig column sums.  A workgroup takes TR_TILES
+// consecutive tiles; a thread owns an item — a histogram field (bin 0 / 1 of the tile, popcount) or a genome's column — adds its
+// values up while the item's destination (the bin's row, the contig's row) stays the same, and flushes one atomic add when it
+// changes: a bin of 200 000 rows is 195 tiles long.  Tiles of contigs whose bins are shorter than a tile carry no counters (the
+// statistics pass did them).  Reads (4 (N + 1) + 64 ceil(nbytes / 4)) bytes per tile where the pass read 1024 rows.
+constexpr uint32_t TR_TILES = 32;
+__global__ __launch_bounds__(256) void k_tile_reduce(const FuseArgs fo, const AnchorDesc *__restrict__ ad, const uint32_t *__restrict__ tile_contig,
+                                                     uint32_t ntiles, uint32_t *__restrict__ bins, unsigned long long *__restrict__ colsums,
+                                                     uint32_t want_cs) {
+    const uint32_t N = fo.ngenomes, N1 = N + 1u;
+    const uint32_t nitems = 2u * N1 + (want_cs ? N : 0u);
+    // a workgroup = as many groups of TR_TILES tiles as its threads hold items for (N = 12: 38 items, 6 groups per 256 threads)
+    const uint32_t per = max(1u, blockDim.x / nitems), slot = threadIdx.x / nitems;
+    const uint32_t it0 = nitems <= blockDim.x ? threadIdx.x - slot * nitems : threadIdx.x;
+    const uint32_t grp = blockIdx.x * per + (nitems <= blockDim.x ? slot : 0u);
+    if (nitems <= blockDim.x && slot >= per) return;
+    const uint32_t t0 = grp * TR_TILES;
+    if (t0 >= ntiles) return;
+    const uint32_t t1 = min(ntiles, t0 + TR_TILES);
+    for (uint32_t it = it0; it < nitems; it += blockDim.x) {
+        const bool is_hist = it < 2u * N1;
+        const uint32_t rel = is_hist ? it / N1 : 0u, pc = it - rel * N1, g = it - 2u * N1;
+        // where the item's u16 sits in a tile's counters
+        const uint32_t word = is_hist ? (it >> 1) : (g >> 5) * 16u + (g & 15u), shift = is_hist ? 16u * (it & 1u) : ((g & 16u) ? 16u : 0u);
+        const uint32_t *src = (is_hist ? fo.tile_hist : fo.tile_cs) + word;
+        const uint32_t stride = is_hist ? fo.hw : fo.csw;
+        uint32_t v[TR_TILES];  // (every tile's word requested at once: the walk below is serial)
+#pragma unroll
+        for (uint32_t j = 0; j < TR_TILES; ++j) v[j] = src[(uint64_t)min(t0 + j, t1 - 1u) * stride];
+        unsigned long long acc = 0, key = ~0ull;
+        uint32_t cur_c = ~0u;
+        AnchorDesc a;
+        a.binlen = 0, a.tile0 = 0, a.bin_off = 0;
+        auto flush = [&]() {
+            if (acc) {
+                if (is_hist) atomicAdd(&bins[key], (uint32_t)acc);
+                else atomicAdd(&colsums[key], acc);
+            }
+            acc = 0;
+        };
+#pragma unroll
+        for (uint32_t j = 0; j < TR_TILES; ++j) {
+            const uint32_t t = t0 + j;
+            if (t >= t1) break;
+            const uint32_t c = tile_contig[t];
+            if (c != cur_c) {
+                cur_c = c;
+                a = ad[c];
+            }
+            if (a.binlen < (uint32_t)PROBE_TILE) continue;  // (not fused: its counters were never written)
+            const unsigned long long k2 = is_hist ? (a.bin_off + (uint64_t)(t - a.tile0) * PROBE_TILE / a.binlen + rel) * N1 + pc
+                                                  : (unsigned long long)c * N + g;
+            if (k2 != key) {
+                flush();
+                key = k2;
+            }
+            acc += (v[j] >> shift) & 0xFFFFu;
+        }
+        flush();
+    }
+}
+
+hipError_t launch_tile_reduce(hipStream_t st, const FuseArgs &fo, const AnchorDesc *ad, const uint32_t *tile_contig, uint32_t ntiles,
+                              uint32_t *bins, unsigned long long *colsums, uint32_t want_colsums) {
+    if (ntiles == 0) return hipSuccess;
+    const uint32_t nitems = 2u * (fo.ngenomes + 1u) + (want_colsums ? fo.ngenomes : 0u);
+    const uint32_t per = std::max(1u, 256u / nitems), groups = (ntiles + TR_TILES - 1) / TR_TILES;
+    hipLaunchKernelGGL(k_tile_reduce, dim3((groups + per - 1) / per), dim3(256), 0, st, fo, ad, tile_contig, ntiles, bins, colsums,
+                       want_colsums);
     return hipGetLastError();
 }
 

@@ -99,6 +99,7 @@ struct pg_table {
     bool m_pinned = false;  // set by pg_table_set_minimizer: re-hashing keeps m
     uint32_t cosched = 0;   // anchor genomes a probe launch will co-schedule (pg_table_set_coscheduled; 0: not told — several)
     uint64_t expected = 0;  // pg_table_create's expected_keys (0: unknown)
+    double load0 = 0.375;   // keys per slot the table was created for (TARGET_LOAD; PG_TABLE_KEYS_PER_LINE / pg_table_create_dense: denser)
     uint64_t first_len = 0;  // k-mer positions of the first sequence set inserted into the empty table (settle_minimizer)
     uint64_t max_len = 0;    // ... of the longest one inserted so far (what a re-hash settles m from)
     std::vector<SubHost> subs;
@@ -182,6 +183,13 @@ struct pg_result {
     size_t hist_skip = 0;  // leading sets of ev_hist from before the last pg_result_timing_reset
     double probe_ms_sum = 0, epi_ms_sum = 0;
     uint32_t probe_runs = 0, epi_runs = 0;
+    // Fused statistics (round 6, pg_kernels.h: FuseArgs): k_probe leaves per-tile counters, k_tile_reduce adds them up; the
+    // statistics pass then only runs over the tiles of contigs whose bins are shorter than a tile (d_small: their ranges).
+    int fuse_state = 0;  // 0: not decided yet, 1: this result's whole runs are fused, -1: they are not (row width, layout, memory)
+    uint32_t *d_tile_hist = nullptr, *d_tile_cs = nullptr;
+    uint2 *d_small = nullptr;
+    uint32_t n_small = 0, small_tiles = 0;
+    uint32_t fused_runs = 0;  // whole runs that took the fused path (pg_result_fused_runs: tests and bench.py say which path was timed)
 };
 static constexpr size_t EV_RING = 128;
 
@@ -470,13 +478,23 @@ static TableGeom geom_for(int ngenomes) {
     return {ndbs, SPLIT_KEYS, LAYOUT_SPLIT};
 }
 
+// keys per slot a table is created for: TARGET_LOAD, or PG_TABLE_KEYS_PER_LINE / 8 when the caller knows its key count
+static double create_load(uint64_t expected_keys, double keys_per_line = 0.0) {
+    if (keys_per_line >= 1.0 && keys_per_line <= 6.4 && expected_keys) return keys_per_line / 8.0;
+    if (const char *e = getenv("PG_TABLE_KEYS_PER_LINE")) {
+        const double kpl = atof(e);
+        if (kpl >= 1.0 && kpl <= 6.4 && expected_keys) return kpl / 8.0;
+    }
+    return TARGET_LOAD;
+}
+
 extern "C" int pg_table_bytes_for(int k, int ngenomes, uint64_t expected_keys, uint64_t *bytes) {
     PG_API_BEGIN
     if (!bytes) return fail(PG_E_INVALID, "pg_table_bytes_for: NULL argument");
     if (k < 1 || k > 32 || ngenomes < 1) return fail(PG_E_INVALID, "pg_table_bytes_for: bad k / ngenomes");
     const TableGeom g = geom_for(ngenomes);
     // (an estimate: one prime search less — the line count itself, not the next prime above it)
-    const uint64_t nb = std::max<uint64_t>((uint64_t)((double)std::max<uint64_t>(expected_keys, 1ull << 18) / (TARGET_LOAD * g.slots)) + 1, 64);
+    const uint64_t nb = std::max<uint64_t>((uint64_t)((double)std::max<uint64_t>(expected_keys, 1ull << 18) / (create_load(expected_keys) * g.slots)) + 1, 64);
     *bytes = g.layout == LAYOUT_SPLIT ? nb * g.slots * (8ull + 4ull * g.W) : g.layout == LAYOUT_INLINE ? nb * 128ull : nb * 16ull * g.slots;
     return PG_OK;
     PG_API_END
@@ -484,7 +502,30 @@ extern "C" int pg_table_bytes_for(int k, int ngenomes, uint64_t expected_keys, u
 
 static uint32_t window_cap(int ngenomes = 0);  // (PG_TABLE_WMAX, below)
 
+static int table_create(pg_ctx *ctx, int k, int ngenomes, uint64_t expected_keys, double keys_per_line, pg_table **out);
 extern "C" int pg_table_create(pg_ctx *ctx, int k, int ngenomes, uint64_t expected_keys, pg_table **out) {
+    PG_API_BEGIN
+    return table_create(ctx, k, ngenomes, expected_keys, 0.0, out);
+    PG_API_END
+}
+extern "C" int pg_table_create_dense(pg_ctx *ctx, int k, int ngenomes, uint64_t expected_keys, double keys_per_line, pg_table **out) {
+    PG_API_BEGIN
+    if (!(keys_per_line >= 1.0 && keys_per_line <= 6.4)) return fail(PG_E_INVALID, "pg_table_create_dense: keys_per_line must be in 1 .. 6.4 (of 8 slots), got %g", keys_per_line);
+    if (!expected_keys) return fail(PG_E_INVALID, "pg_table_create_dense: expected_keys must be known");
+    if (ngenomes > 64) return fail(PG_E_INVALID, "pg_table_create_dense: tables of 8-slot lines only (up to 64 genomes)");
+    return table_create(ctx, k, ngenomes, expected_keys, keys_per_line, out);
+    PG_API_END
+}
+extern "C" int pg_table_bytes_for_dense(int k, int ngenomes, uint64_t expected_keys, double keys_per_line, uint64_t *bytes) {
+    PG_API_BEGIN
+    if (!bytes) return fail(PG_E_INVALID, "pg_table_bytes_for_dense: NULL argument");
+    if (k < 1 || k > 32 || ngenomes < 1 || ngenomes > 64 || !(keys_per_line >= 1.0 && keys_per_line <= 6.4)) return fail(PG_E_INVALID, "pg_table_bytes_for_dense: bad argument");
+    const uint64_t nb = std::max<uint64_t>((uint64_t)((double)std::max<uint64_t>(expected_keys, 1ull << 18) / keys_per_line) + 1, 64);
+    *bytes = nb * 128ull;
+    return PG_OK;
+    PG_API_END
+}
+static int table_create(pg_ctx *ctx, int k, int ngenomes, uint64_t expected_keys, double keys_per_line, pg_table **out) {
     PG_API_BEGIN
     if (!ctx || !out) return fail(PG_E_INVALID, "pg_table_create: NULL argument");
     if (k < 1 || k > 32) return fail(PG_E_INVALID, "k=%d unsupported (1..32)", k);
@@ -515,8 +556,12 @@ extern "C" int pg_table_create(pg_ctx *ctx, int k, int ngenomes, uint64_t expect
     {
         const TableGeom g = geom_for(ngenomes);
         const uint64_t want = expected_keys ? expected_keys : (1ull << 18);
+        // keys per line the table is created for: 3 of 8 slots (TARGET_LOAD) unless PG_TABLE_KEYS_PER_LINE says otherwise (a
+        // tuning knob, 1..6.4 keys per 8 slots; the genome-sharded planner's block tables: distributed.py)
+        const double load = create_load(expected_keys, keys_per_line);
+        t->load0 = load;
         // (pg_table_rehash may widen the lines of the slots layout when the keys call for it)
-        const uint64_t nb = (uint64_t)((double)want / (TARGET_LOAD * g.slots)) + 1;
+        const uint64_t nb = (uint64_t)((double)want / (load * g.slots)) + 1;
         SubHost sh;
         sh.count = 0;
         int r = alloc_sub(ctx, g.W, 0, (uint32_t)k, t->m, g.slots, nb, g.layout, &sh.d);
@@ -724,7 +769,8 @@ static int grow_after_overflow(pg_table *t, int si, uint64_t incoming) {
 static int after_insert(pg_table *t, int si) {
     SubHost &s = t->subs[si];
     const int ns = (int)s.d.slots;
-    if ((double)s.count > GROW_AT * (double)s.d.nbuckets * ns) {
+    // (a table created denser on purpose — the genome-sharded mode's block tables: fewer passes — is not grown back to 3 keys per line)
+    if ((double)s.count > std::max(GROW_AT, t->load0 + 0.1) * (double)s.d.nbuckets * ns) {
         uint64_t nb = (uint64_t)((double)s.count / (TARGET_LOAD * ns)) + 1;
         return regrow(t, si, nb);
     }
@@ -1996,6 +2042,9 @@ extern "C" int pg_result_destroy(pg_result *r) {
     hipFree(r->d_colsums);
     if (r->d_sched) hipFree(r->d_sched);
     if (r->d_ranges) hipFree(r->d_ranges);
+    if (r->d_tile_hist) hipFree(r->d_tile_hist);
+    if (r->d_tile_cs) hipFree(r->d_tile_cs);
+    if (r->d_small) hipFree(r->d_small);
     for (auto e : r->chunk_ev) hipEventDestroy(e);
     for (auto *v : {&r->ev_hist, &r->ev_free})
         for (auto &s : *v)
@@ -2204,6 +2253,79 @@ static int enqueue_epilogue(pg_result *r, hipStream_t st) {
     return PG_OK;
 }
 
+// ---- fused statistics: does this result qualify, and its buffers ----
+// OFF unless PG_FUSE_STATS=1: measured (profiles/r6f_ab_fuse.txt, r6e_phase_fused.txt) the tile's end costs k_probe more than
+// the statistics pass it replaces — rows of 2 / 4 / 8 bytes: step 3.47 -> 3.70, 5.73 -> 5.97, 9.0 -> 9.56 ms — because every
+// instruction of it is issued in the one kernel that is short of issue slots, while the pass runs the same arithmetic in the
+// shadow of its HBM stream.  Read at every run, so that one process can time both.
+static bool fuse_enabled() {
+    const char *e = getenv("PG_FUSE_STATS");
+    return e && *e == '1';
+}
+static bool fuse_table_ok(const TableDesc &T, uint32_t N) {
+    return T.nsub == 1 && T.ngenomes == N && !(T.sub[0].layout == LAYOUT_SLOTS && T.sub[0].slots != 8);
+}
+static int prepare_fuse(pg_result *r, const TableDesc &T) {
+    if (r->fuse_state) return PG_OK;
+    r->fuse_state = -1;
+    const uint32_t nbytes = (r->N + 7) / 8;
+    // rows of 2..16 bytes written whole by ONE sub-table of 128-byte lines (one-byte rows: k_probe is bound by instruction issue
+    // there and their bit-sliced pass costs 8 % of the step; rows beyond 16 bytes: k_epilogue_chunks)
+    if (!fuse_rows_ok(nbytes) || !fuse_table_ok(T, r->N)) return PG_OK;
+    std::vector<uint2> small;  // tile ranges of the contigs whose bins are shorter than a tile: the statistics pass's
+    uint64_t small_tiles = 0, fused_tiles = 0;
+    for (const AnchorDesc &a : r->ad) {
+        const uint32_t nt = (uint32_t)(((uint64_t)a.nkmers + PROBE_TILE - 1) / PROBE_TILE);
+        if (!nt) continue;
+        if (a.binlen >= (uint32_t)PROBE_TILE) {
+            fused_tiles += nt;
+            continue;
+        }
+        small_tiles += nt;
+        if (!small.empty() && small.back().y == a.tile0) small.back().y = a.tile0 + nt;
+        else small.push_back(make_uint2(a.tile0, a.tile0 + nt));
+    }
+    if (!fused_tiles || small.size() > 16384) return PG_OK;  // (thousands of separate short-bin stretches: one pass over everything is simpler)
+    const size_t hb = (size_t)r->ntiles * fuse_hist_words(r->N) * 4, cb = (size_t)r->ntiles * fuse_cs_words(r->N) * 4;
+    if (hipMalloc(reinterpret_cast<void **>(&r->d_tile_hist), hb) != hipSuccess || hipMalloc(reinterpret_cast<void **>(&r->d_tile_cs), cb) != hipSuccess ||
+        (!small.empty() && hipMalloc(reinterpret_cast<void **>(&r->d_small), small.size() * sizeof(uint2)) != hipSuccess)) {
+        (void)hipGetLastError();  // no room for the tiles' counters (0.4-6 % of the rows): the unfused path needs none
+        if (r->d_tile_hist) hipFree(r->d_tile_hist);
+        if (r->d_tile_cs) hipFree(r->d_tile_cs);
+        r->d_tile_hist = r->d_tile_cs = nullptr;
+        return PG_OK;
+    }
+    if (!small.empty()) HIP_TRY(hipMemcpy(r->d_small, small.data(), small.size() * sizeof(uint2), hipMemcpyHostToDevice));
+    r->n_small = (uint32_t)small.size();
+    r->small_tiles = (uint32_t)small_tiles;
+    r->fuse_state = 1;
+    return PG_OK;
+}
+static FuseArgs fuse_args(const pg_result *r) {
+    FuseArgs fa;
+    fa.out100 = r->lowres_step == 100 ? r->d_out100 : nullptr;  // (any other step: k_lowres)
+    fa.tile_hist = r->d_tile_hist;
+    fa.tile_cs = r->d_tile_cs;
+    fa.ngenomes = r->N;
+    fa.hw = fuse_hist_words(r->N);
+    fa.csw = fuse_cs_words(r->N);
+    return fa;
+}
+// what is left of the statistics after a fused probe: the tiles' counters added up, the short-bin contigs' rows through the pass
+static int enqueue_fused_epilogue(pg_result *r, hipStream_t st, const FuseArgs &fa) {
+    const uint32_t N = r->N;
+    HIP_TRY(hipMemsetAsync(r->d_bins, 0, std::max<uint64_t>(1, r->total_bins) * (N + 1) * 4, st));
+    HIP_TRY(hipMemsetAsync(r->d_colsums, 0, std::max<size_t>(1, r->ad.size()) * N * 8, st));
+    HIP_TRY(launch_tile_reduce(st, fa, r->d_ad, r->d_tile_contig, r->ntiles, r->d_bins, r->d_colsums, (r->flags & PG_ANCHOR_COLSUMS) ? 1u : 0u));
+    const uint32_t kflags = (r->flags & PG_ANCHOR_COLSUMS) | (r->lowres_step == 100 ? 0u : 2u);
+    if (r->n_small)
+        HIP_TRY(launch_rows_epilogue(st, N, r->d_ad, r->d_tile_contig, r->ntiles, r->d_out1, r->d_out100, r->d_bins, r->d_colsums, kflags,
+                                     r->d_small, r->n_small, r->small_tiles));
+    if (r->lowres_step != 100)
+        HIP_TRY(launch_lowres(st, N, r->d_ad, r->d_tile_contig, r->ntiles, r->d_out1, r->d_out100, r->lowres_step));
+    return PG_OK;
+}
+
 // make the context's main stream wait for the result's statistics (side stream)
 static int join_result(pg_result *r) {
     if (r->ev_epi) HIP_TRY(hipStreamWaitEvent(r->ctx->stream, r->ev[3], 0));
@@ -2315,24 +2437,34 @@ static int anchor_run(pg_result *r, uint32_t tile_base, uint32_t ntiles, bool wh
     if (int e = join_result(r)) return e;  // a previous run's statistics still read the rows we overwrite
     if (int e = next_events(r, true)) return e;
     TableDesc T = make_desc(t);
-    if (whole && !columns_width && !(r->flags & PG_ANCHOR_ROWS_ONLY)) {
+    const bool stats = whole && !columns_width && !(r->flags & PG_ANCHOR_ROWS_ONLY);
+    bool fuse = false;  // the tiles' statistics inside k_probe (round 6): a whole run of a result that qualifies
+    if (stats && fuse_enabled()) {
+        if (int e = prepare_fuse(r, T)) return e;
+        fuse = r->fuse_state == 1 && fuse_table_ok(T, r->N);  // (the table may have been re-hashed into other lines since)
+    }
+    if (stats && !fuse) {
         if (!r->chunks_ready)
             if (int e = build_chunks(r, nullptr)) return e;
         if (r->chunks.size() > 1) return run_chunks(r, T);
     }
+    const FuseArgs fa = fuse_args(r);
     HIP_TRY(hipEventRecord(r->ev[0], st));
     HIP_TRY(launch_anchor(st, T, r->seqs->d_seqw, r->seqs->d_nmw, r->seqs->d_has_n, r->seqs->d_desc, r->d_ad,
                           r->d_tile_contig, sched_covers(r, tile_base, ntiles) ? r->d_sched : nullptr, tile_base, ntiles,
-                          columns_width ? static_cast<uint8_t *>(d_columns) : r->d_out1, r->out1_bytes, columns_width));
+                          columns_width ? static_cast<uint8_t *>(d_columns) : r->d_out1, r->out1_bytes, columns_width, fuse ? &fa : nullptr));
     HIP_TRY(hipEventRecord(r->ev[1], st));
     r->ev_ok = true;
     r->ev_epi = false;
-    if (whole && !(r->flags & PG_ANCHOR_ROWS_ONLY)) {
+    if (stats) {
         // the streaming statistics pass runs on the side stream, ordered behind the probe kernels by
         // an event, so that it overlaps the next result's probe kernels
         HIP_TRY(hipStreamWaitEvent(aux, r->ev[1], 0));
         HIP_TRY(hipEventRecord(r->ev[2], aux));
-        if (int e = enqueue_epilogue(r, aux)) return e;
+        if (fuse) {
+            if (int e = enqueue_fused_epilogue(r, aux, fa)) return e;
+            ++r->fused_runs;
+        } else if (int e = enqueue_epilogue(r, aux)) return e;
         HIP_TRY(hipEventRecord(r->ev[3], aux));
         r->ev_epi = true;
         r->ev_hist.back().epi = true;
@@ -2390,6 +2522,14 @@ extern "C" int pg_result_timing(pg_result *r, float *probe_ms, float *epilogue_m
     if (r->ev_epi) HIP_TRY(hipEventElapsedTime(&b, r->ev[2], r->ev[3]));
     if (probe_ms) *probe_ms = a;
     if (epilogue_ms) *epilogue_ms = b;
+    return PG_OK;
+    PG_API_END
+}
+
+extern "C" int pg_result_fused_runs(const pg_result *r, uint32_t *n) {
+    PG_API_BEGIN
+    if (!r || !n) return fail(PG_E_INVALID, "pg_result_fused_runs: NULL argument");
+    *n = r->fused_runs;
     return PG_OK;
     PG_API_END
 }

@@ -111,10 +111,38 @@ hipError_t launch_export(hipStream_t st, const SubTable &t, int w, uint64_t *key
                          uint64_t cap, unsigned long long *count);
 hipError_t launch_counters(hipStream_t st, const SubTable &t, int w, int k, const uint64_t *seqw,
                            const uint32_t *nmw, const uint32_t *has_n, uint64_t nkmers, uint32_t *out);
+// Fused statistics (round 6): a k_probe launch that is handed these buffers ends every tile of a contig whose bins are at least
+// a tile long (AnchorDesc::binlen >= PROBE_TILE: a tile then touches at most two bins) by reading its finished rows back —
+// while they are still in the L2 / Infinity Cache, not from HBM — and leaves, per tile:
+//   tile_hist[tile][hw]   hw = N + 1 words = 2 (N + 1) u16 counters: (bin of the row relative to the tile's first: 0 / 1) x (popcount 0..N)
+//   tile_cs[tile][csw]    csw = 16 * ceil(nbytes / 4) words: word 16 w + e = rows of the tile holding genome 32 w + e (low half) and
+//                         genome 32 w + e + 16 (high half)
+// and the tile's 1-in-100 rows in out100 (NULL: another step, k_lowres copies them).  k_tile_reduce sums the tiles' counters into
+// the bins and the per-contig column sums: the statistics pass's re-read of every row from HBM (k_epilogue*) is gone.  Contigs
+// with shorter bins are left to that pass, launched over their tile ranges only.  Replaces the popcount / histogram / 1-in-100
+// part of the reference's scatter loop (cpp/anchor.cpp:156-183) and the column sums of index.py:1051.
+struct FuseArgs {
+    uint8_t *out100;
+    uint32_t *tile_hist;
+    uint32_t *tile_cs;
+    uint32_t ngenomes, hw, csw;
+};
+constexpr uint32_t fuse_hist_words(uint32_t ngenomes) { return ngenomes + 1u; }
+constexpr uint32_t fuse_cs_words(uint32_t ngenomes) { return 16u * ((((ngenomes + 7u) / 8u) + 3u) / 4u); }
+// rows the fused instantiations exist for: 2..8 bytes; 9..16 bytes (the inline and split layouts) only in a -DPG_FUSE_WIDE=1
+// build — held to the 64 vector and 80 scalar registers of eight waves per SIMD their tile end spills, and the probe of 65 /
+// 128 genomes takes 11.0 / 20.7 ms instead of 4.4 / 11.4 (profiles/r6f_ab_fuse.txt).  One-byte rows keep their bit-sliced pass.
+#ifndef PG_FUSE_WIDE
+#define PG_FUSE_WIDE 0
+#endif
+constexpr bool fuse_rows_ok(uint32_t nbytes) { return nbytes >= 2u && nbytes <= (PG_FUSE_WIDE ? 16u : 8u); }
 hipError_t launch_anchor(hipStream_t st, const TableDesc &T, const uint64_t *seqw, const uint32_t *nmw,
                          const uint32_t *has_n, const SeqDesc *sd, const AnchorDesc *ad,
                          const uint32_t *tile_contig, const uint32_t *sched, uint32_t tile_base, uint32_t ntiles, uint8_t *out1,
-                         uint64_t out1_bytes, uint32_t columns_width = 0);
+                         uint64_t out1_bytes, uint32_t columns_width = 0, const FuseArgs *fuse = nullptr);
+// the tiles' counters (FuseArgs) of tiles [0, ntiles) into bins / colsums (atomic adds: both zeroed by the caller)
+hipError_t launch_tile_reduce(hipStream_t st, const FuseArgs &fo, const AnchorDesc *ad, const uint32_t *tile_contig, uint32_t ntiles,
+                              uint32_t *bins, unsigned long long *colsums, uint32_t want_colsums);
 // genome-sharded exchange over the tiles [tile_base, tile_base + ntiles) of a result (a contig range)
 hipError_t launch_cols_extract(hipStream_t st, uint32_t ngenomes, const AnchorDesc *ad, const uint32_t *tile_contig,
                                uint32_t tile_base, uint32_t ntiles, const uint8_t *out1, uint32_t g0, uint32_t width, void *dst);

@@ -1229,8 +1229,11 @@ def run_genome_sharded(index, nblocks: int, group=None, exchange_stats: Optional
     blocks = {b: [inputs[g] for g in range(b * per, min(N, (b + 1) * per)) if g in inputs] for b in my_blocks}
     tbl_mem = None
     if my_blocks:
+        # (denser than the library's 3 keys per line when the planner chose fewer, wider blocks: Index.plan_sharding)
+        kpl = float(getattr(index, "_block_keys_per_line", 0.0) or 0.0)
         tbl_mem = engine.PanTable(ctx, k, per, expected_keys=max(index._expected_keys(blk) for blk in blocks.values()),
-                                  coscheduled=max(1, len(anchors)))  # (a chunk group co-schedules every anchor's chunk)
+                                  coscheduled=max(1, len(anchors)),  # (a chunk group co-schedules every anchor's chunk)
+                                  **({"keys_per_line": kpl} if kpl else {}))
     in_flight = 2 * index.writer_jobs(payload)  # anchors whose full-width rows wait for their writer: bounded
 
     def finished(a, res):

@@ -348,17 +348,21 @@ class KmerSketch:
 class PanTable(_Owner):
     """GPU-resident k-mer -> genome-mask table (replaces kmc/bitvec{i})."""
 
-    def __init__(self, ctx: Context, k: int, ngenomes: int, expected_keys: int = 0, coscheduled: int = 0):
+    def __init__(self, ctx: Context, k: int, ngenomes: int, expected_keys: int = 0, coscheduled: int = 0, keys_per_line: float = 0.0):
         """``coscheduled``: how many anchor genomes one probe launch will anchor side by side against this table (0: not
         known = several; 1: one genome per launch, no co-scheduling partner) — it decides the minimizer window with the
-        key count (pg_table_set_coscheduled, include/panagram_hip.h)"""
+        key count (pg_table_set_coscheduled, include/panagram_hip.h).  ``keys_per_line`` (0: the library's 3): a denser
+        table for a known ``expected_keys`` — pg_table_create_dense: the genome-sharded mode's block tables"""
         self.ctx = ctx
         self._lib = ctx._lib
         self.k, self.ngenomes = k, ngenomes
         self.nbytes = (ngenomes + 7) // 8
         self.ndbs = (ngenomes + 31) // 32
         h = C.c_void_p()
-        check(self._lib.pg_table_create(ctx._h, k, ngenomes, expected_keys, C.byref(h)))
+        if keys_per_line:
+            check(self._lib.pg_table_create_dense(ctx._h, k, ngenomes, expected_keys, float(keys_per_line), C.byref(h)))
+        else:
+            check(self._lib.pg_table_create(ctx._h, k, ngenomes, expected_keys, C.byref(h)))
         self._h = h
         ctx._adopt(self)
         if coscheduled:
@@ -369,10 +373,13 @@ class PanTable(_Owner):
         check(self._lib.pg_table_set_coscheduled(self._h, int(anchors)))
 
     @staticmethod
-    def bytes_for(k: int, ngenomes: int, expected_keys: int) -> int:
-        """device bytes a table created for that many keys takes"""
+    def bytes_for(k: int, ngenomes: int, expected_keys: int, keys_per_line: float = 0.0) -> int:
+        """device bytes a table created for that many keys (at that density; 0: the library's) takes"""
         b = C.c_uint64()
-        check(_lib.load().pg_table_bytes_for(k, ngenomes, expected_keys, C.byref(b)))
+        if keys_per_line:
+            check(_lib.load().pg_table_bytes_for_dense(k, ngenomes, expected_keys, float(keys_per_line), C.byref(b)))
+        else:
+            check(_lib.load().pg_table_bytes_for(k, ngenomes, expected_keys, C.byref(b)))
         return int(b.value)
 
     def insert_seqset(self, genome_idx: int, seqs: SeqSet, min_count: int = 1) -> None:
@@ -620,6 +627,13 @@ class AnchorResult:
         a, b, n = C.c_double(), C.c_double(), C.c_uint32()
         check(self._lib.pg_result_timing_mean(self._h, C.byref(a), C.byref(b), C.byref(n)))
         return a.value, b.value, int(n.value)
+
+    def fused_runs(self) -> int:
+        """whole runs of this result whose statistics were computed inside k_probe (tile by tile, from rows still in the
+        cache) instead of by the pass over every row — pg_result_fused_runs; only with PG_FUSE_STATS=1 (an experiment: slower)"""
+        n = C.c_uint32()
+        check(self._lib.pg_result_fused_runs(self._h, C.byref(n)))
+        return int(n.value)
 
     def rows_epilogue(self) -> None:
         """bitmap.100 / bins / column sums from the (combined) rows in the device buffer (async)."""

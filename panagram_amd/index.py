@@ -610,23 +610,67 @@ class Index:
         by_id = {i[1].id: i for i in inputs}
         if self.shard is None and engine.PanTable.bytes_for(self.k, N, self._replicated_keys(inputs)) <= budget:
             return "replicated", 1
+        # Candidates: nblocks = world, 2 world, ... — FEWER blocks mean fewer passes over the anchors' positions, and a block
+        # table may be created DENSER than the library's 3 keys per line to make its genomes' union fit (round 6,
+        # pg_table_create_dense): a pass against a denser, wider block is slower (``_block_rate``, measured on BASELINE
+        # configs[4]: 8 x 3 Gb at d = 0.05 on one GPU — two genomes per block at 3.4-3.6 keys per line take 4 passes of 0.27 s
+        # where one genome per block took 8 of 0.21 s: 14.1 -> 23 G k-mers/s for the job), so the cheapest candidate by
+        # passes / rate wins; the search ends at the first candidate that fits at the library's density — more blocks only
+        # add passes from there.
+        anchor_positions = sum(int(i[2].lens.sum()) for i in inputs if i[0] in self.anchor_genomes)
+        best = None  # (cost, nblocks, keys_per_line)
         nblocks = max(1, self.world)
         while True:
             nblocks = min(nblocks, N)
             per = (N + nblocks - 1) // nblocks
-            worst = 0
+            keys = 0
             for b0 in range(0, N, per):
                 blk = [by_id[g] for g in range(b0, min(N, b0 + per)) if g in by_id]
-                worst = max(worst, engine.PanTable.bytes_for(self.k, min(per, N - b0), self._expected_keys(blk)))
-            # a block's table sits next to the anchors' rows of ITS genomes only (ceil(per/8) bytes) and the full-width
+                keys = max(keys, self._expected_keys(blk))
+            worst = engine.PanTable.bytes_for(self.k, per, keys)
+            # a block's table sits next to the anchors' rows of ITS genomes only (ceil(per/8) bytes per anchor position, every
+            # anchor's: each rank probes them all — unless the probe emits the block's columns directly) and the full-width
             # rows this rank holds as a writer: with several passes those of ALL its anchors (they gather bits pass by
             # pass), with one pass those whose writer jobs are still in flight (run_genome_sharded bounds them)
             mine = -(-len(self.anchor_genomes) // max(1, self.world))
             passes = -(-((N + per - 1) // per) // max(1, self.world))
             resident = (mine if passes > 1 else min(mine, 2 * self.writer_jobs(longest * nb * mine) + 1)) * longest * nb
-            if worst <= free - self.HBM_RESERVE - max(2 * longest * nb, resident) or nblocks >= N:
-                return "genome", (N + per - 1) // per
+            avail = free - self.HBM_RESERVE - max(2 * longest * nb, resident)
+            fits_sparse = worst <= avail
+            if fits_sparse:
+                cand = (passes / self._block_rate(per, 3.0), (N + per - 1) // per, 0.0)
+            else:
+                from .distributed import ShardedAnchoring
+                direct = engine.COLUMNS_DIRECT and per <= min(8, ShardedAnchoring.DIRECT_MAX_WIDTH)
+                room = avail - (0 if direct else anchor_positions * ((per + 7) // 8))
+                kpl = keys * 128.0 * 1.02 / room if room > 0 else float("inf")  # (+2 %: the line count is rounded up to a prime)
+                cand = (passes / self._block_rate(per, kpl), (N + per - 1) // per, round(kpl + 0.05, 1)) if (per <= 64 and 3.0 < kpl <= self.BLOCK_KPL_MAX) else None
+            if cand is not None and (best is None or cand[0] < best[0] - 1e-9):
+                best = cand
+            if fits_sparse or nblocks >= N:
+                if best is None:  # (nothing fits by this arithmetic: one genome per block at the library's density, as before)
+                    best = (0.0, (N + per - 1) // per, 0.0)
+                self._block_keys_per_line = best[2]
+                return "genome", best[1]
             nblocks += max(1, self.world)
+
+    # relative probe rate of a pass against a block table of ``per`` genomes at ``kpl`` keys per 128-byte line (8 x 3 Gb, d = 0.05,
+    # one MI355X; profiles/r6g*_config5_blocks.txt): G k-mers/s per pass 112 at (1, 3.0); (2, .): 94 at 3.2, 93 at 3.4, 90 at 3.6,
+    # 86-89 at 4.0, 80 at 4.5, 61 at 5.5, 45 at 6.2; 45 at (4, 5.8)
+    BLOCK_KPL = ((3.0, 1.0), (3.6, 0.955), (4.0, 0.92), (4.5, 0.845), (5.5, 0.65), (6.2, 0.476))
+    BLOCK_KPL_MAX = 6.2
+    _block_keys_per_line = 0.0  # what plan_sharding chose for the block tables (0: the library's density)
+
+    @classmethod
+    def _block_rate(cls, per: int, kpl: float) -> float:
+        pts = cls.BLOCK_KPL
+        if kpl <= pts[0][0]:
+            r = pts[0][1]
+        elif kpl >= pts[-1][0]:
+            r = pts[-1][1]
+        else:
+            r = next(a[1] + (b[1] - a[1]) * (kpl - a[0]) / (b[0] - a[0]) for a, b in zip(pts, pts[1:]) if a[0] <= kpl <= b[0])
+        return r * max(1, per) ** -0.27
 
     # ---- panagram index command (index.py:172-191) ----
     def run(self):
@@ -673,10 +717,11 @@ class Index:
 
     def _run_planned(self, ThreadPoolExecutor):
         mode, nblocks = self.plan_sharding()
-        self._check_plan_agreed((mode, nblocks))
+        self._check_plan_agreed((mode, nblocks, self._block_keys_per_line if mode == "genome" else 0.0))
         if mode == "genome":
             from .distributed import run_genome_sharded
-            logger.info("genome-sharded mode: %d genome blocks over %d GPU(s)", nblocks, self.world)
+            logger.info("genome-sharded mode: %d genome blocks over %d GPU(s)%s", nblocks, self.world,
+                        f", block tables at {self._block_keys_per_line:g} keys per line" if self._block_keys_per_line else "")
             self.exchange_stats = {}  # what this rank's exchange moved (bytes_received, passes, chunks): distributed.run_genome_sharded
             run_genome_sharded(self, nblocks, exchange_stats=self.exchange_stats)
             self.close()
@@ -761,7 +806,7 @@ class Index:
         if d is None or self.world <= 1:
             return
         got = [None] * self.world
-        d.all_gather_object(got, (plan[0], int(plan[1])))
+        d.all_gather_object(got, (plan[0], int(plan[1])) + tuple(plan[2:]))
         if any(g != got[0] for g in got):
             raise RuntimeError(f"the ranks planned different sharding modes {got}: pin one with PG_SHARD / PG_GENOME_BLOCKS")
 

@@ -21,6 +21,8 @@ from panagram_amd.engine import BgzfWriter, SmallOutputs  # the host BGZF writer
 
 HBM_FREE = 64 << 30        # what Context.mem_info reports; tests shrink it to force the genome-sharded mode
 BYTES_PER_KEY = 43         # PanTable.bytes_for: 16-byte slots at 0.375 load
+COLUMNS_DIRECT = False     # (engine.COLUMNS_DIRECT: PG_COLUMNS_DIRECT)
+CREATED_DENSITIES = []     # keys_per_line of every PanTable created (0: the library's density): what the planner asked for
 
 
 def usable_cpus() -> int:
@@ -139,17 +141,19 @@ class KmerSketch:
 
 
 class PanTable:
-    def __init__(self, ctx, k, ngenomes, expected_keys=0, coscheduled=0):
+    def __init__(self, ctx, k, ngenomes, expected_keys=0, coscheduled=0, keys_per_line=0.0):
         self.ctx, self.k, self.ngenomes = ctx, k, ngenomes
         self.coscheduled = coscheduled  # (what the product told the table about how it will be probed)
+        self.keys_per_line = keys_per_line  # (... and the density the planner chose for a block table; 0: the library's)
+        CREATED_DENSITIES.append(keys_per_line)
         self.nbytes, self.ndbs = (ngenomes + 7) // 8, (ngenomes + 31) // 32
         self._genomes: List[List[bytes]] = [[] for _ in range(ngenomes)]
         self._min = [1] * ngenomes
         self._dbs = None
 
     @staticmethod
-    def bytes_for(k, ngenomes, expected_keys):
-        return int(expected_keys) * BYTES_PER_KEY * ((((ngenomes + 31) // 32) + 1) // 2)
+    def bytes_for(k, ngenomes, expected_keys, keys_per_line=0.0):
+        return int(int(expected_keys) * BYTES_PER_KEY * ((((ngenomes + 31) // 32) + 1) // 2) * (3.0 / keys_per_line if keys_per_line else 1.0))
 
     def clear(self):
         self._genomes = [[] for _ in range(self.ngenomes)]

@@ -287,6 +287,50 @@ def test_single_process_passes_and_mode_choice(tmp_path, monkeypatch):
     _check_tree(idx_dir, fx)
 
 
+def test_planner_prefers_fewer_denser_genome_blocks(tmp_path, monkeypatch):
+    """Round 6: when the tables do not fit at the library's 3 keys per line, the planner weighs FEWER, denser blocks
+    (pg_table_create_dense) against more passes with the measured rate model (Index._block_rate): HBM that holds one genome's
+    table at 3 keys per line but two genomes' union only at ~4 gives blocks of two at that density — half the passes — and
+    the files are the same."""
+    from panagram_amd import index as pidx
+    from tests import fake_engine
+    fx = H.load_case("n8_k21")
+    idx_dir = _prepare_index(tmp_path, fx)
+    monkeypatch.setattr(pidx, "engine", fake_engine)
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    monkeypatch.setenv("RANK", "0")
+    monkeypatch.setattr(pidx.Index, "HBM_RESERVE", 0)
+    monkeypatch.setattr(pidx.Index, "batch_bytes", 0)
+    idx = pidx.Index(idx_dir, mode="w")
+    inputs = idx.load_inputs()
+    by_id = {i[1].id: i for i in inputs}
+    keys1 = max(pidx.Index._expected_keys([by_id[g]]) for g in range(8))
+    keys2 = max(pidx.Index._expected_keys([by_id[g], by_id[g + 1]]) for g in range(0, 8, 2))
+    positions = sum(int(i[2].lens.sum()) for i in inputs if i[0] in idx.anchor_genomes)
+    longest = max(int(i[2].lens.sum()) for i in inputs)
+    rows = max(2 * longest, len(idx.anchor_genomes) * longest)  # (what plan_sharding keeps for full-width rows, one byte per position here)
+    # room for a two-genome table at 4 keys per line (+ its narrow rows), not at 3; one genome at 3 fits easily
+    room = int(keys2 * 128 * 1.02 / 4.0)
+    assert fake_engine.PanTable.bytes_for(21, 1, keys1) < room < fake_engine.PanTable.bytes_for(21, 2, keys2) * 128 // (fake_engine.BYTES_PER_KEY * 1)
+    monkeypatch.setattr(fake_engine, "HBM_FREE", room + positions + rows)
+    monkeypatch.setattr(fake_engine, "BYTES_PER_KEY", 128 / 3.0)  # (bytes_for at the library's density = 128-byte lines of 3 keys, as the real engine)
+    del fake_engine.CREATED_DENSITIES[:]
+    mode, nblocks = idx.plan_sharding()
+    # (the fixture's genomes are near copies of each other: four of them have few more distinct k-mers than two, so blocks of
+    # four at a higher density may beat blocks of two by the model — either way fewer than eight blocks, denser than 3)
+    kpl = idx._block_keys_per_line
+    assert mode == "genome" and nblocks in (2, 4), (mode, nblocks)
+    assert 3.0 < kpl <= pidx.Index.BLOCK_KPL_MAX + 0.1, kpl
+    per = 8 // nblocks
+    assert nblocks / pidx.Index._block_rate(per, kpl) < 8 / pidx.Index._block_rate(1, 3.0)  # cheaper than one genome per block by the model
+    # the rate model: denser and wider is slower per pass, but not by the factor of two the halved passes win
+    r = pidx.Index._block_rate
+    assert r(1, 3.0) == 1.0 and r(2, 3.6) > 0.75 and r(2, 5.5) < r(2, 4.0) < r(2, 3.0) < r(1, 3.0) and 4 / r(2, 4.0) < 8 / r(1, 3.0)
+    idx.run()
+    assert fake_engine.CREATED_DENSITIES == [kpl], fake_engine.CREATED_DENSITIES  # ONE block table (re-used pass after pass), at the planned density
+    _check_tree(idx_dir, fx)
+
+
 # ---------------------------------------------------------------------------
 # the contig-sharded multi-GPU partition: pieces of homology classes
 # ---------------------------------------------------------------------------

@@ -554,6 +554,30 @@ def test_config5_as_specified_at_reduced_length_through_the_pass_mode(ctx):
     assert min(keys) > 0.95 * max(keys) and 2.9e8 < max(keys) < 3.0e8
 
 
+def test_config5_in_four_passes_of_two_genome_blocks(ctx):
+    """Round 6: the same job with TWO genomes per block in a table created denser than the library's 3 keys per line
+    (pg_table_create_dense: the union of two genomes' k-mers then fits one GPU at BASELINE.json configs[4]'s full size) — four
+    passes instead of eight, two bit columns per pass through the one-byte rows of the narrow result; at a tenth of the
+    length here.  Heads and tails against the CPU oracle again, every anchor holds all of its own k-mers."""
+    import types
+    import bench
+    dev = torch.device("cuda", 0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    try:
+        out = bench.config5_leg(ctx, dev, types.SimpleNamespace(seed=1234), genome_mb=300, contigs=24, sample_n=200_000, per=2, keys_per_line=4.5)
+    finally:
+        ctx.set_stream(None)
+    assert out["rows_equal_gpu"] is True, out["rows_check"]
+    assert out["anchors_hold_all_own_kmers"] and out["anchors_completed"] == 8
+    assert out["genome_blocks"] == 4 and out["genomes_per_block"] == 2 and len(out["passes"]) == 4
+    # two genomes at d = 0.05 from one ancestor share a ninth of their k-mers (0.95^42): the union is nearly twice one genome's
+    keys = [p["table_keys"] for p in out["passes"]]
+    assert 4.6e8 < min(keys) and max(keys) < 6.0e8
+    # created at 4.5 keys per line and not grown back while it filled: the table is 128 B x keys / 4.5, within rounding
+    for p in out["passes"]:
+        assert 0.9 < p["table_bytes"] / (128.0 * max(keys) * 1.04 / 4.5) < 1.1, (p["table_bytes"], max(keys))
+
+
 def test_config5_pass_mode_with_many_chunk_groups(ctx):
     """the same at 8 x 24 Mb with chunks of 2^20 positions: every anchor's contigs spread over 24 chunk groups (the
     double-buffered extract / merge pipeline turns over many times), heads and tails again against the oracle"""

@@ -1006,6 +1006,155 @@ def test_ragged_rows_keep_their_neighbours_first_bytes(ctx, n):
     tbl.close()
 
 
+@pytest.mark.parametrize("n,k,kpl", [(2, 21, 5.5), (8, 31, 6.4), (40, 21, 4.0), (1, 15, 5.0)])
+def test_dense_tables_hold_the_same_sets_and_answer_the_same(ctx, n, k, kpl):
+    """pg_table_create_dense (round 6): a table created at ``kpl`` keys per 128-byte line instead of 3 — more keys outside their
+    home lines, longer probe sequences, the overflow queue at work in every tile — holds exactly the oracle's k-mer sets,
+    answers GetCountersForRead and the anchor step bit for bit, and is not grown back while it fills; fed more keys than it was
+    created for it grows like any other table.  (KMC's sorted arrays have one density: cpp/anchor.cpp:28-31 is the call site.)"""
+    from panagram_amd import engine
+    gen = po.synth_genomes(n, [60_000, 9_000], 0.05, 1234 + n)
+    genomes = [[po.codes_to_ascii(c) for c in g] for g in gen]
+    dbs = po.build_bitvec_dbs(genomes, k)
+    nkeys = len(np.unique(np.concatenate([d[0] for d in dbs])))  # (ONE table of all genomes: the union of the 32-genome groups' sets)
+    tbl = engine.PanTable(ctx, k, n, expected_keys=int(nkeys * 1.03) + 1024, keys_per_line=kpl)
+    bytes0 = tbl.stats()["bytes"]
+    assert abs(bytes0 / (128.0 * (int(nkeys * 1.03) + 1024) / kpl) - 1) < 0.02  # 128-byte lines, kpl keys each
+    big = 3_000_000_000  # (the planner's arithmetic, host only: pg_table_bytes_for_dense)
+    assert abs(engine.PanTable.bytes_for(k, n, big, keys_per_line=kpl) / (128.0 * big / kpl) - 1) < 0.01
+    for g in range(n):
+        ss = engine.SeqSet.from_host(ctx, genomes[g])
+        tbl.insert_seqset(g, ss)
+        ss.close()
+    st = tbl.stats()
+    assert st["bytes"] == bytes0, "a dense table must not be grown back to the library's density while it fills"
+    assert st["nkeys"] == nkeys and st["nkeys"] / st["nbuckets"] > 0.9 * min(kpl, 6.4) / 1.05
+    keys, vals = tbl.export(0)
+    o = np.argsort(keys)
+    assert np.array_equal(keys[o], dbs[0][0]) and np.array_equal(vals[o], dbs[0][1])
+    for g in (0, n - 1):
+        for seq in genomes[g]:
+            rows, rows100, bins, cs = tbl.anchor_contig(seq)
+            o_rows, o_rows100, o_bins, _, o_cs = po.anchor_contig(dbs, seq, k, n)
+            assert np.array_equal(rows, o_rows) and np.array_equal(rows100, o_rows100)
+            assert np.array_equal(bins.astype(np.int64), o_bins) and np.array_equal(cs.astype(np.int64), o_cs)
+    assert np.array_equal(tbl.counters_for_read(0, genomes[0][0][:4000]), po.counters_for_read(dbs[0], genomes[0][0][:4000], k))
+    # far more keys than it was created for: it grows (and still answers)
+    extra = po.codes_to_ascii(np.random.default_rng(5).integers(0, 4, 2_500_000, dtype=np.uint8))
+    ss = engine.SeqSet.from_host(ctx, [extra])
+    tbl.insert_seqset(0, ss)
+    ss.close()
+    assert tbl.stats()["bytes"] > bytes0
+    rows = tbl.anchor_contig(genomes[n - 1][1])[0]
+    dbs2 = po.build_bitvec_dbs([genomes[0] + [extra]] + genomes[1:], k)
+    assert np.array_equal(rows, po.anchor_contig(dbs2, genomes[n - 1][1], k, n)[0])
+    with pytest.raises(Exception):
+        engine.PanTable(ctx, k, n, expected_keys=1000, keys_per_line=7.5)
+    tbl.close()
+
+
+def _bins_of(rows, n, binlen):
+    """popcount histogram per bin of ``binlen`` rows (cpp/anchor.cpp:179-189) from oracle rows"""
+    pc = np.unpackbits(rows, axis=1, bitorder="little")[:, :n].sum(axis=1)
+    nb = (len(rows) + binlen - 1) // binlen
+    out = np.zeros((nb, n + 1), np.int64)
+    for b in range(nb):
+        out[b] = np.bincount(pc[b * binlen:(b + 1) * binlen], minlength=n + 1)
+    return out
+
+
+@pytest.mark.parametrize("n", [9, 12, 20, 27, 32, 40, 47, 52, 64, 65, 73, 80, 90, 96, 100, 108, 116, 128])
+def test_fused_statistics_equal_the_pass_and_the_oracle(ctx, n, monkeypatch):
+    """Round 6 (opt-in, PG_FUSE_STATS=1): rows of 2..8 bytes (..16 in a -DPG_FUSE_WIDE=1 build) end every tile INSIDE k_probe with
+    the tile's popcount histogram, column sums and 1-in-100 rows (read back from the rows just written; k_tile_reduce adds the
+    tiles' counters up) for contigs whose bins are at least a tile (1024 rows) long; contigs with shorter bins stay with the statistics pass, launched over their tiles
+    only.  Bins of 1024 / 1500 / 2500 rows here (AnchorResult(max_bin_len=..., min_bin_count=1)): tiles inside one bin, tiles
+    across two bins, a contig that is one short bin (not fused: mixed launch), partial last tiles, N runs; a lowres step other
+    than 100 (k_lowres) once.  bitmap.100, bins and per-contig column sums against the oracle (cpp/anchor.cpp:156-189,
+    index.py:1051) AND against the unfused pass (PG_FUSE_STATS=0) in the same process; the result says which path ran."""
+    from panagram_amd import engine
+    k = 21 if n % 2 else 31
+    lens = [7000 + 13 * n, 2600, 1100 + k, 700, 4096 + k - 1]
+    rng = np.random.default_rng(31 * n + k)
+    gen = po.synth_genomes(n, lens, 0.02, 1700 + n)
+    genomes = [[bytearray(po.codes_to_ascii(c)) for c in g] for g in gen]
+    for g in (0, n - 1):
+        c = genomes[g][0]
+        p_ = int(rng.integers(100, len(c) - 400))
+        c[p_:p_ + 37] = b"N" * 37
+    genomes = [[bytes(c) for c in g] for g in genomes]
+    dbs = po.build_bitvec_dbs(genomes, k)
+    tbl = engine.PanTable(ctx, k, n)
+    for g in range(n):
+        ss = engine.SeqSet.from_host(ctx, genomes[g])
+        tbl.insert_seqset(g, ss)
+        ss.close()
+    for max_bin, step in ((1024, 100), (1500, 100), (2500, 7)):
+        ga = n - 1 if max_bin == 1500 else 0
+        ss = engine.SeqSet.from_host(ctx, genomes[ga])
+        got = {}
+        for fuse in ("1", "0"):
+            monkeypatch.setenv("PG_FUSE_STATS", fuse)
+            res = engine.AnchorResult(tbl, ss, colsums=True, max_bin_len=max_bin, min_bin_count=1, lowres_step=step)
+            res.run()
+            res.run()  # (a second run over the same buffers: the tiles' counters are overwritten, not added to)
+            # (rows of 9..16 bytes have fused instantiations only in a -DPG_FUSE_WIDE=1 build: csrc/pg_kernels.h)
+            want = (0,) if fuse == "0" else (2,) if (n + 7) // 8 <= 8 else (0, 2)
+            assert res.fused_runs() in want, (n, max_bin, fuse, res.fused_runs())
+            ccs = res.contig_colsums().astype(np.int64)
+            got[fuse] = [res.download(ci) + (ccs[ci],) for ci in range(len(lens))]
+            res.close()
+        for ci, seq in enumerate(genomes[ga]):
+            o_rows, _, _, _, o_cs = po.anchor_contig(dbs, seq, k, n)
+            nk = len(o_rows)
+            binlen = max_bin if nk // max_bin >= 1 else nk
+            for fuse in ("1", "0"):
+                rows, rows_lo, bins, info, cs = got[fuse][ci]
+                assert info["binlen"] == binlen and info["nkmers"] == nk
+                assert np.array_equal(rows, o_rows), (n, max_bin, fuse, ci)
+                assert np.array_equal(rows_lo, o_rows[::step]), (n, max_bin, fuse, ci)
+                assert np.array_equal(bins.astype(np.int64), _bins_of(o_rows, n, binlen)), (n, max_bin, fuse, ci)
+                assert np.array_equal(cs, o_cs), (n, max_bin, fuse, ci)
+        ss.close()
+    tbl.close()
+
+
+def test_fused_statistics_default_bins_long_contigs_coscheduled(ctx, monkeypatch):
+    """The same with the reference's own bin rule (200 000 rows, or a hundredth of the contig: cpp/anchor.cpp:114-118) on contigs
+    long enough for it to give bins of more than a tile — 150 000 and 260 000 k-mers: bins of 1500 and 2600 rows, most tiles
+    across two bins — next to a contig of 30 000 (bins of 300 rows: the pass), two anchor genomes co-scheduled in one launch
+    (bench.py's mode), for rows of 4, 8, 9 and 16 bytes."""
+    from panagram_amd import engine
+    for n, k in ((27, 21), (64, 31), (65, 21), (128, 21)):
+        lens = [150_000 + k - 1, 30_000, 260_000 + k - 1]
+        gen = po.synth_genomes(n, lens, 0.01, 4400 + n)
+        genomes = [[po.codes_to_ascii(c) for c in g] for g in gen]
+        dbs = po.build_bitvec_dbs(genomes, k)
+        tbl = engine.PanTable(ctx, k, n)
+        for g in range(n):
+            ss = engine.SeqSet.from_host(ctx, genomes[g])
+            tbl.insert_seqset(g, ss)
+            ss.close()
+        picks = [1, n - 1]
+        sss = [engine.SeqSet.from_host(ctx, genomes[g]) for g in picks]
+        both = engine.SeqSet.concat(ctx, sss)
+        monkeypatch.setenv("PG_FUSE_STATS", "1")
+        res = engine.AnchorResult(tbl, both, colsums=True)
+        res.coschedule(np.repeat(np.arange(2), len(lens)), 2)
+        res.run()
+        assert res.fused_runs() in ((1,) if (n + 7) // 8 <= 8 else (0, 1))
+        ccs = res.contig_colsums().astype(np.int64)
+        for gi, g in enumerate(picks):
+            for ci, seq in enumerate(genomes[g]):
+                rows, rows100, bins, info = res.download(gi * len(lens) + ci)
+                o_rows, o_rows100, o_bins, _, o_cs = po.anchor_contig(dbs, seq, k, n)
+                assert np.array_equal(rows, o_rows) and np.array_equal(rows100, o_rows100), (n, g, ci)
+                assert np.array_equal(bins.astype(np.int64), o_bins), (n, g, ci, np.argwhere(bins.astype(np.int64) != o_bins)[:5])
+                assert np.array_equal(ccs[gi * len(lens) + ci], o_cs), (n, g, ci)
+        for x in (res, both, *sss, tbl):
+            x.close()
+
+
 _FUZZ_N = [2, 8, 9, 16, 17, 24, 25, 32, 33, 40, 63, 64, 65, 72, 96, 97, 127, 128, 129, 160, 193, 256, 257, 300]
 
 

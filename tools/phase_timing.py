@@ -37,6 +37,10 @@ def main():
     print(f"value {d['value'] / 1e9:.1f} G k-mers/s, k_probe {d['roofline']['avg_launch_ms']:.3f} ms; waves timed {waves}, {tot / waves:.0f} cycles per wave (tile)")
     for n, c in list(zip(NAMES[:9], v[:9])) + [(NAMES[10], v[10])]:
         print(f"  {n:22s} {c / waves:9.0f} cycles per tile  {100.0 * c / tot:5.1f} %")
+    if any(v[11:16]):  # (round 6: the fused statistics at the tile's end, inside "drain + tail")
+        for n, c in zip(["fused: wait for the row stores", "fused: zero LDS, 1-in-100 request", "fused: rows, first pass (+ flush)",
+                         "fused: rows, second pass, 1-in-100 stores", "fused: histogram out"], v[11:16]):
+            print(f"    {n:48s} {c / waves:9.0f} cycles per tile  {100.0 * c / tot:5.1f} %")
 
 
 if __name__ == "__main__":
