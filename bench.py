@@ -670,7 +670,9 @@ def config5_leg(ctx, dev, args, genome_mb=None, contigs=24, sample_n=1_000_000, 
     if chunk_positions:
         pdist.CHUNK_POSITIONS = chunk_positions
     try:
-        sh = pdist.ShardedAnchoring(engine, ctx, k, G, per, 0, 1, seqs, {a: 0 for a in names}, None, None)
+        # (blocks of two genomes in a dense table: the probe emits the block's bit columns itself, as Index.plan_sharding asks — no narrow rows)
+        direct = True if (per == 2 and keys_per_line == "auto") else None
+        sh = pdist.ShardedAnchoring(engine, ctx, k, G, per, 0, 1, seqs, {a: 0 for a in names}, None, None, direct_columns=direct)
     finally:
         pdist.CHUNK_POSITIONS = old_chunk
     # (``per`` genomes per block: the block's table holds the union of their k-mers — at d = 0.05 two genomes share a ninth of
@@ -682,7 +684,7 @@ def config5_leg(ctx, dev, args, genome_mb=None, contigs=24, sample_n=1_000_000, 
         # genomes), the narrow result's rows and the library's reserve, at no fewer than the library's 3 keys per line
         torch.cuda.synchronize()
         free = torch.cuda.mem_get_info()[0]
-        room = free - (8 << 30) - pos * ((G + 7) // 8) - pos * ((per + 7) // 8)
+        room = free - (8 << 30) - pos * ((G + 7) // 8) - (0 if direct else pos * ((per + 7) // 8))
         keys_per_line = max(3.0, round(expect * 128.0 * 1.02 / max(room, 1) + 0.05, 1))
         if keys_per_line > 6.2:
             raise RuntimeError(f"blocks of {per} genomes do not fit this GPU at any usable density ({keys_per_line} keys per line)")
@@ -729,6 +731,7 @@ def config5_leg(ctx, dev, args, genome_mb=None, contigs=24, sample_n=1_000_000, 
                     "(table of block p built in one re-used allocation, every anchor position probed, the block's bit columns extracted and "
                     "OR-ed into the full rows); with 8 GPUs one-genome blocks run side by side in ONE pass and each anchor's columns go to its writer",
         "positions": pos, "genome_blocks": nblocks, "genomes_per_block": per, "table_keys_per_line_at_creation": keys_per_line or 3,
+        "columns_straight_from_the_probe": bool(getattr(sh, "_direct", False)),
         "chunk_groups_per_pass": len(sh.groups),
         "value": pos / total_pass, "value_with_table_builds": pos / (total_pass + total_build), "unit": "k-mers/s",
         "value_note": "the whole job on ONE GPU: all positions / the passes' time (each pass probes every position against one "

@@ -866,12 +866,16 @@ class ShardedAnchoring:
     DIRECT_MAX_WIDTH = int(os.environ.get("PG_DIRECT_MAX_WIDTH", "1"))
 
     def __init__(self, engine, ctx, k: int, ngenomes: int, per: int, rank: int, world: int, seqs: Dict[str, object],
-                 writer: Dict[str, int], geometry: Optional[dict] = None, group=None, always_gather: bool = False):
+                 writer: Dict[str, int], geometry: Optional[dict] = None, group=None, always_gather: bool = False,
+                 direct_columns: Optional[bool] = None):
         """``always_gather``: issue the collective even with one rank (a process group of size 1) — the side-stream
-        and RCCL code path on a single GPU."""
+        and RCCL code path on a single GPU.  ``direct_columns``: whether the probe emits the block's bit columns itself where
+        it can (blocks of up to DIRECT_MAX_WIDTH genomes; None: engine.COLUMNS_DIRECT, i.e. PG_COLUMNS_DIRECT) — no narrow row
+        buffer then, one byte per anchor position saved; the planner asks for it when a block table only fits dense."""
         self.engine, self.ctx, self.k, self.N, self.per = engine, ctx, k, ngenomes, per
         self.rank, self.world, self.seqs, self.writer, self.group = rank, max(1, world), seqs, writer, group
         self.geometry = geometry or {}
+        self.direct_columns = direct_columns
         self.dist = None
         self.collective = self.world > 1 or always_gather
         # how the blocks' bit columns travel: "rccl" — all_gather_into_tensor of device buffers on the default process
@@ -1082,7 +1086,8 @@ class ShardedAnchoring:
                 self._part.close()
             # a block of up to 8 genomes (config 5: ONE genome per GPU): the probe emits the bit columns itself, the
             # narrow result needs no row buffer
-            self._direct = (getattr(self.engine, "COLUMNS_DIRECT", False) and table.ngenomes <= 8 and self.per <= self.DIRECT_MAX_WIDTH
+            want_direct = getattr(self.engine, "COLUMNS_DIRECT", False) if self.direct_columns is None else bool(self.direct_columns)
+            self._direct = (want_direct and table.ngenomes <= 8 and self.per <= max(self.DIRECT_MAX_WIDTH, 2 if self.direct_columns else 0)
                             and table.spill()[1] == 8)  # (8-slot lines: what pg_result_columns_direct asks for)
             self._part = self.engine.AnchorResult(table, self.merged, colsums=False, rows_only=True,
                                                   **({"columns_only": True} if self._direct else {}))
@@ -1220,7 +1225,8 @@ def run_genome_sharded(index, nblocks: int, group=None, exchange_stats: Optional
             if int(ln) < k:
                 index.genomes[a].log.warning(f"Contig {nm} is shorter than k={k}: 0 k-mers (the reference underflows here)")
         index.genomes[a].log.info("Anchoring Started")
-    sh = ShardedAnchoring(engine, ctx, k, N, per, rank, world, seqs, writer, index.result_geometry, group)
+    sh = ShardedAnchoring(engine, ctx, k, N, per, rank, world, seqs, writer, index.result_geometry, group,
+                          direct_columns=True if getattr(index, "_block_direct", False) else None)
     payload = sum(int(seqs[a].lens.sum()) for a in anchors if writer[a] == rank) * ((N + 7) // 8)
     pool = ThreadPoolExecutor(max_workers=index.writer_jobs(payload))
     joins = []

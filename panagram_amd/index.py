@@ -638,19 +638,22 @@ class Index:
             avail = free - self.HBM_RESERVE - max(2 * longest * nb, resident)
             fits_sparse = worst <= avail
             if fits_sparse:
-                cand = (passes / self._block_rate(per, 3.0), (N + per - 1) // per, 0.0)
+                cand = (passes / self._block_rate(per, 3.0), (N + per - 1) // per, 0.0, False)
             else:
+                # (blocks of one or two genomes that only fit dense have the probe emit their bit columns itself — no narrow
+                # rows, one byte per anchor position more for the table: configs[4] on one GPU 3.6 -> 3.2 keys per line, +5 %)
                 from .distributed import ShardedAnchoring
-                direct = engine.COLUMNS_DIRECT and per <= min(8, ShardedAnchoring.DIRECT_MAX_WIDTH)
+                direct = per <= 2 or (engine.COLUMNS_DIRECT and per <= min(8, ShardedAnchoring.DIRECT_MAX_WIDTH))
                 room = avail - (0 if direct else anchor_positions * ((per + 7) // 8))
                 kpl = keys * 128.0 * 1.02 / room if room > 0 else float("inf")  # (+2 %: the line count is rounded up to a prime)
-                cand = (passes / self._block_rate(per, kpl), (N + per - 1) // per, round(kpl + 0.05, 1)) if (per <= 64 and 3.0 < kpl <= self.BLOCK_KPL_MAX) else None
+                kpl = max(kpl, 3.05)
+                cand = (passes / self._block_rate(per, kpl), (N + per - 1) // per, round(kpl + 0.05, 1), direct and per <= 2) if (per <= 64 and kpl <= self.BLOCK_KPL_MAX) else None
             if cand is not None and (best is None or cand[0] < best[0] - 1e-9):
                 best = cand
             if fits_sparse or nblocks >= N:
                 if best is None:  # (nothing fits by this arithmetic: one genome per block at the library's density, as before)
-                    best = (0.0, (N + per - 1) // per, 0.0)
-                self._block_keys_per_line = best[2]
+                    best = (0.0, (N + per - 1) // per, 0.0, False)
+                self._block_keys_per_line, self._block_direct = best[2], best[3]
                 return "genome", best[1]
             nblocks += max(1, self.world)
 
@@ -660,6 +663,7 @@ class Index:
     BLOCK_KPL = ((3.0, 1.0), (3.6, 0.955), (4.0, 0.92), (4.5, 0.845), (5.5, 0.65), (6.2, 0.476))
     BLOCK_KPL_MAX = 6.2
     _block_keys_per_line = 0.0  # what plan_sharding chose for the block tables (0: the library's density)
+    _block_direct = False       # ... and whether the probe emits the blocks' bit columns itself (no narrow rows)
 
     @classmethod
     def _block_rate(cls, per: int, kpl: float) -> float:
