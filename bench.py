@@ -181,7 +181,11 @@ class Pangenome:
         self.filtered = groups > 1 and os.environ.get("PG_FULL_TABLE", "") in ("", "0")
         est = int(L * (1 + max(0, g_hi - g_lo - 1) * novel) * 1.05) * (1 if self.filtered else groups)
         t0 = time.perf_counter()
-        self.table = engine.PanTable(ctx, k, g_hi - g_lo, expected_keys=est, coscheduled=self.coscheduled)
+        # (as Index.build_table creates its table: sparser than the library's 3 keys per line where HBM is plentiful — it has to
+        # leave room for this shape's rows, packed sequences and, in the legs that check rows, the ASCII copy)
+        pos_est = G * sum(contig_lens)
+        self.keys_per_line = engine.PanTable.roomy_density(ctx, k, g_hi - g_lo, est, pos_est * ((G + 7) // 8) * 21 // 20 + pos_est * (2 if keep_ascii else 1))
+        self.table = engine.PanTable(ctx, k, g_hi - g_lo, expected_keys=est, coscheduled=self.coscheduled, keys_per_line=self.keys_per_line)
         if minimizer >= 0:
             self.table.set_minimizer(minimizer)
         self.seqsets, self.ascii = None, None
@@ -247,7 +251,9 @@ class Pangenome:
             sketch.add(ss)
         est = sketch.estimate()
         sketch.close()
-        self.table = engine.PanTable(ctx, k, G, expected_keys=est + est // 32 + 1024, coscheduled=self.coscheduled)
+        expected = est + est // 32 + 1024
+        self.keys_per_line = engine.PanTable.roomy_density(ctx, k, G, expected, 0)  # (as Index.build_table: the rows of this rank's pieces are a fraction of the pangenome's)
+        self.table = engine.PanTable(ctx, k, G, expected_keys=expected, coscheduled=self.coscheduled, keys_per_line=self.keys_per_line)
         if minimizer >= 0:
             self.table.set_minimizer(minimizer)
         ctx.synchronize()
@@ -851,7 +857,14 @@ def robustness_legs(ctx, dev, args, k):
                 ss.load_dev(c, t.data_ptr(), t.numel())
             seqsets.append(ss)
         ctx.synchronize()
-        tbl = engine.PanTable(ctx, k, G, expected_keys=int(sum(t.numel() for t in genomes[0]) * (1 + (G - 1) * 0.25)), coscheduled=G)
+        exp_keys = int(sum(t.numel() for t in genomes[0]) * (1 + (G - 1) * 0.25))
+        # (as Index.build_table decides the table's density: sparser where HBM is plentiful, unless one genome's sketch says repeat-rich)
+        sk = engine.KmerSketch(ctx, k)
+        sk.add(seqsets[0])
+        distinct = min(1.0, sk.estimate() / max(1, seqsets[0].total_kmers(k)))
+        sk.close()
+        kpl = engine.PanTable.roomy_density(ctx, k, G, exp_keys, 0, distinct_fraction=distinct)
+        tbl = engine.PanTable(ctx, k, G, expected_keys=exp_keys, coscheduled=G, keys_per_line=kpl)
         if minimizer >= 0:
             tbl.set_minimizer(minimizer)
         tb = time.perf_counter()
@@ -889,7 +902,8 @@ def robustness_legs(ctx, dev, args, k):
         (out if into is None else into)[label] = {
             "what": what, "value": npos / dt, "per_genome_launches_value": npos / dt1, "unit": "k-mers/s",
             "positions_per_step": npos, "table_keys": tbl.stats()["nkeys"], "table_build_s": build_s,
-            "minimizer_length": tbl.minimizer, "table_spill_fraction": tbl.measure_spill()}
+            "minimizer_length": tbl.minimizer, "table_spill_fraction": tbl.measure_spill(),
+            "distinct_kmers_per_position_of_one_genome": round(distinct, 3), "table_keys_per_line_at_creation": kpl or 3.0}
         for r in singles:
             r.close()
         for ss in seqsets:
@@ -1328,6 +1342,7 @@ def main():
             "positions_per_step_per_gpu": pos_per_step,
             "table_keys": st["nkeys"], "table_bytes": st["bytes"], "keys_per_128B_line": round(st["nkeys"] / max(1, st["nbuckets"]), 3),
             "table_rehashed": bool(pg_rehashed), "minimizer_length": pg.table.minimizer,
+            "table_keys_per_line_at_creation": getattr(pg, "keys_per_line", 0.0) or 3.0,
             "table_built_for_coscheduled_anchors": pg.coscheduled,
             "table_build_s": pg.build_s, "table_spill_fraction": pg.table.measure_spill(), "table_slots_per_line": pg.table.spill()[1],
             "probes_per_position": (G + 63) // 64, "nbytes": (G + 7) // 8,
@@ -1348,7 +1363,8 @@ def main():
         from panagram_amd import engine as _engine
         pg1 = pg
         if args.minimizer < 0 and not pg_rehashed:
-            t1 = _engine.PanTable(ctx, k, G, expected_keys=int(st["nkeys"] * 1.02) + 1024, coscheduled=1)
+            t1 = _engine.PanTable(ctx, k, G, expected_keys=int(st["nkeys"] * 1.02) + 1024, coscheduled=1,
+                                  keys_per_line=_engine.PanTable.roomy_density(ctx, k, G, int(st["nkeys"] * 1.02) + 1024, 0))
             tb1 = time.perf_counter()
             for g in range(G):
                 t1.insert_seqset(g, pg.seqsets[g])

@@ -368,6 +368,36 @@ class PanTable(_Owner):
         if coscheduled:
             self.set_coscheduled(coscheduled)
 
+    # Densities a table may be created at when HBM is plentiful (round 6): the library's own 3 keys per 128-byte line date from
+    # 80-GB parts; at 1.5 keys per line fewer keys sit outside their home line (8 x 100 Mb: 15.5 % -> 9.5 %), the overflow drain
+    # of a tile is shorter and k_probe gains 3 % at 8 genomes, 5-6 % at 27-64 (profiles/r6k2_density_sweep.txt) for twice the table
+    # bytes — 21 GB instead of 10 of an MI355X's 288.
+    # Not for repeat-rich genomes: half of every genome in transposable-element families (bench.py's plant-like leg) runs 5 %
+    # SLOWER against the sparser table (profiles/r6m_roomy_robustness.txt) — the lines of a repeat family are the ones that are
+    # used again and again, and at half the density they are twice as many for the caches to hold.  ``distinct_fraction`` =
+    # distinct k-mers / k-mer positions of ONE genome (its sketch) tells the two apart.
+    ROOMY_DENSITIES = (1.5, 2.0, 2.5)
+    ROOMY_SHARE = 0.6       # of what is free beside ``other_bytes`` and the reserve
+    ROOMY_RESERVE = 8 << 30
+    ROOMY_MIN_DISTINCT = 0.85
+
+    @classmethod
+    def roomy_density(cls, ctx: Context, k: int, ngenomes: int, expected_keys: int, other_bytes: int = 0,
+                      distinct_fraction: Optional[float] = None) -> float:
+        """keys per line (0: the library's default) for a table of ``expected_keys`` that has ``other_bytes`` of HBM to leave
+        alone (the rows it will be anchored into, buffers still to come): the sparsest of ROOMY_DENSITIES that fits into
+        ROOMY_SHARE of the rest; tables of more than 64 genomes (inline / split lines), of unknown size and of repeat-rich
+        genomes (``distinct_fraction`` of one genome below ROOMY_MIN_DISTINCT) keep the default"""
+        if not expected_keys or ngenomes > 64 or os.environ.get("PG_TABLE_ROOMY", "1") in ("0", "") or os.environ.get("PG_TABLE_KEYS_PER_LINE"):
+            return 0.0
+        if distinct_fraction is not None and distinct_fraction < cls.ROOMY_MIN_DISTINCT:
+            return 0.0
+        room = (ctx.mem_info()[0] - int(other_bytes) - cls.ROOMY_RESERVE) * cls.ROOMY_SHARE
+        for kpl in cls.ROOMY_DENSITIES:
+            if cls.bytes_for(k, ngenomes, expected_keys, kpl) <= room:
+                return kpl
+        return 0.0
+
     def set_coscheduled(self, anchors: int) -> None:
         """tell an EMPTY table how it will be probed (see __init__)"""
         check(self._lib.pg_table_set_coscheduled(self._h, int(anchors)))

@@ -482,6 +482,24 @@ class Index:
             worst = max(worst, self._expected_keys(mine) if mine else 0)
         return worst or self._expected_keys(inputs)
 
+    def _roomy_density(self, expected_keys: int, anchors, inputs=None) -> float:
+        """keys per 128-byte line for the table about to be built (0: the library's 3): sparser where HBM is plentiful — it has to
+        leave room for two batches of rows (one being written, one being anchored: ``batch_bytes`` each at most) of the
+        anchors given (names, or {name: SeqSet} of pieces) — and the genomes are not repeat-rich (the longest input's sketch:
+        distinct k-mers per position).  engine.PanTable.roomy_density."""
+        nb = (self.ngenomes + 7) // 8
+        if isinstance(anchors, dict):
+            rows = sum(int(ss.lens.sum()) for ss in anchors.values()) * nb
+        else:
+            rows = sum(os.path.getsize(self.genomes[n].fasta) for n in anchors if n in self.genomes) * nb  # (a byte of FASTA per position, about)
+        distinct = None
+        if inputs:
+            big = max(inputs, key=lambda i: int(i[2].lens.sum()))
+            npos = max(1, int(big[2].lens.sum()))
+            distinct = min(1.0, engine.KmerSketch.estimate_registers(big[4]) / npos)
+        return engine.PanTable.roomy_density(self.context, self.k, self.ngenomes, expected_keys, 2 * min(self.batch_bytes, rows) + rows // 50,
+                                             distinct_fraction=distinct)
+
     def build_table(self, keep: Optional[Sequence[str]] = None, insert_sets: Optional[Dict[str, "engine.SeqSet"]] = None) -> engine.PanTable:
         """``keep``: the genomes whose packed sequences stay resident for the anchor step (default: all anchors) — and,
         in the filtered build, the genomes whose k-mers the table is built from.  ``insert_sets`` (the contig-sharded
@@ -529,7 +547,8 @@ class Index:
                 est = sketch.estimate()
                 sketch.close()
                 expected = est + est // 32 + 1024
-                tbl = engine.PanTable(self.context, self.k, self.ngenomes, expected_keys=expected, coscheduled=cosched)
+                tbl = engine.PanTable(self.context, self.k, self.ngenomes, expected_keys=expected, coscheduled=cosched,
+                                      keys_per_line=self._roomy_density(expected, keep if insert_sets is None else insert_sets, inputs))
                 for name, ss in insert_sets.items():
                     tbl.insert_seqset(self.genomes[name].id, ss)
                 for name, g, ss, _, _ in inputs:
@@ -540,7 +559,8 @@ class Index:
             else:
                 filtered = bool(can_filter and first and rest)
                 expected = self._expected_keys(first if filtered else inputs)
-                tbl = engine.PanTable(self.context, self.k, self.ngenomes, expected_keys=expected, coscheduled=cosched)
+                tbl = engine.PanTable(self.context, self.k, self.ngenomes, expected_keys=expected, coscheduled=cosched,
+                                      keys_per_line=self._roomy_density(expected, keep, inputs))
                 for name, g, ss, min_count, _ in (first + rest if filtered else inputs):
                     if filtered and name not in keep:
                         tbl.update_seqset(g.id, ss)

@@ -151,6 +151,10 @@ class PanTable:
         self._min = [1] * ngenomes
         self._dbs = None
 
+    @classmethod
+    def roomy_density(cls, ctx, k, ngenomes, expected_keys, other_bytes=0, distinct_fraction=None):
+        return 0.0  # (the stand-in has no HBM to be generous with)
+
     @staticmethod
     def bytes_for(k, ngenomes, expected_keys, keys_per_line=0.0):
         return int(int(expected_keys) * BYTES_PER_KEY * ((((ngenomes + 31) // 32) + 1) // 2) * (3.0 / keys_per_line if keys_per_line else 1.0))
