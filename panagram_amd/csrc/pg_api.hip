@@ -539,7 +539,7 @@ static int table_create(pg_ctx *ctx, int k, int ngenomes, uint64_t expected_keys
     t->k = k;
     t->ngenomes = ngenomes;
     t->ndbs = ndbs;
-    t->m = minimizer_length((uint32_t)k, expected_keys, 0, window_cap(ngenomes), (uint32_t)ngenomes);
+    t->m = minimizer_length((uint32_t)k, expected_keys, 0, window_cap(ngenomes), (uint32_t)ngenomes, 0, create_load(expected_keys, keys_per_line));
     t->expected = expected_keys;
     t->d_counters = nullptr;
     hipError_t e = hipMalloc(reinterpret_cast<void **>(&t->d_counters), 2 * sizeof(unsigned long long));
@@ -688,7 +688,7 @@ extern "C" int pg_table_set_coscheduled(pg_table *t, int anchors) {
         if (s.count) return fail(PG_E_INVALID, "pg_table_set_coscheduled: the table already holds keys");
     t->cosched = (uint32_t)anchors;
     if (!t->m_pinned) {
-        t->m = minimizer_length((uint32_t)t->k, t->expected, t->first_len, window_cap(t->ngenomes), (uint32_t)t->ngenomes, t->cosched);
+        t->m = minimizer_length((uint32_t)t->k, t->expected, t->first_len, window_cap(t->ngenomes), (uint32_t)t->ngenomes, t->cosched, t->load0);
         for (auto &s : t->subs) s.d.m = t->m;
     }
     return PG_OK;
@@ -700,7 +700,7 @@ static void settle_minimizer(pg_table *t, uint64_t positions) {
     for (auto &s : t->subs)
         if (s.count) return;
     t->first_len = positions;
-    t->m = minimizer_length((uint32_t)t->k, t->expected, positions, window_cap(t->ngenomes), (uint32_t)t->ngenomes, t->cosched);
+    t->m = minimizer_length((uint32_t)t->k, t->expected, positions, window_cap(t->ngenomes), (uint32_t)t->ngenomes, t->cosched, t->load0);
     for (auto &s : t->subs) s.d.m = t->m;
 }
 

@@ -134,12 +134,24 @@ constexpr uint32_t MZ_WMIN = 3, MZ_WMAX = 8;
 // partner fetches every line from HBM at the random-line rate of the memory system, and its time goes with the lines per
 // position, about 2 / (w + 1): the window's price is steeper there and the same rule picked the narrower window for both —
 // round 4 gained 1 % co-scheduled at configs[1] with m = 16 and lost 9 % per genome (125 -> 115 G k-mers/s).
+// `load` (round 6): keys per slot the table is created for (0.375 = the library's 3 keys per 8-slot line).  In a SPARSER table —
+// what Index.build_table asks for where HBM is plentiful — a group that outgrows its home line finds the next lines of its
+// sequence empty more often, and merged groups cost less: at 1.5 keys per line 8 x 100 Mb runs 3.20 ms at m = 15 against 3.33 at
+// m = 16 and 3.71 at m = 17 (at 3 keys per line m = 16 was 1 % ahead), 27 x 40 Mb the same at m = 15 and 16
+// (profiles/r6n_m_sweep_roomy.txt): the penalty goes with the square of the density, down to a quarter — where the m-mers are
+// long enough for the pangenome (r >= 10 below; profiles/r6o_lines_roomy_m.txt).
 __host__ __device__ __forceinline__ uint32_t minimizer_length(uint32_t k, uint64_t expected_keys, uint64_t first_len = 0,
-                                                              uint32_t wmax = MZ_WMAX, uint32_t ngenomes = 0, uint32_t cosched = 0) {
+                                                              uint32_t wmax = MZ_WMAX, uint32_t ngenomes = 0, uint32_t cosched = 0,
+                                                              double load = 0.375) {
     if (k < 20 || k > 32) return 0;
     // (more than 64 genomes: the split layout's lines hold 16 keys, a merged group fits more often — half the penalty:
     // 128 x 40 Mb 83.6 / 80.7 / 76.6 G k-mers/s at m = 15 / 16 / 17, 128 x 10 Mb 74.5 / 72.6 / 69.0)
     const double merged = ngenomes > 64 ? 25.0 : 50.0;
+    double sparse = 1.0;  // what is left of the penalty in a sparser table, where the m-mers are long enough (r >= 10: see the loop)
+    if (load > 0.0 && load < 0.375) {
+        sparse = (load / 0.375) * (load / 0.375);
+        if (sparse < 0.25) sparse = 0.25;
+    }
     double leff = 1.5e8;
     if (first_len) {
         leff = (double)first_len;
@@ -164,7 +176,10 @@ __host__ __device__ __forceinline__ uint32_t minimizer_length(uint32_t k, uint64
     double best_cost = 1e30;
     for (uint32_t m = m_lo; m <= m_hi; ++m) {
         const double r = (m >= 31 ? 4.6e18 : (double)(1ull << (2 * m))) / leff;
-        const double c = wcost[k - m + 1] + merged / r;
+        // (the relief of a sparse table fades where groups merge in earnest: 27 x 135 Mb, r = 5 at m = 15, runs 178 G at m = 15
+        // against 194 at m = 16 whatever the density, 8 x 300 Mb, r = 3.6, 197 against 206 — none of it below r = 5, all of it from 10 on)
+        const double relief = r >= 10.0 ? sparse : r <= 5.0 ? 1.0 : 1.0 + (sparse - 1.0) * (r - 5.0) / 5.0;
+        const double c = wcost[k - m + 1] + merged * relief / r;
         if (c < best_cost) {  // (ties: the wider window)
             best_cost = c;
             best = m;
