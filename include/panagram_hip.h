@@ -91,7 +91,10 @@ int pg_device_free(pg_ctx *ctx, void *ptr);
  * rehash) serialise on a per-table lock; lookups (pg_anchor_run ...) must not overlap them. */
 int pg_table_create(pg_ctx *ctx, int k, int ngenomes, uint64_t expected_keys, pg_table **out);
 /* the same with the table's density chosen by the caller: keys_per_line (1 .. 6.4) keys per 128-byte line of 8 slots instead
- * of the library's 3, for a known expected_keys (> 0) and up to 64 genomes.  What it is for: the genome-sharded mode's block
+ * of the library's 3 (a load of keys_per_line / 8 in the layouts of more than 64 genomes, whose lines hold 6 or 16 keys), for a
+ * known expected_keys (> 0).  SPARSER (1.5): what Index.build_table asks for where HBM is plentiful — fewer keys outside their
+ * home lines, k_probe 3-8 % faster for twice the table bytes (profiles/r6k2_density_sweep.txt, r6q_wide_density.txt).  DENSER:
+ * the genome-sharded mode's block
  * tables (BASELINE configs[4]) — a denser table holds the union of TWO genomes' k-mers in one GPU's HBM, the
  * job takes half the passes over the anchors' positions, and a pass against 3.4-4.5 keys per line is 5-25 % slower, not 100 %
  * (profiles/r6g_config5_blocks.txt).  The table is not grown back to 3 keys per line while it fills.  The reference has one

@@ -512,16 +512,16 @@ extern "C" int pg_table_create_dense(pg_ctx *ctx, int k, int ngenomes, uint64_t 
     PG_API_BEGIN
     if (!(keys_per_line >= 1.0 && keys_per_line <= 6.4)) return fail(PG_E_INVALID, "pg_table_create_dense: keys_per_line must be in 1 .. 6.4 (of 8 slots), got %g", keys_per_line);
     if (!expected_keys) return fail(PG_E_INVALID, "pg_table_create_dense: expected_keys must be known");
-    if (ngenomes > 64) return fail(PG_E_INVALID, "pg_table_create_dense: tables of 8-slot lines only (up to 64 genomes)");
     return table_create(ctx, k, ngenomes, expected_keys, keys_per_line, out);
     PG_API_END
 }
 extern "C" int pg_table_bytes_for_dense(int k, int ngenomes, uint64_t expected_keys, double keys_per_line, uint64_t *bytes) {
     PG_API_BEGIN
     if (!bytes) return fail(PG_E_INVALID, "pg_table_bytes_for_dense: NULL argument");
-    if (k < 1 || k > 32 || ngenomes < 1 || ngenomes > 64 || !(keys_per_line >= 1.0 && keys_per_line <= 6.4)) return fail(PG_E_INVALID, "pg_table_bytes_for_dense: bad argument");
-    const uint64_t nb = std::max<uint64_t>((uint64_t)((double)std::max<uint64_t>(expected_keys, 1ull << 18) / keys_per_line) + 1, 64);
-    *bytes = nb * 128ull;
+    if (k < 1 || k > 32 || ngenomes < 1 || !(keys_per_line >= 1.0 && keys_per_line <= 6.4)) return fail(PG_E_INVALID, "pg_table_bytes_for_dense: bad argument");
+    const TableGeom g = geom_for(ngenomes);  // (keys_per_line counts per 8 slots: a load of keys_per_line / 8 whatever the line holds)
+    const uint64_t nb = std::max<uint64_t>((uint64_t)((double)std::max<uint64_t>(expected_keys, 1ull << 18) / (keys_per_line / 8.0 * g.slots)) + 1, 64);
+    *bytes = g.layout == LAYOUT_SPLIT ? nb * g.slots * (8ull + 4ull * g.W) : g.layout == LAYOUT_INLINE ? nb * 128ull : nb * 16ull * g.slots;
     return PG_OK;
     PG_API_END
 }

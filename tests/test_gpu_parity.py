@@ -1006,7 +1006,7 @@ def test_ragged_rows_keep_their_neighbours_first_bytes(ctx, n):
     tbl.close()
 
 
-@pytest.mark.parametrize("n,k,kpl", [(2, 21, 5.5), (8, 31, 6.4), (40, 21, 4.0), (1, 15, 5.0), (8, 21, 1.5), (27, 31, 2.0)])
+@pytest.mark.parametrize("n,k,kpl", [(2, 21, 5.5), (8, 31, 6.4), (40, 21, 4.0), (1, 15, 5.0), (8, 21, 1.5), (27, 31, 2.0), (70, 21, 1.5), (100, 31, 1.5)])
 def test_dense_tables_hold_the_same_sets_and_answer_the_same(ctx, n, k, kpl):
     """pg_table_create_dense (round 6): a table created at ``kpl`` keys per 128-byte line instead of 3 — denser (the genome-sharded
     mode's block tables: more keys outside their home lines, longer probe sequences, the overflow queue at work in every tile) or
@@ -1020,16 +1020,18 @@ def test_dense_tables_hold_the_same_sets_and_answer_the_same(ctx, n, k, kpl):
     nkeys = len(np.unique(np.concatenate([d[0] for d in dbs])))  # (ONE table of all genomes: the union of the 32-genome groups' sets)
     tbl = engine.PanTable(ctx, k, n, expected_keys=int(nkeys * 1.03) + 1024, keys_per_line=kpl)
     bytes0 = tbl.stats()["bytes"]
-    assert abs(bytes0 / (128.0 * (int(nkeys * 1.03) + 1024) / kpl) - 1) < 0.02  # 128-byte lines, kpl keys each
+    per_line = kpl if n <= 64 else kpl / 8.0 * (6 if n <= 96 else 16)        # (inline lines hold 6 keys, split lines 16: the same load)
+    line_bytes = 128.0 if n <= 96 else 16 * (8 + 4 * ((n + 31) // 32))        # (split layout: 16 bare keys + their mask words in a second array)
+    assert abs(bytes0 / (line_bytes * (int(nkeys * 1.03) + 1024) / per_line) - 1) < 0.02
     big = 3_000_000_000  # (the planner's arithmetic, host only: pg_table_bytes_for_dense)
-    assert abs(engine.PanTable.bytes_for(k, n, big, keys_per_line=kpl) / (128.0 * big / kpl) - 1) < 0.01
+    assert abs(engine.PanTable.bytes_for(k, n, big, keys_per_line=kpl) / (line_bytes * big / per_line) - 1) < 0.01
     for g in range(n):
         ss = engine.SeqSet.from_host(ctx, genomes[g])
         tbl.insert_seqset(g, ss)
         ss.close()
     st = tbl.stats()
     assert st["bytes"] == bytes0, "a dense table must not be grown back to the library's density while it fills"
-    assert st["nkeys"] == nkeys and 0.9 * kpl / 1.05 < st["nkeys"] / st["nbuckets"] < kpl
+    assert st["nkeys"] == nkeys and 0.9 * per_line / 1.05 < st["nkeys"] / st["nbuckets"] < per_line
     keys, vals = tbl.export(0)
     o = np.argsort(keys)
     assert np.array_equal(keys[o], dbs[0][0]) and np.array_equal(vals[o], dbs[0][1])
@@ -1040,6 +1042,9 @@ def test_dense_tables_hold_the_same_sets_and_answer_the_same(ctx, n, k, kpl):
             assert np.array_equal(rows, o_rows) and np.array_equal(rows100, o_rows100)
             assert np.array_equal(bins.astype(np.int64), o_bins) and np.array_equal(cs.astype(np.int64), o_cs)
     assert np.array_equal(tbl.counters_for_read(0, genomes[0][0][:4000]), po.counters_for_read(dbs[0], genomes[0][0][:4000], k))
+    if kpl < 3:  # (a sparse table has room for several times its keys: nothing to grow for here)
+        tbl.close()
+        return
     # far more keys than it was created for: it grows (and still answers)
     extra = po.codes_to_ascii(np.random.default_rng(5).integers(0, 4, 2_500_000, dtype=np.uint8))
     ss = engine.SeqSet.from_host(ctx, [extra])
