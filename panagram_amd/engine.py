@@ -376,7 +376,7 @@ class PanTable(_Owner):
     # SLOWER against the sparser table (profiles/r6m_roomy_robustness.txt) — the lines of a repeat family are the ones that are
     # used again and again, and at half the density they are twice as many for the caches to hold.  ``distinct_fraction`` =
     # distinct k-mers / k-mer positions of ONE genome (its sketch) tells the two apart.
-    ROOMY_DENSITIES = (1.5, 2.0, 2.5)
+    ROOMY_DENSITIES = (1.25, 1.5, 2.0, 2.5)  # (1.25 against 1.5 at configs[1]: 3.154 against 3.206 ms, 1.0 no better: profiles/r6s_density_piece.txt)
     ROOMY_SHARE = 0.6       # of what is free beside ``other_bytes`` and the reserve
     ROOMY_RESERVE = 8 << 30
     ROOMY_MIN_DISTINCT = 0.85
