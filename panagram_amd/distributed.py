@@ -931,6 +931,9 @@ class ShardedAnchoring:
                     dtiles[w] += nt
                     parts.append((seqs[a], c0, nc))
                     contig_anchor += [ai] * nc
+            # (a writer without an anchor in this group — its anchors are shorter — gets an empty piece at its place in the order:
+            # all_to_all_single's input splits are consecutive)
+            doff = [sum(dtiles[:w]) for w in range(self.world)]
             self.groups.append(members)
             self.group_tiles.append(toff)
             self.dest_off.append(doff)
@@ -1028,6 +1031,10 @@ class ShardedAnchoring:
         self.dist.all_gather_into_tensor(hr, hs, group=self.host_group if self.host_group is not None else self.group)
         out_t.copy_(hr, non_blocking=True)
 
+    def _use_all_to_all(self, in_t, backend: str) -> bool:
+        """one all_to_all_single (RCCL) instead of batched isend / irecv: device tensors on an "nccl" group"""
+        return self.exchange == "rccl" and in_t.device.type == "cuda" and backend == "nccl"
+
     def _to_writers_into(self, out_t, in_t, send_off, send_len, own: int) -> None:
         """The writer-only exchange of one chunk group: piece [send_off[w], send_off[w] + send_len[w]) of ``in_t`` — the columns
         of the anchors rank w writes — goes to rank w; ``out_t`` receives ``world`` blocks of ``own`` bytes, block j = what rank
@@ -1037,7 +1044,7 @@ class ShardedAnchoring:
         group = self.group if self.host_group is None else self.host_group
         on_gpu = in_t.device.type == "cuda"
         backend = dist.get_backend(self.group)
-        if self.exchange == "rccl" and on_gpu and backend == "nccl":
+        if self._use_all_to_all(in_t, backend):
             # (the pieces are laid out writer by writer: input split w is exactly what rank w gets)
             assert all(send_off[w] == sum(send_len[:w]) for w in range(world))
             dist.all_to_all_single(out_t[:own * world], in_t[:sum(send_len)], output_split_sizes=[own] * world,

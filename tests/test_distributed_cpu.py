@@ -255,6 +255,67 @@ def test_exchange_sends_columns_to_their_writer_only(world, nblocks, chunk, tmp_
     assert sum(x["bytes_received"] for x in g) == world * sum(x["bytes_received"] for x in w)
 
 
+def _a2a_worker(rank, world, port, idx_dir, nblocks, chunk):
+    """genome-sharded Index.run() whose exchange takes the all_to_all_single BRANCH (what RCCL gets) on a gloo group: the
+    collective itself is stood in for by isend / irecv with the same split semantics, so the split arithmetic — input pieces
+    consecutive by destination, equal output pieces, empty pieces for writers without an anchor in a chunk group — is what is
+    exercised; every call's splits are checked against the collective's contract"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from panagram_amd import distributed as pdist
+        from panagram_amd import index as pidx
+        from tests import fake_engine
+        pidx.engine = fake_engine
+        pdist.CHUNK_POSITIONS = chunk
+        calls = []
+
+        def all_to_all_single(out, inp, output_split_sizes=None, input_split_sizes=None, group=None):
+            assert sum(input_split_sizes) == inp.numel() and sum(output_split_sizes) == out.numel()
+            assert len(input_split_sizes) == len(output_split_sizes) == world and len(set(output_split_sizes)) == 1
+            calls.append((list(input_split_sizes), output_split_sizes[0]))
+            io, oo, ops = 0, 0, []
+            for j in range(world):
+                a, b = inp[io:io + input_split_sizes[j]], out[oo:oo + output_split_sizes[j]]
+                if j == rank:
+                    b.copy_(a)
+                else:
+                    if a.numel():
+                        ops.append(dist.P2POp(dist.isend, a, j, group))
+                    if b.numel():
+                        ops.append(dist.P2POp(dist.irecv, b, j, group))
+                io, oo = io + input_split_sizes[j], oo + output_split_sizes[j]
+            for req in (dist.batch_isend_irecv(ops) if ops else []):
+                req.wait()
+        dist.all_to_all_single = all_to_all_single
+        pdist.ShardedAnchoring._use_all_to_all = lambda self, in_t, backend: True
+        idx = pidx.Index(idx_dir, mode="w", shard="genome", genome_blocks=nblocks)
+        idx.run()
+        assert calls and any(0 in c[0] for c in calls) == (os.environ.get("PG_TEST_EXPECT_EMPTY") == "1"), calls[:4]
+    finally:
+        dist.destroy_process_group()
+
+
+def test_all_to_all_splits_with_writers_that_have_no_anchor_in_a_group(tmp_path, monkeypatch):
+    """The RCCL branch of the writer-only exchange (all_to_all_single with split sizes), never run on hardware by the builder,
+    exercised through a stand-in with the collective's contract: anchors of very different lengths on 3 ranks and small chunks,
+    so that the late chunk groups hold anchors of ONE writer only — the others' input pieces are empty and must still sit at
+    their place in the order of destinations.  The tree equals the one-rank run's."""
+    from panagram_amd import index as pidx
+    from tests import fake_engine
+    s = _small_pangenome(tmp_path, [[30000, 9000], [5000], [12000, 700], [2500]])
+    geo = dict(k=21, lowres_step=50, max_bin_kbp=3, min_bin_count=5)
+    monkeypatch.setattr(pidx, "engine", fake_engine)
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    monkeypatch.setenv("RANK", "0")
+    pidx.Index(str(s), prefix=str(tmp_path / "one"), **geo).run()
+    pidx.Index(str(s), prefix=str(tmp_path / "many"), prepare=True, **geo)
+    monkeypatch.setenv("PG_TEST_EXPECT_EMPTY", "1")
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_a2a_worker, args=(3, port, str(tmp_path / "many"), 4, 2000), nprocs=3, join=True)
+    _trees_equal(tmp_path / "one", tmp_path / "many", [f"g{g}" for g in range(4)])
+
+
 def test_world2_index_run_replicated(tmp_path):
     fx = H.load_case("n9_k21")
     idx_dir = _prepare_index(tmp_path, fx)
