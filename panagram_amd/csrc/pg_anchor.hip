@@ -41,7 +41,43 @@
 
 #include <algorithm>
 
+// ---- translation units (round 6) ----
+// k_probe and k_insert_tile are instantiated per minimizer window (0, 3..8) x row mode x layout x (fused): 300 kernels, three
+// minutes of hipcc in one unit.  panagram_amd/build.py compiles this file THREE times in parallel, each unit instantiating the
+// windows of its part (probe_part<N> / insert_part<N> below); part 0 also holds every other kernel and launcher of the file.
+// -1 (the default: tools/isa.sh, tools/build_variant.sh, a plain `hipcc pg_anchor.hip`): everything in one unit.
+#ifndef PG_ANCHOR_PART
+#define PG_ANCHOR_PART -1
+#endif
+#define PG_HAS_PART(n) (PG_ANCHOR_PART == -1 || PG_ANCHOR_PART == (n))
+#define PG_MAIN_PART (PG_ANCHOR_PART <= 0)
+#if defined(PG_PHASE_TIMING) && PG_ANCHOR_PART != -1
+#error "a -DPG_PHASE_TIMING build keeps its counters in one device variable: compile pg_anchor.hip as ONE unit (PG_ANCHOR_PART unset)"
+#endif
+
 namespace pg {
+
+// windows 0, 3, 4 -> part 0; 5, 6 -> part 1; 7, 8 -> part 2
+hipError_t probe_part0(hipStream_t s, uint32_t w, uint32_t ntiles, const SubTable &st, const uint64_t *seqw, const uint32_t *nmw, const uint32_t *has_n,
+                       const SeqDesc *sd, const AnchorDesc *ad, const uint32_t *tile_contig, const uint32_t *sched, uint32_t tile_base, uint8_t *out1,
+                       uint32_t nbytes, const RowCols &rc, int rowmode, const FuseArgs *fuse);
+hipError_t probe_part1(hipStream_t s, uint32_t w, uint32_t ntiles, const SubTable &st, const uint64_t *seqw, const uint32_t *nmw, const uint32_t *has_n,
+                       const SeqDesc *sd, const AnchorDesc *ad, const uint32_t *tile_contig, const uint32_t *sched, uint32_t tile_base, uint8_t *out1,
+                       uint32_t nbytes, const RowCols &rc, int rowmode, const FuseArgs *fuse);
+hipError_t probe_part2(hipStream_t s, uint32_t w, uint32_t ntiles, const SubTable &st, const uint64_t *seqw, const uint32_t *nmw, const uint32_t *has_n,
+                       const SeqDesc *sd, const AnchorDesc *ad, const uint32_t *tile_contig, const uint32_t *sched, uint32_t tile_base, uint8_t *out1,
+                       uint32_t nbytes, const RowCols &rc, int rowmode, const FuseArgs *fuse);
+hipError_t insert_part0(hipStream_t s, uint32_t win, uint32_t ntiles, const SubTable &st, int w, uint32_t bits, uint32_t count_mode, const uint64_t *seqw,
+                        const uint32_t *nmw, const uint32_t *has_n, const SeqDesc *sd, const uint32_t *tile0, uint32_t ncontigs,
+                        unsigned long long *counters, uint32_t max_probe);
+hipError_t insert_part1(hipStream_t s, uint32_t win, uint32_t ntiles, const SubTable &st, int w, uint32_t bits, uint32_t count_mode, const uint64_t *seqw,
+                        const uint32_t *nmw, const uint32_t *has_n, const SeqDesc *sd, const uint32_t *tile0, uint32_t ncontigs,
+                        unsigned long long *counters, uint32_t max_probe);
+hipError_t insert_part2(hipStream_t s, uint32_t win, uint32_t ntiles, const SubTable &st, int w, uint32_t bits, uint32_t count_mode, const uint64_t *seqw,
+                        const uint32_t *nmw, const uint32_t *has_n, const SeqDesc *sd, const uint32_t *tile0, uint32_t ncontigs,
+                        unsigned long long *counters, uint32_t max_probe);
+hipError_t preload_part1();
+hipError_t preload_part2();
 
 constexpr int PROBE_SEQW = ((PROBE_TILE + 31) / 32 + 6 + 3) & ~3;  // staged 32-base words per tile
 // The tile's packed bases are staged TWICE: as they are (sw) and reverse-complemented (rw: base j of rw = complement of
@@ -2043,6 +2079,7 @@ __global__ __launch_bounds__(64) void k_insert_tile(const SubTable st, int w, ui
     }
 }
 
+#if PG_MAIN_PART  // ======== every other kernel of the file: part 0 (or the one unit) only ========
 // ---------------------------------------------------------------------------
 // statistics from finished rows: bitmap.100, per-bin popcount histogram, column sums.
 // A workgroup (256 threads) walks a CONTIGUOUS range of tiles (PT consecutive positions per
@@ -3883,6 +3920,8 @@ __global__ __launch_bounds__(64) void k_lowres(uint32_t N, const AnchorDesc *__r
     }
 }
 
+#endif  // PG_MAIN_PART
+
 // ---------------------------------------------------------------------------
 // launch
 // ---------------------------------------------------------------------------
@@ -3971,6 +4010,80 @@ static hipError_t probe_w(hipStream_t s, uint32_t ntiles, const SubTable &st, co
 #undef PG_K
 }
 
+template <int W_C>
+static hipError_t insert_tiles_w(hipStream_t s, uint32_t ntiles, const SubTable &st, int w, uint32_t bits, uint32_t count_mode,
+                                 const uint64_t *seqw, const uint32_t *nmw, const uint32_t *has_n, const SeqDesc *sd,
+                                 const uint32_t *tile0, uint32_t ncontigs, unsigned long long *counters, uint32_t max_probe) {
+    if (W_C && st.m > 16)
+        hipLaunchKernelGGL((k_insert_tile<W_C, true>), dim3(ntiles), dim3(64), 0, s, st, w, bits, count_mode, seqw, nmw, has_n, sd,
+                           tile0, ncontigs, counters, max_probe);
+    else
+        hipLaunchKernelGGL((k_insert_tile<W_C, false>), dim3(ntiles), dim3(64), 0, s, st, w, bits, count_mode, seqw, nmw, has_n, sd,
+                           tile0, ncontigs, counters, max_probe);
+    return hipGetLastError();
+}
+
+// the parts' entry points: the windows a unit instantiates (see the top of the file)
+#define PG_PROBE_ARGS hipStream_t s, uint32_t w, uint32_t ntiles, const SubTable &st, const uint64_t *seqw, const uint32_t *nmw, const uint32_t *has_n, \
+                      const SeqDesc *sd, const AnchorDesc *ad, const uint32_t *tile_contig, const uint32_t *sched, uint32_t tile_base, uint8_t *out1,          \
+                      uint32_t nbytes, const RowCols &rc, int rowmode, const FuseArgs *fuse
+#define PG_PROBE_CASE(W) case W: return probe_w<W>(s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, sched, tile_base, out1, nbytes, rc, rowmode, fuse);
+#define PG_INSERT_ARGS hipStream_t s, uint32_t win, uint32_t ntiles, const SubTable &st, int w, uint32_t bits, uint32_t count_mode, const uint64_t *seqw, \
+                       const uint32_t *nmw, const uint32_t *has_n, const SeqDesc *sd, const uint32_t *tile0, uint32_t ncontigs,                          \
+                       unsigned long long *counters, uint32_t max_probe
+#define PG_INSERT_CASE(W) case W: return insert_tiles_w<W>(s, ntiles, st, w, bits, count_mode, seqw, nmw, has_n, sd, tile0, ncontigs, counters, max_probe);
+// (each unit is a code object of its own, loaded by the HIP runtime when the first of its kernels is asked for: preload_anchor_kernels asks)
+#if PG_HAS_PART(1)
+hipError_t preload_part1() {
+    hipFuncAttributes fa;
+    return hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(k_insert_tile<6, false>));
+}
+#endif
+#if PG_HAS_PART(2)
+hipError_t preload_part2() {
+    hipFuncAttributes fa;
+    return hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(k_insert_tile<7, false>));
+}
+#endif
+#if PG_HAS_PART(0)
+hipError_t probe_part0(PG_PROBE_ARGS) {
+    switch (w) { PG_PROBE_CASE(0) PG_PROBE_CASE(3) PG_PROBE_CASE(4) default: return hipErrorInvalidValue; }
+}
+hipError_t insert_part0(PG_INSERT_ARGS) {
+    switch (win) { PG_INSERT_CASE(0) PG_INSERT_CASE(3) PG_INSERT_CASE(4) default: return hipErrorInvalidValue; }
+}
+#endif
+#if PG_HAS_PART(1)
+hipError_t probe_part1(PG_PROBE_ARGS) {
+    switch (w) { PG_PROBE_CASE(5) PG_PROBE_CASE(6) default: return hipErrorInvalidValue; }
+}
+hipError_t insert_part1(PG_INSERT_ARGS) {
+    switch (win) { PG_INSERT_CASE(5) PG_INSERT_CASE(6) default: return hipErrorInvalidValue; }
+}
+#endif
+#if PG_HAS_PART(2)
+hipError_t probe_part2(PG_PROBE_ARGS) {
+    switch (w) { PG_PROBE_CASE(7) PG_PROBE_CASE(8) default: return hipErrorInvalidValue; }
+}
+hipError_t insert_part2(PG_INSERT_ARGS) {
+    switch (win) { PG_INSERT_CASE(7) PG_INSERT_CASE(8) default: return hipErrorInvalidValue; }
+}
+#endif
+#undef PG_PROBE_ARGS
+#undef PG_PROBE_CASE
+#undef PG_INSERT_ARGS
+#undef PG_INSERT_CASE
+
+#if PG_MAIN_PART  // ======== the launchers: part 0 (or the one unit) only ========
+// the kernel's compile-time window must be the one the table was built with: the part that instantiates it
+static hipError_t probe_window(hipStream_t s, uint32_t w, uint32_t ntiles, const SubTable &st, const uint64_t *seqw, const uint32_t *nmw,
+                               const uint32_t *has_n, const SeqDesc *sd, const AnchorDesc *ad, const uint32_t *tile_contig, const uint32_t *sched,
+                               uint32_t tile_base, uint8_t *out1, uint32_t nbytes, const RowCols &rc, int rowmode, const FuseArgs *fuse) {
+    auto *part = (w == 0 || w == 3 || w == 4) ? probe_part0 : (w == 5 || w == 6) ? probe_part1 : (w == 7 || w == 8) ? probe_part2 : nullptr;
+    if (!part) return hipErrorInvalidValue;
+    return part(s, w, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, sched, tile_base, out1, nbytes, rc, rowmode, fuse);
+}
+
 static int row_mode(uint32_t nbytes, const RowCols &rc) {
     if (nbytes == 1) return 1;
     if (nbytes == 8 && rc.col0 == 0 && rc.nb0 == 4 && rc.nb1 == 4) return 2;
@@ -4003,16 +4116,7 @@ hipError_t launch_anchor(hipStream_t s, const TableDesc &T, const uint64_t *seqw
         rc.col0 = T.ngenomes;  // (genomes of the block)
         rc.nb0 = rc.nb1 = rc.words = 0;
         const uint32_t w = st.m ? st.k - st.m + 1 : 0;
-        switch (w) {
-            case 0: return probe_w<0>(s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, sched, tile_base, out1, columns_width, rc, 3);
-            case 3: return probe_w<3>(s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, sched, tile_base, out1, columns_width, rc, 3);
-            case 4: return probe_w<4>(s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, sched, tile_base, out1, columns_width, rc, 3);
-            case 5: return probe_w<5>(s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, sched, tile_base, out1, columns_width, rc, 3);
-            case 6: return probe_w<6>(s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, sched, tile_base, out1, columns_width, rc, 3);
-            case 7: return probe_w<7>(s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, sched, tile_base, out1, columns_width, rc, 3);
-            case 8: return probe_w<8>(s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, sched, tile_base, out1, columns_width, rc, 3);
-            default: return hipErrorInvalidValue;
-        }
+        return probe_window(s, w, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, sched, tile_base, out1, columns_width, rc, 3, nullptr);
     }
     for (uint32_t si = 0; si < T.nsub; ++si) {
         const SubTable &st = T.sub[si];
@@ -4025,16 +4129,7 @@ hipError_t launch_anchor(hipStream_t s, const TableDesc &T, const uint64_t *seqw
         if (rc.words == 1 && rc.nb1 == 4 && rc.col0 % 8 == 0 && nbytes % 8 == 0) rc.words = 4u;  // (one 8-byte store per row: -9 % probe time at N=128)
         const int rm = (T.nsub == 1) ? row_mode(nbytes, rc) : 0;
         const uint32_t w = st.m ? st.k - st.m + 1 : 0;
-        switch (w) {  // the kernel's compile-time window must be the one the table was built with
-            case 0: e = probe_w<0>(s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, sched, tile_base, out1, nbytes, rc, rm, fuse); break;
-            case 3: e = probe_w<3>(s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, sched, tile_base, out1, nbytes, rc, rm, fuse); break;
-            case 4: e = probe_w<4>(s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, sched, tile_base, out1, nbytes, rc, rm, fuse); break;
-            case 5: e = probe_w<5>(s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, sched, tile_base, out1, nbytes, rc, rm, fuse); break;
-            case 6: e = probe_w<6>(s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, sched, tile_base, out1, nbytes, rc, rm, fuse); break;
-            case 7: e = probe_w<7>(s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, sched, tile_base, out1, nbytes, rc, rm, fuse); break;
-            case 8: e = probe_w<8>(s, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, sched, tile_base, out1, nbytes, rc, rm, fuse); break;
-            default: return hipErrorInvalidValue;
-        }
+        e = probe_window(s, w, ntiles, st, seqw, nmw, has_n, sd, ad, tile_contig, sched, tile_base, out1, nbytes, rc, rm, fuse);
         if (e != hipSuccess) return e;
     }
     return e;
@@ -4252,19 +4347,6 @@ hipError_t launch_lowres(hipStream_t st, uint32_t ngenomes, const AnchorDesc *ad
     return hipGetLastError();
 }
 
-template <int W_C>
-static hipError_t insert_tiles_w(hipStream_t s, uint32_t ntiles, const SubTable &st, int w, uint32_t bits, uint32_t count_mode,
-                                 const uint64_t *seqw, const uint32_t *nmw, const uint32_t *has_n, const SeqDesc *sd,
-                                 const uint32_t *tile0, uint32_t ncontigs, unsigned long long *counters, uint32_t max_probe) {
-    if (W_C && st.m > 16)
-        hipLaunchKernelGGL((k_insert_tile<W_C, true>), dim3(ntiles), dim3(64), 0, s, st, w, bits, count_mode, seqw, nmw, has_n, sd,
-                           tile0, ncontigs, counters, max_probe);
-    else
-        hipLaunchKernelGGL((k_insert_tile<W_C, false>), dim3(ntiles), dim3(64), 0, s, st, w, bits, count_mode, seqw, nmw, has_n, sd,
-                           tile0, ncontigs, counters, max_probe);
-    return hipGetLastError();
-}
-
 #ifdef PG_PHASE_TIMING
 }  // namespace pg
 extern "C" int pg_debug_phase_cycles(unsigned long long *out16, int reset) {
@@ -4282,9 +4364,12 @@ extern "C" int pg_debug_phase_cycles(unsigned long long *out16, int reset) {
 }
 namespace pg {
 #endif
-hipError_t preload_anchor_kernels() {
+hipError_t preload_anchor_kernels() {  // (any kernel of this unit loads its code object; the other parts' load with their first launch)
     hipFuncAttributes fa;
-    return hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(k_insert_tile<7, false>));
+    hipError_t e = hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(k_lowres));
+    if (e == hipSuccess) e = preload_part1();
+    if (e == hipSuccess) e = preload_part2();
+    return e;
 }
 
 // every k-mer of the contigs described by sd / tile0 (tile0[c] = first tile of contig c; tile0[ncontigs] = ntiles)
@@ -4293,18 +4378,10 @@ hipError_t launch_insert_tiles(hipStream_t s, const SubTable &st, int w, uint32_
                                uint32_t ncontigs, uint32_t ntiles, unsigned long long *counters, uint32_t max_probe) {
     if (ntiles == 0) return hipSuccess;
     const uint32_t win = st.m ? st.k - st.m + 1 : 0;
-#define PG_I s, ntiles, st, w, bits, (uint32_t)count_mode, seqw, nmw, has_n, sd, tile0, ncontigs, counters, max_probe
-    switch (win) {
-        case 0: return insert_tiles_w<0>(PG_I);
-        case 3: return insert_tiles_w<3>(PG_I);
-        case 4: return insert_tiles_w<4>(PG_I);
-        case 5: return insert_tiles_w<5>(PG_I);
-        case 6: return insert_tiles_w<6>(PG_I);
-        case 7: return insert_tiles_w<7>(PG_I);
-        case 8: return insert_tiles_w<8>(PG_I);
-        default: return hipErrorInvalidValue;
-    }
-#undef PG_I
+    auto *part = (win == 0 || win == 3 || win == 4) ? insert_part0 : (win == 5 || win == 6) ? insert_part1 : (win == 7 || win == 8) ? insert_part2 : nullptr;
+    if (!part) return hipErrorInvalidValue;
+    return part(s, win, ntiles, st, w, bits, (uint32_t)count_mode, seqw, nmw, has_n, sd, tile0, ncontigs, counters, max_probe);
 }
+#endif  // PG_MAIN_PART
 
 }  // namespace pg
