@@ -1084,12 +1084,15 @@ def sharded_leg(ctx, dev, args, rank, world, dist, steps, warmup, nblocks=None):
         "positions_per_step": pos, "genome_blocks": nblocks, "genomes_per_block": per,
         "block_table_keys": pg.stats["nkeys"], "block_table_bytes": pg.stats["bytes"],
         "chunk_groups_per_step": len(sh.groups),
-        "collective": "all_gather_into_tensor of bit columns (RCCL over xGMI)" if world > 1 else "none (one rank)",
+        "collective": ("none (one rank)" if world <= 1 else
+                       ("each anchor's bit columns to its writer only: all_to_all_single with split sizes (RCCL over xGMI; batched isend / irecv "
+                        "on gloo / the host route)" if getattr(sh, "to_writers", False) else "all_gather_into_tensor of bit columns (RCCL over xGMI)")
+                       + f" [PG_SHARD_EXCHANGE: {getattr(sh, 'exchange', 'rccl')}]"),
         "collective_bytes_received_per_rank_per_step": sh.bytes_received / max(1, steps + warmup),
         "parallelism": (f"EMULATED rank 0 of {nblocks}: the table of genome block 0 ({per} genome(s)) only, every position probed, "
                         f"columns extracted and merged, no collective" if emulated else
                         f"genome-sharded x{world}: {nblocks} genome blocks of {per}, every rank probes every position, "
-                        f"columns all-gathered, anchors' rows merged + statistics on their writer rank"),
+                        f"columns sent to the anchors' writers, rows merged + statistics there"),
         "columns_from_the_probe": bool(getattr(sh, "_direct", False)),
     }
     sh.close()
