@@ -203,6 +203,12 @@ int pg_minimizer_length(int k, uint64_t expected_keys, uint64_t first_len, int w
  * the first insert / load); pg_minimizer_length_for is the rule itself. */
 int pg_table_set_coscheduled(pg_table *tbl, int anchors);
 int pg_minimizer_length_for(int k, uint64_t expected_keys, uint64_t first_len, int wmax, int ngenomes, int coscheduled);
+/* ... and the table's DENSITY (round 6): in a table created sparser than the library's 3 keys per line (pg_table_create_dense with
+ * keys_per_line < 3) merged minimizer groups cost less — a group that outgrows its home line finds the next lines empty more often —
+ * and the rule may take the wider window: configs[1] m = 15 at 1.25 keys per line, 16 at 3 (profiles/r6n_m_sweep_roomy.txt,
+ * r6p_lines_roomy_m.txt).  A table applies the rule with its own density; this is the rule itself (host arithmetic). */
+int pg_minimizer_length_dense(int k, uint64_t expected_keys, uint64_t first_len, int wmax, int ngenomes, int coscheduled,
+                              double keys_per_line);
 
 /* ---- sequences: 2-bit packed contigs resident in HBM -------------------
  * Reference: the FASTA record strings handed to write_bits / _write_bitmap

@@ -71,6 +71,7 @@ PROTOTYPES = {
     "pg_table_set_minimizer": (C.c_int, [_vp, C.c_int]),
     "pg_minimizer_length": (C.c_int, [C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_int]),
     "pg_minimizer_length_for": (C.c_int, [C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int]),
+    "pg_minimizer_length_dense": (C.c_int, [C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_double]),
     "pg_table_set_coscheduled": (C.c_int, [_vp, C.c_int]),
     "pg_seqset_create": (C.c_int, [_vp, C.c_uint32, _vp, _vpp]),
     "pg_seqset_destroy": (C.c_int, [_vp]),

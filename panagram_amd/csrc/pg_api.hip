@@ -678,6 +678,16 @@ extern "C" int pg_minimizer_length_for(int k, uint64_t expected_keys, uint64_t f
     PG_API_END
 }
 
+extern "C" int pg_minimizer_length_dense(int k, uint64_t expected_keys, uint64_t first_len, int wmax, int ngenomes, int coscheduled,
+                                         double keys_per_line) {
+    PG_API_BEGIN
+    if (k < 1 || k > 32) return 0;
+    const uint32_t cap = wmax ? (uint32_t)std::min<int>((int)MZ_WMAX, std::max<int>((int)MZ_WMIN, wmax)) : window_cap(ngenomes);
+    const double load = (keys_per_line >= 1.0 && keys_per_line <= 6.4) ? keys_per_line / 8.0 : TARGET_LOAD;
+    return (int)minimizer_length((uint32_t)k, expected_keys, first_len, cap, (uint32_t)std::max(0, ngenomes), (uint32_t)std::max(0, coscheduled), load);
+    PG_API_END
+}
+
 // How the table will be probed (minimizer_length, pg_device.h): the number of anchor genomes one launch co-schedules.  Only
 // while the table is empty — the minimizer length decides every key's home line.
 extern "C" int pg_table_set_coscheduled(pg_table *t, int anchors) {

@@ -407,6 +407,14 @@ def test_minimizer_length_rule():
     # w = 7 does not fit a line (profiles/r5i_inline_layout.txt); 97+ genomes keep the split layout and the wide window
     assert f(21, 123 * M, 10 * M, 0, 65) == 16 and f(21, 172 * M, 10 * M, 0, 96) == 16 and f(31, 241 * M, 10 * M, 0, 96) == 26
     assert f(21, 218 * M, 10 * M, 0, 128) == 15 and f(21, 123 * M, 10 * M, 0, 64) == 15
+    # round 6: the rule knows the table's density — sparse tables (what Index.build_table asks for where HBM is plentiful) take the
+    # wider window where the m-mers are long enough for the pangenome (profiles/r6n…r6p): configs[1] m = 15 at 1.25 keys per line,
+    # 16 at the library's 3; long genomes keep 16 (27 x 135 Mb, 8 x 300 Mb); denser than 3 (block tables) changes nothing
+    g = _lib.load().pg_minimizer_length_dense
+    for keys, first_len, kpl, want in [(232 * M, 100 * M, 1.25, 15), (232 * M, 100 * M, 1.5, 15), (232 * M, 100 * M, 3.0, 16), (232 * M, 100 * M, 0.0, 16),
+                                       (783 * M, 135 * M, 1.25, 16), (697 * M, 300 * M, 1.25, 16), (427 * M, 100 * M, 1.25, 16), (70 * M, 30 * M, 1.25, 15),
+                                       (232 * M, 100 * M, 4.5, 16), (4973 * M, 3000 * M, 3.6, 17)]:
+        assert g(21, keys, first_len, 8, 8, 8, kpl) == want, (keys, first_len, kpl, g(21, keys, first_len, 8, 8, 8, kpl), want)
     for k in range(20, 33):  # whatever the sizes: a window of 3..8, m >= 15 where k allows it
         for keys in (0, 10 ** 6, 10 ** 8, 10 ** 10):
             for first_len in (0, 10 ** 4, 10 ** 8, 3 * 10 ** 9):
