@@ -826,6 +826,7 @@ def e2e_leg(dev, args, G, contig_lens, k):
             "table_build_s": t1 - t0, "anchor_and_write_s": t2 - t1, "anchor_and_write_value": npos / (t2 - t1),
             "fasta_bytes_in": nbytes_in, "index_bytes_out": out_bytes, "bitmap_payload_bytes": npos * ((G + 7) // 8) * 101 // 100,
             "fasta_files_written_in_s": write_s, "tmp_dir_fs": root.rsplit("/", 1)[0],
+            "row_batches": idx.timings.get("batches"), "anchor_batches_s": idx.timings.get("anchor_batches_s"), "writers_wait_s": idx.timings.get("writers_wait_s"),
         }
     finally:
         shutil.rmtree(root, ignore_errors=True)

@@ -70,7 +70,8 @@ struct pg_ctx {
     struct DfSet {
         uint8_t *d_slots[2] = {nullptr, nullptr}, *d_packed[2] = {nullptr, nullptr}, *h_slots[2] = {nullptr, nullptr};
         uint32_t *d_sizes[2] = {nullptr, nullptr}, *d_offs[2] = {nullptr, nullptr}, *h_sizes[2] = {nullptr, nullptr};
-        uint32_t *d_crc = nullptr;
+        uint32_t *d_crc = nullptr, *d_hist = nullptr;
+        void *d_code = nullptr;  // the file's Huffman code and block header (k_df_build_code)
         bool ready = false, busy = false;
     } df[4];
     std::mutex df_mu;
@@ -2665,34 +2666,35 @@ extern "C" int pg_rows_epilogue(pg_result *r) {
 // GPU-compressed BGZF: k_row_deflate turns every 65280 payload bytes into a finished BGZF block in
 // a 64 KiB slot; the host copies the slots back in batches and appends the blocks to the file.
 // ---------------------------------------------------------------------------
-static constexpr uint32_t CRC_TAB_WORDS = 256 + 8 * 1024;
-// [0..256): the CRC-32 byte table; then 8 sets of 4 x 256: set j = the register after 255 * 2^j more
-// (zero) bytes, as a function of each of its four bytes
+static constexpr uint32_t CRC_TAB_WORDS = DF_CRC_TAB_WORDS;
+// [0..1024): CRC-32 slicing-by-four tables T0..T3 (T0 = the byte table); then DF_CRC_LEVELS sets of 4 x 256: set j = the
+// register after DF_CHUNK_BYTES * 2^j more (zero) bytes, as a function of each of its four bytes
 static const uint32_t *crc_tables_host() {
     static uint32_t tab[CRC_TAB_WORDS];
-    static bool init = false;
-    if (!init) {
+    static std::once_flag once;
+    std::call_once(once, [] {
         for (uint32_t i = 0; i < 256; ++i) {
             uint32_t c = i;
             for (int k = 0; k < 8; ++k) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
             tab[i] = c;
         }
-        uint32_t *T0 = tab + 256;
+        for (uint32_t k = 1; k < 4; ++k)
+            for (uint32_t b = 0; b < 256; ++b) tab[256 * k + b] = (tab[256 * (k - 1) + b] >> 8) ^ tab[tab[256 * (k - 1) + b] & 255u];
+        uint32_t *T0 = tab + 1024;
         for (uint32_t k = 0; k < 4; ++k)
             for (uint32_t b = 0; b < 256; ++b) {
                 uint32_t s = b << (8 * k);
-                for (int z = 0; z < 255; ++z) s = tab[s & 255u] ^ (s >> 8);
+                for (uint32_t z = 0; z < DF_CHUNK_BYTES; ++z) s = tab[s & 255u] ^ (s >> 8);
                 T0[256 * k + b] = s;
             }
-        for (uint32_t j = 1; j < 8; ++j) {  // set j = set j-1 applied twice
-            const uint32_t *P = tab + 256 + 1024 * (j - 1);
-            uint32_t *T = tab + 256 + 1024 * j;
+        for (uint32_t j = 1; j < DF_CRC_LEVELS; ++j) {  // set j = set j-1 applied twice
+            const uint32_t *P = tab + 1024 + 1024 * (j - 1);
+            uint32_t *T = tab + 1024 + 1024 * j;
             auto apply = [&](uint32_t x) { return P[x & 255u] ^ P[256 + ((x >> 8) & 255u)] ^ P[512 + ((x >> 16) & 255u)] ^ P[768 + (x >> 24)]; };
             for (uint32_t k = 0; k < 4; ++k)
                 for (uint32_t b = 0; b < 256; ++b) T[256 * k + b] = apply(apply(b << (8 * k)));
         }
-        init = true;
-    }
+    });
     return tab;
 }
 
@@ -2732,7 +2734,10 @@ static void df_free_buffers(pg_ctx::DfSet &d) {
         d.d_sizes[i] = d.d_offs[i] = d.h_sizes[i] = nullptr;
     }
     if (d.d_crc) hipFree(d.d_crc);
-    d.d_crc = nullptr;
+    if (d.d_hist) hipFree(d.d_hist);
+    if (d.d_code) hipFree(d.d_code);
+    d.d_crc = d.d_hist = nullptr;
+    d.d_code = nullptr;
     d.ready = false;
 }
 
@@ -2762,6 +2767,8 @@ static int write_bgzf_gpu(pg_result *r, const uint8_t *src, const std::vector<st
     };
     if (!D->ready) {
         ok(hipMalloc(reinterpret_cast<void **>(&D->d_crc), CRC_TAB_WORDS * 4));
+        ok(hipMalloc(reinterpret_cast<void **>(&D->d_hist), DF_HIST_WORDS * 4));
+        ok(hipMalloc(&D->d_code, DF_CODE_BYTES));
         for (int i = 0; i < 2; ++i) {
             ok(hipMalloc(reinterpret_cast<void **>(&D->d_slots[i]), (size_t)DF_BATCH * 65536));
             ok(hipMalloc(reinterpret_cast<void **>(&D->d_packed[i]), (size_t)DF_BATCH * 65536));
@@ -2786,6 +2793,8 @@ static int write_bgzf_gpu(pg_result *r, const uint8_t *src, const std::vector<st
         ok(hipMemcpyAsync(d_segs, segs.data(), segs.size() * sizeof(PaySeg), hipMemcpyHostToDevice, cs));
         ok(hipStreamWaitEvent(cs, r->ev[r->ev_epi ? 3 : 1], 0));
     }
+    // ONE Huffman code for the file, from a sample of its blocks (pg_deflate.hip)
+    if (e == hipSuccess && nblocks) ok(launch_deflate_code(cs, src, d_segs, (uint32_t)segs.size() - 1, total, row, D->d_hist, D->d_code));
     std::vector<uint64_t> coffs, uoffs;
     uint64_t cpos = 0;
     int rc = PG_OK;
@@ -2795,7 +2804,7 @@ static int write_bgzf_gpu(pg_result *r, const uint8_t *src, const std::vector<st
         const uint32_t nb = (uint32_t)std::min<uint64_t>(DF_BATCH, nblocks - b0);
         hipError_t x = hipMemsetAsync(D->d_slots[slot], 0, (size_t)nb * 65536, cs);
         if (x == hipSuccess)
-            x = launch_row_deflate(cs, src, d_segs, (uint32_t)segs.size() - 1, total, b0, nb, row, D->d_crc, D->d_slots[slot],
+            x = launch_row_deflate(cs, src, d_segs, (uint32_t)segs.size() - 1, total, b0, nb, row, D->d_crc, D->d_code, D->d_slots[slot],
                                    D->d_sizes[slot], getenv("PG_DEFLATE_FORCE_STORED") ? (uint32_t)atoi(getenv("PG_DEFLATE_FORCE_STORED")) : 0u, D->d_offs[slot], D->d_packed[slot]);
         if (x == hipSuccess)
             x = hipMemcpyAsync(D->h_sizes[slot], D->d_offs[slot], (size_t)(nb + 1) * 4, hipMemcpyDeviceToHost, cs);

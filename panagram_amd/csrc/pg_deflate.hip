@@ -2,25 +2,57 @@
 //
 // Replaces, for payloads resident in HBM, the per-block deflate of htslib's bgzf_write
 // (cpp/anchor.cpp:167,177) / bgzip.BGZipWriter (index.py:1035-1037): the host only writes the
-// finished blocks to the file.  One workgroup = one BGZF block (65280 payload bytes), one thread =
-// 255 of them.  Same scheme as the host's row-aware encoder (pg_bgzf.cpp): the only match tried is
-// "same byte as one row earlier" — (length, distance = row width) — literals otherwise, one dynamic
-// Huffman code per block.  Output is ordinary RFC 1951 / BGZF: header, raw DEFLATE, CRC32, ISIZE.
+// finished blocks to the file.  Same scheme as the host's row-aware encoder (pg_bgzf.cpp): the only match tried is
+// "same byte as one row earlier" — (length, distance = row width) — literals otherwise.  Output is ordinary
+// RFC 1951 / BGZF: header, raw DEFLATE (one dynamic-Huffman block), CRC32, ISIZE.
 //
-//   stage   the block's 65280 bytes -> LDS (78 KB per workgroup, two per CU), every walk reads LDS
-//   pass A  bytes -> equality bits (vs one row earlier), CRC32 of the thread's chunk
-//   tokens  a maximal run of equal bytes [s, e) becomes matches of 258, then one of r = (e-s) % 258
-//           if r >= 3, else r literals: every position knows its role from (s, e) alone, so threads
-//           tokenize their chunks independently once run boundaries crossing chunks are known
-//   pass B  symbol histogram (LDS)            thread 0: Huffman lengths / codes / block header
-//   pass C  bits per thread -> offsets -> codes OR-ed into the (zeroed) output slot
+// Round 6 (second half): ONE Huffman code per FILE instead of one per block.  Per block the old kernel spent 37 % of its
+// 1.5 M cycles in thread 0 (Huffman lengths, block header), 17 % on the histogram walk and its rank sort, and the rest in
+// three walks of 255 bytes per thread at two waves per SIMD (profiles/r6y_deflate_phases.txt: 50 GB/s at best, the bound of
+// every files -> files run).  A bitmap's blocks look alike, so:
+//   k_df_sample_hist   up to 512 blocks spread over the file -> symbol counts (the same tokens the encoder emits)
+//   k_df_build_code    one workgroup: counts + 1 for EVERY symbol (a block may hold what the sample did not) -> code lengths
+//                      (<= 15), canonical codes, the dynamic block header's bits — the same for every block of the file
+//   k_row_deflate      one workgroup = one BGZF block (65280 payload bytes), 1024 threads, one thread = 68 bytes (17 dwords:
+//                      an odd dword stride keeps the threads' LDS walks off each other's banks), 2 workgroups = 32 waves per CU:
+//       stage   the block's bytes -> LDS (every walk reads LDS)
+//       pass A  equality with one row earlier, dword-wise; CRC32 of the thread's chunk (slicing by four)
+//       scans   last / next unequal byte outside the chunk (wave shuffles + 16 partials)
+//       tokens  a maximal run of equal bytes [s, e) becomes matches of 258, then one of r = (e-s) % 258 if r >= 3, else r
+//               literals: every position knows its role from (s, e) alone, so threads tokenize their chunks independently
+//       pass C  bits per thread -> offsets (scan) -> codes OR-ed into the (zeroed) output slot
 // Not bit-identical with the host encoders; parity is the decompressed payload and the .gzi geometry.
 #include "pg_kernels.h"
 
 namespace pg {
 
-constexpr int DF_THREADS = 256;
-constexpr uint32_t DF_BLOCK = 65280, DF_CHUNK = 255;
+constexpr int DF_THREADS = 1024, DF_WAVES = DF_THREADS / 64;
+constexpr uint32_t DF_BLOCK = 65280, DF_CHUNK = DF_CHUNK_BYTES, DF_NCHUNK = DF_BLOCK / DF_CHUNK;
+static_assert(DF_BLOCK % DF_CHUNK == 0 && DF_CHUNK % 4 == 0 && ((DF_CHUNK / 4) & 1) == 1 && DF_NCHUNK <= (uint32_t)DF_THREADS &&
+              DF_NCHUNK <= (1u << DF_CRC_LEVELS), "chunks: whole dwords, an odd number of them, one per thread, within the CRC shift tables' reach");
+constexpr int DF_CODE_THREADS = 256;
+
+// what k_df_build_code leaves for the blocks of a file (DF_CODE_BYTES of device memory)
+struct DfCode {
+    uint16_t lcode[288];  // canonical codes, bit-reversed for the LSB-first stream ([286]: the distance code, 0)
+    uint8_t llen[288];    // their lengths ([286]: the distance SYMBOL of the row width)
+    uint8_t hdr[768];     // the dynamic block header's bits
+    uint32_t hdr_bits;
+};
+static_assert(sizeof(DfCode) <= DF_CODE_BYTES, "DfCode must fit the buffer the host allocates");
+
+// -DPG_DF_PHASE: a measuring build (tools/deflate_phases.py) — thread 0 of every k_row_deflate workgroup stamps the cycle counter at
+// the kernel's phase boundaries (the barriers make its timeline the workgroup's) and adds the phases' cycles to pg_df_phase_cycles.
+// Slots: 0 stage, 1 pass A, 2 run boundaries (scans), 3 CRC combine, 4 bit counts, 5 offsets (scan), 6 emission, 7 trailer,
+// 15 workgroups.
+#ifdef PG_DF_PHASE
+__device__ unsigned long long pg_df_phase_cycles[256 * 16];
+#define DF_PH_DECL uint32_t ph_t = (uint32_t)__builtin_readcyclecounter();
+#define DF_PH(i) { if (threadIdx.x == 0) { const uint32_t ph_n = (uint32_t)__builtin_readcyclecounter(); atomicAdd(&pg_df_phase_cycles[(blockIdx.x & 255u) * 16u + (i)], (unsigned long long)(ph_n - ph_t)); ph_t = ph_n; } }
+#else
+#define DF_PH_DECL
+#define DF_PH(i)
+#endif
 
 __constant__ uint16_t DF_DIST_BASE[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
 __constant__ uint8_t DF_DIST_EXTRA[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
@@ -175,51 +207,91 @@ __device__ __forceinline__ int df_len_sym(uint32_t L, uint32_t &nx, uint32_t &xv
     return (int)(4u * nx + 4u + ((x >> nx) & 3u));
 }
 
-__global__ __launch_bounds__(DF_THREADS) void k_row_deflate(const uint8_t *__restrict__ base, const PaySeg *__restrict__ segs,
-                                                            uint32_t nseg, uint64_t total, uint64_t first_block,
-                                                            uint32_t row, const uint32_t *__restrict__ crc_tabs,
-                                                            uint8_t *__restrict__ slots, uint32_t *__restrict__ sizes,
-                                                            uint32_t force_stored) {
-    __shared__ uint32_t hist[288];
-    __shared__ uint32_t crc_t[256];
-    __shared__ uint16_t lcode[288];
-    __shared__ uint8_t llen[288];
-    __shared__ int lastNE[DF_THREADS], firstNE[DF_THREADS];
-    __shared__ uint32_t tbits[DF_THREADS], crcp[DF_THREADS];
-    __shared__ uint8_t hdr[768];
-    __shared__ uint32_t hdr_bits, blk_crc, crc_acc;
-    // thread-0 scratch of the Huffman builder
-    __shared__ uint16_t h_order[288], h_kid0[576], h_kid1[576];
-    __shared__ uint32_t h_wgt[576], h_cnt[33], h_m, s_cfl[19];
-    __shared__ uint8_t s_cll[19];
-    __shared__ uint16_t s_clc[19];
-    __shared__ uint8_t h_dep[576], cl_sym[320], cl_extra[320];
 
-    struct __attribute__((packed)) U32 { uint32_t v; };
-    struct __attribute__((packed)) U64 { uint64_t v; };
-    const int tid = threadIdx.x;
-    const uint64_t blk = first_block + blockIdx.x;
-    const uint64_t L0 = blk * DF_BLOCK;
-    const uint32_t n = (uint32_t)min((uint64_t)DF_BLOCK, total - L0);  // bytes of this block
-    uint8_t *slot = slots + (uint64_t)blockIdx.x * 65536;
-    for (int i = tid; i < 288; i += DF_THREADS) hist[i] = 0;
-    if (tid == 0) crc_acc = 0;
-    crc_t[tid] = crc_tabs[tid];
-    // ---- the block's bytes into LDS once (gfx950: 160 KB per CU, two of these workgroups fit): a
-    // block inside one payload segment is copied coalesced, one that straddles segments chunk-wise ----
-    __shared__ uint8_t data[DF_BLOCK];
-    __shared__ PayCur blk_cur;
-    if (tid == 0) cur_seek(blk_cur, base, segs, nseg, L0);
+// ---- workgroup scans over the threads' values (DF_WAVES waves): wave shuffles, then the waves' partials through LDS.
+// Every thread of the workgroup calls them (barriers inside); `part` holds DF_WAVES words. ----
+__device__ __forceinline__ uint32_t df_excl_sum(uint32_t v, uint32_t *part, uint32_t &total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_up((int)inc, d);
+        if (lane >= d) inc += o;
+    }
+    if (lane == 63) part[wave] = inc;
     __syncthreads();
-    const uint32_t c0 = min(n, (uint32_t)tid * DF_CHUNK), c1 = min(n, c0 + DF_CHUNK);
-    if (blk_cur.left >= n) {  // block-uniform
-        const uint8_t *sp = blk_cur.p;
+    uint32_t basev = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < DF_WAVES; ++w) {
+        const uint32_t p = part[w];
+        if (w < wave) basev += p;
+        all += p;
+    }
+    __syncthreads();
+    total = all;
+    return basev + inc - v;
+}
+// max over the threads BEFORE this one (-1 if none)
+__device__ __forceinline__ int df_excl_max(int v, int *part) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(inc, d);
+        if (lane >= d) inc = max(inc, o);
+    }
+    if (lane == 63) part[wave] = inc;
+    int ex = __shfl_up(inc, 1);
+    if (lane == 0) ex = -1;
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < DF_WAVES; ++w)
+        if (w < wave) ex = max(ex, part[w]);
+    __syncthreads();
+    return ex;
+}
+// min over the threads BEHIND this one (`none` if there is none)
+__device__ __forceinline__ int df_rexcl_min(int v, int none, int *part) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_down(inc, d);
+        if (lane + d < 64) inc = min(inc, o);
+    }
+    if (lane == 0) part[wave] = inc;
+    int ex = __shfl_down(inc, 1);
+    if (lane == 63) ex = none;
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < DF_WAVES; ++w)
+        if (w > wave) ex = min(ex, part[w]);
+    __syncthreads();
+    return ex;
+}
+
+struct __attribute__((packed)) DfU32 { uint32_t v; };
+struct __attribute__((packed)) DfU64 { uint64_t v; };
+
+// ---- the block's bytes into LDS once: a block inside one payload segment is copied coalesced, one that straddles
+// segments chunk-wise.  Returns the block's byte count; [c0, c1) is the calling thread's chunk. ----
+__device__ __forceinline__ uint32_t df_stage(uint8_t *data, PayCur *blk_cur, const uint8_t *base, const PaySeg *segs, uint32_t nseg,
+                                             uint64_t total, uint64_t blk, uint32_t &c0, uint32_t &c1) {
+    const int tid = threadIdx.x;
+    const uint64_t L0 = blk * DF_BLOCK;
+    const uint32_t n = (uint32_t)min((uint64_t)DF_BLOCK, total - L0);
+    if (tid == 0) cur_seek(*blk_cur, base, segs, nseg, L0);
+    __syncthreads();
+    c0 = min(n, (uint32_t)tid * DF_CHUNK);
+    c1 = min(n, c0 + DF_CHUNK);
+    if (blk_cur->left >= n) {  // block-uniform
+        const uint8_t *sp = blk_cur->p;
         const uint32_t head = min(n, (uint32_t)((4 - (reinterpret_cast<uintptr_t>(sp) & 3)) & 3));  // bytes up to 4-alignment
         if ((uint32_t)tid < head) data[tid] = sp[tid];
         const uint32_t nw = (n - head) >> 2;
         // (data + head is generally not 4-aligned in LDS: packed stores)
         const uint32_t *sw = reinterpret_cast<const uint32_t *>(sp + head);
-        for (uint32_t i = tid; i < nw; i += DF_THREADS) reinterpret_cast<U32 *>(data + head + 4 * i)->v = sw[i];
+        for (uint32_t i = tid; i < nw; i += DF_THREADS) reinterpret_cast<DfU32 *>(data + head + 4 * i)->v = sw[i];
         for (uint32_t i = head + 4 * nw + tid; i < n; i += DF_THREADS) data[i] = sp[i];
     } else if (c0 < c1) {
         PayCur cur;
@@ -227,121 +299,166 @@ __global__ __launch_bounds__(DF_THREADS) void k_row_deflate(const uint8_t *__res
         for (uint32_t i = c0; i < c1; ++i) data[i] = (uint8_t)cur_next(cur, base, segs, nseg);
     }
     __syncthreads();
+    return n;
+}
 
-    // ---- pass A: chunk CRC and the chunk's first / last byte that differs from one row earlier ----
-    auto is_eq = [&](uint32_t i) { return i >= row && data[i] == data[i - row]; };
-    int fne = 0x7fffffff, lne = -1;
-    uint32_t crc = tid == 0 ? 0xFFFFFFFFu : 0u;
-    for (uint32_t i = c0; i < c1; ++i) {
+// ---- pass A over the thread's chunk, a dword at a time: its first / last byte that differs from one row earlier (bytes
+// before the block's first row differ by definition) and, CRC: the chunk's CRC32 register (slicing by four: S = T0..T3) ----
+template <bool CRC>
+__device__ __forceinline__ void df_pass_a(const uint8_t *data, const uint32_t *S, uint32_t c0, uint32_t c1, uint32_t row, int &fne, int &lne,
+                                          uint32_t &crc) {
+    fne = 0x7fffffff;
+    lne = -1;
+    crc = threadIdx.x == 0 ? 0xFFFFFFFFu : 0u;
+    uint32_t i = c0;
+    for (; i + 4 <= c1; i += 4) {  // (c0 is a multiple of 4)
+        const uint32_t v = *reinterpret_cast<const uint32_t *>(data + i);
+        if (CRC) {
+            const uint32_t x = crc ^ v;
+            crc = S[768 + (x & 255u)] ^ S[512 + ((x >> 8) & 255u)] ^ S[256 + ((x >> 16) & 255u)] ^ S[x >> 24];
+        }
+        uint32_t xr;
+        if (i >= row) {
+            xr = v ^ reinterpret_cast<const DfU32 *>(data + i - row)->v;
+        } else {
+            xr = 0;
+#pragma unroll
+            for (uint32_t b = 0; b < 4; ++b) {
+                const uint32_t idx = i + b;
+                const uint32_t d = idx >= row ? (uint32_t)(data[idx] ^ data[idx - row]) : 0xFFu;
+                xr |= d << (8 * b);
+            }
+        }
+        if (xr) {
+            if (fne == 0x7fffffff) fne = (int)(i + ((uint32_t)(__ffs((int)xr) - 1) >> 3));
+            lne = (int)(i + ((31u - (uint32_t)__clz((int)xr)) >> 3));
+        }
+    }
+    for (; i < c1; ++i) {  // (a file's last block: up to three bytes behind the last whole dword)
         const uint32_t v = data[i];
-        crc = crc_t[(crc ^ v) & 255u] ^ (crc >> 8);
+        if (CRC) crc = S[(crc ^ v) & 255u] ^ (crc >> 8);
         if (!(i >= row && data[i - row] == v)) {
             if (fne == 0x7fffffff) fne = (int)i;
             lne = (int)i;
         }
     }
-    firstNE[tid] = fne;
-    lastNE[tid] = lne;
-    crcp[tid] = crc;
-    __syncthreads();
-    // run boundaries beyond the chunk
-    int prevNE = -1, nextNE = (int)n;
-    for (int t = 0; t < tid; ++t) prevNE = max(prevNE, lastNE[t]);
-    for (int t = tid + 1; t < DF_THREADS; ++t)
-        if (firstNE[t] != 0x7fffffff) {
-            nextNE = firstNE[t];
-            break;
-        }
-    // The tokens of this thread's chunk, run by run (not position by position: lanes of a wave are in
-    // different runs, and a per-position walk pays for the longest forward scan at every step).  A run of
-    // bytes equal to one row earlier, [s, e), is cut into matches of 258 from s, then one match of
-    // r = (e - s) % 258 if r >= 3, else r literals — the same for every thread that sees part of the run.
-    auto tokens = [&](auto &&on_lit, auto &&on_match) {
-        uint32_t i = c0;
-        while (i < c1) {
-            if (!is_eq(i)) {
-                on_lit((uint32_t)data[i]);
-                ++i;
-                continue;
-            }
-            const uint32_t s = (i == c0) ? (uint32_t)(prevNE + 1) : i;
-            uint32_t e = i + 1;
-            // the run's end, eight bytes at a time (unaligned LDS words; e > i >= row here)
-            bool open_end = true;
-            while (e + 8 <= c1) {
-                const uint64_t x = reinterpret_cast<const U64 *>(data + e)->v ^ reinterpret_cast<const U64 *>(data + e - row)->v;
-                if (x) {
-                    e += (uint32_t)(__ffsll((long long)x) - 1) >> 3;
-                    open_end = false;
-                    break;
-                }
-                e += 8;
-            }
-            if (open_end)
-                while (e < c1 && is_eq(e)) ++e;
-            const uint32_t hi = e;                     // end of the run inside this chunk
-            if (e == c1) e = (uint32_t)nextNE;         // ... and its true end
-            const uint32_t R = e - s, q258 = (R / 258u) * 258u, r = R - q258;
-            uint32_t p = s + ((i - s + 257u) / 258u) * 258u;  // first match start >= i
-            for (; p < min(s + q258, hi); p += 258u) on_match(258u);
-            const uint32_t tz = s + q258;              // tail zone [tz, e)
-            if (r >= 3) {
-                if (tz >= i && tz < hi) on_match(r);
-            } else {
-                for (uint32_t q = max(i, tz); q < hi; ++q) on_lit((uint32_t)data[q]);
-            }
-            i = hi;
-        }
-    };
-    // ---- pass B: symbol histogram ----
-    tokens([&](uint32_t v) { atomicAdd(&hist[v], 1u); },
-           [&](uint32_t L) {
-               uint32_t nx, xv;
-               atomicAdd(&hist[257 + df_len_sym(L, nx, xv)], 1u);
-           });
-    __syncthreads();
+}
 
-    // ---- Huffman code of the literal/length alphabet: the used symbols are rank-sorted by the whole
-    // workgroup, thread 0 builds the tree over the sorted list, every thread derives its symbols' codes ----
-    if (tid == 0) {
-        hist[256] = 1;
-        h_m = 0;
+// The tokens of a thread's chunk [c0, c1), run by run (not position by position: lanes of a wave are in different runs, and a
+// per-position walk pays for the longest forward scan at every step).  A run of bytes equal to one row earlier, [s, e), is cut
+// into matches of 258 from s, then one match of r = (e - s) % 258 if r >= 3, else r literals — the same for every thread that
+// sees part of the run.  prevNE / nextNE: the last unequal byte before the chunk (-1: none), the first one behind it (n: none).
+template <typename Lit, typename Match>
+__device__ __forceinline__ void df_tokens(const uint8_t *data, uint32_t c0, uint32_t c1, uint32_t row, int prevNE, int nextNE, Lit &&on_lit,
+                                          Match &&on_match) {
+    auto is_eq = [&](uint32_t i) { return i >= row && data[i] == data[i - row]; };
+    uint32_t i = c0;
+    while (i < c1) {
+        if (!is_eq(i)) {
+            on_lit((uint32_t)data[i]);
+            ++i;
+            continue;
+        }
+        const uint32_t s = (i == c0) ? (uint32_t)(prevNE + 1) : i;
+        uint32_t e = i + 1;
+        // the run's end, eight bytes at a time (unaligned LDS words; e > i >= row here)
+        bool open_end = true;
+        while (e + 8 <= c1) {
+            const uint64_t x = reinterpret_cast<const DfU64 *>(data + e)->v ^ reinterpret_cast<const DfU64 *>(data + e - row)->v;
+            if (x) {
+                e += (uint32_t)(__ffsll((long long)x) - 1) >> 3;
+                open_end = false;
+                break;
+            }
+            e += 8;
+        }
+        if (open_end)
+            while (e < c1 && is_eq(e)) ++e;
+        const uint32_t hi = e;              // end of the run inside this chunk
+        if (e == c1) e = (uint32_t)nextNE;  // ... and its true end
+        const uint32_t R = e - s, q258 = (R / 258u) * 258u, r = R - q258;
+        uint32_t p = s + ((i - s + 257u) / 258u) * 258u;  // first match start >= i
+        for (; p < min(s + q258, hi); p += 258u) on_match(258u);
+        const uint32_t tz = s + q258;  // tail zone [tz, e)
+        if (r >= 3) {
+            if (tz >= i && tz < hi) on_match(r);
+        } else {
+            for (uint32_t q = max(i, tz); q < hi; ++q) on_lit((uint32_t)data[q]);
+        }
+        i = hi;
     }
+}
+
+// ---- symbol counts of sampled blocks: block (blockIdx.x * nblocks / nsamp) of the file, tokenised as the encoder will ----
+__global__ __launch_bounds__(DF_THREADS, 8) void k_df_sample_hist(const uint8_t *__restrict__ base, const PaySeg *__restrict__ segs, uint32_t nseg,
+                                                               uint64_t total, uint64_t nblocks, uint32_t nsamp, uint32_t row,
+                                                               uint32_t *__restrict__ ghist) {
+    __shared__ __attribute__((aligned(16))) uint8_t data[DF_BLOCK];
+    __shared__ uint32_t hist[288];
+    __shared__ int part[DF_WAVES];
+    __shared__ PayCur blk_cur;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 288; i += DF_THREADS) hist[i] = 0;
+    const uint64_t blk = (uint64_t)blockIdx.x * nblocks / nsamp;
+    uint32_t c0, c1;
+    const uint32_t n = df_stage(data, &blk_cur, base, segs, nseg, total, blk, c0, c1);
+    int fne, lne;
+    uint32_t crc;
+    df_pass_a<false>(data, nullptr, c0, c1, row, fne, lne, crc);
+    const int prevNE = df_excl_max(lne, part);
+    const int nextNE = df_rexcl_min(fne == 0x7fffffff ? (int)n : fne, (int)n, part);
+    df_tokens(data, c0, c1, row, prevNE, nextNE, [&](uint32_t v) { atomicAdd(&hist[v], 1u); },
+              [&](uint32_t L) {
+                  uint32_t nx, xv;
+                  atomicAdd(&hist[257 + df_len_sym(L, nx, xv)], 1u);
+              });
     __syncthreads();
-    for (int sy = tid; sy < 286; sy += DF_THREADS) {
+    for (int i = tid; i < 286; i += DF_THREADS)
+        if (hist[i]) atomicAdd(&ghist[i], hist[i]);
+}
+
+// ---- the file's Huffman code and block header out of the sampled counts: one workgroup.  Every symbol gets a code (count
+// + 1): a block may hold literals or match lengths the sample did not; the end-of-block symbol counts once per sampled block.
+// The used symbols are rank-sorted by the workgroup, thread 0 builds the tree over the sorted list and the header. ----
+__global__ __launch_bounds__(DF_CODE_THREADS) void k_df_build_code(const uint32_t *__restrict__ ghist, uint32_t nsamp, uint32_t row,
+                                                                   DfCode *__restrict__ code) {
+    __shared__ uint32_t hist[288];
+    __shared__ uint16_t lcode[288];
+    __shared__ uint8_t llen[288];
+    __shared__ uint8_t hdr[768];
+    __shared__ uint32_t hdr_bits;
+    __shared__ uint16_t h_order[288], h_kid0[576], h_kid1[576];
+    __shared__ uint32_t h_wgt[576], h_cnt[33], s_cfl[19];
+    __shared__ uint8_t s_cll[19];
+    __shared__ uint16_t s_clc[19];
+    __shared__ uint8_t h_dep[576], cl_sym[320], cl_extra[320];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 288; i += DF_CODE_THREADS) hist[i] = i < 286 ? (i == 256 ? max(1u, nsamp) : ghist[i] + 1u) : 0u;
+    for (int i = tid; i < 768; i += DF_CODE_THREADS) hdr[i] = 0;
+    __syncthreads();
+    for (int sy = tid; sy < 286; sy += DF_CODE_THREADS) {
         llen[sy] = 0;
         const uint32_t f = hist[sy];
-        if (f) {
-            uint32_t rank = 0;
-            for (int j = 0; j < 286; ++j) {
-                const uint32_t fj = hist[j];
-                rank += (fj && (fj < f || (fj == f && j < sy))) ? 1u : 0u;
-            }
-            h_order[rank] = (uint16_t)sy;
-            atomicAdd(&h_m, 1u);
+        uint32_t rank = 0;
+        for (int j = 0; j < 286; ++j) {
+            const uint32_t fj = hist[j];
+            rank += (fj < f || (fj == f && j < sy)) ? 1u : 0u;
         }
+        h_order[rank] = (uint16_t)sy;
     }
     __syncthreads();
-    if (tid == 0) df_huff_from_sorted(hist, (int)h_m, 15, llen, h_order, h_wgt, h_kid0, h_kid1, h_dep, h_cnt);
+    if (tid == 0) df_huff_from_sorted(hist, 286, 15, llen, h_order, h_wgt, h_kid0, h_kid1, h_dep, h_cnt);
     __syncthreads();
-    for (int sy = tid; sy < 286; sy += DF_THREADS) lcode[sy] = (uint16_t)df_canon_code(llen, 286, sy);
-    // ---- thread 0: block header ----
+    for (int sy = tid; sy < 286; sy += DF_CODE_THREADS) lcode[sy] = (uint16_t)df_canon_code(llen, 286, sy);
     if (tid == 0) {
-        bool any_match = false;
-        for (int i = 257; i < 286; ++i) any_match |= hist[i] != 0;
         int dsym = 0;
         while (dsym < 29 && DF_DIST_BASE[dsym + 1] <= row) ++dsym;
-        int nlit = 286;
-        while (nlit > 257 && llen[nlit - 1] == 0) --nlit;
-        const int ndist = any_match ? dsym + 1 : 1;
+        const int nlit = 286, ndist = dsym + 1;
         // code lengths of both alphabets, run-length coded (16/17/18); hist[] is reused for their counts
         uint32_t *cf = hist;  // 19 counters at hist[0..18]: the literal counts are no longer needed
-        auto all_at = [&](int a) -> uint32_t { return a < nlit ? llen[a] : ((any_match && a - nlit == dsym) ? 1u : 0u); };
+        auto all_at = [&](int a) -> uint32_t { return a < nlit ? llen[a] : ((a - nlit == dsym) ? 1u : 0u); };
         const int nall = nlit + ndist;
         int ncl_tok = 0;
-        // (counters, lengths and codes of the 19 code-length symbols live in LDS: as thread-local arrays indexed
-        // by a run-time symbol they sat in scratch memory, and this thread-serial stretch took 0.54 of the kernel's
-        // 2.3 ms)
         uint32_t *cfl = s_cfl;
         for (int i = 0; i < 19; ++i) cfl[i] = 0;
         for (int a = 0; a < nall;) {
@@ -398,21 +515,70 @@ __global__ __launch_bounds__(DF_THREADS) void k_row_deflate(const uint8_t *__res
         hdr_bits = bw.bits;
         // distance code: the one used symbol gets the 1-bit code 0
         lcode[286] = 0;
-        llen[286] = (uint8_t)dsym;  // (slot 286 carries the distance symbol for pass C)
+        llen[286] = (uint8_t)dsym;  // (slot 286 carries the distance symbol for the encoder)
+        lcode[287] = 0;
+        llen[287] = 0;
     }
+    __syncthreads();
+    for (int i = tid; i < 288; i += DF_CODE_THREADS) {
+        code->lcode[i] = lcode[i];
+        code->llen[i] = llen[i];
+    }
+    for (int i = tid; i < 768; i += DF_CODE_THREADS) code->hdr[i] = hdr[i];
+    if (tid == 0) code->hdr_bits = hdr_bits;
+}
+
+// (64 vector and 80 scalar registers: two workgroups = 32 waves per CU, MI355X_MICROARCH.md's occupancy rules)
+__global__ __launch_bounds__(DF_THREADS, 8) __attribute__((amdgpu_num_sgpr(80))) void k_row_deflate(const uint8_t *__restrict__ base, const PaySeg *__restrict__ segs,
+                                                            uint32_t nseg, uint64_t total, uint64_t first_block,
+                                                            uint32_t row, const uint32_t *__restrict__ crc_tabs,
+                                                            const DfCode *__restrict__ code, uint8_t *__restrict__ slots,
+                                                            uint32_t *__restrict__ sizes, uint32_t force_stored) {
+    __shared__ __attribute__((aligned(16))) uint8_t data[DF_BLOCK];
+    __shared__ uint32_t S[1024];  // CRC-32, slicing by four
+    __shared__ uint16_t lcode[288];
+    __shared__ uint8_t llen[288];
+    __shared__ uint32_t crcp[DF_THREADS];
+    __shared__ int part[DF_WAVES];
+    __shared__ uint32_t blk_crc, crc_acc;
+    __shared__ PayCur blk_cur;
+    const int tid = threadIdx.x;
+    DF_PH_DECL
+    const uint64_t blk = first_block + blockIdx.x;
+    uint8_t *slot = slots + (uint64_t)blockIdx.x * 65536;
+    if (tid == 0) crc_acc = 0;
+    S[tid] = crc_tabs[tid];
+    if (tid < 288) {
+        lcode[tid] = code->lcode[tid];
+        llen[tid] = code->llen[tid];
+    }
+    const uint32_t hdr_bits = code->hdr_bits;
+    uint32_t c0, c1;
+    const uint32_t n = df_stage(data, &blk_cur, base, segs, nseg, total, blk, c0, c1);  // bytes of this block
+    DF_PH(0)
+
+    // ---- pass A: chunk CRC and the chunk's first / last byte that differs from one row earlier ----
+    int fne, lne;
+    uint32_t crc;
+    df_pass_a<true>(data, S, c0, c1, row, fne, lne, crc);
+    crcp[tid] = crc;
+    DF_PH(1)
+    const int prevNE = df_excl_max(lne, part);
+    const int nextNE = df_rexcl_min(fne == 0x7fffffff ? (int)n : fne, (int)n, part);
+    DF_PH(2)
     // CRC32 of the block out of the chunk CRCs.  The register is linear in its state: after a further
     // chunk, state = shift(state) ^ crc(chunk), so the block's CRC is the XOR over the full chunks t of
-    // shift^(F-1-t)(crc_t), F = number of full chunks; shift^(2^j) is a table set (crc_tabs[256 +
-    // 1024 j ..]), so every thread applies at most 8 of them, in parallel; a short tail chunk (last
+    // shift^(F-1-t)(crc_t), F = number of full chunks; shift^(2^j) is a table set (crc_tabs[1024 +
+    // 1024 j ..]), so every thread applies at most DF_CRC_LEVELS of them, in parallel; a short tail chunk (last
     // block of a file) is appended bytewise by thread 0.
     {
         const uint32_t F = n / DF_CHUNK;
         if ((uint32_t)tid < F) {
-            uint32_t x = crcp[tid];
+            uint32_t x = crc;
             const uint32_t e = F - 1 - (uint32_t)tid;
-            for (uint32_t j = 0; j < 8; ++j)
+            for (uint32_t j = 0; j < DF_CRC_LEVELS; ++j)
                 if ((e >> j) & 1u) {
-                    const uint32_t *T = crc_tabs + 256 + 1024 * j;
+                    const uint32_t *T = crc_tabs + 1024 + 1024 * j;
                     x = T[x & 255u] ^ T[256 + ((x >> 8) & 255u)] ^ T[512 + ((x >> 16) & 255u)] ^ T[768 + (x >> 24)];
                 }
             atomicXor(&crc_acc, x);
@@ -425,51 +591,54 @@ __global__ __launch_bounds__(DF_THREADS) void k_row_deflate(const uint8_t *__res
         if (tail) {
             if (F == 0) c = crcp[0];
             else {
-                for (uint32_t z = 0; z < tail; ++z) c = crc_t[c & 255u] ^ (c >> 8);
+                for (uint32_t z = 0; z < tail; ++z) c = S[c & 255u] ^ (c >> 8);
                 c ^= crcp[F];
             }
         }
         blk_crc = c ^ 0xFFFFFFFFu;
     }
-    __syncthreads();
+    DF_PH(3)
     const uint32_t dsym = llen[286];
     const uint32_t dbits = 1u + DF_DIST_EXTRA[dsym];
     const uint32_t dval = (row - DF_DIST_BASE[dsym]) << 1;  // code 0 in bit 0, extra bits above
 
     // ---- pass C: bit counts, offsets, emission.  One walk = a lambda over the tokens ----
     auto walk = [&](auto &&emit) {
-        tokens([&](uint32_t v) { emit(lcode[v], llen[v]); },
-               [&](uint32_t L) {
-                   uint32_t nx, xv;
-                   const int ls = df_len_sym(L, nx, xv);
-                   emit(lcode[257 + ls], llen[257 + ls]);
-                   if (nx) emit(xv, nx);
-                   emit(dval, dbits);
-               });
+        df_tokens(data, c0, c1, row, prevNE, nextNE, [&](uint32_t v) { emit(lcode[v], llen[v]); },
+                  [&](uint32_t L) {
+                      uint32_t nx, xv;
+                      const int ls = df_len_sym(L, nx, xv);
+                      emit(lcode[257 + ls], llen[257 + ls]);
+                      if (nx) emit(xv, nx);
+                      emit(dval, dbits);
+                  });
         if (c0 < c1 && c1 == n) emit(lcode[256], llen[256]);  // end of block, by the owner of the last byte
     };
     uint32_t mybits = 0;
     walk([&](uint32_t, uint32_t nb) { mybits += nb; });
-    tbits[tid] = mybits;
-    __syncthreads();
-    // the deflate stream starts behind the 18-byte BGZF header: block header (written by thread 0 in
-    // front of its own tokens), then the threads' tokens in order
-    uint64_t bitpos = tid == 0 ? 144 : 144 + hdr_bits;
-    uint32_t allbits = hdr_bits;
-    for (int t = 0; t < DF_THREADS; ++t) {
-        if (t < tid) bitpos += tbits[t];
-        allbits += tbits[t];
-    }
+    DF_PH(4)
+    // the deflate stream starts behind the 18-byte BGZF header: the file's block header, then the threads' tokens in order
+    uint32_t tokbits;
+    const uint32_t before = df_excl_sum(mybits, reinterpret_cast<uint32_t *>(part), tokbits);
+    const uint32_t allbits = hdr_bits + tokbits;
     const uint32_t sbytes = (allbits + 7) / 8;
     const bool fits = sbytes <= 65536 - 18 - 8 && !force_stored;  // (force_stored: test hook for the fallback)
     uint32_t *slotw = reinterpret_cast<uint32_t *>(slot);
+    DF_PH(5)
     if (fits) {
+        // the header's whole bytes, copied by everybody; its last bits open thread 0's stream
+        const uint32_t hb = hdr_bits >> 3, hr = hdr_bits & 7u;
+        for (uint32_t b = tid; b < hb; b += DF_THREADS) slot[18 + b] = code->hdr[b];
         // every thread ORs its bits into the zeroed slot: words shared with a neighbour atomically
+        uint64_t bitpos = tid == 0 ? 144ull + 8ull * hb : 144ull + hdr_bits + before;
         uint64_t acc = 0;
-        uint32_t nacc = 0;
+        uint32_t nacc = (uint32_t)(bitpos & 31);
         uint32_t widx = (uint32_t)(bitpos >> 5);
         const uint32_t first_w = widx;
-        nacc = (uint32_t)(bitpos & 31);
+        if (tid == 0 && hr) {
+            acc = (uint64_t)(code->hdr[hb] & ((1u << hr) - 1u)) << nacc;
+            nacc += hr;
+        }
         auto flush_word = [&](bool last) {
             const uint32_t wv = (uint32_t)acc;
             if (widx == first_w || last) {
@@ -486,10 +655,7 @@ __global__ __launch_bounds__(DF_THREADS) void k_row_deflate(const uint8_t *__res
             nacc += nb;
             if (nacc >= 32) flush_word(false);
         };
-        if (tid == 0) {  // the block header goes first, byte by byte
-            acc = 0;
-            for (uint32_t b = 0; b * 8 < hdr_bits; ++b) put(hdr[b], min(8u, hdr_bits - 8 * b));
-        }
+        if (nacc >= 32) flush_word(false);  // (thread 0: the header's last bits may have filled the word)
         walk(put);
         if (nacc) {
             nacc += 32;  // flush_word subtracts 32
@@ -497,6 +663,7 @@ __global__ __launch_bounds__(DF_THREADS) void k_row_deflate(const uint8_t *__res
         }
     }
     __syncthreads();
+    DF_PH(6)
     if (!fits) {  // incompressible: a stored block (BFINAL=1, BTYPE=00, LEN, NLEN, the bytes)
         if (tid == 0) {
             slot[18] = 1;
@@ -519,6 +686,10 @@ __global__ __launch_bounds__(DF_THREADS) void k_row_deflate(const uint8_t *__res
         for (int i = 0; i < 4; ++i) tr[4 + i] = (uint8_t)(n >> (8 * i));
         sizes[blockIdx.x] = tot;
     }
+    DF_PH(7)
+#ifdef PG_DF_PHASE
+    if (tid == 0) atomicAdd(&pg_df_phase_cycles[(blockIdx.x & 255u) * 16u + 15], 1ull);
+#endif
 }
 
 // finished blocks of a batch packed back to back (what goes to the file): offsets by one workgroup,
@@ -556,15 +727,45 @@ hipError_t preload_deflate_kernels() {
     return hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(k_bgzf_offsets));
 }
 
+// the file's code: symbol counts of up to DF_SAMPLE_BLOCKS of its blocks, then lengths / codes / header -> `code`
+// (DF_CODE_BYTES), `hist` = DF_HIST_WORDS words of scratch
+hipError_t launch_deflate_code(hipStream_t st, const uint8_t *base, const PaySeg *segs, uint32_t nseg, uint64_t total, uint32_t row,
+                               uint32_t *hist, void *code) {
+    const uint64_t nblocks = (total + DF_BLOCK - 1) / DF_BLOCK;
+    if (nblocks == 0) return hipSuccess;
+    const uint32_t nsamp = (uint32_t)std::min<uint64_t>(nblocks, DF_SAMPLE_BLOCKS);
+    hipError_t e = hipMemsetAsync(hist, 0, DF_HIST_WORDS * 4, st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_df_sample_hist, dim3(nsamp), dim3(DF_THREADS), 0, st, base, segs, nseg, total, nblocks, nsamp, row, hist);
+    hipLaunchKernelGGL(k_df_build_code, dim3(1), dim3(DF_CODE_THREADS), 0, st, hist, nsamp, row, static_cast<DfCode *>(code));
+    return hipGetLastError();
+}
+
 hipError_t launch_row_deflate(hipStream_t st, const uint8_t *base, const PaySeg *segs, uint32_t nseg, uint64_t total,
-                              uint64_t first_block, uint32_t nblocks, uint32_t row, const uint32_t *crc_tabs, uint8_t *slots,
-                              uint32_t *sizes, uint32_t force_stored, uint32_t *offs, uint8_t *packed) {
+                              uint64_t first_block, uint32_t nblocks, uint32_t row, const uint32_t *crc_tabs, const void *code,
+                              uint8_t *slots, uint32_t *sizes, uint32_t force_stored, uint32_t *offs, uint8_t *packed) {
     if (nblocks == 0) return hipSuccess;
     hipLaunchKernelGGL(k_row_deflate, dim3(nblocks), dim3(DF_THREADS), 0, st, base, segs, nseg, total, first_block, row,
-                       crc_tabs, slots, sizes, force_stored);
+                       crc_tabs, static_cast<const DfCode *>(code), slots, sizes, force_stored);
     hipLaunchKernelGGL(k_bgzf_offsets, dim3(1), dim3(1024), 0, st, sizes, nblocks, offs);
     hipLaunchKernelGGL(k_bgzf_pack, dim3(nblocks), dim3(256), 0, st, slots, sizes, offs, packed);
     return hipGetLastError();
 }
 
 }  // namespace pg
+
+#ifdef PG_DF_PHASE
+extern "C" int pg_debug_df_phase_cycles(unsigned long long *out16, int reset) {
+    hipDeviceSynchronize();
+    static unsigned long long all[256 * 16];
+    if (hipMemcpyFromSymbol(all, HIP_SYMBOL(pg::pg_df_phase_cycles), sizeof all) != hipSuccess) return -1;
+    for (int i = 0; i < 16; ++i) out16[i] = 0;
+    for (int b = 0; b < 256; ++b)
+        for (int i = 0; i < 16; ++i) out16[i] += all[b * 16 + i];
+    if (reset) {
+        for (auto &x : all) x = 0;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(pg::pg_df_phase_cycles), all, sizeof all) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif

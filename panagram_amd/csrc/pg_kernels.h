@@ -157,9 +157,16 @@ hipError_t launch_lowres(hipStream_t st, uint32_t ngenomes, const AnchorDesc *ad
 struct PaySeg {
     uint64_t lstart, doff;
 };
+// (a thread of k_row_deflate takes DF_CHUNK_BYTES of a block; crc_tabs: 1024 words of CRC-32 slicing-by-four tables, then
+// DF_CRC_LEVELS sets of 4 x 256: set j = the register after DF_CHUNK_BYTES * 2^j more zero bytes, by each of its four bytes)
+constexpr uint32_t DF_CHUNK_BYTES = 68, DF_CRC_LEVELS = 10, DF_CRC_TAB_WORDS = 1024 + DF_CRC_LEVELS * 1024;
+constexpr uint32_t DF_CODE_BYTES = 2048, DF_HIST_WORDS = 288, DF_SAMPLE_BLOCKS = 512;
+// one Huffman code per file: symbol counts of up to DF_SAMPLE_BLOCKS blocks -> code + block header in `code` (DF_CODE_BYTES)
+hipError_t launch_deflate_code(hipStream_t st, const uint8_t *base, const PaySeg *segs, uint32_t nseg, uint64_t total, uint32_t row,
+                               uint32_t *hist, void *code);
 hipError_t launch_row_deflate(hipStream_t st, const uint8_t *base, const PaySeg *segs, uint32_t nseg, uint64_t total,
-                              uint64_t first_block, uint32_t nblocks, uint32_t row, const uint32_t *crc_tabs, uint8_t *slots,
-                              uint32_t *sizes, uint32_t force_stored, uint32_t *offs, uint8_t *packed);
+                              uint64_t first_block, uint32_t nblocks, uint32_t row, const uint32_t *crc_tabs, const void *code,
+                              uint8_t *slots, uint32_t *sizes, uint32_t force_stored, uint32_t *offs, uint8_t *packed);
 hipError_t launch_window_stats(hipStream_t st, uint32_t ngenomes, const uint8_t *rows, uint64_t nrows, uint32_t nwin,
                                uint32_t pieces, const uint64_t *starts, const uint64_t *ends, unsigned long long *hist,
                                unsigned long long *cs);

@@ -740,6 +740,7 @@ class Index:
         return True
 
     def _run_planned(self, ThreadPoolExecutor):
+        import time
         mode, nblocks = self.plan_sharding()
         self._check_plan_agreed((mode, nblocks, self._block_keys_per_line if mode == "genome" else 0.0))
         if mode == "genome":
@@ -786,13 +787,21 @@ class Index:
         with ThreadPoolExecutor(max_workers=self.writer_jobs(payload)) as pool:
             previous = None
             for batch in batches:
+                t0 = time.perf_counter()
                 job = self._anchor_batch(tbl, batch)
+                t1 = time.perf_counter()
                 futs = [pool.submit(self.genomes[name].write_from_result, job, gi) for gi, name in enumerate(batch)]
                 if previous is not None:  # at most two batches of rows resident
                     self._finish_batch(*previous)
                 previous = (job, batch, futs)
+                # (where the time of a multi-batch run goes: rows allocated + anchored + tabulated / waiting for the writers of the batch before)
+                self.timings["anchor_batches_s"] = self.timings.get("anchor_batches_s", 0.0) + t1 - t0
+                self.timings["writers_wait_s"] = self.timings.get("writers_wait_s", 0.0) + time.perf_counter() - t1
+            t1 = time.perf_counter()
             if previous is not None:
                 self._finish_batch(*previous)
+            self.timings["writers_wait_s"] = self.timings.get("writers_wait_s", 0.0) + time.perf_counter() - t1
+            self.timings["batches"] = len(batches)
         self.close()
 
     @staticmethod
