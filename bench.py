@@ -30,7 +30,12 @@ import threading
 import time
 
 import numpy as np
-import torch
+# (the files -> files child of baseline_config_legs runs WITHOUT torch, as `python -m panagram_amd index` does: with torch in the
+# process the library shares torch's bundled HIP runtime, whose large allocations cost 24 ms per GB — the 90 GB table of
+# BASELINE configs[3] then takes 2.2 s to create instead of 0.2)
+_TORCHLESS_CHILD = any(a.startswith("run:") for a in sys.argv[1:])
+if not _TORCHLESS_CHILD:
+    import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -560,17 +565,52 @@ def baseline_config_legs(ctx, dev, args):
             if free < 80e9:
                 e2e = {"skipped": f"{free / 1e9:.0f} GB free under {tempfile.gettempdir()}: 13 GB of FASTA + the index need more"}
             else:
-                a4 = argparse.Namespace(**vars(args))
-                a4.d, a4.seed = 0.005, args.seed + 4
-                e2e = e2e_leg(dev, a4, 64, [20_000_000] * 10, 31)
-                e2e["config"] = "BASELINE.json configs[3]: 64 x 200 Mb, k=31, files -> files"
-                e2e["payload_gb_per_s"] = e2e["bitmap_payload_bytes"] / e2e["anchor_and_write_s"] / 1e9
-                e2e["index_write_gb_per_s"] = e2e["index_bytes_out"] / e2e["anchor_and_write_s"] / 1e9
+                # In a process of its own, as a user's `panagram index` is: this one has allocated and freed hundreds of GB by
+                # now, and hipFree's cost is paid inside the NEXT large hipMalloc on this stack (40 ms per GB: the 90 GB table of
+                # this leg took 2.5 s to create here, 0.25 s in a fresh process).
+                import subprocess
+                ctx.trim()
+                torch.cuda.empty_cache()
+                root = tempfile.mkdtemp(prefix="pg_bench_e2e4_")
+                try:
+                    recs = []
+                    # (the FASTA files by one process, Index.run() in the next — twice: the first process that touches 150 GB of a
+                    # box's HBM may pay for it once, 24 ms per GB inside its hipMallocs — 2.6 s for the table, 1 s for the rows —
+                    # whatever it runs; a second process right behind it does not.  Both on the line, the second as the figure.)
+                    for mode in ("write", "run", "run"):
+                        if mode == "run":
+                            shutil.rmtree(os.path.join(root, "idx"), ignore_errors=True)
+                        cmd = [sys.executable, os.path.abspath(__file__), "--e2e-config4-child", f"{mode}:{root}", "--seed", str(args.seed)]
+                        p = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+                        lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+                        if p.returncode != 0 or not lines:
+                            raise RuntimeError(f"child ({mode}) exited {p.returncode}: {p.stderr[-400:]}")
+                        recs.append(json.loads(lines[-1]))
+                    e2e = recs[2]
+                    e2e["fasta_files_written_in_s"] = recs[0].get("fasta_files_written_in_s")
+                    e2e["first_process_on_this_box"] = {k_: recs[1].get(k_) for k_ in ("seconds", "read_parse_sketch_s", "table_insert_s", "anchor_and_write_s", "anchor_batches_s", "writers_wait_s")}
+                    e2e["process"] = ("a fresh process without torch, as `python -m panagram_amd index` is (python bench.py --e2e-config4-child "
+                                      "run:DIR), the FASTA files written by another")
+                finally:
+                    shutil.rmtree(root, ignore_errors=True)
         except Exception as e:  # noqa: BLE001
             e2e = {"error": f"{type(e).__name__}: {e}"}
         ctx.trim()
         torch.cuda.empty_cache()
     return legs, e2e
+
+
+def e2e_config4(dev, args, prewritten=None, write_only=None):
+    """BASELINE.json configs[3] files -> files: 64 synthetic 200 Mb genomes, k = 31, d = 0.005, every genome anchored"""
+    a4 = argparse.Namespace(**vars(args))
+    a4.d, a4.seed = 0.005, args.seed + 4
+    e2e = e2e_leg(dev, a4, 64, [20_000_000] * 10, 31, prewritten=prewritten, write_only=write_only)
+    if write_only:
+        return e2e
+    e2e["config"] = "BASELINE.json configs[3]: 64 x 200 Mb, k=31, files -> files"
+    e2e["payload_gb_per_s"] = e2e["bitmap_payload_bytes"] / e2e["anchor_and_write_s"] / 1e9
+    e2e["index_write_gb_per_s"] = e2e["index_bytes_out"] / e2e["anchor_and_write_s"] / 1e9
+    return e2e
 
 
 def wide_legs(ctx, dev, args, k=21):
@@ -778,7 +818,7 @@ def write_fasta_from_device(path, names, contigs, width=80):
                 f.write(t[full:].cpu().numpy().tobytes() + b"\n")
 
 
-def e2e_leg(dev, args, G, contig_lens, k):
+def e2e_leg(dev, args, G, contig_lens, k, prewritten=None, write_only=None):
     """anchor END TO END — FASTA files on disk -> (table) -> every anchor's BGZF / .gzi / TSV files on disk
     through the product's `panagram index` entry, Index.run() (the reference times the whole rule,
     workflow/Snakefile:43-44).  Outside the timed region of `value`; the table build (FASTA read + GPU parse + sketch +
@@ -788,21 +828,27 @@ def e2e_leg(dev, args, G, contig_lens, k):
     import tempfile
     import pandas as pd
     from panagram_amd import index as pidx
-    root = tempfile.mkdtemp(prefix="pg_bench_e2e_")
+    # (prewritten / write_only: the FASTA files written by one process, Index.run() timed in another that has allocated and freed
+    # nothing yet — see baseline_config_legs)
+    root = prewritten or write_only or tempfile.mkdtemp(prefix="pg_bench_e2e_")
     try:
-        genomes = synth_genomes_device(G, contig_lens, args.d, args.seed, dev)
-        rows, nbytes_in = ["name\tfasta"], 0
-        t0 = time.perf_counter()
-        for g in range(G):
-            fa = os.path.join(root, f"g{g}.fa")
-            write_fasta_from_device(fa, [f"chr{c + 1}" for c in range(len(contig_lens))], genomes[g])
-            nbytes_in += os.path.getsize(fa)
-            rows.append(f"g{g}\t{fa}")
-        del genomes
-        torch.cuda.empty_cache()
-        with open(os.path.join(root, "samples.tsv"), "w") as f:
-            f.write("\n".join(rows) + "\n")
-        write_s = time.perf_counter() - t0
+        nbytes_in, write_s = 0, None
+        if prewritten is None:
+            genomes = synth_genomes_device(G, contig_lens, args.d, args.seed, dev)
+            rows = ["name\tfasta"]
+            t0 = time.perf_counter()
+            for g in range(G):
+                fa = os.path.join(root, f"g{g}.fa")
+                write_fasta_from_device(fa, [f"chr{c + 1}" for c in range(len(contig_lens))], genomes[g])
+                rows.append(f"g{g}\t{fa}")
+            del genomes
+            torch.cuda.empty_cache()
+            with open(os.path.join(root, "samples.tsv"), "w") as f:
+                f.write("\n".join(rows) + "\n")
+            write_s = time.perf_counter() - t0
+            if write_only:
+                return {"fasta_files_written_in_s": write_s}
+        nbytes_in = sum(os.path.getsize(os.path.join(root, f"g{g}.fa")) for g in range(G))
         t0 = time.perf_counter()
         import contextlib
         with contextlib.redirect_stdout(sys.stderr):  # (the CLI's progress lines: stdout carries the ONE JSON line)
@@ -829,7 +875,8 @@ def e2e_leg(dev, args, G, contig_lens, k):
             "row_batches": idx.timings.get("batches"), "anchor_batches_s": idx.timings.get("anchor_batches_s"), "writers_wait_s": idx.timings.get("writers_wait_s"),
         }
     finally:
-        shutil.rmtree(root, ignore_errors=True)
+        if not (prewritten or write_only):
+            shutil.rmtree(root, ignore_errors=True)
 
 
 def _revcomp_ascii(t):
@@ -1161,12 +1208,18 @@ def main():
     ap.add_argument("--no-config5", action="store_true", help="skip the BASELINE configs[4] leg (8 x 3 Gb, d=0.05, 8 genome blocks as passes on this GPU)")
     ap.add_argument("--settle-s", type=float, default=0.4, help="seconds of untimed steps before the warm-up steps (the shader clock settles; 0: none)")
     ap.add_argument("--cpu-sample-mb", type=float, default=20.0, help="bases per thread of the CPU baseline leg (about 12 s of CPU work)")
+    ap.add_argument("--e2e-config4-child", default="", metavar="write:DIR|run:DIR", help=argparse.SUPPRESS)  # (baseline_config_legs' files -> files leg, in processes of its own)
     ap.add_argument("--emulate-rank", type=str, default="", metavar="R/N",
                     help="one process plays rank R of an N-rank contig-sharded run (no collective): the N x longer "
                          "pangenome, the replicated table and rank R's contig group, for checking the multi-GPU "
                          "set-up on a one-GPU box; the reported value is this rank's alone")
     args = ap.parse_args()
 
+    if args.e2e_config4_child:
+        mode, d = args.e2e_config4_child.split(":", 1)
+        dev = None if mode == "run" else torch.device("cuda", 0)
+        print(json.dumps(e2e_config4(dev, args, prewritten=d if mode == "run" else None, write_only=d if mode == "write" else None)))
+        return
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback)")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
