@@ -439,6 +439,50 @@ def test_gpu_bgzf_multi_batch(ctx, tmp_path):
         x.close()
 
 
+@pytest.mark.parametrize("ngenomes", [8, 27])
+def test_gpu_bgzf_one_code_per_file_covers_what_the_sample_did_not_see(ctx, ngenomes, tmp_path):
+    """k_row_deflate codes a whole file with ONE Huffman code built from a sample of its blocks (every fourth block here: 2048
+    blocks, 512 sampled).  Blocks the sample never saw hold byte values, run lengths and incompressible stretches of their own:
+    every symbol must have a code (k_df_build_code counts each at least once), a block that does not fit falls back to a stored
+    block, and the file inflates to the rows."""
+    import torch
+    from panagram_amd import engine
+    nb = (ngenomes + 7) // 8
+    npos = 2048 * 65280 // nb + 12345
+    ss = engine.SeqSet(ctx, [npos + 20])
+    res = engine.AnchorResult.rows_container(ctx, 21, ngenomes, ss)
+    rows = res.rows_tensor()[:npos * nb]  # (the buffer is padded behind the last row)
+    gen = torch.Generator(device=rows.device)
+    gen.manual_seed(5)
+    # what the sampled blocks look like: two row values in long runs
+    base = torch.where(torch.rand(rows.numel() // (64 * nb) + 1, device=rows.device, generator=gen) < 0.3, 0x81, 0x7F).to(torch.uint8)
+    rows.copy_(base.repeat_interleave(64 * nb)[:rows.numel()])
+    blk = 65280
+    # unsampled blocks (the sample takes blocks 0, 4, 8, ...): every byte value, incompressible
+    for b in (1, 2, 1027):
+        rows[b * blk:(b + 1) * blk] = torch.randint(0, 256, (blk,), dtype=torch.uint8, device=rows.device, generator=gen)
+    # ... every run length 1..300 between rare separator bytes (all 29 length symbols), in an unsampled block
+    lens = torch.arange(1, 301, device=rows.device)
+    runs = torch.full((int(lens.sum()) + 300,), 0x33, dtype=torch.uint8, device=rows.device)
+    runs[torch.cumsum(lens + 1, 0) - 1] = torch.arange(300, device=rows.device).to(torch.uint8) | 0x80
+    rows[5 * blk:5 * blk + min(blk, runs.numel())] = runs[:blk]
+    # ... and rare literals sprinkled over another one
+    idx = 9 * blk + torch.arange(0, blk, 97, device=rows.device)
+    rows[idx] = (torch.arange(idx.numel(), device=rows.device) % 251 + 3).to(torch.uint8)
+    torch.cuda.synchronize()
+    want = rows.cpu().numpy().tobytes()
+    res.rows_epilogue()  # (a rows container is written once its statistics have been enqueued)
+    gz, gzi = str(tmp_path / "h.gz"), str(tmp_path / "h.gzi")
+    res.write_bgzf(1, gz, gzi, level=-2)
+    assert gzip.open(gz, "rb").read() == want
+    g = np.fromfile(gzi, "<u8")
+    nblocks = (len(want) + 65279) // 65280
+    assert nblocks > 2048 and g[0] == nblocks - 1 and np.array_equal(g[2::2], np.arange(1, nblocks, dtype=np.uint64) * 65280)
+    assert os.path.getsize(gz) < 0.05 * len(want)  # (the long runs compress; the three random blocks are stored)
+    res.close()
+    ss.close()
+
+
 def _same_index_payload(one, many, steps=(1, 100)):
     """two index trees hold the same index: decompressed bitmaps and every table byte for byte (the compressed
     bytes and the .gzi follow the BGZF block boundaries, which may differ), the .gzi addressing its own payload"""
