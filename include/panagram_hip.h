@@ -69,6 +69,12 @@ int pg_ctx_destroy(pg_ctx *ctx);
 int pg_ctx_trim(pg_ctx *ctx);
 /* device memory free for new tables / results (cached row buffers counted as free), and the device's total */
 int pg_ctx_mem_info(pg_ctx *ctx, uint64_t *free_bytes, uint64_t *total_bytes);
+/* page-locked host memory for the buffers a caller hands to the library (ownership: "caller allocates all host
+ * buffers, ideally pinned"): a FASTA image read straight into one goes up by DMA instead of through the runtime's staging
+ * copy of pageable memory, and re-used it costs no page faults per file (Index.load_inputs: index.py:922-930's reading of
+ * the sample files).  Free with pg_host_free, any time before the context is destroyed. */
+int pg_host_alloc(pg_ctx *ctx, uint64_t nbytes, void **out);
+int pg_host_free(pg_ctx *ctx, void *p);
 /* adopt an external hipStream_t (e.g. torch.cuda.current_stream().cuda_stream; NULL is
  * HIP's legacy default stream, which is what torch's default stream is); use_own != 0
  * restores the context's own non-blocking stream instead. */

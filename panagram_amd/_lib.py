@@ -35,6 +35,8 @@ PROTOTYPES = {
     "pg_ctx_destroy": (C.c_int, [_vp]),
     "pg_ctx_trim": (C.c_int, [_vp]),
     "pg_ctx_mem_info": (C.c_int, [_vp, _u64p, _u64p]),
+    "pg_host_alloc": (C.c_int, [_vp, C.c_uint64, C.POINTER(C.c_void_p)]),
+    "pg_host_free": (C.c_int, [_vp, _vp]),
     "pg_ctx_set_stream": (C.c_int, [_vp, _vp, C.c_int]),
     "pg_ctx_synchronize": (C.c_int, [_vp]),
     "pg_device_alloc": (C.c_int, [_vp, C.c_uint64, _vpp]),

@@ -304,6 +304,31 @@ static void row_free(pg_ctx *c, uint8_t *p, uint64_t cap) {
     hipFree(p);
 }
 
+extern "C" int pg_host_alloc(pg_ctx *c, uint64_t nbytes, void **out) {
+    PG_API_BEGIN
+    if (!c || !out) return fail(PG_E_INVALID, "pg_host_alloc: NULL argument");
+    if (int r = use_device(c)) return r;
+    *out = nullptr;
+    hipError_t e = hipHostMalloc(out, std::max<uint64_t>(nbytes, 1), hipHostMallocDefault);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        *out = nullptr;
+        return fail(PG_E_HIP, "hipHostMalloc(%llu bytes) failed: %s", (unsigned long long)nbytes, hipGetErrorString(e));
+    }
+    return PG_OK;
+    PG_API_END
+}
+
+extern "C" int pg_host_free(pg_ctx *c, void *p) {
+    PG_API_BEGIN
+    if (!c) return fail(PG_E_INVALID, "ctx is NULL");
+    if (!p) return PG_OK;
+    if (int r = use_device(c)) return r;
+    HIP_TRY(hipHostFree(p));
+    return PG_OK;
+    PG_API_END
+}
+
 extern "C" int pg_ctx_mem_info(pg_ctx *c, uint64_t *free_bytes, uint64_t *total_bytes) {
     PG_API_BEGIN
     if (!c) return fail(PG_E_INVALID, "ctx is NULL");
@@ -1620,8 +1645,40 @@ extern "C" int pg_seqset_from_fasta(pg_ctx *ctx, const void *text_, uint64_t nby
         uint64_t s, e;
     };
     std::vector<Rec> recs;
+    // A large text's header lines are looked for ON THE DEVICE once the text is there (k_text_headers): the host's memchr pass
+    // over the same bytes runs at 20 GB/s — 10 ms per 200 MB, more than the DMA of a page-locked text takes (4 ms), and beside
+    // the staging copy of a pageable one it competes for the same memory.  The few positions come back sorted; more than
+    // HDR_CAP of them (a read set passed off as FASTA), or any error: the host looks for itself, as for small texts.
+    constexpr uint32_t HDR_CAP = 1u << 16;
+    std::vector<uint64_t> hdrs;
+    bool have_hdrs = false;
+    if (nbytes >= (4u << 20) && !getenv("PG_FASTA_HOST_SCAN")) {
+        if (up.th.joinable()) up.th.join();
+        uint64_t *d_hdr = nullptr;
+        uint32_t *d_nhdr = nullptr, nh = 0;
+        if (e_up == hipSuccess && hipMalloc(reinterpret_cast<void **>(&d_hdr), (size_t)HDR_CAP * 8) == hipSuccess &&
+            hipMalloc(reinterpret_cast<void **>(&d_nhdr), 4) == hipSuccess) {
+            hipStream_t st = ctx->stream;
+            if (launch_text_headers(st, d_text, nbytes, d_hdr, HDR_CAP, d_nhdr) == hipSuccess &&
+                hipMemcpyAsync(&nh, d_nhdr, 4, hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess && nh <= HDR_CAP) {
+                hdrs.resize(nh);
+                if (nh == 0 || hipMemcpy(hdrs.data(), d_hdr, (size_t)nh * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+                    std::sort(hdrs.begin(), hdrs.end());
+                    have_hdrs = true;
+                }
+            }
+        }
+        (void)hipGetLastError();
+        if (d_hdr) hipFree(d_hdr);
+        if (d_nhdr) hipFree(d_nhdr);
+    }
+    size_t hdr_at = 0;
     // first header: at offset 0 or right after a newline; anything before it is ignored
     auto next_header = [&](uint64_t from) -> uint64_t {
+        if (have_hdrs) {  // (asked for in ascending order)
+            while (hdr_at < hdrs.size() && hdrs[hdr_at] < from) ++hdr_at;
+            return hdr_at < hdrs.size() ? hdrs[hdr_at] : nbytes;
+        }
         uint64_t p = from;
         while (p < nbytes) {
             const void *q = memchr(text + p, '>', nbytes - p);

@@ -62,6 +62,8 @@ struct TextChunk {
 hipError_t launch_text_pack(hipStream_t st, const uint8_t *d_text, const TextChunk *d_chunks, uint64_t nchunks,
                             const uint64_t *d_rec_chunk0, uint32_t nrec, uint32_t *d_counts, uint64_t *d_base,
                             uint64_t *d_rec_len, const SeqDesc *sd, uint64_t *seqw, uint32_t *nmw, uint32_t *has_n);
+// header lines of a FASTA text on the device ('>' at offset 0 or behind a line feed), unordered: count[0] of them, the first cap in d_out
+hipError_t launch_text_headers(hipStream_t st, const uint8_t *d_text, uint64_t nbytes, uint64_t *d_out, uint32_t cap, uint32_t *d_count);
 hipError_t launch_seq_tailmask(hipStream_t st, const SeqDesc *sd, uint32_t n, uint64_t *seqw, uint32_t *nmw);
 // packed contigs gathered into another seqset's planes: job i copies nwords words of both planes and the contig's flag
 struct SeqCopy {

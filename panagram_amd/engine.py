@@ -118,6 +118,10 @@ class Context(_Owner):
         """give back device memory kept for reuse (row buffers of closed results)"""
         check(self._lib.pg_ctx_trim(self._h))
 
+    def host_buffer(self, nbytes: int) -> "HostBuffer":
+        """page-locked host memory (pg_host_alloc): a numpy uint8 array that goes to the device by DMA"""
+        return HostBuffer(self, nbytes)
+
     def torch_device(self):
         """the torch device the context's buffers live on (torch only carries the collectives' buffers)"""
         import torch
@@ -161,6 +165,34 @@ class DeviceBuffer:
         try:
             self.close()
         except Exception:
+            pass
+
+
+class HostBuffer:
+    """``nbytes`` of page-locked host memory as ``.array`` (numpy uint8); ``close()`` gives it back (not before every view of
+    ``.array`` is out of use)."""
+
+    def __init__(self, ctx: Context, nbytes: int):
+        import threading
+        self.ctx, self.nbytes = ctx, int(nbytes)
+        self._lock = threading.Lock()  # (a pool may give its buffers back from a helper thread while the context is being closed)
+        p = C.c_void_p()
+        check(ctx._lib.pg_host_alloc(ctx._h, self.nbytes, C.byref(p)))
+        self._p = p
+        self.array = np.ctypeslib.as_array((C.c_uint8 * max(1, self.nbytes)).from_address(p.value))[:self.nbytes]
+        ctx._adopt(self)  # (closed with the context at the latest)
+
+    def close(self) -> None:
+        with self._lock:
+            p, self._p = self._p, None
+            if p is not None and p.value and self.ctx._h:
+                self.array = None
+                check(self.ctx._lib.pg_host_free(self.ctx._h, p))
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001 — interpreter shutdown / a context that is gone already
             pass
 
 

@@ -88,6 +88,77 @@ def _read_fasta_image(path: str) -> np.ndarray:
     return np.fromfile(path, dtype=np.uint8)
 
 
+class _PinnedPool:
+    """up to ``budget`` page-locked buffers of ``cap`` bytes (engine.HostBuffer) that go round between the reader threads and
+    the thread that uploads their contents; a reader locks the memory of a new one itself (in parallel with the others' reads)
+    as long as the budget is not spent.  ``get()`` returns None once locking memory has failed: read into pageable memory."""
+
+    def __init__(self, make, cap: int, budget: int):
+        import queue
+        import threading
+        self.make, self.cap, self.budget = make, cap, budget
+        self.free, self.lock, self.made, self.failed, self.all = queue.Queue(), threading.Lock(), 0, False, []
+
+    def get(self):
+        import queue
+        try:
+            return self.free.get_nowait()
+        except queue.Empty:
+            pass
+        with self.lock:
+            create = not self.failed and self.made < self.budget
+            if create:
+                self.made += 1
+        if create:
+            try:
+                buf = self.make(self.cap)
+            except Exception:  # noqa: BLE001 — no memory to lock
+                with self.lock:
+                    self.made -= 1
+                    self.failed = True
+                return None
+            with self.lock:
+                self.all.append(buf)
+            return buf
+        if self.failed and not self.made:
+            return None
+        return self.free.get()
+
+    def put(self, buf) -> None:
+        self.free.put(buf)
+
+    def close(self) -> None:
+        for b in self.all:
+            b.close()
+        self.all = []
+
+
+def _read_fasta_pinned(path: str, pool: _PinnedPool):
+    """a plain FASTA file read into a page-locked buffer of ``pool``: ``(uint8 view of the text, the buffer)`` — the caller puts
+    the buffer back once the text is on the device; compressed files, and any file when no memory can be locked, as
+    ``_read_fasta_image`` reads them: ``(image, None)``"""
+    if path.endswith((".gz", ".bgz")):
+        return _read_fasta_image(path), None
+    buf = pool.get()
+    if buf is None:
+        return _read_fasta_image(path), None
+    try:
+        n = 0
+        with open(path, "rb", buffering=0) as f:
+            view = memoryview(buf.array)
+            while n < len(view):
+                got = f.readinto(view[n:])
+                if not got:
+                    break
+                n += got
+            if n == len(view) and f.read(1):  # (the file grew since it was sized)
+                raise OSError(f"{path} is larger than when the index was prepared")
+        return buf.array[:n], buf
+    except BaseException:
+        pool.put(buf)
+        raise
+
+
 def is_fastq(path) -> bool:
     return isinstance(path, str) and path.endswith(FASTQ_SUFFIXES)
 
@@ -412,6 +483,19 @@ class Index:
             self._ctx = engine.Context(self.device)
         return self._ctx
 
+    def _pinned_reader_pool(self, names, count: int):
+        """a ``_PinnedPool`` for reading the plain FASTA files of ``names`` — buffers as large as the largest of them, at most
+        ``count`` and 8 GB in all — or None: nothing to read that way, or an engine without page-locked buffers (the CPU tests'
+        stand-in); the files are then read into pageable arrays"""
+        sizes = [os.path.getsize(self.genomes[n].fasta) for n in names if not self.genomes[n].fasta.endswith((".gz", ".bgz"))]
+        make = getattr(self.context, "host_buffer", None)
+        if not sizes or make is None or os.environ.get("PG_PINNED_READS", "1") in ("0", ""):
+            return None
+        cap = max(sizes) + 1  # (+ 1: a file that grew is noticed)
+        if cap > (4 << 30):
+            return None
+        return _PinnedPool(make, cap, max(2, min(count, len(sizes), (8 << 30) // cap)))
+
     def load_inputs(self):
         """Every sample's sequence parsed and packed on the GPU (0.375 byte per base), with the HyperLogLog
         registers of its distinct canonical k-mers.  Returns ``[(name, genome, seqset, min_count, registers)]`` in
@@ -424,19 +508,35 @@ class Index:
         t_start = time.perf_counter()
         inputs = []
         sketch = engine.KmerSketch(self.context, self.k)
-        # the FASTA files are read a few ahead by host threads while the GPU parses and sketches
+        # the FASTA files are read a few ahead by host threads while the GPU parses and sketches — plain files straight into a
+        # small pool of page-locked buffers (engine.HostBuffer) that go round: the text then goes up by DMA instead of through
+        # the runtime's staging copy of pageable memory, and a file costs neither 50 000 page faults nor their unmapping
+        # (64 x 200 Mb: 22 -> 10 ms per file beside the readers, tools/attic/r6_load_inputs_breakdown.py)
         todo = [n for n, g in self.genomes.items() if not pd.isna(g.fasta) and not is_fastq(g.fasta) and n not in self._seqsets]
-        nread = max(2, min(6, engine.usable_cpus() // 2))
+        nread = int(os.environ.get("PG_READERS", "0")) or max(2, min(6, engine.usable_cpus() // 2))
         reader = ThreadPoolExecutor(max_workers=nread)
-        ahead = {n: reader.submit(_read_fasta_image, self.genomes[n].fasta) for n in todo[:nread + 2]}
-        nxt = nread + 2
+        pool = self._pinned_reader_pool(todo, nread + 2)
+        read = (lambda path: _read_fasta_pinned(path, pool)) if pool is not None else (lambda path: (_read_fasta_image(path), None))
+        # (never more files in flight than buffers: a reader that waited for one held by a LATER file's finished read would wait for ever)
+        window = pool.budget if pool is not None else nread + 2
+        ahead = {n: reader.submit(read, self.genomes[n].fasta) for n in todo[:window]}
+        nxt = window
         for name, g in self.genomes.items():
             if pd.isna(g.fasta):
                 continue
             if name in ahead:
-                self._seqsets[name] = engine.SeqSet.from_fasta(self.context, ahead.pop(name).result())
+                t0 = time.perf_counter()
+                image, buf = ahead.pop(name).result()
+                t1 = time.perf_counter()
+                self._seqsets[name] = engine.SeqSet.from_fasta(self.context, image)
+                del image
+                if buf is not None:
+                    pool.put(buf)  # (the text is on the device: the buffer takes the next file)
+                # (where a load's time goes: waiting for the readers / upload + parse + pack of the text)
+                self.timings["load_wait_read_s"] = self.timings.get("load_wait_read_s", 0.0) + t1 - t0
+                self.timings["load_parse_s"] = self.timings.get("load_parse_s", 0.0) + time.perf_counter() - t1
                 if nxt < len(todo):
-                    ahead[todo[nxt]] = reader.submit(_read_fasta_image, self.genomes[todo[nxt]].fasta)
+                    ahead[todo[nxt]] = reader.submit(read, self.genomes[todo[nxt]].fasta)
                     nxt += 1
             if is_fastq(g.fasta):
                 # read sets: kmc -ci2 -fq (workflow/Snakefile:88-89) — k-mers seen once are dropped
@@ -446,10 +546,14 @@ class Index:
                 ss, min_count = engine.SeqSet.from_host(self.context, [read_fastq_joined(g.fasta)]), 2
             else:
                 ss, min_count = self.seqset_for(name), 1
+            t0 = time.perf_counter()
             sketch.reset()
             sketch.add(ss)
             inputs.append((name, g, ss, min_count, sketch.registers()))
-        reader.shutdown()
+            self.timings["load_sketch_s"] = self.timings.get("load_sketch_s", 0.0) + time.perf_counter() - t0
+        if pool is not None:
+            reader.submit(pool.close)  # (unlocking the memory costs as much as locking it, 40 ms per GB: beside the table build)
+        reader.shutdown(wait=False)
         sketch.close()
         self.context.trim()  # (the FASTA text buffer the parser kept for the next file)
         self._inputs = inputs

@@ -209,6 +209,39 @@ def test_gpu_fasta_parser_large_random_wrapping(ctx, tmp_path):
     ss.close()
 
 
+def test_fasta_files_read_into_page_locked_buffers_or_pageable_arrays_give_the_same_tree(tmp_path, monkeypatch):
+    """Index.load_inputs reads plain FASTA files into a pool of page-locked buffers (engine.HostBuffer: fewer buffers than
+    files here, so they go round; files of different sizes) and compressed ones, or everything with PG_PINNED_READS=0, into
+    pageable arrays: the same index either way — and the golden one."""
+    from panagram_amd import engine, index as pidx
+    fx = H.load_case("n9_k21")
+    k = int(fx["k"])
+    s = _write_case(tmp_path, fx)
+    lines = s.read_text().splitlines()
+    name, fa = lines[3].split("\t")  # one sample as .gz: read through gzip into a pageable array beside the pooled ones
+    with open(fa, "rb") as f, gzip.open(fa + ".gz", "wb") as z:
+        z.write(f.read())
+    lines[3] = f"{name}\t{fa}.gz"
+    s.write_text("\n".join(lines) + "\n")
+    monkeypatch.setenv("PG_READERS", "2")  # (four buffers for nine files)
+    pidx.Index(str(s), prefix=str(tmp_path / "pinned"), k=k).run()
+    monkeypatch.setenv("PG_PINNED_READS", "0")
+    pidx.Index(str(s), prefix=str(tmp_path / "pageable"), k=k).run()
+    _same_index_payload(str(tmp_path / "pinned"), str(tmp_path / "pageable"))
+    for g in fx["anchors"]:
+        assert gzip.open(tmp_path / "pinned" / "anchor" / f"g{g}" / "bitmap.1.gz", "rb").read() == fx[f"a{g}_bitmap1"].tobytes()
+    # the buffer itself: a numpy view of page-locked memory that the parser takes like any other text
+    ctx = engine.Context(0)
+    text = fx["fasta_0"].tobytes()
+    hb = ctx.host_buffer(len(text) + 100)
+    hb.array[:len(text)] = np.frombuffer(text, np.uint8)
+    a, b = engine.SeqSet.from_fasta(ctx, hb.array[:len(text)]), engine.SeqSet.from_fasta(ctx, text)
+    assert a.names == b.names and np.array_equal(a.lens, b.lens)
+    for x in (a, b, hb, hb):  # (closing a buffer twice is harmless)
+        x.close()
+    ctx.close()
+
+
 def test_write_bgzf_from_hbm_equals_host_writer(ctx, tmp_path):
     import gzip
     from panagram_amd import engine
