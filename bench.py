@@ -574,21 +574,22 @@ def baseline_config_legs(ctx, dev, args):
                 root = tempfile.mkdtemp(prefix="pg_bench_e2e4_")
                 try:
                     recs = []
-                    # (the FASTA files by one process, Index.run() in the next — twice: the first process that touches 150 GB of a
-                    # box's HBM may pay for it once, 24 ms per GB inside its hipMallocs — 2.6 s for the table, 1 s for the rows —
-                    # whatever it runs; a second process right behind it does not.  Both on the line, the second as the figure.)
-                    for mode in ("write", "run", "run"):
+                    # (the FASTA files by one process, Index.run() in the next — after a pause: a process that starts right behind one
+                    # that held 150-190 GB, as this one did until a moment ago, finds its large hipMallocs waiting, 24-40 ms per GB
+                    # (2 s for the table, 1-2 s for the rows: tools/e2e_fresh.py runs one behind the other show it every other time,
+                    # HISTORY round 6 item 12) — the driver's housekeeping of the memory just released, not this job's work)
+                    for mode in ("write", "run"):
                         if mode == "run":
                             shutil.rmtree(os.path.join(root, "idx"), ignore_errors=True)
+                            time.sleep(float(os.environ.get("PG_BENCH_E2E_PAUSE_S", "10")))
                         cmd = [sys.executable, os.path.abspath(__file__), "--e2e-config4-child", f"{mode}:{root}", "--seed", str(args.seed)]
                         p = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
                         lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
                         if p.returncode != 0 or not lines:
                             raise RuntimeError(f"child ({mode}) exited {p.returncode}: {p.stderr[-400:]}")
                         recs.append(json.loads(lines[-1]))
-                    e2e = recs[2]
+                    e2e = recs[1]
                     e2e["fasta_files_written_in_s"] = recs[0].get("fasta_files_written_in_s")
-                    e2e["first_process_on_this_box"] = {k_: recs[1].get(k_) for k_ in ("seconds", "read_parse_sketch_s", "table_insert_s", "anchor_and_write_s", "anchor_batches_s", "writers_wait_s")}
                     e2e["process"] = ("a fresh process without torch, as `python -m panagram_amd index` is (python bench.py --e2e-config4-child "
                                       "run:DIR), the FASTA files written by another")
                 finally:

@@ -485,11 +485,15 @@ class Index:
 
     def _pinned_reader_pool(self, names, count: int):
         """a ``_PinnedPool`` for reading the plain FASTA files of ``names`` — buffers as large as the largest of them, at most
-        ``count`` and 8 GB in all — or None: nothing to read that way, or an engine without page-locked buffers (the CPU tests'
-        stand-in); the files are then read into pageable arrays"""
+        ``count`` and 8 GB in all — or None: less than 2 GB to read that way, or an engine without page-locked buffers (the CPU
+        tests' stand-in); the files are then read into pageable arrays"""
         sizes = [os.path.getsize(self.genomes[n].fasta) for n in names if not self.genomes[n].fasta.endswith((".gz", ".bgz"))]
         make = getattr(self.context, "host_buffer", None)
         if not sizes or make is None or os.environ.get("PG_PINNED_READS", "1") in ("0", ""):
+            return None
+        # (a small job gains nothing: locking and unlocking the pool's memory — 40 ms per GB each way, the unlocking a device-wide
+        # wait beside the first kernels — is what the page faults of eight 100 MB arrays cost; PG_PINNED_READS=2: any size)
+        if sum(sizes) < (2 << 30) and os.environ.get("PG_PINNED_READS", "1") != "2":
             return None
         cap = max(sizes) + 1  # (+ 1: a file that grew is noticed)
         if cap > (4 << 30):

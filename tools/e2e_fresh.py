@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--k", type=int, default=31)
     ap.add_argument("--d", type=float, default=0.005)
     ap.add_argument("--env", action="append", default=None)
+    ap.add_argument("--pause", type=float, default=0.0, help="seconds between a process's end and the next one's start")
     ap.add_argument("--write-only", default="", help=argparse.SUPPRESS)
     a = ap.parse_args()
     if a.write_only:  # (the writer process)
@@ -67,6 +68,7 @@ def main():
                 n, v = kv.split("=", 1)
                 env[n] = v
             shutil.rmtree(os.path.join(d, "idx"), ignore_errors=True)
+            time.sleep(a.pause)
             t0 = time.perf_counter()
             p = subprocess.run([sys.executable, "-c", CHILD % dict(root=ROOT, d=d, k=a.k)], env=env, capture_output=True, text=True)
             wall = time.perf_counter() - t0
