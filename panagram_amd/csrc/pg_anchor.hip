@@ -94,6 +94,27 @@ constexpr int PROBE_SEQW = ((PROBE_TILE + 31) / 32 + 6 + 3) & ~3;  // staged 32-
 #define PG_PROBE_PIPE 2  // 1: the front end of batch i + 1 ahead of the table look-up of batch i (k_probe); 2: and its fetch issued as soon as batch i's chunks are staged
 #endif
 constexpr uint32_t PROBE_SEQ_BASES = 32u * PROBE_SEQW;
+// k_probe's workgroup is ONE wave: what its lanes hand each other through LDS (the staged lines, the batch's line numbers, the
+// overflow queue) needs no barrier — a wave's LDS instructions are executed in the order they were issued, so a read issued
+// behind a write sees it.  __syncthreads() costs such a kernel an s_waitcnt lgkmcnt(0) — every LDS operation in flight drained —
+// where a wavefront-scope fence emits nothing (38 -> 31 full drains in the one-byte instantiation, the read of the batch's line
+// numbers issued right behind their write).  -DPG_WAVE_SYNC=1 builds that; measured (profiles/r6z_ab_wave_sync.txt, two rounds
+// on one box): configs[1] 3.26 / 3.18 -> 3.27 / 3.23 ms, 27 x 40 Mb 4.45 -> 4.38, 64 x 20 Mb k = 31 5.79 -> 5.79, one launch per
+// genome and d = 5 % unchanged — the round trips it takes off a wave's critical path are slots the seven other waves were already
+// using (latency is not what binds).  Off: the barriers say what is meant.
+#ifndef PG_WAVE_SYNC
+#define PG_WAVE_SYNC 0
+#endif
+#if PG_WAVE_SYNC
+#define PG_WSYNC()                                              \
+    do {                                                        \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  \
+        __builtin_amdgcn_wave_barrier();                        \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  \
+    } while (0)
+#else
+#define PG_WSYNC() __syncthreads()
+#endif
 // -DPG_PHASE_TIMING: a measuring build (tools/phase_timing.py) — every wave of k_probe stamps s_memtime at its phase
 // boundaries and adds the phases' cycles to pg_phase_cycles at the end of its tile: where a wave's time goes, waits for
 // the other waves of its SIMD included.  Slots: 0 prologue, 1 front end, 2 wait for the lines, 3 staging, 4 issue of the
@@ -767,7 +788,7 @@ __device__ __forceinline__ void drain_queue(const SubTable &st, uint32_t qn, con
     const uint32_t lbytes = INL ? st.layout * 64u : st.slots * (WIDE ? 8u : 16u);  // (= 16 * SLOTS = 128, as a run-time scalar: see k_probe)
     static_assert(LEVELS >= 1, "k_probe's entries (home line, group) are turned into (next line, step) by level 1's staged batches");
     for (int level = 1; qn > 0; ++level) {
-        __syncthreads();
+        PG_WSYNC();
         if (level > LEVELS) {
             // the few entries still unresolved (long chains) walk their sequences lane by lane:
             // 8 slot loads in flight per line, no staging overhead
@@ -818,7 +839,7 @@ __device__ __forceinline__ void drain_queue(const SubTable &st, uint32_t qn, con
                 const uint32_t nl = min((uint32_t)MAXRUN, nruns - r0);
                 if (lane < MAXRUN) lines_w[lane] = padline;
                 if (leader && rid - r0 < nl) lines_w[rid - r0] = line;
-                __syncthreads();
+                PG_WSYNC();
                 uint4 v[STAGE_ITERS];
                 uint32_t ln[STAGE_ITERS];
 #pragma unroll
@@ -831,7 +852,7 @@ __device__ __forceinline__ void drain_queue(const SubTable &st, uint32_t qn, con
                     if constexpr (WIDE) buf[(idx / SLOTS) * LDS_LINE_U4 + (idx % SLOTS)] = v[u];  // (bare keys: as they are)
                     else stage_chunk(buf + (idx / SLOTS) * LDS_LINE_U4, idx % SLOTS, SLOTS, v[u]);
                 }
-                __syncthreads();
+                PG_WSYNC();
                 if (act && rid - r0 < nl) {
                     if constexpr (WIDE && INL) {
                         rcode = scan_keys_inl(buf + (rid - r0) * LDS_LINE_U4, key, st.slots, m1);
@@ -843,7 +864,7 @@ __device__ __forceinline__ void drain_queue(const SubTable &st, uint32_t qn, con
                         rcode = scan_line_lds<TWO, SLOTS>(buf + (rid - r0) * LDS_LINE_U4, key, m0, m1);
                     }
                 }
-                __syncthreads();
+                PG_WSYNC();
             }
             const bool again = act && rcode < 0;
             if constexpr (WIDE && INL) {
@@ -870,7 +891,7 @@ __device__ __forceinline__ void drain_queue(const SubTable &st, uint32_t qn, con
                 q_pl[slot] = (uint16_t)pl;
             }
             kept += (uint32_t)__popcll(kmask2);
-            __syncthreads();
+            PG_WSYNC();
         }
         qn = kept;
     }
@@ -1193,7 +1214,7 @@ __attribute__((amdgpu_num_sgpr(80))) void k_probe(const SubTable st, const uint6
         nw[i] = (hasn && wi < s.nwords) ? nmw[s.seq_off + wi] : 0u;
     }
     if (lane == 0) rw[PROBE_SEQW] = 0;  // (a window's three dwords may reach one word past the end)
-    __syncthreads();  // single wave: compiles to a wave-level wait, not an s_barrier
+    PG_WSYNC();  // single wave: compiles to a wave-level wait, not an s_barrier
 
     // (minimizer tables: k >= 20, the mask's low word is all ones — spelt out, the compiler drops the ANDs with it: two per
     // position)
@@ -1353,7 +1374,7 @@ __attribute__((amdgpu_num_sgpr(80))) void k_probe(const SubTable st, const uint6
             const bool leader = __builtin_amdgcn_inverse_ballot_w64(f.lmask);
             if (lane < MAXRUN) lines_w[0][lane] = f.padline;
             if (leader && f.rid < (uint32_t)MAXRUN) lines_w[0][f.rid] = f.line;
-            __syncthreads();
+            PG_WSYNC();
 #pragma unroll
             for (int it = 0; it < STAGE_ITERS; ++it) f.ln[it] = lines_w[0][it * (64 / SLOTS) + lane / SLOTS];
         }
@@ -1378,7 +1399,7 @@ __attribute__((amdgpu_num_sgpr(80))) void k_probe(const SubTable st, const uint6
             const bool leader = __builtin_amdgcn_inverse_ballot_w64(f.lmask);
             if (lane < MAXRUN) lines_w[0][lane] = f.padline;
             if (leader && f.rid - r0 < nl) lines_w[0][f.rid - r0] = f.line;
-            __syncthreads();
+            PG_WSYNC();
         }
 #pragma unroll
         for (int it = 0; it < STAGE_ITERS; ++it) {
@@ -1410,14 +1431,14 @@ __attribute__((amdgpu_num_sgpr(80))) void k_probe(const SubTable st, const uint6
                 if constexpr (WIDE) mine[it * (64 / SLOTS) * LDS_LINE_U4 + ((uint32_t)lane % SLOTS)] = S.v[it];  // (bare keys: as they are)
                 else stage_chunk(mine + it * (64 / SLOTS) * LDS_LINE_U4, (uint32_t)lane % SLOTS, SLOTS, S.v[it]);
             }
-            __syncthreads();
+            PG_WSYNC();
         };
         constexpr bool FLAT = PG_SCAN_FLAT && PG_ABLATE == 0 && CUT && !WIDE && SLOTS == 8;  // (CUT: an active lane's run is one of the step's)
         unsigned long long ovf_flat = 0;
         auto scan = [&](const uint32_t r0) __attribute__((always_inline)) {
             if constexpr (FLAT) {
                 ovf_flat = scan_line_lds_flat<TWO>(buf[0] + min(f.rid, (uint32_t)MAXRUN - 1u) * LDS_LINE_U4, f.key, f.amask, m0, m1);
-                __syncthreads();
+                PG_WSYNC();
                 return;
             }
             const uint32_t nl = min((uint32_t)MAXRUN, f.nruns - r0);
@@ -1439,7 +1460,7 @@ __attribute__((amdgpu_num_sgpr(80))) void k_probe(const SubTable st, const uint6
                 }
             }
 #endif
-            __syncthreads();
+            PG_WSYNC();
         };
         // The batch's lines are waited for HERE, on every path (a batch without runs has none in flight).  Left to the
         // compiler, the wait sits inside the branch below, the chunks count as possibly still on their way where the
@@ -1657,7 +1678,7 @@ __attribute__((amdgpu_num_sgpr(80))) void k_probe(const SubTable st, const uint6
         drain_queue<TWO, ROWMODE, SLOTS, MAXRUN, WIDE, LEVELS, INL>(st, qn, sw, rw, q_line, q_step, q_pl, lines_w[0], buf[0], tile_rows, nbytes, rc, lane);
         qn = 0;
         if (b0 >= npos) break;
-        __syncthreads();
+        PG_WSYNC();
         carry = carry_at(b0);  // (the hot loop may have left with the front end of a batch it did not finish)
         while (b0 < npos && qn <= QROOM) {
             const Front f = front(std::false_type{}, b0);
