@@ -485,19 +485,21 @@ class Index:
 
     def _pinned_reader_pool(self, names, count: int):
         """a ``_PinnedPool`` for reading the plain FASTA files of ``names`` — buffers as large as the largest of them, at most
-        ``count`` and 8 GB in all — or None: less than 2 GB to read that way, or an engine without page-locked buffers (the CPU
+        ``count`` and 8 GB in all — or None: less than 256 MB to read that way, or an engine without page-locked buffers (the CPU
         tests' stand-in); the files are then read into pageable arrays"""
         sizes = [os.path.getsize(self.genomes[n].fasta) for n in names if not self.genomes[n].fasta.endswith((".gz", ".bgz"))]
         make = getattr(self.context, "host_buffer", None)
         if not sizes or make is None or os.environ.get("PG_PINNED_READS", "1") in ("0", ""):
             return None
-        # (a small job gains nothing: locking and unlocking the pool's memory — 40 ms per GB each way, the unlocking a device-wide
-        # wait beside the first kernels — is what the page faults of eight 100 MB arrays cost; PG_PINNED_READS=2: any size)
-        if sum(sizes) < (2 << 30) and os.environ.get("PG_PINNED_READS", "1") != "2":
+        # (a small job gains nothing: locking and unlocking the pool's memory costs 40 ms per GB each way; PG_PINNED_READS=2: any size)
+        if sum(sizes) < (256 << 20) and os.environ.get("PG_PINNED_READS", "1") != "2":
             return None
         cap = max(sizes) + 1  # (+ 1: a file that grew is noticed)
         if cap > (4 << 30):
             return None
+        # (four buffers keep the upload busy — a reader fills one in 10-20 ms, the parser empties one in 5-7 — and cost half of what
+        # eight cost to lock and unlock: 8 x 100 Mb 0.43 -> 0.39 s, 64 x 200 Mb 2.1-2.2 -> 1.9-2.0 s, tools/e2e_fresh.py)
+        count = int(os.environ.get("PG_PINNED_BUFFERS", "0")) or min(count, 4)
         return _PinnedPool(make, cap, max(2, min(count, len(sizes), (8 << 30) // cap)))
 
     def load_inputs(self):

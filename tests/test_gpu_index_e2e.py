@@ -223,8 +223,8 @@ def test_fasta_files_read_into_page_locked_buffers_or_pageable_arrays_give_the_s
         z.write(f.read())
     lines[3] = f"{name}\t{fa}.gz"
     s.write_text("\n".join(lines) + "\n")
-    monkeypatch.setenv("PG_READERS", "2")  # (four buffers for nine files)
-    monkeypatch.setenv("PG_PINNED_READS", "2")  # (whatever the files' size: the pool is for jobs of 2 GB and more)
+    monkeypatch.setenv("PG_PINNED_BUFFERS", "3")  # (three buffers for nine files)
+    monkeypatch.setenv("PG_PINNED_READS", "2")  # (whatever the files' size: the pool is for jobs of 256 MB and more)
     pidx.Index(str(s), prefix=str(tmp_path / "pinned"), k=k).run()
     monkeypatch.setenv("PG_PINNED_READS", "0")
     pidx.Index(str(s), prefix=str(tmp_path / "pageable"), k=k).run()
