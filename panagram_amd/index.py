@@ -120,7 +120,7 @@ class _PinnedPool:
             with self.lock:
                 self.all.append(buf)
             return buf
-        if self.failed and not self.made:
+        if self.failed:  # (fewer buffers than files in flight: waiting for one could wait for a LATER file's, which is handed on only after this one)
             return None
         return self.free.get()
 

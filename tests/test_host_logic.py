@@ -420,3 +420,48 @@ def test_minimizer_length_rule():
             for first_len in (0, 10 ** 4, 10 ** 8, 3 * 10 ** 9):
                 m = f(k, keys, first_len, 8, 0)
                 assert 3 <= k - m + 1 <= 8 and m >= min(15, k - 2), (k, keys, first_len, m)
+
+
+def test_reader_pool_never_waits_for_a_later_files_buffer(tmp_path):
+    """index._PinnedPool / _read_fasta_pinned (the page-locked buffers Index.load_inputs reads plain FASTA files into): buffers
+    are made on demand up to the budget and go round; once locking memory has failed no reader ever WAITS for a buffer (it
+    could be one a later file holds until the files before it are consumed) — it reads into pageable memory instead."""
+    import numpy as np
+    from panagram_amd import index as pidx
+
+    class Buf:
+        def __init__(self, n):
+            self.array = np.zeros(n, np.uint8)
+
+        def close(self):
+            self.array = None
+
+    made = []
+
+    def make(cap):
+        if len(made) >= 2:
+            raise MemoryError("no memory to lock")
+        made.append(Buf(cap))
+        return made[-1]
+
+    files = []
+    for i in range(4):
+        f = tmp_path / f"g{i}.fa"
+        f.write_bytes(b">c\n" + bytes([65 + i]) * (50 + i) + b"\n")
+        files.append(str(f))
+    pool = pidx._PinnedPool(make, 100, 4)
+    got = [pidx._read_fasta_pinned(f, pool) for f in files]  # (nothing handed back in between: four files in flight)
+    assert [b is not None for _, b in got] == [True, True, False, False] and pool.failed
+    for (img, _), f in zip(got, files):
+        assert bytes(img) == open(f, "rb").read()
+    pool.put(got[0][1])
+    img, buf = pidx._read_fasta_pinned(files[3], pool)  # a buffer that came back is used again
+    assert buf is got[0][1] and bytes(img) == open(files[3], "rb").read()
+    big = tmp_path / "big.fa"
+    big.write_bytes(b">c\n" + b"A" * 200 + b"\n")
+    pool.put(buf)
+    with pytest.raises(OSError):
+        pidx._read_fasta_pinned(str(big), pool)  # larger than the buffers were sized for: said, not truncated
+    assert pool.free.qsize() == 1  # (and the buffer is back in the pool)
+    pool.close()
+
