@@ -302,16 +302,27 @@ __device__ __forceinline__ uint32_t df_stage(uint8_t *data, PayCur *blk_cur, con
     return n;
 }
 
-// ---- pass A over the thread's chunk, a dword at a time: its first / last byte that differs from one row earlier (bytes
-// before the block's first row differ by definition) and, CRC: the chunk's CRC32 register (slicing by four: S = T0..T3) ----
+// the chunk's bytes that differ from one row earlier, one bit each (bit j = byte c0 + j; the bits behind the chunk's end are SET: a
+// run of equal bytes never reaches past them) — what pass A leaves for the token walks, which then touch LDS for literals only
+struct DfMask {
+    uint64_t lo;  // bytes 0..63 of the chunk
+    uint32_t hi;  // bytes 64..(DF_CHUNK - 1), and ones above
+};
+static_assert(DF_CHUNK > 64 && DF_CHUNK <= 96, "DfMask holds a chunk of 65..96 bytes");
+
+// ---- pass A over the thread's chunk, a dword at a time: the bytes that differ from one row earlier (bytes before the block's
+// first row differ by definition) as a mask, the first / last of them and, CRC: the chunk's CRC32 register (slicing by four:
+// S = T0..T3) ----
 template <bool CRC>
 __device__ __forceinline__ void df_pass_a(const uint8_t *data, const uint32_t *S, uint32_t c0, uint32_t c1, uint32_t row, int &fne, int &lne,
-                                          uint32_t &crc) {
-    fne = 0x7fffffff;
-    lne = -1;
+                                          uint32_t &crc, DfMask &ne) {
     crc = threadIdx.x == 0 ? 0xFFFFFFFFu : 0u;
+    uint64_t mlo = 0;
+    uint32_t mhi = 0;
     uint32_t i = c0;
-    for (; i + 4 <= c1; i += 4) {  // (c0 is a multiple of 4)
+#pragma unroll
+    for (uint32_t j = 0; j < DF_CHUNK / 4; ++j) {  // (c0 is a multiple of 4; a short chunk — a file's last block — leaves early)
+        if (i + 4 > c1) break;
         const uint32_t v = *reinterpret_cast<const uint32_t *>(data + i);
         if (CRC) {
             const uint32_t x = crc ^ v;
@@ -329,63 +340,83 @@ __device__ __forceinline__ void df_pass_a(const uint8_t *data, const uint32_t *S
                 xr |= d << (8 * b);
             }
         }
-        if (xr) {
-            if (fne == 0x7fffffff) fne = (int)(i + ((uint32_t)(__ffs((int)xr) - 1) >> 3));
-            lne = (int)(i + ((31u - (uint32_t)__clz((int)xr)) >> 3));
-        }
+        // one bit per non-zero byte of xr: OR every byte's bits down to its bit 0, gather the four bit 0s
+        uint32_t t = xr | (xr >> 4);
+        t |= t >> 2;
+        t |= t >> 1;
+        t &= 0x01010101u;
+        const uint32_t nib = ((t * 0x01020408u) >> 24) & 0xFu;
+        if (j < 16) mlo |= (uint64_t)nib << (4 * j);
+        else mhi |= nib << (4 * (j - 16));
+        i += 4;
     }
     for (; i < c1; ++i) {  // (a file's last block: up to three bytes behind the last whole dword)
         const uint32_t v = data[i];
         if (CRC) crc = S[(crc ^ v) & 255u] ^ (crc >> 8);
         if (!(i >= row && data[i - row] == v)) {
-            if (fne == 0x7fffffff) fne = (int)i;
-            lne = (int)i;
+            const uint32_t j = i - c0;
+            if (j < 64) mlo |= 1ull << j;
+            else mhi |= 1u << (j - 64);
         }
     }
+    fne = mlo ? (int)c0 + (__ffsll((long long)mlo) - 1) : mhi ? (int)c0 + 64 + (__ffs((int)mhi) - 1) : 0x7fffffff;
+    lne = mhi ? (int)c0 + 64 + (31 - __clz((int)mhi)) : mlo ? (int)c0 + (63 - __clzll((long long)mlo)) : -1;
+    // the bits behind the chunk's end
+    const uint32_t len = c1 - c0;
+    if (len < 64) {
+        mlo |= ~0ull << len;
+        mhi = ~0u;
+    } else {
+        mhi |= ~0u << (len - 64);  // (len <= DF_CHUNK < 96)
+    }
+    ne.lo = mlo;
+    ne.hi = mhi;
 }
 
 // The tokens of a thread's chunk [c0, c1), run by run (not position by position: lanes of a wave are in different runs, and a
 // per-position walk pays for the longest forward scan at every step).  A run of bytes equal to one row earlier, [s, e), is cut
 // into matches of 258 from s, then one match of r = (e - s) % 258 if r >= 3, else r literals — the same for every thread that
 // sees part of the run.  prevNE / nextNE: the last unequal byte before the chunk (-1: none), the first one behind it (n: none).
+// The walk reads the chunk's mask of unequal bytes (pass A), shifted along as it goes; LDS only for the literals' values.
 template <typename Lit, typename Match>
-__device__ __forceinline__ void df_tokens(const uint8_t *data, uint32_t c0, uint32_t c1, uint32_t row, int prevNE, int nextNE, Lit &&on_lit,
+__device__ __forceinline__ void df_tokens(const uint8_t *data, uint32_t c0, uint32_t c1, DfMask ne, int prevNE, int nextNE, Lit &&on_lit,
                                           Match &&on_match) {
-    auto is_eq = [&](uint32_t i) { return i >= row && data[i] == data[i - row]; };
+    uint64_t lo = ne.lo;
+    uint32_t hi = ne.hi;
+    auto advance = [&](uint32_t by) {  // the mask moved on by `by` (1..DF_CHUNK) bytes, ones coming in at the top
+        if (by >= 64) {
+            lo = (by >= 96) ? ~0ull : (((uint64_t)hi >> (by - 64)) | (~0ull << (96 - by)));
+            hi = ~0u;
+        } else {
+            lo = (lo >> by) | ((uint64_t)hi << (64 - by));  // (by >= 1: the shift is below 64)
+            if (by > 32) lo |= ~0ull << (96 - by);           // (ones from behind the 96 bits the mask holds)
+            hi = by >= 32 ? ~0u : ((hi >> by) | (~0u << (32 - by)));
+        }
+    };
     uint32_t i = c0;
     while (i < c1) {
-        if (!is_eq(i)) {
+        if (lo & 1ull) {
             on_lit((uint32_t)data[i]);
             ++i;
+            advance(1u);
             continue;
         }
+        // a run of equal bytes: up to the next unequal one (the mask's ones behind the chunk end it at c1 at the latest)
+        const uint32_t run = lo ? (uint32_t)(__ffsll((long long)lo) - 1) : 64u + (uint32_t)(__ffs((int)hi) - 1);
         const uint32_t s = (i == c0) ? (uint32_t)(prevNE + 1) : i;
-        uint32_t e = i + 1;
-        // the run's end, eight bytes at a time (unaligned LDS words; e > i >= row here)
-        bool open_end = true;
-        while (e + 8 <= c1) {
-            const uint64_t x = reinterpret_cast<const DfU64 *>(data + e)->v ^ reinterpret_cast<const DfU64 *>(data + e - row)->v;
-            if (x) {
-                e += (uint32_t)(__ffsll((long long)x) - 1) >> 3;
-                open_end = false;
-                break;
-            }
-            e += 8;
-        }
-        if (open_end)
-            while (e < c1 && is_eq(e)) ++e;
-        const uint32_t hi = e;              // end of the run inside this chunk
-        if (e == c1) e = (uint32_t)nextNE;  // ... and its true end
+        const uint32_t hiend = i + run;             // end of the run inside this chunk (<= c1)
+        const uint32_t e = hiend == c1 ? (uint32_t)nextNE : hiend;  // ... and its true end
         const uint32_t R = e - s, q258 = (R / 258u) * 258u, r = R - q258;
         uint32_t p = s + ((i - s + 257u) / 258u) * 258u;  // first match start >= i
-        for (; p < min(s + q258, hi); p += 258u) on_match(258u);
+        for (; p < min(s + q258, hiend); p += 258u) on_match(258u);
         const uint32_t tz = s + q258;  // tail zone [tz, e)
         if (r >= 3) {
-            if (tz >= i && tz < hi) on_match(r);
+            if (tz >= i && tz < hiend) on_match(r);
         } else {
-            for (uint32_t q = max(i, tz); q < hi; ++q) on_lit((uint32_t)data[q]);
+            for (uint32_t q = max(i, tz); q < hiend; ++q) on_lit((uint32_t)data[q]);
         }
-        i = hi;
+        i = hiend;
+        advance(run);
     }
 }
 
@@ -404,10 +435,11 @@ __global__ __launch_bounds__(DF_THREADS, 8) void k_df_sample_hist(const uint8_t 
     const uint32_t n = df_stage(data, &blk_cur, base, segs, nseg, total, blk, c0, c1);
     int fne, lne;
     uint32_t crc;
-    df_pass_a<false>(data, nullptr, c0, c1, row, fne, lne, crc);
+    DfMask ne;
+    df_pass_a<false>(data, nullptr, c0, c1, row, fne, lne, crc, ne);
     const int prevNE = df_excl_max(lne, part);
     const int nextNE = df_rexcl_min(fne == 0x7fffffff ? (int)n : fne, (int)n, part);
-    df_tokens(data, c0, c1, row, prevNE, nextNE, [&](uint32_t v) { atomicAdd(&hist[v], 1u); },
+    df_tokens(data, c0, c1, ne, prevNE, nextNE, [&](uint32_t v) { atomicAdd(&hist[v], 1u); },
               [&](uint32_t L) {
                   uint32_t nx, xv;
                   atomicAdd(&hist[257 + df_len_sym(L, nx, xv)], 1u);
@@ -536,8 +568,7 @@ __global__ __launch_bounds__(DF_THREADS, 8) __attribute__((amdgpu_num_sgpr(80)))
                                                             uint32_t *__restrict__ sizes, uint32_t force_stored) {
     __shared__ __attribute__((aligned(16))) uint8_t data[DF_BLOCK];
     __shared__ uint32_t S[1024];  // CRC-32, slicing by four
-    __shared__ uint16_t lcode[288];
-    __shared__ uint8_t llen[288];
+    __shared__ uint32_t lcl[288];  // a symbol's code (low half) and its length (high half): one LDS word per token
     __shared__ uint32_t crcp[DF_THREADS];
     __shared__ int part[DF_WAVES];
     __shared__ uint32_t blk_crc, crc_acc;
@@ -548,10 +579,7 @@ __global__ __launch_bounds__(DF_THREADS, 8) __attribute__((amdgpu_num_sgpr(80)))
     uint8_t *slot = slots + (uint64_t)blockIdx.x * 65536;
     if (tid == 0) crc_acc = 0;
     S[tid] = crc_tabs[tid];
-    if (tid < 288) {
-        lcode[tid] = code->lcode[tid];
-        llen[tid] = code->llen[tid];
-    }
+    if (tid < 288) lcl[tid] = (uint32_t)code->lcode[tid] | ((uint32_t)code->llen[tid] << 16);
     const uint32_t hdr_bits = code->hdr_bits;
     uint32_t c0, c1;
     const uint32_t n = df_stage(data, &blk_cur, base, segs, nseg, total, blk, c0, c1);  // bytes of this block
@@ -560,7 +588,8 @@ __global__ __launch_bounds__(DF_THREADS, 8) __attribute__((amdgpu_num_sgpr(80)))
     // ---- pass A: chunk CRC and the chunk's first / last byte that differs from one row earlier ----
     int fne, lne;
     uint32_t crc;
-    df_pass_a<true>(data, S, c0, c1, row, fne, lne, crc);
+    DfMask ne;
+    df_pass_a<true>(data, S, c0, c1, row, fne, lne, crc, ne);
     crcp[tid] = crc;
     DF_PH(1)
     const int prevNE = df_excl_max(lne, part);
@@ -598,21 +627,29 @@ __global__ __launch_bounds__(DF_THREADS, 8) __attribute__((amdgpu_num_sgpr(80)))
         blk_crc = c ^ 0xFFFFFFFFu;
     }
     DF_PH(3)
-    const uint32_t dsym = llen[286];
+    const uint32_t dsym = lcl[286] >> 16;
     const uint32_t dbits = 1u + DF_DIST_EXTRA[dsym];
     const uint32_t dval = (row - DF_DIST_BASE[dsym]) << 1;  // code 0 in bit 0, extra bits above
 
     // ---- pass C: bit counts, offsets, emission.  One walk = a lambda over the tokens ----
     auto walk = [&](auto &&emit) {
-        df_tokens(data, c0, c1, row, prevNE, nextNE, [&](uint32_t v) { emit(lcode[v], llen[v]); },
+        df_tokens(data, c0, c1, ne, prevNE, nextNE,
+                  [&](uint32_t v) {
+                      const uint32_t cl = lcl[v];
+                      emit(cl & 0xFFFFu, cl >> 16);
+                  },
                   [&](uint32_t L) {
                       uint32_t nx, xv;
                       const int ls = df_len_sym(L, nx, xv);
-                      emit(lcode[257 + ls], llen[257 + ls]);
-                      if (nx) emit(xv, nx);
-                      emit(dval, dbits);
+                      const uint32_t cl = lcl[257 + ls];
+                      const uint32_t lb = cl >> 16;
+                      emit((cl & 0xFFFFu) | (xv << lb), lb + nx);  // the length code and its extra bits: 20 bits at most
+                      emit(dval, dbits);                           // the distance code (one bit) and its extra bits: 14 at most
                   });
-        if (c0 < c1 && c1 == n) emit(lcode[256], llen[256]);  // end of block, by the owner of the last byte
+        if (c0 < c1 && c1 == n) {  // end of block, by the owner of the last byte
+            const uint32_t cl = lcl[256];
+            emit(cl & 0xFFFFu, cl >> 16);
+        }
     };
     uint32_t mybits = 0;
     walk([&](uint32_t, uint32_t nb) { mybits += nb; });
