@@ -182,6 +182,49 @@ def test_gpu_fasta_parser_matches_host_reader(ctx, case, tmp_path):
     ss2.close()
 
 
+def test_gpu_fasta_header_lines_found_on_the_device(ctx, tmp_path, monkeypatch):
+    """Texts of 4 MB and more have their header lines looked for on the device (k_text_headers): '>' at offset 0, behind
+    '\\n' and '\\r\\n', NOT in the middle of a line or at a line's end; headers at every alignment of the 16-byte groups the
+    kernel reads, next to each other, and as the text's last byte — the host's reader and the host's scan
+    (PG_FASTA_HOST_SCAN=1) agree with it."""
+    from panagram_amd import engine, index as pidx
+    rng = np.random.default_rng(78)
+    out = bytearray()
+    recs = []
+    for r in range(60):
+        n = int(rng.choice([0, 1, 15, 16, 17, 33, 100003, 250001])) if r % 3 else 250001 + r
+        seq = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=n).tobytes()
+        if r % 5 == 1 and n > 50:  # a '>' inside a sequence line and at its end: not headers (bytes outside ACGT, like any other)
+            seq = seq[:20] + b">" + seq[21:-1] + b">"
+        pad = b"x" * int(rng.integers(0, 16))  # (moves the next '>' through the 16 alignments)
+        out += b">r%d %s\n" % (r, pad)
+        recs.append((f"r{r}", seq))
+        p = 0
+        while p < n:
+            w = int(rng.integers(30, 90))
+            out += seq[p:p + w] + (b"\r\n" if r % 7 == 3 else b"\n")
+            p += w
+    out += b">last_without_a_line_end"
+    recs.append(("last_without_a_line_end", b""))
+    out += b"\n>"  # ... and a '>' as the very last byte: a header without a name
+    recs.append(("", b""))
+    assert len(out) > (4 << 20)
+    fa = tmp_path / "h.fa"
+    fa.write_bytes(bytes(out))
+    assert [(n, s) for n, s in pidx.read_fasta(str(fa))] == recs
+    got = []
+    for host_scan in (False, True):
+        if host_scan:
+            monkeypatch.setenv("PG_FASTA_HOST_SCAN", "1")
+        ss = engine.SeqSet.from_fasta(ctx, bytes(out))
+        got.append((list(ss.names), [int(x) for x in ss.lens], [ss.unpack(i) for i in range(len(ss.names))]))
+        ss.close()
+    assert got[0] == got[1]
+    assert got[0][0] == [n for n, _ in recs] and got[0][1] == [len(s) for _, s in recs]
+    for i, (_, s) in enumerate(recs):
+        assert got[0][2][i] == bytes(c if c in b"ACGT" else ord("N") for c in s)
+
+
 def test_gpu_fasta_parser_large_random_wrapping(ctx, tmp_path):
     """multi-chunk records, line widths from 1 to 200, N runs and lower case, .gz input"""
     import gzip
